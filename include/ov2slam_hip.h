@@ -1,0 +1,217 @@
+/*
+ * ov2slam_hip.h -- C ABI of libov2slam_hip.so (MI355X / gfx950 HIP kernels).
+ *
+ * Drop-in boundary for OV2SLAM's front-end + local-BA hot path.  The reference
+ * has no FFI layer: the boundary is three C++ classes (FeatureExtractor,
+ * FeatureTracker, Optimizer) that call OpenCV / Ceres.  A thin C++ adapter with
+ * the reference's own signatures (the headers in ov2slam_amd/host/)
+ * forwards to the entry points below.  Plain pointers and sizes only; no
+ * OpenCV / Eigen / torch types.  All citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns 0 (OV2_OK) on success, a negative OV2_E* otherwise,
+ *     and never throws or aborts; on error no output buffer is modified unless
+ *     stated (the adapter maps errors to the reference's "nothing tracked /
+ *     BA skipped" behaviour, SURVEY.md 5 "failure detection").
+ *   - `*_h` pointers are host memory, `*_d` pointers are device (HBM) memory.
+ *   - an ov2_ctx owns one HIP stream + scratch; one ctx per calling thread
+ *     (fbKltTracking is called concurrently from the SLAM and mapper threads,
+ *     src/visual_front_end.cpp:196 vs src/map_manager.cpp:510).  The library is
+ *     re-entrant across contexts.
+ *   - keypoints are float2 (x,y) interleaved, like std::vector<cv::Point2f>.
+ */
+#ifndef OV2SLAM_HIP_H
+#define OV2SLAM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OV2_OK            0
+#define OV2_EINVAL       -1   /* bad argument                                  */
+#define OV2_EHIP         -2   /* HIP runtime error (see ov2_last_error)        */
+#define OV2_ENOMEM       -3
+#define OV2_EUNSUPPORTED -4   /* e.g. LK window size without a kernel instance */
+#define OV2_ENODEVICE    -5   /* no gfx950 device visible                      */
+
+typedef struct ov2_ctx ov2_ctx;
+typedef struct ov2_pyr ov2_pyr;
+
+/* ---- context ------------------------------------------------------- */
+int  ov2_version(void);
+/* last error message of the calling thread ("" if none); never NULL */
+const char *ov2_last_error(void);
+/* creates a context with its own non-blocking HIP stream on `device` */
+int  ov2_ctx_create(int device, ov2_ctx **out);
+/* same, but enqueue on an existing hipStream_t (e.g. torch's current stream) */
+int  ov2_ctx_create_on_stream(int device, void *hip_stream, ov2_ctx **out);
+void ov2_ctx_destroy(ov2_ctx *ctx);
+int  ov2_ctx_sync(ov2_ctx *ctx);
+void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing */
+
+/* ---- image pyramid -------------------------------------------------
+ * Replaces cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), max_level)
+ *   src/visual_front_end.cpp:1172, :53 ; src/mapper.cpp:81
+ * (withDerivatives=true, pyrBorder=REFLECT_101, derivBorder=CONSTANT).
+ * `batch` independent images of identical size are built in one launch set
+ * (batch=1 is the drop-in case; batch>1 is the offline batch-of-sequences
+ * mode of BASELINE.json config 5).  Image b starts at img + b*img_batch_stride.
+ */
+int  ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch, ov2_pyr **out);
+void ov2_pyr_destroy(ov2_pyr *p);
+int  ov2_pyr_levels(const ov2_pyr *p);                 /* levels actually built */
+int  ov2_pyr_level_size(const ov2_pyr *p, int level, int *w, int *h);
+int  ov2_pyr_batch(const ov2_pyr *p);
+/* (re)build from host images: H2D copy + kernels, asynchronous on ctx's stream
+ * (the host buffer must stay valid until ov2_ctx_sync / a later blocking call) */
+int  ov2_pyr_build_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, size_t img_batch_stride);
+/* (re)build from images already resident in HBM */
+int  ov2_pyr_build_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride);
+/* D2H of one level of batch item b: un-padded image (w*h u8) and/or derivative
+ * (w*h int16x2); either pointer may be NULL.  Blocking.                        */
+int  ov2_pyr_download(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h);
+/* same but including the `win` border on every side ((w+2win)*(h+2win))        */
+int  ov2_pyr_download_padded(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h);
+/* algorithmic HBM bytes of one build of one image (SURVEY.md 8d "B_pyr")       */
+size_t ov2_pyr_algorithmic_bytes(const ov2_pyr *p);
+
+/* ---- Lucas-Kanade --------------------------------------------------
+ * ov2_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts,
+ * nextPts, status, err, Size(win,win), max_level, TermCriteria(COUNT+EPS,
+ * max_iter, eps), flags, 1e-4)  -- src/feature_tracker.cpp:66-69, :113-116.
+ * flags: OV2_LK_USE_INITIAL_FLOW | OV2_LK_GET_MIN_EIGENVALS (the only
+ * combination the reference uses); without GET_MIN_EIGENVALS err is left 0.
+ * All point buffers are host memory, n points per batch item, batch items
+ * contiguous (n_per_item[b] points for item b stored at offset b*n_max).
+ */
+#define OV2_LK_USE_INITIAL_FLOW   4
+#define OV2_LK_GET_MIN_EIGENVALS  8
+
+int ov2_lk_track(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *next,
+                 int win, int max_level, int max_iter, float eps, int flags,
+                 const float *prev_xy_h, float *next_xy_inout_h, int n,
+                 uint8_t *status_h, float *err_h, int *iters_h /* per point, may be NULL */);
+
+/* ov2_fb_klt replaces FeatureTracker::fbKltTracking (src/feature_tracker.cpp:35-137):
+ * forward LK (max_level = nbpyrlvl, clamped to the pyramid), status / err>err_th /
+ * 1-px border filter, backward LK at level 0 from the tracked point with the
+ * original keypoint as initial guess, reject if |kp - back| > fb_dist.
+ * One fused kernel launch.  prior_xy_inout_h: in = initial guess, out = tracked
+ * position (entries whose forward level-0 step was skipped keep OpenCV's
+ * semantics).  n == 0 returns OV2_OK and touches nothing (:43-46).
+ * stats (may be NULL): [0] = total GN iterations, [1] = (point,level) patch builds. */
+int ov2_fb_klt(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur,
+               int win, int nbpyrlvl, int max_iter, float eps, float err_th, float fb_dist,
+               const float *kps_xy_h, float *prior_xy_inout_h, int n,
+               uint8_t *status_h, long long stats[2]);
+
+/* Device-resident, batched form used by the offline batch-of-sequences path and
+ * by bench.py: kps / priors / status live in HBM, item b uses points
+ * [b*n_max, b*n_max + n_per_item_d[b])  (n_per_item_d == NULL -> n_max each).
+ * stats_d (may be NULL): 2 x int64 accumulated with atomics (zero it yourself). */
+int ov2_fb_klt_d(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur,
+                 int win, int nbpyrlvl, int max_iter, float eps, float err_th, float fb_dist,
+                 const float *kps_xy_d, float *prior_xy_inout_d, int n_max, const int *n_per_item_d,
+                 uint8_t *status_d, long long *stats_d);
+
+/* ---- keypoint detection ---------------------------------------------
+ * mask_mode for the FAST grid detector: the reference passes a
+ * CV_32F mask to cv::FastFeatureDetector::detect, which reads it as bytes.     */
+#define OV2_MASK_AS_EXECUTED 0
+#define OV2_MASK_INTENDED    1
+
+/* FeatureExtractor::detectGridFAST (src/feature_extractor.cpp:443-570).
+ * fast_th_inout mirrors the member nfast_th_ (adapted at :546-552).
+ * out_xy_h capacity (w/cell)*(h/cell) points.  do_subpix=0 skips cv::cornerSubPix. */
+int ov2_detect_grid_fast(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride, int cell,
+                         const float *cur_xy_h, int ncur, int *fast_th_inout, int mask_mode,
+                         int do_subpix, float *out_xy_h, int *out_n);
+
+/* FeatureExtractor::detectSingleScale (src/feature_extractor.cpp:288-440).
+ * roi = {x, y, width, height} (the 5-px border rect of camera_calibration.cpp:72-73).
+ * quality_inout mirrors dmaxquality_ (:418-423).  out_xy_h capacity 2*(w/cell)*(h/cell). */
+int ov2_detect_singlescale(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride, int cell,
+                           const float *cur_xy_h, int ncur, const int roi[4], double *quality_inout,
+                           int do_subpix, float *out_xy_h, int *out_n);
+
+/* cv::cornerSubPix(im, pts, Size(hw,hw), Size(-1,-1), TermCriteria(EPS+MAX_ITER, max_iter, eps))
+ * src/feature_extractor.cpp:434, :564 (hw = 3, 30, 0.01).  In place.             */
+int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride,
+                      float *xy_inout_h, int n, int half_win, int max_iter, double eps);
+
+/* ---- local bundle adjustment ----------------------------------------
+ * Replaces the two ceres::Solve calls of Optimizer::localBA
+ * (src/optimizer.cpp:479 and :618) on the anchored-inverse-depth problem built at
+ * :128-407.  The adapter walks the map on the CPU (as the reference does) into
+ * the flat arrays below.  Residual types follow src/ceres_parametrization.cpp.
+ */
+enum {
+    OV2_RES_LEFT       = 0, /* DirectLeftSE3::ReprojectionErrorKSE3AnchInvDepth         :361-473 */
+    OV2_RES_RIGHT      = 1, /* DirectLeftSE3::ReprojectionErrorRightCamKSE3AnchInvDepth :579-712 */
+    OV2_RES_RIGHT_ANCH = 2  /* DirectLeftSE3::ReprojectionErrorRightAnchCamKSE3AnchInvDepth :476-577 */
+};
+
+typedef struct {
+    int n_kf;                    /* keyframe poses Twc, [tx ty tz qx qy qz qw] each (se3_param_block.hpp:40-46) */
+    const double *poses;         /* 7*n_kf                                        */
+    const uint8_t *kf_const;     /* n_kf; 1 = SetParameterBlockConstant (optimizer.cpp:176-185, :229-246, :397-407) */
+    int n_lm;                    /* anchored inverse-depth landmarks              */
+    const double *invdepth;      /* n_lm                                          */
+    const int *lm_anchor_kf;     /* n_lm; index into poses                        */
+    const double *lm_anchor_uv;  /* 2*n_lm; undistorted anchor pixel              */
+    int n_res;                   /* 2-row residual blocks                         */
+    const uint8_t *res_type;     /* n_res; OV2_RES_*                              */
+    const int *res_kf;           /* n_res; observing keyframe (unused for RIGHT_ANCH) */
+    const int *res_lm;           /* n_res                                         */
+    const double *res_uv;        /* 2*n_res; observed pixel                       */
+    const double *res_sigma;     /* n_res; 2^scale (always 1 in the reference)    */
+    const uint8_t *res_active;   /* n_res or NULL; 0 = residual block removed (optimizer.cpp:500-592) */
+    double calib_l[4];           /* fx fy cx cy, constant block                   */
+    double calib_r[4];
+    double T_rl[7];              /* right <- left extrinsic, [t q], constant block */
+} ov2_ba_problem;
+
+typedef struct {
+    int max_iter;                /* 5 (robust pass) / 10 (L2 pass), optimizer.cpp:461, :611 */
+    double function_tolerance;   /* 1e-3, :462                                    */
+    double gradient_tolerance;   /* Ceres default 1e-10                           */
+    double parameter_tolerance;  /* Ceres default 1e-8                            */
+    double huber_delta;          /* sqrt(5.9915), :49; <= 0: no loss function     */
+    double initial_radius;       /* 1e4  (Ceres initial_trust_region_radius)      */
+    double max_radius;           /* 1e16                                          */
+    double min_radius;           /* 1e-32                                         */
+    double min_lm_diagonal;      /* 1e-6                                          */
+    double max_lm_diagonal;      /* 1e32                                          */
+    double min_relative_decrease;/* 1e-3                                          */
+    int jacobi_scaling;          /* 1                                             */
+    int max_consecutive_invalid_steps; /* 5                                       */
+} ov2_ba_options;
+
+enum {
+    OV2_TERM_NO_CONVERGENCE = 0, OV2_TERM_FUNCTION_TOL = 1, OV2_TERM_PARAMETER_TOL = 2,
+    OV2_TERM_GRADIENT_TOL = 3, OV2_TERM_MIN_RADIUS = 4, OV2_TERM_INVALID_STEPS = 5,
+    OV2_TERM_FAILURE = 6
+};
+
+typedef struct {
+    double *poses_out;           /* 7*n_kf                                        */
+    double *invdepth_out;        /* n_lm                                          */
+    double *chi2_last_eval;      /* n_res: chi2err_ cached by the last Evaluate */
+    uint8_t *depthpos_last_eval; /* n_res: isdepthpositive_ likewise              */
+    int iterations;              /* LM iterations executed (Ceres summary.iterations.size()-1) */
+    int num_successful_steps;
+    double initial_cost, final_cost;
+    int termination;             /* OV2_TERM_*                                    */
+    double solve_ms;             /* device time of the solve (HIP events)         */
+} ov2_ba_result;
+
+void ov2_ba_default_options(ov2_ba_options *o);
+int  ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OV2SLAM_HIP_H */

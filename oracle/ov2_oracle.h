@@ -1,0 +1,231 @@
+/*
+ * ov2_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the arithmetic on OV2SLAM's front-end + local-BA hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product (ov2slam_amd/) never links or calls it.
+ *
+ * PARITY STATUS
+ *   - front-end (pyramid / LK / FAST / min-eig / subpix): "parity unpinned".
+ *     The reference delegates these to OpenCV (unvendored, version unpinned,
+ *     absent from this container) and ships no tests or golden vectors for
+ *     them.  The oracle restates the public OpenCV 3.4/4.x
+ *     algorithms named at each function and is pinned only by self-consistency
+ *     tests + independent numpy/scipy cross-checks.
+ *   - local BA: sub-steps pinned by the known-answer tests vendored under
+ *     /root/reference/Thirdparty/ceres-solver/internal/ceres/ (the _test.cc files)
+ *     (Huber loss, corrector, LM radius schedule, Schur vs dense) and by a
+ *     dense numpy/scipy LM cross-check; Optimizer::localBA outputs themselves
+ *     have no reference golden vectors.
+ *
+ * All file:line citations are relative to /root/reference/.
+ */
+#ifndef OV2_ORACLE_H
+#define OV2_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Pyramid (cv::buildOpticalFlowPyramid, called at                     */
+/* src/visual_front_end.cpp:1172, :53 and src/mapper.cpp:81)           */
+/* ------------------------------------------------------------------ */
+#define ORC_MAX_LEVELS 8
+
+typedef struct {
+    int w, h;            /* un-padded level size                               */
+    int pad;             /* padding on every side (= win)                      */
+    int img_pitch;       /* bytes per padded image row                         */
+    int der_pitch;       /* int16 elements per padded derivative row           */
+    uint8_t *img;        /* (h+2pad) x img_pitch, REFLECT_101 border           */
+    int16_t *der;        /* (h+2pad) x der_pitch, (dx,dy) interleaved, 0 border */
+} orc_level;
+
+typedef struct {
+    int n_levels;        /* levels actually built (maxLevel+1 or fewer)        */
+    int win;
+    orc_level lv[ORC_MAX_LEVELS];
+} orc_pyr;
+
+/* returns 0 on success. img is u8 row-major, `stride` bytes per row. */
+int  orc_pyr_build(const uint8_t *img, int w, int h, int stride, int win,
+                   int max_level, orc_pyr *out);
+void orc_pyr_free(orc_pyr *p);
+/* accessors used by the python tests (copy out the un-padded ROI) */
+int  orc_pyr_level_size(const orc_pyr *p, int level, int *w, int *h);
+int  orc_pyr_copy_level(const orc_pyr *p, int level, uint8_t *img_out, int16_t *der_out);
+/* copy out a padded level (pad pixels on each side) for border checks */
+int  orc_pyr_copy_level_padded(const orc_pyr *p, int level, uint8_t *img_out, int16_t *der_out);
+
+/* single building blocks, exposed for unit tests */
+void orc_pyr_down_u8(const uint8_t *src, int sw, int sh, int sstride,
+                     uint8_t *dst, int dw, int dh, int dstride);
+void orc_scharr_u8(const uint8_t *src, int w, int h, int sstride,
+                   int16_t *dst, int dstride_elems);
+
+/* ------------------------------------------------------------------ */
+/* LK (cv::calcOpticalFlowPyrLK, called at src/feature_tracker.cpp:66, */
+/* :113) and FeatureTracker::fbKltTracking (src/feature_tracker.cpp:35)*/
+/* ------------------------------------------------------------------ */
+#define ORC_LK_USE_INITIAL_FLOW   4   /* cv::OPTFLOW_USE_INITIAL_FLOW    */
+#define ORC_LK_GET_MIN_EIGENVALS  8   /* cv::OPTFLOW_LK_GET_MIN_EIGENVALS */
+
+/* One calcOpticalFlowPyrLK call on pre-built pyramids.
+ * next_xy is in/out (initial flow when USE_INITIAL_FLOW).  iters_out (may be
+ * NULL) receives, per point, the total number of Gauss-Newton iterations that
+ * were executed over all levels (used for the algorithmic-bytes figure).
+ * nthreads > 1 splits the points over pthreads (mirrors cv::parallel_for_).  */
+int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
+                 const float *prev_xy, float *next_xy, int n,
+                 uint8_t *status, float *err,
+                 int win, int max_level, int max_count, double epsilon,
+                 int flags, double min_eig_threshold,
+                 int *iters_out, int nthreads);
+
+/* FeatureTracker::fbKltTracking.  status_out has n entries (0/1).
+ * Returns 0; n==0 is a no-op like the reference (:43-46).
+ * iters_total (may be NULL): sum of GN iterations (fwd+bwd) for byte counting;
+ * lvl_visits (may be NULL): number of (point,level) patch builds.            */
+int orc_fb_klt(const orc_pyr *prevpyr, const orc_pyr *curpyr,
+               int win, int nbpyrlvl, int max_iter, float eps_px,
+               float ferr, float fmax_fbklt_dist,
+               const float *kps_xy, float *prior_xy_inout, int n,
+               uint8_t *status_out, long long *iters_total, long long *lvl_visits,
+               int nthreads);
+
+/* ------------------------------------------------------------------ */
+/* Detection (src/feature_extractor.cpp:288-570)                       */
+/* ------------------------------------------------------------------ */
+#define ORC_MASK_AS_EXECUTED 0  /* CV_32F mask read through at<uchar> */
+#define ORC_MASK_INTENDED    1  /* true per-pixel float mask                       */
+
+/* FAST-9/16 + score + 3x3 NMS on a standalone w x h u8 image (cv::FAST).
+ * Outputs raster-ordered keypoints; returns count (<= cap).                */
+int orc_fast9_16(const uint8_t *img, int w, int h, int stride, int threshold,
+                 int nonmax, int *xs, int *ys, int *scores, int cap);
+
+/* FeatureExtractor::detectGridFAST (:443-570), serial raster order (N2).
+ * out_xy capacity: (w/cell)*(h/cell) points.  do_subpix=0 skips cornerSubPix. */
+int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
+                         const float *cur_xy, int ncur, int *fast_th_inout,
+                         int mask_mode, int do_subpix,
+                         float *out_xy, int *out_n);
+
+/* FeatureExtractor::detectSingleScale (:288-440), serial raster order.
+ * roi = {x, y, width, height}.  out_xy capacity: 2*(w/cell)*(h/cell).        */
+int orc_detect_singlescale(const uint8_t *img, int w, int h, int stride, int cell,
+                           const float *cur_xy, int ncur, const int roi[4],
+                           double *quality_inout, int do_subpix,
+                           float *out_xy, int *out_n);
+
+/* min-eigenvalue response map of one cell (blur w/ parent pixels + isolated
+ * cornerMinEigenVal); exposed for unit tests. hmap is cell*cell floats.      */
+void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,
+                     int x0, int y0, int cell, float *hmap);
+
+/* cv::cornerSubPix(win=(3,3), zeroZone=(-1,-1), 30 it / 0.01) in place.      */
+void orc_corner_subpix(const uint8_t *img, int w, int h, int stride,
+                       float *xy_inout, int n, int half_win, int max_iter, double eps);
+
+/* cv::circle(mask, c, r, 0, FILLED) on a w x h byte mask (1 = free).          */
+void orc_circle_fill0(uint8_t *mask, int w, int h, int cx, int cy, int r);
+
+/* ------------------------------------------------------------------ */
+/* Local BA (src/optimizer.cpp:34-897 + Ceres 2.0.0 TR-LM / Schur)     */
+/* ------------------------------------------------------------------ */
+enum {
+    ORC_RES_LEFT        = 0, /* ReprojectionErrorKSE3AnchInvDepth        ceres_parametrization.cpp:361 */
+    ORC_RES_RIGHT       = 1, /* ReprojectionErrorRightCamKSE3AnchInvDepth  :579 */
+    ORC_RES_RIGHT_ANCH  = 2, /* ReprojectionErrorRightAnchCamKSE3AnchInvDepth :476 */
+};
+
+typedef struct {
+    int n_kf;               /* poses, Twc, [tx ty tz qx qy qz qw]  */
+    const double *poses;    /* 7*n_kf                                         */
+    const uint8_t *kf_const;/* n_kf                                           */
+    int n_lm;
+    const double *invdepth; /* n_lm                                           */
+    const int *lm_anchor_kf;/* n_lm                                           */
+    const double *lm_anchor_uv; /* 2*n_lm  anchor (undistorted) pixel          */
+    int n_res;
+    const uint8_t *res_type;/* n_res  ORC_RES_*                               */
+    const int *res_kf;      /* n_res  observing KF (ignored for RIGHT_ANCH)   */
+    const int *res_lm;      /* n_res                                          */
+    const double *res_uv;   /* 2*n_res observed pixel                         */
+    const double *res_sigma;/* n_res                                          */
+    const uint8_t *res_active; /* n_res or NULL (all active)                   */
+    double calib_l[4];      /* fx fy cx cy                                    */
+    double calib_r[4];
+    double T_rl[7];         /* [t, q] of Trl (right <- left)                  */
+} orc_ba_problem;
+
+typedef struct {
+    int max_iter;
+    double function_tolerance;   /* 1e-3 in localBA (optimizer.cpp:462)          */
+    double gradient_tolerance;   /* ceres default 1e-10                          */
+    double parameter_tolerance;  /* ceres default 1e-8                           */
+    double huber_delta;          /* sqrt(5.9915); <= 0 -> trivial loss           */
+    double initial_radius;       /* 1e4                                          */
+    double max_radius;           /* 1e16                                         */
+    double min_radius;           /* 1e-32                                        */
+    double min_lm_diagonal;      /* 1e-6                                         */
+    double max_lm_diagonal;      /* 1e32                                         */
+    double min_relative_decrease;/* 1e-3                                         */
+    int jacobi_scaling;          /* 1                                            */
+    int max_consecutive_invalid_steps; /* 5                                      */
+} orc_ba_options;
+
+enum {
+    ORC_TERM_NO_CONVERGENCE = 0,   /* hit max_iter                               */
+    ORC_TERM_FUNCTION_TOL   = 1,
+    ORC_TERM_PARAMETER_TOL  = 2,
+    ORC_TERM_GRADIENT_TOL   = 3,
+    ORC_TERM_MIN_RADIUS     = 4,
+    ORC_TERM_INVALID_STEPS  = 5,
+    ORC_TERM_FAILURE        = 6,
+};
+
+typedef struct {
+    double *poses_out;        /* 7*n_kf  */
+    double *invdepth_out;     /* n_lm    */
+    double *chi2_last_eval;   /* n_res   (value at last evaluated point) */
+    uint8_t *depthpos_last_eval; /* n_res */
+    int iterations;           /* ceres "num_iterations" = LM iterations run (excluding iter 0) */
+    int num_successful_steps;
+    double initial_cost, final_cost;
+    int termination;
+} orc_ba_result;
+
+void orc_ba_default_options(orc_ba_options *o);
+int  orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result *r);
+
+/* building blocks exposed for the known-answer tests */
+void orc_huber(double a, double s, double rho[3]);                 /* loss_function.cc:48-62  */
+/* corrector.cc:42-156; residuals (n_rows) and jacobian (n_rows x n_cols,
+ * row-major) corrected in place                                               */
+void orc_corrector(double sq_norm, const double rho[3], int n_rows, int n_cols,
+                   double *residuals, double *jacobian);
+/* levenberg_marquardt_strategy.cc:147-160 */
+void orc_lm_step_accepted(double step_quality, double *radius, double *decrease_factor, double max_radius);
+void orc_lm_step_rejected(double *radius, double *decrease_factor);
+/* Sophus SE3 exp (se3.hpp:763-784), tangent [v, w] -> (t, q=[x y z w])          */
+void orc_se3_exp(const double tangent[6], double t_out[3], double q_out[4]);
+/* left-multiplicative update  T' = Exp(delta) * T  (se3left_parametrization.hpp:45-57) */
+void orc_se3_left_plus(const double pose[7], const double delta[6], double pose_out[7]);
+/* one residual block: residual (2), jacobians wrt anchor pose (2x6 local),
+ * obs pose (2x6 local), inverse depth (2x1); un-robustified.
+ * Returns depth-positive flag; chi2 in *chi2.                                 */
+int orc_ba_residual(int type, const double calib_l[4], const double calib_r[4], const double T_rl[7],
+                    const double anchor_pose[7], const double obs_pose[7], double invdepth,
+                    const double anchor_uv[2], const double uv[2], double sigma,
+                    double r[2], double J_anchor[12], double J_obs[12], double J_lambda[2],
+                    double *chi2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OV2_ORACLE_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libov2slam_hip.so (the C ABI declared in include/ov2slam_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing this module
+raises at import of the symbol table, and if no GPU is visible every compute entry
+point returns OV2_ENODEVICE which is surfaced as Ov2Error.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libov2slam_hip.so")
+
+OV2_OK = 0
+OV2_EINVAL, OV2_EHIP, OV2_ENOMEM, OV2_EUNSUPPORTED, OV2_ENODEVICE = -1, -2, -3, -4, -5
+OV2_LK_USE_INITIAL_FLOW = 4
+OV2_LK_GET_MIN_EIGENVALS = 8
+OV2_MASK_AS_EXECUTED, OV2_MASK_INTENDED = 0, 1
+OV2_RES_LEFT, OV2_RES_RIGHT, OV2_RES_RIGHT_ANCH = 0, 1, 2
+
+
+class Ov2Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ov2slam_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class BAProblem(C.Structure):
+    _fields_ = [
+        ("n_kf", C.c_int), ("poses", C.POINTER(C.c_double)), ("kf_const", C.POINTER(C.c_uint8)),
+        ("n_lm", C.c_int), ("invdepth", C.POINTER(C.c_double)), ("lm_anchor_kf", C.POINTER(C.c_int)),
+        ("lm_anchor_uv", C.POINTER(C.c_double)),
+        ("n_res", C.c_int), ("res_type", C.POINTER(C.c_uint8)), ("res_kf", C.POINTER(C.c_int)),
+        ("res_lm", C.POINTER(C.c_int)), ("res_uv", C.POINTER(C.c_double)), ("res_sigma", C.POINTER(C.c_double)),
+        ("res_active", C.POINTER(C.c_uint8)),
+        ("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7),
+    ]
+
+
+class BAOptions(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("huber_delta", C.c_double), ("initial_radius", C.c_double),
+        ("max_radius", C.c_double), ("min_radius", C.c_double), ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double), ("min_relative_decrease", C.c_double), ("jacobi_scaling", C.c_int),
+        ("max_consecutive_invalid_steps", C.c_int),
+    ]
+
+
+class BAResult(C.Structure):
+    _fields_ = [
+        ("poses_out", C.POINTER(C.c_double)), ("invdepth_out", C.POINTER(C.c_double)),
+        ("chi2_last_eval", C.POINTER(C.c_double)), ("depthpos_last_eval", C.POINTER(C.c_uint8)),
+        ("iterations", C.c_int), ("num_successful_steps", C.c_int),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("termination", C.c_int),
+        ("solve_ms", C.c_double),
+    ]
+
+
+_vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  Must list every symbol include/ov2slam_hip.h declares
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "ov2_version": (_i, []),
+    "ov2_last_error": (C.c_char_p, []),
+    "ov2_ctx_create": (_i, [_i, _pp]),
+    "ov2_ctx_create_on_stream": (_i, [_i, _vp, _pp]),
+    "ov2_ctx_destroy": (None, [_vp]),
+    "ov2_ctx_sync": (_i, [_vp]),
+    "ov2_ctx_stream": (_vp, [_vp]),
+    "ov2_pyr_create": (_i, [_vp, _i, _i, _i, _i, _i, _pp]),
+    "ov2_pyr_destroy": (None, [_vp]),
+    "ov2_pyr_levels": (_i, [_vp]),
+    "ov2_pyr_level_size": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "ov2_pyr_batch": (_i, [_vp]),
+    "ov2_pyr_build_h": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
+    "ov2_pyr_build_d": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
+    "ov2_pyr_download": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ov2_pyr_download_padded": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ov2_pyr_algorithmic_bytes": (C.c_size_t, [_vp]),
+    "ov2_lk_track": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "ov2_fb_klt": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
+    "ov2_fb_klt_d": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
+    "ov2_detect_grid_fast": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.POINTER(_i), _i, _i, _vp, C.POINTER(_i)]),
+    "ov2_detect_singlescale": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.POINTER(_i), C.POINTER(_d), _i, _vp, C.POINTER(_i)]),
+    "ov2_corner_subpix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _d]),
+    "ov2_ba_default_options": (None, [C.POINTER(BAOptions)]),
+    "ov2_ba_solve": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(BAOptions), C.POINTER(BAResult)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libov2slam_hip.so and bind every symbol.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ov2slam_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OV2_OK:
+        raise Ov2Error(rc, load().ov2_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,77 @@
+// common.hpp -- shared declarations of libov2slam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/ov2slam_hip.h"
+
+#define OV2_MAX_LEVELS 8
+
+// ---- error plumbing (never throws across the C ABI) ------------------------
+void ov2_set_error(const char *fmt, ...);
+
+#define OV2_HIP_CHECK(expr)                                                        \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            ov2_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                          hipGetErrorString(_e));                                  \
+            return OV2_EHIP;                                                       \
+        }                                                                          \
+    } while (0)
+
+#define OV2_REQUIRE(cond, code, msg)                                               \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            ov2_set_error("%s:%d: %s", __FILE__, __LINE__, msg);                   \
+            return (code);                                                         \
+        }                                                                          \
+    } while (0)
+
+// ---- context ---------------------------------------------------------------
+struct ov2_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // grow-only scratch (device + pinned host), reused across calls of this ctx
+    void *d_scratch = nullptr;  size_t d_scratch_bytes = 0;
+    void *h_scratch = nullptr;  size_t h_scratch_bytes = 0;
+    int reserve_device(size_t bytes);
+    int reserve_host(size_t bytes);
+};
+
+// ---- pyramid layout in HBM ---------------------------------------------------
+// One allocation per ov2_pyr holding `batch` items of identical layout.  Per
+// level: a padded u8 image (REFLECT_101 border, ROI origin 16-byte aligned) and a
+// padded int16x2 Scharr derivative (zero border, ROI origin 64-byte aligned).
+struct PyrLevelDesc {
+    int w, h;
+    int img_pitch;        // bytes per padded image row (multiple of 64)
+    int der_pitch;        // int16x2 elements (4 B) per padded derivative row (multiple of 16)
+    long long img_roi;    // byte offset (from the item base) of image ROI pixel (0,0)
+    long long der_roi;    // byte offset (from the item base) of derivative ROI element (0,0)
+    int img_padx, der_padx, pady;
+};
+
+struct PyrDesc {
+    uint8_t *base;            // device pointer of batch item 0
+    long long item_stride;    // bytes between batch items
+    int n_levels;
+    int win;
+    int batch;
+    PyrLevelDesc lv[OV2_MAX_LEVELS];
+};
+
+struct ov2_pyr {
+    PyrDesc d;
+    int w = 0, h = 0, max_level = 0;
+    size_t bytes = 0;
+    int device = 0;
+};
+
+// kernels' host launchers (defined in the .hip files)
+int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride);

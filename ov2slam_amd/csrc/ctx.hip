@@ -1,0 +1,95 @@
+// ctx.hip -- context / error handling of libov2slam_hip.so
+#include "common.hpp"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void ov2_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ov2_ctx::reserve_device(size_t bytes)
+{
+    if (bytes <= d_scratch_bytes) return OV2_OK;
+    if (d_scratch) { OV2_HIP_CHECK(hipStreamSynchronize(stream)); OV2_HIP_CHECK(hipFree(d_scratch)); d_scratch = nullptr; d_scratch_bytes = 0; }
+    size_t cap = bytes + bytes / 2 + 4096;
+    OV2_HIP_CHECK(hipMalloc(&d_scratch, cap));
+    d_scratch_bytes = cap;
+    return OV2_OK;
+}
+
+int ov2_ctx::reserve_host(size_t bytes)
+{
+    if (bytes <= h_scratch_bytes) return OV2_OK;
+    if (h_scratch) { OV2_HIP_CHECK(hipStreamSynchronize(stream)); OV2_HIP_CHECK(hipHostFree(h_scratch)); h_scratch = nullptr; h_scratch_bytes = 0; }
+    size_t cap = bytes + bytes / 2 + 4096;
+    OV2_HIP_CHECK(hipHostMalloc(&h_scratch, cap, hipHostMallocDefault));
+    h_scratch_bytes = cap;
+    return OV2_OK;
+}
+
+extern "C" {
+
+int ov2_version(void) { return 100; }
+
+const char *ov2_last_error(void) { return g_err; }
+
+static int ctx_create_common(int device, hipStream_t stream, bool own, ov2_ctx **out)
+{
+    OV2_REQUIRE(out != nullptr, OV2_EINVAL, "out == NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        ov2_set_error("no HIP device visible (%s)", e == hipSuccess ? "count == 0" : hipGetErrorString(e));
+        return OV2_ENODEVICE;
+    }
+    OV2_REQUIRE(device >= 0 && device < ndev, OV2_EINVAL, "device index out of range");
+    OV2_HIP_CHECK(hipSetDevice(device));
+    ov2_ctx *c = new (std::nothrow) ov2_ctx();
+    OV2_REQUIRE(c != nullptr, OV2_ENOMEM, "out of host memory");
+    c->device = device;
+    if (own) {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete c; ov2_set_error("hipStreamCreate: %s", hipGetErrorString(se)); return OV2_EHIP; }
+        c->owns_stream = true;
+    } else {
+        c->stream = stream;
+        c->owns_stream = false;
+    }
+    *out = c;
+    return OV2_OK;
+}
+
+int ov2_ctx_create(int device, ov2_ctx **out) { return ctx_create_common(device, nullptr, true, out); }
+
+int ov2_ctx_create_on_stream(int device, void *hip_stream, ov2_ctx **out)
+{
+    return ctx_create_common(device, (hipStream_t)hip_stream, false, out);
+}
+
+void ov2_ctx_destroy(ov2_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int ov2_ctx_sync(ov2_ctx *ctx)
+{
+    OV2_REQUIRE(ctx != nullptr, OV2_EINVAL, "ctx == NULL");
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OV2_OK;
+}
+
+void *ov2_ctx_stream(ov2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+} // extern "C"

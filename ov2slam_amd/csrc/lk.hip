@@ -1,0 +1,424 @@
+// lk.hip -- forward/backward pyramidal Lucas-Kanade for gfx950 (wave64).
+//
+// Replaces cv::calcOpticalFlowPyrLK as called by FeatureTracker::fbKltTracking
+// (/root/reference/src/feature_tracker.cpp:66-69 forward, :113-116 backward) and
+// the filtering between / after the two calls (:79-101, :119-134).
+//
+// Work mapping (CDNA4): one keypoint per 16-lane DPP row, 4 keypoints per
+// wavefront, 16 per 256-thread workgroup.  Lane r of a row owns window row r
+// (r < WIN) and source row r (r <= WIN):
+//   * it loads its source row as (WIN+1+3) bytes -> aligned dwords straight from the
+//     padded level image in HBM/L2 (one row = one or two cache lines), the row below
+//     comes from lane r+1 through a DPP row_shl:1 move -- no LDS, no bank conflicts;
+//   * the template patch (I, dIx, dIy: WIN int16 each) lives in VGPRs for the whole
+//     Gauss-Newton loop;
+//   * the 2x2 normal matrix and the mismatch vector are exact integer sums reduced
+//     with a 4-step DPP butterfly inside the row (quad_perm, quad_perm, row_ror:4,
+//     row_ror:8), so the result does not depend on reduction order and matches the
+//     oracle (OpenCV's `int64 acctype` variant) bit for bit.
+// All levels (coarse -> fine), the forward pass, the status/err/border filter, the
+// backward pass and the forward-backward distance test run in ONE launch.
+#include "common.hpp"
+#include <float.h>
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+struct LKParams {
+    int win, max_level, max_iter;
+    double eps2;          // clamp(eps,0,10)^2 (double, like cv::TermCriteria::epsilon)
+    float min_eig_th;     // 1e-4f
+    int flags;
+    float err_th, fb_dist;
+    int do_fb;            // 1: fbKltTracking, 0: single calcOpticalFlowPyrLK
+    int n_max;            // points per batch item (stride)
+};
+
+#define DPP_ROW_SHL1   0x101
+#define DPP_QP_1032    0xB1
+#define DPP_QP_2301    0x4E
+#define DPP_ROW_ROR4   0x124
+#define DPP_ROW_ROR8   0x128
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// all-reduce (sum) of an int32 inside each 16-lane row
+__device__ __forceinline__ int row_allreduce_i32(int v)
+{
+    v += dpp_mov<DPP_QP_1032>(v);
+    v += dpp_mov<DPP_QP_2301>(v);
+    v += dpp_mov<DPP_ROW_ROR4>(v);
+    v += dpp_mov<DPP_ROW_ROR8>(v);
+    return v;
+}
+
+// exact sum of per-lane int32 partials (|p| < 2^31) as a double, via two int32 butterflies
+__device__ __forceinline__ double row_allreduce_exact(int p)
+{
+    const int lo = p & 0xFFFF;       // [0, 65535]
+    const int hi = p >> 16;          // arithmetic shift: p == hi*65536 + lo
+    const int slo = row_allreduce_i32(lo);
+    const int shi = row_allreduce_i32(hi);
+    return (double)shi * 65536.0 + (double)slo;
+}
+
+__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
+__device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+template <int WIN>
+struct RowBytes {
+    static constexpr int ND = (WIN + 1 + 3 + 3) / 4;   // aligned dwords covering WIN+1 bytes at any byte phase
+    static constexpr int NR = (WIN + 1 + 3) / 4;       // dwords after re-alignment
+    uint32_t d[NR];
+    __device__ __forceinline__ int px(int k) const { return (int)((d[k >> 2] >> ((k & 3) * 8)) & 0xFFu); }
+};
+
+// load bytes [x, x+WIN] of one padded image row as aligned dwords and shift them so
+// that byte 0 is pixel x.
+template <int WIN>
+__device__ __forceinline__ RowBytes<WIN> load_row(const uint8_t *roi_row, int x)
+{
+    constexpr int ND = RowBytes<WIN>::ND, NR = RowBytes<WIN>::NR;
+    const int xa = x & ~3;                 // floor to a multiple of 4 (two's complement: works for x < 0)
+    const int sh = x - xa;                 // 0..3
+    const uint32_t *p = (const uint32_t *)(roi_row + xa);
+    uint32_t raw[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) raw[i] = p[i];
+    RowBytes<WIN> r;
+#pragma unroll
+    for (int i = 0; i < NR; i++) r.d[i] = __builtin_amdgcn_alignbyte(raw[i + 1 < ND ? i + 1 : i], raw[i], (uint32_t)sh);
+    return r;
+}
+
+template <int WIN>
+__device__ __forceinline__ RowBytes<WIN> row_from_next_lane(const RowBytes<WIN> &r)
+{
+    RowBytes<WIN> o;
+#pragma unroll
+    for (int i = 0; i < RowBytes<WIN>::NR; i++) o.d[i] = (uint32_t)dpp_mov<DPP_ROW_SHL1>((int)r.d[i]);
+    return o;
+}
+
+struct LKPointState {
+    float nx, ny;     // nextPts[i] as OpenCV stores it between levels
+    int status;
+    float err;
+    int iters;
+    int visits;
+};
+
+// One pyramid level for the keypoint owned by this 16-lane row.
+// I = template level (image + derivative), J = search level (image only).
+template <int WIN>
+__device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, const PyrLevelDesc &LI,
+                                         const uint8_t *__restrict__ itemJ, const PyrLevelDesc &LJ,
+                                         const LKParams &prm, int level, int top_level, bool use_initial,
+                                         float px0, float py0, int r, LKPointState &st)
+{
+    const float halfWin = (float)(WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const float W14 = (float)(1 << 14);
+    const float lvl_scale = (float)(1. / (double)(1 << level));
+
+    float prevx = px0 * lvl_scale, prevy = py0 * lvl_scale;
+    float nextx, nexty;
+    if (level == top_level) {
+        if (use_initial) { nextx = st.nx * lvl_scale; nexty = st.ny * lvl_scale; }
+        else { nextx = prevx; nexty = prevy; }
+    } else {
+        nextx = st.nx * 2.f; nexty = st.ny * 2.f;
+    }
+    st.nx = nextx; st.ny = nexty;
+
+    prevx -= halfWin; prevy -= halfWin;
+    const int ipx = cv_floor(prevx), ipy = cv_floor(prevy);
+    if (ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h) {
+        if (level == 0) { st.status = 0; st.err = 0.f; }
+        return;
+    }
+    st.visits++;
+    float a = prevx - (float)ipx, b = prevy - (float)ipy;
+    int iw00 = cv_round((1.f - a) * (1.f - b) * W14);
+    int iw01 = cv_round(a * (1.f - b) * W14);
+    int iw10 = cv_round((1.f - a) * b * W14);
+    int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+
+    const int rr = r <= WIN ? r : WIN;          // idle lanes (r > WIN) re-read the last row; results are masked
+    const bool row_active = r < WIN;
+
+    // ---- template patch: I (5 fractional bits), dIx, dIy; exact sums of products ----
+    int Iw[WIN], dIx[WIN], dIy[WIN];
+    double A11d, A12d, A22d;
+    {
+        const uint8_t *irow = itemI + LI.img_roi + (long long)(ipy + rr) * LI.img_pitch;
+        const RowBytes<WIN> r0 = load_row<WIN>(irow, ipx);
+        const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
+        const uint32_t *drow = (const uint32_t *)(itemI + LI.der_roi) + (long long)(ipy + rr) * LI.der_pitch + ipx;
+        uint32_t d0[WIN + 1], d1[WIN + 1];
+#pragma unroll
+        for (int k = 0; k <= WIN; k++) d0[k] = drow[k];
+#pragma unroll
+        for (int k = 0; k <= WIN; k++) d1[k] = (uint32_t)dpp_mov<DPP_ROW_SHL1>((int)d0[k]);
+        int s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+        for (int x = 0; x < WIN; x++) {
+            const int ival = descale(r0.px(x) * iw00 + r0.px(x + 1) * iw01 + r1.px(x) * iw10 + r1.px(x + 1) * iw11, 14 - 5);
+            const int x00 = (int)(int16_t)(d0[x] & 0xFFFF), y00 = (int)d0[x] >> 16;
+            const int x01 = (int)(int16_t)(d0[x + 1] & 0xFFFF), y01 = (int)d0[x + 1] >> 16;
+            const int x10 = (int)(int16_t)(d1[x] & 0xFFFF), y10 = (int)d1[x] >> 16;
+            const int x11 = (int)(int16_t)(d1[x + 1] & 0xFFFF), y11 = (int)d1[x + 1] >> 16;
+            const int ixval = descale(x00 * iw00 + x01 * iw01 + x10 * iw10 + x11 * iw11, 14);
+            const int iyval = descale(y00 * iw00 + y01 * iw01 + y10 * iw10 + y11 * iw11, 14);
+            Iw[x] = ival; dIx[x] = ixval; dIy[x] = iyval;
+            if (row_active) { s11 += ixval * ixval; s12 += ixval * iyval; s22 += iyval * iyval; }
+        }
+        // per-lane partials: WIN * 4080^2 < 2^31 for WIN <= 15
+        A11d = row_allreduce_exact(s11);
+        A12d = row_allreduce_exact(s12);
+        A22d = row_allreduce_exact(s22);
+    }
+    const float A11 = (float)A11d * FLT_SCALE, A12 = (float)A12d * FLT_SCALE, A22 = (float)A22d * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+    if (prm.flags & OV2_LK_GET_MIN_EIGENVALS) st.err = minEig;
+    if (minEig < prm.min_eig_th || D < FLT_EPSILON) {
+        if (level == 0) st.status = 0;
+        return;
+    }
+    D = 1.f / D;
+    nextx -= halfWin; nexty -= halfWin;
+    float pdx = 0.f, pdy = 0.f;
+    const uint8_t *jroi = itemJ + LJ.img_roi;
+    for (int j = 0; j < prm.max_iter; j++) {
+        const int inx = cv_floor(nextx), iny = cv_floor(nexty);
+        if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+            if (level == 0) st.status = 0;
+            break;
+        }
+        st.iters++;
+        a = nextx - (float)inx; b = nexty - (float)iny;
+        iw00 = cv_round((1.f - a) * (1.f - b) * W14);
+        iw01 = cv_round(a * (1.f - b) * W14);
+        iw10 = cv_round((1.f - a) * b * W14);
+        iw11 = (1 << 14) - iw00 - iw01 - iw10;
+        const RowBytes<WIN> r0 = load_row<WIN>(jroi + (long long)(iny + rr) * LJ.img_pitch, inx);
+        const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
+        int sb1 = 0, sb2 = 0;
+#pragma unroll
+        for (int x = 0; x < WIN; x++) {
+            const int diff = descale(r0.px(x) * iw00 + r0.px(x + 1) * iw01 + r1.px(x) * iw10 + r1.px(x + 1) * iw11, 14 - 5) - Iw[x];
+            sb1 += diff * dIx[x];
+            sb2 += diff * dIy[x];
+        }
+        if (!row_active) { sb1 = 0; sb2 = 0; }
+        // |diff * dI| <= 8160*4080 -> per-lane partial < WIN * 3.33e7 < 2^31 for WIN <= 15
+        const float b1 = (float)row_allreduce_exact(sb1) * FLT_SCALE;
+        const float b2 = (float)row_allreduce_exact(sb2) * FLT_SCALE;
+        const float dx = (A12 * b2 - A22 * b1) * D;
+        const float dy = (A12 * b1 - A11 * b2) * D;
+        nextx += dx; nexty += dy;
+        st.nx = nextx + halfWin; st.ny = nexty + halfWin;
+        if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
+        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            st.nx -= dx * 0.5f; st.ny -= dy * 0.5f;
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+}
+
+template <int WIN>
+__global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams prm,
+                                                const float2 *__restrict__ kps, float2 *__restrict__ priors,
+                                                uint8_t *__restrict__ status, float *__restrict__ err_out,
+                                                int *__restrict__ iters_out, const int *__restrict__ n_per_item,
+                                                long long *__restrict__ stats)
+{
+    const int b = blockIdx.y;
+    const int n = n_per_item ? n_per_item[b] : prm.n_max;
+    const int r = threadIdx.x & 15;
+    const int i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    if (i >= n) return;                                  // whole 16-lane rows exit together
+    const long long gi = (long long)b * prm.n_max + i;
+    const uint8_t *itemP = P.base + (long long)b * P.item_stride;
+    const uint8_t *itemC = C.base + (long long)b * C.item_stride;
+
+    const float2 kp = kps[gi];
+    const float2 pr = priors[gi];
+    LKPointState st;
+    st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
+
+    // forward: prev -> cur, levels max_level..0   (feature_tracker.cpp:66-69)
+    for (int level = prm.max_level; level >= 0; level--)
+        lk_level<WIN>(itemP, P.lv[level], itemC, C.lv[level], prm, level, prm.max_level,
+                      (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, r, st);
+
+    const float fx = st.nx, fy = st.ny;
+    int ok = st.status;
+    if (prm.do_fb) {
+        // feature_tracker.cpp:79-101
+        if (ok && st.err > prm.err_th) ok = 0;
+        const float W0 = (float)C.lv[0].w, H0 = (float)C.lv[0].h;
+        if (ok && !(1.f <= fx && fx < W0 - 1.f && 1.f <= fy && fy < H0 - 1.f)) ok = 0;   // inBorder :216-221
+        if (ok) {
+            // backward: cur -> prev at level 0, initial guess = original keypoint (:113-116)
+            LKPointState sb;
+            sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0; sb.visits = 0;
+            lk_level<WIN>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
+            st.iters += sb.iters; st.visits += sb.visits;
+            if (!sb.status) ok = 0;
+            else {
+                const float ddx = kp.x - sb.nx, ddy = kp.y - sb.ny;      // cv::norm(Point2f) (:128)
+                const double nrm = sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                if (nrm > (double)prm.fb_dist) ok = 0;
+            }
+        }
+    }
+    if (r == 0) {
+        priors[gi] = make_float2(fx, fy);
+        status[gi] = (uint8_t)ok;
+        if (err_out) err_out[gi] = st.err;
+        if (iters_out) iters_out[gi] = st.iters;
+        if (stats) {
+            atomicAdd((unsigned long long *)&stats[0], (unsigned long long)st.iters);
+            atomicAdd((unsigned long long *)&stats[1], (unsigned long long)st.visits);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------
+template <int WIN>
+static void launch_fb_klt(hipStream_t s, dim3 grid, const PyrDesc &P, const PyrDesc &C, const LKParams &prm,
+                          const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
+                          const int *n_per_item, long long *stats)
+{
+    hipLaunchKernelGGL(k_fb_klt<WIN>, grid, dim3(256), 0, s, P, C, prm, kps, priors, status, err, iters, n_per_item, stats);
+}
+
+static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LKParams prm,
+                       const float2 *kps_d, float2 *priors_d, uint8_t *status_d, float *err_d, int *iters_d,
+                       const int *n_per_item_d, long long *stats_d)
+{
+    const PyrDesc &P = prev->d, &C = cur->d;
+    OV2_REQUIRE(P.n_levels == C.n_levels && P.batch == C.batch && P.win == C.win, OV2_EINVAL,
+                "prev/cur pyramids differ in geometry");
+    OV2_REQUIRE(P.lv[0].w == C.lv[0].w && P.lv[0].h == C.lv[0].h, OV2_EINVAL, "prev/cur image size differs");
+    OV2_REQUIRE(prm.win == P.win, OV2_EINVAL, "LK window differs from the window the pyramid was padded for");
+    dim3 grid((prm.n_max + 15) / 16, P.batch);
+    switch (prm.win) {
+    case 5:  launch_fb_klt<5>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    case 7:  launch_fb_klt<7>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    case 9:  launch_fb_klt<9>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    case 11: launch_fb_klt<11>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    case 13: launch_fb_klt<13>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    case 15: launch_fb_klt<15>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    default:
+        ov2_set_error("LK window %d has no kernel instance (supported: 5,7,9,11,13,15; the reference ships 9)", prm.win);
+        return OV2_EUNSUPPORTED;
+    }
+    OV2_HIP_CHECK(hipGetLastError());
+    return OV2_OK;
+}
+
+static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_iter, float eps, int flags,
+                            float err_th, float fb_dist, int do_fb, int n_max)
+{
+    LKParams prm;
+    prm.win = win;
+    // calcOpticalFlowPyrLK: maxLevel = min(maxLevel, levels in the pyramid)
+    prm.max_level = max_level > pyr->d.n_levels - 1 ? pyr->d.n_levels - 1 : max_level;
+    if (prm.max_level < 0) prm.max_level = 0;
+    prm.max_iter = max_iter < 0 ? 0 : (max_iter > 100 ? 100 : max_iter);
+    double e = (double)eps;                      // TermCriteria::epsilon is a double holding the float
+    if (e < 0.) e = 0.;
+    if (e > 10.) e = 10.;
+    prm.eps2 = e * e;
+    prm.min_eig_th = 1e-4f;
+    prm.flags = flags;
+    prm.err_th = err_th; prm.fb_dist = fb_dist; prm.do_fb = do_fb; prm.n_max = n_max;
+    return prm;
+}
+
+extern "C" {
+
+int ov2_fb_klt_d(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur,
+                 int win, int nbpyrlvl, int max_iter, float eps, float err_th, float fb_dist,
+                 const float *kps_xy_d, float *prior_xy_inout_d, int n_max, const int *n_per_item_d,
+                 uint8_t *status_d, long long *stats_d)
+{
+    OV2_REQUIRE(ctx && prev && cur, OV2_EINVAL, "NULL argument");
+    if (n_max <= 0) return OV2_OK;
+    OV2_REQUIRE(kps_xy_d && prior_xy_inout_d && status_d, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(nbpyrlvl >= 0, OV2_EINVAL, "nbpyrlvl < 0");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    LKParams prm = make_params(prev, win, nbpyrlvl, max_iter, eps,
+                               OV2_LK_USE_INITIAL_FLOW | OV2_LK_GET_MIN_EIGENVALS, err_th, fb_dist, 1, n_max);
+    return lk_dispatch(ctx, prev, cur, prm, (const float2 *)kps_xy_d, (float2 *)prior_xy_inout_d, status_d,
+                       nullptr, nullptr, n_per_item_d, stats_d);
+}
+
+// host-buffer wrappers: stage through the context's scratch, one H2D + one D2H
+static int lk_host_call(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LKParams prm,
+                        const float *kps_h, float *priors_h, int n, uint8_t *status_h, float *err_h, int *iters_h,
+                        long long *stats_h)
+{
+    OV2_REQUIRE(prev->d.batch == 1 && cur->d.batch == 1, OV2_EINVAL, "host-buffer LK entry points take batch=1 pyramids");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    // layout: [kps 8n][priors 8n][err 4n][iters 4n][stats 16][status n]
+    const size_t o_kps = 0, o_pri = 8 * (size_t)n, o_err = 16 * (size_t)n, o_it = 20 * (size_t)n;
+    const size_t o_stats = 24 * (size_t)n, o_st = o_stats + 16, total = o_st + (size_t)n;
+    int rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(total);        if (rc) return rc;
+    uint8_t *hs = (uint8_t *)ctx->h_scratch, *ds = (uint8_t *)ctx->d_scratch;
+    memcpy(hs + o_kps, kps_h, 8 * (size_t)n);
+    memcpy(hs + o_pri, priors_h, 8 * (size_t)n);
+    memset(hs + o_stats, 0, 16);
+    OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, o_err, hipMemcpyHostToDevice, ctx->stream));
+    OV2_HIP_CHECK(hipMemsetAsync(ds + o_stats, 0, 16, ctx->stream));
+    rc = lk_dispatch(ctx, prev, cur, prm, (const float2 *)(ds + o_kps), (float2 *)(ds + o_pri), ds + o_st,
+                     (float *)(ds + o_err), (int *)(ds + o_it), nullptr, (long long *)(ds + o_stats));
+    if (rc) return rc;
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_pri, ds + o_pri, total - o_pri, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(priors_h, hs + o_pri, 8 * (size_t)n);
+    memcpy(status_h, hs + o_st, (size_t)n);
+    if (err_h) memcpy(err_h, hs + o_err, 4 * (size_t)n);
+    if (iters_h) memcpy(iters_h, hs + o_it, 4 * (size_t)n);
+    if (stats_h) memcpy(stats_h, hs + o_stats, 16);
+    return OV2_OK;
+}
+
+int ov2_fb_klt(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur,
+               int win, int nbpyrlvl, int max_iter, float eps, float err_th, float fb_dist,
+               const float *kps_xy_h, float *prior_xy_inout_h, int n,
+               uint8_t *status_h, long long stats[2])
+{
+    OV2_REQUIRE(ctx && prev && cur, OV2_EINVAL, "NULL argument");
+    if (n <= 0) return OV2_OK;                       // feature_tracker.cpp:43-46
+    OV2_REQUIRE(kps_xy_h && prior_xy_inout_h && status_h, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(nbpyrlvl >= 0, OV2_EINVAL, "nbpyrlvl < 0");
+    LKParams prm = make_params(prev, win, nbpyrlvl, max_iter, eps,
+                               OV2_LK_USE_INITIAL_FLOW | OV2_LK_GET_MIN_EIGENVALS, err_th, fb_dist, 1, n);
+    return lk_host_call(ctx, prev, cur, prm, kps_xy_h, prior_xy_inout_h, n, status_h, nullptr, nullptr, stats);
+}
+
+int ov2_lk_track(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *next,
+                 int win, int max_level, int max_iter, float eps, int flags,
+                 const float *prev_xy_h, float *next_xy_inout_h, int n,
+                 uint8_t *status_h, float *err_h, int *iters_h)
+{
+    OV2_REQUIRE(ctx && prev && next, OV2_EINVAL, "NULL argument");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(prev_xy_h && next_xy_inout_h && status_h, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(max_level >= 0, OV2_EINVAL, "max_level < 0");
+    LKParams prm = make_params(prev, win, max_level, max_iter, eps, flags, 0.f, 0.f, 0, n);
+    return lk_host_call(ctx, prev, next, prm, prev_xy_h, next_xy_inout_h, n, status_h, err_h, iters_h, nullptr);
+}
+
+} // extern "C"

@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's front-end operator interface, on top of the
+C ABI (include/ov2slam_hip.h).  Names, argument meaning and failure behaviour follow
+/root/reference/include/feature_tracker.hpp and feature_extractor.hpp so that the
+parity tests read like calls into the reference:
+
+    reference (C++ / OpenCV)                              here
+    ----------------------------------------------------  ---------------------------------
+    cv::buildOpticalFlowPyramid(img, pyr, win, lvl)       Pyramid(ctx, w, h, win, lvl).build(img)
+    FeatureTracker::fbKltTracking(prevpyr, curpyr, ...)   FeatureTracker.fbKltTracking(...)
+    FeatureExtractor::detectGridFAST(im, cell, kps, roi)  FeatureExtractor.detectGridFAST(...)
+    FeatureExtractor::detectSingleScale(im, cell, ...)    FeatureExtractor.detectSingleScale(...)
+
+numpy arrays are the host buffers; nothing here computes on the CPU.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One HIP stream + scratch (ov2_ctx).  One per calling thread."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = L.load()
+        h = C.c_void_p()
+        if stream is None:
+            L.check(self.lib.ov2_ctx_create(device, C.byref(h)))
+        else:
+            L.check(self.lib.ov2_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        L.check(self.lib.ov2_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.ov2_ctx_stream(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ov2_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pyramid:
+    """Device-resident result of cv::buildOpticalFlowPyramid (image + Scharr
+    derivative per level, padded by `win`), for `batch` images of equal size."""
+
+    def __init__(self, ctx, w, h, win=9, max_level=3, batch=1):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.w, self.h, self.win, self.max_level, self.batch = w, h, win, max_level, batch
+        hp = C.c_void_p()
+        L.check(self.lib.ov2_pyr_create(ctx.h, w, h, win, max_level, batch, C.byref(hp)))
+        self.h_pyr = hp
+
+    @property
+    def levels(self):
+        return self.lib.ov2_pyr_levels(self.h_pyr)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        L.check(self.lib.ov2_pyr_level_size(self.h_pyr, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def build(self, img):
+        """img: (h,w) or (batch,h,w) uint8 numpy array (host).  Asynchronous."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        if img.ndim == 2:
+            img = img[None]
+        assert img.shape == (self.batch, self.h, self.w), img.shape
+        self._keep = img
+        L.check(self.lib.ov2_pyr_build_h(self.ctx.h, self.h_pyr, _ptr(img), self.w, self.w * self.h))
+        return self
+
+    def build_from_device(self, dev_ptr, stride=None, batch_stride=None):
+        stride = stride or self.w
+        batch_stride = batch_stride or stride * self.h
+        L.check(self.lib.ov2_pyr_build_d(self.ctx.h, self.h_pyr, C.c_void_p(dev_ptr), stride, batch_stride))
+        return self
+
+    def download(self, level, b=0, padded=False):
+        w, h = self.level_size(level)
+        if padded:
+            w, h = w + 2 * self.win, h + 2 * self.win
+        img = np.empty((h, w), np.uint8)
+        der = np.empty((h, w, 2), np.int16)
+        fn = self.lib.ov2_pyr_download_padded if padded else self.lib.ov2_pyr_download
+        L.check(fn(self.ctx.h, self.h_pyr, b, level, _ptr(img), _ptr(der)))
+        return img, der
+
+    @property
+    def algorithmic_bytes(self):
+        return self.lib.ov2_pyr_algorithmic_bytes(self.h_pyr)
+
+    def close(self):
+        if getattr(self, "h_pyr", None):
+            self.lib.ov2_pyr_destroy(self.h_pyr)
+            self.h_pyr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FeatureTracker:
+    """Mirror of /root/reference/include/feature_tracker.hpp:36-56.
+
+    FeatureTracker(nmax_iter, fmax_px_precision) stores the KLT convergence criteria
+    (cv::TermCriteria(COUNT+EPS, nmax_iter, fmax_px_precision), :39-40)."""
+
+    def __init__(self, ctx, nmax_iter=30, fmax_px_precision=0.01):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.nmax_iter = int(nmax_iter)
+        self.fmax_px_precision = float(np.float32(fmax_px_precision))
+
+    def fbKltTracking(self, vprevpyr, vcurpyr, nwinsize, nbpyrlvl, ferr, fmax_fbklt_dist, vkps, vpriorkps,
+                      return_stats=False):
+        """src/feature_tracker.cpp:35-137.  vkps / vpriorkps: (n,2) float32.
+        Returns (vpriorkps_out, vkpstatus) -- the reference updates vpriorkps in place
+        and push_back()s into vkpstatus; with no keypoints it returns untouched
+        outputs (:43-46), here an empty status list."""
+        kps = np.ascontiguousarray(vkps, dtype=np.float32).reshape(-1, 2)
+        pri = np.array(vpriorkps, dtype=np.float32, copy=True).reshape(-1, 2)
+        n = kps.shape[0]
+        assert pri.shape[0] == n
+        status = np.zeros(n, np.uint8)
+        stats = (C.c_longlong * 2)(0, 0)
+        L.check(self.lib.ov2_fb_klt(self.ctx.h, vprevpyr.h_pyr, vcurpyr.h_pyr, int(nwinsize), int(nbpyrlvl),
+                                    self.nmax_iter, self.fmax_px_precision, float(ferr), float(fmax_fbklt_dist),
+                                    _ptr(kps), _ptr(pri), n, _ptr(status), stats))
+        if return_stats:
+            return pri, status.astype(bool), (int(stats[0]), int(stats[1]))
+        return pri, status.astype(bool)
+
+    def calcOpticalFlowPyrLK(self, prevpyr, nextpyr, prevpts, nextpts, nwinsize, maxlevel,
+                             flags=L.OV2_LK_USE_INITIAL_FLOW | L.OV2_LK_GET_MIN_EIGENVALS):
+        """One cv::calcOpticalFlowPyrLK call (src/feature_tracker.cpp:66-69)."""
+        p0 = np.ascontiguousarray(prevpts, dtype=np.float32).reshape(-1, 2)
+        p1 = np.array(nextpts, dtype=np.float32, copy=True).reshape(-1, 2)
+        n = p0.shape[0]
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        iters = np.zeros(n, np.int32)
+        L.check(self.lib.ov2_lk_track(self.ctx.h, prevpyr.h_pyr, nextpyr.h_pyr, int(nwinsize), int(maxlevel),
+                                      self.nmax_iter, self.fmax_px_precision, int(flags),
+                                      _ptr(p0), _ptr(p1), n, _ptr(status), _ptr(err), _ptr(iters)))
+        return p1, status, err, iters
+
+
+class FeatureExtractor:
+    """Mirror of /root/reference/include/feature_extractor.hpp:30-54: holds the
+    adaptive thresholds nfast_th_ and dmaxquality_ that the two grid detectors update."""
+
+    def __init__(self, ctx, nfast_th=10, dmaxquality=0.001, mask_mode=L.OV2_MASK_AS_EXECUTED):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.nfast_th_ = int(nfast_th)
+        self.dmaxquality_ = float(dmaxquality)
+        self.mask_mode = mask_mode
+
+    def detectGridFAST(self, im, ncellsize, vcurkps, roi=None, subpix=True):
+        """src/feature_extractor.cpp:443-570 (roi is unused there too)."""
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        if im.size == 0:
+            return np.zeros((0, 2), np.float32)               # :446-449
+        h, w = im.shape
+        cur = np.ascontiguousarray(vcurkps, dtype=np.float32).reshape(-1, 2)
+        cap = max(1, (w // ncellsize) * (h // ncellsize))
+        out = np.zeros((cap, 2), np.float32)
+        n = C.c_int(0)
+        th = C.c_int(self.nfast_th_)
+        L.check(self.lib.ov2_detect_grid_fast(self.ctx.h, _ptr(im), w, h, w, int(ncellsize), _ptr(cur), cur.shape[0],
+                                              C.byref(th), self.mask_mode, int(bool(subpix)), _ptr(out), C.byref(n)))
+        self.nfast_th_ = th.value
+        return out[:n.value].copy()
+
+    def detectSingleScale(self, im, ncellsize, vcurkps, roi, subpix=True):
+        """src/feature_extractor.cpp:288-440.  roi = (x, y, width, height)."""
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        if im.size == 0:
+            return np.zeros((0, 2), np.float32)               # :291-294
+        h, w = im.shape
+        cur = np.ascontiguousarray(vcurkps, dtype=np.float32).reshape(-1, 2)
+        cap = max(1, 2 * (w // ncellsize) * (h // ncellsize))
+        out = np.zeros((cap, 2), np.float32)
+        n = C.c_int(0)
+        q = C.c_double(self.dmaxquality_)
+        roi_a = (C.c_int * 4)(*[int(v) for v in roi])
+        L.check(self.lib.ov2_detect_singlescale(self.ctx.h, _ptr(im), w, h, w, int(ncellsize), _ptr(cur), cur.shape[0],
+                                                roi_a, C.byref(q), int(bool(subpix)), _ptr(out), C.byref(n)))
+        self.dmaxquality_ = q.value
+        return out[:n.value].copy()
+
+    def cornerSubPix(self, im, pts, half_win=3, max_iter=30, eps=0.01):
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        h, w = im.shape
+        p = np.array(pts, dtype=np.float32, copy=True).reshape(-1, 2)
+        if p.shape[0]:
+            L.check(self.lib.ov2_corner_subpix(self.ctx.h, _ptr(im), w, h, w, _ptr(p), p.shape[0], half_win, max_iter, eps))
+        return p

@@ -1,0 +1,47 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol the header declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "ov2slam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ov2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ov2slam_amd
+    from ov2slam_amd import _lib
+    lib = ov2slam_amd.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libov2slam_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+    assert lib.ov2_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product path must fail loudly, not compute on the CPU."""
+    import ov2slam_amd
+    try:
+        ctx = ov2slam_amd.Context(0)
+    except ov2slam_amd.Ov2Error as e:
+        assert e.code == -5          # OV2_ENODEVICE
+        return
+    ctx.close()                       # a GPU is present: nothing to check here
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "ov2slam_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "liboracle" not in txt and "ov2_oracle.h" not in txt and "orc_" not in txt, os.path.join(dp, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
