@@ -123,3 +123,63 @@ def fb_klt(prev, cur, win, nbpyrlvl, ferr, fbdist, kps, priors, max_iter=30, eps
                           C.byref(it), C.byref(vis), nthreads)
     assert rc == 0, rc
     return pr, status.astype(bool), (it.value, vis.value)
+
+
+# ---------------------------------------------------------------- detection
+def fast9_16(img, threshold, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+    n = lib().orc_fast9_16(_p(img), w, h, w, int(threshold), int(nonmax), _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def circle_fill0(mask, cx, cy, r):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w = mask.shape
+    lib().orc_circle_fill0(_p(mask), w, h, int(cx), int(cy), int(r))
+    return mask
+
+
+def cell_mineig(img, x0, y0, cell):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    hmap = np.zeros((cell, cell), np.float32)
+    lib().orc_cell_mineig(_p(img), w, h, w, int(x0), int(y0), int(cell), _p(hmap))
+    return hmap
+
+
+def corner_subpix(img, pts, half_win=3, max_iter=30, eps=0.01):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    p = np.array(pts, np.float32, copy=True).reshape(-1, 2)
+    lib().orc_corner_subpix(_p(img), w, h, w, _p(p), p.shape[0], int(half_win), int(max_iter), C.c_double(eps))
+    return p
+
+
+def detect_grid_fast(img, cell, cur_kps, fast_th, mask_mode=MASK_AS_EXECUTED, subpix=True):
+    """returns (points (n,2) float32, new fast threshold)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cur = np.ascontiguousarray(cur_kps, np.float32).reshape(-1, 2)
+    out = np.zeros((max(1, (w // cell) * (h // cell)), 2), np.float32)
+    n = C.c_int(0); th = C.c_int(int(fast_th))
+    rc = lib().orc_detect_grid_fast(_p(img), w, h, w, int(cell), _p(cur), cur.shape[0], C.byref(th), int(mask_mode),
+                                    int(bool(subpix)), _p(out), C.byref(n))
+    assert rc == 0, rc
+    return out[:n.value].copy(), th.value
+
+
+def detect_singlescale(img, cell, cur_kps, roi, quality, subpix=True):
+    """returns (points (n,2) float32, new dmaxquality)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cur = np.ascontiguousarray(cur_kps, np.float32).reshape(-1, 2)
+    out = np.zeros((max(1, 2 * (w // cell) * (h // cell)), 2), np.float32)
+    n = C.c_int(0); q = C.c_double(float(quality))
+    roi_a = (C.c_int * 4)(*[int(v) for v in roi])
+    rc = lib().orc_detect_singlescale(_p(img), w, h, w, int(cell), _p(cur), cur.shape[0], roi_a, C.byref(q),
+                                      int(bool(subpix)), _p(out), C.byref(n))
+    assert rc == 0, rc
+    return out[:n.value].copy(), q.value

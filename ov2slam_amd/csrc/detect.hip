@@ -1,0 +1,645 @@
+// detect.hip -- grid keypoint detection for gfx950.
+//
+// Replaces FeatureExtractor::detectGridFAST  (/root/reference/src/feature_extractor.cpp:443-570)
+//      and FeatureExtractor::detectSingleScale (/root/reference/src/feature_extractor.cpp:288-440)
+// including the OpenCV calls inside them (FAST-9/16 + NMS, GaussianBlur 3x3,
+// cornerMinEigenVal(3,3), minMaxLoc, circle(FILLED), cornerSubPix).
+//
+// Structure (per image):
+//   1. k_fast_cells / k_mineig_cells : one workgroup per grid cell, cell tile staged in LDS,
+//      produces the cell's response map (NMS'ed FAST score bytes / min-eigenvalue floats).
+//   2. k_grid_select : ONE workgroup.  The exclusion mask (the reference's CV_32F ones image with
+//      zeroed discs) lives in LDS as a bitmask.  The reference walks the cells serially and every
+//      accepted point zeroes a disc of radius cell/4 that can only reach the 8 neighbouring cells,
+//      so cell (r,c) depends on (r,c-1), (r-1,c-1), (r-1,c), (r-1,c+1) only: cells with equal
+//      2r+c are independent.  One wavefront per cell sweeps the anti-diagonals (2*rows+cols steps
+//      instead of rows*cols), giving bit-identical results to the serial raster order.
+//   3. k_corner_subpix : cv::cornerSubPix, one lane per point (<= 2 points per cell).
+#include "common.hpp"
+#include <float.h>
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+#define DET_MAX_CELL 64
+
+__device__ __forceinline__ int d_reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------
+// FAST-9/16 + score + 3x3 NMS on the cs x cs sub-image of every cell (cv::FAST semantics)
+// out: per cell cs*cs bytes, NMS-surviving corners hold their score (>0), everything else 0
+// ---------------------------------------------------------------------------------
+__constant__ int c_fast_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__constant__ int c_fast_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
+                                                    int cs, int nwcells, int threshold, uint8_t *__restrict__ nms_out)
+{
+    __shared__ uint8_t tile[DET_MAX_CELL * DET_MAX_CELL];
+    __shared__ uint8_t score[DET_MAX_CELL * DET_MAX_CELL];
+    const int cell = blockIdx.x;
+    const int x0 = (cell % nwcells) * cs, y0 = (cell / nwcells) * cs;
+    const int npx = cs * cs;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int ly = p / cs, lx = p - ly * cs;
+        tile[p] = img[(long long)(y0 + ly) * stride + x0 + lx];
+        score[p] = 0;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int ly = p / cs, lx = p - ly * cs;
+        if (ly < 3 || ly >= cs - 3 || lx < 3 || lx >= cs - 3) continue;
+        const int v = tile[p];
+        int ring[16];
+        unsigned dark = 0, bright = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            ring[k] = tile[p + c_fast_dy[k] * cs + c_fast_dx[k]];
+            dark |= (unsigned)(ring[k] < v - threshold) << k;
+            bright |= (unsigned)(ring[k] > v + threshold) << k;
+        }
+        unsigned md = dark | (dark << 16), mb = bright | (bright << 16);
+        unsigned rd = md, rb = mb;
+#pragma unroll
+        for (int i = 1; i <= 8; i++) { rd &= md >> i; rb &= mb >> i; }
+        if (((rd | rb) & 0xFFFFu) == 0) continue;
+        // cornerScore<16>
+        int d[25];
+#pragma unroll
+        for (int k = 0; k < 25; k++) d[k] = v - ring[k & 15];
+        int a0 = threshold;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            int a = min(d[k + 1], min(d[k + 2], d[k + 3]));
+            a = min(a, min(d[k + 4], min(d[k + 5], min(d[k + 6], min(d[k + 7], d[k + 8])))));
+            a0 = max(a0, min(a, d[k]));
+            a0 = max(a0, min(a, d[k + 9]));
+        }
+        int b0 = -a0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            int b = max(d[k + 1], max(d[k + 2], d[k + 3]));
+            b = max(b, max(d[k + 4], max(d[k + 5], max(d[k + 6], max(d[k + 7], d[k + 8])))));
+            b0 = min(b0, max(b, d[k]));
+            b0 = min(b0, max(b, d[k + 9]));
+        }
+        score[p] = (uint8_t)(-b0 - 1);
+    }
+    __syncthreads();
+    uint8_t *out = nms_out + (long long)cell * npx;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int ly = p / cs, lx = p - ly * cs;
+        int keep = 0;
+        const int s = score[p];
+        if (s > 0 && ly >= 3 && ly < cs - 3 && lx >= 3 && lx < cs - 3) {
+            keep = s > score[p - 1] && s > score[p + 1] && s > score[p - cs - 1] && s > score[p - cs] &&
+                   s > score[p - cs + 1] && s > score[p + cs - 1] && s > score[p + cs] && s > score[p + cs + 1];
+        }
+        out[p] = keep ? (uint8_t)s : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// min-eigenvalue response of every cell: GaussianBlur 3x3 (parent pixels, fixed point) ->
+// Sobel/3060 -> (dx^2, dxdy, dy^2) -> 3x3 box (double sums, sliding column) -> lambda_min
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
+                                                      int cs, int nwcells, float *__restrict__ hmap_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int npx = cs * cs;
+    // carve: rows (double 3*npx) | dxm (float npx) | dym (float npx) | cov (float 3*npx) | blur (u8 npx)
+    double *rows = (double *)smem;
+    float *dxm = (float *)(rows + 3 * npx);
+    float *dym = dxm + npx;
+    float *cov = dym + npx;
+    uint8_t *blur = (uint8_t *)(cov + 3 * npx);
+    const int cell = blockIdx.x;
+    const int x0 = (cell % nwcells) * cs, y0 = (cell / nwcells) * cs;
+
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int j = p / cs, i = p - j * cs;
+        int s = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const uint8_t *row = img + (long long)d_reflect101(y0 + j + dy, h) * stride;
+            const int wy = dy == 0 ? 2 : 1;
+            s += wy * ((int)row[d_reflect101(x0 + i - 1, w)] + 2 * (int)row[d_reflect101(x0 + i, w)] +
+                       (int)row[d_reflect101(x0 + i + 1, w)]);
+        }
+        blur[p] = (uint8_t)((s + 8) >> 4);
+    }
+    __syncthreads();
+    const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
+#define BL(yy, xx) ((int)blur[d_reflect101((yy), cs) * cs + d_reflect101((xx), cs)])
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int y = p / cs, x = p - y * cs;
+        const float r0 = (float)(BL(y - 1, x + 1) - BL(y - 1, x - 1));
+        const float r1 = (float)(BL(y, x + 1) - BL(y, x - 1));
+        const float r2 = (float)(BL(y + 1, x + 1) - BL(y + 1, x - 1));
+        dxm[p] = (r0 + r2) * f1 + r1 * f0;
+        const float s0 = (float)(BL(y - 1, x - 1) + 2 * BL(y - 1, x) + BL(y - 1, x + 1));
+        const float s2 = (float)(BL(y + 1, x - 1) + 2 * BL(y + 1, x) + BL(y + 1, x + 1));
+        dym[p] = (s2 - s0) * f1;
+    }
+#undef BL
+    __syncthreads();
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int y = p / cs, x = p - y * cs;
+        double s[3];
+#pragma unroll
+        for (int k = -1; k <= 1; k++) {
+            const int xx = d_reflect101(x + k, cs);
+            const float dx = dxm[y * cs + xx], dy = dym[y * cs + xx];
+            const float v0 = dx * dx, v1 = dx * dy, v2 = dy * dy;
+            if (k == -1) { s[0] = (double)v0; s[1] = (double)v1; s[2] = (double)v2; }
+            else { s[0] = s[0] + (double)v0; s[1] = s[1] + (double)v1; s[2] = s[2] + (double)v2; }
+        }
+        rows[3 * p] = s[0]; rows[3 * p + 1] = s[1]; rows[3 * p + 2] = s[2];
+    }
+    __syncthreads();
+    // sliding column sums, one lane per (column, channel), exactly ColumnSum's recurrence
+    for (int t = threadIdx.x; t < cs * 3; t += blockDim.x) {
+        const int x = t / 3, ch = t - x * 3;
+        double SUM = 0;
+        SUM += rows[(d_reflect101(-1, cs) * cs + x) * 3 + ch];
+        SUM += rows[(0 * cs + x) * 3 + ch];
+        for (int y = 0; y < cs; y++) {
+            const double s0 = SUM + rows[(d_reflect101(y + 1, cs) * cs + x) * 3 + ch];
+            cov[(y * cs + x) * 3 + ch] = (float)s0;
+            SUM = s0 - rows[(d_reflect101(y - 1, cs) * cs + x) * 3 + ch];
+        }
+    }
+    __syncthreads();
+    float *out = hmap_out + (long long)cell * npx;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const float a = cov[3 * p] * 0.5f, b = cov[3 * p + 1], c = cov[3 * p + 2] * 0.5f;
+        out[p] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// selection sweep
+// ---------------------------------------------------------------------------------
+struct SelectParams {
+    int w, h, cs, nwcells, nhcells, radius, mask_words_per_row;
+    int mode;            // 0 = FAST, 1 = single scale
+    int mask_mode;       // OV2_MASK_AS_EXECUTED / OV2_MASK_INTENDED (FAST only)
+    int ncur;
+    int roi_x, roi_y, roi_w, roi_h;
+    double quality;
+};
+
+struct SelectOut {
+    int n;               // points written to out_xy
+    int nboccup, nbempty, nbkps;
+};
+
+__device__ __forceinline__ void mask_clear_span(unsigned *mask, int wpr, int y, int xa, int xb)
+{
+    // clear bits [xa, xb] of row y (already clipped, xa <= xb)
+    unsigned *row = mask + y * wpr;
+    const int wa = xa >> 5, wb = xb >> 5;
+    for (int wd = wa; wd <= wb; wd++) {
+        const int lo = wd == wa ? (xa & 31) : 0, hi = wd == wb ? (xb & 31) : 31;
+        const unsigned bits = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        atomicAnd(&row[wd], ~bits);
+    }
+}
+
+// cv::circle(mask, (cx,cy), R, 0, FILLED) using the precomputed midpoint half-widths hw[0..R];
+// `lane`/`nlanes` cooperate over the 2R+1 scan lines.
+__device__ __forceinline__ void mask_draw_circle(unsigned *mask, const SelectParams &P, const int *hw,
+                                                 int cx, int cy, int lane, int nlanes)
+{
+    for (int k = lane - P.radius; k <= P.radius; k += nlanes) {
+        const int y = cy + k;
+        if (y < 0 || y >= P.h) continue;
+        const int half = hw[k < 0 ? -k : k];
+        if (half < 0) continue;
+        int xa = cx - half, xb = cx + half;
+        if (xa >= P.w || xb < 0) continue;
+        xa = xa < 0 ? 0 : xa; xb = xb > P.w - 1 ? P.w - 1 : xb;
+        mask_clear_span(mask, P.mask_words_per_row, y, xa, xb);
+    }
+}
+
+__device__ __forceinline__ int mask_test(const unsigned *mask, int wpr, int x, int y)
+{
+    return (mask[y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+}
+
+// wave-wide arg-max of (value, smaller index wins ties); all 64 lanes participate
+__device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
+                                                      const uint8_t *__restrict__ nms_maps,
+                                                      const float *__restrict__ hmaps,
+                                                      float2 *__restrict__ out_xy, SelectOut *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned *mask = (unsigned *)smem;                                   // h * wpr words
+    const int mask_words = P.h * P.mask_words_per_row;
+    int *hw = (int *)(mask + mask_words);                                // radius+1 (padded to 64)
+    uint8_t *occ = (uint8_t *)(hw + 64);                                 // (nh+1)*(nw+1)
+    const int nocc = (P.nhcells + 1) * (P.nwcells + 1);
+    const int ncells = P.nhcells * P.nwcells;
+    // per-cell results (cell order): prim/sec as packed (x | y << 16), -1 = none
+    int *prim = (int *)(occ + ((nocc + 3) & ~3));
+    int *sec = prim + ncells;
+
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+
+    for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
+    for (int i = tid; i < ncells; i += nthreads) { prim[i] = -1; sec[i] = -1; }
+    if (tid == 0) {
+        // midpoint circle half-widths (drawing.cpp Circle()): rows +-dy get dx, rows +-dx get dy
+        for (int k = 0; k < 64; k++) hw[k] = -1;
+        int err = 0, dx = P.radius, dy = 0, plus = 1, minus = (P.radius << 1) - 1;
+        while (dx >= dy) {
+            if (dx > hw[dy]) hw[dy] = dx;
+            if (dy > hw[dx]) hw[dx] = dy;
+            dy++; err += plus; plus += 2;
+            const int m = (err <= 0) - 1;
+            err -= minus & m; dx += m; minus -= m & 2;
+        }
+    }
+    __syncthreads();
+    // prologue (:296-319 / :451-474): occupancy + exclusion discs of the current keypoints
+    for (int i = tid; i < P.ncur; i += nthreads) {
+        const float2 p = cur_xy[i];
+        const int r = (int)(p.y / (float)P.cs), c = (int)(p.x / (float)P.cs);
+        if (r >= 0 && r <= P.nhcells && c >= 0 && c <= P.nwcells) occ[r * (P.nwcells + 1) + c] = 1;
+    }
+    for (int i = wave; i < P.ncur; i += nwaves) {
+        const float2 p = cur_xy[i];
+        mask_draw_circle(mask, P, hw, __float2int_rn(p.x), __float2int_rn(p.y), lane, 64);
+    }
+    __syncthreads();
+
+    const int npx = P.cs * P.cs;
+    const int nsteps = 2 * (P.nhcells - 1) + P.nwcells;
+    for (int t = 0; t < nsteps; t++) {
+        // cells on this anti-diagonal: (r, c = t - 2r)
+        for (int r = wave; r < P.nhcells; r += nwaves) {
+            const int c = t - 2 * r;
+            if (c < 0 || c >= P.nwcells) continue;                       // wave-uniform
+            const int cell = r * P.nwcells + c;
+            if (occ[r * (P.nwcells + 1) + c]) continue;
+            const int x0 = c * P.cs, y0 = r * P.cs;
+            if (!(x0 + P.cs < P.w - 1 && y0 + P.cs < P.h - 1)) continue;  // :350 / :510
+            if (P.mode == 0) {
+                // best response among the mask-surviving FAST corners, raster order on ties
+                const uint8_t *m = nms_maps + (long long)cell * npx;
+                float bv = -1.f; int bi = 0x7FFFFFFF;
+                for (int p = lane; p < npx; p += 64) {
+                    const int s = m[p];
+                    if (!s) continue;
+                    const int ly = p / P.cs, lx = p - ly * P.cs;
+                    int keep;
+                    if (P.mask_mode == OV2_MASK_AS_EXECUTED)
+                        keep = ((lx & 3) >= 2) && mask_test(mask, P.mask_words_per_row, x0 + (lx >> 2), y0 + ly);
+                    else
+                        keep = mask_test(mask, P.mask_words_per_row, x0 + lx, y0 + ly);
+                    if (keep && ((float)s > bv)) { bv = (float)s; bi = p; }   // p increases per lane: first max kept
+                }
+                wave_argmax_f(bv, bi);
+                if (bv >= 20.f) {                                         // :521
+                    const int ly = bi / P.cs, lx = bi - ly * P.cs;
+                    const int px = x0 + lx, py = y0 + ly;
+                    if (lane == 0) prim[cell] = px | (py << 16);
+                    mask_draw_circle(mask, P, hw, px, py, lane, 64);      // :527
+                }
+            } else {
+                const float *hm = hmaps + (long long)cell * npx;
+                bool stop = false;
+                for (int pass = 0; pass < 2 && !stop; pass++) {
+                    float bv = -FLT_MAX; int bi = 0;                      // minMaxLoc: first maximum, row-major
+                    bool any = false;
+                    for (int p = lane; p < npx; p += 64) {
+                        const int ly = p / P.cs, lx = p - ly * P.cs;
+                        const float v = hm[p] * (mask_test(mask, P.mask_words_per_row, x0 + lx, y0 + ly) ? 1.f : 0.f);
+                        if (!any || v > bv) { bv = v; bi = p; any = true; }
+                    }
+                    if (!any) { bv = -FLT_MAX; bi = 0x7FFFFFFF; }
+                    wave_argmax_f(bv, bi);
+                    const int ly = bi / P.cs, lx = bi - ly * P.cs;
+                    const int mx = x0 + lx, my = y0 + ly;
+                    if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) {
+                        stop = true;                                      // `continue` at :363-368 / :379-384
+                    } else if ((double)bv >= P.quality) {
+                        if (lane == 0) { if (pass == 0) prim[cell] = mx | (my << 16); else sec[cell] = mx | (my << 16); }
+                        mask_draw_circle(mask, P, hw, mx, my, lane, 64);
+                        // make the disc visible to this wave's second pass
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // compaction in cell order by one thread (<= a few hundred cells)
+    if (tid == 0) {
+        int n = 0, nboccup = 0, nbempty = 0;
+        for (int i = 0; i < ncells; i++) {
+            const int r = i / P.nwcells, c = i - r * P.nwcells;
+            if (occ[r * (P.nwcells + 1) + c]) nboccup++; else nbempty++;
+            if (prim[i] >= 0) { out_xy[n] = make_float2((float)(prim[i] & 0xFFFF), (float)(prim[i] >> 16)); n++; }
+        }
+        const int nbprim = n;
+        if (P.mode == 1 && nbprim + nboccup < ncells) {                    // :400-414
+            const int nbsec = ncells - (nbprim + nboccup);
+            int k = 0;
+            for (int i = 0; i < ncells && k < nbsec; i++)
+                if (sec[i] >= 0) { out_xy[n] = make_float2((float)(sec[i] & 0xFFFF), (float)(sec[i] >> 16)); n++; k++; }
+        }
+        out->n = n; out->nboccup = nboccup; out->nbempty = nbempty; out->nbkps = nbprim;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// cv::cornerSubPix (imgproc/src/cornersubpix.cpp), one lane per point
+// ---------------------------------------------------------------------------------
+#define SP_MAX_HALF 5
+struct SubpixParams {
+    int w, h, stride, n, half_win, max_iters;
+    double eps2;
+    float e[2 * SP_MAX_HALF + 1];       // exp(-((i-hw)/hw)^2) computed by the host libm (like the reference)
+};
+
+// getRectSubPix(u8 -> f32), patch pw x ph around (cx, cy)  (imgproc/src/samplers.cpp)
+template <int PW>
+__device__ void d_get_rect_subpix(const uint8_t *__restrict__ src, int src_step, int sw, int sh,
+                                  float *dst, float cx_f, float cy_f)
+{
+    const int pw = PW, ph = PW;
+    const double cxd = (double)cx_f - (pw - 1) * 0.5, cyd = (double)cy_f - (ph - 1) * 0.5;
+    int ipx = (int)floor(cxd), ipy = (int)floor(cyd);
+    if (0 <= ipx && ipx + pw < sw && 0 <= ipy && ipy + ph < sh) {
+        float a = (float)(cxd - ipx), b = (float)(cyd - ipy);
+        a = a > 0.0001f ? a : 0.0001f;
+        const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+        const double s = (1. - (double)a) / (double)a;
+        const uint8_t *p = src + (long long)ipy * src_step + ipx;
+        for (int i = 0; i < ph; i++, p += src_step, dst += pw) {
+            float prev = (1 - a) * (b1 * p[0] + b2 * p[src_step]);
+            for (int j = 0; j < pw; j++) {
+                const float t = a12 * p[j + 1] + a22 * p[j + 1 + src_step];
+                dst[j] = prev + t;
+                prev = (float)(t * s);
+            }
+        }
+        return;
+    }
+    const float cx = cx_f - (pw - 1) * 0.5f, cy = cy_f - (ph - 1) * 0.5f;
+    ipx = (int)floorf(cx); ipy = (int)floorf(cy);
+    const float a = cx - ipx, b = cy - ipy;
+    const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+    const float b1 = 1.f - b, b2 = b;
+    if (0 <= ipx && ipx < sw - pw && 0 <= ipy && ipy < sh - ph) {
+        const uint8_t *p = src + (long long)ipy * src_step + ipx;
+        for (int i = 0; i < ph; i++, p += src_step, dst += pw)
+            for (int j = 0; j < pw; j++)
+                dst[j] = p[j] * a11 + p[j + 1] * a12 + p[j + src_step] * a21 + p[j + src_step + 1] * a22;
+        return;
+    }
+    int rx, ry, rw, rh;
+    const uint8_t *p = src;
+    if (ipx >= 0) { p += ipx; rx = 0; }
+    else { rx = -ipx; if (rx > pw) rx = pw; }
+    if (ipx < sw - pw) rw = pw;
+    else { rw = sw - ipx - 1; if (rw < 0) { p += rw; rw = 0; } }
+    if (ipy >= 0) { p += (long long)ipy * src_step; ry = 0; }
+    else ry = -ipy;
+    if (ipy < sh - ph) rh = ph;
+    else { rh = sh - ipy - 1; if (rh < 0) { p += (long long)rh * src_step; rh = 0; } }
+    p -= rx;
+    for (int i = 0; i < ph; i++, dst += pw) {
+        const uint8_t *p2 = p + src_step;
+        if (i < ry || i >= rh) p2 -= src_step;
+        float s0 = p[rx] * b1 + p2[rx] * b2;
+        for (int j = 0; j < rx; j++) dst[j] = s0;
+        for (int j = rx; j < rw; j++) dst[j] = p[j] * a11 + p[j + 1] * a12 + p2[j] * a21 + p2[j + 1] * a22;
+        s0 = p[rw] * b1 + p2[rw] * b2;
+        for (int j = rw; j < pw; j++) dst[j] = s0;
+        if (i < rh) p = p2;
+    }
+}
+
+template <int HALF>
+__global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint8_t *__restrict__ img, float2 *__restrict__ xy)
+{
+    constexpr int WINW = 2 * HALF + 1, SW = WINW + 2;
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= P.n) return;
+    float sub[SW * SW];
+    const float2 cT = xy[pt];
+    float cIx = cT.x, cIy = cT.y;
+    int iter = 0;
+    double err = 0;
+    do {
+        double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+        d_get_rect_subpix<SW>(img, P.stride, P.w, P.h, sub, cIx, cIy);
+        for (int i = 0; i < WINW; i++) {
+            const float *sp = sub + (i + 1) * SW + 1;
+            const double py = i - HALF;
+            for (int j = 0; j < WINW; j++) {
+                const double m = (double)(float)(P.e[i] * P.e[j]);
+                const double tgx = sp[j + 1] - sp[j - 1];
+                const double tgy = sp[j + SW] - sp[j - SW];
+                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                const double px = j - HALF;
+                a += gxx; b += gxy; c += gyy;
+                bb1 += gxx * px + gxy * py;
+                bb2 += gxy * px + gyy * py;
+            }
+        }
+        const double det = a * c - b * b;
+        if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
+        const double scale = 1.0 / det;
+        const float c2x = (float)(cIx + c * scale * bb1 - b * scale * bb2);
+        const float c2y = (float)(cIy - b * scale * bb1 + a * scale * bb2);
+        err = (double)((c2x - cIx) * (c2x - cIx) + (c2y - cIy) * (c2y - cIy));
+        cIx = c2x; cIy = c2y;
+        if (cIx < 0 || cIx >= P.w || cIy < 0 || cIy >= P.h) break;
+    } while (++iter < P.max_iters && err > P.eps2);
+    if (fabs((double)(cIx - cT.x)) > HALF || fabs((double)(cIy - cT.y)) > HALF) { cIx = cT.x; cIy = cT.y; }
+    xy[pt] = make_float2(cIx, cIy);
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int stride, float2 *xy_d, int n,
+                         int half_win, int max_iter, double eps)
+{
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(half_win >= 1 && half_win <= SP_MAX_HALF, OV2_EUNSUPPORTED, "cornerSubPix half window must be in [1,5]");
+    OV2_REQUIRE(w >= half_win * 2 + 5 && h >= half_win * 2 + 5, OV2_EINVAL, "image too small for cornerSubPix");
+    SubpixParams P;
+    P.w = w; P.h = h; P.stride = stride; P.n = n; P.half_win = half_win;
+    P.max_iters = max_iter < 1 ? 1 : (max_iter > 100 ? 100 : max_iter);
+    if (eps < 0.) eps = 0.;
+    P.eps2 = eps * eps;
+    for (int i = 0; i < 2 * half_win + 1; i++) {
+        const float x = (float)(i - half_win) / half_win;
+        P.e[i] = expf(-x * x);
+    }
+    dim3 grid((n + 63) / 64), block(64);
+    switch (half_win) {
+    case 1: hipLaunchKernelGGL(k_corner_subpix<1>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
+    case 2: hipLaunchKernelGGL(k_corner_subpix<2>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
+    case 3: hipLaunchKernelGGL(k_corner_subpix<3>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
+    case 4: hipLaunchKernelGGL(k_corner_subpix<4>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
+    default: hipLaunchKernelGGL(k_corner_subpix<5>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
+    }
+    OV2_HIP_CHECK(hipGetLastError());
+    return OV2_OK;
+}
+
+static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, int h, int stride, int cell,
+                         const float *cur_xy_h, int ncur, int fast_th, int mask_mode, const int roi[4], double quality,
+                         int do_subpix, float *out_xy_h, int *out_n, SelectOut *so_h)
+{
+    OV2_REQUIRE(ctx && out_xy_h && out_n, OV2_EINVAL, "NULL argument");
+    *out_n = 0;
+    memset(so_h, 0, sizeof(*so_h));
+    if (!img_h || w <= 0 || h <= 0) return OV2_OK;            // empty image -> empty vector (:291-294 / :446-449)
+    OV2_REQUIRE(stride >= w, OV2_EINVAL, "stride < width");
+    OV2_REQUIRE(cell >= 8 && cell <= DET_MAX_CELL, OV2_EUNSUPPORTED, "cell size must be in [8,64]");
+    OV2_REQUIRE(ncur >= 0 && (ncur == 0 || cur_xy_h), OV2_EINVAL, "bad current keypoints");
+    OV2_REQUIRE(w < 65536 && h < 32768, OV2_EUNSUPPORTED, "image too large");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nw = w / cell, nh = h / cell, ncells = nw * nh;
+    if (ncells == 0) return OV2_OK;
+    const int npx = cell * cell;
+    const int wpr = (w + 31) / 32;
+    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
+    OV2_REQUIRE(sel_lds <= 160 * 1024, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask");
+
+    // device scratch: [img w*h][maps][cur 8*ncur][out 8*2*ncells][SelectOut]
+    const size_t o_img = 0;
+    const size_t map_bytes = (size_t)ncells * npx * (mode == 0 ? 1 : 4);
+    const size_t o_map = ((size_t)w * h + 255) & ~(size_t)255;
+    const size_t o_cur = (o_map + map_bytes + 255) & ~(size_t)255;
+    const size_t o_out = (o_cur + 8 * (size_t)(ncur > 0 ? ncur : 1) + 255) & ~(size_t)255;
+    const size_t o_so = o_out + 16 * (size_t)ncells;
+    const size_t total = o_so + sizeof(SelectOut);
+    int rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(16 * (size_t)ncells + sizeof(SelectOut)); if (rc) return rc;
+    uint8_t *ds = (uint8_t *)ctx->d_scratch;
+    OV2_HIP_CHECK(hipMemcpy2DAsync(ds + o_img, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    if (ncur > 0) OV2_HIP_CHECK(hipMemcpyAsync(ds + o_cur, cur_xy_h, 8 * (size_t)ncur, hipMemcpyHostToDevice, ctx->stream));
+
+    if (mode == 0) {
+        int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
+        hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, ds + o_img, w, h, w, cell, nw, th, ds + o_map);
+    } else {
+        const size_t lds = (size_t)npx * (3 * 8 + 4 + 4 + 3 * 4 + 1) + 16;
+        OV2_REQUIRE(lds <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 58)");
+        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_mineig_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, ds + o_img, w, h, w, cell, nw, (float *)(ds + o_map));
+    }
+    SelectParams P;
+    P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
+    P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
+    P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
+    P.quality = quality;
+    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+    hipLaunchKernelGGL(k_grid_select, dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),
+                       (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so));
+    OV2_HIP_CHECK(hipGetLastError());
+    // the count is needed on the host to size the sub-pixel launch
+    uint8_t *hs = (uint8_t *)ctx->h_scratch;
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + 16 * (size_t)ncells, ds + o_so, sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(so_h, hs + 16 * (size_t)ncells, sizeof(SelectOut));
+    const int n = so_h->n;
+    if (n > 0) {
+        if (do_subpix) {
+            rc = launch_subpix(ctx, ds + o_img, w, h, w, (float2 *)(ds + o_out), n, 3, 30, 0.01);
+            if (rc) return rc;
+        }
+        OV2_HIP_CHECK(hipMemcpyAsync(hs, ds + o_out, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(out_xy_h, hs, 8 * (size_t)n);
+    }
+    *out_n = n;
+    return OV2_OK;
+}
+
+extern "C" {
+
+int ov2_detect_grid_fast(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride, int cell,
+                         const float *cur_xy_h, int ncur, int *fast_th_inout, int mask_mode,
+                         int do_subpix, float *out_xy_h, int *out_n)
+{
+    OV2_REQUIRE(fast_th_inout != nullptr, OV2_EINVAL, "fast_th_inout == NULL");
+    OV2_REQUIRE(mask_mode == OV2_MASK_AS_EXECUTED || mask_mode == OV2_MASK_INTENDED, OV2_EINVAL, "bad mask_mode");
+    SelectOut so;
+    const int th = *fast_th_inout;
+    const int rc = detect_common(ctx, 0, img_h, w, h, stride, cell, cur_xy_h, ncur, th, mask_mode, nullptr, 0.0,
+                                 do_subpix, out_xy_h, out_n, &so);
+    if (rc != OV2_OK) return rc;
+    if (!img_h || w <= 0 || h <= 0) return OV2_OK;
+    // threshold adaptation (:546-552), int *= double truncates
+    if ((double)so.nbkps < 0.5 * (double)so.nbempty && so.nbempty > 10) *fast_th_inout = (int)(th * 0.66);
+    else if (so.nbkps == so.nbempty) *fast_th_inout = (int)(th * 1.5);
+    return OV2_OK;
+}
+
+int ov2_detect_singlescale(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride, int cell,
+                           const float *cur_xy_h, int ncur, const int roi[4], double *quality_inout,
+                           int do_subpix, float *out_xy_h, int *out_n)
+{
+    OV2_REQUIRE(quality_inout != nullptr && roi != nullptr, OV2_EINVAL, "quality_inout / roi == NULL");
+    SelectOut so;
+    const double q = *quality_inout;
+    const int rc = detect_common(ctx, 1, img_h, w, h, stride, cell, cur_xy_h, ncur, 0, 0, roi, q,
+                                 do_subpix, out_xy_h, out_n, &so);
+    if (rc != OV2_OK) return rc;
+    if (!img_h || w <= 0 || h <= 0) return OV2_OK;
+    // :418-423 (nbkps there is the size after the secondary top-up)
+    const int ncells = (w / cell) * (h / cell);
+    if ((double)so.n < 0.33 * (double)(ncells - so.nboccup)) *quality_inout = q / 2.;
+    else if ((double)so.n > 0.9 * (double)(ncells - so.nboccup)) *quality_inout = q * 1.5;
+    return OV2_OK;
+}
+
+int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride,
+                      float *xy_inout_h, int n, int half_win, int max_iter, double eps)
+{
+    OV2_REQUIRE(ctx && img_h && w > 0 && h > 0 && stride >= w, OV2_EINVAL, "bad image");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(xy_inout_h != nullptr, OV2_EINVAL, "xy == NULL");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t o_xy = ((size_t)w * h + 255) & ~(size_t)255;
+    int rc = ctx->reserve_device(o_xy + 8 * (size_t)n); if (rc) return rc;
+    uint8_t *ds = (uint8_t *)ctx->d_scratch;
+    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    OV2_HIP_CHECK(hipMemcpyAsync(ds + o_xy, xy_inout_h, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_subpix(ctx, ds, w, h, w, (float2 *)(ds + o_xy), n, half_win, max_iter, eps);
+    if (rc) return rc;
+    OV2_HIP_CHECK(hipMemcpyAsync(xy_inout_h, ds + o_xy, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OV2_OK;
+}
+
+} // extern "C"

@@ -244,51 +244,62 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
     const int n = n_per_item ? n_per_item[b] : prm.n_max;
     const int r = threadIdx.x & 15;
     const int i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    if (i >= n) return;                                  // whole 16-lane rows exit together
-    const long long gi = (long long)b * prm.n_max + i;
-    const uint8_t *itemP = P.base + (long long)b * P.item_stride;
-    const uint8_t *itemC = C.base + (long long)b * C.item_stride;
+    __shared__ unsigned int s_stats[2];
+    if (stats) {                                         // uniform branch (kernel argument)
+        if (threadIdx.x < 2) s_stats[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    if (i < n) {                                         // whole 16-lane rows take the same side
+        const long long gi = (long long)b * prm.n_max + i;
+        const uint8_t *itemP = P.base + (long long)b * P.item_stride;
+        const uint8_t *itemC = C.base + (long long)b * C.item_stride;
 
-    const float2 kp = kps[gi];
-    const float2 pr = priors[gi];
-    LKPointState st;
-    st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
+        const float2 kp = kps[gi];
+        const float2 pr = priors[gi];
+        LKPointState st;
+        st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
 
-    // forward: prev -> cur, levels max_level..0   (feature_tracker.cpp:66-69)
-    for (int level = prm.max_level; level >= 0; level--)
-        lk_level<WIN>(itemP, P.lv[level], itemC, C.lv[level], prm, level, prm.max_level,
-                      (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, r, st);
+        // forward: prev -> cur, levels max_level..0   (feature_tracker.cpp:66-69)
+        for (int level = prm.max_level; level >= 0; level--)
+            lk_level<WIN>(itemP, P.lv[level], itemC, C.lv[level], prm, level, prm.max_level,
+                          (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, r, st);
 
-    const float fx = st.nx, fy = st.ny;
-    int ok = st.status;
-    if (prm.do_fb) {
-        // feature_tracker.cpp:79-101
-        if (ok && st.err > prm.err_th) ok = 0;
-        const float W0 = (float)C.lv[0].w, H0 = (float)C.lv[0].h;
-        if (ok && !(1.f <= fx && fx < W0 - 1.f && 1.f <= fy && fy < H0 - 1.f)) ok = 0;   // inBorder :216-221
-        if (ok) {
-            // backward: cur -> prev at level 0, initial guess = original keypoint (:113-116)
-            LKPointState sb;
-            sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0; sb.visits = 0;
-            lk_level<WIN>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
-            st.iters += sb.iters; st.visits += sb.visits;
-            if (!sb.status) ok = 0;
-            else {
-                const float ddx = kp.x - sb.nx, ddy = kp.y - sb.ny;      // cv::norm(Point2f) (:128)
-                const double nrm = sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
-                if (nrm > (double)prm.fb_dist) ok = 0;
+        const float fx = st.nx, fy = st.ny;
+        int ok = st.status;
+        if (prm.do_fb) {
+            // feature_tracker.cpp:79-101
+            if (ok && st.err > prm.err_th) ok = 0;
+            const float W0 = (float)C.lv[0].w, H0 = (float)C.lv[0].h;
+            if (ok && !(1.f <= fx && fx < W0 - 1.f && 1.f <= fy && fy < H0 - 1.f)) ok = 0;   // inBorder :216-221
+            if (ok) {
+                // backward: cur -> prev at level 0, initial guess = original keypoint (:113-116)
+                LKPointState sb;
+                sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0; sb.visits = 0;
+                lk_level<WIN>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
+                st.iters += sb.iters; st.visits += sb.visits;
+                if (!sb.status) ok = 0;
+                else {
+                    const float ddx = kp.x - sb.nx, ddy = kp.y - sb.ny;      // cv::norm(Point2f) (:128)
+                    const double nrm = sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                    if (nrm > (double)prm.fb_dist) ok = 0;
+                }
+            }
+        }
+        if (r == 0) {
+            priors[gi] = make_float2(fx, fy);
+            status[gi] = (uint8_t)ok;
+            if (err_out) err_out[gi] = st.err;
+            if (iters_out) iters_out[gi] = st.iters;
+            if (stats) {                                 // workgroup-level pre-reduction in LDS
+                atomicAdd(&s_stats[0], (unsigned int)st.iters);
+                atomicAdd(&s_stats[1], (unsigned int)st.visits);
             }
         }
     }
-    if (r == 0) {
-        priors[gi] = make_float2(fx, fy);
-        status[gi] = (uint8_t)ok;
-        if (err_out) err_out[gi] = st.err;
-        if (iters_out) iters_out[gi] = st.iters;
-        if (stats) {
-            atomicAdd((unsigned long long *)&stats[0], (unsigned long long)st.iters);
-            atomicAdd((unsigned long long *)&stats[1], (unsigned long long)st.visits);
-        }
+    if (stats) {
+        __syncthreads();
+        if (threadIdx.x < 2 && s_stats[threadIdx.x])
+            atomicAdd((unsigned long long *)&stats[threadIdx.x], (unsigned long long)s_stats[threadIdx.x]);
     }
 }
 

@@ -2,12 +2,6 @@
 // written yet.  They fail loudly (OV2_EUNSUPPORTED); there is no CPU fallback.
 #include "common.hpp"
 extern "C" {
-int ov2_detect_grid_fast(ov2_ctx *, const uint8_t *, int, int, int, int, const float *, int, int *, int, int, float *, int *)
-{ ov2_set_error("ov2_detect_grid_fast: not implemented yet"); return OV2_EUNSUPPORTED; }
-int ov2_detect_singlescale(ov2_ctx *, const uint8_t *, int, int, int, int, const float *, int, const int *, double *, int, float *, int *)
-{ ov2_set_error("ov2_detect_singlescale: not implemented yet"); return OV2_EUNSUPPORTED; }
-int ov2_corner_subpix(ov2_ctx *, const uint8_t *, int, int, int, float *, int, int, int, double)
-{ ov2_set_error("ov2_corner_subpix: not implemented yet"); return OV2_EUNSUPPORTED; }
 void ov2_ba_default_options(ov2_ba_options *o)
 {
     if (!o) return;

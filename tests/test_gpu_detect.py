@@ -1,0 +1,119 @@
+"""GPU parity tests (through the C ABI) of the HIP grid detectors against the oracle.
+Bar: keypoint sets bit-exact (integer pixel coordinates) and sub-pixel coordinates bit-exact
+(float32 bits), adaptive thresholds identical."""
+import numpy as np
+import pytest
+
+import ov2slam_amd
+from ov2slam_amd import synth
+from ov2slam_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _images():
+    out = []
+    a, _, _ = synth.frame_pair(752, 480, seed=8)
+    out.append(("euroc", a))
+    b, _, _ = synth.frame_pair(1241, 376, seed=13)
+    out.append(("kitti", b))
+    rng = np.random.default_rng(3)
+    out.append(("noise", rng.integers(0, 256, (480, 752), dtype=np.uint8)))
+    return out
+
+
+IMAGES = _images()
+
+
+@pytest.mark.parametrize("name", [n for n, _ in IMAGES])
+@pytest.mark.parametrize("cell", [50, 35])
+@pytest.mark.parametrize("mode", [L.OV2_MASK_AS_EXECUTED, L.OV2_MASK_INTENDED])
+def test_grid_fast_bit_exact(gpu_ctx, oracle, name, cell, mode):
+    img = dict(IMAGES)[name]
+    rng = np.random.default_rng(17)
+    h, w = img.shape
+    cur = synth.grid_keypoints(w, h, cell, rng)[::3]                  # a third of the cells already occupied
+    for subpix in (False, True):
+        fx = ov2slam_amd.FeatureExtractor(gpu_ctx, nfast_th=10, mask_mode=mode)
+        g = fx.detectGridFAST(img, cell, cur, subpix=subpix)
+        r, rth = oracle.detect_grid_fast(img, cell, cur, 10, mode, subpix=subpix)
+        assert g.shape == r.shape, (g.shape, r.shape)
+        assert np.array_equal(_bits(g), _bits(r))
+        assert fx.nfast_th_ == rth
+    assert len(r) > 10
+
+
+@pytest.mark.parametrize("name", [n for n, _ in IMAGES])
+@pytest.mark.parametrize("cell", [35, 45])
+def test_singlescale_bit_exact(gpu_ctx, oracle, name, cell):
+    img = dict(IMAGES)[name]
+    h, w = img.shape
+    roi = (5, 5, w - 10, h - 10)                                      # camera_calibration.cpp:72-73
+    rng = np.random.default_rng(19)
+    for cur in (np.zeros((0, 2), np.float32), synth.grid_keypoints(w, h, cell, rng)[::2]):
+        for subpix in (False, True):
+            fx = ov2slam_amd.FeatureExtractor(gpu_ctx, dmaxquality=0.001)
+            g = fx.detectSingleScale(img, cell, cur, roi, subpix=subpix)
+            r, rq = oracle.detect_singlescale(img, cell, cur, roi, 0.001, subpix=subpix)
+            assert g.shape == r.shape, (g.shape, r.shape)
+            assert np.array_equal(_bits(g), _bits(r))
+            assert fx.dmaxquality_ == rq
+    assert len(r) > 10
+
+
+def test_threshold_adaptation_sequence(gpu_ctx, oracle):
+    """Run the detectors repeatedly like successive keyframes: the adaptive state must follow
+    the oracle step by step (nfast_th_: :546-552, dmaxquality_: :418-423)."""
+    img = dict(IMAGES)["euroc"]
+    fx = ov2slam_amd.FeatureExtractor(gpu_ctx, nfast_th=40, dmaxquality=0.02, mask_mode=L.OV2_MASK_INTENDED)
+    th, q = 40, 0.02
+    none = np.zeros((0, 2), np.float32)
+    for _ in range(5):
+        g = fx.detectGridFAST(img, 50, none, subpix=False)
+        r, th = oracle.detect_grid_fast(img, 50, none, th, L.OV2_MASK_INTENDED, subpix=False)
+        assert np.array_equal(g, r) and fx.nfast_th_ == th
+        g2 = fx.detectSingleScale(img, 35, none, (5, 5, 742, 470), subpix=False)
+        r2, q = oracle.detect_singlescale(img, 35, none, (5, 5, 742, 470), q, subpix=False)
+        assert np.array_equal(g2, r2) and fx.dmaxquality_ == q
+
+
+def test_detect_edge_cases(gpu_ctx, oracle):
+    fx = ov2slam_amd.FeatureExtractor(gpu_ctx)
+    # empty image -> empty result (:291-294 / :446-449)
+    assert fx.detectGridFAST(np.zeros((0, 0), np.uint8), 35, np.zeros((0, 2))).shape == (0, 2)
+    assert fx.detectSingleScale(np.zeros((0, 0), np.uint8), 35, np.zeros((0, 2)), (0, 0, 0, 0)).shape == (0, 2)
+    # flat image: nothing detected, thresholds decay like the oracle's
+    flat = np.full((480, 752), 128, np.uint8)
+    g = fx.detectGridFAST(flat, 50, np.zeros((0, 2)))
+    r, th = oracle.detect_grid_fast(flat, 50, np.zeros((0, 2), np.float32), 10)
+    assert len(g) == 0 and len(r) == 0 and fx.nfast_th_ == th
+    g = fx.detectSingleScale(flat, 35, np.zeros((0, 2)), (5, 5, 742, 470))
+    r, q = oracle.detect_singlescale(flat, 35, np.zeros((0, 2), np.float32), (5, 5, 742, 470), 0.001)
+    assert len(g) == 0 and len(r) == 0 and fx.dmaxquality_ == q
+    # every cell occupied
+    img = dict(IMAGES)["euroc"]
+    cur = synth.grid_keypoints(752, 480, 35, np.random.default_rng(0), jitter=0.1)
+    assert len(fx.detectSingleScale(img, 35, cur, (5, 5, 742, 470))) == 0
+    # image smaller than one cell row/col of slack: cells that fail the in-image test are skipped
+    small = np.ascontiguousarray(img[:71, :106])
+    fx2 = ov2slam_amd.FeatureExtractor(gpu_ctx)
+    g = fx2.detectSingleScale(small, 35, np.zeros((0, 2)), (5, 5, 96, 61), subpix=False)
+    r, _ = oracle.detect_singlescale(small, 35, np.zeros((0, 2), np.float32), (5, 5, 96, 61), 0.001, subpix=False)
+    assert np.array_equal(g, r)
+
+
+def test_corner_subpix_bit_exact_including_border(gpu_ctx, oracle):
+    img = dict(IMAGES)["euroc"]
+    rng = np.random.default_rng(23)
+    pts = np.stack([rng.uniform(0, 751, 600), rng.uniform(0, 479, 600)], 1).astype(np.float32)
+    pts[:40, 0] = rng.uniform(0, 6, 40); pts[40:80, 1] = rng.uniform(474, 479.9, 40)      # generic (border) sampler path
+    pts[80:120] = np.rint(pts[80:120])
+    fx = ov2slam_amd.FeatureExtractor(gpu_ctx)
+    g = fx.cornerSubPix(img, pts)
+    r = oracle.corner_subpix(img, pts)
+    assert np.array_equal(_bits(g), _bits(r))
+    assert np.abs(g - pts).max() <= 3.0 + 1e-6
