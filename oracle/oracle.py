@@ -183,3 +183,121 @@ def detect_singlescale(img, cell, cur_kps, roi, quality, subpix=True):
                                       int(bool(subpix)), _p(out), C.byref(n))
     assert rc == 0, rc
     return out[:n.value].copy(), q.value
+
+
+# ---------------------------------------------------------------- local BA
+class _BAProblem(C.Structure):
+    _fields_ = [
+        ("n_kf", C.c_int), ("poses", C.c_void_p), ("kf_const", C.c_void_p),
+        ("n_lm", C.c_int), ("invdepth", C.c_void_p), ("lm_anchor_kf", C.c_void_p), ("lm_anchor_uv", C.c_void_p),
+        ("n_res", C.c_int), ("res_type", C.c_void_p), ("res_kf", C.c_void_p), ("res_lm", C.c_void_p),
+        ("res_uv", C.c_void_p), ("res_sigma", C.c_void_p), ("res_active", C.c_void_p),
+        ("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7),
+    ]
+
+
+class BAOptions(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("huber_delta", C.c_double), ("initial_radius", C.c_double),
+        ("max_radius", C.c_double), ("min_radius", C.c_double), ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double), ("min_relative_decrease", C.c_double), ("jacobi_scaling", C.c_int),
+        ("max_consecutive_invalid_steps", C.c_int),
+    ]
+
+
+class _BAResult(C.Structure):
+    _fields_ = [
+        ("poses_out", C.c_void_p), ("invdepth_out", C.c_void_p), ("chi2_last_eval", C.c_void_p),
+        ("depthpos_last_eval", C.c_void_p), ("iterations", C.c_int), ("num_successful_steps", C.c_int),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("termination", C.c_int),
+    ]
+
+
+def ba_default_options(**kw):
+    o = BAOptions()
+    lib().orc_ba_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def ba_solve(prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None):
+    """prob: dict in the layout produced by ov2slam_amd.synth.make_ba_problem."""
+    opts = opts or ba_default_options()
+    keep = {}
+
+    def arr(name, dt):
+        a = np.ascontiguousarray(prob[name], dt)
+        keep[name] = a
+        return a.ctypes.data
+
+    P = _BAProblem()
+    P.n_kf, P.n_lm, P.n_res = int(prob["n_kf"]), int(prob["n_lm"]), int(prob["n_res"])
+    P.poses = arr("poses", np.float64); P.kf_const = arr("kf_const", np.uint8)
+    P.invdepth = arr("invdepth", np.float64); P.lm_anchor_kf = arr("lm_anchor_kf", np.int32)
+    P.lm_anchor_uv = arr("lm_anchor_uv", np.float64)
+    P.res_type = arr("res_type", np.uint8); P.res_kf = arr("res_kf", np.int32); P.res_lm = arr("res_lm", np.int32)
+    P.res_uv = arr("res_uv", np.float64); P.res_sigma = arr("res_sigma", np.float64)
+    if res_active is not None:
+        ra = np.ascontiguousarray(res_active, np.uint8); keep["ra"] = ra
+        P.res_active = ra.ctypes.data
+    for i in range(4):
+        P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
+    for i in range(7):
+        P.T_rl[i] = float(prob["T_rl"][i])
+    poses_out = np.zeros((P.n_kf, 7)); lam_out = np.zeros(P.n_lm)
+    chi2 = np.full(P.n_res, np.nan) if chi2_init is None else np.array(chi2_init, np.float64, copy=True)
+    dpos = np.zeros(P.n_res, np.uint8) if depthpos_init is None else np.array(depthpos_init, np.uint8, copy=True)
+    R = _BAResult()
+    R.poses_out = poses_out.ctypes.data; R.invdepth_out = lam_out.ctypes.data
+    R.chi2_last_eval = chi2.ctypes.data; R.depthpos_last_eval = dpos.ctypes.data
+    rc = lib().orc_ba_solve(C.byref(P), C.byref(opts), C.byref(R))
+    assert rc == 0, rc
+    return dict(poses=poses_out, invdepth=lam_out, chi2=chi2, depthpos=dpos, iterations=R.iterations,
+                num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost, final_cost=R.final_cost,
+                termination=R.termination)
+
+
+def huber(a, s):
+    rho = (C.c_double * 3)()
+    lib().orc_huber(C.c_double(a), C.c_double(s), rho)
+    return [rho[0], rho[1], rho[2]]
+
+
+def corrector(sq_norm, rho, residuals, jacobian):
+    r = np.array(residuals, np.float64, copy=True).reshape(-1)
+    J = np.array(jacobian, np.float64, copy=True)
+    J2 = J.reshape(r.shape[0], -1)
+    rho_a = (C.c_double * 3)(*rho)
+    lib().orc_corrector(C.c_double(sq_norm), rho_a, r.shape[0], J2.shape[1], _p(r), _p(J2))
+    return r, J2
+
+
+def lm_radius_sequence(initial, max_radius, events):
+    rad, dec = C.c_double(initial), C.c_double(2.0)
+    out = []
+    for kind, q in events:
+        if kind == "reject":
+            lib().orc_lm_step_rejected(C.byref(rad), C.byref(dec))
+        else:
+            lib().orc_lm_step_accepted(C.c_double(q), C.byref(rad), C.byref(dec), C.c_double(max_radius))
+        out.append(rad.value)
+    return out
+
+
+def se3_left_plus(pose, delta):
+    p = np.ascontiguousarray(pose, np.float64); d = np.ascontiguousarray(delta, np.float64)
+    out = np.zeros(7)
+    lib().orc_se3_left_plus(_p(p), _p(d), _p(out))
+    return out
+
+
+def ba_residual(rtype, calib_l, calib_r, T_rl, anchor_pose, obs_pose, invdepth, anchor_uv, uv, sigma=1.0):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    cl, cr, trl, ap, op, auv, uvv = f(calib_l), f(calib_r), f(T_rl), f(anchor_pose), f(obs_pose), f(anchor_uv), f(uv)
+    r = np.zeros(2); Ja = np.zeros(12); Jo = np.zeros(12); Jl = np.zeros(2); chi2 = C.c_double(0)
+    lib().orc_ba_residual.restype = C.c_int
+    dp = lib().orc_ba_residual(int(rtype), _p(cl), _p(cr), _p(trl), _p(ap), _p(op), C.c_double(invdepth), _p(auv), _p(uvv),
+                               C.c_double(sigma), _p(r), _p(Ja), _p(Jo), _p(Jl), C.byref(chi2))
+    return r, Ja.reshape(2, 6), Jo.reshape(2, 6), Jl, chi2.value, bool(dp)

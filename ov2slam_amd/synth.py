@@ -75,3 +75,108 @@ def grid_keypoints(w, h, cell, rng, jitter=0.45):
     g[:, 0] = np.clip(g[:, 0], 6, w - 7)
     g[:, 1] = np.clip(g[:, 1], 6, h - 7)
     return g.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- local BA
+def _quat_from_R(R):
+    """rotation matrix -> [x y z w] (Eigen coefficient order)"""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s]
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0, 0, 0, 0]
+        q[i] = 0.25 * s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+        q[3] = (R[k, j] - R[j, k]) / s
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
+def _R_from_quat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def make_ba_problem(n_kf=50, n_lm=10000, obs_per_lm=30, stereo=False, seed=42, px_noise=1.0,
+                    outlier_frac=0.02, pose_noise=(0.02, np.deg2rad(0.5)), invdepth_noise=0.05):
+    """Synthetic anchored-inverse-depth local-BA problem: KFs on a 10 m arc
+    looking inward (3 deg apart), landmarks in the viewed volume, each seen by a contiguous range
+    of `obs_per_lm` KFs starting at its anchor.  Returns a dict of flat numpy arrays in the layout
+    of ov2_ba_problem (include/ov2slam_hip.h) plus the ground truth."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.654; cx, cy = 367.215, 248.375
+    K = np.array([fx, fy, cx, cy])
+    obs_per_lm = min(obs_per_lm, n_kf)
+    poses_gt = np.zeros((n_kf, 7))
+    Rs, ts = [], []
+    for k in range(n_kf):
+        th = np.deg2rad(3.0) * k
+        c = 10.0 * np.array([np.cos(th), np.sin(th), 0.0])
+        zc = -np.array([np.cos(th), np.sin(th), 0.0]); yc = np.array([0, 0, -1.0]); xc = np.cross(yc, zc)
+        R = np.stack([xc, yc, zc], 1)
+        Rs.append(R); ts.append(c)
+        poses_gt[k, :3] = c; poses_gt[k, 3:] = _quat_from_R(R)
+    baseline = 0.11
+    T_rl = np.array([-baseline, 0, 0, 0, 0, 0, 1.0])
+
+    def project(k, X, right=False):
+        pc = Rs[k].T @ (X - ts[k])
+        if right:
+            pc = pc + T_rl[:3]
+        return np.array([fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy]), pc[2]
+
+    anchors = rng.integers(0, n_kf - obs_per_lm + 1, n_lm)
+    X = np.stack([rng.uniform(-3, 3, n_lm), rng.uniform(-3, 3, n_lm), rng.uniform(-2, 2, n_lm)], 1)
+    lm_anchor_uv = np.zeros((n_lm, 2)); invdepth_gt = np.zeros(n_lm)
+    res_type, res_kf, res_lm, res_uv = [], [], [], []
+    is_outlier = []
+    for l in range(n_lm):
+        a = int(anchors[l])
+        uv, z = project(a, X[l])
+        lm_anchor_uv[l] = uv
+        invdepth_gt[l] = 1.0 / z
+        if stereo:
+            uvr, _ = project(a, X[l], True)
+            res_type.append(2); res_kf.append(a); res_lm.append(l); res_uv.append(uvr + rng.normal(0, px_noise, 2)); is_outlier.append(False)
+        for k in range(a + 1, a + obs_per_lm):
+            uvk, _ = project(k, X[l])
+            out = rng.uniform() < outlier_frac
+            n = rng.uniform(-50, 50, 2) if out else rng.normal(0, px_noise, 2)
+            res_type.append(0); res_kf.append(k); res_lm.append(l); res_uv.append(uvk + n); is_outlier.append(out)
+            if stereo:
+                uvr, _ = project(k, X[l], True)
+                res_type.append(1); res_kf.append(k); res_lm.append(l); res_uv.append(uvr + rng.normal(0, px_noise, 2)); is_outlier.append(False)
+    poses0 = poses_gt.copy()
+    for k in range(n_kf):
+        dt = rng.normal(0, pose_noise[0], 3); dw = rng.normal(0, pose_noise[1], 3)
+        R = _so3_exp(dw) @ Rs[k]
+        poses0[k, :3] = ts[k] + dt; poses0[k, 3:] = _quat_from_R(R)
+    kf_const = np.zeros(n_kf, np.uint8); kf_const[0] = 1
+    if not stereo and n_kf > 1:
+        kf_const[1] = 1
+    poses0[kf_const == 1] = poses_gt[kf_const == 1]
+    invdepth0 = invdepth_gt * (1 + rng.normal(0, invdepth_noise, n_lm))
+    n_res = len(res_type)
+    return dict(n_kf=n_kf, n_lm=n_lm, n_res=n_res,
+                poses=np.ascontiguousarray(poses0), kf_const=kf_const,
+                invdepth=np.ascontiguousarray(invdepth0), lm_anchor_kf=anchors.astype(np.int32),
+                lm_anchor_uv=np.ascontiguousarray(lm_anchor_uv),
+                res_type=np.array(res_type, np.uint8), res_kf=np.array(res_kf, np.int32), res_lm=np.array(res_lm, np.int32),
+                res_uv=np.ascontiguousarray(np.array(res_uv, np.float64).reshape(-1, 2)), res_sigma=np.ones(n_res),
+                calib_l=K.copy(), calib_r=K.copy(), T_rl=T_rl,
+                poses_gt=poses_gt, invdepth_gt=invdepth_gt, is_outlier=np.array(is_outlier, bool))
