@@ -87,6 +87,9 @@ SIGNATURES = {
     "ov2_corner_subpix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _d]),
     "ov2_ba_default_options": (None, [C.POINTER(BAOptions)]),
     "ov2_ba_solve": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(BAOptions), C.POINTER(BAResult)]),
+    "ov2_ba_create": (_i, [_vp, C.POINTER(BAProblem), _pp]),
+    "ov2_ba_solve_resident": (_i, [_vp, _vp, C.POINTER(BAOptions), C.POINTER(BAResult)]),
+    "ov2_ba_destroy": (None, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,983 @@
+// ba.hip -- anchored-inverse-depth local bundle adjustment on gfx950 (fp64).
+//
+// Replaces the two ceres::Solve calls of Optimizer::localBA
+// (/root/reference/src/optimizer.cpp:479 robust pass, :618 L2 pass) together with the factor
+// arithmetic of src/ceres_parametrization.cpp:361-712 and Ceres 2.0.0's trust-region
+// Levenberg-Marquardt + Schur-complement machinery (trust_region_minimizer.cc,
+// levenberg_marquardt_strategy.cc, schur_eliminator_impl.h, corrector.cc, loss_function.cc).
+//
+// Device-side design
+//   * The whole LM loop runs on the GPU: every kernel reads a control block (BACtl) in HBM and
+//     returns at once when the solver has terminated or its phase is not needed, so the host
+//     enqueues a fixed kernel sequence for max_iter iterations and synchronises ONCE.
+//   * Linearisation (k_ba_linearize): one wavefront per landmark, one lane per residual block.
+//     Per-residual 2x6 / 2x6 / 2x1 Jacobians are built in registers, robustified (Huber +
+//     Ceres corrector) and immediately contracted: the landmark's E-side sums (E^T E, E^T b and
+//     its dense row of W = E^T F) are reduced inside the wave (shuffles / an LDS row) and written
+//     once, coalesced; pose-side blocks (F^T F, F^T b) are accumulated with fp64 atomics.
+//     No Jacobian is ever materialised in HBM.
+//   * The normal equations are kept UNSCALED; Jacobi scaling s, the LM diagonal D and the trust
+//     region radius enter algebraically per iteration:
+//         S  = s_i s_j (H_ij - sum_l W_li c_l W_lj) + delta_ij D_i^2,  c_l = s_l^2 / (s_l^2 ete_l + D_l^2)
+//     so a rejected step re-runs only the W^T C W contraction (k_ba_schur_gemm, LDS-tiled,
+//     split over landmarks), the dense Cholesky (k_ba_cholesky, one workgroup) and the
+//     back-substitution -- not the Jacobians.
+//   * Step acceptance, radius update, tolerances and the "last evaluated point" bookkeeping
+//     (chi2err_/isdepthpositive_ caching) follow Ceres exactly (k_ba_iter_begin,
+//     k_ba_candidate, k_ba_decide).
+#include "common.hpp"
+#include <math.h>
+#include <float.h>
+#include <algorithm>
+#include <vector>
+
+#pragma clang fp contract(fast)   // BA parity is 1e-4 relative in fp64: FMA contraction is fine here
+
+#define BA_TILE 32
+
+struct BACtl {
+    // accumulators
+    double cost_acc;
+    double acc1, acc2;            // sum_l y_l g'_l ; sum_l (2 y_l s_l t_l + s_l^2 ete_l y_l^2)
+    // LM / TR state
+    double radius, decrease_factor;
+    double x_cost, cand_cost, model_cost_change, x_norm, minimum_cost, initial_cost, gmax;
+    double ev_min, ev_cur, ev_ref, ev_cand, ev_acc_ref, ev_acc_cand;
+    int ev_nonmono;
+    int reuse_diag;
+    int iteration, n_steps, n_success, num_invalid, termination, done;
+    int need_lin, fresh_lin, step_successful, step_valid, lin_fail, scaled;
+};
+
+struct BADev {                    // device pointers + sizes (passed by value to kernels)
+    int n_kf, n_lm, n_act, nf, nfp;
+    // problem (landmark-sorted residuals)
+    const int *pose_col;          // n_kf  (-1 = constant)
+    const int *lm_ptr;            // n_lm+1
+    const int *lm_anchor;         // n_lm
+    const double *lm_auv;         // 2*n_lm
+    const uint8_t *res_type;      // n_act
+    const int *res_kf;            // n_act
+    const int *res_orig;          // n_act -> index in the caller's arrays
+    const double *res_uv;         // 2*n_act
+    const double *res_sigma;      // n_act
+    double calib_l[4], calib_r[4];
+    double Rrl[9], trl[3];
+    double huber;                 // <= 0 : trivial loss
+    // state
+    double *x_pose, *c_pose;      // 7*n_kf
+    double *x_RT, *c_RT;          // 12*n_kf : Rwc row-major (9) + t (3)
+    double *x_lam, *c_lam;        // n_lm
+    double *scale_f, *diag_f;     // nfp
+    double *scale_l, *diag_l;     // n_lm
+    double *ete, *etb;            // n_lm  (unscaled E^T E, E^T b)
+    double *cl, *ce;              // n_lm  c_l, c_l * etb_l
+    double *W;                    // n_lm * nfp (unscaled E^T F)
+    double *H, *G;                // nfp*nfp (unscaled F^T F ; W^T C W, upper tiles)
+    double *bf, *v;               // nfp  (unscaled F^T b ; W^T (c etb))
+    double *S;                    // nfp*nfp scratch for the Cholesky
+    double *yf;                   // nfp
+    double *yl;                   // n_lm
+    double *chi2;                 // n_res (caller order)
+    uint8_t *dpos;                // n_res
+    BACtl *ctl;
+};
+
+struct BAOpt {
+    int max_iter;
+    double ftol, gtol, ptol, max_radius, min_radius, min_diag, max_diag, min_rel_decrease;
+    int jacobi, max_invalid;
+};
+
+// ---------------------------------------------------------------------------------- algebra
+__device__ __forceinline__ void d_quat_to_R(const double *q, double *R)
+{
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double n = sqrt(x * x + y * y + z * z + w * w);
+    x /= n; y /= n; z /= n; w /= n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// T' = Exp(delta) * T   (se3left_parametrization.hpp:45-57, Sophus se3.hpp:763-784, so3.hpp:585-621)
+__device__ void d_se3_left_plus(const double *pose, const double *a, double *out)
+{
+    const double *om = a + 3;
+    const double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    double theta, imag, real;
+    if (theta_sq < 1e-10 * 1e-10) {
+        theta = 0;
+        const double t4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * t4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * t4;
+    } else {
+        theta = sqrt(theta_sq);
+        const double half = 0.5 * theta;
+        imag = sin(half) / theta;
+        real = cos(half);
+    }
+    const double qe[4] = {imag * om[0], imag * om[1], imag * om[2], real};
+    double V[9], Re[9];
+    d_quat_to_R(qe, Re);
+    if (theta < 1e-10) {
+        for (int k = 0; k < 9; k++) V[k] = Re[k];
+    } else {
+        const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+        const double c1 = (1.0 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                const double o2 = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+                V[3 * i + j] = c1 * O[3 * i + j] + c2 * o2 + (i == j ? 1.0 : 0.0);
+            }
+    }
+    double q[4] = {pose[3], pose[4], pose[5], pose[6]};
+    const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= qn; q[1] /= qn; q[2] /= qn; q[3] /= qn;
+    const double ax = qe[0], ay = qe[1], az = qe[2], aw = qe[3], bx = q[0], by = q[1], bz = q[2], bw = q[3];
+    double r[4];
+    r[3] = aw * bw - ax * bx - ay * by - az * bz;
+    r[0] = aw * bx + ax * bw + ay * bz - az * by;
+    r[1] = aw * by + ay * bw + az * bx - ax * bz;
+    r[2] = aw * bz + az * bw + ax * by - ay * bx;
+    const double rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    for (int i = 0; i < 3; i++)
+        out[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2] +
+                 Re[3 * i] * pose[0] + Re[3 * i + 1] * pose[1] + Re[3 * i + 2] * pose[2];
+    out[3] = r[0] / rn; out[4] = r[1] / rn; out[5] = r[2] / rn; out[6] = r[3] / rn;
+}
+
+__device__ __forceinline__ void d_pose_to_RT(const double *pose, double *RT)
+{
+    d_quat_to_R(pose + 3, RT);
+    RT[9] = pose[0]; RT[10] = pose[1]; RT[11] = pose[2];
+}
+
+// Huber (loss_function.cc:48-62) -> (rho, rho')
+__device__ __forceinline__ void d_huber(double a, double s, double &rho0, double &rho1)
+{
+    if (a > 0 && s > a * a) {
+        const double r = sqrt(s);
+        rho0 = 2.0 * a * r - a * a;
+        rho1 = fmax(DBL_MIN, a / r);
+    } else { rho0 = s; rho1 = 1.0; }
+}
+
+// One residual block.  RTa / RTo: anchor / observer (Rwc | t).  Returns the depth-positive flag.
+// Jacobians are w.r.t. the left-multiplicative se(3) tangents [dt, dw] (2x6 row-major) and lambda.
+template <bool JAC>
+__device__ __forceinline__ int d_residual(const BADev &D, int type, const double *RTa, const double *RTo, double lam,
+                                          const double *auv, const double *uv, double sigma,
+                                          double *r, double *Ja, double *Jo, double *Jl)
+{
+    const double sqrt_info = 1.0 / sigma, zanch = 1.0 / lam;
+    const double ap[3] = {zanch * ((auv[0] - D.calib_l[2]) / D.calib_l[0]), zanch * ((auv[1] - D.calib_l[3]) / D.calib_l[1]), zanch};
+    const double *K = type == OV2_RES_LEFT ? D.calib_l : D.calib_r;
+    double cam[3], wpt[3] = {0, 0, 0}, Ra[3] = {0, 0, 0};
+    if (type == OV2_RES_RIGHT_ANCH) {
+        for (int i = 0; i < 3; i++) cam[i] = D.Rrl[3 * i] * ap[0] + D.Rrl[3 * i + 1] * ap[1] + D.Rrl[3 * i + 2] * ap[2] + D.trl[i];
+    } else {
+        for (int i = 0; i < 3; i++) { Ra[i] = RTa[3 * i] * ap[0] + RTa[3 * i + 1] * ap[1] + RTa[3 * i + 2] * ap[2]; wpt[i] = Ra[i] + RTa[9 + i]; }
+        const double d[3] = {wpt[0] - RTo[9], wpt[1] - RTo[10], wpt[2] - RTo[11]};
+        double lc[3];
+        for (int i = 0; i < 3; i++) lc[i] = RTo[i] * d[0] + RTo[3 + i] * d[1] + RTo[6 + i] * d[2];      // Rcw = Rwc^T
+        if (type == OV2_RES_LEFT) { cam[0] = lc[0]; cam[1] = lc[1]; cam[2] = lc[2]; }
+        else for (int i = 0; i < 3; i++) cam[i] = D.Rrl[3 * i] * lc[0] + D.Rrl[3 * i + 1] * lc[1] + D.Rrl[3 * i + 2] * lc[2] + D.trl[i];
+    }
+    const double invz = 1.0 / cam[2];
+    r[0] = sqrt_info * (K[0] * cam[0] * invz + K[2] - uv[0]);
+    r[1] = sqrt_info * (K[1] * cam[1] * invz + K[3] - uv[1]);
+    const int dp = cam[2] > 0;
+    if (!JAC) return dp;
+    const double invz2 = invz * invz;
+    const double Jc[6] = {invz * K[0], 0, -cam[0] * invz2 * K[0], 0, invz * K[1], -cam[1] * invz2 * K[1]};
+    double M[9];
+    if (type == OV2_RES_RIGHT_ANCH) { for (int k = 0; k < 9; k++) M[k] = D.Rrl[k]; }
+    else if (type == OV2_RES_LEFT) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = RTo[3 * j + i]; }
+    else for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+        M[3 * i + j] = D.Rrl[3 * i] * RTo[j] + D.Rrl[3 * i + 1] * RTo[3 + j] + D.Rrl[3 * i + 2] * RTo[6 + j];   // Rrl * Rcw
+    double JR[6];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) JR[3 * i + j] = Jc[3 * i] * M[j] + Jc[3 * i + 1] * M[3 + j] + Jc[3 * i + 2] * M[6 + j];
+    if (type == OV2_RES_RIGHT_ANCH) {
+        for (int k = 0; k < 12; k++) { Ja[k] = 0; Jo[k] = 0; }
+        const double jl[3] = {-zanch * ap[0], -zanch * ap[1], -zanch * ap[2]};
+        Jl[0] = sqrt_info * (JR[0] * jl[0] + JR[1] * jl[1] + JR[2] * jl[2]);
+        Jl[1] = sqrt_info * (JR[3] * jl[0] + JR[4] * jl[1] + JR[5] * jl[2]);
+        return dp;
+    }
+    const double S[9] = {0, -wpt[2], wpt[1], wpt[2], 0, -wpt[0], -wpt[1], wpt[0], 0};
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 3; j++) {
+            const double jrs = JR[3 * i] * S[j] + JR[3 * i + 1] * S[3 + j] + JR[3 * i + 2] * S[6 + j];
+            Ja[6 * i + j] = sqrt_info * JR[3 * i + j];  Ja[6 * i + 3 + j] = -sqrt_info * jrs;
+            Jo[6 * i + j] = -sqrt_info * JR[3 * i + j]; Jo[6 * i + 3 + j] = sqrt_info * jrs;
+        }
+    const double jl[3] = {-zanch * Ra[0], -zanch * Ra[1], -zanch * Ra[2]};
+    Jl[0] = sqrt_info * (JR[0] * jl[0] + JR[1] * jl[1] + JR[2] * jl[2]);
+    Jl[1] = sqrt_info * (JR[3] * jl[0] + JR[4] * jl[1] + JR[5] * jl[2]);
+    return dp;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------- linearize
+// grid: ceil(n_lm / 4) blocks of 256 threads; dynamic LDS: 4 * nfp doubles (one W row per wave)
+__global__ __launch_bounds__(256) void k_ba_linearize(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->need_lin) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *wrow = (double *)smem_raw + (threadIdx.x >> 6) * D.nfp;
+    const int lane = threadIdx.x & 63;
+    const int lm = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double cost = 0;
+    if (lm < D.n_lm) {
+        for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
+        const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
+        const int a = D.lm_anchor[lm];
+        const int ca = D.pose_col[a];
+        const double lam = D.x_lam[lm];
+        const double auv[2] = {D.lm_auv[2 * lm], D.lm_auv[2 * lm + 1]};
+        double ete = 0, etb = 0, wa[6] = {0, 0, 0, 0, 0, 0}, ba[6] = {0, 0, 0, 0, 0, 0}, Haa[21];
+        for (int k = 0; k < 21; k++) Haa[k] = 0;
+        for (int base = beg; base < end; base += 64) {
+            const int k = base + lane;
+            if (k < end) {
+                const int type = D.res_type[k];
+                const int o = type == OV2_RES_RIGHT_ANCH ? a : D.res_kf[k];
+                const int co = type == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[o];
+                const int cae = type == OV2_RES_RIGHT_ANCH ? -1 : ca;
+                const double uv[2] = {D.res_uv[2 * k], D.res_uv[2 * k + 1]};
+                double r[2], Ja[12], Jo[12], Jl[2];
+                const int dp = d_residual<true>(D, type, D.x_RT + 12 * a, D.x_RT + 12 * o, lam, auv, uv, D.res_sigma[k], r, Ja, Jo, Jl);
+                const double s = r[0] * r[0] + r[1] * r[1];
+                const int orig = D.res_orig[k];
+                D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
+                double rho0, rho1;
+                d_huber(D.huber, s, rho0, rho1);
+                cost += 0.5 * rho0;
+                // corrector.cc: rho'' <= 0 for Huber / trivial loss -> scale residual and Jacobians by sqrt(rho')
+                const double sc = sqrt(rho1);
+                r[0] *= sc; r[1] *= sc; Jl[0] *= sc; Jl[1] *= sc;
+                for (int q = 0; q < 12; q++) { Ja[q] *= sc; Jo[q] *= sc; }
+                ete += Jl[0] * Jl[0] + Jl[1] * Jl[1];
+                etb += Jl[0] * r[0] + Jl[1] * r[1];
+                if (cae >= 0) {
+                    int t = 0;
+                    for (int c = 0; c < 6; c++) {
+                        wa[c] += Jl[0] * Ja[c] + Jl[1] * Ja[6 + c];
+                        ba[c] += Ja[c] * r[0] + Ja[6 + c] * r[1];
+                        for (int d = c; d < 6; d++) Haa[t++] += Ja[c] * Ja[d] + Ja[6 + c] * Ja[6 + d];
+                    }
+                }
+                if (co >= 0) {
+                    for (int c = 0; c < 6; c++) {
+                        atomicAdd(&wrow[co + c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);      // LDS fp64 atomic (stereo L+R share o)
+                        atomicAdd(&D.bf[co + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+                        for (int d = 0; d < 6; d++) {
+                            atomicAdd(&D.H[(long long)(co + c) * D.nfp + co + d], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                            if (cae >= 0) {
+                                const double vv = Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c];    // H[a_d][o_c]
+                                atomicAdd(&D.H[(long long)(cae + d) * D.nfp + co + c], vv);
+                                atomicAdd(&D.H[(long long)(co + c) * D.nfp + cae + d], vv);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        ete = wave_sum(ete); etb = wave_sum(etb);
+        if (ca >= 0) {
+            for (int c = 0; c < 6; c++) { wa[c] = wave_sum(wa[c]); ba[c] = wave_sum(ba[c]); }
+            for (int k = 0; k < 21; k++) Haa[k] = wave_sum(Haa[k]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) { D.ete[lm] = ete; D.etb[lm] = etb; }
+        if (ca >= 0) {
+            if (lane < 6) { wrow[ca + lane] += wa[lane]; atomicAdd(&D.bf[ca + lane], ba[lane]); }
+            if (lane == 0) {
+                int t = 0;
+                for (int c = 0; c < 6; c++)
+                    for (int d = c; d < 6; d++, t++) {
+                        atomicAdd(&D.H[(long long)(ca + c) * D.nfp + ca + d], Haa[t]);
+                        if (d != c) atomicAdd(&D.H[(long long)(ca + d) * D.nfp + ca + c], Haa[t]);
+                    }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double *Wg = D.W + (long long)lm * D.nfp;
+        for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
+    }
+    cost = wave_sum(cost);
+    if (lane == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+}
+
+// ---------------------------------------------------------------------------------- cost only
+__global__ __launch_bounds__(256) void k_ba_cost(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->step_valid) return;
+    const int lane = threadIdx.x & 63;
+    double cost = 0;
+    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
+        const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
+        const int a = D.lm_anchor[lm];
+        const double lam = D.c_lam[lm];
+        const double auv[2] = {D.lm_auv[2 * lm], D.lm_auv[2 * lm + 1]};
+        for (int k = beg + lane; k < end; k += 64) {
+            const int type = D.res_type[k];
+            const int o = type == OV2_RES_RIGHT_ANCH ? a : D.res_kf[k];
+            const double uv[2] = {D.res_uv[2 * k], D.res_uv[2 * k + 1]};
+            double r[2];
+            const int dp = d_residual<false>(D, type, D.c_RT + 12 * a, D.c_RT + 12 * o, lam, auv, uv, D.res_sigma[k], r, nullptr, nullptr, nullptr);
+            const double s = r[0] * r[0] + r[1] * r[1];
+            const int orig = D.res_orig[k];
+            D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
+            double rho0, rho1;
+            d_huber(D.huber, s, rho0, rho1);
+            cost += 0.5 * rho0;
+        }
+    }
+    cost = wave_sum(cost);
+    if (lane == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+}
+
+// ---------------------------------------------------------------------------------- iteration begin (1 block)
+__global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    __shared__ double s_red[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int fresh = ctl->fresh_lin;
+    if (fresh) {
+        // a new linearisation at x is available: jacobi scaling (iteration 0 only), gradient max-norm
+        if (O.jacobi && !ctl->scaled) {
+            for (int c = tid; c < D.nf; c += nt) D.scale_f[c] = 1.0 / (1.0 + sqrt(D.H[(long long)c * D.nfp + c]));
+            for (int l = tid; l < D.n_lm; l += nt) D.scale_l[l] = 1.0 / (1.0 + sqrt(D.ete[l]));
+        }
+        // |x - Plus(x, -g)|_inf  (trust_region_minimizer.cc:283-297)
+        double gm = 0;
+        for (int k = tid; k < D.n_kf; k += nt) {
+            const int pc = D.pose_col[k];
+            if (pc < 0) continue;
+            double d[6], out[7];
+            for (int c = 0; c < 6; c++) d[c] = -D.bf[pc + c];
+            d_se3_left_plus(D.x_pose + 7 * k, d, out);
+            for (int c = 0; c < 7; c++) gm = fmax(gm, fabs(D.x_pose[7 * k + c] - out[c]));
+        }
+        for (int l = tid; l < D.n_lm; l += nt)
+            if (D.lm_ptr[l] != D.lm_ptr[l + 1]) gm = fmax(gm, fabs(D.etb[l]));
+        s_red[tid] = gm;
+        __syncthreads();
+        for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (fresh) {
+            ctl->gmax = s_red[0];
+            ctl->x_cost = ctl->cost_acc;
+            ctl->cost_acc = 0;
+            if (!ctl->scaled) {             // iteration zero
+                ctl->scaled = 1;
+                ctl->initial_cost = ctl->x_cost; ctl->minimum_cost = ctl->x_cost;
+                ctl->ev_min = ctl->ev_cur = ctl->ev_ref = ctl->ev_cand = ctl->x_cost;
+                ctl->ev_acc_ref = ctl->ev_acc_cand = 0; ctl->ev_nonmono = 0;
+            }
+            ctl->fresh_lin = 0;
+            ctl->reuse_diag = 0;
+        }
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
+        if (ctl->step_successful) {
+            ctl->n_success++;
+            if (ctl->x_cost < ctl->minimum_cost) ctl->minimum_cost = ctl->x_cost;
+        }
+        if (ctl->iteration >= O.max_iter) { ctl->termination = OV2_TERM_NO_CONVERGENCE; ctl->done = 1; }
+        else if (ctl->step_successful && ctl->gmax <= O.gtol) { ctl->termination = OV2_TERM_GRADIENT_TOL; ctl->done = 1; }
+        else if (ctl->radius <= O.min_radius) { ctl->termination = OV2_TERM_MIN_RADIUS; ctl->done = 1; }
+        else {
+            ctl->iteration++;
+            ctl->step_successful = 0;
+            ctl->step_valid = 0;
+            ctl->lin_fail = 0;
+            ctl->n_steps++;
+            ctl->acc1 = 0; ctl->acc2 = 0;
+        }
+    }
+    __syncthreads();
+    if (ctl->done) return;
+    // LevenbergMarquardtStrategy::ComputeStep: diagonal of the (scaled) J^T J, clamped, unless reused
+    const double radius = ctl->radius;
+    const int reuse = ctl->reuse_diag;
+    for (int c = tid; c < D.nfp; c += nt) {
+        if (c < D.nf) {
+            if (!reuse) {
+                const double s = D.scale_f[c];
+                D.diag_f[c] = fmin(fmax(s * s * D.H[(long long)c * D.nfp + c], O.min_diag), O.max_diag);
+            }
+        }
+        D.v[c] = 0;
+    }
+    for (int l = tid; l < D.n_lm; l += nt) {
+        if (D.lm_ptr[l] == D.lm_ptr[l + 1]) { D.cl[l] = 0; D.ce[l] = 0; continue; }
+        const double s = D.scale_l[l];
+        if (!reuse) D.diag_l[l] = fmin(fmax(s * s * D.ete[l], O.min_diag), O.max_diag);
+        const double etep = s * s * D.ete[l] + D.diag_l[l] / radius;     // scaled E^T E + D_e^2
+        const double c = s * s / etep;
+        D.cl[l] = c; D.ce[l] = c * D.etb[l];
+    }
+    __syncthreads();
+    if (tid == 0) ctl->reuse_diag = 1;
+}
+
+// ---------------------------------------------------------------------------------- W^T C W (+ W^T (c etb))
+// grid: (n_upper_tiles, ksplit); block 256 threads, each thread a 2x2 patch of a 32x32 tile
+__global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int lm_per_split)
+{
+    if (D.ctl->done) return;
+    // decode upper-triangular tile index
+    int t = blockIdx.x, ti = 0;
+    while (t >= ntiles - ti) { t -= ntiles - ti; ti++; }
+    const int tj = ti + t;
+    __shared__ double As[BA_TILE][BA_TILE + 1], Bs[BA_TILE][BA_TILE + 1];
+    __shared__ double ces[BA_TILE];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int l0 = blockIdx.y * lm_per_split;
+    const int l1 = min(D.n_lm, l0 + lm_per_split);
+    double acc[2][2] = {{0, 0}, {0, 0}};
+    double vacc = 0;                                        // threads 0..31 of diagonal tiles accumulate v
+    for (int lb = l0; lb < l1; lb += BA_TILE) {
+        // load 32 landmarks x 32 columns of both panels; A is pre-multiplied by c_l
+        for (int e = tid; e < BA_TILE * BA_TILE; e += 256) {
+            const int kk = e >> 5, cc = e & 31;
+            const int l = lb + kk;
+            double a = 0, b = 0;
+            if (l < l1) {
+                const double *wr = D.W + (long long)l * D.nfp;
+                a = wr[ti * BA_TILE + cc] * D.cl[l];
+                b = wr[tj * BA_TILE + cc];
+            }
+            As[kk][cc] = a; Bs[kk][cc] = b;
+        }
+        if (tid < BA_TILE) ces[tid] = (lb + tid < l1) ? D.etb[lb + tid] : 0.0;
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < BA_TILE; kk++) {
+            const double a0 = As[kk][2 * ty], a1 = As[kk][2 * ty + 1];
+            const double b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        if (ti == tj && tid < BA_TILE)
+            for (int kk = 0; kk < BA_TILE; kk++) vacc += As[kk][tid] * ces[kk];
+        __syncthreads();
+    }
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+            const int gi = ti * BA_TILE + 2 * ty + i, gj = tj * BA_TILE + 2 * tx + j;
+            if (acc[i][j] != 0.0) atomicAdd(&D.G[(long long)gi * D.nfp + gj], acc[i][j]);
+        }
+    if (ti == tj && tid < BA_TILE && vacc != 0.0) atomicAdd(&D.v[ti * BA_TILE + tid], vacc);
+}
+
+// ---------------------------------------------------------------------------------- reduced system (1 block)
+// S = s_i s_j (H_ij - G_ij) + delta_ij diag_i / radius ; rhs = s_i (b_i - v_i); dense Cholesky; solve.
+__global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    const int n = D.nf, ld = D.nfp, tid = threadIdx.x, nt = blockDim.x;
+    __shared__ double s_diag;
+    __shared__ int s_fail;
+    const double radius = ctl->radius;
+    double *S = D.S;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, j = e - i * n;
+        if (j > i) continue;                               // lower triangle only
+        const int gi = (i / BA_TILE <= j / BA_TILE) ? i : j, gj = (i / BA_TILE <= j / BA_TILE) ? j : i;   // G holds upper tiles
+        double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)i * ld + j] - D.G[(long long)gi * ld + gj]);
+        if (i == j) val += D.diag_f[i] / radius;
+        S[(long long)i * ld + j] = val;
+    }
+    for (int i = tid; i < n; i += nt) D.yf[i] = D.scale_f[i] * (D.bf[i] - D.v[i]);
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    // right-looking Cholesky, lower triangle, in HBM/L2 (n <= a few hundred)
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) {
+            const double d = S[(long long)j * ld + j];
+            if (!(d > 0.0) || !isfinite(d)) s_fail = 1;
+            s_diag = sqrt(d);
+        }
+        __syncthreads();
+        if (s_fail) break;
+        const double dj = s_diag;
+        for (int i = j + tid; i < n; i += nt) S[(long long)i * ld + j] = (i == j) ? dj : S[(long long)i * ld + j] / dj;
+        __syncthreads();
+        // trailing update: S[i][k] -= L[i][j] * L[k][j] for j < k <= i
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += nt) {
+            const int ii = e / m, kk = e - ii * m;
+            if (kk > ii) continue;
+            const int i = j + 1 + ii, k = j + 1 + kk;
+            S[(long long)i * ld + k] -= S[(long long)i * ld + j] * S[(long long)k * ld + j];
+        }
+        __syncthreads();
+    }
+    if (s_fail) { if (tid == 0) ctl->lin_fail = 1; return; }
+    // forward / backward substitution by one wavefront (dot products reduced across lanes)
+    if (tid < 64) {
+        for (int i = 0; i < n; i++) {
+            double s = 0;
+            for (int k = tid; k < i; k += 64) s += S[(long long)i * ld + k] * D.yf[k];
+            s = wave_sum(s);
+            if (tid == 0) D.yf[i] = (D.yf[i] - s) / S[(long long)i * ld + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = 0;
+            for (int k = i + 1 + tid; k < n; k += 64) s += S[(long long)k * ld + i] * D.yf[k];
+            s = wave_sum(s);
+            if (tid == 0) D.yf[i] = (D.yf[i] - s) / S[(long long)i * ld + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- back substitution
+// one wavefront per landmark: t_l = W_l . (s .* yf); y_l = s_l (etb_l - t_l) / etep_l
+__global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || ctl->lin_fail) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *sy = (double *)smem_raw;                        // s_j * yf_j
+    for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    double a1 = 0, a2 = 0;
+    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
+        if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) { if (lane == 0) D.yl[lm] = 0; continue; }
+        const double *wr = D.W + (long long)lm * D.nfp;
+        double t = 0;
+        for (int c = lane; c < D.nfp; c += 64) t += wr[c] * sy[c];
+        t = wave_sum(t);
+        if (lane == 0) {
+            const double s = D.scale_l[lm], ete = D.ete[lm], etb = D.etb[lm];
+            const double c = D.cl[lm];                     // s^2 / etep
+            const double y = (c / s) * (etb - t);          // s (etb - t) / etep
+            D.yl[lm] = y;
+            a1 += y * s * etb;
+            a2 += 2.0 * y * s * t + s * s * ete * y * y;
+        }
+    }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { if (a1 != 0.0) atomicAdd(&ctl->acc1, a1); if (a2 != 0.0) atomicAdd(&ctl->acc2, a2); }
+}
+
+// ---------------------------------------------------------------------------------- candidate (1 block)
+__global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    __shared__ double s_red[1024];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int ok = !ctl->lin_fail;
+    // yf . g'_f  and  yf^T H'_pp yf  ; finite check
+    double p1 = 0, p2 = 0; int bad = 0;
+    if (ok) {
+        for (int i = tid; i < D.nf; i += nt) {
+            const double yi = D.yf[i], si = D.scale_f[i];
+            if (!isfinite(yi)) bad = 1;
+            p1 += yi * si * D.bf[i];
+            double row = 0;
+            for (int j = 0; j < D.nf; j++) row += D.H[(long long)i * D.nfp + j] * D.scale_f[j] * D.yf[j];
+            p2 += yi * si * row;
+        }
+        for (int l = tid; l < D.n_lm; l += nt) if (!isfinite(D.yl[l])) bad = 1;
+    }
+    s_red[tid] = p1; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+    const double P1 = s_red[0]; __syncthreads();
+    s_red[tid] = p2; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+    const double P2 = s_red[0]; __syncthreads();
+    s_red[tid] = (double)bad; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+    if (s_red[0] > 0) ok = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int valid = 0;
+        if (ok) {
+            // model_cost_change = -(J step).(r + J step / 2) with step = -y  ==  y.g' - y^T H' y / 2
+            const double mcc = (P1 + ctl->acc1) - 0.5 * (P2 + ctl->acc2);
+            ctl->model_cost_change = mcc;
+            valid = mcc > 0.0;
+        }
+        if (!valid) {
+            // HandleInvalidStep (trust_region_minimizer.cc:436-459)
+            if (++ctl->num_invalid >= O.max_invalid) { ctl->termination = OV2_TERM_INVALID_STEPS; ctl->done = 1; }
+            else { ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1; }
+            ctl->step_valid = 0;
+        } else {
+            ctl->num_invalid = 0;
+            ctl->step_valid = 1;
+        }
+        s_flag = valid;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    // candidate = Plus(x, step .* scale), step = -y
+    for (int k = tid; k < D.n_kf; k += nt) {
+        const int pc = D.pose_col[k];
+        double out[7];
+        if (pc >= 0) {
+            double d[6];
+            for (int c = 0; c < 6; c++) d[c] = -D.yf[pc + c] * D.scale_f[pc + c];
+            d_se3_left_plus(D.x_pose + 7 * k, d, out);
+        } else for (int c = 0; c < 7; c++) out[c] = D.x_pose[7 * k + c];
+        for (int c = 0; c < 7; c++) D.c_pose[7 * k + c] = out[c];
+        d_pose_to_RT(out, D.c_RT + 12 * k);
+    }
+    for (int l = tid; l < D.n_lm; l += nt) D.c_lam[l] = D.x_lam[l] - D.yl[l] * D.scale_l[l];
+}
+
+// ---------------------------------------------------------------------------------- decision (1 block)
+__global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->step_valid) return;
+    __shared__ double s_red[1024];
+    __shared__ int s_accept;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // |x - candidate|^2 and |candidate|^2 over the variable blocks
+    double sn = 0, xn = 0;
+    for (int k = tid; k < D.n_kf; k += nt) {
+        if (D.pose_col[k] < 0) continue;
+        for (int c = 0; c < 7; c++) {
+            const double d = D.x_pose[7 * k + c] - D.c_pose[7 * k + c];
+            sn += d * d; xn += D.c_pose[7 * k + c] * D.c_pose[7 * k + c];
+        }
+    }
+    for (int l = tid; l < D.n_lm; l += nt) {
+        if (D.lm_ptr[l] == D.lm_ptr[l + 1]) continue;
+        const double d = D.x_lam[l] - D.c_lam[l];
+        sn += d * d; xn += D.c_lam[l] * D.c_lam[l];
+    }
+    s_red[tid] = sn; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+    const double SN = s_red[0]; __syncthreads();
+    s_red[tid] = xn; __syncthreads();
+    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+    const double XN = s_red[0]; __syncthreads();
+    if (tid == 0) {
+        s_accept = 0;
+        const double cand = ctl->cost_acc;
+        ctl->cost_acc = 0;
+        ctl->cand_cost = cand;
+        if (sqrt(SN) <= O.ptol * (ctl->x_norm + O.ptol)) { ctl->termination = OV2_TERM_PARAMETER_TOL; ctl->done = 1; }
+        else if (fabs(ctl->x_cost - cand) <= O.ftol * ctl->x_cost) { ctl->termination = OV2_TERM_FUNCTION_TOL; ctl->done = 1; }
+        else {
+            const double mcc = ctl->model_cost_change;
+            const double r1 = (ctl->ev_cur - cand) / mcc, r2 = (ctl->ev_ref - cand) / (ctl->ev_acc_ref + mcc);
+            const double rel = fmax(r1, r2);
+            if (rel > O.min_rel_decrease) {
+                s_accept = 1;
+                ctl->x_norm = sqrt(XN);
+                ctl->step_successful = 1;
+                ctl->need_lin = 1;
+                // LevenbergMarquardtStrategy::StepAccepted
+                const double t = 2.0 * rel - 1.0;
+                ctl->radius = fmin(O.max_radius, ctl->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                ctl->decrease_factor = 2.0; ctl->reuse_diag = 0;
+                // TrustRegionStepEvaluator::StepAccepted (max_consecutive_nonmonotonic_steps = 0)
+                ctl->ev_cur = cand; ctl->ev_acc_cand += mcc; ctl->ev_acc_ref += mcc;
+                if (ctl->ev_cur < ctl->ev_min) { ctl->ev_min = ctl->ev_cur; ctl->ev_nonmono = 0; ctl->ev_cand = ctl->ev_cur; ctl->ev_acc_cand = 0; }
+                else { ctl->ev_nonmono++; if (ctl->ev_cur > ctl->ev_cand) { ctl->ev_cand = ctl->ev_cur; ctl->ev_acc_cand = 0; } }
+                if (ctl->ev_nonmono == 0) { ctl->ev_ref = ctl->ev_cand; ctl->ev_acc_ref = ctl->ev_acc_cand; }
+            } else {
+                ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_accept) return;
+    // x <- candidate ; clear the pose-side accumulators for the re-linearisation
+    for (int e = tid; e < 7 * D.n_kf; e += nt) D.x_pose[e] = D.c_pose[e];
+    for (int e = tid; e < 12 * D.n_kf; e += nt) D.x_RT[e] = D.c_RT[e];
+    for (int l = tid; l < D.n_lm; l += nt) D.x_lam[l] = D.c_lam[l];
+    for (int e = tid; e < D.nfp * D.nfp; e += nt) D.H[e] = 0;
+    for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
+}
+
+// marks that k_ba_linearize has produced a linearisation (1 thread; keeps the flag flip race-free)
+__global__ void k_ba_lin_done(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->need_lin) return;
+    ctl->need_lin = 0; ctl->fresh_lin = 1;
+}
+
+__global__ __launch_bounds__(256) void k_ba_init(BADev D)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.n_kf; k += gridDim.x * blockDim.x)
+        d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);
+}
+
+// ---------------------------------------------------------------------------------- host
+struct ov2_ba_dev {
+    BADev D;
+    void *pool = nullptr; size_t pool_bytes = 0;
+    int n_res = 0;
+    std::vector<double> h_poses0, h_lam0;
+    int device = 0;
+};
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
+{
+    OV2_REQUIRE(p && out, OV2_EINVAL, "NULL problem");
+    OV2_REQUIRE(p->n_kf > 0 && p->n_lm >= 0 && p->n_res >= 0, OV2_EINVAL, "bad problem sizes");
+    OV2_REQUIRE(p->poses && p->kf_const, OV2_EINVAL, "NULL pose arrays");
+    OV2_REQUIRE(p->n_lm == 0 || (p->invdepth && p->lm_anchor_kf && p->lm_anchor_uv), OV2_EINVAL, "NULL landmark arrays");
+    OV2_REQUIRE(p->n_res == 0 || (p->res_type && p->res_kf && p->res_lm && p->res_uv && p->res_sigma), OV2_EINVAL, "NULL residual arrays");
+    // validate + landmark-sorted order of the active residual blocks
+    std::vector<int> cnt(p->n_lm + 1, 0);
+    int n_act = 0;
+    for (int i = 0; i < p->n_res; i++) {
+        if (p->res_active && !p->res_active[i]) continue;
+        const int lm = p->res_lm[i];
+        OV2_REQUIRE(lm >= 0 && lm < p->n_lm, OV2_EINVAL, "res_lm out of range");
+        OV2_REQUIRE(p->res_type[i] <= OV2_RES_RIGHT_ANCH, OV2_EINVAL, "unknown residual type");
+        if (p->res_type[i] != OV2_RES_RIGHT_ANCH) OV2_REQUIRE(p->res_kf[i] >= 0 && p->res_kf[i] < p->n_kf, OV2_EINVAL, "res_kf out of range");
+        OV2_REQUIRE(p->res_sigma[i] > 0, OV2_EINVAL, "res_sigma must be positive");
+        cnt[lm + 1]++; n_act++;
+    }
+    for (int l = 0; l < p->n_lm; l++) {
+        OV2_REQUIRE(p->lm_anchor_kf[l] >= 0 && p->lm_anchor_kf[l] < p->n_kf, OV2_EINVAL, "lm_anchor_kf out of range");
+        cnt[l + 1] += cnt[l];
+    }
+    std::vector<int> pose_col(p->n_kf);
+    int n_opt = 0;
+    for (int k = 0; k < p->n_kf; k++) pose_col[k] = p->kf_const[k] ? -1 : 6 * n_opt++;
+    const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
+    OV2_REQUIRE(nfp <= 2048, OV2_EUNSUPPORTED, "more than 341 optimised keyframes: dense reduced system too large");
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
+    std::vector<uint8_t> res_type(n_act);
+    std::vector<double> res_uv(2 * (size_t)n_act), res_sigma(n_act);
+    for (int i = 0; i < p->n_res; i++) {
+        if (p->res_active && !p->res_active[i]) continue;
+        const int k = fill[p->res_lm[i]]++;
+        res_type[k] = p->res_type[i]; res_kf[k] = p->res_type[i] == OV2_RES_RIGHT_ANCH ? p->lm_anchor_kf[p->res_lm[i]] : p->res_kf[i];
+        res_orig[k] = i; res_uv[2 * k] = p->res_uv[2 * i]; res_uv[2 * k + 1] = p->res_uv[2 * i + 1]; res_sigma[k] = p->res_sigma[i];
+    }
+
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    ov2_ba_dev *dev = new (std::nothrow) ov2_ba_dev();
+    OV2_REQUIRE(dev != nullptr, OV2_ENOMEM, "out of host memory");
+    dev->device = ctx->device; dev->n_res = p->n_res;
+    dev->h_poses0.assign(p->poses, p->poses + 7 * (size_t)p->n_kf);
+    dev->h_lam0.assign(p->invdepth, p->invdepth + (p->n_lm > 0 ? p->n_lm : 0));
+    BADev &D = dev->D;
+    memset(&D, 0, sizeof(D));
+    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp;
+    const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
+    const size_t o_pose_col = take(4 * (size_t)p->n_kf), o_lm_ptr = take(4 * (nl + 1)), o_lm_anchor = take(4 * nl), o_lm_auv = take(16 * nl);
+    const size_t o_res_type = take(na), o_res_kf = take(4 * na), o_res_orig = take(4 * na), o_res_uv = take(16 * na), o_res_sigma = take(8 * na);
+    const size_t o_x_pose = take(56 * (size_t)p->n_kf), o_c_pose = take(56 * (size_t)p->n_kf), o_x_RT = take(96 * (size_t)p->n_kf), o_c_RT = take(96 * (size_t)p->n_kf);
+    const size_t o_x_lam = take(8 * nl), o_c_lam = take(8 * nl), o_scale_f = take(8 * (size_t)nfp), o_diag_f = take(8 * (size_t)nfp);
+    const size_t o_scale_l = take(8 * nl), o_diag_l = take(8 * nl), o_ete = take(8 * nl), o_etb = take(8 * nl), o_cl = take(8 * nl), o_ce = take(8 * nl);
+    const size_t o_W = take(8 * nl * nfp), o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
+    const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
+    const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl));
+    dev->pool_bytes = off;
+    hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
+    if (e != hipSuccess) { delete dev; ov2_set_error("hipMalloc(%zu): %s", off, hipGetErrorString(e)); return OV2_ENOMEM; }
+    uint8_t *b = (uint8_t *)dev->pool;
+    D.pose_col = (int *)(b + o_pose_col); D.lm_ptr = (int *)(b + o_lm_ptr); D.lm_anchor = (int *)(b + o_lm_anchor); D.lm_auv = (double *)(b + o_lm_auv);
+    D.res_type = b + o_res_type; D.res_kf = (int *)(b + o_res_kf); D.res_orig = (int *)(b + o_res_orig); D.res_uv = (double *)(b + o_res_uv); D.res_sigma = (double *)(b + o_res_sigma);
+    D.x_pose = (double *)(b + o_x_pose); D.c_pose = (double *)(b + o_c_pose); D.x_RT = (double *)(b + o_x_RT); D.c_RT = (double *)(b + o_c_RT);
+    D.x_lam = (double *)(b + o_x_lam); D.c_lam = (double *)(b + o_c_lam); D.scale_f = (double *)(b + o_scale_f); D.diag_f = (double *)(b + o_diag_f);
+    D.scale_l = (double *)(b + o_scale_l); D.diag_l = (double *)(b + o_diag_l); D.ete = (double *)(b + o_ete); D.etb = (double *)(b + o_etb);
+    D.cl = (double *)(b + o_cl); D.ce = (double *)(b + o_ce); D.W = (double *)(b + o_W); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
+    D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
+    D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
+    for (int i = 0; i < 4; i++) { D.calib_l[i] = p->calib_l[i]; D.calib_r[i] = p->calib_r[i]; }
+    {   // Trl: normalised quaternion -> R (host)
+        double q[4] = {p->T_rl[3], p->T_rl[4], p->T_rl[5], p->T_rl[6]};
+        const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n > 0) { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; } else { q[0] = q[1] = q[2] = 0; q[3] = 1; }
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        D.Rrl[0] = 1 - 2 * (y * y + z * z); D.Rrl[1] = 2 * (x * y - z * w); D.Rrl[2] = 2 * (x * z + y * w);
+        D.Rrl[3] = 2 * (x * y + z * w); D.Rrl[4] = 1 - 2 * (x * x + z * z); D.Rrl[5] = 2 * (y * z - x * w);
+        D.Rrl[6] = 2 * (x * z - y * w); D.Rrl[7] = 2 * (y * z + x * w); D.Rrl[8] = 1 - 2 * (x * x + y * y);
+        D.trl[0] = p->T_rl[0]; D.trl[1] = p->T_rl[1]; D.trl[2] = p->T_rl[2];
+    }
+    hipStream_t s = ctx->stream;
+#define UP(dst, src, bytes) do { if ((bytes) > 0) { hipError_t _e = hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, s); \
+        if (_e != hipSuccess) { (void)hipFree(dev->pool); delete dev; ov2_set_error("H2D: %s", hipGetErrorString(_e)); return OV2_EHIP; } } } while (0)
+    UP(D.pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
+    UP(D.lm_ptr, cnt.data(), 4 * ((size_t)p->n_lm + 1));
+    UP(D.lm_anchor, p->lm_anchor_kf, 4 * (size_t)p->n_lm);
+    UP(D.lm_auv, p->lm_anchor_uv, 16 * (size_t)p->n_lm);
+    UP(D.res_type, res_type.data(), (size_t)n_act);
+    UP(D.res_kf, res_kf.data(), 4 * (size_t)n_act);
+    UP(D.res_orig, res_orig.data(), 4 * (size_t)n_act);
+    UP(D.res_uv, res_uv.data(), 16 * (size_t)n_act);
+    UP(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
+#undef UP
+    // the staging vectors die at return: make sure the copies are done
+    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    *out = dev;
+    return OV2_OK;
+}
+
+static void ba_destroy(ov2_ba_dev *dev)
+{
+    if (!dev) return;
+    (void)hipSetDevice(dev->device);
+    if (dev->pool) (void)hipFree(dev->pool);
+    delete dev;
+}
+
+static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba_result *r,
+                  const double *chi2_init, const uint8_t *dpos_init)
+{
+    OV2_REQUIRE(o && r, OV2_EINVAL, "NULL options/result");
+    OV2_REQUIRE(o->max_iter >= 0 && o->initial_radius > 0 && o->min_lm_diagonal > 0 && o->min_lm_diagonal <= o->max_lm_diagonal,
+                OV2_EINVAL, "bad solver options");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    BADev D = dev->D;
+    D.huber = o->huber_delta;
+    hipStream_t s = ctx->stream;
+    BAOpt O;
+    O.max_iter = o->max_iter; O.ftol = o->function_tolerance; O.gtol = o->gradient_tolerance; O.ptol = o->parameter_tolerance;
+    O.max_radius = o->max_radius; O.min_radius = o->min_radius; O.min_diag = o->min_lm_diagonal; O.max_diag = o->max_lm_diagonal;
+    O.min_rel_decrease = o->min_relative_decrease; O.jacobi = o->jacobi_scaling; O.max_invalid = o->max_consecutive_invalid_steps;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    OV2_HIP_CHECK(hipEventCreate(&e0));
+    OV2_HIP_CHECK(hipEventCreate(&e1));
+    // state reset: x = initial parameters, everything else zero, scales one
+    OV2_HIP_CHECK(hipMemcpyAsync(D.x_pose, dev->h_poses0.data(), 56 * (size_t)D.n_kf, hipMemcpyHostToDevice, s));
+    if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.x_lam, dev->h_lam0.data(), 8 * (size_t)D.n_lm, hipMemcpyHostToDevice, s));
+    if (chi2_init) OV2_HIP_CHECK(hipMemcpyAsync(D.chi2, chi2_init, 8 * (size_t)dev->n_res, hipMemcpyHostToDevice, s));
+    else OV2_HIP_CHECK(hipMemsetAsync(D.chi2, 0xFF, 8 * (size_t)std::max(1, dev->n_res), s));     // NaN pattern
+    if (dpos_init) OV2_HIP_CHECK(hipMemcpyAsync(D.dpos, dpos_init, (size_t)dev->n_res, hipMemcpyHostToDevice, s));
+    else OV2_HIP_CHECK(hipMemsetAsync(D.dpos, 0, (size_t)std::max(1, dev->n_res), s));
+    OV2_HIP_CHECK(hipEventRecord(e0, s));
+    BACtl h_ctl;
+    memset(&h_ctl, 0, sizeof(h_ctl));
+    h_ctl.radius = o->initial_radius; h_ctl.decrease_factor = 2.0; h_ctl.x_norm = -1.0;
+    h_ctl.need_lin = 1; h_ctl.step_successful = 1;
+    h_ctl.termination = OV2_TERM_NO_CONVERGENCE;
+    OV2_HIP_CHECK(hipMemcpyAsync(D.ctl, &h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, s));
+    OV2_HIP_CHECK(hipMemsetAsync(D.H, 0, 8 * (size_t)D.nfp * D.nfp, s));
+    OV2_HIP_CHECK(hipMemsetAsync(D.bf, 0, 8 * (size_t)D.nfp, s));
+    OV2_HIP_CHECK(hipMemsetAsync(D.yf, 0, 8 * (size_t)D.nfp, s));
+    {   // scales = 1 (jacobi off) : fill through a tiny staging vector
+        std::vector<double> ones((size_t)std::max(D.nfp, std::max(1, D.n_lm)), 1.0);
+        OV2_HIP_CHECK(hipMemcpyAsync(D.scale_f, ones.data(), 8 * (size_t)D.nfp, hipMemcpyHostToDevice, s));
+        if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.scale_l, ones.data(), 8 * (size_t)D.n_lm, hipMemcpyHostToDevice, s));
+        OV2_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_ba_init, dim3((D.n_kf + 255) / 256), dim3(256), 0, s, D);
+
+    const int lin_blocks = std::max(1, (D.n_lm + 3) / 4);
+    const size_t lin_lds = 4 * (size_t)D.nfp * 8;
+    const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
+    int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
+    int lm_per_split = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
+    ksplit = std::max(1, (D.n_lm + lm_per_split - 1) / lm_per_split);
+    const int ws_blocks = std::max(1, std::min(1024, (D.n_lm + 3) / 4));
+
+    auto linearize = [&]() {
+        hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D);
+        hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
+    };
+    linearize();
+    for (int it = 0; it < o->max_iter; it++) {
+        hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
+        OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
+        if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, D, ntiles, lm_per_split);
+        hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(1024), 0, s, D);
+        hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
+        hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
+        hipLaunchKernelGGL(k_ba_cost, dim3(ws_blocks), dim3(256), 0, s, D);
+        hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D, O);
+        linearize();
+    }
+    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);    // final bookkeeping
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipEventRecord(e1, s));
+    // results
+    OV2_HIP_CHECK(hipMemcpyAsync(&h_ctl, D.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+    if (r->poses_out) OV2_HIP_CHECK(hipMemcpyAsync(r->poses_out, D.x_pose, 56 * (size_t)D.n_kf, hipMemcpyDeviceToHost, s));
+    if (r->invdepth_out && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->invdepth_out, D.x_lam, 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost, s));
+    if (r->chi2_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->chi2_last_eval, D.chi2, 8 * (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+    if (r->depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    OV2_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    r->iterations = h_ctl.n_steps; r->num_successful_steps = h_ctl.n_success;
+    r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
+    r->solve_ms = ms;
+    return OV2_OK;
+}
+
+extern "C" {
+
+void ov2_ba_default_options(ov2_ba_options *o)
+{
+    if (!o) return;
+    o->max_iter = 5; o->function_tolerance = 1e-3; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->huber_delta = sqrt(5.9915); o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32;
+    o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->min_relative_decrease = 1e-3; o->jacobi_scaling = 1;
+    o->max_consecutive_invalid_steps = 5;
+}
+
+int ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r)
+{
+    OV2_REQUIRE(ctx && p && o && r, OV2_EINVAL, "NULL argument");
+    ov2_ba_dev *dev = nullptr;
+    int rc = ba_create(ctx, p, &dev);
+    if (rc != OV2_OK) return rc;
+    // chi2 / depth flags of inactive residual blocks keep the caller's values (the reference's removed
+    // residual blocks keep their cached chi2err_): seed the device arrays with them
+    rc = ba_run(ctx, dev, o, r, p->res_active ? r->chi2_last_eval : nullptr, p->res_active ? r->depthpos_last_eval : nullptr);
+    ba_destroy(dev);
+    return rc;
+}
+
+int ov2_ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
+{
+    OV2_REQUIRE(ctx && out, OV2_EINVAL, "NULL argument");
+    *out = nullptr;
+    return ba_create(ctx, p, out);
+}
+
+int ov2_ba_solve_resident(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba_result *r)
+{
+    OV2_REQUIRE(ctx && dev, OV2_EINVAL, "NULL argument");
+    return ba_run(ctx, dev, o, r, nullptr, nullptr);
+}
+
+void ov2_ba_destroy(ov2_ba_dev *dev) { ba_destroy(dev); }
+
+} // extern "C"

@@ -1,0 +1,172 @@
+"""Host-side mirror of Optimizer::localBA's solve stage (/root/reference/src/optimizer.cpp:436-627)
+on the flat problem layout of include/ov2slam_hip.h.  The map walk that builds the problem
+(:43-430) and the write-back (:741-883) stay in the caller, exactly as the C++ adapter described
+in INTEGRATION.md does; everything Ceres did runs on the GPU through ov2_ba_solve."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+RES_LEFT, RES_RIGHT, RES_RIGHT_ANCH = 0, 1, 2
+TERMINATION = {0: "NO_CONVERGENCE", 1: "FUNCTION_TOLERANCE", 2: "PARAMETER_TOLERANCE", 3: "GRADIENT_TOLERANCE",
+               4: "MIN_RADIUS", 5: "INVALID_STEPS", 6: "FAILURE"}
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def pack_problem(prob, res_active=None):
+    """dict of arrays (see ov2slam_amd.synth.make_ba_problem) -> (BAProblem, keep-alive list)"""
+    keep = []
+
+    def arr(name, dt):
+        a = np.ascontiguousarray(prob[name], dt)
+        keep.append(a)
+        return a
+
+    P = L.BAProblem()
+    P.n_kf, P.n_lm, P.n_res = int(prob["n_kf"]), int(prob["n_lm"]), int(prob["n_res"])
+    P.poses = _dp(arr("poses", np.float64)); P.kf_const = _u8p(arr("kf_const", np.uint8))
+    P.invdepth = _dp(arr("invdepth", np.float64)); P.lm_anchor_kf = _ip(arr("lm_anchor_kf", np.int32))
+    P.lm_anchor_uv = _dp(arr("lm_anchor_uv", np.float64))
+    P.res_type = _u8p(arr("res_type", np.uint8)); P.res_kf = _ip(arr("res_kf", np.int32)); P.res_lm = _ip(arr("res_lm", np.int32))
+    P.res_uv = _dp(arr("res_uv", np.float64)); P.res_sigma = _dp(arr("res_sigma", np.float64))
+    if res_active is not None:
+        ra = np.ascontiguousarray(res_active, np.uint8)
+        keep.append(ra)
+        P.res_active = _u8p(ra)
+    for i in range(4):
+        P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
+    for i in range(7):
+        P.T_rl[i] = float(prob["T_rl"][i])
+    return P, keep
+
+
+def default_options(lib, **kw):
+    o = L.BAOptions()
+    lib.ov2_ba_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def solve(ctx, prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None):
+    """One ceres::Solve (ov2_ba_solve).  Returns a dict like oracle.ba_solve."""
+    lib = ctx.lib
+    opts = opts or default_options(lib)
+    P, keep = pack_problem(prob, res_active)
+    poses = np.zeros((P.n_kf, 7)); lam = np.zeros(max(1, P.n_lm))
+    chi2 = np.full(max(1, P.n_res), np.nan) if chi2_init is None else np.array(chi2_init, np.float64, copy=True)
+    dpos = np.zeros(max(1, P.n_res), np.uint8) if depthpos_init is None else np.array(depthpos_init, np.uint8, copy=True)
+    R = L.BAResult()
+    R.poses_out = _dp(poses); R.invdepth_out = _dp(lam); R.chi2_last_eval = _dp(chi2); R.depthpos_last_eval = _u8p(dpos)
+    L.check(lib.ov2_ba_solve(ctx.h, C.byref(P), C.byref(opts), C.byref(R)))
+    return dict(poses=poses, invdepth=lam[:P.n_lm], chi2=chi2[:P.n_res], depthpos=dpos[:P.n_res], iterations=R.iterations,
+                num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost, final_cost=R.final_cost,
+                termination=R.termination, solve_ms=R.solve_ms)
+
+
+class ResidentProblem:
+    """ov2_ba_create / ov2_ba_solve_resident: the problem stays in HBM between solves."""
+
+    def __init__(self, ctx, prob):
+        self.ctx, self.lib = ctx, ctx.lib
+        P, self._keep = pack_problem(prob)
+        self.n_kf, self.n_lm, self.n_res = P.n_kf, P.n_lm, P.n_res
+        h = C.c_void_p()
+        L.check(self.lib.ov2_ba_create(ctx.h, C.byref(P), C.byref(h)))
+        self.h = h
+        self.poses = np.zeros((P.n_kf, 7)); self.lam = np.zeros(max(1, P.n_lm))
+        self.chi2 = np.zeros(max(1, P.n_res)); self.dpos = np.zeros(max(1, P.n_res), np.uint8)
+
+    def solve(self, opts=None):
+        opts = opts or default_options(self.lib)
+        R = L.BAResult()
+        R.poses_out = _dp(self.poses); R.invdepth_out = _dp(self.lam)
+        R.chi2_last_eval = _dp(self.chi2); R.depthpos_last_eval = _u8p(self.dpos)
+        L.check(self.lib.ov2_ba_solve_resident(self.ctx.h, self.h, C.byref(opts), C.byref(R)))
+        return dict(poses=self.poses, invdepth=self.lam[:self.n_lm], chi2=self.chi2[:self.n_res], depthpos=self.dpos[:self.n_res],
+                    iterations=R.iterations, num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost,
+                    final_cost=R.final_cost, termination=R.termination, solve_ms=R.solve_ms)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ov2_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Optimizer:
+    """Mirror of /root/reference/include/optimizer.hpp:36-60 restricted to localBA.
+
+    localBA(problem, buse_robust_cost) runs optimizer.cpp:436-627 on a flat problem:
+      pass 1  Huber(sqrt(robust_mono_th)), 5 iterations, function_tolerance 1e-3          (:436-485)
+      outlier test  chi2err_ > robust_mono_th or depth <= 0 on the values cached by the last
+                    Evaluate of pass 1; residual blocks removed if
+                    apply_l2_after_robust                                                (:492-594)
+      pass 2  only if outliers were found: loss reset to L2 when both the left and the right
+              residual lists are still non-empty (mono runs keep Huber!), 10 iterations  (:603-627)
+    `solver` is injectable so that the tests can run the identical protocol on the oracle."""
+
+    def __init__(self, ctx=None, robust_mono_th=5.9915, apply_l2_after_robust=True, solver=None):
+        self.ctx = ctx
+        self.robust_mono_th = float(robust_mono_th)
+        self.apply_l2_after_robust = bool(apply_l2_after_robust)
+        self._solver = solver
+        self._stop = False
+
+    def signalStopLocalBA(self):          # optimizer.hpp:48
+        self._stop = True
+
+    def stopLocalBA(self):                # optimizer.hpp:49
+        return self._stop
+
+    def _solve(self, prob, res_active, chi2_init, depthpos_init, **opt_kw):
+        if self._solver is not None:
+            return self._solver(prob, res_active, chi2_init, depthpos_init, **opt_kw)
+        opts = default_options(self.ctx.lib, **opt_kw)
+        return solve(self.ctx, prob, opts, res_active, chi2_init, depthpos_init)
+
+    def localBA(self, prob, buse_robust_cost=True):
+        th = self.robust_mono_th
+        huber = math.sqrt(th) if buse_robust_cost else -1.0
+        n_res = int(prob["n_res"])
+        p1 = self._solve(prob, None, None, None, max_iter=5, function_tolerance=1e-3, huber_delta=huber)
+        bad = (p1["chi2"] > th) | (p1["depthpos"] == 0)
+        rtype = np.asarray(prob["res_type"])
+        nbbadobs = int(bad.sum())
+        out = dict(pass1=p1, bad_after_pass1=bad.copy(), l2_done=False)
+        poses, lam, chi2, dpos = p1["poses"], p1["invdepth"], p1["chi2"], p1["depthpos"]
+        active = np.ones(n_res, np.uint8)
+        if self.apply_l2_after_robust:
+            active[bad] = 0
+        if self.apply_l2_after_robust and buse_robust_cost and not self.stopLocalBA() and nbbadobs > 0:
+            left_remaining = bool(((rtype == RES_LEFT) & ~bad).any())
+            right_remaining = bool(((rtype == RES_RIGHT) & ~bad).any())
+            huber2 = -1.0 if (left_remaining and right_remaining) else huber       # :606-608
+            prob2 = dict(prob)
+            prob2["poses"] = poses; prob2["invdepth"] = lam
+            p2 = self._solve(prob2, active, chi2, dpos, max_iter=10, function_tolerance=1e-3, huber_delta=huber2)
+            out["pass2"] = p2; out["l2_done"] = True
+            poses, lam, chi2, dpos = p2["poses"], p2["invdepth"], p2["chi2"], p2["depthpos"]
+            # second outlier test on the residual blocks that are still in the problem (:637-735)
+            bad2 = (active == 1) & ((chi2 > th) | (dpos == 0))
+            bad = bad | bad2
+        out.update(poses=poses, invdepth=lam, chi2=chi2, depthpos=dpos, bad_obs=bad)
+        return out
