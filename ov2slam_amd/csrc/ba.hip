@@ -198,7 +198,7 @@ __device__ __forceinline__ int d_residual(const BADev &D, int type, const double
     if (type == OV2_RES_RIGHT_ANCH) { for (int k = 0; k < 9; k++) M[k] = D.Rrl[k]; }
     else if (type == OV2_RES_LEFT) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = RTo[3 * j + i]; }
     else for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
-        M[3 * i + j] = D.Rrl[3 * i] * RTo[j] + D.Rrl[3 * i + 1] * RTo[3 + j] + D.Rrl[3 * i + 2] * RTo[6 + j];   // Rrl * Rcw
+        M[3 * i + j] = D.Rrl[3 * i] * RTo[3 * j] + D.Rrl[3 * i + 1] * RTo[3 * j + 1] + D.Rrl[3 * i + 2] * RTo[3 * j + 2];   // Rrl * Rcw (Rcw = Rwc^T)
     double JR[6];
     for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) JR[3 * i + j] = Jc[3 * i] * M[j] + Jc[3 * i + 1] * M[3 + j] + Jc[3 * i + 2] * M[6 + j];
     if (type == OV2_RES_RIGHT_ANCH) {

@@ -1,0 +1,5 @@
+// compile_check.cpp -- keeps the C++ adapters compiling (g++ -fsyntax-only, see tests/test_abi.py)
+#include "feature_tracker.hpp"
+#include "feature_extractor.hpp"
+#include "optimizer.hpp"
+int main() { return 0; }

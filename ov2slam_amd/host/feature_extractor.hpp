@@ -1,0 +1,53 @@
+// feature_extractor.hpp -- C++ adapter with the signatures of the reference's FeatureExtractor grid
+// detectors (/root/reference/include/feature_extractor.hpp:40-46, src/feature_extractor.cpp:288-570).
+// Holds the same adaptive state (nfast_th_, dmaxquality_).  Errors degrade to an empty vector, like
+// the reference's empty-image path (:291-294, :446-449).
+#pragma once
+#include "ov2_types.hpp"
+
+namespace ov2 {
+
+class FeatureExtractor {
+public:
+    // reference: FeatureExtractor(size_t nmaxpts, size_t nmaxdist, double dmaxquality, int nfast_th)
+    FeatureExtractor(size_t nmaxpts, size_t nmaxdist, double dmaxquality, int nfast_th, int mask_mode = OV2_MASK_AS_EXECUTED)
+        : nmaxpts_(nmaxpts), nmaxdist_(nmaxdist), dmaxquality_(dmaxquality), nfast_th_(nfast_th), mask_mode_(mask_mode) {}
+
+    // reference: std::vector<cv::Point2f> detectGridFAST(const cv::Mat &im, const int ncellsize,
+    //                const std::vector<cv::Point2f> &vcurkps, const cv::Rect &roi)
+    std::vector<Point2f> detectGridFAST(Context &ctx, const Image8 &im, const int ncellsize,
+                                        const std::vector<Point2f> &vcurkps, const Rect & /*roi: unused there too*/)
+    {
+        if (im.empty()) return std::vector<Point2f>();
+        std::vector<Point2f> out((size_t)(im.cols / ncellsize) * (im.rows / ncellsize) + 1);
+        int n = 0;
+        const int rc = ov2_detect_grid_fast(ctx.get(), im.data, im.cols, im.rows, im.step, ncellsize,
+                                            vcurkps.empty() ? nullptr : &vcurkps[0].x, (int)vcurkps.size(),
+                                            &nfast_th_, mask_mode_, 1, &out[0].x, &n);
+        out.resize(rc == OV2_OK ? (size_t)n : 0);
+        return out;
+    }
+
+    // reference: std::vector<cv::Point2f> detectSingleScale(const cv::Mat &im, const int ncellsize,
+    //                const std::vector<cv::Point2f> &vcurkps, const cv::Rect &roi)
+    std::vector<Point2f> detectSingleScale(Context &ctx, const Image8 &im, const int ncellsize,
+                                           const std::vector<Point2f> &vcurkps, const Rect &roi)
+    {
+        if (im.empty()) return std::vector<Point2f>();
+        std::vector<Point2f> out(2 * (size_t)(im.cols / ncellsize) * (im.rows / ncellsize) + 1);
+        int n = 0;
+        const int r[4] = {roi.x, roi.y, roi.width, roi.height};
+        const int rc = ov2_detect_singlescale(ctx.get(), im.data, im.cols, im.rows, im.step, ncellsize,
+                                              vcurkps.empty() ? nullptr : &vcurkps[0].x, (int)vcurkps.size(),
+                                              r, &dmaxquality_, 1, &out[0].x, &n);
+        out.resize(rc == OV2_OK ? (size_t)n : 0);
+        return out;
+    }
+
+    size_t nmaxpts_, nmaxdist_;
+    double dmaxquality_;       // feature_extractor.hpp:50
+    int nfast_th_;             // feature_extractor.hpp:52
+    int mask_mode_;
+};
+
+}  // namespace ov2

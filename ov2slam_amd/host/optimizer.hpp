@@ -1,0 +1,101 @@
+// optimizer.hpp -- C++ adapter for the solve stage of Optimizer::localBA
+// (/root/reference/src/optimizer.cpp:436-627).  The map walk (:43-430) fills a FlatProblem instead of a
+// ceres::Problem (one push per AddParameterBlock / AddResidualBlock call); solve()
+// then replaces the two ceres::Solve calls and the outlier bookkeeping between them, and the caller's
+// write-back (:741-883) reads poses / invdepth / bad_obs from the result.
+#pragma once
+#include <cmath>
+#include "ov2_types.hpp"
+
+namespace ov2 {
+
+struct FlatProblem {
+    std::vector<double> poses;          // 7 per keyframe  [tx ty tz qx qy qz qw]   (PoseParametersBlock)
+    std::vector<uint8_t> kf_const;      // SetParameterBlockConstant
+    std::vector<double> invdepth;       // InvDepthParametersBlock
+    std::vector<int> lm_anchor_kf;
+    std::vector<double> lm_anchor_uv;   // 2 per landmark
+    std::vector<uint8_t> res_type;      // OV2_RES_*
+    std::vector<int> res_kf, res_lm;
+    std::vector<double> res_uv, res_sigma;
+    double calib_l[4] = {0, 0, 0, 0}, calib_r[4] = {0, 0, 0, 0}, T_rl[7] = {0, 0, 0, 0, 0, 0, 1};
+
+    int addKeyframe(const double pose[7], bool constant) { poses.insert(poses.end(), pose, pose + 7); kf_const.push_back(constant); return (int)kf_const.size() - 1; }
+    int addLandmark(double inv_depth, int anchor_kf, double u, double v) {
+        invdepth.push_back(inv_depth); lm_anchor_kf.push_back(anchor_kf); lm_anchor_uv.push_back(u); lm_anchor_uv.push_back(v);
+        return (int)invdepth.size() - 1;
+    }
+    int addResidual(int type, int kf, int lm, double u, double v, double sigma) {
+        res_type.push_back((uint8_t)type); res_kf.push_back(kf); res_lm.push_back(lm); res_uv.push_back(u); res_uv.push_back(v); res_sigma.push_back(sigma);
+        return (int)res_type.size() - 1;
+    }
+    ov2_ba_problem view(const uint8_t *res_active) const {
+        ov2_ba_problem p;
+        p.n_kf = (int)kf_const.size(); p.poses = poses.data(); p.kf_const = kf_const.data();
+        p.n_lm = (int)invdepth.size(); p.invdepth = invdepth.data(); p.lm_anchor_kf = lm_anchor_kf.data(); p.lm_anchor_uv = lm_anchor_uv.data();
+        p.n_res = (int)res_type.size(); p.res_type = res_type.data(); p.res_kf = res_kf.data(); p.res_lm = res_lm.data();
+        p.res_uv = res_uv.data(); p.res_sigma = res_sigma.data(); p.res_active = res_active;
+        for (int i = 0; i < 4; i++) { p.calib_l[i] = calib_l[i]; p.calib_r[i] = calib_r[i]; }
+        for (int i = 0; i < 7; i++) p.T_rl[i] = T_rl[i];
+        return p;
+    }
+};
+
+struct LocalBAResult {
+    bool ok = false, l2_done = false;
+    std::vector<double> poses, invdepth, chi2;
+    std::vector<uint8_t> depthpos, bad_obs;     // bad_obs[i] = 1: observation i is an outlier (:500-592, :637-735)
+    int iterations[2] = {0, 0};
+    double solve_ms[2] = {0, 0};
+};
+
+class Optimizer {
+public:
+    Optimizer(double robust_mono_th, bool apply_l2_after_robust) : robust_mono_th_(robust_mono_th), apply_l2_after_robust_(apply_l2_after_robust) {}
+    void signalStopLocalBA() { bstop_localba_ = true; }     // optimizer.hpp:48
+    bool stopLocalBA() const { return bstop_localba_; }     // optimizer.hpp:49
+
+    LocalBAResult solveLocalBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost) const
+    {
+        LocalBAResult R;
+        const size_t n_res = fp.res_type.size();
+        R.poses.resize(fp.poses.size()); R.invdepth.resize(fp.invdepth.size());
+        R.chi2.assign(n_res, 0.0); R.depthpos.assign(n_res, 1); R.bad_obs.assign(n_res, 0);
+        ov2_ba_options opt; ov2_ba_default_options(&opt);
+        opt.max_iter = 5; opt.function_tolerance = 1e-3;
+        opt.huber_delta = buse_robust_cost ? std::sqrt(robust_mono_th_) : -1.0;
+        ov2_ba_result res{};
+        res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
+        ov2_ba_problem p = fp.view(nullptr);
+        if (ov2_ba_solve(ctx.get(), &p, &opt, &res) != OV2_OK) return R;        // BA skipped
+        R.ok = true; R.iterations[0] = res.iterations; R.solve_ms[0] = res.solve_ms;
+        std::vector<uint8_t> active(n_res, 1);
+        size_t nbbad = 0; bool left_rem = false, right_rem = false;
+        for (size_t i = 0; i < n_res; i++) {
+            const bool bad = R.chi2[i] > robust_mono_th_ || !R.depthpos[i];
+            R.bad_obs[i] = bad; nbbad += bad;
+            if (bad && apply_l2_after_robust_) active[i] = 0;
+            if (!bad && fp.res_type[i] == OV2_RES_LEFT) left_rem = true;
+            if (!bad && fp.res_type[i] == OV2_RES_RIGHT) right_rem = true;
+        }
+        if (apply_l2_after_robust_ && buse_robust_cost && !stopLocalBA() && nbbad > 0) {
+            if (left_rem && right_rem) opt.huber_delta = -1.0;                   // :606-608
+            opt.max_iter = 10;
+            fp.poses = R.poses; fp.invdepth = R.invdepth;                        // warm start from pass 1
+            p = fp.view(active.data());
+            if (ov2_ba_solve(ctx.get(), &p, &opt, &res) == OV2_OK) {
+                R.l2_done = true; R.iterations[1] = res.iterations; R.solve_ms[1] = res.solve_ms;
+                for (size_t i = 0; i < n_res; i++)
+                    if (active[i] && (R.chi2[i] > robust_mono_th_ || !R.depthpos[i])) R.bad_obs[i] = 1;
+            }
+        }
+        return R;
+    }
+
+private:
+    double robust_mono_th_;
+    bool apply_l2_after_robust_;
+    bool bstop_localba_ = false;
+};
+
+}  // namespace ov2
