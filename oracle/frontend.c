@@ -52,12 +52,20 @@ void orc_pyr_down_u8(const uint8_t *src, int sw, int sh, int sstride,
                      uint8_t *dst, int dw, int dh, int dstride)
 {
     int *rows = (int *)malloc(sizeof(int) * (size_t)dw * 5);
+    /* interior columns need no border handling: 2x-2 >= 0 and 2x+2 <= sw-1 */
+    int xi0 = 1, xi1 = (sw - 3) / 2;           /* inclusive range of interior x */
+    if (xi1 > dw - 1) xi1 = dw - 1;
     for (int y = 0; y < dh; y++) {
         for (int k = 0; k < 5; k++) {
             int sy = reflect101(2 * y - 2 + k, sh);
             const uint8_t *s = src + (size_t)sy * sstride;
             int *row = rows + (size_t)k * dw;
             for (int x = 0; x < dw; x++) {
+                if (x >= xi0 && x <= xi1) {
+                    const uint8_t *q = s + 2 * x;
+                    row[x] = q[0] * 6 + (q[-1] + q[1]) * 4 + q[-2] + q[2];
+                    continue;
+                }
                 int x0 = reflect101(2 * x - 2, sw), x1 = reflect101(2 * x - 1, sw);
                 int x2 = reflect101(2 * x, sw), x3 = reflect101(2 * x + 1, sw);
                 int x4 = reflect101(2 * x + 2, sw);
@@ -316,7 +324,13 @@ static void lk_level_range(const lk_job *jb)
     }
 }
 
-static void *lk_thread(void *arg) { lk_level_range((const lk_job *)arg); return NULL; }
+static void *lk_thread(void *arg)
+{
+    /* points are independent across levels, so a thread walks all levels for its own range */
+    lk_job jb = *(const lk_job *)arg;
+    for (int level = jb.max_level; level >= 0; level--) { jb.level = level; lk_level_range(&jb); }
+    return NULL;
+}
 
 int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
                  const float *prev_xy, float *next_xy, int n,
@@ -338,24 +352,23 @@ int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
     for (int i = 0; i < n; i++) { status[i] = 1; if (err) err[i] = 0.f; if (iters_out) iters_out[i] = 0; }
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
-    for (int level = max_level; level >= 0; level--) {
-        lk_job jobs[64]; pthread_t th[64];
-        int per = (n + nthreads - 1) / nthreads, nt = 0;
-        for (int t = 0; t < nthreads; t++) {
-            int b = t * per, e = b + per; if (e > n) e = n;
-            if (b >= e) break;
-            lk_job *jb = &jobs[nt++];
-            jb->prev = prev; jb->next = next; jb->prev_xy = prev_xy; jb->next_xy = next_xy;
-            jb->status = status; jb->err = err; jb->win = win; jb->max_level = max_level;
-            jb->max_count = max_count; jb->epsilon = epsilon; jb->flags = flags;
-            jb->min_eig_threshold = min_eig_threshold; jb->iters_out = iters_out;
-            jb->level = level; jb->begin = b; jb->end = e;
-        }
-        if (nt == 1) lk_level_range(&jobs[0]);
-        else {
-            for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, lk_thread, &jobs[t]);
-            for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
-        }
+    lk_job jobs[64]; pthread_t th[64];
+    int per = (n + nthreads - 1) / nthreads, nt = 0;
+    for (int t = 0; t < nthreads; t++) {
+        int b = t * per, e = b + per; if (e > n) e = n;
+        if (b >= e) break;
+        lk_job *jb = &jobs[nt++];
+        jb->prev = prev; jb->next = next; jb->prev_xy = prev_xy; jb->next_xy = next_xy;
+        jb->status = status; jb->err = err; jb->win = win; jb->max_level = max_level;
+        jb->max_count = max_count; jb->epsilon = epsilon; jb->flags = flags;
+        jb->min_eig_threshold = min_eig_threshold; jb->iters_out = iters_out;
+        jb->level = max_level; jb->begin = b; jb->end = e;
+    }
+    if (nt == 1) lk_thread(&jobs[0]);
+    else {
+        for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, lk_thread, &jobs[t]);
+        lk_thread(&jobs[0]);
+        for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
     }
     return 0;
 }

@@ -116,67 +116,79 @@ def make_ba_problem(n_kf=50, n_lm=10000, obs_per_lm=30, stereo=False, seed=42, p
                     outlier_frac=0.02, pose_noise=(0.02, np.deg2rad(0.5)), invdepth_noise=0.05):
     """Synthetic anchored-inverse-depth local-BA problem: KFs on a 10 m arc
     looking inward (3 deg apart), landmarks in the viewed volume, each seen by a contiguous range
-    of `obs_per_lm` KFs starting at its anchor.  Returns a dict of flat numpy arrays in the layout
-    of ov2_ba_problem (include/ov2slam_hip.h) plus the ground truth."""
+    of `obs_per_lm` KFs starting at its anchor (the anchor's own left observation carries no factor,
+    src/optimizer.cpp:269-289).  Returns a dict of flat numpy arrays in the layout of ov2_ba_problem
+    (include/ov2slam_hip.h) plus the ground truth.  Residual blocks are emitted landmark by landmark:
+    [RIGHT_ANCH] then for every observer [LEFT, RIGHT]."""
     rng = np.random.default_rng(seed)
     fx = fy = 458.654; cx, cy = 367.215, 248.375
     K = np.array([fx, fy, cx, cy])
     obs_per_lm = min(obs_per_lm, n_kf)
+    th = np.deg2rad(3.0) * np.arange(n_kf)
+    ts = 10.0 * np.stack([np.cos(th), np.sin(th), np.zeros(n_kf)], 1)
+    zc = -np.stack([np.cos(th), np.sin(th), np.zeros(n_kf)], 1)
+    yc = np.tile(np.array([0, 0, -1.0]), (n_kf, 1))
+    xc = np.cross(yc, zc)
+    Rs = np.stack([xc, yc, zc], 2)                      # (n_kf,3,3) Rwc, columns = camera axes
     poses_gt = np.zeros((n_kf, 7))
-    Rs, ts = [], []
+    poses_gt[:, :3] = ts
     for k in range(n_kf):
-        th = np.deg2rad(3.0) * k
-        c = 10.0 * np.array([np.cos(th), np.sin(th), 0.0])
-        zc = -np.array([np.cos(th), np.sin(th), 0.0]); yc = np.array([0, 0, -1.0]); xc = np.cross(yc, zc)
-        R = np.stack([xc, yc, zc], 1)
-        Rs.append(R); ts.append(c)
-        poses_gt[k, :3] = c; poses_gt[k, 3:] = _quat_from_R(R)
+        poses_gt[k, 3:] = _quat_from_R(Rs[k])
     baseline = 0.11
     T_rl = np.array([-baseline, 0, 0, 0, 0, 0, 1.0])
 
-    def project(k, X, right=False):
-        pc = Rs[k].T @ (X - ts[k])
+    def project(kf, X, right=False):
+        pc = np.einsum("nji,nj->ni", Rs[kf], X - ts[kf])             # Rcw (X - t)
         if right:
             pc = pc + T_rl[:3]
-        return np.array([fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy]), pc[2]
+        return np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1), pc[:, 2]
 
     anchors = rng.integers(0, n_kf - obs_per_lm + 1, n_lm)
     X = np.stack([rng.uniform(-3, 3, n_lm), rng.uniform(-3, 3, n_lm), rng.uniform(-2, 2, n_lm)], 1)
-    lm_anchor_uv = np.zeros((n_lm, 2)); invdepth_gt = np.zeros(n_lm)
-    res_type, res_kf, res_lm, res_uv = [], [], [], []
-    is_outlier = []
-    for l in range(n_lm):
-        a = int(anchors[l])
-        uv, z = project(a, X[l])
-        lm_anchor_uv[l] = uv
-        invdepth_gt[l] = 1.0 / z
-        if stereo:
-            uvr, _ = project(a, X[l], True)
-            res_type.append(2); res_kf.append(a); res_lm.append(l); res_uv.append(uvr + rng.normal(0, px_noise, 2)); is_outlier.append(False)
-        for k in range(a + 1, a + obs_per_lm):
-            uvk, _ = project(k, X[l])
-            out = rng.uniform() < outlier_frac
-            n = rng.uniform(-50, 50, 2) if out else rng.normal(0, px_noise, 2)
-            res_type.append(0); res_kf.append(k); res_lm.append(l); res_uv.append(uvk + n); is_outlier.append(out)
-            if stereo:
-                uvr, _ = project(k, X[l], True)
-                res_type.append(1); res_kf.append(k); res_lm.append(l); res_uv.append(uvr + rng.normal(0, px_noise, 2)); is_outlier.append(False)
+    lm_anchor_uv, z_a = project(anchors, X)
+    invdepth_gt = 1.0 / z_a
+    n_obs = obs_per_lm - 1
+    lm_rep = np.repeat(np.arange(n_lm), n_obs)
+    kf_rep = (anchors[:, None] + 1 + np.arange(n_obs)[None, :]).reshape(-1)
+    uv_l, _ = project(kf_rep, X[lm_rep])
+    out_l = rng.uniform(size=len(lm_rep)) < outlier_frac
+    noise_l = np.where(out_l[:, None], rng.uniform(-50, 50, uv_l.shape), rng.normal(0, px_noise, uv_l.shape))
+    uv_l = uv_l + noise_l
+    if stereo:
+        uv_ra, _ = project(anchors, X, True)
+        uv_ra = uv_ra + rng.normal(0, px_noise, uv_ra.shape)
+        uv_r, _ = project(kf_rep, X[lm_rep], True)
+        uv_r = uv_r + rng.normal(0, px_noise, uv_r.shape)
+        per = 1 + 2 * n_obs
+        n_res = n_lm * per
+        res_type = np.zeros((n_lm, per), np.uint8); res_kf = np.zeros((n_lm, per), np.int32)
+        res_uv = np.zeros((n_lm, per, 2)); is_out = np.zeros((n_lm, per), bool)
+        res_type[:, 0] = 2; res_kf[:, 0] = anchors; res_uv[:, 0] = uv_ra
+        res_type[:, 1::2] = 0; res_type[:, 2::2] = 1
+        res_kf[:, 1::2] = kf_rep.reshape(n_lm, n_obs); res_kf[:, 2::2] = kf_rep.reshape(n_lm, n_obs)
+        res_uv[:, 1::2] = uv_l.reshape(n_lm, n_obs, 2); res_uv[:, 2::2] = uv_r.reshape(n_lm, n_obs, 2)
+        is_out[:, 1::2] = out_l.reshape(n_lm, n_obs)
+        res_lm = np.repeat(np.arange(n_lm, dtype=np.int32), per)
+        res_type = res_type.reshape(-1); res_kf = res_kf.reshape(-1); res_uv = res_uv.reshape(-1, 2); is_out = is_out.reshape(-1)
+    else:
+        n_res = len(lm_rep)
+        res_type = np.zeros(n_res, np.uint8); res_kf = kf_rep.astype(np.int32); res_lm = lm_rep.astype(np.int32)
+        res_uv = uv_l; is_out = out_l
     poses0 = poses_gt.copy()
     for k in range(n_kf):
         dt = rng.normal(0, pose_noise[0], 3); dw = rng.normal(0, pose_noise[1], 3)
-        R = _so3_exp(dw) @ Rs[k]
-        poses0[k, :3] = ts[k] + dt; poses0[k, 3:] = _quat_from_R(R)
+        poses0[k, :3] = ts[k] + dt; poses0[k, 3:] = _quat_from_R(_so3_exp(dw) @ Rs[k])
     kf_const = np.zeros(n_kf, np.uint8); kf_const[0] = 1
     if not stereo and n_kf > 1:
         kf_const[1] = 1
     poses0[kf_const == 1] = poses_gt[kf_const == 1]
     invdepth0 = invdepth_gt * (1 + rng.normal(0, invdepth_noise, n_lm))
-    n_res = len(res_type)
-    return dict(n_kf=n_kf, n_lm=n_lm, n_res=n_res,
+    return dict(n_kf=n_kf, n_lm=n_lm, n_res=int(n_res),
                 poses=np.ascontiguousarray(poses0), kf_const=kf_const,
                 invdepth=np.ascontiguousarray(invdepth0), lm_anchor_kf=anchors.astype(np.int32),
                 lm_anchor_uv=np.ascontiguousarray(lm_anchor_uv),
-                res_type=np.array(res_type, np.uint8), res_kf=np.array(res_kf, np.int32), res_lm=np.array(res_lm, np.int32),
-                res_uv=np.ascontiguousarray(np.array(res_uv, np.float64).reshape(-1, 2)), res_sigma=np.ones(n_res),
+                res_type=np.ascontiguousarray(res_type), res_kf=np.ascontiguousarray(res_kf, np.int32),
+                res_lm=np.ascontiguousarray(res_lm, np.int32),
+                res_uv=np.ascontiguousarray(res_uv, np.float64), res_sigma=np.ones(int(n_res)),
                 calib_l=K.copy(), calib_r=K.copy(), T_rl=T_rl,
-                poses_gt=poses_gt, invdepth_gt=invdepth_gt, is_outlier=np.array(is_outlier, bool))
+                poses_gt=poses_gt, invdepth_gt=invdepth_gt, is_outlier=np.ascontiguousarray(is_out))

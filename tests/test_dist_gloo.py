@@ -1,0 +1,78 @@
+"""N>1 path on CPU: world_size-2 gloo process group exercising the batch launcher logic
+(sequence assignment + all-gather of timings / ATE) that bench.py --gpus N and the offline
+batch-of-sequences mode rely on."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ov2slam_amd import batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = batch.assign_sequences(batch.EUROC_FRAMES, world)
+    mine = plan[rank]
+    frames = sum(batch.EUROC_FRAMES[s] for s in mine)
+    # a synthetic trajectory per rank: rotated + translated + 1 cm noise -> ATE ~ noise level
+    rng = np.random.default_rng(rank)
+    gt = np.cumsum(rng.normal(0, 0.1, (200, 3)), 0)
+    Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    est = (Rz @ gt.T).T + np.array([1.0, 2.0, 3.0]) + rng.normal(0, 0.01, gt.shape)
+    rmse, sq, n = batch.ate_rmse(est, gt)
+    dist.barrier()
+    stats = batch.gather_stats({"frames": frames, "seconds": 10.0 + rank, "ba_iterations": 100 * (rank + 1),
+                                "ba_seconds": 2.0, "ate_sq_sum": sq, "ate_n": n})
+    agg = batch.aggregate(stats)
+    t = torch.tensor([10.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)             # what bench.py does with the elapsed time
+    q.put((rank, mine, agg, float(t.item()), rmse))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, seqs0, agg0, tmax0, rmse0), (r1, seqs1, agg1, tmax1, rmse1) = res
+    assert sorted(seqs0 + seqs1) == sorted(batch.EUROC_FRAMES)           # every sequence exactly once
+    assert agg0 == agg1                                                  # all ranks see the same aggregate
+    assert agg0["frames"] == sum(batch.EUROC_FRAMES.values())
+    assert agg0["seconds"] == 11.0 and tmax0 == tmax1 == 11.0            # max over ranks
+    assert abs(agg0["fps"] - agg0["frames"] / 11.0) < 1e-9
+    assert agg0["ba_iters_per_s"] == 150.0
+    assert 0.005 < agg0["ate_rmse"] < 0.03 and rmse0 < 0.03 and rmse1 < 0.03
+
+
+def test_assign_sequences_is_balanced():
+    for world in (1, 2, 4, 8):
+        plan = batch.assign_sequences(batch.EUROC_FRAMES, world)
+        assert sorted(sum(plan, [])) == sorted(batch.EUROC_FRAMES)
+        loads = [sum(batch.EUROC_FRAMES[s] for s in p) for p in plan]
+        assert max(loads) <= 1.35 * (sum(loads) / world) + max(batch.EUROC_FRAMES.values()) * (world >= 8)
+
+
+def test_gather_stats_single_process():
+    s = batch.gather_stats({"frames": 5, "seconds": 2.0})
+    assert s == {"frames": [5.0], "seconds": [2.0]} and batch.aggregate(s)["fps"] == 2.5
