@@ -221,6 +221,13 @@ __device__ __forceinline__ int d_residual(const BADev &D, int type, const double
     return dp;
 }
 
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -229,21 +236,78 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------- linearize
-// grid: ceil(n_lm / 4) blocks of 256 threads; dynamic LDS: 4 * nfp doubles (one W row per wave)
-__global__ __launch_bounds__(256) void k_ba_linearize(BADev D)
+// Persistent wavefronts: wave w owns a contiguous chunk of the anchor-sorted landmark order, one lane
+// per residual block.  Pose-side sums are pre-aggregated in LDS (fp64 ds_add):
+//   block-shared  Hoo[n_opt][21], bo[n_opt][6]        (observer diagonal blocks, F^T b)
+//   per-wave      Hao[n_opt][36]                      (anchor x observer blocks of the CURRENT anchor)
+//   per-wave regs Haa[21], ba[6]                      (anchor diagonal block, flushed when the anchor changes)
+// and reach HBM as a few thousand atomics per workgroup instead of ~60 per residual block.
+// H is stored as its UPPER triangle only (row <= col).
+// dynamic LDS: 4*nfp (W rows) + n_opt*27 + 4*n_opt*36 doubles
+__device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, double v)
+{
+    if (r <= c) atomicAdd(&H[(long long)r * ld + c], v); else atomicAdd(&H[(long long)c * ld + r], v);
+}
+
+__global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__restrict__ lm_order)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->need_lin) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double *wrow = (double *)smem_raw + (threadIdx.x >> 6) * D.nfp;
-    const int lane = threadIdx.x & 63;
-    const int lm = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_opt = D.nf / 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *wrow = (double *)smem_raw + wave * D.nfp;
+    double *Hoo = (double *)smem_raw + 4 * D.nfp;
+    double *bo = Hoo + n_opt * 21;
+    double *Hao = bo + n_opt * 6 + wave * n_opt * 36;
+    for (int e = threadIdx.x; e < n_opt * 27 + 4 * n_opt * 36; e += blockDim.x) Hoo[e] = 0;
+    __syncthreads();
+
+    const int total_waves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int chunk = (D.n_lm + total_waves - 1) / total_waves;
+    const int i0 = gw * chunk, i1 = min(D.n_lm, i0 + chunk);
     double cost = 0;
-    if (lm < D.n_lm) {
-        for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
+    int cur_ca = -1;
+    double HaaAcc[21], baAcc[6];
+    for (int k = 0; k < 21; k++) HaaAcc[k] = 0;
+    for (int k = 0; k < 6; k++) baAcc[k] = 0;
+
+    auto flush_anchor = [&](int ca) {
+        if (ca < 0) return;
+        // anchor diagonal block + F^T b (uniform values in every lane; lanes 0..26 issue one atomic each)
+        if (lane < 21) {
+            int c = 0, d = 0, t = lane;
+            for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 21; q++) if (q == lane) v = HaaAcc[q];
+            if (v != 0.0) atomicAdd(&D.H[(long long)(ca + c) * D.nfp + ca + d], v);
+        } else if (lane < 27) {
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) if (q == lane - 21) v = baAcc[q];
+            if (v != 0.0) atomicAdd(&D.bf[ca + lane - 21], v);
+        }
+        for (int e = lane; e < n_opt * 36; e += 64) {
+            const double v = Hao[e];
+            if (v != 0.0) {
+                const int ob = e / 36, r = e - ob * 36, d = r / 6, c = r - d * 6;     // (Ja^T Jo)[d][c]
+                h_add_upper(D.H, D.nfp, ca + d, ob * 6 + c, v);
+                Hao[e] = 0;
+            }
+        }
+        for (int k = 0; k < 21; k++) HaaAcc[k] = 0;
+        for (int k = 0; k < 6; k++) baAcc[k] = 0;
+    };
+
+    for (int idx = i0; idx < i1; idx++) {
+        const int lm = lm_order[idx];
         const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
         const int a = D.lm_anchor[lm];
         const int ca = D.pose_col[a];
+        if (ca != cur_ca) { wave_lds_sync(); flush_anchor(cur_ca); wave_lds_sync(); cur_ca = ca; }
+        for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
+        wave_lds_sync();
         const double lam = D.x_lam[lm];
         const double auv[2] = {D.lm_auv[2 * lm], D.lm_auv[2 * lm + 1]};
         double ete = 0, etb = 0, wa[6] = {0, 0, 0, 0, 0, 0}, ba[6] = {0, 0, 0, 0, 0, 0}, Haa[21];
@@ -279,45 +343,50 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D)
                     }
                 }
                 if (co >= 0) {
+                    const int ob = co / 6;
+                    int t = 0;
                     for (int c = 0; c < 6; c++) {
-                        atomicAdd(&wrow[co + c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);      // LDS fp64 atomic (stereo L+R share o)
-                        atomicAdd(&D.bf[co + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
-                        for (int d = 0; d < 6; d++) {
-                            atomicAdd(&D.H[(long long)(co + c) * D.nfp + co + d], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
-                            if (cae >= 0) {
-                                const double vv = Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c];    // H[a_d][o_c]
-                                atomicAdd(&D.H[(long long)(cae + d) * D.nfp + co + c], vv);
-                                atomicAdd(&D.H[(long long)(co + c) * D.nfp + cae + d], vv);
-                            }
-                        }
+                        atomicAdd(&wrow[co + c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);      // LDS fp64 atomics
+                        atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+                        for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                        if (cae >= 0)
+                            for (int d = 0; d < 6; d++) atomicAdd(&Hao[ob * 36 + d * 6 + c], Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c]);
                     }
                 }
             }
         }
         ete = wave_sum(ete); etb = wave_sum(etb);
         if (ca >= 0) {
-            for (int c = 0; c < 6; c++) { wa[c] = wave_sum(wa[c]); ba[c] = wave_sum(ba[c]); }
-            for (int k = 0; k < 21; k++) Haa[k] = wave_sum(Haa[k]);
+            for (int c = 0; c < 6; c++) { wa[c] = wave_sum(wa[c]); baAcc[c] += wave_sum(ba[c]); }
+            for (int k = 0; k < 21; k++) HaaAcc[k] += wave_sum(Haa[k]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_sync();
         if (lane == 0) { D.ete[lm] = ete; D.etb[lm] = etb; }
-        if (ca >= 0) {
-            if (lane < 6) { wrow[ca + lane] += wa[lane]; atomicAdd(&D.bf[ca + lane], ba[lane]); }
-            if (lane == 0) {
-                int t = 0;
-                for (int c = 0; c < 6; c++)
-                    for (int d = c; d < 6; d++, t++) {
-                        atomicAdd(&D.H[(long long)(ca + c) * D.nfp + ca + d], Haa[t]);
-                        if (d != c) atomicAdd(&D.H[(long long)(ca + d) * D.nfp + ca + c], Haa[t]);
-                    }
-            }
+        if (ca >= 0 && lane < 6) {
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) if (q == lane) v = wa[q];
+            wrow[ca + lane] += v;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_sync();
         double *Wg = D.W + (long long)lm * D.nfp;
         for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
+        wave_lds_sync();
     }
+    wave_lds_sync();
+    flush_anchor(cur_ca);
+    __syncthreads();
+    // block-shared observer blocks
+    for (int e = threadIdx.x; e < n_opt * 21; e += blockDim.x) {
+        const double v = Hoo[e];
+        if (v != 0.0) {
+            const int ob = e / 21;
+            int t = e - ob * 21, c = 0, d = 0;
+            for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
+            atomicAdd(&D.H[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
+        }
+    }
+    for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
     cost = wave_sum(cost);
     if (lane == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
 }
@@ -490,13 +559,22 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 }
 
 // ---------------------------------------------------------------------------------- reduced system (1 block)
-// S = s_i s_j (H_ij - G_ij) + delta_ij diag_i / radius ; rhs = s_i (b_i - v_i); dense Cholesky; solve.
+// S = s_i s_j (H_ij - G_ij) + delta_ij diag_i / radius ; rhs = s_i (b_i - v_i); blocked Cholesky; solve.
+// Right-looking, 32-wide panels: the diagonal block is factored in LDS by one wavefront, the panel
+// below it is solved row-per-thread against that block and parked in LDS, and the trailing update
+// reads the panel from LDS only (each S entry is touched once per panel).
+#define CH_NB 32
+#define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
+
 __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *L11 = (double *)smem_raw;                       // CH_NB x CH_LDP
+    double *yv = L11 + CH_NB * CH_LDP;                      // nfp
+    double *P = yv + D.nfp;                                 // (n - CH_NB) x CH_LDP
     const int n = D.nf, ld = D.nfp, tid = threadIdx.x, nt = blockDim.x;
-    __shared__ double s_diag;
     __shared__ int s_fail;
     const double radius = ctl->radius;
     double *S = D.S;
@@ -504,55 +582,139 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
         const int i = e / n, j = e - i * n;
         if (j > i) continue;                               // lower triangle only
         const int gi = (i / BA_TILE <= j / BA_TILE) ? i : j, gj = (i / BA_TILE <= j / BA_TILE) ? j : i;   // G holds upper tiles
-        double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)i * ld + j] - D.G[(long long)gi * ld + gj]);
+        double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)j * ld + i] - D.G[(long long)gi * ld + gj]);   // H: upper triangle (j <= i)
         if (i == j) val += D.diag_f[i] / radius;
         S[(long long)i * ld + j] = val;
     }
-    for (int i = tid; i < n; i += nt) D.yf[i] = D.scale_f[i] * (D.bf[i] - D.v[i]);
+    for (int i = tid; i < D.nfp; i += nt) yv[i] = i < n ? D.scale_f[i] * (D.bf[i] - D.v[i]) : 0.0;
     if (tid == 0) s_fail = 0;
     __syncthreads();
-    // right-looking Cholesky, lower triangle, in HBM/L2 (n <= a few hundred)
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            const double d = S[(long long)j * ld + j];
-            if (!(d > 0.0) || !isfinite(d)) s_fail = 1;
-            s_diag = sqrt(d);
+
+    for (int k0 = 0; k0 < n; k0 += CH_NB) {
+        const int nb = min(CH_NB, n - k0);
+        const int m = n - k0 - nb;                          // rows below the diagonal block
+        // (a) diagonal block -> LDS
+        for (int e = tid; e < nb * nb; e += nt) {
+            const int i = e / nb, j = e - i * nb;
+            if (j <= i) L11[i * CH_LDP + j] = S[(long long)(k0 + i) * ld + k0 + j];
+        }
+        __syncthreads();
+        // (b) one wavefront factors it (lane i owns row i)
+        if (tid < 64) {
+            const int i = tid;
+            for (int c = 0; c < nb; c++) {
+                const double d = L11[c * CH_LDP + c];
+                if (!(d > 0.0) || !isfinite(d)) { if (tid == 0) s_fail = 1; break; }   // uniform: every lane reads the same d
+                const double dj = sqrt(d);
+                wave_lds_sync();
+                if (i == c) L11[c * CH_LDP + c] = dj;
+                else if (i > c && i < nb) L11[i * CH_LDP + c] /= dj;
+                wave_lds_sync();
+                if (i > c && i < nb) {
+                    const double lic = L11[i * CH_LDP + c];
+                    for (int j = c + 1; j <= i; j++) L11[i * CH_LDP + j] -= lic * L11[j * CH_LDP + c];
+                }
+                wave_lds_sync();
+            }
         }
         __syncthreads();
         if (s_fail) break;
-        const double dj = s_diag;
-        for (int i = j + tid; i < n; i += nt) S[(long long)i * ld + j] = (i == j) ? dj : S[(long long)i * ld + j] / dj;
+        // write the factored block back; (c) panel solve  X L11^T = A21, one row per thread
+        for (int e = tid; e < nb * nb; e += nt) {
+            const int i = e / nb, j = e - i * nb;
+            if (j <= i) S[(long long)(k0 + i) * ld + k0 + j] = L11[i * CH_LDP + j];
+        }
+        for (int t = tid; t < m; t += nt) {
+            double *row = S + (long long)(k0 + nb + t) * ld + k0;
+            double x[CH_NB];
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) {
+                if (j < nb) {
+                    double a = x[j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) a -= x[k] * L11[j * CH_LDP + k];
+                    x[j] = a / L11[j * CH_LDP + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) if (j < nb) { row[j] = x[j]; P[t * CH_LDP + j] = x[j]; }
+        }
         __syncthreads();
-        // trailing update: S[i][k] -= L[i][j] * L[k][j] for j < k <= i
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m; e += nt) {
-            const int ii = e / m, kk = e - ii * m;
-            if (kk > ii) continue;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            S[(long long)i * ld + k] -= S[(long long)i * ld + j] * S[(long long)k * ld + j];
+        // (d) trailing update  A22 -= P P^T  (lower triangle), 32x32 thread tiles
+        {
+            const int ty = tid >> 5, tx = tid & 31;
+            const int nbk = (m + 31) / 32;
+            for (int bi = 0; bi < nbk; bi++) {
+                const int i = bi * 32 + ty;
+                for (int bj = 0; bj <= bi; bj++) {
+                    const int j = bj * 32 + tx;
+                    if (i < m && j <= i) {
+                        double acc = 0;
+#pragma unroll 8
+                        for (int k = 0; k < CH_NB; k++) acc += P[i * CH_LDP + k] * P[j * CH_LDP + k];   // nb < 32 only in the last panel (m = 0)
+                        S[(long long)(k0 + nb + i) * ld + k0 + nb + j] -= acc;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
     if (s_fail) { if (tid == 0) ctl->lin_fail = 1; return; }
-    // forward / backward substitution by one wavefront (dot products reduced across lanes)
-    if (tid < 64) {
-        for (int i = 0; i < n; i++) {
-            double s = 0;
-            for (int k = tid; k < i; k += 64) s += S[(long long)i * ld + k] * D.yf[k];
-            s = wave_sum(s);
-            if (tid == 0) D.yf[i] = (D.yf[i] - s) / S[(long long)i * ld + i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // forward substitution  L y = rhs  (blocked; yv in LDS)
+    for (int k0 = 0; k0 < n; k0 += CH_NB) {
+        const int nb = min(CH_NB, n - k0);
+        for (int e = tid; e < nb * nb; e += nt) {
+            const int i = e / nb, j = e - i * nb;
+            if (j <= i) L11[i * CH_LDP + j] = S[(long long)(k0 + i) * ld + k0 + j];
         }
-        for (int i = n - 1; i >= 0; i--) {
-            double s = 0;
-            for (int k = i + 1 + tid; k < n; k += 64) s += S[(long long)k * ld + i] * D.yf[k];
-            s = wave_sum(s);
-            if (tid == 0) D.yf[i] = (D.yf[i] - s) / S[(long long)i * ld + i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __syncthreads();
+        if (tid < 64) {
+            const int i = tid;
+            for (int c = 0; c < nb; c++) {
+                if (i == c) yv[k0 + c] /= L11[c * CH_LDP + c];
+                wave_lds_sync();
+                if (i > c && i < nb) yv[k0 + i] -= L11[i * CH_LDP + c] * yv[k0 + c];
+                wave_lds_sync();
+            }
         }
+        __syncthreads();
+        for (int i = k0 + nb + tid; i < n; i += nt) {
+            const double *row = S + (long long)i * ld + k0;
+            double a = 0;
+            for (int k = 0; k < nb; k++) a += row[k] * yv[k0 + k];
+            yv[i] -= a;
+        }
+        __syncthreads();
     }
+    // backward substitution  L^T x = y
+    for (int k0 = ((n - 1) / CH_NB) * CH_NB; k0 >= 0; k0 -= CH_NB) {
+        const int nb = min(CH_NB, n - k0);
+        for (int e = tid; e < nb * nb; e += nt) {
+            const int i = e / nb, j = e - i * nb;
+            if (j <= i) L11[i * CH_LDP + j] = S[(long long)(k0 + i) * ld + k0 + j];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int i = tid;
+            for (int c = nb - 1; c >= 0; c--) {
+                if (i == c) yv[k0 + c] /= L11[c * CH_LDP + c];
+                wave_lds_sync();
+                if (i < c) yv[k0 + i] -= L11[c * CH_LDP + i] * yv[k0 + c];
+                wave_lds_sync();
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < k0; i += nt) {
+            double a = 0;
+            for (int k = 0; k < nb; k++) a += S[(long long)(k0 + k) * ld + i] * yv[k0 + k];
+            yv[i] -= a;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
 }
 
 // ---------------------------------------------------------------------------------- back substitution
@@ -602,9 +764,10 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
             const double yi = D.yf[i], si = D.scale_f[i];
             if (!isfinite(yi)) bad = 1;
             p1 += yi * si * D.bf[i];
-            double row = 0;
-            for (int j = 0; j < D.nf; j++) row += D.H[(long long)i * D.nfp + j] * D.scale_f[j] * D.yf[j];
-            p2 += yi * si * row;
+            // z^T H z over the stored upper triangle: sum_i z_i (H_ii z_i + 2 sum_{j>i} H_ij z_j)
+            double row = 0.5 * D.H[(long long)i * D.nfp + i] * si * yi;
+            for (int j = i + 1; j < D.nf; j++) row += D.H[(long long)i * D.nfp + j] * D.scale_f[j] * D.yf[j];
+            p2 += 2.0 * yi * si * row;
         }
         for (int l = tid; l < D.n_lm; l += nt) if (!isfinite(D.yl[l])) bad = 1;
     }
@@ -741,6 +904,7 @@ struct ov2_ba_dev {
     BADev D;
     void *pool = nullptr; size_t pool_bytes = 0;
     int n_res = 0;
+    int *lm_order = nullptr;            // landmarks sorted by anchor keyframe (device)
     std::vector<double> h_poses0, h_lam0;
     int device = 0;
 };
@@ -804,7 +968,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     const size_t o_scale_l = take(8 * nl), o_diag_l = take(8 * nl), o_ete = take(8 * nl), o_etb = take(8 * nl), o_cl = take(8 * nl), o_ce = take(8 * nl);
     const size_t o_W = take(8 * nl * nfp), o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
-    const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl));
+    const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
     dev->pool_bytes = off;
     hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
     if (e != hipSuccess) { delete dev; ov2_set_error("hipMalloc(%zu): %s", off, hipGetErrorString(e)); return OV2_ENOMEM; }
@@ -817,6 +981,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     D.cl = (double *)(b + o_cl); D.ce = (double *)(b + o_ce); D.W = (double *)(b + o_W); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
+    dev->lm_order = (int *)(b + o_lm_order);
     for (int i = 0; i < 4; i++) { D.calib_l[i] = p->calib_l[i]; D.calib_r[i] = p->calib_r[i]; }
     {   // Trl: normalised quaternion -> R (host)
         double q[4] = {p->T_rl[3], p->T_rl[4], p->T_rl[5], p->T_rl[6]};
@@ -831,6 +996,10 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     hipStream_t s = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) { hipError_t _e = hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, s); \
         if (_e != hipSuccess) { (void)hipFree(dev->pool); delete dev; ov2_set_error("H2D: %s", hipGetErrorString(_e)); return OV2_EHIP; } } } while (0)
+    std::vector<int> lm_order(p->n_lm);
+    for (int l = 0; l < p->n_lm; l++) lm_order[l] = l;
+    std::stable_sort(lm_order.begin(), lm_order.end(), [&](int x, int y) { return p->lm_anchor_kf[x] < p->lm_anchor_kf[y]; });
+    UP(dev->lm_order, lm_order.data(), 4 * (size_t)p->n_lm);
     UP(D.pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
     UP(D.lm_ptr, cnt.data(), 4 * ((size_t)p->n_lm + 1));
     UP(D.lm_anchor, p->lm_anchor_kf, 4 * (size_t)p->n_lm);
@@ -898,16 +1067,22 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     }
     hipLaunchKernelGGL(k_ba_init, dim3((D.n_kf + 255) / 256), dim3(256), 0, s, D);
 
-    const int lin_blocks = std::max(1, (D.n_lm + 3) / 4);
-    const size_t lin_lds = 4 * (size_t)D.nfp * 8;
+    const int n_opt = D.nf / 6;
+    const int lin_blocks = std::max(1, std::min(256, (D.n_lm + 15) / 16));
+    const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36) + 64;
+    OV2_REQUIRE(lin_lds <= 160 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
+    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
     int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
     int lm_per_split = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
     ksplit = std::max(1, (D.n_lm + lm_per_split - 1) / lm_per_split);
     const int ws_blocks = std::max(1, std::min(1024, (D.n_lm + 3) / 4));
+    const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
+    OV2_REQUIRE(chol_lds <= 160 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (max ~95 optimised keyframes)");
+    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_cholesky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
 
     auto linearize = [&]() {
-        hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D);
+        hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
     linearize();
@@ -915,7 +1090,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, D, ntiles, lm_per_split);
-        hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(1024), 0, s, D);
+        hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(1024), chol_lds, s, D);
         hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
         hipLaunchKernelGGL(k_ba_cost, dim3(ws_blocks), dim3(256), 0, s, D);

@@ -69,6 +69,10 @@ __device__ __forceinline__ double row_allreduce_exact(int p)
 __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
 __device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// every integer product on this path has operands below 2^23 (pixels, 14-bit weights, 13/14-bit
+// derivatives and differences, row indices, pitches): use the full-rate 24-bit multiplier
+// (v_mul_i32_i24 / v_mad_i32_i24) instead of the quarter-rate v_mul_lo_u32.
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
 
 template <int WIN>
 struct RowBytes {
@@ -156,10 +160,10 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
     int Iw[WIN], dIx[WIN], dIy[WIN];
     double A11d, A12d, A22d;
     {
-        const uint8_t *irow = itemI + LI.img_roi + (long long)(ipy + rr) * LI.img_pitch;
+        const uint8_t *irow = itemI + LI.img_roi + m24(ipy + rr, LI.img_pitch);
         const RowBytes<WIN> r0 = load_row<WIN>(irow, ipx);
         const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
-        const uint32_t *drow = (const uint32_t *)(itemI + LI.der_roi) + (long long)(ipy + rr) * LI.der_pitch + ipx;
+        const uint32_t *drow = (const uint32_t *)(itemI + LI.der_roi) + (m24(ipy + rr, LI.der_pitch) + ipx);
         uint32_t d0[WIN + 1], d1[WIN + 1];
 #pragma unroll
         for (int k = 0; k <= WIN; k++) d0[k] = drow[k];
@@ -168,15 +172,15 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
         int s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
         for (int x = 0; x < WIN; x++) {
-            const int ival = descale(r0.px(x) * iw00 + r0.px(x + 1) * iw01 + r1.px(x) * iw10 + r1.px(x + 1) * iw11, 14 - 5);
+            const int ival = descale(m24(r0.px(x), iw00) + m24(r0.px(x + 1), iw01) + m24(r1.px(x), iw10) + m24(r1.px(x + 1), iw11), 14 - 5);
             const int x00 = (int)(int16_t)(d0[x] & 0xFFFF), y00 = (int)d0[x] >> 16;
             const int x01 = (int)(int16_t)(d0[x + 1] & 0xFFFF), y01 = (int)d0[x + 1] >> 16;
             const int x10 = (int)(int16_t)(d1[x] & 0xFFFF), y10 = (int)d1[x] >> 16;
             const int x11 = (int)(int16_t)(d1[x + 1] & 0xFFFF), y11 = (int)d1[x + 1] >> 16;
-            const int ixval = descale(x00 * iw00 + x01 * iw01 + x10 * iw10 + x11 * iw11, 14);
-            const int iyval = descale(y00 * iw00 + y01 * iw01 + y10 * iw10 + y11 * iw11, 14);
+            const int ixval = descale(m24(x00, iw00) + m24(x01, iw01) + m24(x10, iw10) + m24(x11, iw11), 14);
+            const int iyval = descale(m24(y00, iw00) + m24(y01, iw01) + m24(y10, iw10) + m24(y11, iw11), 14);
             Iw[x] = ival; dIx[x] = ixval; dIy[x] = iyval;
-            if (row_active) { s11 += ixval * ixval; s12 += ixval * iyval; s22 += iyval * iyval; }
+            if (row_active) { s11 += m24(ixval, ixval); s12 += m24(ixval, iyval); s22 += m24(iyval, iyval); }
         }
         // per-lane partials: WIN * 4080^2 < 2^31 for WIN <= 15
         A11d = row_allreduce_exact(s11);
@@ -207,14 +211,14 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
         iw01 = cv_round(a * (1.f - b) * W14);
         iw10 = cv_round((1.f - a) * b * W14);
         iw11 = (1 << 14) - iw00 - iw01 - iw10;
-        const RowBytes<WIN> r0 = load_row<WIN>(jroi + (long long)(iny + rr) * LJ.img_pitch, inx);
+        const RowBytes<WIN> r0 = load_row<WIN>(jroi + m24(iny + rr, LJ.img_pitch), inx);
         const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
         int sb1 = 0, sb2 = 0;
 #pragma unroll
         for (int x = 0; x < WIN; x++) {
-            const int diff = descale(r0.px(x) * iw00 + r0.px(x + 1) * iw01 + r1.px(x) * iw10 + r1.px(x + 1) * iw11, 14 - 5) - Iw[x];
-            sb1 += diff * dIx[x];
-            sb2 += diff * dIy[x];
+            const int diff = descale(m24(r0.px(x), iw00) + m24(r0.px(x + 1), iw01) + m24(r1.px(x), iw10) + m24(r1.px(x + 1), iw11), 14 - 5) - Iw[x];
+            sb1 += m24(diff, dIx[x]);
+            sb2 += m24(diff, dIy[x]);
         }
         if (!row_active) { sb1 = 0; sb2 = 0; }
         // |diff * dI| <= 8160*4080 -> per-lane partial < WIN * 3.33e7 < 2^31 for WIN <= 15

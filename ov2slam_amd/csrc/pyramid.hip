@@ -21,88 +21,146 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-// ---- level 0: copy + REFLECT_101 border ---------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_level0(PyrDesc P, const uint8_t *__restrict__ src, int stride, long long src_item_stride)
+// ---- fused level kernel ------------------------------------------------------------------
+// One launch per level L: a 128x16 tile of level L (+2 halo) is staged in LDS with aligned dword
+// loads and consumed three times: (i) L == 0 only: the padded level-0 copy, (ii) the Scharr
+// derivative of level L (16-byte stores), (iii) level L+1 = pyrDown(level L) including its
+// REFLECT_101 border (mirrored stores).  Algorithmic traffic per level-L pixel: 1 B read,
+// 4 B (+1 B at L == 0, +0.25 B next level) written -- the HBM-streaming stage of the front-end.
+#define PT_W 128
+#define PT_H 16
+#define PT_LDS_DW 34                 // (PT_W + 8) / 4 dwords per tile row: columns x0-4 .. x0+131
+#define PT_ROWS (PT_H + 3)           // rows y0-2 .. y0+16
+
+// store one pixel of a level image at (x,y) and at its REFLECT_101 mirror positions inside the border
+__device__ __forceinline__ void store_px_with_border(uint8_t *roi, int pitch, int w, int h, int win, int x, int y, uint8_t v)
 {
-    const PyrLevelDesc L = P.lv[0];
-    const int b = blockIdx.z;
-    const int pw = L.w + 2 * P.win, ph = L.h + 2 * P.win;
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    const int py = blockIdx.y;
-    if (px >= pw || py >= ph) return;
-    const int x = px - P.win, y = py - P.win;
-    const int sx = reflect101(x, L.w), sy = reflect101(y, L.h);
-    uint8_t *dst = P.base + (long long)b * P.item_stride + L.img_roi;
-    dst[(long long)y * L.img_pitch + x] = src[(long long)b * src_item_stride + (long long)sy * stride + sx];
+    int xs[3], ys[3], nx = 0, ny = 0;
+    xs[nx++] = x; ys[ny++] = y;
+    if (x >= 1 && x <= win) xs[nx++] = -x;
+    if (x <= w - 2 && x >= w - 1 - win) xs[nx++] = 2 * (w - 1) - x;
+    if (y >= 1 && y <= win) ys[ny++] = -y;
+    if (y <= h - 2 && y >= h - 1 - win) ys[ny++] = 2 * (h - 1) - y;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) roi[(long long)ys[j] * pitch + xs[i]] = v;
 }
 
-// ---- level l>0: pyrDown of level l-1 (+ border) --------------------------------
-// One thread per padded output pixel; the border pixels recompute the stencil at
-// the reflected coordinate (no dependency on other threads).  The source level's
-// own REFLECT_101 border supplies the 2-pixel stencil overhang.
-__global__ __launch_bounds__(256) void k_pyr_down(PyrDesc P, int level)
+template <bool FROM_RAW>
+__global__ __launch_bounds__(256) void k_pyr_fused(PyrDesc P, int level, const uint8_t *__restrict__ raw, int raw_stride,
+                                                   long long raw_item_stride)
 {
-    const PyrLevelDesc S = P.lv[level - 1];
+    __shared__ uint32_t tile[PT_ROWS][PT_LDS_DW];
     const PyrLevelDesc L = P.lv[level];
     const int b = blockIdx.z;
-    const int pw = L.w + 2 * P.win, ph = L.h + 2 * P.win;
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    const int py = blockIdx.y;
-    if (px >= pw || py >= ph) return;
-    const int x = px - P.win, y = py - P.win;
-    const int ox = reflect101(x, L.w), oy = reflect101(y, L.h);
-    const uint8_t *s = P.base + (long long)b * P.item_stride + S.img_roi;
-    int acc = 0;
+    uint8_t *item = P.base + (long long)b * P.item_stride;
+    const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
+    const int tid = threadIdx.x;
+
+    // ---- stage the tile ----
+    for (int e = tid; e < PT_ROWS * PT_LDS_DW; e += 256) {
+        const int row = e / PT_LDS_DW, dc = e - row * PT_LDS_DW;
+        const int gy = y0 - 2 + row, gx = x0 - 4 + 4 * dc;
+        uint32_t v;
+        if (FROM_RAW) {
+            const uint8_t *src = raw + (long long)b * raw_item_stride;
+            const int sy = reflect101(gy, L.h);
+            if (gx >= 0 && gx + 3 < L.w && ((raw_stride | (int)(size_t)src) & 3) == 0) {
+                v = *(const uint32_t *)(src + (long long)sy * raw_stride + gx);
+            } else {
+                v = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int wy = (k == 0 || k == 4) ? 1 : (k == 2 ? 6 : 4);
-        const uint8_t *r = s + (long long)(2 * oy - 2 + k) * S.img_pitch + (2 * ox - 2);
-        const int row = r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4];
-        acc += wy * row;
+                for (int k = 0; k < 4; k++) v |= (uint32_t)src[(long long)sy * raw_stride + reflect101(gx + k, L.w)] << (8 * k);
+            }
+        } else {
+            // padded source: the REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed)
+            const int cy = min(max(gy, -P.win), L.h + P.win - 1);
+            const int cx = min(gx, L.w + P.win + 4) & ~3;
+            v = *(const uint32_t *)(item + L.img_roi + (long long)cy * L.img_pitch + cx);
+        }
+        tile[row][dc] = v;
     }
-    uint8_t *dst = P.base + (long long)b * P.item_stride + L.img_roi;
-    dst[(long long)y * L.img_pitch + x] = (uint8_t)((acc + 128) >> 8);
-}
+    __syncthreads();
 
-// ---- Scharr derivative of one level ---------------------------------------------
-__global__ __launch_bounds__(256) void k_scharr(PyrDesc P, int level)
-{
-    const PyrLevelDesc L = P.lv[level];
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= L.w || y >= L.h) return;
-    const uint8_t *s = P.base + (long long)b * P.item_stride + L.img_roi + (long long)y * L.img_pitch + x;
-    const int p = L.img_pitch;
-    const int a00 = s[-p - 1], a01 = s[-p], a02 = s[-p + 1];
-    const int a10 = s[-1],                 a12 = s[1];
-    const int a20 = s[p - 1],  a21 = s[p],  a22 = s[p + 1];
-    // t0 = 3*(up+down) + 10*mid per column ; t1 = down - up per column
-    const int t0l = (a00 + a20) * 3 + a10 * 10, t0r = (a02 + a22) * 3 + a12 * 10;
-    const int t1l = a20 - a00, t1c = a21 - a01, t1r = a22 - a02;
-    const int dx = t0r - t0l;
-    const int dy = (t1l + t1r) * 3 + t1c * 10;
-    uint32_t *d = (uint32_t *)(P.base + (long long)b * P.item_stride + L.der_roi) + (long long)y * L.der_pitch + x;
-    *d = ((uint32_t)(uint16_t)(int16_t)dx) | (((uint32_t)(uint16_t)(int16_t)dy) << 16);
+    const int ty = tid >> 5, tx = tid & 31;
+    const int x = x0 + 4 * tx, y = y0 + 2 * ty;          // this thread: pixels (x..x+3, y..y+1)
+    // bytes x-2 .. x+5 of the five rows y-2 .. y+2 (tile rows 2ty .. 2ty+4)
+    int p[5][8];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t a = tile[2 * ty + r][tx], bq = tile[2 * ty + r][tx + 1], c = tile[2 * ty + r][tx + 2];
+        p[r][0] = (a >> 16) & 0xFF; p[r][1] = a >> 24;
+        p[r][2] = bq & 0xFF; p[r][3] = (bq >> 8) & 0xFF; p[r][4] = (bq >> 16) & 0xFF; p[r][5] = bq >> 24;
+        p[r][6] = c & 0xFF; p[r][7] = (c >> 8) & 0xFF;
+    }
+
+    // ---- (i) level-0 copy with border ----
+    if (FROM_RAW) {
+        uint8_t *roi = item + L.img_roi;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int yy = y + rr;
+            if (yy >= L.h) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x + j < L.w) store_px_with_border(roi, L.img_pitch, L.w, L.h, P.win, x + j, yy, (uint8_t)p[2 + rr][2 + j]);
+        }
+    }
+    // ---- (ii) Scharr derivative of rows y, y+1 ----
+    {
+        uint32_t *droi = (uint32_t *)(item + L.der_roi);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int yy = y + rr;
+            if (yy >= L.h || x >= L.w) continue;
+            int t0[6], t1[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {                    // columns x-1 .. x+4
+                const int up = p[1 + rr][1 + k], mid = p[2 + rr][1 + k], dn = p[3 + rr][1 + k];
+                t0[k] = (up + dn) * 3 + mid * 10;
+                t1[k] = dn - up;
+            }
+            uint32_t out[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int dx = t0[j + 2] - t0[j];
+                const int dy = (t1[j] + t1[j + 2]) * 3 + t1[j + 1] * 10;
+                out[j] = ((uint32_t)(uint16_t)(int16_t)dx) | (((uint32_t)(uint16_t)(int16_t)dy) << 16);
+            }
+            uint32_t *d = droi + (long long)yy * L.der_pitch + x;
+            if (x + 3 < L.w) *(uint4 *)d = make_uint4(out[0], out[1], out[2], out[3]);
+            else for (int j = 0; j < 4 && x + j < L.w; j++) d[j] = out[j];
+        }
+    }
+    // ---- (iii) next level: pyrDown at (X, Y), (X+1, Y) with X = x/2, Y = y/2 ----
+    if (level + 1 < P.n_levels) {
+        const PyrLevelDesc N = P.lv[level + 1];
+        const int X = x >> 1, Y = y >> 1;
+        if (Y < N.h) {
+            uint8_t *nroi = item + N.img_roi;
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                if (X + o >= N.w) continue;
+                const int c = 2 + 2 * o;                     // centre byte index
+                int acc = 0;
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    const int hsum = p[r][c] * 6 + (p[r][c - 1] + p[r][c + 1]) * 4 + p[r][c - 2] + p[r][c + 2];
+                    acc += ((r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4)) * hsum;
+                }
+                store_px_with_border(nroi, N.img_pitch, N.w, N.h, P.win, X + o, Y, (uint8_t)((acc + 128) >> 8));
+            }
+        }
+    }
 }
 
 int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride)
 {
     const PyrDesc &P = p->d;
-    const int win = P.win;
-    {
-        const PyrLevelDesc &L = P.lv[0];
-        dim3 grid((L.w + 2 * win + 255) / 256, L.h + 2 * win, P.batch);
-        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, ctx->stream, P, img_d, stride, (long long)img_batch_stride);
-    }
     for (int l = 0; l < P.n_levels; l++) {
         const PyrLevelDesc &L = P.lv[l];
-        if (l > 0) {
-            dim3 grid((L.w + 2 * win + 255) / 256, L.h + 2 * win, P.batch);
-            hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, P, l);
-        }
-        dim3 grid((L.w + 255) / 256, L.h, P.batch);
-        hipLaunchKernelGGL(k_scharr, grid, dim3(256), 0, ctx->stream, P, l);
+        dim3 grid((L.w + PT_W - 1) / PT_W, (L.h + PT_H - 1) / PT_H, P.batch);
+        if (l == 0) hipLaunchKernelGGL(k_pyr_fused<true>, grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
+        else hipLaunchKernelGGL(k_pyr_fused<false>, grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
     }
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
