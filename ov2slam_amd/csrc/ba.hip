@@ -29,6 +29,7 @@
 #include <math.h>
 #include <float.h>
 #include <algorithm>
+#include <stdlib.h>
 #include <vector>
 
 #pragma clang fp contract(fast)   // BA parity is 1e-4 relative in fp64: FMA contraction is fine here
@@ -38,7 +39,8 @@
 struct BACtl {
     // accumulators
     double cost_acc;
-    double acc1, acc2;            // sum_l y_l g'_l ; sum_l (2 y_l s_l t_l + s_l^2 ete_l y_l^2)
+    double acc1, acc2, acc3;      // sum_l y_l g'_l ; sum_l (2 y_l s_l t_l + s_l^2 ete_l y_l^2) ; sum_l c_l t_l^2
+    unsigned long long dbg[8];    // phase clocks of the last k_ba_cholesky (wall_clock64 ticks)
     // LM / TR state
     double radius, decrease_factor;
     double x_cost, cand_cost, model_cost_change, x_norm, minimum_cost, initial_cost, gmax;
@@ -235,6 +237,19 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// sum over the workgroup (<= 16 wavefronts); result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *s_part)
+{
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) s_part[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int w = 0; w < nw; w++) t += s_part[w];
+    return t;
+}
+
 // ---------------------------------------------------------------------------------- linearize
 // Persistent wavefronts: wave w owns a contiguous chunk of the anchor-sorted landmark order, one lane
 // per residual block.  Pose-side sums are pre-aggregated in LDS (fp64 ds_add):
@@ -387,8 +402,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         }
     }
     for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
-    cost = wave_sum(cost);
-    if (lane == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+    __shared__ double s_part[4];
+    cost = block_sum(cost, s_part);
+    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
 }
 
 // ---------------------------------------------------------------------------------- cost only
@@ -417,8 +433,9 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
             cost += 0.5 * rho0;
         }
     }
-    cost = wave_sum(cost);
-    if (lane == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+    __shared__ double s_part[4];
+    cost = block_sum(cost, s_part);
+    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
 }
 
 // ---------------------------------------------------------------------------------- iteration begin (1 block)
@@ -480,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
             ctl->step_valid = 0;
             ctl->lin_fail = 0;
             ctl->n_steps++;
-            ctl->acc1 = 0; ctl->acc2 = 0;
+            ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0;
         }
     }
     __syncthreads();
@@ -590,6 +607,9 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
     if (tid == 0) s_fail = 0;
     __syncthreads();
 
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tc = wall_clock64();
+#define CH_TICK(i) do { const unsigned long long t_ = wall_clock64(); tk[i] += t_ - tc; tc = t_; } while (0)
+    CH_TICK(0);
     for (int k0 = 0; k0 < n; k0 += CH_NB) {
         const int nb = min(CH_NB, n - k0);
         const int m = n - k0 - nb;                          // rows below the diagonal block
@@ -618,6 +638,7 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
             }
         }
         __syncthreads();
+        CH_TICK(1);
         if (s_fail) break;
         // write the factored block back; (c) panel solve  X L11^T = A21, one row per thread
         for (int e = tid; e < nb * nb; e += nt) {
@@ -642,6 +663,7 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
             for (int j = 0; j < CH_NB; j++) if (j < nb) { row[j] = x[j]; P[t * CH_LDP + j] = x[j]; }
         }
         __syncthreads();
+        CH_TICK(2);
         // (d) trailing update  A22 -= P P^T  (lower triangle), 32x32 thread tiles
         {
             const int ty = tid >> 5, tx = tid & 31;
@@ -660,6 +682,7 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
             }
         }
         __syncthreads();
+        CH_TICK(3);
     }
     if (s_fail) { if (tid == 0) ctl->lin_fail = 1; return; }
 
@@ -715,6 +738,9 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
         __syncthreads();
     }
     for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
+    CH_TICK(4);
+    if (tid == 0) for (int i = 0; i < 6; i++) ctl->dbg[i] = tk[i];
+#undef CH_TICK
 }
 
 // ---------------------------------------------------------------------------------- back substitution
@@ -728,7 +754,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
     for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    double a1 = 0, a2 = 0;
+    double a1 = 0, a2 = 0, a3 = 0;
     for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
         if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) { if (lane == 0) D.yl[lm] = 0; continue; }
         const double *wr = D.W + (long long)lm * D.nfp;
@@ -742,10 +768,16 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
             D.yl[lm] = y;
             a1 += y * s * etb;
             a2 += 2.0 * y * s * t + s * s * ete * y * y;
+            a3 += c * t * t;                               // y_f^T G' y_f  (G' = scaled W^T C W)
         }
     }
-    a1 = wave_sum(a1); a2 = wave_sum(a2);
-    if (lane == 0) { if (a1 != 0.0) atomicAdd(&ctl->acc1, a1); if (a2 != 0.0) atomicAdd(&ctl->acc2, a2); }
+    __shared__ double s_part[4];
+    a1 = block_sum(a1, s_part); a2 = block_sum(a2, s_part); a3 = block_sum(a3, s_part);
+    if (threadIdx.x == 0) {
+        if (a1 != 0.0) atomicAdd(&ctl->acc1, a1);
+        if (a2 != 0.0) atomicAdd(&ctl->acc2, a2);
+        if (a3 != 0.0) atomicAdd(&ctl->acc3, a3);
+    }
 }
 
 // ---------------------------------------------------------------------------------- candidate (1 block)
@@ -757,17 +789,16 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
     __shared__ int s_flag;
     const int tid = threadIdx.x, nt = blockDim.x;
     int ok = !ctl->lin_fail;
-    // yf . g'_f  and  yf^T H'_pp yf  ; finite check
+    // yf . g'_f ; yf^T H'_pp yf from the solved system (S y = rhs, S = H' - G' + D^2):
+    //   y^T H' y = y . rhs + y^T G' y - sum_i D_i^2 y_i^2   with y^T G' y = sum_l c_l t_l^2 (k_ba_backsub)
     double p1 = 0, p2 = 0; int bad = 0;
     if (ok) {
+        const double radius = ctl->radius;
         for (int i = tid; i < D.nf; i += nt) {
             const double yi = D.yf[i], si = D.scale_f[i];
             if (!isfinite(yi)) bad = 1;
             p1 += yi * si * D.bf[i];
-            // z^T H z over the stored upper triangle: sum_i z_i (H_ii z_i + 2 sum_{j>i} H_ij z_j)
-            double row = 0.5 * D.H[(long long)i * D.nfp + i] * si * yi;
-            for (int j = i + 1; j < D.nf; j++) row += D.H[(long long)i * D.nfp + j] * D.scale_f[j] * D.yf[j];
-            p2 += 2.0 * yi * si * row;
+            p2 += yi * si * (D.bf[i] - D.v[i]) - (D.diag_f[i] / radius) * yi * yi;
         }
         for (int l = tid; l < D.n_lm; l += nt) if (!isfinite(D.yl[l])) bad = 1;
     }
@@ -785,7 +816,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
         int valid = 0;
         if (ok) {
             // model_cost_change = -(J step).(r + J step / 2) with step = -y  ==  y.g' - y^T H' y / 2
-            const double mcc = (P1 + ctl->acc1) - 0.5 * (P2 + ctl->acc2);
+            const double mcc = (P1 + ctl->acc1) - 0.5 * (P2 + ctl->acc3 + ctl->acc2);
             ctl->model_cost_change = mcc;
             valid = mcc > 0.0;
         }
@@ -1076,7 +1107,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
     int lm_per_split = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
     ksplit = std::max(1, (D.n_lm + lm_per_split - 1) / lm_per_split);
-    const int ws_blocks = std::max(1, std::min(1024, (D.n_lm + 3) / 4));
+    const int ws_blocks = std::max(1, std::min(512, (D.n_lm + 3) / 4));
     const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
     OV2_REQUIRE(chol_lds <= 160 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (max ~95 optimised keyframes)");
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_cholesky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
@@ -1113,6 +1144,9 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     r->iterations = h_ctl.n_steps; r->num_successful_steps = h_ctl.n_success;
     r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
     r->solve_ms = ms;
+    if (getenv("OV2_BA_DEBUG"))
+        fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): assemble %llu diag %llu panel %llu trail %llu solve %llu\n",
+                h_ctl.dbg[0], h_ctl.dbg[1], h_ctl.dbg[2], h_ctl.dbg[3], h_ctl.dbg[4]);
     return OV2_OK;
 }
 
