@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--seqs", type=int, default=64, help="sequences processed in lock-step per GPU")
+    ap.add_argument("--seqs", type=int, default=256, help="sequences processed in lock-step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the BA / detect / single-sequence sections")
     args = ap.parse_args()

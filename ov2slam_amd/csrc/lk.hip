@@ -35,6 +35,8 @@ struct LKParams {
 };
 
 #define DPP_ROW_SHL1   0x101
+#define DPP_ROW_SHL2   0x102
+#define DPP_ROW_SHL3   0x103
 #define DPP_QP_1032    0xB1
 #define DPP_QP_2301    0x4E
 #define DPP_ROW_ROR4   0x124
@@ -109,6 +111,94 @@ __device__ __forceinline__ RowBytes<WIN> row_from_next_lane(const RowBytes<WIN> 
     return o;
 }
 
+
+// ---- template rows for on-the-fly Scharr ---------------------------------------------------
+// bytes [x-1, x+WIN+2) of one padded image row (WIN+3 bytes), re-phased so that byte 0 is column x-1
+template <int WIN>
+struct TRow {
+    static constexpr int NB = WIN + 3;                 // bytes
+    static constexpr int NR = (NB + 3) / 4;            // dwords after re-alignment
+    static constexpr int ND = (NB + 3 + 3) / 4;        // aligned dwords covering NB bytes at any phase
+    uint32_t d[NR];
+    __device__ __forceinline__ int px(int k) const { return (int)((d[k >> 2] >> ((k & 3) * 8)) & 0xFFu); }
+};
+
+template <int WIN>
+__device__ __forceinline__ TRow<WIN> trow_load(const uint8_t *roi, const PyrLevelDesc &L, int x, int y)
+{
+    constexpr int ND = TRow<WIN>::ND, NR = TRow<WIN>::NR;
+    // rows beyond the padded buffer only feed derivatives of out-of-image rows (defined as 0): clamp
+    y = y < -L.pady ? -L.pady : (y > L.h + L.pady - 1 ? L.h + L.pady - 1 : y);
+    const uint8_t *rp = roi + m24(y, L.img_pitch);
+    const int x1 = x - 1, xa = x1 & ~3, sh = x1 - xa;
+    const uint32_t *p = (const uint32_t *)(rp + xa);
+    uint32_t raw[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) raw[i] = p[i];
+    TRow<WIN> r;
+#pragma unroll
+    for (int i = 0; i < NR; i++) r.d[i] = __builtin_amdgcn_alignbyte(raw[i + 1 < ND ? i + 1 : i], raw[i], (uint32_t)sh);
+    return r;
+}
+
+template <int WIN, int CTRL>
+__device__ __forceinline__ TRow<WIN> trow_dpp(const TRow<WIN> &r)
+{
+    TRow<WIN> o;
+#pragma unroll
+    for (int i = 0; i < TRow<WIN>::NR; i++) o.d[i] = (uint32_t)dpp_mov<CTRL>((int)r.d[i]);
+    return o;
+}
+
+// ---- search-image neighbourhood held in registers -----------------------------------------
+// Lane r of the 16-lane row holds bytes [jx0, jx0+16) of image row jy0 + r: a 16x16 block that
+// contains every (WIN+1)^2 bilinear footprint whose origin lies within +-NBH_R pixels of the
+// position the level started from.  A Gauss-Newton iteration then needs NO global load: it pulls
+// its two source rows from lanes r+oy, r+oy+1 (ds_bpermute inside the row / DPP) and re-phases the
+// columns with v_alignbyte.  Only when the track drifts further than NBH_R pixels is the block
+// re-fetched.  (SQ_WAIT_ANY was 56 % of the wave cycles with one global round trip per iteration.)
+template <int WIN> struct Nbh { static constexpr int R = (15 - WIN) / 2; static constexpr bool USE = (15 - WIN) / 2 >= 2; };
+
+struct NbhRegs { uint32_t d[4]; };
+
+__device__ __forceinline__ NbhRegs nbh_load(const uint8_t *jroi, const PyrLevelDesc &LJ, int jx0, int jy0, int r)
+{
+    // rows beyond the padded image are never consumed by a legal window: clamp them into the buffer
+    int row = jy0 + r;
+    row = row < -LJ.pady ? -LJ.pady : (row > LJ.h + LJ.pady - 1 ? LJ.h + LJ.pady - 1 : row);
+    const uint8_t *rp = jroi + m24(row, LJ.img_pitch);
+    const int xa = jx0 & ~3, sh = jx0 - xa;
+    const uint32_t *p = (const uint32_t *)(rp + xa);
+    uint32_t raw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) raw[i] = p[i];
+    NbhRegs n;
+#pragma unroll
+    for (int i = 0; i < 4; i++) n.d[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], (uint32_t)sh);
+    return n;
+}
+
+// window rows for lane r at offset (ox, oy) inside the neighbourhood
+template <int WIN>
+__device__ __forceinline__ RowBytes<WIN> nbh_window_row(const NbhRegs &n, int ox, int oy, int r)
+{
+    int src = r + oy; src = src > 15 ? 15 : src;
+    uint32_t g[5];
+#pragma unroll
+    for (int k = 0; k < 4; k++) g[k] = (uint32_t)__shfl((int)n.d[k], src, 16);
+    g[4] = 0;
+    const int q = ox >> 2;
+    const uint32_t sh = (uint32_t)(ox & 3);
+    RowBytes<WIN> o;
+#pragma unroll
+    for (int i = 0; i < RowBytes<WIN>::NR; i++) {
+        const uint32_t lo = q ? g[i + 1] : g[i];
+        const uint32_t hi = q ? (i + 2 <= 4 ? g[i + 2] : 0u) : g[i + 1];
+        o.d[i] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    }
+    return o;
+}
+
 struct LKPointState {
     float nx, ny;     // nextPts[i] as OpenCV stores it between levels
     int status;
@@ -156,29 +246,62 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
     const int rr = r <= WIN ? r : WIN;          // idle lanes (r > WIN) re-read the last row; results are masked
     const bool row_active = r < WIN;
 
+    // search-image neighbourhood around the position this level starts from (loads issued together
+    // with the template loads below: one memory round trip per level)
+    const uint8_t *jroi = itemJ + LJ.img_roi;
+    int jx0 = 0, jy0 = 0;
+    NbhRegs jn;
+    jn.d[0] = jn.d[1] = jn.d[2] = jn.d[3] = 0;
+    if (Nbh<WIN>::USE) {
+        // clamp the start so that an out-of-image search position (rejected below) cannot index outside the buffer
+        const float sx = nextx - halfWin, sy = nexty - halfWin;
+        int cx0 = cv_floor(fminf(fmaxf(sx, (float)(-WIN)), (float)(LJ.w - 1)));
+        int cy0 = cv_floor(fminf(fmaxf(sy, (float)(-WIN)), (float)(LJ.h - 1)));
+        jx0 = cx0 - Nbh<WIN>::R; jy0 = cy0 - Nbh<WIN>::R;
+        jn = nbh_load(jroi, LJ, jx0, jy0, r);
+    }
+
     // ---- template patch: I (5 fractional bits), dIx, dIy; exact sums of products ----
+    // The Scharr derivative image of the reference's pyramid is NOT materialised: lane q fetches image
+    // row ipy-1+q (columns ipx-1 .. ipx+WIN+1), the three rows below arrive through DPP row_shl:1..3,
+    // and the derivative at the (WIN+1)^2 integer positions of the bilinear footprint is evaluated in
+    // registers -- same integers as calcSharrDeriv + copyMakeBorder(BORDER_CONSTANT 0).
     int Iw[WIN], dIx[WIN], dIy[WIN];
     double A11d, A12d, A22d;
     {
-        const uint8_t *irow = itemI + LI.img_roi + m24(ipy + rr, LI.img_pitch);
-        const RowBytes<WIN> r0 = load_row<WIN>(irow, ipx);
-        const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
-        const uint32_t *drow = (const uint32_t *)(itemI + LI.der_roi) + (m24(ipy + rr, LI.der_pitch) + ipx);
-        uint32_t d0[WIN + 1], d1[WIN + 1];
+        const uint8_t *iroi = itemI + LI.img_roi;
+        const int rq = r <= WIN + 2 ? r : WIN + 2;                 // lanes 0..WIN+2 fetch rows ipy-1 .. ipy+WIN+1
+        const TRow<WIN> R0 = trow_load<WIN>(iroi, LI, ipx, ipy - 1 + rq);
+        const TRow<WIN> R1 = trow_dpp<WIN, DPP_ROW_SHL1>(R0);      // row ipy + r
+        const TRow<WIN> R2 = trow_dpp<WIN, DPP_ROW_SHL2>(R0);      // row ipy + r + 1
+        const TRow<WIN> R3 = trow_dpp<WIN, DPP_ROW_SHL3>(R0);      // row ipy + r + 2
+        // derivative rows Y0 = ipy + r (rows R0,R1,R2) and Y1 = Y0 + 1 (rows R1,R2,R3); byte k <-> column ipx-1+k
+        const int Y0 = ipy + rr;
+        const bool y0in = Y0 >= 0 && Y0 < LI.h, y1in = Y0 + 1 >= 0 && Y0 + 1 < LI.h;
+        int t0a[WIN + 3], t1a[WIN + 3], t0b[WIN + 3], t1b[WIN + 3];
 #pragma unroll
-        for (int k = 0; k <= WIN; k++) d0[k] = drow[k];
+        for (int k = 0; k < WIN + 3; k++) {
+            const int p0 = R0.px(k), p1 = R1.px(k), p2 = R2.px(k), p3 = R3.px(k);
+            t0a[k] = (p0 + p2) * 3 + p1 * 10; t1a[k] = p2 - p0;
+            t0b[k] = (p1 + p3) * 3 + p2 * 10; t1b[k] = p3 - p1;
+        }
+        int dx0[WIN + 1], dy0[WIN + 1], dx1[WIN + 1], dy1[WIN + 1];
 #pragma unroll
-        for (int k = 0; k <= WIN; k++) d1[k] = (uint32_t)dpp_mov<DPP_ROW_SHL1>((int)d0[k]);
+        for (int c = 0; c <= WIN; c++) {
+            const int X = ipx + c;
+            const bool xin = X >= 0 && X < LI.w;
+            const bool in0 = xin && y0in, in1 = xin && y1in;
+            dx0[c] = in0 ? t0a[c + 2] - t0a[c] : 0;
+            dy0[c] = in0 ? (t1a[c] + t1a[c + 2]) * 3 + t1a[c + 1] * 10 : 0;
+            dx1[c] = in1 ? t0b[c + 2] - t0b[c] : 0;
+            dy1[c] = in1 ? (t1b[c] + t1b[c + 2]) * 3 + t1b[c + 1] * 10 : 0;
+        }
         int s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
         for (int x = 0; x < WIN; x++) {
-            const int ival = descale(m24(r0.px(x), iw00) + m24(r0.px(x + 1), iw01) + m24(r1.px(x), iw10) + m24(r1.px(x + 1), iw11), 14 - 5);
-            const int x00 = (int)(int16_t)(d0[x] & 0xFFFF), y00 = (int)d0[x] >> 16;
-            const int x01 = (int)(int16_t)(d0[x + 1] & 0xFFFF), y01 = (int)d0[x + 1] >> 16;
-            const int x10 = (int)(int16_t)(d1[x] & 0xFFFF), y10 = (int)d1[x] >> 16;
-            const int x11 = (int)(int16_t)(d1[x + 1] & 0xFFFF), y11 = (int)d1[x + 1] >> 16;
-            const int ixval = descale(m24(x00, iw00) + m24(x01, iw01) + m24(x10, iw10) + m24(x11, iw11), 14);
-            const int iyval = descale(m24(y00, iw00) + m24(y01, iw01) + m24(y10, iw10) + m24(y11, iw11), 14);
+            const int ival = descale(m24(R1.px(x + 1), iw00) + m24(R1.px(x + 2), iw01) + m24(R2.px(x + 1), iw10) + m24(R2.px(x + 2), iw11), 14 - 5);
+            const int ixval = descale(m24(dx0[x], iw00) + m24(dx0[x + 1], iw01) + m24(dx1[x], iw10) + m24(dx1[x + 1], iw11), 14);
+            const int iyval = descale(m24(dy0[x], iw00) + m24(dy0[x + 1], iw01) + m24(dy1[x], iw10) + m24(dy1[x + 1], iw11), 14);
             Iw[x] = ival; dIx[x] = ixval; dIy[x] = iyval;
             if (row_active) { s11 += m24(ixval, ixval); s12 += m24(ixval, iyval); s22 += m24(iyval, iyval); }
         }
@@ -198,7 +321,6 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
     D = 1.f / D;
     nextx -= halfWin; nexty -= halfWin;
     float pdx = 0.f, pdy = 0.f;
-    const uint8_t *jroi = itemJ + LJ.img_roi;
     for (int j = 0; j < prm.max_iter; j++) {
         const int inx = cv_floor(nextx), iny = cv_floor(nexty);
         if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
@@ -211,7 +333,18 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
         iw01 = cv_round(a * (1.f - b) * W14);
         iw10 = cv_round((1.f - a) * b * W14);
         iw11 = (1 << 14) - iw00 - iw01 - iw10;
-        const RowBytes<WIN> r0 = load_row<WIN>(jroi + m24(iny + rr, LJ.img_pitch), inx);
+        RowBytes<WIN> r0;
+        if (Nbh<WIN>::USE) {
+            int ox = inx - jx0, oy = iny - jy0;
+            if ((unsigned)ox > (unsigned)(2 * Nbh<WIN>::R) || (unsigned)oy > (unsigned)(2 * Nbh<WIN>::R)) {
+                jx0 = inx - Nbh<WIN>::R; jy0 = iny - Nbh<WIN>::R;            // drifted: re-centre the block
+                jn = nbh_load(jroi, LJ, jx0, jy0, r);
+                ox = Nbh<WIN>::R; oy = Nbh<WIN>::R;
+            }
+            r0 = nbh_window_row<WIN>(jn, ox, oy, r);
+        } else {
+            r0 = load_row<WIN>(jroi + m24(iny + rr, LJ.img_pitch), inx);
+        }
         const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
         int sb1 = 0, sb2 = 0;
 #pragma unroll
@@ -332,9 +465,8 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
     case 9:  launch_fb_klt<9>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
     case 11: launch_fb_klt<11>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
     case 13: launch_fb_klt<13>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
-    case 15: launch_fb_klt<15>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
     default:
-        ov2_set_error("LK window %d has no kernel instance (supported: 5,7,9,11,13,15; the reference ships 9)", prm.win);
+        ov2_set_error("LK window %d has no kernel instance (supported: 5,7,9,11,13; the reference ships 9)", prm.win);
         return OV2_EUNSUPPORTED;
     }
     OV2_HIP_CHECK(hipGetLastError());

@@ -5,7 +5,9 @@
 // /root/reference/src/visual_front_end.cpp:1172, :53 and src/mapper.cpp:81.
 // Arithmetic (all integer, bit-exact vs the oracle):
 //   level l>0 : 5x5 [1 4 6 4 1]^2 pyrDown, (sum + 128) >> 8, REFLECT_101
-//   derivative: Scharr 3/10/3, int16 (dx,dy) interleaved, REFLECT_101 on the image
+//   derivative: Scharr 3/10/3, int16 (dx,dy) interleaved, REFLECT_101 on the image --
+//               NOT materialised in HBM: the LK kernel evaluates it in registers from the image
+//               rows it fetches anyway (lk.hip); k_scharr_level exists only for ov2_pyr_download.
 // Layout: see PyrDesc in common.hpp.  Every level image carries a REFLECT_101
 // border of >= win pixels so that (a) LK windows that hang over the image edge
 // read legal memory exactly like OpenCV's padded Mats and (b) the 5x5 / 3x3
@@ -23,10 +25,9 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 // ---- fused level kernel ------------------------------------------------------------------
 // One launch per level L: a 128x16 tile of level L (+2 halo) is staged in LDS with aligned dword
-// loads and consumed three times: (i) L == 0 only: the padded level-0 copy, (ii) the Scharr
-// derivative of level L (16-byte stores), (iii) level L+1 = pyrDown(level L) including its
-// REFLECT_101 border (mirrored stores).  Algorithmic traffic per level-L pixel: 1 B read,
-// 4 B (+1 B at L == 0, +0.25 B next level) written -- the HBM-streaming stage of the front-end.
+// loads and consumed twice: (i) L == 0 only: the padded level-0 copy, (iii) level L+1 =
+// pyrDown(level L) including its REFLECT_101 border (mirrored stores).  HBM traffic per level-0
+// pixel: 1 B read, 1 B + 0.25 B written (the reference's pyramid also stores 4 B/px of derivatives).
 #define PT_W 128
 #define PT_H 16
 #define PT_LDS_DW 34                 // (PT_W + 8) / 4 dwords per tile row: columns x0-4 .. x0+131
@@ -105,32 +106,6 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrDesc P, int level, const u
                 if (x + j < L.w) store_px_with_border(roi, L.img_pitch, L.w, L.h, P.win, x + j, yy, (uint8_t)p[2 + rr][2 + j]);
         }
     }
-    // ---- (ii) Scharr derivative of rows y, y+1 ----
-    {
-        uint32_t *droi = (uint32_t *)(item + L.der_roi);
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int yy = y + rr;
-            if (yy >= L.h || x >= L.w) continue;
-            int t0[6], t1[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {                    // columns x-1 .. x+4
-                const int up = p[1 + rr][1 + k], mid = p[2 + rr][1 + k], dn = p[3 + rr][1 + k];
-                t0[k] = (up + dn) * 3 + mid * 10;
-                t1[k] = dn - up;
-            }
-            uint32_t out[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int dx = t0[j + 2] - t0[j];
-                const int dy = (t1[j] + t1[j + 2]) * 3 + t1[j + 1] * 10;
-                out[j] = ((uint32_t)(uint16_t)(int16_t)dx) | (((uint32_t)(uint16_t)(int16_t)dy) << 16);
-            }
-            uint32_t *d = droi + (long long)yy * L.der_pitch + x;
-            if (x + 3 < L.w) *(uint4 *)d = make_uint4(out[0], out[1], out[2], out[3]);
-            else for (int j = 0; j < 4 && x + j < L.w; j++) d[j] = out[j];
-        }
-    }
     // ---- (iii) next level: pyrDown at (X, Y), (X+1, Y) with X = x/2, Y = y/2 ----
     if (level + 1 < P.n_levels) {
         const PyrLevelDesc N = P.lv[level + 1];
@@ -151,6 +126,26 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrDesc P, int level, const u
             }
         }
     }
+}
+
+
+// ---- Scharr derivative of one level of one item, on demand (ov2_pyr_download only) -----------
+__global__ __launch_bounds__(256) void k_scharr_level(PyrDesc P, int level, int b, uint32_t *__restrict__ out)
+{
+    const PyrLevelDesc L = P.lv[level];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= L.w || y >= L.h) return;
+    const uint8_t *s = P.base + (long long)b * P.item_stride + L.img_roi + (long long)y * L.img_pitch + x;
+    const int p = L.img_pitch;
+    const int a00 = s[-p - 1], a01 = s[-p], a02 = s[-p + 1];
+    const int a10 = s[-1],                 a12 = s[1];
+    const int a20 = s[p - 1],  a21 = s[p],  a22 = s[p + 1];
+    const int t0l = (a00 + a20) * 3 + a10 * 10, t0r = (a02 + a22) * 3 + a12 * 10;
+    const int t1l = a20 - a00, t1c = a21 - a01, t1r = a22 - a02;
+    const int dx = t0r - t0l;
+    const int dy = (t1l + t1r) * 3 + t1c * 10;
+    out[(long long)y * L.w + x] = ((uint32_t)(uint16_t)(int16_t)dx) | (((uint32_t)(uint16_t)(int16_t)dy) << 16);
 }
 
 int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride)
@@ -192,17 +187,11 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
         L.pady = win;
         L.img_padx = (int)round_up(win + 3, 16);           // aligned-dword row reads may start 3 B early
         L.img_pitch = (int)round_up(L.img_padx + lw + win + 8, 64);
-        L.der_padx = 16;
-        if (L.der_padx < win) L.der_padx = (int)round_up(win, 16);
-        L.der_pitch = (int)round_up(L.der_padx + lw + win, 16);
+        L.der_padx = 0; L.der_pitch = 0; L.der_roi = -1;    // derivatives are not stored (see header)
         const long long img_bytes = (long long)(lh + 2 * win) * L.img_pitch;
-        const long long der_bytes = (long long)(lh + 2 * win) * L.der_pitch * 4;
         off = round_up(off, 256);
         L.img_roi = off + (long long)L.pady * L.img_pitch + L.img_padx;
         off += img_bytes;
-        off = round_up(off, 256);
-        L.der_roi = off + ((long long)L.pady * L.der_pitch + L.der_padx) * 4;
-        off += der_bytes;
         D.n_levels = l + 1;
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
         if (lw <= win || lh <= win) break;     // buildOpticalFlowPyramid stops early
@@ -211,7 +200,7 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
     p->bytes = (size_t)D.item_stride * (size_t)batch;
     hipError_t e = hipMalloc((void **)&D.base, p->bytes);
     if (e != hipSuccess) { delete p; ov2_set_error("hipMalloc(%zu): %s", p->bytes, hipGetErrorString(e)); return OV2_ENOMEM; }
-    // derivative borders are BORDER_CONSTANT(0) and never written again
+    // alignment slack around the borders is read (never consumed) by the dword row loads: keep it defined
     e = hipMemsetAsync(D.base, 0, p->bytes, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(D.base); delete p; ov2_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return OV2_EHIP; }
     *out = p;
@@ -277,9 +266,15 @@ static int pyr_download_impl(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, u
                                        hipMemcpyDeviceToHost, ctx->stream));
     }
     if (deriv_h) {
-        const uint8_t *src = item + L.der_roi - ((long long)pad * L.der_pitch + pad) * 4;
-        OV2_HIP_CHECK(hipMemcpy2DAsync(deriv_h, (size_t)ow * 4, src, (size_t)L.der_pitch * 4, (size_t)ow * 4, (size_t)oh,
-                                       hipMemcpyDeviceToHost, ctx->stream));
+        // evaluate the derivative of this level on demand; border = BORDER_CONSTANT(0) like the reference's Mats
+        const size_t bytes = (size_t)L.w * L.h * 4;
+        const int rc = ctx->reserve_device(bytes);
+        if (rc != OV2_OK) return rc;
+        hipLaunchKernelGGL(k_scharr_level, dim3((L.w + 255) / 256, L.h), dim3(256), 0, ctx->stream, p->d, level, b, (uint32_t *)ctx->d_scratch);
+        OV2_HIP_CHECK(hipGetLastError());
+        if (pad) memset(deriv_h, 0, (size_t)ow * oh * 4);
+        OV2_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)deriv_h + ((size_t)pad * ow + pad) * 4, (size_t)ow * 4, ctx->d_scratch, (size_t)L.w * 4,
+                                       (size_t)L.w * 4, (size_t)L.h, hipMemcpyDeviceToHost, ctx->stream));
     }
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OV2_OK;
