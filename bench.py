@@ -234,6 +234,17 @@ def main():
     achieved = bytes_total / max(1, n_launch) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     tracked = float(status_d.float().mean().item())
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; they come
+    # from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of tools/profile.sh whose summary
+    # is committed under profiles/ (same workload and seqs_per_gpu, else null)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))
+        if tj.get("seqs_per_gpu") == S:
+            traffic = tj["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+
     if rank == 0:
         frames = args.steps * S * world
         out = {
@@ -247,7 +258,7 @@ def main():
                                    "(92 kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px",
                        "seqs_per_gpu": S, "keypoints_per_frame": NKPS, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fb_klt<9>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_total / max(1, n_launch),
                          "gn_iterations": iters, "patch_builds": visits},

@@ -23,31 +23,21 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-// ---- fused level kernel ------------------------------------------------------------------
-// One launch per level L: a 128x16 tile of level L (+2 halo) is staged in LDS with aligned dword
-// loads and consumed twice: (i) L == 0 only: the padded level-0 copy, (iii) level L+1 =
-// pyrDown(level L) including its REFLECT_101 border (mirrored stores).  HBM traffic per level-0
-// pixel: 1 B read, 1 B + 0.25 B written (the reference's pyramid also stores 4 B/px of derivatives).
+// ---- level kernel ----------------------------------------------------------------------------
+// One launch per level L: a 128x32 tile of level L (+2 halo) is staged in LDS with aligned dword
+// loads; each thread then owns 4 pixels x 4 rows:
+//   (i)   L == 0 only: the level-0 copy (four aligned dword stores straight from the tile),
+//   (iii) level L+1 = pyrDown(level L): a 2x2 block of outputs (two 2-byte stores).
+// Only ROI pixels are written here; the REFLECT_101 borders are filled by k_pyr_border (tiny).
+// HBM traffic per level-0 pixel: 1 B read, 1 B + 0.25 B written -- the reference's pyramid also
+// stores 4 B/px of derivatives, which this design never materialises.
 #define PT_W 128
-#define PT_H 16
+#define PT_H 32
 #define PT_LDS_DW 34                 // (PT_W + 8) / 4 dwords per tile row: columns x0-4 .. x0+131
-#define PT_ROWS (PT_H + 3)           // rows y0-2 .. y0+16
-
-// store one pixel of a level image at (x,y) and at its REFLECT_101 mirror positions inside the border
-__device__ __forceinline__ void store_px_with_border(uint8_t *roi, int pitch, int w, int h, int win, int x, int y, uint8_t v)
-{
-    int xs[3], ys[3], nx = 0, ny = 0;
-    xs[nx++] = x; ys[ny++] = y;
-    if (x >= 1 && x <= win) xs[nx++] = -x;
-    if (x <= w - 2 && x >= w - 1 - win) xs[nx++] = 2 * (w - 1) - x;
-    if (y >= 1 && y <= win) ys[ny++] = -y;
-    if (y <= h - 2 && y >= h - 1 - win) ys[ny++] = 2 * (h - 1) - y;
-    for (int j = 0; j < ny; j++)
-        for (int i = 0; i < nx; i++) roi[(long long)ys[j] * pitch + xs[i]] = v;
-}
+#define PT_ROWS (PT_H + 4)           // rows y0-2 .. y0+33
 
 template <bool FROM_RAW>
-__global__ __launch_bounds__(256) void k_pyr_fused(PyrDesc P, int level, const uint8_t *__restrict__ raw, int raw_stride,
+__global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const uint8_t *__restrict__ raw, int raw_stride,
                                                    long long raw_item_stride)
 {
     __shared__ uint32_t tile[PT_ROWS][PT_LDS_DW];
@@ -58,76 +48,100 @@ __global__ __launch_bounds__(256) void k_pyr_fused(PyrDesc P, int level, const u
     const int tid = threadIdx.x;
 
     // ---- stage the tile ----
+    const uint8_t *src = FROM_RAW ? raw + (long long)b * raw_item_stride : item + L.img_roi;
+    const bool aligned_src = FROM_RAW ? (((raw_stride | (int)(size_t)src) & 3) == 0) : true;
     for (int e = tid; e < PT_ROWS * PT_LDS_DW; e += 256) {
         const int row = e / PT_LDS_DW, dc = e - row * PT_LDS_DW;
         const int gy = y0 - 2 + row, gx = x0 - 4 + 4 * dc;
         uint32_t v;
         if (FROM_RAW) {
-            const uint8_t *src = raw + (long long)b * raw_item_stride;
             const int sy = reflect101(gy, L.h);
-            if (gx >= 0 && gx + 3 < L.w && ((raw_stride | (int)(size_t)src) & 3) == 0) {
-                v = *(const uint32_t *)(src + (long long)sy * raw_stride + gx);
-            } else {
+            const uint8_t *rp = src + sy * raw_stride;
+            if (aligned_src && gx >= 0 && gx + 3 < L.w) v = *(const uint32_t *)(rp + gx);
+            else {
                 v = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) v |= (uint32_t)src[(long long)sy * raw_stride + reflect101(gx + k, L.w)] << (8 * k);
+                for (int k = 0; k < 4; k++) v |= (uint32_t)rp[reflect101(gx + k, L.w)] << (8 * k);
             }
         } else {
-            // padded source: the REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed)
+            // padded source: its REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed)
             const int cy = min(max(gy, -P.win), L.h + P.win - 1);
             const int cx = min(gx, L.w + P.win + 4) & ~3;
-            v = *(const uint32_t *)(item + L.img_roi + (long long)cy * L.img_pitch + cx);
+            v = *(const uint32_t *)(src + cy * L.img_pitch + cx);
         }
         tile[row][dc] = v;
     }
     __syncthreads();
 
     const int ty = tid >> 5, tx = tid & 31;
-    const int x = x0 + 4 * tx, y = y0 + 2 * ty;          // this thread: pixels (x..x+3, y..y+1)
-    // bytes x-2 .. x+5 of the five rows y-2 .. y+2 (tile rows 2ty .. 2ty+4)
-    int p[5][8];
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        const uint32_t a = tile[2 * ty + r][tx], bq = tile[2 * ty + r][tx + 1], c = tile[2 * ty + r][tx + 2];
-        p[r][0] = (a >> 16) & 0xFF; p[r][1] = a >> 24;
-        p[r][2] = bq & 0xFF; p[r][3] = (bq >> 8) & 0xFF; p[r][4] = (bq >> 16) & 0xFF; p[r][5] = bq >> 24;
-        p[r][6] = c & 0xFF; p[r][7] = (c >> 8) & 0xFF;
-    }
+    const int x = x0 + 4 * tx, y = y0 + 4 * ty;          // this thread: pixels (x..x+3, y..y+3); tile rows 4ty+2 ..
+    if (x >= L.w || y >= L.h) return;
 
-    // ---- (i) level-0 copy with border ----
+    // ---- (i) level-0 copy ----
     if (FROM_RAW) {
         uint8_t *roi = item + L.img_roi;
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
+        for (int rr = 0; rr < 4; rr++) {
             const int yy = y + rr;
-            if (yy >= L.h) continue;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (x + j < L.w) store_px_with_border(roi, L.img_pitch, L.w, L.h, P.win, x + j, yy, (uint8_t)p[2 + rr][2 + j]);
+            if (yy >= L.h) break;
+            const uint32_t v = tile[4 * ty + 2 + rr][tx + 1];
+            uint8_t *d = roi + yy * L.img_pitch + x;
+            if (x + 3 < L.w) *(uint32_t *)d = v;
+            else for (int j = 0; j < 4 && x + j < L.w; j++) d[j] = (uint8_t)(v >> (8 * j));
         }
     }
-    // ---- (iii) next level: pyrDown at (X, Y), (X+1, Y) with X = x/2, Y = y/2 ----
+    // ---- (iii) next level: 2x2 outputs (X..X+1, Y..Y+1), X = x/2, Y = y/2 ----
     if (level + 1 < P.n_levels) {
         const PyrLevelDesc N = P.lv[level + 1];
         const int X = x >> 1, Y = y >> 1;
-        if (Y < N.h) {
-            uint8_t *nroi = item + N.img_roi;
+        // horizontal 5-tap sums of the seven rows y-2 .. y+4 at centre columns x and x+2
+        int h0[7], h1[7];
 #pragma unroll
-            for (int o = 0; o < 2; o++) {
-                if (X + o >= N.w) continue;
-                const int c = 2 + 2 * o;                     // centre byte index
-                int acc = 0;
+        for (int r = 0; r < 7; r++) {
+            const uint32_t a = tile[4 * ty + r][tx], q = tile[4 * ty + r][tx + 1], c = tile[4 * ty + r][tx + 2];
+            const int m2 = (a >> 16) & 0xFF, m1 = a >> 24;                         // columns x-2, x-1
+            const int p0 = q & 0xFF, p1 = (q >> 8) & 0xFF, p2 = (q >> 16) & 0xFF, p3 = q >> 24;   // x .. x+3
+            const int p4 = c & 0xFF;                                               // x+4
+            h0[r] = p0 * 6 + (m1 + p1) * 4 + m2 + p2;
+            h1[r] = p2 * 6 + (p1 + p3) * 4 + p0 + p4;
+        }
+        uint8_t *nroi = item + N.img_roi;
 #pragma unroll
-                for (int r = 0; r < 5; r++) {
-                    const int hsum = p[r][c] * 6 + (p[r][c - 1] + p[r][c + 1]) * 4 + p[r][c - 2] + p[r][c + 2];
-                    acc += ((r == 0 || r == 4) ? 1 : (r == 2 ? 6 : 4)) * hsum;
-                }
-                store_px_with_border(nroi, N.img_pitch, N.w, N.h, P.win, X + o, Y, (uint8_t)((acc + 128) >> 8));
-            }
+        for (int oy = 0; oy < 2; oy++) {
+            if (Y + oy >= N.h) break;
+            const int r = 2 * oy;                                                  // rows y-2+2oy .. y+2+2oy
+            const int v0 = (h0[r + 2] * 6 + (h0[r + 1] + h0[r + 3]) * 4 + h0[r] + h0[r + 4] + 128) >> 8;
+            const int v1 = (h1[r + 2] * 6 + (h1[r + 1] + h1[r + 3]) * 4 + h1[r] + h1[r + 4] + 128) >> 8;
+            uint8_t *d = nroi + (Y + oy) * N.img_pitch + X;
+            if (X + 1 < N.w) *(uint16_t *)d = (uint16_t)(v0 | (v1 << 8));         // X even, ROI origin / pitch even
+            else d[0] = (uint8_t)v0;
         }
     }
 }
 
+// ---- REFLECT_101 border of one level: thread per border pixel --------------------------------
+// border = padded rect [-win, w+win) x [-win, h+win) minus the ROI; enumerated as two horizontal
+// strips (full padded width) followed by two vertical strips (ROI height).
+__global__ __launch_bounds__(256) void k_pyr_border(PyrDesc P, int level)
+{
+    const PyrLevelDesc L = P.lv[level];
+    const int win = P.win, pw = L.w + 2 * win;
+    const int n_h = 2 * win * pw, n_v = 2 * win * L.h;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_h + n_v) return;
+    int x, y;
+    if (e < n_h) {
+        const int row = e / pw;
+        x = e - row * pw - win;
+        y = row < win ? row - win : L.h + (row - win);
+    } else {
+        const int f = e - n_h, row = f / (2 * win), c = f - row * (2 * win);
+        y = row;
+        x = c < win ? c - win : L.w + (c - win);
+    }
+    uint8_t *roi = P.base + (long long)blockIdx.z * P.item_stride + L.img_roi;
+    roi[y * L.img_pitch + x] = roi[reflect101(y, L.h) * L.img_pitch + reflect101(x, L.w)];
+}
 
 // ---- Scharr derivative of one level of one item, on demand (ov2_pyr_download only) -----------
 __global__ __launch_bounds__(256) void k_scharr_level(PyrDesc P, int level, int b, uint32_t *__restrict__ out)
@@ -151,11 +165,21 @@ __global__ __launch_bounds__(256) void k_scharr_level(PyrDesc P, int level, int 
 int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride)
 {
     const PyrDesc &P = p->d;
+    auto border = [&](int l) {
+        const PyrLevelDesc &L = P.lv[l];
+        const int n = 2 * P.win * (L.w + 2 * P.win) + 2 * P.win * L.h;
+        hipLaunchKernelGGL(k_pyr_border, dim3((n + 255) / 256, 1, P.batch), dim3(256), 0, ctx->stream, P, l);
+    };
     for (int l = 0; l < P.n_levels; l++) {
         const PyrLevelDesc &L = P.lv[l];
         dim3 grid((L.w + PT_W - 1) / PT_W, (L.h + PT_H - 1) / PT_H, P.batch);
-        if (l == 0) hipLaunchKernelGGL(k_pyr_fused<true>, grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
-        else hipLaunchKernelGGL(k_pyr_fused<false>, grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
+        if (l == 0) {
+            hipLaunchKernelGGL(k_pyr_level<true>, grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
+            border(0);
+        } else if (l + 1 < P.n_levels) {
+            hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
+        }
+        if (l + 1 < P.n_levels) border(l + 1);       // level l+1 was just produced
     }
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
