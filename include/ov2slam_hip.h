@@ -78,6 +78,17 @@ int  ov2_pyr_download_padded(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, u
 /* algorithmic HBM bytes of one build of one image (SURVEY.md 8d "B_pyr")       */
 size_t ov2_pyr_algorithmic_bytes(const ov2_pyr *p);
 
+/* ---- CLAHE ----------------------------------------------------------
+ * Replaces cv::CLAHE::apply(img_raw, cur_img_) -- src/visual_front_end.cpp:1159 (left image, every
+ * frame when use_clahe: 1), src/mapper.cpp:76 (right image) -- for the handle created at
+ * src/ov2slam.cpp:85-89: cv::createCLAHE(clip_limit = fclahe_val, tiles = (w/50, h/50)).
+ * CV_8UC1 only (what the reference feeds it).  _h: host buffers (drop-in); _d: `batch` images
+ * already in HBM, src and dst must not overlap. */
+int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
+                uint8_t *dst_h, int dst_stride);
+int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
+                double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride);
+
 /* ---- Lucas-Kanade --------------------------------------------------
  * ov2_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts,
  * nextPts, status, err, Size(win,win), max_level, TermCriteria(COUNT+EPS,

@@ -301,3 +301,13 @@ def ba_residual(rtype, calib_l, calib_r, T_rl, anchor_pose, obs_pose, invdepth, 
     dp = lib().orc_ba_residual(int(rtype), _p(cl), _p(cr), _p(trl), _p(ap), _p(op), C.c_double(invdepth), _p(auv), _p(uvv),
                                C.c_double(sigma), _p(r), _p(Ja), _p(Jo), _p(Jl), C.byref(chi2))
     return r, Ja.reshape(2, 6), Jo.reshape(2, 6), Jl, chi2.value, bool(dp)
+
+
+# ---------------------------------------------------------------- CLAHE
+def clahe(img, clip_limit, tiles_x, tiles_y):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty_like(img)
+    rc = lib().orc_clahe(_p(img), w, h, w, C.c_double(clip_limit), int(tiles_x), int(tiles_y), _p(out), w)
+    assert rc == 0, rc
+    return out

@@ -67,6 +67,11 @@ void orc_pyr_down_u8(const uint8_t *src, int sw, int sh, int sstride,
 void orc_scharr_u8(const uint8_t *src, int w, int h, int sstride,
                    int16_t *dst, int dstride_elems);
 
+/* cv::CLAHE::apply (CV_8UC1): src/ov2slam.cpp:85-89 (createCLAHE(fclahe_val, Size(w/50, h/50))),
+ * src/visual_front_end.cpp:1159, src/mapper.cpp:76.  dst may alias src only if strides match. */
+int orc_clahe(const uint8_t *src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t *dst, int dst_stride);
+
 /* ------------------------------------------------------------------ */
 /* LK (cv::calcOpticalFlowPyrLK, called at src/feature_tracker.cpp:66, */
 /* :113) and FeatureTracker::fbKltTracking (src/feature_tracker.cpp:35)*/

@@ -116,6 +116,23 @@ class Pyramid:
             pass
 
 
+class CLAHE:
+    """Mirror of the cv::CLAHE handle the reference creates at src/ov2slam.cpp:85-89 and applies at
+    src/visual_front_end.cpp:1159 / src/mapper.cpp:76:  createCLAHE(clipLimit, tileGridSize).apply(src)."""
+
+    def __init__(self, ctx, clipLimit=3.0, tileGridSize=(15, 9)):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.clipLimit = float(clipLimit)
+        self.tiles_x, self.tiles_y = int(tileGridSize[0]), int(tileGridSize[1])
+
+    def apply(self, src):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        h, w = src.shape
+        dst = np.empty_like(src)
+        L.check(self.lib.ov2_clahe_h(self.ctx.h, _ptr(src), w, h, w, self.clipLimit, self.tiles_x, self.tiles_y, _ptr(dst), w))
+        return dst
+
+
 class FeatureTracker:
     """Mirror of /root/reference/include/feature_tracker.hpp:36-56.
 
