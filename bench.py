@@ -7,8 +7,8 @@ One timed "step" = one camera frame of config[1] (EuRoC MH_01 stereo, 'accurate'
 752x480, LK 9x9, 3+1 pyramid levels, 30 it / 0.01 px, 308 keypoints) pushed through the HIP hot
 path for each of the `--seqs` sequences this GPU processes in lock-step (offline
 batch-of-sequences mode of config[4]; `--seqs 1` is the single-sequence drop-in case):
-    preprocessImage : device-resident pyramid build of the new left image
-                      (/root/reference/src/visual_front_end.cpp:1143-1177)
+    preprocessImage : CLAHE (clip 3.0, 15x9 tiles: use_clahe 1 in parameters_files/accurate) of the new left
+                      image + device-resident pyramid build (/root/reference/src/visual_front_end.cpp:1143-1177)
     kltTracking     : fbKltTracking pass A (nbpyrlvl=1) on the keypoints that carry a 3-D prior,
                       pass B (nbpyrlvl=3) on the others (src/visual_front_end.cpp:186-268)
 `value` = tracked frames/s over all sequences and ranks (max-over-ranks time).  Images, keypoints
@@ -37,6 +37,7 @@ N_PASS_A = 216              # keypoints with a 3-D prior -> pass A (2 levels)
 N_PASS_B = NKPS - N_PASS_A  # pass B (4 levels)
 NF = 6                      # distinct synthetic views per sequence (cycled)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+CLAHE_CLIP, CLAHE_TILES = 3.0, (W // 50, H // 50)   # ov2slam.cpp:85-89, accurate/euroc: fclahe_val 3
 
 
 def make_inputs(seqs, seed):
@@ -104,8 +105,8 @@ def cpu_baseline(views, kps, pri, ba_problem, budget_s=10.0):
     while True:
         f = frames % NF
         if f == 0:
-            prevp = O.Pyramid(views[0], WIN, LEVELS)
-        curp = O.Pyramid(views[f + 1], WIN, LEVELS)
+            prevp = O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+        curp = O.Pyramid(O.clahe(views[f + 1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
         k, p = kps[f, 0], pri[f, 0]
         O.fb_klt(prevp, curp, WIN, 1, 30., 0.5, k[:N_PASS_A], p[:N_PASS_A], nthreads=best_nt)
         O.fb_klt(prevp, curp, WIN, LEVELS, 30., 0.5, k[N_PASS_A:], p[N_PASS_A:], nthreads=best_nt)
@@ -115,7 +116,7 @@ def cpu_baseline(views, kps, pri, ba_problem, budget_s=10.0):
         if el > budget_s and frames >= 20:
             break
     out = {"value": frames / el, "unit": "frames/s", "cores": best_nt, "kind": "port", "host_cores": cores,
-           "sample": "%d frames of the same synthetic 752x480 step (pyramid build + LK pass A/B) through "
+           "sample": "%d frames of the same synthetic 752x480 step (CLAHE + pyramid build + LK pass A/B) through "
                      "oracle/liboracle.so, LK over keypoints on %d pthreads (best of 1..64)" % (frames, best_nt)}
     if ba_problem is not None:
         t0 = time.perf_counter()
@@ -180,16 +181,22 @@ def main():
     a_pB = [vp(pri_work[f][:, N_PASS_A:]) for f in range(NF)]
     a_st, a_stB, a_stats, a_nA, a_nB = vp(status_d), vp(status_d[:, N_PASS_A:]), vp(stats_d), vp(nA_d), vp(nB_d)
     hp = [p.h_pyr for p in pyrs]
-    fb, build = lib.ov2_fb_klt_d, lib.ov2_pyr_build_d
+    fb, build, clahe = lib.ov2_fb_klt_d, lib.ov2_pyr_build_d, lib.ov2_clahe_d
+    clahe_buf = torch.empty((S, H, W), dtype=torch.uint8, device=dev)
+    a_cl = vp(clahe_buf)
     lk_events = []
+
+    def preprocess(pyr, img):
+        L.check(clahe(ctx.h, img, W, H, W, W * H, S, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1], a_cl, W, W * H))
+        L.check(build(ctx.h, pyr, a_cl, W, W * H))
 
     def step(i, timed):
         f = i % NF
         prevp, curp = hp[i % 2], hp[(i + 1) % 2]
         if f == 0:
             pri_work.copy_(pri_d)                                   # priors are in/out: restore once per cycle
-            L.check(build(ctx.h, prevp, a_img[0], W, W * H))
-        L.check(build(ctx.h, curp, a_img[f + 1], W, W * H))         # preprocessImage
+            preprocess(prevp, a_img[0])
+        preprocess(curp, a_img[f + 1])                              # preprocessImage
         if timed:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record(stream)
@@ -253,8 +260,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 fixed point + f32 (LK), f64 (BA)", "data": "synthetic",
-            "config": {"workload": "EuRoC MH_01 stereo 'accurate' tracking step on synthetic 752x480 frames: pyramid "
-                                   "build (4 levels + Scharr) + fbKltTracking pass A (216 kps, nbpyrlvl 1) + pass B "
+            "config": {"workload": "EuRoC MH_01 stereo 'accurate' tracking step on synthetic 752x480 frames: CLAHE + pyramid "
+                                   "build (4 levels) + fbKltTracking pass A (216 kps, nbpyrlvl 1) + pass B "
                                    "(92 kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px",
                        "seqs_per_gpu": S, "keypoints_per_frame": NKPS, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fb_klt<9>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -293,8 +300,9 @@ def main():
                 det = fx.detectSingleScale(views[0], CELL, np.zeros((0, 2), np.float32), roi)
             det_ms = (time.perf_counter() - t1) / 20 * 1e3
             t1 = time.perf_counter()
+            cl = ov2slam_amd.CLAHE(ctx1, CLAHE_CLIP, CLAHE_TILES)
             for _ in range(50):
-                P1.build(views[1])
+                P1.build(cl.apply(views[1]))
                 trk.fbKltTracking(P0, P1, WIN, 1, 30., 0.5, kps[0, 0][:N_PASS_A], pri[0, 0][:N_PASS_A])
                 trk.fbKltTracking(P0, P1, WIN, LEVELS, 30., 0.5, kps[0, 0][N_PASS_A:], pri[0, 0][N_PASS_A:])
             trk_ms = (time.perf_counter() - t1) / 50 * 1e3
