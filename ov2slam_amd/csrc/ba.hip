@@ -78,6 +78,7 @@ struct BADev {                    // device pointers + sizes (passed by value to
     double *H, *G;                // nfp*nfp (unscaled F^T F ; W^T C W, upper tiles)
     double *bf, *v;               // nfp  (unscaled F^T b ; W^T (c etb))
     double *S;                    // nfp*nfp scratch for the Cholesky
+    double *Linv;                 // nfp*32: inverse 32x32 diagonal blocks of the factor
     double *yf;                   // nfp
     double *yl;                   // n_lm
     double *chi2;                 // n_res (caller order)
@@ -583,18 +584,21 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #define CH_NB 32
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
 
-__global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
+__global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    double *L11 = (double *)smem_raw;                       // CH_NB x CH_LDP
+    double *L11 = (double *)smem_raw;                       // CH_NB x CH_LDP : diagonal block / its inverse
     double *yv = L11 + CH_NB * CH_LDP;                      // nfp
-    double *P = yv + D.nfp;                                 // (n - CH_NB) x CH_LDP
+    double *P = yv + D.nfp;                                 // (n - CH_NB) x CH_LDP : panel below the diagonal block
     const int n = D.nf, ld = D.nfp, tid = threadIdx.x, nt = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63;
     __shared__ int s_fail;
+    __shared__ double s_red[32][33];
     const double radius = ctl->radius;
     double *S = D.S;
+    double *Linv = D.Linv;                                  // (nfp / 32) blocks of 32 x 32 (row-major), inverse diagonal blocks
     for (int e = tid; e < n * n; e += nt) {
         const int i = e / n, j = e - i * n;
         if (j > i) continue;                               // lower triangle only
@@ -609,75 +613,124 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
 
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tc = wall_clock64();
 #define CH_TICK(i) do { const unsigned long long t_ = wall_clock64(); tk[i] += t_ - tc; tc = t_; } while (0)
-    CH_TICK(0);
     for (int k0 = 0; k0 < n; k0 += CH_NB) {
         const int nb = min(CH_NB, n - k0);
         const int m = n - k0 - nb;                          // rows below the diagonal block
-        // (a) diagonal block -> LDS
-        for (int e = tid; e < nb * nb; e += nt) {
-            const int i = e / nb, j = e - i * nb;
-            if (j <= i) L11[i * CH_LDP + j] = S[(long long)(k0 + i) * ld + k0 + j];
+        // (a) diagonal block -> LDS (identity padding when nb < 32), panel rows -> LDS (coalesced)
+        for (int e = tid; e < CH_NB * CH_NB; e += nt) {
+            const int i = e >> 5, j = e & 31;
+            double v = (i == j) ? 1.0 : 0.0;
+            if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
+            L11[i * CH_LDP + j] = v;
+        }
+        for (int e = tid; e < m * CH_NB; e += nt) {
+            const int t = e >> 5, j = e & 31;
+            P[t * CH_LDP + j] = j < nb ? S[(long long)(k0 + nb + t) * ld + k0 + j] : 0.0;
         }
         __syncthreads();
-        // (b) one wavefront factors it (lane i owns row i)
-        if (tid < 64) {
-            const int i = tid;
-            for (int c = 0; c < nb; c++) {
-                const double d = L11[c * CH_LDP + c];
-                if (!(d > 0.0) || !isfinite(d)) { if (tid == 0) s_fail = 1; break; }   // uniform: every lane reads the same d
+        // (b) wavefront 0: left-looking factorisation, lane i owns row i in registers; one LDS sync per column
+        if (wave == 0) {
+            double a[CH_NB];
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) a[j] = lane < CH_NB ? L11[lane * CH_LDP + j] : 0.0;
+            bool fail = false;
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) {
+                double sacc = a[c];
+#pragma unroll
+                for (int k = 0; k < c; k++) sacc -= a[k] * L11[c * CH_LDP + k];     // row c of L, final for k < c (broadcast read)
+                const double d = __shfl(sacc, c, 64);
+                if (!(d > 0.0) || !isfinite(d)) fail = true;
                 const double dj = sqrt(d);
-                wave_lds_sync();
-                if (i == c) L11[c * CH_LDP + c] = dj;
-                else if (i > c && i < nb) L11[i * CH_LDP + c] /= dj;
-                wave_lds_sync();
-                if (i > c && i < nb) {
-                    const double lic = L11[i * CH_LDP + c];
-                    for (int j = c + 1; j <= i; j++) L11[i * CH_LDP + j] -= lic * L11[j * CH_LDP + c];
-                }
+                const double l = lane == c ? dj : sacc / dj;
+                a[c] = lane >= c ? l : 0.0;
+                if (lane >= c && lane < CH_NB) L11[lane * CH_LDP + c] = a[c];
                 wave_lds_sync();
             }
+            if (fail && lane == 0) s_fail = 1;
         }
         __syncthreads();
         CH_TICK(1);
         if (s_fail) break;
-        // write the factored block back; (c) panel solve  X L11^T = A21, one row per thread
+        // (c) last wavefront: inverse of the factored block (lane j solves L x = e_j), kept for the triangular solves;
+        //     all other threads: panel solve X L11^T = A21, one row per thread, operands in LDS
+        if (wave == (nt >> 6) - 1) {
+            if (lane < CH_NB) {
+                double x[CH_NB];
+#pragma unroll
+                for (int i = 0; i < CH_NB; i++) {
+                    double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; k++) acc -= L11[i * CH_LDP + k] * x[k];
+                    x[i] = i < lane ? 0.0 : acc / L11[i * CH_LDP + i];
+                }
+                double *dst = Linv + (long long)(k0 / CH_NB) * CH_NB * CH_NB;
+#pragma unroll
+                for (int i = 0; i < CH_NB; i++) dst[i * CH_NB + lane] = x[i];            // Linv[i][j], coalesced over j
+            }
+        } else {
+            for (int t = tid; t < m; t += nt - 64) {
+                double x[CH_NB];
+#pragma unroll
+                for (int j = 0; j < CH_NB; j++) x[j] = P[t * CH_LDP + j];
+#pragma unroll
+                for (int j = 0; j < CH_NB; j++) {
+                    double acc = x[j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
+                    x[j] = acc / L11[j * CH_LDP + j];
+                }
+#pragma unroll
+                for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
+            }
+        }
+        __syncthreads();
+        // factored block and panel back to HBM (coalesced)
         for (int e = tid; e < nb * nb; e += nt) {
             const int i = e / nb, j = e - i * nb;
             if (j <= i) S[(long long)(k0 + i) * ld + k0 + j] = L11[i * CH_LDP + j];
         }
-        for (int t = tid; t < m; t += nt) {
-            double *row = S + (long long)(k0 + nb + t) * ld + k0;
-            double x[CH_NB];
-#pragma unroll
-            for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.0;
-#pragma unroll
-            for (int j = 0; j < CH_NB; j++) {
-                if (j < nb) {
-                    double a = x[j];
-#pragma unroll
-                    for (int k = 0; k < j; k++) a -= x[k] * L11[j * CH_LDP + k];
-                    x[j] = a / L11[j * CH_LDP + j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < CH_NB; j++) if (j < nb) { row[j] = x[j]; P[t * CH_LDP + j] = x[j]; }
+        for (int e = tid; e < m * CH_NB; e += nt) {
+            const int t = e >> 5, j = e & 31;
+            if (j < nb) S[(long long)(k0 + nb + t) * ld + k0 + j] = P[t * CH_LDP + j];
         }
-        __syncthreads();
         CH_TICK(2);
-        // (d) trailing update  A22 -= P P^T  (lower triangle), 32x32 thread tiles
+        // (d) trailing update  A22 -= P P^T  (lower triangle), 32x32 thread tiles, loads batched 4 tiles deep
         {
-            const int ty = tid >> 5, tx = tid & 31;
-            const int nbk = (m + 31) / 32;
-            for (int bi = 0; bi < nbk; bi++) {
-                const int i = bi * 32 + ty;
-                for (int bj = 0; bj <= bi; bj++) {
-                    const int j = bj * 32 + tx;
-                    if (i < m && j <= i) {
-                        double acc = 0;
-#pragma unroll 8
-                        for (int k = 0; k < CH_NB; k++) acc += P[i * CH_LDP + k] * P[j * CH_LDP + k];   // nb < 32 only in the last panel (m = 0)
-                        S[(long long)(k0 + nb + i) * ld + k0 + nb + j] -= acc;
+            const int ty = tid >> 5, tx = tid & 31, rpt = nt >> 5;       // rpt rows of 32 columns per pass
+            const int nrb = (m + rpt - 1) / rpt;
+            for (int rb = 0; rb < nrb; rb++) {
+                const int i = rb * rpt + ty;
+                const int bi = i >> 5;                                   // last column tile that intersects the lower triangle
+                double pi[CH_NB];
+                if (i < m) {
+#pragma unroll
+                    for (int k = 0; k < CH_NB; k++) pi[k] = P[i * CH_LDP + k];
+                }
+                const int bimax = min((rb * rpt + rpt - 1) >> 5, (m - 1) >> 5);   // uniform loop bound for the whole pass
+                // software pipeline: the S values of the next 4 tiles are in flight while the current 4 are computed
+                double sv[4], svn[4];
+                auto tile_ok = [&](int bj) { const int j = bj * 32 + tx; return bj <= bi && i < m && j <= i; };
+#pragma unroll
+                for (int q = 0; q < 4; q++) sv[q] = tile_ok(q) ? S[(long long)(k0 + nb + i) * ld + k0 + nb + q * 32 + tx] : 0.0;
+                for (int bj0 = 0; bj0 <= bimax; bj0 += 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int bj = bj0 + 4 + q;
+                        svn[q] = (bj <= bimax && tile_ok(bj)) ? S[(long long)(k0 + nb + i) * ld + k0 + nb + bj * 32 + tx] : 0.0;
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int bj = bj0 + q, j = bj * 32 + tx;
+                        if (tile_ok(bj)) {
+                            double t = 0;
+#pragma unroll
+                            for (int k = 0; k < CH_NB; k++) t += pi[k] * P[j * CH_LDP + k];
+                            S[(long long)(k0 + nb + i) * ld + k0 + nb + j] = sv[q] - t;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) sv[q] = svn[q];
                 }
             }
         }
@@ -686,54 +739,51 @@ __global__ __launch_bounds__(1024) void k_ba_cholesky(BADev D)
     }
     if (s_fail) { if (tid == 0) ctl->lin_fail = 1; return; }
 
-    // forward substitution  L y = rhs  (blocked; yv in LDS)
+    // forward substitution  L y = rhs, left-looking by blocks:  y_blk = Linv_blk (b_blk - L[blk, 0:k0] y[0:k0])
+    const int tr = tid >> 5, tcn = tid & 31, ngr = nt >> 5;  // ngr groups of 32 partial-sum threads
     for (int k0 = 0; k0 < n; k0 += CH_NB) {
         const int nb = min(CH_NB, n - k0);
-        for (int e = tid; e < nb * nb; e += nt) {
-            const int i = e / nb, j = e - i * nb;
-            if (j <= i) L11[i * CH_LDP + j] = S[(long long)(k0 + i) * ld + k0 + j];
+        for (int r = tr; r < CH_NB; r += ngr) {
+            double part = 0;
+            if (r < nb) for (int k = tcn; k < k0; k += 32) part += S[(long long)(k0 + r) * ld + k] * yv[k];
+            s_red[r][tcn] = part;
+        }
+        for (int e = tid; e < CH_NB * CH_NB; e += nt) L11[(e >> 5) * CH_LDP + (e & 31)] = Linv[(long long)(k0 / CH_NB) * CH_NB * CH_NB + e];
+        __syncthreads();
+        if (tid < CH_NB) {
+            double r = 0;
+            for (int q = 0; q < 32; q++) r += s_red[tid][q];
+            s_red[tid][32] = tid < nb ? yv[k0 + tid] - r : 0.0;
         }
         __syncthreads();
-        if (tid < 64) {
-            const int i = tid;
-            for (int c = 0; c < nb; c++) {
-                if (i == c) yv[k0 + c] /= L11[c * CH_LDP + c];
-                wave_lds_sync();
-                if (i > c && i < nb) yv[k0 + i] -= L11[i * CH_LDP + c] * yv[k0 + c];
-                wave_lds_sync();
-            }
-        }
-        __syncthreads();
-        for (int i = k0 + nb + tid; i < n; i += nt) {
-            const double *row = S + (long long)i * ld + k0;
-            double a = 0;
-            for (int k = 0; k < nb; k++) a += row[k] * yv[k0 + k];
-            yv[i] -= a;
+        if (tid < nb) {
+            double r = 0;
+            for (int k = 0; k <= tid; k++) r += L11[tid * CH_LDP + k] * s_red[k][32];
+            yv[k0 + tid] = r;
         }
         __syncthreads();
     }
-    // backward substitution  L^T x = y
+    // backward substitution  L^T x = y:  x_blk = Linv_blk^T (y_blk - L[below, blk]^T x[below])
     for (int k0 = ((n - 1) / CH_NB) * CH_NB; k0 >= 0; k0 -= CH_NB) {
         const int nb = min(CH_NB, n - k0);
-        for (int e = tid; e < nb * nb; e += nt) {
-            const int i = e / nb, j = e - i * nb;
-            if (j <= i) L11[i * CH_LDP + j] = S[(long long)(k0 + i) * ld + k0 + j];
+        // lanes along the block's columns (coalesced), thread groups along the rows below
+        for (int g = tr; g < 32; g += ngr) {
+            double part = 0;
+            if (tcn < nb) for (int i = k0 + nb + g; i < n; i += 32) part += S[(long long)i * ld + k0 + tcn] * yv[i];
+            s_red[tcn][g] = part;
+        }
+        for (int e = tid; e < CH_NB * CH_NB; e += nt) L11[(e >> 5) * CH_LDP + (e & 31)] = Linv[(long long)(k0 / CH_NB) * CH_NB * CH_NB + e];
+        __syncthreads();
+        if (tid < CH_NB) {
+            double r = 0;
+            for (int q = 0; q < 32; q++) r += s_red[tid][q];
+            s_red[tid][32] = tid < nb ? yv[k0 + tid] - r : 0.0;
         }
         __syncthreads();
-        if (tid < 64) {
-            const int i = tid;
-            for (int c = nb - 1; c >= 0; c--) {
-                if (i == c) yv[k0 + c] /= L11[c * CH_LDP + c];
-                wave_lds_sync();
-                if (i < c) yv[k0 + i] -= L11[c * CH_LDP + i] * yv[k0 + c];
-                wave_lds_sync();
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < k0; i += nt) {
-            double a = 0;
-            for (int k = 0; k < nb; k++) a += S[(long long)(k0 + k) * ld + i] * yv[k0 + k];
-            yv[i] -= a;
+        if (tid < nb) {
+            double r = 0;
+            for (int k = tid; k < nb; k++) r += L11[k * CH_LDP + tid] * s_red[k][32];     // Linv^T
+            yv[k0 + tid] = r;
         }
         __syncthreads();
     }
@@ -999,6 +1049,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     const size_t o_scale_l = take(8 * nl), o_diag_l = take(8 * nl), o_ete = take(8 * nl), o_etb = take(8 * nl), o_cl = take(8 * nl), o_ce = take(8 * nl);
     const size_t o_W = take(8 * nl * nfp), o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
+    const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
     dev->pool_bytes = off;
     hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
@@ -1010,6 +1061,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     D.x_lam = (double *)(b + o_x_lam); D.c_lam = (double *)(b + o_c_lam); D.scale_f = (double *)(b + o_scale_f); D.diag_f = (double *)(b + o_diag_f);
     D.scale_l = (double *)(b + o_scale_l); D.diag_l = (double *)(b + o_diag_l); D.ete = (double *)(b + o_ete); D.etb = (double *)(b + o_etb);
     D.cl = (double *)(b + o_cl); D.ce = (double *)(b + o_ce); D.W = (double *)(b + o_W); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
+    D.Linv = (double *)(b + o_Linv);
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
     dev->lm_order = (int *)(b + o_lm_order);
@@ -1121,7 +1173,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, D, ntiles, lm_per_split);
-        hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(1024), chol_lds, s, D);
+        hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
         hipLaunchKernelGGL(k_ba_cost, dim3(ws_blocks), dim3(256), 0, s, D);

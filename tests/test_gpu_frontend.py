@@ -136,3 +136,27 @@ def test_fbklt_size_independent_properties_full_size(gpu_ctx):
     bwd, s2 = trk.fbKltTracking(Gb, Ga, 9, 3, 30., 0.5, fwd, fwd)
     both = s1 & s2
     assert np.abs(bwd[both] - kps[both]).max() < 0.1
+
+
+@pytest.mark.parametrize("win", [5, 7, 11, 13])
+def test_fbklt_other_window_sizes_bit_exact(gpu_ctx, oracle, euroc_pair, win):
+    """Every kernel instance (row-byte / neighbourhood register layouts differ per WIN) against the oracle."""
+    d = euroc_pair
+    Gp, Rp = _pyr_pair(gpu_ctx, oracle, d["prev"], win, 3)
+    Gc, Rc = _pyr_pair(gpu_ctx, oracle, d["cur"], win, 3)
+    trk = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01)
+    rng = np.random.default_rng(win)
+    kps = np.concatenate([d["kps"], np.array([[0.4, 0.2], [751.5, 479.5], [-3.0, 100.0], [300.0, -2.5]], np.float32)])
+    pri = np.concatenate([d["pri"], kps[-4:] + rng.normal(0, 2, (4, 2)).astype(np.float32)])
+    for lvl in (3, 0):
+        gout, gst, gstats = trk.fbKltTracking(Gp, Gc, win, lvl, 30., 0.5, kps, pri, return_stats=True)
+        rout, rst, rstats = oracle.fb_klt(Rp, Rc, win, lvl, 30., 0.5, kps, pri)
+        assert np.array_equal(gst, rst)
+        _assert_same_float_bits(gout, rout, "win %d lvl %d" % (win, lvl))
+        assert gstats[0] == rstats[0]
+    # large drifts force neighbourhood re-fetches: priors 12 px off
+    far = (d["gt"] + 12.0).astype(np.float32)
+    gout, gst = trk.fbKltTracking(Gp, Gc, win, 3, 30., 0.5, d["kps"], far)
+    rout, rst, _ = oracle.fb_klt(Rp, Rc, win, 3, 30., 0.5, d["kps"], far)
+    assert np.array_equal(gst, rst)
+    _assert_same_float_bits(gout, rout, "far priors win %d" % win)
