@@ -192,9 +192,12 @@ __device__ __forceinline__ RowBytes<WIN> nbh_window_row(const NbhRegs &n, int ox
     RowBytes<WIN> o;
 #pragma unroll
     for (int i = 0; i < RowBytes<WIN>::NR; i++) {
-        const uint32_t lo = q ? g[i + 1] : g[i];
-        const uint32_t hi = q ? (i + 2 <= 4 ? g[i + 2] : 0u) : g[i + 1];
-        o.d[i] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        // dword offset q = ox / 4 is 0..2 (ox <= 2 R <= 10); g[] lives in registers, so select instead of indexing
+        auto pick = [&](int k) -> uint32_t {
+            const uint32_t a0 = k <= 4 ? g[k] : 0u, a1 = k + 1 <= 4 ? g[k + 1] : 0u, a2 = k + 2 <= 4 ? g[k + 2] : 0u;
+            return q == 0 ? a0 : (q == 1 ? a1 : a2);
+        };
+        o.d[i] = __builtin_amdgcn_alignbyte(pick(i + 1), pick(i), sh);
     }
     return o;
 }
