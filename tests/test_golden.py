@@ -1,0 +1,25 @@
+"""Oracle regression digests (tests/golden/oracle_digests.json, produced by tests/golden/make_golden.py).
+Self-pinned: the reference provides no golden vectors for this path (see the script's docstring)."""
+import importlib.util
+import json
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_oracle_matches_committed_digests(oracle):
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(HERE, "golden", "oracle_digests.json")))
+    got = mod.compute()
+    assert got == want, {k: (got[k], want[k]) for k in want if got.get(k) != want[k]}
+
+
+def test_cpp_adapters_compile():
+    """The C++ mirrors of FeatureTracker / FeatureExtractor / Optimizer (ov2slam_amd/host) stay in sync with the C ABI."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "ov2slam_amd", "host", "compile_check.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
