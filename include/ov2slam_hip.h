@@ -162,7 +162,10 @@ int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stri
 enum {
     OV2_RES_LEFT       = 0, /* DirectLeftSE3::ReprojectionErrorKSE3AnchInvDepth         :361-473 */
     OV2_RES_RIGHT      = 1, /* DirectLeftSE3::ReprojectionErrorRightCamKSE3AnchInvDepth :579-712 */
-    OV2_RES_RIGHT_ANCH = 2  /* DirectLeftSE3::ReprojectionErrorRightAnchCamKSE3AnchInvDepth :476-577 */
+    OV2_RES_RIGHT_ANCH = 2, /* DirectLeftSE3::ReprojectionErrorRightAnchCamKSE3AnchInvDepth :476-577 */
+    OV2_RES_PNP        = 3  /* DirectLeftSE3::ReprojectionErrorSE3 (fixed world point) :301-358 -- the factor of
+                               MultiViewGeometry::ceresPnP, src/multi_view_geometry.cpp:492-586; uses res_kf, res_xyz,
+                               res_uv, res_sigma and calib_l; res_lm is ignored */
 };
 
 typedef struct {
@@ -180,6 +183,7 @@ typedef struct {
     const double *res_uv;        /* 2*n_res; observed pixel                       */
     const double *res_sigma;     /* n_res; 2^scale (always 1 in the reference)    */
     const uint8_t *res_active;   /* n_res or NULL; 0 = residual block removed (optimizer.cpp:500-592) */
+    const double *res_xyz;       /* 3*n_res; world point of OV2_RES_PNP blocks (ignored for the others); NULL if none */
     double calib_l[4];           /* fx fy cx cy, constant block                   */
     double calib_r[4];
     double T_rl[7];              /* right <- left extrinsic, [t q], constant block */

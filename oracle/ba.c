@@ -274,6 +274,39 @@ int orc_ba_residual(int type, const double calib_l[4], const double calib_r[4], 
     return depthpos;
 }
 
+/* DirectLeftSE3::ReprojectionErrorSE3::Evaluate (src/ceres_parametrization.cpp:301-358): fixed world point */
+static int pnp_residual(const double calib[4], const double pose[7], const double xyz[3], const double uv[2], double sigma,
+                        double r[2], double Jo[12], double *chi2)
+{
+    const double sqrt_info = 1.0 / sigma;
+    double q[4] = {pose[3], pose[4], pose[5], pose[6]};
+    quat_normalize(q);
+    double Rwc[9], Rcw[9];
+    quat_to_R(q, Rwc);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rcw[3 * i + j] = Rwc[3 * j + i];
+    const double d[3] = {xyz[0] - pose[0], xyz[1] - pose[1], xyz[2] - pose[2]};
+    double c[3];
+    mat3_vec(Rcw, d, c);
+    const double invz = 1.0 / c[2];
+    r[0] = sqrt_info * (calib[0] * c[0] * invz + calib[2] - uv[0]);
+    r[1] = sqrt_info * (calib[1] * c[1] * invz + calib[3] - uv[1]);
+    *chi2 = r[0] * r[0] + r[1] * r[1];
+    if (Jo) {
+        const double invz2 = invz * invz;
+        const double Jc[6] = {invz * calib[0], 0, -c[0] * invz2 * calib[0], 0, invz * calib[1], -c[1] * invz2 * calib[1]};
+        double JR[6];
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) JR[3 * i + j] = Jc[3 * i] * Rcw[j] + Jc[3 * i + 1] * Rcw[3 + j] + Jc[3 * i + 2] * Rcw[6 + j];
+        const double S[9] = {0, -xyz[2], xyz[1], xyz[2], 0, -xyz[0], -xyz[1], xyz[0], 0};
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 3; j++) {
+                const double jrs = JR[3 * i] * S[j] + JR[3 * i + 1] * S[3 + j] + JR[3 * i + 2] * S[6 + j];
+                Jo[6 * i + j] = -sqrt_info * JR[3 * i + j];
+                Jo[6 * i + 3 + j] = sqrt_info * jrs;
+            }
+    }
+    return c[2] > 0;
+}
+
 /* ---------------- solver ---------------- */
 typedef struct {
     const orc_ba_problem *p;
@@ -298,13 +331,19 @@ static double ba_evaluate(ba_ws *w, const double *poses, const double *lam, int 
     if (grad_l) memset(grad_l, 0, sizeof(double) * (size_t)p->n_lm);
     for (int k = 0; k < w->n_act; k++) {
         const int i = w->act[k];
-        const int lm = p->res_lm[i], a = p->lm_anchor_kf[lm];
         const int type = p->res_type[i];
+        const int lm = type == ORC_RES_PNP ? -1 : p->res_lm[i];
+        const int a = lm >= 0 ? p->lm_anchor_kf[lm] : p->res_kf[i];
         const int o = type == ORC_RES_RIGHT_ANCH ? a : p->res_kf[i];
         double r[2], Ja[12], Jo[12], Jl[2], chi2;
-        const int dp = orc_ba_residual(type, p->calib_l, p->calib_r, p->T_rl, poses + 7 * a, poses + 7 * o, lam[lm],
-                                       p->lm_anchor_uv + 2 * lm, p->res_uv + 2 * i, p->res_sigma[i],
-                                       r, want_jac ? Ja : NULL, want_jac ? Jo : NULL, want_jac ? Jl : NULL, &chi2);
+        int dp;
+        if (type == ORC_RES_PNP) {
+            dp = pnp_residual(p->calib_l, poses + 7 * o, p->res_xyz + 3 * i, p->res_uv + 2 * i, p->res_sigma[i], r, want_jac ? Jo : NULL, &chi2);
+            memset(Ja, 0, sizeof(Ja)); Jl[0] = Jl[1] = 0;
+        } else
+            dp = orc_ba_residual(type, p->calib_l, p->calib_r, p->T_rl, poses + 7 * a, poses + 7 * o, lam[lm],
+                                 p->lm_anchor_uv + 2 * lm, p->res_uv + 2 * i, p->res_sigma[i],
+                                 r, want_jac ? Ja : NULL, want_jac ? Jo : NULL, want_jac ? Jl : NULL, &chi2);
         if (chi2_out) chi2_out[i] = chi2;
         if (dpos_out) dpos_out[i] = (uint8_t)dp;
         const double s = r[0] * r[0] + r[1] * r[1];
@@ -320,7 +359,7 @@ static double ba_evaluate(ba_ws *w, const double *poses, const double *lam, int 
         orc_corrector(s, rho, 2, 1, rr, Jl);
         /* an anchor==obs residual (possible only through bad input) would alias; the reference never builds one */
         const int ca = w->pose_col[a], co = w->pose_col[o];
-        if (type == ORC_RES_RIGHT_ANCH || ca < 0) memset(Ja, 0, sizeof(Ja));
+        if (type == ORC_RES_RIGHT_ANCH || type == ORC_RES_PNP || ca < 0) memset(Ja, 0, sizeof(Ja));
         if (type == ORC_RES_RIGHT_ANCH || co < 0) memset(Jo, 0, sizeof(Jo));
         /* gradient with the un-scaled jacobian (evaluator), then jacobi scaling */
         if (grad_f) {
@@ -329,7 +368,7 @@ static double ba_evaluate(ba_ws *w, const double *poses, const double *lam, int 
                 if (co >= 0) grad_f[co + c] += Jo[c] * rr[0] + Jo[6 + c] * rr[1];
             }
         }
-        if (grad_l) grad_l[lm] += Jl[0] * rr[0] + Jl[1] * rr[1];
+        if (grad_l && lm >= 0) grad_l[lm] += Jl[0] * rr[0] + Jl[1] * rr[1];
         memcpy(w->r + 2 * k, rr, sizeof(rr));
         memcpy(w->Ja + 12 * k, Ja, sizeof(Ja));
         memcpy(w->Jo + 12 * k, Jo, sizeof(Jo));
@@ -338,21 +377,32 @@ static double ba_evaluate(ba_ws *w, const double *poses, const double *lam, int 
     return cost;
 }
 
+/* landmark (-1 for pose-only blocks), anchor / observer keyframes and their first columns (-1 = constant / absent) */
+static void ba_res_blocks(const ba_ws *w, int i, int *lm, int *ca, int *co)
+{
+    const orc_ba_problem *p = w->p;
+    const int type = p->res_type[i];
+    if (type == ORC_RES_PNP) { *lm = -1; *ca = -1; *co = w->pose_col[p->res_kf[i]]; return; }
+    *lm = p->res_lm[i];
+    const int a = p->lm_anchor_kf[*lm];
+    if (type == ORC_RES_RIGHT_ANCH) { *ca = -1; *co = -1; return; }
+    *ca = w->pose_col[a]; *co = w->pose_col[p->res_kf[i]];
+}
+
 static void ba_col_sqnorm(const ba_ws *w, double *nf, double *nl)
 {
     const orc_ba_problem *p = w->p;
     memset(nf, 0, sizeof(double) * (size_t)w->nf);
     memset(nl, 0, sizeof(double) * (size_t)p->n_lm);
     for (int k = 0; k < w->n_act; k++) {
-        const int i = w->act[k], lm = p->res_lm[i], a = p->lm_anchor_kf[lm];
-        const int o = p->res_type[i] == ORC_RES_RIGHT_ANCH ? a : p->res_kf[i];
-        const int ca = w->pose_col[a], co = w->pose_col[o];
+        int lm, ca, co;
+        ba_res_blocks(w, w->act[k], &lm, &ca, &co);
         const double *Ja = w->Ja + 12 * k, *Jo = w->Jo + 12 * k, *Jl = w->Jl + 2 * k;
         for (int c = 0; c < 6; c++) {
             if (ca >= 0) nf[ca + c] += Ja[c] * Ja[c] + Ja[6 + c] * Ja[6 + c];
             if (co >= 0) nf[co + c] += Jo[c] * Jo[c] + Jo[6 + c] * Jo[6 + c];
         }
-        nl[lm] += Jl[0] * Jl[0] + Jl[1] * Jl[1];
+        if (lm >= 0) nl[lm] += Jl[0] * Jl[0] + Jl[1] * Jl[1];
     }
 }
 
@@ -360,16 +410,16 @@ static void ba_scale_columns(ba_ws *w)
 {
     const orc_ba_problem *p = w->p;
     for (int k = 0; k < w->n_act; k++) {
-        const int i = w->act[k], lm = p->res_lm[i], a = p->lm_anchor_kf[lm];
-        const int o = p->res_type[i] == ORC_RES_RIGHT_ANCH ? a : p->res_kf[i];
-        const int ca = w->pose_col[a], co = w->pose_col[o];
+        int lm, ca, co;
+        ba_res_blocks(w, w->act[k], &lm, &ca, &co);
         double *Ja = w->Ja + 12 * k, *Jo = w->Jo + 12 * k, *Jl = w->Jl + 2 * k;
         for (int c = 0; c < 6; c++) {
             if (ca >= 0) { Ja[c] *= w->scale_f[ca + c]; Ja[6 + c] *= w->scale_f[ca + c]; }
             if (co >= 0) { Jo[c] *= w->scale_f[co + c]; Jo[6 + c] *= w->scale_f[co + c]; }
         }
-        Jl[0] *= w->scale_l[lm]; Jl[1] *= w->scale_l[lm];
+        if (lm >= 0) { Jl[0] *= w->scale_l[lm]; Jl[1] *= w->scale_l[lm]; }
     }
+    (void)p;
 }
 
 /* dense Cholesky (lower) in place; returns 0 on success */
@@ -468,6 +518,18 @@ static int ba_schur_solve(const ba_ws *w, const double *Df, const double *Dl, do
             }
         for (int x = 0; x < nt; x++) flag[touched[x] / 6] = 0;
     }
+    /* rows without an e-block (SchurEliminator::NoEBlockRowsUpdate): pose-only residual blocks */
+    for (int k = 0; k < w->n_act; k++) {
+        const int i = w->act[k];
+        if (p->res_type[i] != ORC_RES_PNP) continue;
+        const int co = w->pose_col[p->res_kf[i]];
+        if (co < 0) continue;
+        const double *Jo = w->Jo + 12 * k, *r = w->r + 2 * k;
+        for (int c = 0; c < 6; c++) {
+            rhs[co + c] += Jo[c] * r[0] + Jo[6 + c] * r[1];
+            for (int d = 0; d < 6; d++) S[(size_t)(co + c) * nf + co + d] += Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d];
+        }
+    }
     int rc = 0;
     if (nf > 0) {
         rc = chol_lower(S, nf);
@@ -518,20 +580,24 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
     w.act = (int *)malloc(sizeof(int) * (size_t)(p->n_res + 1));
     for (int i = 0; i < p->n_res; i++) {
         if (p->res_active && !p->res_active[i]) continue;
-        const int lm = p->res_lm[i];
-        if (lm < 0 || lm >= p->n_lm || p->lm_anchor_kf[lm] < 0 || p->lm_anchor_kf[lm] >= p->n_kf) { free(w.pose_col); free(w.act); return -1; }
-        if (p->res_type[i] != ORC_RES_RIGHT_ANCH && (p->res_kf[i] < 0 || p->res_kf[i] >= p->n_kf)) { free(w.pose_col); free(w.act); return -1; }
+        if (p->res_type[i] == ORC_RES_PNP) {
+            if (!p->res_xyz || p->res_kf[i] < 0 || p->res_kf[i] >= p->n_kf) { free(w.pose_col); free(w.act); return -1; }
+        } else {
+            const int lm = p->res_lm[i];
+            if (lm < 0 || lm >= p->n_lm || p->lm_anchor_kf[lm] < 0 || p->lm_anchor_kf[lm] >= p->n_kf) { free(w.pose_col); free(w.act); return -1; }
+            if (p->res_type[i] != ORC_RES_RIGHT_ANCH && (p->res_kf[i] < 0 || p->res_kf[i] >= p->n_kf)) { free(w.pose_col); free(w.act); return -1; }
+        }
         w.act[w.n_act++] = i;
     }
     /* landmark -> residual CSR */
     w.lm_ptr = (int *)calloc((size_t)p->n_lm + 2, sizeof(int));
     w.lm_idx = (int *)malloc(sizeof(int) * (size_t)(w.n_act + 1));
-    for (int k = 0; k < w.n_act; k++) w.lm_ptr[p->res_lm[w.act[k]] + 1]++;
+    for (int k = 0; k < w.n_act; k++) if (p->res_type[w.act[k]] != ORC_RES_PNP) w.lm_ptr[p->res_lm[w.act[k]] + 1]++;
     for (int l = 0; l < p->n_lm; l++) w.lm_ptr[l + 1] += w.lm_ptr[l];
     {
         int *fill = (int *)malloc(sizeof(int) * (size_t)(p->n_lm + 1));
         memcpy(fill, w.lm_ptr, sizeof(int) * (size_t)(p->n_lm + 1));
-        for (int k = 0; k < w.n_act; k++) w.lm_idx[fill[p->res_lm[w.act[k]]]++] = k;
+        for (int k = 0; k < w.n_act; k++) if (p->res_type[w.act[k]] != ORC_RES_PNP) w.lm_idx[fill[p->res_lm[w.act[k]]]++] = k;
         free(fill);
     }
     const size_t na = (size_t)w.n_act + 1;
@@ -625,16 +691,15 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
         if (lin_ok) {
             /* model_cost_change = -(J step) . (r + J step / 2) */
             for (int k = 0; k < w.n_act; k++) {
-                const int i = w.act[k], lm = p->res_lm[i], a = p->lm_anchor_kf[lm];
-                const int ob = p->res_type[i] == ORC_RES_RIGHT_ANCH ? a : p->res_kf[i];
-                const int ca = w.pose_col[a], co = w.pose_col[ob];
+                int lm, ca, co;
+                ba_res_blocks(&w, w.act[k], &lm, &ca, &co);
                 const double *Ja = w.Ja + 12 * k, *Jo = w.Jo + 12 * k, *Jl = w.Jl + 2 * k, *r = w.r + 2 * k;
-                double m0 = Jl[0] * yl[lm], m1 = Jl[1] * yl[lm];
-                if (p->res_type[i] != ORC_RES_RIGHT_ANCH)
-                    for (int c = 0; c < 6; c++) {
-                        if (ca >= 0) { m0 += Ja[c] * yf[ca + c]; m1 += Ja[6 + c] * yf[ca + c]; }
-                        if (co >= 0) { m0 += Jo[c] * yf[co + c]; m1 += Jo[6 + c] * yf[co + c]; }
-                    }
+                double m0 = 0, m1 = 0;
+                if (lm >= 0) { m0 = Jl[0] * yl[lm]; m1 = Jl[1] * yl[lm]; }
+                for (int c = 0; c < 6; c++) {
+                    if (ca >= 0) { m0 += Ja[c] * yf[ca + c]; m1 += Ja[6 + c] * yf[ca + c]; }
+                    if (co >= 0) { m0 += Jo[c] * yf[co + c]; m1 += Jo[6 + c] * yf[co + c]; }
+                }
                 model_cost_change -= m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0);
             }
             step_valid = model_cost_change > 0.0;

@@ -191,7 +191,7 @@ class _BAProblem(C.Structure):
         ("n_kf", C.c_int), ("poses", C.c_void_p), ("kf_const", C.c_void_p),
         ("n_lm", C.c_int), ("invdepth", C.c_void_p), ("lm_anchor_kf", C.c_void_p), ("lm_anchor_uv", C.c_void_p),
         ("n_res", C.c_int), ("res_type", C.c_void_p), ("res_kf", C.c_void_p), ("res_lm", C.c_void_p),
-        ("res_uv", C.c_void_p), ("res_sigma", C.c_void_p), ("res_active", C.c_void_p),
+        ("res_uv", C.c_void_p), ("res_sigma", C.c_void_p), ("res_active", C.c_void_p), ("res_xyz", C.c_void_p),
         ("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7),
     ]
 
@@ -242,6 +242,8 @@ def ba_solve(prob, opts=None, res_active=None, chi2_init=None, depthpos_init=Non
     if res_active is not None:
         ra = np.ascontiguousarray(res_active, np.uint8); keep["ra"] = ra
         P.res_active = ra.ctypes.data
+    if prob.get("res_xyz") is not None:
+        P.res_xyz = arr("res_xyz", np.float64)
     for i in range(4):
         P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
     for i in range(7):

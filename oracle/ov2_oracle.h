@@ -146,6 +146,8 @@ enum {
     ORC_RES_LEFT        = 0, /* ReprojectionErrorKSE3AnchInvDepth        ceres_parametrization.cpp:361 */
     ORC_RES_RIGHT       = 1, /* ReprojectionErrorRightCamKSE3AnchInvDepth  :579 */
     ORC_RES_RIGHT_ANCH  = 2, /* ReprojectionErrorRightAnchCamKSE3AnchInvDepth :476 */
+    ORC_RES_PNP         = 3, /* DirectLeftSE3::ReprojectionErrorSE3 (fixed world point), ceres_parametrization.cpp:301-358;
+                                used by MultiViewGeometry::ceresPnP, src/multi_view_geometry.cpp:492-586 */
 };
 
 typedef struct {
@@ -163,6 +165,7 @@ typedef struct {
     const double *res_uv;   /* 2*n_res observed pixel                         */
     const double *res_sigma;/* n_res                                          */
     const uint8_t *res_active; /* n_res or NULL (all active)                   */
+    const double *res_xyz;  /* 3*n_res world point of ORC_RES_PNP blocks (ignored for the others); NULL if none */
     double calib_l[4];      /* fx fy cx cy                                    */
     double calib_r[4];
     double T_rl[7];         /* [t, q] of Trl (right <- left)                  */

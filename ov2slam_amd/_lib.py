@@ -15,7 +15,7 @@ OV2_EINVAL, OV2_EHIP, OV2_ENOMEM, OV2_EUNSUPPORTED, OV2_ENODEVICE = -1, -2, -3, 
 OV2_LK_USE_INITIAL_FLOW = 4
 OV2_LK_GET_MIN_EIGENVALS = 8
 OV2_MASK_AS_EXECUTED, OV2_MASK_INTENDED = 0, 1
-OV2_RES_LEFT, OV2_RES_RIGHT, OV2_RES_RIGHT_ANCH = 0, 1, 2
+OV2_RES_LEFT, OV2_RES_RIGHT, OV2_RES_RIGHT_ANCH, OV2_RES_PNP = 0, 1, 2, 3
 
 
 class Ov2Error(RuntimeError):
@@ -31,7 +31,7 @@ class BAProblem(C.Structure):
         ("lm_anchor_uv", C.POINTER(C.c_double)),
         ("n_res", C.c_int), ("res_type", C.POINTER(C.c_uint8)), ("res_kf", C.POINTER(C.c_int)),
         ("res_lm", C.POINTER(C.c_int)), ("res_uv", C.POINTER(C.c_double)), ("res_sigma", C.POINTER(C.c_double)),
-        ("res_active", C.POINTER(C.c_uint8)),
+        ("res_active", C.POINTER(C.c_uint8)), ("res_xyz", C.POINTER(C.c_double)),
         ("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7),
     ]
 

@@ -63,6 +63,10 @@ struct BADev {                    // device pointers + sizes (passed by value to
     const int *res_orig;          // n_act -> index in the caller's arrays
     const double *res_uv;         // 2*n_act
     const double *res_sigma;      // n_act
+    // pose-only residual blocks (OV2_RES_PNP), not attached to a landmark
+    int n_po;
+    const int *po_kf, *po_orig;   // n_po
+    const double *po_xyz, *po_uv, *po_sigma;   // 3, 2, 1 per block
     double calib_l[4], calib_r[4];
     double Rrl[9], trl[3];
     double huber;                 // <= 0 : trivial loss
@@ -229,6 +233,35 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// DirectLeftSE3::ReprojectionErrorSE3 (ceres_parametrization.cpp:301-358): fixed world point, Jacobian w.r.t. the pose
+template <bool JAC>
+__device__ __forceinline__ int d_residual_pnp(const BADev &D, const double *RTo, const double *xyz, const double *uv, double sigma,
+                                              double *r, double *Jo)
+{
+    const double sqrt_info = 1.0 / sigma;
+    const double d[3] = {xyz[0] - RTo[9], xyz[1] - RTo[10], xyz[2] - RTo[11]};
+    double c[3];
+    for (int i = 0; i < 3; i++) c[i] = RTo[i] * d[0] + RTo[3 + i] * d[1] + RTo[6 + i] * d[2];      // Rcw = Rwc^T
+    const double invz = 1.0 / c[2];
+    const double *K = D.calib_l;
+    r[0] = sqrt_info * (K[0] * c[0] * invz + K[2] - uv[0]);
+    r[1] = sqrt_info * (K[1] * c[1] * invz + K[3] - uv[1]);
+    if (JAC) {
+        const double invz2 = invz * invz;
+        const double Jc[6] = {invz * K[0], 0, -c[0] * invz2 * K[0], 0, invz * K[1], -c[1] * invz2 * K[1]};
+        double JR[6];
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) JR[3 * i + j] = Jc[3 * i] * RTo[3 * j] + Jc[3 * i + 1] * RTo[3 * j + 1] + Jc[3 * i + 2] * RTo[3 * j + 2];
+        const double S[9] = {0, -xyz[2], xyz[1], xyz[2], 0, -xyz[0], -xyz[1], xyz[0], 0};
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 3; j++) {
+                const double jrs = JR[3 * i] * S[j] + JR[3 * i + 1] * S[3 + j] + JR[3 * i + 2] * S[6 + j];
+                Jo[6 * i + j] = -sqrt_info * JR[3 * i + j];
+                Jo[6 * i + 3 + j] = sqrt_info * jrs;
+            }
+    }
+    return c[2] > 0;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -408,6 +441,56 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
 }
 
+// ---------------------------------------------------------------------------------- pose-only residual blocks
+// rows without an e-block (Ceres: SchurEliminator::NoEBlockRowsUpdate): F^T F / F^T b pre-aggregated per workgroup in LDS.
+// dynamic LDS: n_opt * 27 doubles
+__global__ __launch_bounds__(256) void k_ba_linearize_po(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->need_lin) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int n_opt = D.nf / 6;
+    double *Hoo = (double *)smem_raw, *bo = Hoo + n_opt * 21;
+    for (int e = threadIdx.x; e < n_opt * 27; e += blockDim.x) Hoo[e] = 0;
+    __syncthreads();
+    double cost = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.n_po; k += gridDim.x * blockDim.x) {
+        const int o = D.po_kf[k], co = D.pose_col[o];
+        double r[2], Jo[12];
+        const int dp = d_residual_pnp<true>(D, D.x_RT + 12 * o, D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, Jo);
+        const double s = r[0] * r[0] + r[1] * r[1];
+        const int orig = D.po_orig[k];
+        D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
+        double rho0, rho1;
+        d_huber(D.huber, s, rho0, rho1);
+        cost += 0.5 * rho0;
+        if (co < 0) continue;
+        const double sc = sqrt(rho1);
+        r[0] *= sc; r[1] *= sc;
+        for (int q = 0; q < 12; q++) Jo[q] *= sc;
+        const int ob = co / 6;
+        int t = 0;
+        for (int c = 0; c < 6; c++) {
+            atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+            for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_opt * 21; e += blockDim.x) {
+        const double v = Hoo[e];
+        if (v != 0.0) {
+            const int ob = e / 21;
+            int t = e - ob * 21, c = 0, d = 0;
+            for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
+            atomicAdd(&D.H[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
+        }
+    }
+    for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
+    __shared__ double s_part[4];
+    cost = block_sum(cost, s_part);
+    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+}
+
 // ---------------------------------------------------------------------------------- cost only
 __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
 {
@@ -433,6 +516,17 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
             d_huber(D.huber, s, rho0, rho1);
             cost += 0.5 * rho0;
         }
+    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.n_po; k += gridDim.x * blockDim.x) {
+        double r[2];
+        const int o = D.po_kf[k];
+        const int dp = d_residual_pnp<false>(D, D.c_RT + 12 * o, D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, nullptr);
+        const double s = r[0] * r[0] + r[1] * r[1];
+        const int orig = D.po_orig[k];
+        D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
+        double rho0, rho1;
+        d_huber(D.huber, s, rho0, rho1);
+        cost += 0.5 * rho0;
     }
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
@@ -999,16 +1093,22 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     OV2_REQUIRE(p->poses && p->kf_const, OV2_EINVAL, "NULL pose arrays");
     OV2_REQUIRE(p->n_lm == 0 || (p->invdepth && p->lm_anchor_kf && p->lm_anchor_uv), OV2_EINVAL, "NULL landmark arrays");
     OV2_REQUIRE(p->n_res == 0 || (p->res_type && p->res_kf && p->res_lm && p->res_uv && p->res_sigma), OV2_EINVAL, "NULL residual arrays");
-    // validate + landmark-sorted order of the active residual blocks
+    // validate + landmark-sorted order of the active residual blocks; pose-only blocks (OV2_RES_PNP) go to their own list
     std::vector<int> cnt(p->n_lm + 1, 0);
-    int n_act = 0;
+    int n_act = 0, n_po = 0;
     for (int i = 0; i < p->n_res; i++) {
         if (p->res_active && !p->res_active[i]) continue;
+        OV2_REQUIRE(p->res_type[i] <= OV2_RES_PNP, OV2_EINVAL, "unknown residual type");
+        OV2_REQUIRE(p->res_sigma[i] > 0, OV2_EINVAL, "res_sigma must be positive");
+        if (p->res_type[i] == OV2_RES_PNP) {
+            OV2_REQUIRE(p->res_xyz != nullptr, OV2_EINVAL, "OV2_RES_PNP blocks need res_xyz");
+            OV2_REQUIRE(p->res_kf[i] >= 0 && p->res_kf[i] < p->n_kf, OV2_EINVAL, "res_kf out of range");
+            n_po++;
+            continue;
+        }
         const int lm = p->res_lm[i];
         OV2_REQUIRE(lm >= 0 && lm < p->n_lm, OV2_EINVAL, "res_lm out of range");
-        OV2_REQUIRE(p->res_type[i] <= OV2_RES_RIGHT_ANCH, OV2_EINVAL, "unknown residual type");
         if (p->res_type[i] != OV2_RES_RIGHT_ANCH) OV2_REQUIRE(p->res_kf[i] >= 0 && p->res_kf[i] < p->n_kf, OV2_EINVAL, "res_kf out of range");
-        OV2_REQUIRE(p->res_sigma[i] > 0, OV2_EINVAL, "res_sigma must be positive");
         cnt[lm + 1]++; n_act++;
     }
     for (int l = 0; l < p->n_lm; l++) {
@@ -1023,8 +1123,18 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
     std::vector<uint8_t> res_type(n_act);
     std::vector<double> res_uv(2 * (size_t)n_act), res_sigma(n_act);
+    std::vector<int> po_kf(n_po), po_orig(n_po);
+    std::vector<double> po_xyz(3 * (size_t)n_po), po_uv(2 * (size_t)n_po), po_sigma(n_po);
+    int kp = 0;
     for (int i = 0; i < p->n_res; i++) {
         if (p->res_active && !p->res_active[i]) continue;
+        if (p->res_type[i] == OV2_RES_PNP) {
+            po_kf[kp] = p->res_kf[i]; po_orig[kp] = i; po_sigma[kp] = p->res_sigma[i];
+            po_uv[2 * kp] = p->res_uv[2 * i]; po_uv[2 * kp + 1] = p->res_uv[2 * i + 1];
+            for (int c = 0; c < 3; c++) po_xyz[3 * kp + c] = p->res_xyz[3 * i + c];
+            kp++;
+            continue;
+        }
         const int k = fill[p->res_lm[i]]++;
         res_type[k] = p->res_type[i]; res_kf[k] = p->res_type[i] == OV2_RES_RIGHT_ANCH ? p->lm_anchor_kf[p->res_lm[i]] : p->res_kf[i];
         res_orig[k] = i; res_uv[2 * k] = p->res_uv[2 * i]; res_uv[2 * k + 1] = p->res_uv[2 * i + 1]; res_sigma[k] = p->res_sigma[i];
@@ -1038,7 +1148,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     dev->h_lam0.assign(p->invdepth, p->invdepth + (p->n_lm > 0 ? p->n_lm : 0));
     BADev &D = dev->D;
     memset(&D, 0, sizeof(D));
-    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp;
+    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po;
     const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
@@ -1051,6 +1161,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
+    const size_t npo = (size_t)std::max(1, n_po);
+    const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
     hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
     if (e != hipSuccess) { delete dev; ov2_set_error("hipMalloc(%zu): %s", off, hipGetErrorString(e)); return OV2_ENOMEM; }
@@ -1065,6 +1177,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
     dev->lm_order = (int *)(b + o_lm_order);
+    D.po_kf = (int *)(b + o_po_kf); D.po_orig = (int *)(b + o_po_orig); D.po_xyz = (double *)(b + o_po_xyz); D.po_uv = (double *)(b + o_po_uv); D.po_sigma = (double *)(b + o_po_sigma);
     for (int i = 0; i < 4; i++) { D.calib_l[i] = p->calib_l[i]; D.calib_r[i] = p->calib_r[i]; }
     {   // Trl: normalised quaternion -> R (host)
         double q[4] = {p->T_rl[3], p->T_rl[4], p->T_rl[5], p->T_rl[6]};
@@ -1092,6 +1205,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     UP(D.res_orig, res_orig.data(), 4 * (size_t)n_act);
     UP(D.res_uv, res_uv.data(), 16 * (size_t)n_act);
     UP(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
+    UP(D.po_kf, po_kf.data(), 4 * (size_t)n_po); UP(D.po_orig, po_orig.data(), 4 * (size_t)n_po);
+    UP(D.po_xyz, po_xyz.data(), 24 * (size_t)n_po); UP(D.po_uv, po_uv.data(), 16 * (size_t)n_po); UP(D.po_sigma, po_sigma.data(), 8 * (size_t)n_po);
 #undef UP
     // the staging vectors die at return: make sure the copies are done
     OV2_HIP_CHECK(hipStreamSynchronize(s));
@@ -1159,13 +1274,15 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
     int lm_per_split = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
     ksplit = std::max(1, (D.n_lm + lm_per_split - 1) / lm_per_split);
-    const int ws_blocks = std::max(1, std::min(512, (D.n_lm + 3) / 4));
+    const int ws_blocks = std::max(1, std::min(512, std::max((D.n_lm + 3) / 4, (D.n_po + 255) / 256)));
+    const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
     const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
     OV2_REQUIRE(chol_lds <= 160 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (max ~95 optimised keyframes)");
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_cholesky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
 
     auto linearize = [&]() {
-        hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (size_t)n_opt * 27 * 8 + 16, s, D);
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
     linearize();

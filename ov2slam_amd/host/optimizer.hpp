@@ -17,7 +17,7 @@ struct FlatProblem {
     std::vector<double> lm_anchor_uv;   // 2 per landmark
     std::vector<uint8_t> res_type;      // OV2_RES_*
     std::vector<int> res_kf, res_lm;
-    std::vector<double> res_uv, res_sigma;
+    std::vector<double> res_uv, res_sigma, res_xyz;   // res_xyz: 3 per residual, used by OV2_RES_PNP blocks only
     double calib_l[4] = {0, 0, 0, 0}, calib_r[4] = {0, 0, 0, 0}, T_rl[7] = {0, 0, 0, 0, 0, 0, 1};
 
     int addKeyframe(const double pose[7], bool constant) { poses.insert(poses.end(), pose, pose + 7); kf_const.push_back(constant); return (int)kf_const.size() - 1; }
@@ -27,14 +27,20 @@ struct FlatProblem {
     }
     int addResidual(int type, int kf, int lm, double u, double v, double sigma) {
         res_type.push_back((uint8_t)type); res_kf.push_back(kf); res_lm.push_back(lm); res_uv.push_back(u); res_uv.push_back(v); res_sigma.push_back(sigma);
+        res_xyz.push_back(0); res_xyz.push_back(0); res_xyz.push_back(0);
         return (int)res_type.size() - 1;
+    }
+    int addPnPResidual(int kf, const double xyz[3], double u, double v, double sigma) {
+        const int i = addResidual(OV2_RES_PNP, kf, -1, u, v, sigma);
+        res_xyz[3 * i] = xyz[0]; res_xyz[3 * i + 1] = xyz[1]; res_xyz[3 * i + 2] = xyz[2];
+        return i;
     }
     ov2_ba_problem view(const uint8_t *res_active) const {
         ov2_ba_problem p;
         p.n_kf = (int)kf_const.size(); p.poses = poses.data(); p.kf_const = kf_const.data();
         p.n_lm = (int)invdepth.size(); p.invdepth = invdepth.data(); p.lm_anchor_kf = lm_anchor_kf.data(); p.lm_anchor_uv = lm_anchor_uv.data();
         p.n_res = (int)res_type.size(); p.res_type = res_type.data(); p.res_kf = res_kf.data(); p.res_lm = res_lm.data();
-        p.res_uv = res_uv.data(); p.res_sigma = res_sigma.data(); p.res_active = res_active;
+        p.res_uv = res_uv.data(); p.res_sigma = res_sigma.data(); p.res_active = res_active; p.res_xyz = res_xyz.data();
         for (int i = 0; i < 4; i++) { p.calib_l[i] = calib_l[i]; p.calib_r[i] = calib_r[i]; }
         for (int i = 0; i < 7; i++) p.T_rl[i] = T_rl[i];
         return p;

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib as L
 
-RES_LEFT, RES_RIGHT, RES_RIGHT_ANCH = 0, 1, 2
+RES_LEFT, RES_RIGHT, RES_RIGHT_ANCH, RES_PNP = 0, 1, 2, 3
 TERMINATION = {0: "NO_CONVERGENCE", 1: "FUNCTION_TOLERANCE", 2: "PARAMETER_TOLERANCE", 3: "GRADIENT_TOLERANCE",
                4: "MIN_RADIUS", 5: "INVALID_STEPS", 6: "FAILURE"}
 
@@ -46,6 +46,8 @@ def pack_problem(prob, res_active=None):
         ra = np.ascontiguousarray(res_active, np.uint8)
         keep.append(ra)
         P.res_active = _u8p(ra)
+    if prob.get("res_xyz") is not None:
+        P.res_xyz = _dp(arr("res_xyz", np.float64))
     for i in range(4):
         P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
     for i in range(7):
@@ -170,3 +172,45 @@ class Optimizer:
             bad = bad | bad2
         out.update(poses=poses, invdepth=lam, chi2=chi2, depthpos=dpos, bad_obs=bad)
         return out
+
+
+class MultiViewGeometry:
+    """Mirror of MultiViewGeometry::ceresPnP (/root/reference/src/multi_view_geometry.cpp:492-586), the per-frame
+    motion-only BA called from VisualFrontEnd::computePose (src/visual_front_end.cpp:788-801):
+      pass 1  Huber(sqrt(chi2th)) if buse_robust, nmaxiter iterations, function_tolerance 1e-3   (:519-544)
+      outliers  chi2err_ > chi2th or depth <= 0 (values cached by the last Evaluate, N4); residual blocks removed
+                if bapply_l2_after_robust; returns False when every observation is bad                (:547-565)
+      pass 2  loss reset to L2, same options, only if outliers were found                           (:567-570)
+    `solver` is injectable so that the tests can run the identical protocol on the oracle."""
+
+    def __init__(self, ctx=None, solver=None):
+        self.ctx, self._solver = ctx, solver
+
+    def _solve(self, prob, res_active, chi2_init, depthpos_init, **kw):
+        if self._solver is not None:
+            return self._solver(prob, res_active, chi2_init, depthpos_init, **kw)
+        return solve(self.ctx, prob, default_options(self.ctx.lib, **kw), res_active, chi2_init, depthpos_init)
+
+    def ceresPnP(self, vunkps, vwpts, vscales, Twc, nmaxiter, chi2th, buse_robust, bapply_l2_after_robust, fx, fy, cx, cy):
+        """Twc: [tx ty tz qx qy qz qw].  Returns (success, Twc_out, voutliersidx)."""
+        n = len(vunkps)
+        K = np.array([fx, fy, cx, cy], np.float64)
+        prob = dict(n_kf=1, n_lm=0, n_res=n, poses=np.asarray(Twc, np.float64).reshape(1, 7), kf_const=np.zeros(1, np.uint8),
+                    invdepth=np.zeros(0), lm_anchor_kf=np.zeros(0, np.int32), lm_anchor_uv=np.zeros((0, 2)),
+                    res_type=np.full(n, RES_PNP, np.uint8), res_kf=np.zeros(n, np.int32), res_lm=np.full(n, -1, np.int32),
+                    res_uv=np.asarray(vunkps, np.float64).reshape(n, 2), res_sigma=np.power(2.0, np.asarray(vscales, np.float64)),
+                    res_xyz=np.asarray(vwpts, np.float64).reshape(n, 3), calib_l=K, calib_r=K, T_rl=np.array([0, 0, 0, 0, 0, 0, 1.0]))
+        huber = math.sqrt(chi2th) if buse_robust else -1.0
+        p1 = self._solve(prob, None, None, None, max_iter=int(nmaxiter), function_tolerance=1e-3, huber_delta=huber)
+        bad = (p1["chi2"] > chi2th) | (p1["depthpos"] == 0)
+        vout = np.nonzero(bad)[0]
+        pose, last = p1["poses"][0], p1
+        if bad.all():
+            return False, pose, vout
+        if bapply_l2_after_robust and len(vout):
+            prob2 = dict(prob); prob2["poses"] = p1["poses"]
+            last = self._solve(prob2, (~bad).astype(np.uint8), p1["chi2"], p1["depthpos"], max_iter=int(nmaxiter),
+                               function_tolerance=1e-3, huber_delta=-1.0)
+            pose = last["poses"][0]
+        usable = last["termination"] in (0, 1, 2, 3, 4)      # Summary::IsSolutionUsable: CONVERGENCE / NO_CONVERGENCE
+        return bool(usable), pose, vout

@@ -192,3 +192,27 @@ def make_ba_problem(n_kf=50, n_lm=10000, obs_per_lm=30, stereo=False, seed=42, p
                 res_uv=np.ascontiguousarray(res_uv, np.float64), res_sigma=np.ones(int(n_res)),
                 calib_l=K.copy(), calib_r=K.copy(), T_rl=T_rl,
                 poses_gt=poses_gt, invdepth_gt=invdepth_gt, is_outlier=np.ascontiguousarray(is_out))
+
+
+def make_pnp_problem(n_pts=300, seed=7, px_noise=1.0, outlier_frac=0.05, pose_noise=(0.05, np.deg2rad(1.0))):
+    """Motion-only BA (MultiViewGeometry::ceresPnP, src/multi_view_geometry.cpp:492-586): one free pose, `n_pts`
+    fixed world points observed in the left camera.  Same flat layout as make_ba_problem (n_lm = 0, residual
+    type 3 = OV2_RES_PNP with res_xyz)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.654; cx, cy = 367.215, 248.375
+    R = _so3_exp(rng.normal(0, 0.3, 3)); t = rng.normal(0, 1.0, 3)
+    pose_gt = np.concatenate([t, _quat_from_R(R)])
+    pc = np.stack([rng.uniform(-3, 3, n_pts), rng.uniform(-2, 2, n_pts), rng.uniform(2, 12, n_pts)], 1)   # camera frame
+    X = (R @ pc.T).T + t
+    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1)
+    out = rng.uniform(size=n_pts) < outlier_frac
+    uv = uv + np.where(out[:, None], rng.uniform(-60, 60, uv.shape), rng.normal(0, px_noise, uv.shape))
+    R0 = _so3_exp(rng.normal(0, pose_noise[1], 3)) @ R
+    pose0 = np.concatenate([t + rng.normal(0, pose_noise[0], 3), _quat_from_R(R0)])
+    K = np.array([fx, fy, cx, cy])
+    return dict(n_kf=1, n_lm=0, n_res=n_pts, poses=pose0[None].copy(), kf_const=np.zeros(1, np.uint8),
+                invdepth=np.zeros(0), lm_anchor_kf=np.zeros(0, np.int32), lm_anchor_uv=np.zeros((0, 2)),
+                res_type=np.full(n_pts, 3, np.uint8), res_kf=np.zeros(n_pts, np.int32), res_lm=np.full(n_pts, -1, np.int32),
+                res_uv=np.ascontiguousarray(uv), res_sigma=np.ones(n_pts), res_xyz=np.ascontiguousarray(X),
+                calib_l=K.copy(), calib_r=K.copy(), T_rl=np.array([0, 0, 0, 0, 0, 0, 1.0]),
+                poses_gt=pose_gt[None].copy(), is_outlier=out)

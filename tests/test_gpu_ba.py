@@ -85,3 +85,47 @@ def test_ba_edge_cases(gpu_ctx, oracle):
     bad = dict(pb); bad["res_lm"] = pb["res_lm"].copy(); bad["res_lm"][0] = 10**6
     with pytest.raises(ov2slam_amd.Ov2Error):
         optimizer.solve(gpu_ctx, bad)
+
+
+def test_pnp_matches_oracle(gpu_ctx, oracle):
+    """OV2_RES_PNP (ReprojectionErrorSE3, ceresPnP) through the device solver vs the oracle."""
+    for n, seed in ((30, 1), (300, 2), (2000, 3)):
+        pb = synth.make_pnp_problem(n, seed=seed)
+        for kw in (dict(), dict(huber_delta=-1.0, max_iter=10), dict(max_iter=12, function_tolerance=1e-9)):
+            g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+            r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
+            _cmp(g, r, pb)
+
+
+def test_ceres_pnp_protocol_matches_oracle(gpu_ctx, oracle):
+    def oracle_solver(prob, res_active, chi2_init, depthpos_init, **kw):
+        return oracle.ba_solve(prob, oracle.ba_default_options(**kw), res_active, chi2_init, depthpos_init)
+    pb = synth.make_pnp_problem(300, seed=9)
+    K = pb["calib_l"]
+    args = (pb["res_uv"], pb["res_xyz"], np.zeros(300), pb["poses"][0], 5, 5.9915, True, True) + tuple(K)
+    gok, gT, gout = ov2slam_amd.MultiViewGeometry(gpu_ctx).ceresPnP(*args)
+    rok, rT, rout = ov2slam_amd.MultiViewGeometry(None, solver=oracle_solver).ceresPnP(*args)
+    assert gok == rok and np.array_equal(gout, rout)
+    assert np.abs(gT[:3] - rT[:3]).max() <= 1e-7 * max(1.0, np.abs(rT[:3]).max())
+    assert np.abs(gT[3:] * np.sign(gT[3:] @ rT[3:]) - rT[3:]).max() <= 1e-7
+
+
+def test_mixed_problem_with_pose_only_blocks(gpu_ctx, oracle):
+    """Landmark factors and pose-only factors in one problem (rows with and without an e-block)."""
+    pb = synth.make_ba_problem(8, 200, 5, stereo=True, seed=12)
+    pn = synth.make_pnp_problem(60, seed=4)
+    n0, n1 = pb["n_res"], pn["n_res"]
+    # attach the PnP observations to keyframe 3 of the BA problem (world points expressed for that pose)
+    from tests.test_oracle_ba import np_T
+    T3 = np_T(pb["poses_gt"][3]) @ np.linalg.inv(np_T(pn["poses_gt"][0]))
+    X = (T3[:3, :3] @ pn["res_xyz"].T).T + T3[:3, 3]
+    mix = dict(pb)
+    mix["n_res"] = n0 + n1
+    mix["res_type"] = np.concatenate([pb["res_type"], pn["res_type"]])
+    mix["res_kf"] = np.concatenate([pb["res_kf"], np.full(n1, 3, np.int32)])
+    mix["res_lm"] = np.concatenate([pb["res_lm"], pn["res_lm"]])
+    mix["res_uv"] = np.concatenate([pb["res_uv"], pn["res_uv"]])
+    mix["res_sigma"] = np.concatenate([pb["res_sigma"], pn["res_sigma"]])
+    mix["res_xyz"] = np.concatenate([np.zeros((n0, 3)), X])
+    g = optimizer.solve(gpu_ctx, mix); r = oracle.ba_solve(mix)
+    _cmp(g, r, mix)

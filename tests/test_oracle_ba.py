@@ -281,3 +281,94 @@ def test_degenerate_inputs(oracle):
     assert out["final_cost"] <= out["initial_cost"] and np.array_equal(out["poses"], pb["poses"])
     none_active = oracle.ba_solve(pb, res_active=np.zeros(pb["n_res"], np.uint8))
     assert none_active["initial_cost"] == 0.0
+
+
+# ----------------------------------------------------------------------------- ceresPnP (pose-only factor)
+def np_pnp_residuals(pb, pose):
+    T = np.linalg.inv(np_T(pose))
+    pc = (T[:3, :3] @ pb["res_xyz"].T).T + T[:3, 3]
+    K = pb["calib_l"]
+    return np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1) - pb["res_uv"], pc[:, 2] > 0
+
+
+def dense_lm_pnp(pb, max_iter, huber, ftol):
+    """Independent dense LM on the 6-dof pose (numeric Jacobian, QR-free normal equations)."""
+    pose = pb["poses"][0].copy()
+
+    def lin(pose):
+        R, _ = np_pnp_residuals(pb, pose)
+        s = (R * R).sum(1)
+        if huber > 0:
+            big = s > huber * huber
+            rho = np.where(big, 2 * huber * np.sqrt(np.where(big, s, 1)) - huber * huber, s)
+            w = np.where(big, np.sqrt(huber / np.sqrt(np.where(big, s, 1))), 1.0)
+        else:
+            rho, w = s, np.ones_like(s)
+        J = np.zeros((2 * len(R), 6)); eps = 1e-6
+        for c in range(6):
+            d = np.zeros(6); d[c] = eps
+            rp, _ = np_pnp_residuals(pb, np_plus(pose, d)); rm, _ = np_pnp_residuals(pb, np_plus(pose, -d))
+            J[:, c] = ((rp - rm) / (2 * eps) * w[:, None]).reshape(-1)
+        return (R * w[:, None]).reshape(-1), J, 0.5 * rho.sum()
+
+    def cost_of(pose):
+        R, _ = np_pnp_residuals(pb, pose)
+        s = (R * R).sum(1)
+        if huber > 0:
+            big = s > huber * huber
+            s = np.where(big, 2 * huber * np.sqrt(np.where(big, s, 1)) - huber * huber, s)
+        return 0.5 * s.sum()
+
+    r, J, cost = lin(pose)
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0))); J = J * scale
+    radius, nu, reuse, diag, iters = 1e4, 2.0, False, None, 0
+    for _ in range(max_iter):
+        if not reuse:
+            diag = np.clip((J * J).sum(0), 1e-6, 1e32)
+        D = np.sqrt(diag / radius); iters += 1
+        step = -np.linalg.solve(J.T @ J + np.diag(D * D), J.T @ r); reuse = True
+        m = J @ step; model = -m @ (r + m / 2)
+        if model <= 0:
+            radius /= nu; nu *= 2; continue
+        cand = np_plus(pose, step * scale); cc = cost_of(cand)
+        if abs(cost - cc) <= ftol * cost:
+            break
+        q = (cost - cc) / model
+        if q > 1e-3:
+            pose = cand; r, J, cost = lin(pose); J = J * scale
+            radius = min(1e16, radius / max(1 / 3, 1 - (2 * q - 1) ** 3)); nu = 2.0; reuse = False
+        else:
+            radius /= nu; nu *= 2
+    return pose, cost, iters
+
+
+@pytest.mark.parametrize("huber", [np.sqrt(5.9915), -1.0])
+def test_pnp_matches_dense_lm(oracle, huber):
+    pb = synth.make_pnp_problem(120, seed=3)
+    out = oracle.ba_solve(pb, oracle.ba_default_options(max_iter=8, function_tolerance=1e-7, huber_delta=huber))
+    pose, cost, iters = dense_lm_pnp(pb, 8, huber, 1e-7)
+    assert out["iterations"] == iters and abs(out["final_cost"] - cost) < 1e-6 * cost
+    q = out["poses"][0, 3:] * np.sign(out["poses"][0, 3:] @ pose[3:])
+    assert np.allclose(out["poses"][0, :3], pose[:3], atol=1e-6) and np.allclose(q, pose[3:], atol=1e-7)
+    r, dp = np_pnp_residuals(pb, out["poses"][0])
+    assert np.array_equal(out["depthpos"].astype(bool), dp)
+
+
+def test_ceres_pnp_protocol(oracle):
+    """MultiViewGeometry.ceresPnP on the oracle: recovers the pose, flags the injected outliers."""
+    import ov2slam_amd
+
+    def oracle_solver(prob, res_active, chi2_init, depthpos_init, **kw):
+        return oracle.ba_solve(prob, oracle.ba_default_options(**kw), res_active, chi2_init, depthpos_init)
+    pb = synth.make_pnp_problem(300, seed=9)
+    K = pb["calib_l"]
+    mvg = ov2slam_amd.MultiViewGeometry(None, solver=oracle_solver)
+    ok, Twc, outl = mvg.ceresPnP(pb["res_uv"], pb["res_xyz"], np.zeros(300), pb["poses"][0], 5, 5.9915, True, True, *K)
+    assert ok
+    assert np.linalg.norm(Twc[:3] - pb["poses_gt"][0, :3]) < 0.25 * np.linalg.norm(pb["poses"][0, :3] - pb["poses_gt"][0, :3])
+    flagged = np.zeros(300, bool); flagged[outl] = True
+    assert flagged[pb["is_outlier"]].mean() > 0.9 and flagged[~pb["is_outlier"]].mean() < 0.1
+    # every observation bad -> False (multi_view_geometry.cpp:563-565)
+    bad_uv = pb["res_uv"] + 500.0
+    ok2, _, outl2 = mvg.ceresPnP(bad_uv, pb["res_xyz"], np.zeros(300), pb["poses_gt"][0], 5, 5.9915, True, True, *K)
+    assert not ok2 and len(outl2) == 300
