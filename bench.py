@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--seqs", type=int, default=256, help="sequences processed in lock-step per GPU")
+    ap.add_argument("--seqs", type=int, default=1024, help="sequences processed in lock-step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the BA / detect / single-sequence sections")
     args = ap.parse_args()
@@ -231,7 +231,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                  # RCCL: 8 bytes, timings only
     elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel: k_fb_klt<9> -------------------------------------------
+    # ---- roofline of the dominant kernel: k_fb_klt3 (lk3.hip) -------------------------------------------
     iters, visits = [int(v) for v in stats_d.tolist()]
     ms_A = sum(a.elapsed_time(b) for a, b, c in lk_events)
     ms_B = sum(b.elapsed_time(c) for a, b, c in lk_events)
@@ -264,7 +264,7 @@ def main():
                                    "build (4 levels) + fbKltTracking pass A (216 kps, nbpyrlvl 1) + pass B "
                                    "(92 kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px",
                        "seqs_per_gpu": S, "keypoints_per_frame": NKPS, "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_fb_klt<9>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_fb_klt3", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_total / max(1, n_launch),

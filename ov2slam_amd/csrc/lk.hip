@@ -444,6 +444,18 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
 }
 
 // ---- host side -------------------------------------------------------------------
+// lk3.hip: 3-lanes-per-keypoint kernel for the reference's window (9)
+int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int max_level, int max_iter, double eps2,
+                       float min_eig_th, int flags, float err_th, float fb_dist, int do_fb, int n_max,
+                       const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
+                       const int *n_per_item, long long *stats);
+
+static bool lk_use_row_kernel()
+{
+    static const bool v = [] { const char *e = getenv("OV2_LK_IMPL"); return e && !strcmp(e, "row"); }();
+    return v;
+}
+
 template <int WIN>
 static void launch_fb_klt(hipStream_t s, dim3 grid, const PyrDesc &P, const PyrDesc &C, const LKParams &prm,
                           const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
@@ -462,6 +474,12 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
     OV2_REQUIRE(P.lv[0].w == C.lv[0].w && P.lv[0].h == C.lv[0].h, OV2_EINVAL, "prev/cur image size differs");
     OV2_REQUIRE(prm.win == P.win, OV2_EINVAL, "LK window differs from the window the pyramid was padded for");
     dim3 grid((prm.n_max + 15) / 16, P.batch);
+    if (prm.win == 9 && !lk_use_row_kernel()) {
+        ov2_launch_fb_klt3(ctx->stream, P, C, prm.max_level, prm.max_iter, prm.eps2, prm.min_eig_th, prm.flags, prm.err_th,
+                           prm.fb_dist, prm.do_fb, prm.n_max, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d);
+        OV2_HIP_CHECK(hipGetLastError());
+        return OV2_OK;
+    }
     switch (prm.win) {
     case 5:  launch_fb_klt<5>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
     case 7:  launch_fb_klt<7>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
