@@ -181,14 +181,12 @@ def main():
     a_pB = [vp(pri_work[f][:, N_PASS_A:]) for f in range(NF)]
     a_st, a_stB, a_stats, a_nA, a_nB = vp(status_d), vp(status_d[:, N_PASS_A:]), vp(stats_d), vp(nA_d), vp(nB_d)
     hp = [p.h_pyr for p in pyrs]
-    fb, build, clahe = lib.ov2_fb_klt_d, lib.ov2_pyr_build_d, lib.ov2_clahe_d
-    clahe_buf = torch.empty((S, H, W), dtype=torch.uint8, device=dev)
-    a_cl = vp(clahe_buf)
+    fb, build_clahe = lib.ov2_fb_klt_d, lib.ov2_pyr_build_clahe_d
     lk_events = []
 
     def preprocess(pyr, img):
-        L.check(clahe(ctx.h, img, W, H, W, W * H, S, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1], a_cl, W, W * H))
-        L.check(build(ctx.h, pyr, a_cl, W, W * H))
+        # clahe->apply + buildOpticalFlowPyramid (visual_front_end.cpp:1159, :1172) in one call
+        L.check(build_clahe(ctx.h, pyr, img, W, W * H, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1]))
 
     def step(i, timed):
         f = i % NF

@@ -88,6 +88,13 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
                 uint8_t *dst_h, int dst_stride);
 int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                 double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride);
+/* preprocessImage in one call: CLAHE of img_d written straight into the pyramid's level 0, then the
+ * coarser levels -- the pair clahe->apply(img_raw, cur_img_) + cv::buildOpticalFlowPyramid(cur_img_, ...)
+ * of src/visual_front_end.cpp:1159 + :1172 (mapper.cpp:76 + :81) without the intermediate image.
+ * Results are identical to ov2_clahe_d followed by ov2_pyr_build_d; the equalised image stays
+ * available as level 0 of the pyramid.                                                            */
+int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
+                          double clip_limit, int tiles_x, int tiles_y);
 
 /* ---- Lucas-Kanade --------------------------------------------------
  * ov2_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts,

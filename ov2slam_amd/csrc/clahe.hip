@@ -26,8 +26,14 @@ struct ClaheParams {
 };
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
-// tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip into its own
-// 256-bin LDS histogram; clip / redistribute / scan run on 4 bins per lane with wave shuffles.
+// tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
+//   * every wavefront keeps 8 private 256-bin copies -- copy = (row & 3, dword column & 1) -- staggered by
+//     4 banks, so that neighbouring pixels (equal or adjacent gray values) rarely meet on one address;
+//   * bytes of an edge dword that lie outside the tile are counted into a scratch copy instead of being
+//     branched around; all loads of a tile are in flight before the first ds_add (the loop is latency-bound
+//     otherwise);
+//   * clip / redistribute / scan / LUT run on 4 bins per lane with DPP row scans and readlane, no division
+//     per bin.
 __device__ __forceinline__ void clahe_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -35,71 +41,102 @@ __device__ __forceinline__ void clahe_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#define CH_COPIES 8
+#define CH_STRIDE 260                 // dwords per copy: 256 + 4 (bank stagger, keeps 16-byte alignment)
+#define CH_WAVE_DW (CH_COPIES * CH_STRIDE + 256)      // + scratch copy for out-of-tile bytes
+typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // out-of-row sources read 0
+
 __global__ __launch_bounds__(256) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
 {
-    __shared__ int hist_all[4][4][256];                              // [wave][lane & 3][bin]: fewer same-address ds_add collisions
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ntiles = P.tiles_x * P.tiles_y;
     const int t = blockIdx.x * 4 + wave, b = blockIdx.y;
     if (t >= ntiles) return;                                        // whole wavefront exits
-    int *hist = hist_all[wave][lane & 3];
-    int *hist0 = hist_all[wave][0];
+    uint32_t *hw = hist_all[wave];
     const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
     const uint8_t *img = src + (long long)b * P.src_item_stride;
-#pragma unroll
-    for (int k = 0; k < 16; k++) hist0[lane + 64 * k] = 0;
+    for (int e = lane; e < CH_COPIES * CH_STRIDE / 4; e += 64) ((c_u32x4 *)hw)[e] = (c_u32x4)(0u);
     clahe_wave_sync();
     const int sub = lane >> 4, l16 = lane & 15;
+    uint32_t *hist = hw + ((sub << 1) | (l16 & 1)) * CH_STRIDE;
+    uint32_t *trash = hw + CH_COPIES * CH_STRIDE;
     const int x_begin = tx * P.tw, x_end = x_begin + P.tw;          // tile columns in padded coordinates
     const bool fast = x_end <= P.w && P.tw <= 61 && ((P.stride | (int)(size_t)img) & 3) == 0;
     const int xa = (x_begin & ~3) + 4 * l16;                        // aligned dword l16 of a row segment
-    for (int ly = sub; ly < P.th; ly += 4) {
-        const int y = c_reflect101(ty * P.th + ly, P.h);            // bottom REFLECT_101 padding
-        const uint8_t *row = img + y * P.stride;
-        if (fast) {
-            if (xa < x_end) {
-                const uint32_t v = *(const uint32_t *)(row + xa);
+    if (fast) {
+        // which bytes of this lane's dword column belong to the tile (same for every row)
+        const bool in0 = xa >= x_begin && xa < x_end, in1 = xa + 1 >= x_begin && xa + 1 < x_end;
+        const bool in2 = xa + 2 >= x_begin && xa + 2 < x_end, in3 = xa + 3 >= x_begin && xa + 3 < x_end;
+        uint32_t *h0 = in0 ? hist : trash, *h1 = in1 ? hist : trash, *h2 = in2 ? hist : trash, *h3 = in3 ? hist : trash;
+        if (in0 || in1 || in2 || in3) {
+            const int ybase = ty * P.th + sub;
+            for (int i0 = 0; 4 * i0 + sub < P.th; i0 += 16) {
+                uint32_t vv[16];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int x = xa + k;
-                    if (x >= x_begin && x < x_end) atomicAdd(&hist[(v >> (8 * k)) & 0xFF], 1);
+                for (int i = 0; i < 16; i++) {
+                    const int ly = 4 * (i0 + i) + sub;
+                    int y = ybase + 4 * (i0 + i);
+                    y = y >= P.h ? 2 * P.h - 2 - y : y;             // bottom REFLECT_101 padding (< one tile high)
+                    y = y < 0 ? 0 : y;
+                    vv[i] = 0;
+                    if (ly < P.th) vv[i] = *(const uint32_t *)(img + y * P.stride + xa);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    if (4 * (i0 + i) + sub < P.th) {
+                        const uint32_t v = vv[i];
+                        atomicAdd(&h0[v & 0xFF], 1u);
+                        atomicAdd(&h1[(v >> 8) & 0xFF], 1u);
+                        atomicAdd(&h2[(v >> 16) & 0xFF], 1u);
+                        atomicAdd(&h3[v >> 24], 1u);
+                    }
                 }
             }
-        } else {
-            for (int lx = l16; lx < P.tw; lx += 16) atomicAdd(&hist[row[c_reflect101(x_begin + lx, P.w)]], 1);
+        }
+    } else {
+        for (int ly = sub; ly < P.th; ly += 4) {
+            const uint8_t *row = img + c_reflect101(ty * P.th + ly, P.h) * P.stride;
+            for (int lx = l16; lx < P.tw; lx += 16) atomicAdd(&hist[row[c_reflect101(x_begin + lx, P.w)]], 1u);
         }
     }
     clahe_wave_sync();
     // lane owns bins 4*lane .. 4*lane+3
-    int hv[4];
+    int hv[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; k++) hv[k] = hist0[4 * lane + k] + hist0[256 + 4 * lane + k] + hist0[512 + 4 * lane + k] + hist0[768 + 4 * lane + k];
+    for (int c = 0; c < CH_COPIES; c++) {
+        const c_u32x4 q = *(const c_u32x4 *)(hw + c * CH_STRIDE + 4 * lane);
+        hv[0] += (int)q.x; hv[1] += (int)q.y; hv[2] += (int)q.z; hv[3] += (int)q.w;
+    }
     if (P.clip > 0) {
         int over = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (hv[k] > P.clip) { over += hv[k] - P.clip; hv[k] = P.clip; }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) over += __shfl_xor(over, off, 64);
-        const int clipped = over;
-        const int batch = clipped / 256, residual = clipped - batch * 256;
-        int step = residual ? 256 / residual : 1; if (step < 1) step = 1;
+        for (int k = 0; k < 4; k++) { over += max(hv[k] - P.clip, 0); hv[k] = min(hv[k], P.clip); }
+        over += c_dpp0<0xB1>(over); over += c_dpp0<0x4E>(over); over += c_dpp0<0x124>(over); over += c_dpp0<0x128>(over);   // row totals
+        const int clipped = __builtin_amdgcn_readlane(over, 0) + __builtin_amdgcn_readlane(over, 16) +
+                            __builtin_amdgcn_readlane(over, 32) + __builtin_amdgcn_readlane(over, 48);
+        const int batch = clipped >> 8, residual = clipped & 255;
+        // serial loop `for (i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++` : bin gets +1 iff
+        // bin % step == 0 && bin / step < residual, step = max(256 / residual, 1)
+        int step = residual ? (int)(256.0f / (float)residual) : 1;          // exact: |256 - r n| >= 1
+        int q = (int)((float)(4 * lane) / (float)step), r = 4 * lane - q * step;    // exact for the same reason
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int bin = 4 * lane + k;
-            hv[k] += batch;
-            // serial loop `for (i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++`
-            if (residual != 0 && bin % step == 0 && bin / step < residual) hv[k]++;
+            hv[k] += batch + ((residual != 0 && r == 0 && q < residual) ? 1 : 0);
+            r++;
+            if (r == step) { r = 0; q++; }
         }
     }
-    // inclusive scan over the 256 bins: in-lane prefix + wave scan of the lane totals
+    // inclusive scan over the 256 bins: in-lane prefix, DPP scan inside the 16-lane rows, row offsets by readlane
     hv[1] += hv[0]; hv[2] += hv[1]; hv[3] += hv[2];
-    int tot = hv[3], v = tot;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(v, off, 64);
-        if (lane >= off) v += u;
-    }
-    const int base = v - tot;
+    int v = hv[3];
+    v += c_dpp0<0x111>(v); v += c_dpp0<0x112>(v); v += c_dpp0<0x114>(v); v += c_dpp0<0x118>(v);      // row_shr:1,2,4,8 (zero fill)
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int rowoff = sub == 0 ? 0 : (sub == 1 ? r0 : (sub == 2 ? r0 + r1 : r0 + r1 + r2));
+    const int base = v + rowoff - hv[3];
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -110,68 +147,100 @@ __global__ __launch_bounds__(256) void k_clahe_lut(ClaheParams P, const uint8_t 
     *(uint32_t *)(lut + ((long long)b * ntiles + t) * 256 + 4 * lane) = packed;
 }
 
-// One workgroup per (row of interpolation cells, image): pixels of rows whose two surrounding tile rows are
+// One workgroup per (row of interpolation cells, image): the rows whose two surrounding tile rows are
 // (cy-1, cy).  LDS holds, for every cell column, the four surrounding tile LUTs packed as one dword per gray
-// value, plus the per-column cell index and horizontal weight -- a pixel costs two LDS reads.
+// value.  A thread owns one dword column (4 pixels: horizontal weights and cell column are per-thread
+// constants) and walks down the rows of the cell row: per pixel one LDS look-up, four byte->float
+// conversions, the bilinear blend in packed fp32 (two pixels per v_pk_mul/add_f32, same operation order
+// and rounding as the scalar formula), round-to-even and a byte insert.
 #define CLAHE_MAX_CELLS 48
+#define CA_UNROLL 6
+typedef float c_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float c_ub(uint32_t q, int k) { return (float)((q >> (8 * k)) & 0xFFu); }    // v_cvt_f32_ubyteK
+
 __global__ __launch_bounds__(256) void k_clahe_apply(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
                                                      uint8_t *__restrict__ dst)
 {
     extern __shared__ __align__(16) unsigned char clahe_smem[];
     const int ncx = P.tiles_x + 1;
     uint32_t *lut4 = (uint32_t *)clahe_smem;                            // ncx * 256
-    float *xaT = (float *)(lut4 + ncx * 256);                           // w
-    uint8_t *cxT = (uint8_t *)(xaT + P.w);                              // w
-    const int cy = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cy = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
     const int ty1 = max(cy - 1, 0), ty2 = min(cy, P.tiles_y - 1);
     const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;
-    for (int e = tid; e < ncx * 256; e += 256) {
-        const int cx = e >> 8, v = e & 255;
+    // stage: item = (cell column, 4 consecutive gray values): four dword loads, a 4x4 byte transpose, one b128 store
+    for (int e = tid; e < ncx * 64; e += nthr) {
+        const int cx = e >> 6, v4 = (e & 63) * 4;
         const int tx1 = max(cx - 1, 0), tx2 = min(cx, P.tiles_x - 1);
-        lut4[e] = (uint32_t)L[(ty1 * P.tiles_x + tx1) * 256 + v] | ((uint32_t)L[(ty1 * P.tiles_x + tx2) * 256 + v] << 8) |
-                  ((uint32_t)L[(ty2 * P.tiles_x + tx1) * 256 + v] << 16) | ((uint32_t)L[(ty2 * P.tiles_x + tx2) * 256 + v] << 24);
-    }
-    for (int x = tid; x < P.w; x += 256) {
-        const float txf = (float)x * P.inv_tw - 0.5f;
-        const int fx = (int)floorf(txf);
-        xaT[x] = txf - (float)fx;
-        cxT[x] = (uint8_t)(fx + 1);
+        const uint32_t a = *(const uint32_t *)(L + (ty1 * P.tiles_x + tx1) * 256 + v4), bb = *(const uint32_t *)(L + (ty1 * P.tiles_x + tx2) * 256 + v4);
+        const uint32_t c = *(const uint32_t *)(L + (ty2 * P.tiles_x + tx1) * 256 + v4), d = *(const uint32_t *)(L + (ty2 * P.tiles_x + tx2) * 256 + v4);
+        // entry k = a.byte[k] | b.byte[k] << 8 | c.byte[k] << 16 | d.byte[k] << 24
+        const uint32_t ab01 = __builtin_amdgcn_perm(bb, a, 0x05010400u), ab23 = __builtin_amdgcn_perm(bb, a, 0x07030602u);   // (a0 b0 a1 b1), (a2 b2 a3 b3)
+        const uint32_t cd01 = __builtin_amdgcn_perm(d, c, 0x05010400u), cd23 = __builtin_amdgcn_perm(d, c, 0x07030602u);
+        c_u32x4 o;
+        o.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u); o.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
+        o.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u); o.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
+        *(c_u32x4 *)(lut4 + (cx << 8) + v4) = o;
     }
     __syncthreads();
-    // candidate rows of this cell row (membership decided by the float formula, like the reference)
-    const int ys = max(0, (int)floorf(((float)cy - 0.5f) * (float)P.th) - 1), ye = min(P.h, (int)ceilf(((float)cy + 0.5f) * (float)P.th) + 2);
+    // rows of this cell row: fy + 1 == cy with fy = floor(y * inv_th - 0.5), decided by the float formula like the reference
+    int y0 = max(0, (int)floorf(((float)cy - 0.5f) * (float)P.th) - 1), y1 = min(P.h, (int)ceilf(((float)cy + 0.5f) * (float)P.th) + 2);
+    while (y0 < y1 && (int)floorf((float)y0 * P.inv_th - 0.5f) + 1 != cy) y0++;
+    while (y1 > y0 && (int)floorf((float)(y1 - 1) * P.inv_th - 0.5f) + 1 != cy) y1--;
     const uint8_t *simg = src + (long long)b * P.src_item_stride;
     uint8_t *dimg = dst + (long long)b * P.dst_item_stride;
     const bool aligned = ((P.stride | P.dst_stride | (int)(size_t)simg | (int)(size_t)dimg) & 3) == 0;
     const int ndw = (P.w + 3) >> 2;
-    const int total = (ye - ys) * ndw;
-    for (int e = tid; e < total; e += 256) {
-        const int ry = e / ndw, dwi = e - ry * ndw;
-        const int y = ys + ry, xb = 4 * dwi;
-        const float tyf = (float)y * P.inv_th - 0.5f;
-        const int fy = (int)floorf(tyf);
-        if (fy + 1 != cy) continue;                                    // row belongs to another cell row
-        const float ya = tyf - (float)fy, ya1 = 1.0f - ya;
-        const uint8_t *srow = simg + y * P.stride;
-        uint8_t *drow = dimg + y * P.dst_stride;
-        const bool full = aligned && xb + 3 < P.w;
-        uint32_t in = 0;
-        if (full) in = *(const uint32_t *)(srow + xb);
-        else for (int k = 0; k < 4; k++) if (xb + k < P.w) in |= (uint32_t)srow[xb + k] << (8 * k);
-        uint32_t out = 0;
+    for (int dwi = tid; dwi < ndw; dwi += nthr) {
+        const int xb = 4 * dwi;
+        float xa[4], xa1[4];
+        const uint32_t *lutc[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = min(xb + k, P.w - 1);
-            const float xa = xaT[x], xa1 = 1.0f - xa;
-            const uint32_t q = lut4[((int)cxT[x] << 8) + ((in >> (8 * k)) & 0xFF)];
-            const float l11 = (float)(q & 0xFF), l12 = (float)((q >> 8) & 0xFF), l21 = (float)((q >> 16) & 0xFF), l22 = (float)(q >> 24);
-            const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
-            int r = __float2int_rn(res);
-            r = r < 0 ? 0 : (r > 255 ? 255 : r);
-            out |= (uint32_t)r << (8 * k);
+            const float txf = (float)x * P.inv_tw - 0.5f;
+            const int fx = (int)floorf(txf);
+            xa[k] = txf - (float)fx; xa1[k] = 1.0f - xa[k];
+            lutc[k] = lut4 + ((fx + 1) << 8);
         }
-        if (full) *(uint32_t *)(drow + xb) = out;
-        else for (int k = 0; k < 4; k++) if (xb + k < P.w) drow[xb + k] = (uint8_t)(out >> (8 * k));
+        const c_f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
+        const bool full = aligned && xb + 3 < P.w;
+        for (int yb = y0; yb < y1; yb += CA_UNROLL) {
+            // issue the loads of CA_UNROLL rows before consuming any (the row loop is latency-bound otherwise)
+            uint32_t inr[CA_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CA_UNROLL; u++) {
+                const int y = min(yb + u, y1 - 1);
+                const uint8_t *srow = simg + y * P.stride;
+                uint32_t in = 0;
+                if (full) in = *(const uint32_t *)(srow + xb);
+                else for (int k = 0; k < 4; k++) if (xb + k < P.w) in |= (uint32_t)srow[xb + k] << (8 * k);
+                inr[u] = in;
+            }
+#pragma unroll
+            for (int u = 0; u < CA_UNROLL; u++) {
+                const int y = yb + u;
+                if (y >= y1) break;
+                const float tyf = (float)y * P.inv_th - 0.5f;
+                const float ya = tyf - (float)(cy - 1), ya1 = 1.0f - ya;
+                const c_f32x2 YA = {ya, ya}, YB = {ya1, ya1};
+                uint8_t *drow = dimg + y * P.dst_stride;
+                const uint32_t in = inr[u];
+                const uint32_t q0 = lutc[0][in & 0xFF], q1 = lutc[1][(in >> 8) & 0xFF], q2 = lutc[2][(in >> 16) & 0xFF], q3 = lutc[3][in >> 24];
+                // res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya, pixels (0,1) and (2,3) side by side
+                const c_f32x2 A11 = {c_ub(q0, 0), c_ub(q1, 0)}, A12 = {c_ub(q0, 1), c_ub(q1, 1)}, A21 = {c_ub(q0, 2), c_ub(q1, 2)}, A22 = {c_ub(q0, 3), c_ub(q1, 3)};
+                const c_f32x2 B11 = {c_ub(q2, 0), c_ub(q3, 0)}, B12 = {c_ub(q2, 1), c_ub(q3, 1)}, B21 = {c_ub(q2, 2), c_ub(q3, 2)}, B22 = {c_ub(q2, 3), c_ub(q3, 3)};
+                const c_f32x2 r01 = (A11 * XB01 + A12 * XA01) * YB + (A21 * XB01 + A22 * XA01) * YA;
+                const c_f32x2 r23 = (B11 * XB23 + B12 * XA23) * YB + (B21 * XB23 + B22 * XA23) * YA;
+                // cvRound + saturate_cast<uchar>: round to nearest even, then a saturating byte insert (exact on integers)
+                uint32_t out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.x), 0, 0u);
+                out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.y), 1, out);
+                out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.x), 2, out);
+                out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.y), 3, out);
+                if (full) *(uint32_t *)(drow + xb) = out;
+                else for (int k = 0; k < 4; k++) if (xb + k < P.w) drow[xb + k] = (uint8_t)(out >> (8 * k));
+            }
+        }
     }
 }
 
@@ -191,10 +260,13 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     P.inv_tw = 1.0f / (float)P.tw; P.inv_th = 1.0f / (float)P.th;
     P.src_item_stride = (long long)src_batch_stride; P.dst_item_stride = (long long)dst_batch_stride; P.dst_stride = dst_stride;
     hipLaunchKernelGGL(k_clahe_lut, dim3((tiles_x * tiles_y + 3) / 4, batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
-    const size_t apply_lds = (size_t)(tiles_x + 1) * 1024 + (size_t)w * 5 + 16;
+    const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
+    // one thread per dword column; several column passes only for images wider than 1024 pixels
+    const int ndw = (w + 3) / 4, passes = (ndw + 255) / 256;
+    const int apply_threads = (((ndw + passes - 1) / passes) + 63) / 64 * 64;
     OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && apply_lds <= 160 * 1024, OV2_EUNSUPPORTED, "CLAHE: too many tile columns / too wide an image for the LDS tables");
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
-    hipLaunchKernelGGL(k_clahe_apply, dim3(tiles_y + 1, batch), dim3(256), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
+    hipLaunchKernelGGL(k_clahe_apply, dim3(tiles_y + 1, batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
@@ -213,6 +285,25 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
     if (rc != OV2_OK) return rc;
     return clahe_launch(ctx, src_d, w, h, stride, src_batch_stride, batch, clip_limit, tiles_x, tiles_y, dst_d, dst_stride,
                         dst_batch_stride, (uint8_t *)ctx->d_scratch);
+}
+
+int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
+                          double clip_limit, int tiles_x, int tiles_y)
+{
+    OV2_REQUIRE(ctx && p && img_d, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(stride >= p->w && tiles_x > 0 && tiles_y > 0 && tiles_x <= p->w && tiles_y <= p->h, OV2_EINVAL, "bad geometry");
+    OV2_REQUIRE(p->d.batch == 1 || img_batch_stride >= (size_t)stride * (size_t)p->h, OV2_EINVAL, "img_batch_stride too small");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t lut_bytes = (size_t)p->d.batch * tiles_x * tiles_y * 256;
+    int rc = ctx->reserve_device(lut_bytes);
+    if (rc != OV2_OK) return rc;
+    // the equalised image is written straight into the pyramid's padded level-0 slot (no intermediate image,
+    // no level-0 copy); borders and the coarser levels follow from there
+    const PyrLevelDesc &L0 = p->d.lv[0];
+    rc = clahe_launch(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
+                      p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch);
+    if (rc != OV2_OK) return rc;
+    return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
 }
 
 int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,

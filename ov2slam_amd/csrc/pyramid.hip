@@ -173,9 +173,13 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
     for (int l = 0; l < P.n_levels; l++) {
         const PyrLevelDesc &L = P.lv[l];
         dim3 grid((L.w + PT_W - 1) / PT_W, (L.h + PT_H - 1) / PT_H, P.batch);
-        if (l == 0) {
+        if (l == 0 && img_d) {
             hipLaunchKernelGGL(k_pyr_level<true>, grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
             border(0);
+        } else if (l == 0) {
+            // level 0 was written in place by the producer (ov2_pyr_build_clahe_d): borders, then pyrDown from the padded image
+            border(0);
+            if (P.n_levels > 1) hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, 0, (const uint8_t *)nullptr, 0, 0LL);
         } else if (l + 1 < P.n_levels) {
             hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
         }

@@ -90,6 +90,14 @@ class Pyramid:
         L.check(self.lib.ov2_pyr_build_d(self.ctx.h, self.h_pyr, C.c_void_p(dev_ptr), stride, batch_stride))
         return self
 
+    def build_clahe_from_device(self, dev_ptr, clip_limit, tiles_x, tiles_y, stride=None, batch_stride=None):
+        """preprocessImage: CLAHE written straight into level 0, then the coarser levels (one call)."""
+        stride = stride or self.w
+        batch_stride = batch_stride or stride * self.h
+        L.check(self.lib.ov2_pyr_build_clahe_d(self.ctx.h, self.h_pyr, C.c_void_p(dev_ptr), stride, batch_stride,
+                                               float(clip_limit), int(tiles_x), int(tiles_y)))
+        return self
+
     def download(self, level, b=0, padded=False):
         w, h = self.level_size(level)
         if padded:

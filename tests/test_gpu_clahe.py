@@ -42,6 +42,16 @@ ctx.sync()
 out = dst.cpu().numpy()
 for b in range(3):
     assert np.array_equal(out[b], O.clahe(imgs[b], 3.0, 15, 9)), b
+# fused preprocessImage: CLAHE straight into the pyramid == ov2_clahe_d + ov2_pyr_build_d == oracle
+pf = ov2slam_amd.Pyramid(ctx, 752, 480, 9, 3, batch=3).build_clahe_from_device(src.data_ptr(), 3.0, 15, 9)
+ps = ov2slam_amd.Pyramid(ctx, 752, 480, 9, 3, batch=3).build_from_device(dst.data_ptr())
+ctx.sync()
+for b in range(3):
+    ref = O.Pyramid(O.clahe(imgs[b], 3.0, 15, 9), 9, 3)
+    for lvl in range(pf.levels):
+        a = pf.download(lvl, b, padded=True)[0]; c = ps.download(lvl, b, padded=True)[0]
+        assert np.array_equal(a, c), (b, lvl)
+        assert np.array_equal(pf.download(lvl, b, padded=True)[0], ref.level(lvl, padded=True)[0]), (b, lvl)
 print("DEVICE_PATH_OK")
 """
 
