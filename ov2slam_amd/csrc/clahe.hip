@@ -23,6 +23,7 @@ struct ClaheParams {
     float lut_scale, inv_tw, inv_th;
     long long src_item_stride, dst_item_stride;
     int dst_stride;
+    int border;          // > 0: dst is a padded pyramid level -- also write its REFLECT_101 border of this many pixels
 };
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
@@ -49,46 +50,59 @@ typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 template <int CTRL>
 __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // out-of-row sources read 0
 
-__global__ __launch_bounds__(256) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
+__global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
 {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ntiles = P.tiles_x * P.tiles_y;
-    const int t = blockIdx.x * 4 + wave, b = blockIdx.y;
-    if (t >= ntiles) return;                                        // whole wavefront exits
+    const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * gridDim.x;
+    const int b = blockIdx.y;
     uint32_t *hw = hist_all[wave];
-    const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
     const uint8_t *img = src + (long long)b * P.src_item_stride;
-    for (int e = lane; e < CH_COPIES * CH_STRIDE / 4; e += 64) ((c_u32x4 *)hw)[e] = (c_u32x4)(0u);
-    clahe_wave_sync();
     const int sub = lane >> 4, l16 = lane & 15;
     uint32_t *hist = hw + ((sub << 1) | (l16 & 1)) * CH_STRIDE;
     uint32_t *trash = hw + CH_COPIES * CH_STRIDE;
-    const int x_begin = tx * P.tw, x_end = x_begin + P.tw;          // tile columns in padded coordinates
-    const bool fast = x_end <= P.w && P.tw <= 61 && ((P.stride | (int)(size_t)img) & 3) == 0;
-    const int xa = (x_begin & ~3) + 4 * l16;                        // aligned dword l16 of a row segment
-    if (fast) {
-        // which bytes of this lane's dword column belong to the tile (same for every row)
-        const bool in0 = xa >= x_begin && xa < x_end, in1 = xa + 1 >= x_begin && xa + 1 < x_end;
-        const bool in2 = xa + 2 >= x_begin && xa + 2 < x_end, in3 = xa + 3 >= x_begin && xa + 3 < x_end;
-        uint32_t *h0 = in0 ? hist : trash, *h1 = in1 ? hist : trash, *h2 = in2 ? hist : trash, *h3 = in3 ? hist : trash;
-        if (in0 || in1 || in2 || in3) {
-            const int ybase = ty * P.th + sub;
-            for (int i0 = 0; 4 * i0 + sub < P.th; i0 += 16) {
-                uint32_t vv[16];
+    const bool fast_geom = P.tw <= 61 && P.th <= 64 && ((P.stride | (int)(size_t)img) & 3) == 0;
+
+    // a wavefront walks over several tiles; the 16 row-dwords of the NEXT tile are requested before the
+    // current one is histogrammed, so the global round trip hides behind the LDS work
+    auto tile_fast = [&](int t) { const int tx = t % P.tiles_x; return fast_geom && (tx + 1) * P.tw <= P.w; };
+    auto tile_load = [&](int t, uint32_t (&vv)[16]) {
+        const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+        const int x_begin = tx * P.tw, x_end = x_begin + P.tw;
+        const int xa = (x_begin & ~3) + 4 * l16;                    // aligned dword l16 of a row segment
+        const bool any = xa + 3 >= x_begin && xa < x_end;
+        const int ybase = ty * P.th + sub;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            int y = ybase + 4 * i;
+            y = y >= P.h ? 2 * P.h - 2 - y : y;                     // bottom REFLECT_101 padding (< one tile high)
+            y = y < 0 ? 0 : y;
+            vv[i] = 0;
+            if (any && 4 * i + sub < P.th) vv[i] = *(const uint32_t *)(img + y * P.stride + xa);
+        }
+    };
+
+    uint32_t cur[16], nxt[16];
+    int t = blockIdx.x * 4 + wave;
+    if (t < ntiles && tile_fast(t)) tile_load(t, cur);
+#pragma nounroll
+    for (; t < ntiles; t += tstride) {
+        const int tn = t + tstride;
+        if (tn < ntiles && tile_fast(tn)) tile_load(tn, nxt);
+        const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+        const int x_begin = tx * P.tw, x_end = x_begin + P.tw;      // tile columns in padded coordinates
+        for (int e = lane; e < CH_COPIES * CH_STRIDE / 4; e += 64) ((c_u32x4 *)hw)[e] = (c_u32x4)(0u);
+        clahe_wave_sync();
+        if (tile_fast(t)) {
+            // bytes of this lane's dword column outside the tile are counted into the scratch copy
+            const int xa = (x_begin & ~3) + 4 * l16;
+            uint32_t *h0 = (xa >= x_begin && xa < x_end) ? hist : trash, *h1 = (xa + 1 >= x_begin && xa + 1 < x_end) ? hist : trash;
+            uint32_t *h2 = (xa + 2 >= x_begin && xa + 2 < x_end) ? hist : trash, *h3 = (xa + 3 >= x_begin && xa + 3 < x_end) ? hist : trash;
+            if (xa + 3 >= x_begin && xa < x_end) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const int ly = 4 * (i0 + i) + sub;
-                    int y = ybase + 4 * (i0 + i);
-                    y = y >= P.h ? 2 * P.h - 2 - y : y;             // bottom REFLECT_101 padding (< one tile high)
-                    y = y < 0 ? 0 : y;
-                    vv[i] = 0;
-                    if (ly < P.th) vv[i] = *(const uint32_t *)(img + y * P.stride + xa);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    if (4 * (i0 + i) + sub < P.th) {
-                        const uint32_t v = vv[i];
+                    if (4 * i + sub < P.th) {
+                        const uint32_t v = cur[i];
                         atomicAdd(&h0[v & 0xFF], 1u);
                         atomicAdd(&h1[(v >> 8) & 0xFF], 1u);
                         atomicAdd(&h2[(v >> 16) & 0xFF], 1u);
@@ -96,55 +110,58 @@ __global__ __launch_bounds__(256) void k_clahe_lut(ClaheParams P, const uint8_t 
                     }
                 }
             }
+        } else {
+            for (int ly = sub; ly < P.th; ly += 4) {
+                const uint8_t *row = img + c_reflect101(ty * P.th + ly, P.h) * P.stride;
+                for (int lx = l16; lx < P.tw; lx += 16) atomicAdd(&hist[row[c_reflect101(x_begin + lx, P.w)]], 1u);
+            }
         }
-    } else {
-        for (int ly = sub; ly < P.th; ly += 4) {
-            const uint8_t *row = img + c_reflect101(ty * P.th + ly, P.h) * P.stride;
-            for (int lx = l16; lx < P.tw; lx += 16) atomicAdd(&hist[row[c_reflect101(x_begin + lx, P.w)]], 1u);
+        clahe_wave_sync();
+        // lane owns bins 4*lane .. 4*lane+3
+        int hv[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < CH_COPIES; c++) {
+            const c_u32x4 q = *(const c_u32x4 *)(hw + c * CH_STRIDE + 4 * lane);
+            hv[0] += (int)q.x; hv[1] += (int)q.y; hv[2] += (int)q.z; hv[3] += (int)q.w;
         }
-    }
-    clahe_wave_sync();
-    // lane owns bins 4*lane .. 4*lane+3
-    int hv[4] = {0, 0, 0, 0};
+        clahe_wave_sync();                                            // the copies may be cleared for the next tile
+        if (P.clip > 0) {
+            int over = 0;
 #pragma unroll
-    for (int c = 0; c < CH_COPIES; c++) {
-        const c_u32x4 q = *(const c_u32x4 *)(hw + c * CH_STRIDE + 4 * lane);
-        hv[0] += (int)q.x; hv[1] += (int)q.y; hv[2] += (int)q.z; hv[3] += (int)q.w;
-    }
-    if (P.clip > 0) {
-        int over = 0;
+            for (int k = 0; k < 4; k++) { over += max(hv[k] - P.clip, 0); hv[k] = min(hv[k], P.clip); }
+            over += c_dpp0<0xB1>(over); over += c_dpp0<0x4E>(over); over += c_dpp0<0x124>(over); over += c_dpp0<0x128>(over);   // row totals
+            const int clipped = __builtin_amdgcn_readlane(over, 0) + __builtin_amdgcn_readlane(over, 16) +
+                                __builtin_amdgcn_readlane(over, 32) + __builtin_amdgcn_readlane(over, 48);
+            const int batch = clipped >> 8, residual = clipped & 255;
+            // serial loop `for (i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++` : bin gets +1 iff
+            // bin % step == 0 && bin / step < residual, step = max(256 / residual, 1)
+            int step = residual ? (int)(256.0f / (float)residual) : 1;          // exact: |256 - r n| >= 1
+            int q = (int)((float)(4 * lane) / (float)step), r = 4 * lane - q * step;    // exact for the same reason
 #pragma unroll
-        for (int k = 0; k < 4; k++) { over += max(hv[k] - P.clip, 0); hv[k] = min(hv[k], P.clip); }
-        over += c_dpp0<0xB1>(over); over += c_dpp0<0x4E>(over); over += c_dpp0<0x124>(over); over += c_dpp0<0x128>(over);   // row totals
-        const int clipped = __builtin_amdgcn_readlane(over, 0) + __builtin_amdgcn_readlane(over, 16) +
-                            __builtin_amdgcn_readlane(over, 32) + __builtin_amdgcn_readlane(over, 48);
-        const int batch = clipped >> 8, residual = clipped & 255;
-        // serial loop `for (i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++` : bin gets +1 iff
-        // bin % step == 0 && bin / step < residual, step = max(256 / residual, 1)
-        int step = residual ? (int)(256.0f / (float)residual) : 1;          // exact: |256 - r n| >= 1
-        int q = (int)((float)(4 * lane) / (float)step), r = 4 * lane - q * step;    // exact for the same reason
+            for (int k = 0; k < 4; k++) {
+                hv[k] += batch + ((residual != 0 && r == 0 && q < residual) ? 1 : 0);
+                r++;
+                if (r == step) { r = 0; q++; }
+            }
+        }
+        // inclusive scan over the 256 bins: in-lane prefix, DPP scan inside the 16-lane rows, row offsets by readlane
+        hv[1] += hv[0]; hv[2] += hv[1]; hv[3] += hv[2];
+        int v = hv[3];
+        v += c_dpp0<0x111>(v); v += c_dpp0<0x112>(v); v += c_dpp0<0x114>(v); v += c_dpp0<0x118>(v);      // row_shr:1,2,4,8 (zero fill)
+        const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+        const int rowoff = sub == 0 ? 0 : (sub == 1 ? r0 : (sub == 2 ? r0 + r1 : r0 + r1 + r2));
+        const int base = v + rowoff - hv[3];
+        uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            hv[k] += batch + ((residual != 0 && r == 0 && q < residual) ? 1 : 0);
-            r++;
-            if (r == step) { r = 0; q++; }
+            int r = __float2int_rn((float)(hv[k] + base) * P.lut_scale);   // saturate_cast<uchar>(float)
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+            packed |= (uint32_t)r << (8 * k);
         }
-    }
-    // inclusive scan over the 256 bins: in-lane prefix, DPP scan inside the 16-lane rows, row offsets by readlane
-    hv[1] += hv[0]; hv[2] += hv[1]; hv[3] += hv[2];
-    int v = hv[3];
-    v += c_dpp0<0x111>(v); v += c_dpp0<0x112>(v); v += c_dpp0<0x114>(v); v += c_dpp0<0x118>(v);      // row_shr:1,2,4,8 (zero fill)
-    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
-    const int rowoff = sub == 0 ? 0 : (sub == 1 ? r0 : (sub == 2 ? r0 + r1 : r0 + r1 + r2));
-    const int base = v + rowoff - hv[3];
-    uint32_t packed = 0;
+        *(uint32_t *)(lut + ((long long)b * ntiles + t) * 256 + 4 * lane) = packed;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int r = __float2int_rn((float)(hv[k] + base) * P.lut_scale);   // saturate_cast<uchar>(float)
-        r = r < 0 ? 0 : (r > 255 ? 255 : r);
-        packed |= (uint32_t)r << (8 * k);
+        for (int i = 0; i < 16; i++) cur[i] = nxt[i];
     }
-    *(uint32_t *)(lut + ((long long)b * ntiles + t) * 256 + 4 * lane) = packed;
 }
 
 // One workgroup per (row of interpolation cells, image): the rows whose two surrounding tile rows are
@@ -242,13 +259,47 @@ __global__ __launch_bounds__(256) void k_clahe_apply(ClaheParams P, const uint8_
             }
         }
     }
+    if (P.border > 0) {
+        // REFLECT_101 border of the padded destination (pyramid level 0), written by the workgroup that owns
+        // the mirrored source rows while they are still in L2: left/right dwords of rows [y0, y1), and the
+        // mirror images of rows 1..border / h-1-border..h-2 above / below the image (full padded width).
+        __threadfence_block();
+        __syncthreads();
+        const int win = P.border, pbl = (win + 3) & ~3, wend = (P.w + win + 3) & ~3, rbeg = P.w & ~3;
+        const int ndw_lr = pbl / 4 + ((wend - rbeg) >> 2), ndw_row = (pbl + wend) >> 2;
+        auto put = [&](int yt, int ysrc, int c0) {
+            const uint8_t *srow = dimg + ysrc * P.dst_stride;
+            uint32_t v;
+            if (c0 >= 0 && c0 + 3 < P.w) v = *(const uint32_t *)(srow + c0);
+            else {
+                v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int c = c0 + k;
+                    c = c < -win ? -win : (c > P.w + win - 1 ? P.w + win - 1 : c);       // padding bytes: any value
+                    v |= (uint32_t)srow[c_reflect101(c, P.w)] << (8 * k);
+                }
+            }
+            *(uint32_t *)(dimg + yt * P.dst_stride + c0) = v;
+        };
+        // left/right: 8 threads per row (ndw_lr <= 8 for win <= 15; wider borders take more passes over d)
+        for (int row = tid >> 3; row < y1 - y0; row += nthr >> 3)
+            for (int d = tid & 7; d < ndw_lr; d += 8)
+                put(y0 + row, y0 + row, d < pbl / 4 ? 4 * d - pbl : rbeg + 4 * (d - pbl / 4));
+        // rows above the image mirror rows 1..win, rows below mirror h-2..h-1-win: only the owners of those rows work
+        for (int k = max(1, y0); k <= min(win, y1 - 1); k++)
+            for (int d = tid; d < ndw_row; d += nthr) put(-k, k, 4 * d - pbl);
+        for (int k = max(1, P.h - y1); k <= min(win, P.h - 1 - y0); k++)
+            for (int d = tid; d < ndw_row; d += nthr) put(P.h - 1 + k, P.h - 1 - k, 4 * d - pbl);
+    }
 }
 
 static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                         double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                        uint8_t *lut_d)
+                        uint8_t *lut_d, int border = 0)
 {
     ClaheParams P;
+    P.border = border;
     int ew = w, eh = h;
     if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
     P.w = w; P.h = h; P.stride = stride; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
@@ -259,7 +310,7 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     if (clip_limit > 0.0) { P.clip = (int)(clip_limit * total / 256); if (P.clip < 1) P.clip = 1; }
     P.inv_tw = 1.0f / (float)P.tw; P.inv_th = 1.0f / (float)P.th;
     P.src_item_stride = (long long)src_batch_stride; P.dst_item_stride = (long long)dst_batch_stride; P.dst_stride = dst_stride;
-    hipLaunchKernelGGL(k_clahe_lut, dim3((tiles_x * tiles_y + 3) / 4, batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+    hipLaunchKernelGGL(k_clahe_lut, dim3((tiles_x * tiles_y + 19) / 20, batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 1024 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 255) / 256;
@@ -301,7 +352,7 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
     // no level-0 copy); borders and the coarser levels follow from there
     const PyrLevelDesc &L0 = p->d.lv[0];
     rc = clahe_launch(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
-                      p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch);
+                      p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win);
     if (rc != OV2_OK) return rc;
     return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
 }

@@ -50,26 +50,37 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
     // ---- stage the tile ----
     const uint8_t *src = FROM_RAW ? raw + (long long)b * raw_item_stride : item + L.img_roi;
     const bool aligned_src = FROM_RAW ? (((raw_stride | (int)(size_t)src) & 3) == 0) : true;
-    for (int e = tid; e < PT_ROWS * PT_LDS_DW; e += 256) {
+    // all loads of the tile are in flight before the first LDS store (a load -> store loop is latency-bound)
+    constexpr int NE = PT_ROWS * PT_LDS_DW, NPT = (NE + 255) / 256;
+    uint32_t stage[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        const int e = tid + 256 * i;
         const int row = e / PT_LDS_DW, dc = e - row * PT_LDS_DW;
         const int gy = y0 - 2 + row, gx = x0 - 4 + 4 * dc;
-        uint32_t v;
-        if (FROM_RAW) {
-            const int sy = reflect101(gy, L.h);
-            const uint8_t *rp = src + sy * raw_stride;
-            if (aligned_src && gx >= 0 && gx + 3 < L.w) v = *(const uint32_t *)(rp + gx);
-            else {
-                v = 0;
+        uint32_t v = 0;
+        if (e < NE) {
+            if (FROM_RAW) {
+                const int sy = reflect101(gy, L.h);
+                const uint8_t *rp = src + sy * raw_stride;
+                if (aligned_src && gx >= 0 && gx + 3 < L.w) v = *(const uint32_t *)(rp + gx);
+                else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) v |= (uint32_t)rp[reflect101(gx + k, L.w)] << (8 * k);
+                    for (int k = 0; k < 4; k++) v |= (uint32_t)rp[reflect101(gx + k, L.w)] << (8 * k);
+                }
+            } else {
+                // padded source: its REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed)
+                const int cy = min(max(gy, -P.win), L.h + P.win - 1);
+                const int cx = min(gx, L.w + P.win + 4) & ~3;
+                v = *(const uint32_t *)(src + cy * L.img_pitch + cx);
             }
-        } else {
-            // padded source: its REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed)
-            const int cy = min(max(gy, -P.win), L.h + P.win - 1);
-            const int cx = min(gx, L.w + P.win + 4) & ~3;
-            v = *(const uint32_t *)(src + cy * L.img_pitch + cx);
         }
-        tile[row][dc] = v;
+        stage[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        const int e = tid + 256 * i;
+        if (e < NE) (&tile[0][0])[e] = stage[i];
     }
     __syncthreads();
 
@@ -119,28 +130,48 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
     }
 }
 
-// ---- REFLECT_101 border of one level: thread per border pixel --------------------------------
-// border = padded rect [-win, w+win) x [-win, h+win) minus the ROI; enumerated as two horizontal
-// strips (full padded width) followed by two vertical strips (ROI height).
+// ---- REFLECT_101 border of one level: thread per border DWORD ---------------------------------
+// border = padded rect [-win, w+win) x [-win, h+win) minus the ROI.  Work items are aligned dwords:
+//   * 2*win border rows, each from column -round_up(win, 4) to round_up(w+win, 4)      (plain dword copies of the
+//     mirrored ROI row, except for the few edge dwords that also mirror columns),
+//   * h ROI rows x (round_up(win, 4)/4 left dwords + the dwords covering [w & ~3, w+win) on the right).
+// Bytes written outside [-win, w+win) lie in the row padding (img_padx >= 16, pitch slack >= 8) and are
+// never consumed; bytes of a right-edge dword that belong to the ROI are rewritten with their own value.
 __global__ __launch_bounds__(256) void k_pyr_border(PyrDesc P, int level)
 {
     const PyrLevelDesc L = P.lv[level];
-    const int win = P.win, pw = L.w + 2 * win;
-    const int n_h = 2 * win * pw, n_v = 2 * win * L.h;
+    const int win = P.win, PB_LEFT = (P.win + 3) & ~3;
+    const int wend = (L.w + win + 3) & ~3;
+    const int ndw_row = (PB_LEFT + wend) >> 2;                       // dwords of a full border row
+    const int rbeg = L.w & ~3, ndw_r = (wend - rbeg) >> 2, ndw_lr = PB_LEFT / 4 + ndw_r;
+    const int n_tb = 2 * win * ndw_row, n_lr = L.h * ndw_lr;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_h + n_v) return;
-    int x, y;
-    if (e < n_h) {
-        const int row = e / pw;
-        x = e - row * pw - win;
-        y = row < win ? row - win : L.h + (row - win);
+    if (e >= n_tb + n_lr) return;
+    int yt, c0;
+    if (e < n_tb) {
+        const int row = e / ndw_row;
+        c0 = (e - row * ndw_row) * 4 - PB_LEFT;
+        yt = row < win ? row - win : L.h + (row - win);
     } else {
-        const int f = e - n_h, row = f / (2 * win), c = f - row * (2 * win);
-        y = row;
-        x = c < win ? c - win : L.w + (c - win);
+        const int f = e - n_tb;
+        yt = f / ndw_lr;
+        const int d = f - yt * ndw_lr;
+        c0 = d < PB_LEFT / 4 ? 4 * d - PB_LEFT : rbeg + 4 * (d - PB_LEFT / 4);
     }
     uint8_t *roi = P.base + (long long)blockIdx.z * P.item_stride + L.img_roi;
-    roi[y * L.img_pitch + x] = roi[reflect101(y, L.h) * L.img_pitch + reflect101(x, L.w)];
+    const uint8_t *srow = roi + reflect101(yt, L.h) * L.img_pitch;
+    uint32_t v;
+    if (c0 >= 0 && c0 + 3 < L.w) v = *(const uint32_t *)(srow + c0);
+    else {
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int c = c0 + k;
+            c = c < -win ? -win : (c > L.w + win - 1 ? L.w + win - 1 : c);       // padding bytes: any value
+            v |= (uint32_t)srow[reflect101(c, L.w)] << (8 * k);
+        }
+    }
+    *(uint32_t *)(roi + yt * L.img_pitch + c0) = v;
 }
 
 // ---- Scharr derivative of one level of one item, on demand (ov2_pyr_download only) -----------
@@ -167,7 +198,8 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
     const PyrDesc &P = p->d;
     auto border = [&](int l) {
         const PyrLevelDesc &L = P.lv[l];
-        const int n = 2 * P.win * (L.w + 2 * P.win) + 2 * P.win * L.h;
+        const int wend = (L.w + P.win + 3) & ~3, PB_LEFT = (P.win + 3) & ~3;
+        const int n = 2 * P.win * ((PB_LEFT + wend) >> 2) + L.h * (PB_LEFT / 4 + ((wend - (L.w & ~3)) >> 2));
         hipLaunchKernelGGL(k_pyr_border, dim3((n + 255) / 256, 1, P.batch), dim3(256), 0, ctx->stream, P, l);
     };
     for (int l = 0; l < P.n_levels; l++) {
@@ -177,8 +209,7 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
             hipLaunchKernelGGL(k_pyr_level<true>, grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
             border(0);
         } else if (l == 0) {
-            // level 0 was written in place by the producer (ov2_pyr_build_clahe_d): borders, then pyrDown from the padded image
-            border(0);
+            // level 0 and its border were written in place by the producer (ov2_pyr_build_clahe_d): pyrDown from the padded image
             if (P.n_levels > 1) hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, 0, (const uint8_t *)nullptr, 0, 0LL);
         } else if (l + 1 < P.n_levels) {
             hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
