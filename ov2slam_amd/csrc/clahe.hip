@@ -310,7 +310,9 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     if (clip_limit > 0.0) { P.clip = (int)(clip_limit * total / 256); if (P.clip < 1) P.clip = 1; }
     P.inv_tw = 1.0f / (float)P.tw; P.inv_th = 1.0f / (float)P.th;
     P.src_item_stride = (long long)src_batch_stride; P.dst_item_stride = (long long)dst_batch_stride; P.dst_stride = dst_stride;
-    hipLaunchKernelGGL(k_clahe_lut, dim3((tiles_x * tiles_y + 19) / 20, batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+    // ~5 tiles per wavefront (prefetch pipeline) once the batch alone fills the GPU, one tile per wavefront otherwise (latency)
+    const int tiles_per_wave = (long long)batch * tiles_x * tiles_y >= 32768 ? 5 : 1;
+    hipLaunchKernelGGL(k_clahe_lut, dim3((tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave), batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 1024 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 255) / 256;

@@ -450,10 +450,15 @@ int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int ma
                        const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
                        const int *n_per_item, long long *stats);
 
-static bool lk_use_row_kernel()
+// Kernel choice for the reference's window (9): the 3-lanes-per-keypoint kernel needs >= ~3000 wavefronts of
+// 20 keypoints to fill the 1024 SIMDs (offline batch-of-sequences mode); below that -- the single-sequence
+// drop-in case: a few hundred keypoints -- the row-per-lane kernel has 5x more, 4x shorter wavefronts and
+// the lower latency.  OV2_LK_IMPL=row|lane3 forces one of them (A/B measurements).
+static bool lk_use_row_kernel(long long points)
 {
-    static const bool v = [] { const char *e = getenv("OV2_LK_IMPL"); return e && !strcmp(e, "row"); }();
-    return v;
+    static const int forced = [] { const char *e = getenv("OV2_LK_IMPL"); return !e ? 0 : (!strcmp(e, "row") ? 1 : (!strcmp(e, "lane3") ? 2 : 0)); }();
+    if (forced) return forced == 1;
+    return points < 65536;
 }
 
 template <int WIN>
@@ -474,7 +479,7 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
     OV2_REQUIRE(P.lv[0].w == C.lv[0].w && P.lv[0].h == C.lv[0].h, OV2_EINVAL, "prev/cur image size differs");
     OV2_REQUIRE(prm.win == P.win, OV2_EINVAL, "LK window differs from the window the pyramid was padded for");
     dim3 grid((prm.n_max + 15) / 16, P.batch);
-    if (prm.win == 9 && !lk_use_row_kernel()) {
+    if (prm.win == 9 && !lk_use_row_kernel((long long)prm.n_max * P.batch)) {
         ov2_launch_fb_klt3(ctx->stream, P, C, prm.max_level, prm.max_iter, prm.eps2, prm.min_eig_th, prm.flags, prm.err_th,
                            prm.fb_dist, prm.do_fb, prm.n_max, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d);
         OV2_HIP_CHECK(hipGetLastError());

@@ -7,7 +7,7 @@
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/summarize_profile.py condenses them into profiles/.
 set -u
 TAG=${1:-r1}
-ARGS=${2:-"--steps 60 --warmup 10 --no-extras"}
+ARGS=${2:-"--steps 60 --warmup 10 --no-extras --no-cpu-baseline"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
