@@ -244,6 +244,25 @@ int  ov2_ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out);
 int  ov2_ba_solve_resident(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba_result *r);
 void ov2_ba_destroy(ov2_ba_dev *dev);
 
+/* ------------------------------------------------------------------ */
+/* Per-keypoint undistortion + bearing vector                           */
+/* ------------------------------------------------------------------ */
+/* Frame::computeKeypoint (src/frame.cpp:246-254) for n keypoints in one launch:
+ *   unpx = CameraCalibration::undistortImagePoint(px)   (src/camera_calibration.cpp:313-333:
+ *          cv::undistortPoints(.., K, D, noArray(), K) for model pinhole, 5 iterations;
+ *          cv::fisheye::undistortPoints(.., K, D, Mat(), K) for model fisheye; `return pt` when D is empty)
+ *   bv   = normalize(iK * (unpx.x, unpx.y, 1))          (iK = the reference's K_.inverse(), row-major)
+ * K = (fx, fy, cx, cy); D / nD = distortion coefficients (pinhole: 4, 5, 8 or 12; fisheye: 4; 0 = none).
+ * px / unpx: n x (x,y) float; bv: n x 3 double, may be NULL.  The reference calls this per keypoint from
+ * Frame::addKeypoint / updateKeypoint (src/frame.cpp:257-354) and for right-image points (:408).      */
+#define OV2_CAM_PINHOLE 0
+#define OV2_CAM_FISHEYE 1
+int ov2_compute_keypoints(ov2_ctx *ctx, int model, const double K[4], const double *D, int nD, const double iK[9],
+                          const float *px_xy_h, int n, float *unpx_xy_h, double *bv_xyz_h);
+/* same on device-resident buffers (asynchronous on ctx's stream), e.g. straight on the output of ov2_fb_klt_d */
+int ov2_compute_keypoints_d(ov2_ctx *ctx, int model, const double K[4], const double *D, int nD, const double iK[9],
+                            const float *px_xy_d, int n, float *unpx_xy_d, double *bv_xyz_d);
+
 #ifdef __cplusplus
 }
 #endif

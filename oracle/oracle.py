@@ -313,3 +313,20 @@ def clahe(img, clip_limit, tiles_x, tiles_y):
     rc = lib().orc_clahe(_p(img), w, h, w, C.c_double(clip_limit), int(tiles_x), int(tiles_y), _p(out), w)
     assert rc == 0, rc
     return out
+
+
+# ---- per-keypoint undistortion + bearing (undistort.c) -------------------------------------------
+CAM_PINHOLE, CAM_FISHEYE = 0, 1
+
+
+def compute_keypoints(model, K, D, iK, px):
+    """Frame::computeKeypoint for an (n,2) float32 array: returns (unpx (n,2) float32, bv (n,3) float64)."""
+    px = np.ascontiguousarray(px, dtype=np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, dtype=np.float64); iK = np.ascontiguousarray(iK, dtype=np.float64).reshape(9)
+    D = np.ascontiguousarray(D if D is not None else [], dtype=np.float64)
+    n = len(px)
+    unpx = np.empty((n, 2), np.float32); bv = np.empty((n, 3), np.float64)
+    f = lib().orc_compute_keypoints
+    f.restype = None
+    f(int(model), _p(K), _p(D) if len(D) else None, int(len(D)), _p(iK), _p(px), n, _p(unpx), _p(bv))
+    return unpx, bv

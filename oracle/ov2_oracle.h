@@ -233,6 +233,20 @@ int orc_ba_residual(int type, const double calib_l[4], const double calib_r[4], 
                     double r[2], double J_anchor[12], double J_obs[12], double J_lambda[2],
                     double *chi2);
 
+/* ------------------------------------------------------------------ */
+/* Per-keypoint undistortion + bearing vector (Frame::computeKeypoint,  */
+/* src/frame.cpp:246-254; CameraCalibration::undistortImagePoint,       */
+/* src/camera_calibration.cpp:313-333) -- see undistort.c               */
+/* ------------------------------------------------------------------ */
+#define ORC_CAM_PINHOLE 0
+#define ORC_CAM_FISHEYE 1
+/* K = (fx, fy, cx, cy); D = distortion coefficients (nD = 4, 5, 8, 12 or 14 for pinhole; 4 for fisheye) */
+void orc_undistort_pinhole(const double K[4], const double *D, int nD, const float *px, int n, float *out);
+void orc_undistort_fisheye(const double K[4], const double D[4], const float *px, int n, float *out);
+/* iK row-major 3x3 (the reference's K_.inverse()); bv: 3 doubles per point */
+void orc_compute_keypoints(int model, const double K[4], const double *D, int nD, const double iK[9],
+                           const float *px, int n, float *unpx, double *bv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ OV2_EINVAL, OV2_EHIP, OV2_ENOMEM, OV2_EUNSUPPORTED, OV2_ENODEVICE = -1, -2, -3, 
 OV2_LK_USE_INITIAL_FLOW = 4
 OV2_LK_GET_MIN_EIGENVALS = 8
 OV2_MASK_AS_EXECUTED, OV2_MASK_INTENDED = 0, 1
+OV2_CAM_PINHOLE, OV2_CAM_FISHEYE = 0, 1
 OV2_RES_LEFT, OV2_RES_RIGHT, OV2_RES_RIGHT_ANCH, OV2_RES_PNP = 0, 1, 2, 3
 
 
@@ -81,6 +82,8 @@ SIGNATURES = {
     "ov2_pyr_algorithmic_bytes": (C.c_size_t, [_vp]),
     "ov2_clahe_h": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _i, _vp, _i]),
     "ov2_clahe_d": (_i, [_vp, _vp, _i, _i, _i, C.c_size_t, _i, _d, _i, _i, _vp, _i, C.c_size_t]),
+    "ov2_compute_keypoints": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "ov2_compute_keypoints_d": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "ov2_pyr_build_clahe_d": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _d, _i, _i]),
     "ov2_lk_track": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_fb_klt": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),

@@ -1,0 +1,162 @@
+// keypoint.hip -- per-keypoint undistortion + bearing vector for gfx950.
+//
+// Replaces the per-keypoint scalar loop of Frame::computeKeypoint (/root/reference/src/frame.cpp:246-254):
+//     kp.unpx_ = pcalib_leftcam_->undistortImagePoint(pt)      (camera_calibration.cpp:313-333:
+//                cv::undistortPoints / cv::fisheye::undistortPoints with P = K, one point per call)
+//     kp.bv_   = (iK_ * (unpx.x, unpx.y, 1)).normalized()
+// which the reference runs ~300 times per frame (addKeypoint / updateKeypoint after detection and
+// tracking).  One thread per keypoint, fp64 like OpenCV / Eigen, no FMA contraction: the pinhole model
+// (rational + tangential + thin-prism, 5 fixed-point iterations) and the bearing are +,-,*,/ and sqrt
+// only and match the oracle bit for bit; the fisheye model calls tan(), whose last bit may differ
+// between libm implementations (the float output hides it except at rounding boundaries).
+#include "common.hpp"
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+struct KpCalib {
+    double fx, fy, cx, cy;
+    double k[14];
+    double iK[9];
+    int nD, model;
+};
+
+__device__ __forceinline__ void kp_undistort_pinhole(const KpCalib &c, double u, double v, double &ox, double &oy)
+{
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    double x = (u - c.cx) * ifx, y = (v - c.cy) * ify;
+    const double x0 = x, y0 = y;
+    const double *k = c.k;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - c.cx) * ifx; y = (v - c.cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = c.fx * x + 0. * y + c.cx, yy = 0. * x + c.fy * y + c.cy, ww = 1. / (0. * x + 0. * y + 1.);
+    ox = xx * ww; oy = yy * ww;
+}
+
+__device__ __forceinline__ bool kp_undistort_fisheye(const KpCalib &c, double u, double v, double &ox, double &oy)
+{
+    const double EPS = 1e-8, PI_2 = 3.1415926535897932384626433832795 / 2.;
+    const double pwx = (u - c.cx) / c.fx, pwy = (v - c.cy) / c.fy;
+    double theta_d = sqrt(pwx * pwx + pwy * pwy);
+    theta_d = fmin(fmax(-PI_2, theta_d), PI_2);
+    bool converged = false;
+    double theta = theta_d, scale = 0.0;
+    if (fabs(theta_d) > EPS) {
+        for (int j = 0; j < 10; j++) {
+            const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
+            const double k0_theta2 = c.k[0] * theta2, k1_theta4 = c.k[1] * theta4, k2_theta6 = c.k[2] * theta6, k3_theta8 = c.k[3] * theta8;
+            const double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                     (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabs(theta_fix) < EPS) { converged = true; break; }
+        }
+        scale = tan(theta) / theta_d;
+    } else converged = true;
+    const bool flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
+    if (!converged || flipped) return false;
+    const double pux = pwx * scale, puy = pwy * scale;
+    const double prx = (0. + c.fx * pux) + 0. * puy + c.cx * 1.0;
+    const double pry = (0. + 0. * pux) + c.fy * puy + c.cy * 1.0;
+    const double prz = (0. + 0. * pux) + 0. * puy + 1. * 1.0;
+    ox = prx / prz; oy = pry / prz;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_compute_keypoints(KpCalib c, const float2 *__restrict__ px, int n,
+                                                           float2 *__restrict__ unpx, double *__restrict__ bv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = px[i];
+    float2 u = p;
+    if (c.nD > 0) {
+        double ox, oy;
+        if (c.model == OV2_CAM_FISHEYE) {
+            if (kp_undistort_fisheye(c, (double)p.x, (double)p.y, ox, oy)) u = make_float2((float)ox, (float)oy);
+            else u = make_float2(-1000000.0f, -1000000.0f);
+        } else {
+            kp_undistort_pinhole(c, (double)p.x, (double)p.y, ox, oy);
+            u = make_float2((float)ox, (float)oy);
+        }
+    }
+    unpx[i] = u;
+    if (bv) {
+        const double x = (double)u.x, y = (double)u.y;
+        double b[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) b[r] = (c.iK[3 * r] * x + c.iK[3 * r + 1] * y) + c.iK[3 * r + 2] * 1.;
+        const double nrm = sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]);
+        bv[3 * (long long)i] = b[0] / nrm; bv[3 * (long long)i + 1] = b[1] / nrm; bv[3 * (long long)i + 2] = b[2] / nrm;
+    }
+}
+
+static int kp_calib(int model, const double K[4], const double *D, int nD, const double iK[9], KpCalib &c)
+{
+    OV2_REQUIRE(K && iK, OV2_EINVAL, "K / iK == NULL");
+    OV2_REQUIRE(model == OV2_CAM_PINHOLE || model == OV2_CAM_FISHEYE, OV2_EINVAL, "unknown camera model");
+    OV2_REQUIRE(nD >= 0 && nD <= 14 && (nD == 0 || D), OV2_EINVAL, "bad distortion vector");
+    OV2_REQUIRE(model != OV2_CAM_FISHEYE || nD == 0 || nD == 4, OV2_EINVAL, "the fisheye model takes 4 coefficients");
+    OV2_REQUIRE(nD == 0 || model == OV2_CAM_FISHEYE || (nD == 4 || nD == 5 || nD == 8 || nD == 12), OV2_EUNSUPPORTED,
+                "pinhole distortion vectors of 4, 5, 8 or 12 coefficients (the tilted-sensor terms of the 14-vector are not implemented)");
+    memset(&c, 0, sizeof(c));
+    c.fx = K[0]; c.fy = K[1]; c.cx = K[2]; c.cy = K[3];
+    for (int i = 0; i < nD; i++) c.k[i] = D[i];
+    for (int i = 0; i < 9; i++) c.iK[i] = iK[i];
+    c.nD = nD; c.model = model;
+    return OV2_OK;
+}
+
+extern "C" {
+
+int ov2_compute_keypoints_d(ov2_ctx *ctx, int model, const double K[4], const double *D, int nD, const double iK[9],
+                            const float *px_xy_d, int n, float *unpx_xy_d, double *bv_xyz_d)
+{
+    OV2_REQUIRE(ctx, OV2_EINVAL, "ctx == NULL");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(px_xy_d && unpx_xy_d, OV2_EINVAL, "NULL point buffer");
+    KpCalib c;
+    const int rc = kp_calib(model, K, D, nD, iK, c);
+    if (rc != OV2_OK) return rc;
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_compute_keypoints, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, c, (const float2 *)px_xy_d, n,
+                       (float2 *)unpx_xy_d, bv_xyz_d);
+    OV2_HIP_CHECK(hipGetLastError());
+    return OV2_OK;
+}
+
+int ov2_compute_keypoints(ov2_ctx *ctx, int model, const double K[4], const double *D, int nD, const double iK[9],
+                          const float *px_xy_h, int n, float *unpx_xy_h, double *bv_xyz_h)
+{
+    OV2_REQUIRE(ctx, OV2_EINVAL, "ctx == NULL");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(px_xy_h && unpx_xy_h, OV2_EINVAL, "NULL point buffer");
+    KpCalib c;
+    int rc = kp_calib(model, K, D, nD, iK, c);
+    if (rc != OV2_OK) return rc;
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    // layout: [bv 24n][px 8n][unpx 8n]
+    const size_t o_bv = 0, o_px = 24 * (size_t)n, o_un = 32 * (size_t)n, total = 40 * (size_t)n;
+    rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(total);    if (rc) return rc;
+    uint8_t *hs = (uint8_t *)ctx->h_scratch, *ds = (uint8_t *)ctx->d_scratch;
+    memcpy(hs + o_px, px_xy_h, 8 * (size_t)n);
+    OV2_HIP_CHECK(hipMemcpyAsync(ds + o_px, hs + o_px, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_compute_keypoints, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, c, (const float2 *)(ds + o_px), n,
+                       (float2 *)(ds + o_un), bv_xyz_h ? (double *)(ds + o_bv) : nullptr);
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_un, ds + o_un, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (bv_xyz_h) OV2_HIP_CHECK(hipMemcpyAsync(hs + o_bv, ds + o_bv, 24 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(unpx_xy_h, hs + o_un, 8 * (size_t)n);
+    if (bv_xyz_h) memcpy(bv_xyz_h, hs + o_bv, 24 * (size_t)n);
+    return OV2_OK;
+}
+
+} // extern "C"

@@ -236,3 +236,35 @@ class FeatureExtractor:
         if p.shape[0]:
             L.check(self.lib.ov2_corner_subpix(self.ctx.h, _ptr(im), w, h, w, _ptr(p), p.shape[0], half_win, max_iter, eps))
         return p
+
+
+class CameraCalibration:
+    """Mirror of the reference's CameraCalibration / Frame::computeKeypoint pair
+    (/root/reference/src/camera_calibration.cpp:313-333, src/frame.cpp:246-254) for arrays of keypoints.
+
+    model: "pinhole" | "fisheye"; K = (fx, fy, cx, cy); D = distortion coefficients or None
+    (`Dcv_.empty()` -> undistortImagePoint returns the point unchanged)."""
+
+    MODELS = {"pinhole": L.OV2_CAM_PINHOLE, "fisheye": L.OV2_CAM_FISHEYE}
+
+    def __init__(self, ctx, model, fx, fy, cx, cy, D=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.model = self.MODELS[model]
+        self.K = np.array([fx, fy, cx, cy], np.float64)
+        self.D = None if D is None or len(D) == 0 else np.ascontiguousarray(D, dtype=np.float64)
+        Km = np.array([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]])
+        self.iK = np.ascontiguousarray(np.linalg.inv(Km))            # the reference's iK_ = K_.inverse()
+
+    def computeKeypoints(self, px, want_bv=True):
+        """px (n,2) float32 -> (unpx (n,2) float32, bv (n,3) float64 or None)."""
+        px = np.ascontiguousarray(px, dtype=np.float32).reshape(-1, 2)
+        n = len(px)
+        unpx = np.empty((n, 2), np.float32)
+        bv = np.empty((n, 3), np.float64) if want_bv else None
+        L.check(self.lib.ov2_compute_keypoints(self.ctx.h, self.model, _ptr(self.K), _ptr(self.D) if self.D is not None else None,
+                                               0 if self.D is None else len(self.D), _ptr(self.iK), _ptr(px), n, _ptr(unpx),
+                                               _ptr(bv) if want_bv else None))
+        return unpx, bv
+
+    def undistortImagePoint(self, pt):
+        return self.computeKeypoints(np.asarray(pt, np.float32).reshape(1, 2), want_bv=False)[0][0]

@@ -2,4 +2,5 @@
 #include "feature_tracker.hpp"
 #include "feature_extractor.hpp"
 #include "optimizer.hpp"
+#include "camera_calibration.hpp"
 int main() { return 0; }
