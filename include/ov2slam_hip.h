@@ -263,6 +263,27 @@ int ov2_compute_keypoints(ov2_ctx *ctx, int model, const double K[4], const doub
 int ov2_compute_keypoints_d(ov2_ctx *ctx, int model, const double K[4], const double *D, int nD, const double iK[9],
                             const float *px_xy_d, int n, float *unpx_xy_d, double *bv_xyz_d);
 
+/* ------------------------------------------------------------------ */
+/* Stereo matching front half (MapManager::stereoMatching,              */
+/* src/map_manager.cpp:367-611)                                         */
+/* ------------------------------------------------------------------ */
+/* FeatureTracker::getLineMinSAD (src/feature_tracker.cpp:138-206) for n keypoints in one launch, as called at
+ * src/map_manager.cpp:431 on the coarsest pyramid level of a rectified pair: pts are ALREADY scaled to
+ * `level` (kp.px_ * downpyrcoef), nwinsize odd (the reference uses 7), go_left = bgoleft.
+ * xprior[i] = best column at that level or -1 (multiply by uppyrcoef like :433); l1err[i] = the minimal mean
+ * absolute difference, 255 when nothing qualified (the reference leaves it unset on its early returns).
+ * left/right: batch-1 pyramids of the two images (the image of `level` is read, REPLICATE border as
+ * cv::getRectSubPix does); keypoints must lie inside that image.                                        */
+int ov2_line_min_sad(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int level, int nwinsize, int go_left,
+                     const float *pts_xy_h, int n, float *xprior_h, float *l1err_h);
+/* Epipolar gate of src/map_manager.cpp:568-590 for n (left keypoint, tracked right keypoint) pairs:
+ *   runpx = pcalib_rightcam_->undistortImagePoint(rkps[i])        (model / K / D / nD as in ov2_compute_keypoints)
+ *   rect != 0: epi_err = |lunpx.y - runpx.y| and rkps[i].y = lunpx[i].y (written back, :578)
+ *   rect == 0: epi_err = MultiViewGeometry::computeSampsonDistance(Frl, lunpx, runpx)  (src/multi_view_geometry.cpp:797-822)
+ *   ok[i] = epi_err <= 2.   runpx_xy_h / epi_err_h may be NULL.                                          */
+int ov2_stereo_epipolar_check(ov2_ctx *ctx, int rect, const double Frl[9], int model, const double K[4], const double *D, int nD,
+                              const float *lunpx_xy_h, float *rkps_xy_inout_h, int n, float *runpx_xy_h, float *epi_err_h, uint8_t *ok_h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -330,3 +330,50 @@ def compute_keypoints(model, K, D, iK, px):
     f.restype = None
     f(int(model), _p(K), _p(D) if len(D) else None, int(len(D)), _p(iK), _p(px), n, _p(unpx), _p(bv))
     return unpx, bv
+
+
+# ---- stereo matching front half (stereo.c) --------------------------------------------------------
+def get_rect_subpix_8u(img, pw, ph, cx, cy):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((ph, pw), np.uint8)
+    f = lib().orc_get_rect_subpix_8u
+    f.restype = None
+    f(_p(img), w, w, h, _p(out), int(pw), int(ph), C.c_float(cx), C.c_float(cy))
+    return out
+
+
+def line_min_sad(iml, imr, pts, nwinsize=7, go_left=True):
+    """FeatureTracker::getLineMinSAD for an (n,2) array of points: (xprior (n,), l1err (n,))."""
+    iml = np.ascontiguousarray(iml, dtype=np.uint8); imr = np.ascontiguousarray(imr, dtype=np.uint8)
+    h, w = iml.shape
+    assert imr.shape == iml.shape
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+    n = len(pts)
+    xp = np.empty(n, np.float32); err = np.empty(n, np.float32)
+    f = lib().orc_line_min_sad_batch
+    f.restype = None
+    f(_p(iml), w, _p(imr), w, w, h, _p(pts), n, int(nwinsize), int(bool(go_left)), _p(xp), _p(err))
+    return xp, err
+
+
+def sampson_distance(F, l, r):
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    f = lib().orc_sampson_distance
+    f.restype = C.c_float
+    return float(f(_p(F), C.c_float(l[0]), C.c_float(l[1]), C.c_float(r[0]), C.c_float(r[1])))
+
+
+def stereo_epipolar_check(rect, Frl, model, K, D, lunpx, rkps):
+    """returns (rkps_out, runpx, epi_err, ok) like the loop at map_manager.cpp:568-590."""
+    Frl = np.ascontiguousarray(Frl, dtype=np.float64).reshape(9)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    D = np.ascontiguousarray(D if D is not None else [], dtype=np.float64)
+    lunpx = np.ascontiguousarray(lunpx, dtype=np.float32).reshape(-1, 2)
+    rk = np.array(rkps, dtype=np.float32).reshape(-1, 2).copy()
+    n = len(rk)
+    runpx = np.empty((n, 2), np.float32); err = np.empty(n, np.float32); ok = np.empty(n, np.uint8)
+    f = lib().orc_stereo_epipolar_check
+    f.restype = None
+    f(int(bool(rect)), _p(Frl), int(model), _p(K), _p(D) if len(D) else None, int(len(D)), _p(lunpx), _p(rk), n, _p(runpx), _p(err), _p(ok))
+    return rk, runpx, err, ok.astype(bool)

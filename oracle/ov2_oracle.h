@@ -247,6 +247,19 @@ void orc_undistort_fisheye(const double K[4], const double D[4], const float *px
 void orc_compute_keypoints(int model, const double K[4], const double *D, int nD, const double iK[9],
                            const float *px, int n, float *unpx, double *bv);
 
+/* ------------------------------------------------------------------ */
+/* Stereo matching front half (MapManager::stereoMatching,              */
+/* src/map_manager.cpp:367-611) -- see stereo.c                         */
+/* ------------------------------------------------------------------ */
+void orc_get_rect_subpix_8u(const uint8_t *src, int src_step, int sw, int sh, uint8_t *dst, int pw, int ph, float cx, float cy);
+void orc_line_min_sad(const uint8_t *iml, int lstride, const uint8_t *imr, int rstride, int w, int h,
+                      float x, float y, int nwinsize, int go_left, float *xprior, float *l1err);
+void orc_line_min_sad_batch(const uint8_t *iml, int lstride, const uint8_t *imr, int rstride, int w, int h,
+                            const float *xy, int n, int nwinsize, int go_left, float *xprior, float *l1err);
+float orc_sampson_distance(const double F[9], float lx, float ly, float rx, float ry);
+void orc_stereo_epipolar_check(int rect, const double Frl[9], int model, const double K[4], const double *D, int nD,
+                               const float *lunpx, float *rkps, int n, float *runpx, float *epi_err, uint8_t *ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,6 @@
 #include <math.h>
 #include <float.h>
 
-#pragma STDC FP_CONTRACT OFF
 
 void orc_undistort_pinhole(const double K[4], const double *D, int nD, const float *px, int n, float *out)
 {
@@ -99,6 +98,7 @@ void orc_compute_keypoints(int model, const double K[4], const double *D, int nD
     if (nD <= 0) for (int i = 0; i < 2 * n; i++) unpx[i] = px[i];          /* Dcv_.empty(): return pt (camera_calibration.cpp:317-319) */
     else if (model == ORC_CAM_FISHEYE) orc_undistort_fisheye(K, D, px, n, unpx);
     else orc_undistort_pinhole(K, D, nD, px, n, unpx);
+    if (!bv) return;
     for (int i = 0; i < n; i++) {
         const double x = (double)unpx[2 * i], y = (double)unpx[2 * i + 1];
         double b[3];

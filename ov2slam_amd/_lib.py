@@ -84,6 +84,8 @@ SIGNATURES = {
     "ov2_clahe_d": (_i, [_vp, _vp, _i, _i, _i, C.c_size_t, _i, _d, _i, _i, _vp, _i, C.c_size_t]),
     "ov2_compute_keypoints": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "ov2_compute_keypoints_d": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "ov2_line_min_sad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "ov2_stereo_epipolar_check": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_pyr_build_clahe_d": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _d, _i, _i]),
     "ov2_lk_track": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_fb_klt": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),

@@ -9,65 +9,9 @@
 // (rational + tangential + thin-prism, 5 fixed-point iterations) and the bearing are +,-,*,/ and sqrt
 // only and match the oracle bit for bit; the fisheye model calls tan(), whose last bit may differ
 // between libm implementations (the float output hides it except at rounding boundaries).
-#include "common.hpp"
-#include <math.h>
+#include "keypoint_dev.hpp"
 
 #pragma clang fp contract(off)
-
-struct KpCalib {
-    double fx, fy, cx, cy;
-    double k[14];
-    double iK[9];
-    int nD, model;
-};
-
-__device__ __forceinline__ void kp_undistort_pinhole(const KpCalib &c, double u, double v, double &ox, double &oy)
-{
-    const double ifx = 1. / c.fx, ify = 1. / c.fy;
-    double x = (u - c.cx) * ifx, y = (v - c.cy) * ify;
-    const double x0 = x, y0 = y;
-    const double *k = c.k;
-    for (int j = 0; j < 5; j++) {
-        const double r2 = x * x + y * y;
-        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
-        if (icdist < 0) { x = (u - c.cx) * ifx; y = (v - c.cy) * ify; break; }
-        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
-        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
-    }
-    const double xx = c.fx * x + 0. * y + c.cx, yy = 0. * x + c.fy * y + c.cy, ww = 1. / (0. * x + 0. * y + 1.);
-    ox = xx * ww; oy = yy * ww;
-}
-
-__device__ __forceinline__ bool kp_undistort_fisheye(const KpCalib &c, double u, double v, double &ox, double &oy)
-{
-    const double EPS = 1e-8, PI_2 = 3.1415926535897932384626433832795 / 2.;
-    const double pwx = (u - c.cx) / c.fx, pwy = (v - c.cy) / c.fy;
-    double theta_d = sqrt(pwx * pwx + pwy * pwy);
-    theta_d = fmin(fmax(-PI_2, theta_d), PI_2);
-    bool converged = false;
-    double theta = theta_d, scale = 0.0;
-    if (fabs(theta_d) > EPS) {
-        for (int j = 0; j < 10; j++) {
-            const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
-            const double k0_theta2 = c.k[0] * theta2, k1_theta4 = c.k[1] * theta4, k2_theta6 = c.k[2] * theta6, k3_theta8 = c.k[3] * theta8;
-            const double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
-                                     (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
-            theta = theta - theta_fix;
-            if (fabs(theta_fix) < EPS) { converged = true; break; }
-        }
-        scale = tan(theta) / theta_d;
-    } else converged = true;
-    const bool flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
-    if (!converged || flipped) return false;
-    const double pux = pwx * scale, puy = pwy * scale;
-    const double prx = (0. + c.fx * pux) + 0. * puy + c.cx * 1.0;
-    const double pry = (0. + 0. * pux) + c.fy * puy + c.cy * 1.0;
-    const double prz = (0. + 0. * pux) + 0. * puy + 1. * 1.0;
-    ox = prx / prz; oy = pry / prz;
-    return true;
-}
 
 __global__ __launch_bounds__(256) void k_compute_keypoints(KpCalib c, const float2 *__restrict__ px, int n,
                                                            float2 *__restrict__ unpx, double *__restrict__ bv)
@@ -75,17 +19,7 @@ __global__ __launch_bounds__(256) void k_compute_keypoints(KpCalib c, const floa
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float2 p = px[i];
-    float2 u = p;
-    if (c.nD > 0) {
-        double ox, oy;
-        if (c.model == OV2_CAM_FISHEYE) {
-            if (kp_undistort_fisheye(c, (double)p.x, (double)p.y, ox, oy)) u = make_float2((float)ox, (float)oy);
-            else u = make_float2(-1000000.0f, -1000000.0f);
-        } else {
-            kp_undistort_pinhole(c, (double)p.x, (double)p.y, ox, oy);
-            u = make_float2((float)ox, (float)oy);
-        }
-    }
+    const float2 u = kp_undistort_image_point(c, p);
     unpx[i] = u;
     if (bv) {
         const double x = (double)u.x, y = (double)u.y;
@@ -97,7 +31,7 @@ __global__ __launch_bounds__(256) void k_compute_keypoints(KpCalib c, const floa
     }
 }
 
-static int kp_calib(int model, const double K[4], const double *D, int nD, const double iK[9], KpCalib &c)
+int ov2_kp_calib(int model, const double K[4], const double *D, int nD, const double iK[9], KpCalib &c)
 {
     OV2_REQUIRE(K && iK, OV2_EINVAL, "K / iK == NULL");
     OV2_REQUIRE(model == OV2_CAM_PINHOLE || model == OV2_CAM_FISHEYE, OV2_EINVAL, "unknown camera model");
@@ -122,7 +56,7 @@ int ov2_compute_keypoints_d(ov2_ctx *ctx, int model, const double K[4], const do
     if (n <= 0) return OV2_OK;
     OV2_REQUIRE(px_xy_d && unpx_xy_d, OV2_EINVAL, "NULL point buffer");
     KpCalib c;
-    const int rc = kp_calib(model, K, D, nD, iK, c);
+    const int rc = ov2_kp_calib(model, K, D, nD, iK, c);
     if (rc != OV2_OK) return rc;
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_compute_keypoints, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, c, (const float2 *)px_xy_d, n,
@@ -138,7 +72,7 @@ int ov2_compute_keypoints(ov2_ctx *ctx, int model, const double K[4], const doub
     if (n <= 0) return OV2_OK;
     OV2_REQUIRE(px_xy_h && unpx_xy_h, OV2_EINVAL, "NULL point buffer");
     KpCalib c;
-    int rc = kp_calib(model, K, D, nD, iK, c);
+    int rc = ov2_kp_calib(model, K, D, nD, iK, c);
     if (rc != OV2_OK) return rc;
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     // layout: [bv 24n][px 8n][unpx 8n]

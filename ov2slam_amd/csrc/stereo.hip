@@ -1,0 +1,226 @@
+// stereo.hip -- data-parallel front half of MapManager::stereoMatching for gfx950
+// (/root/reference/src/map_manager.cpp:367-611):
+//   k_line_min_sad     FeatureTracker::getLineMinSAD (src/feature_tracker.cpp:138-206): for every left
+//                      keypoint a 1-D scan along the same row of the right image (rectified pairs), cost =
+//                      mean absolute difference of (2 halfwin + 1)^2 cv::getRectSubPix patches; one WAVEFRONT
+//                      per keypoint, one candidate column per lane, the left patch staged in LDS;
+//   k_epipolar_check   the gate at :568-590: right keypoint undistorted, |dy| (rectified) or Sampson
+//                      distance (src/multi_view_geometry.cpp:797-822) <= 2, y snapped to the left row.
+// The two fbKltTracking calls in between (:507, :546) are ov2_fb_klt on (left pyramid, right pyramid).
+// Patch arithmetic is cv::getRectSubPix u8->u8: 16.16 fixed-point bilinear weights, (t + 2^15) >> 16,
+// replicated border with the vertical-only weights b1/b2 outside the columns (adjustRect) -- integers,
+// bit-exact against the oracle.
+#include "keypoint_dev.hpp"
+
+#pragma clang fp contract(off)
+
+#define SAD_MAX_WS 21                 // halfwin can grow through the reference's `halfwin += (x + halfwin - cols - 1)` quirk
+
+struct SadWeights { int a11, a12, a21, a22, b1, b2, ipx_off, ipy; };
+
+__device__ __forceinline__ int sad_fixpt(float a) { return __float2int_rn(a * (float)(1 << 16)); }
+
+// one pixel (i, j) of getRectSubPix(src, (ws, ws), centre) where ipx/ipy = floor(centre - (ws-1)/2)
+__device__ __forceinline__ int sad_subpix(const uint8_t *__restrict__ img, int pitch, int w, int h, int ipx, int ipy, int i, int j,
+                                          const SadWeights &W)
+{
+    int y0 = ipy + i, y1 = y0 + 1;
+    y0 = min(max(y0, 0), h - 1); y1 = min(max(y1, 0), h - 1);
+    const int x = ipx + j;
+    const uint8_t *r0 = img + y0 * pitch, *r1 = img + y1 * pitch;
+    int t;
+    if (x < 0) t = (int)r0[0] * W.b1 + (int)r1[0] * W.b2;                       // left of the image: column 0, vertical blend only
+    else if (x >= w - 1) t = (int)r0[w - 1] * W.b1 + (int)r1[w - 1] * W.b2;     // no right neighbour: column w-1, vertical blend only
+    else t = (int)r0[x] * W.a11 + (int)r0[x + 1] * W.a12 + (int)r1[x] * W.a21 + (int)r1[x + 1] * W.a22;
+    return ((t + (1 << 15)) >> 16) & 0xFF;
+}
+
+__global__ __launch_bounds__(256) void k_line_min_sad(PyrDesc PL, PyrDesc PR, int level, int nwinsize, int go_left,
+                                                      const float2 *__restrict__ pts, int n, float *__restrict__ xprior,
+                                                      float *__restrict__ l1err)
+{
+    __shared__ uint8_t patch_all[4][SAD_MAX_WS * SAD_MAX_WS + 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;                                              // whole wavefront
+    uint8_t *patch = patch_all[wave];
+    const PyrLevelDesc L = PL.lv[level];
+    const uint8_t *iml = PL.base + L.img_roi, *imr = PR.base + PR.lv[level].img_roi;
+    const int pitch_l = L.img_pitch, pitch_r = PR.lv[level].img_pitch, w = L.w, h = L.h;
+    const float x = pts[i].x, y = pts[i].y;
+    float best_e = 255.f, best_c = -1.f;
+    int halfwin = nwinsize / 2;
+    // int += float: formed in float, truncated toward zero (feature_tracker.cpp:154-161)
+    if (x - (float)halfwin < 0.f) halfwin = (int)((float)halfwin + (x - (float)halfwin));
+    if (x + (float)halfwin >= (float)w) halfwin = (int)((float)halfwin + (x + (float)halfwin - (float)w - 1.f));
+    if (y - (float)halfwin < 0.f) halfwin = (int)((float)halfwin + (y - (float)halfwin));
+    if (y + (float)halfwin >= (float)h) halfwin = (int)((float)halfwin + (y + (float)halfwin - (float)h - 1.f));
+    const int ws = 2 * halfwin + 1;
+    if ((nwinsize & 1) && halfwin > 0 && ws <= SAD_MAX_WS) {
+        const int npx = ws * ws;
+        // the patch centre (x, y) and every candidate (x -+ k, y) share the fractional parts: one weight set
+        const float cx = x - (float)(ws - 1) * 0.5f, cy = y - (float)(ws - 1) * 0.5f;
+        const int ipx = (int)floorf(cx), ipy = (int)floorf(cy);
+        const float a = cx - (float)ipx, b = cy - (float)ipy;
+        SadWeights W;
+        W.a11 = sad_fixpt((1.f - a) * (1.f - b)); W.a12 = sad_fixpt(a * (1.f - b)); W.a21 = sad_fixpt((1.f - a) * b); W.a22 = sad_fixpt(a * b);
+        W.b1 = sad_fixpt(1.f - b); W.b2 = sad_fixpt(b);
+        for (int e = lane; e < npx; e += 64) {
+            const int pi = e / ws, pj = e - pi * ws;
+            patch[e] = (uint8_t)sad_subpix(iml, pitch_l, w, h, ipx, ipy, pi, pj, W);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // candidates in scan order k = 0, 1, ...: c_k = x - k while c >= halfwin (left; exact in float, so every
+        // candidate shares the patch's fractional offsets and weights), or c <- c + 1 while c < w - halfwin
+        // (right; the running float sum may round when it crosses a power of two, so c is accumulated step by
+        // step like the reference's `c += 1.` and the weights are recomputed from it)
+        int best_k = 0x7fffffff;
+        float cr = x;
+        if (!go_left) for (int t = 0; t < lane; t++) cr += 1.f;
+        for (int k = lane; ; k += 64) {
+            const float c = go_left ? x - (float)k : cr;
+            const bool valid = go_left ? (c >= (float)halfwin) : (c < (float)(w - halfwin));
+            if (__builtin_amdgcn_ballot_w64(valid) == 0) break;        // candidates are monotone in k
+            if (valid) {
+                int cipx = ipx - k;                                     // floor(c - (ws-1)/2) = ipx - k going left
+                SadWeights Wc = W;
+                if (!go_left) {
+                    const float ccx = c - (float)(ws - 1) * 0.5f;
+                    cipx = (int)floorf(ccx);
+                    const float ac = ccx - (float)cipx;
+                    Wc.a11 = sad_fixpt((1.f - ac) * (1.f - b)); Wc.a12 = sad_fixpt(ac * (1.f - b));
+                    Wc.a21 = sad_fixpt((1.f - ac) * b); Wc.a22 = sad_fixpt(ac * b);
+                }
+                int sad = 0;
+                for (int pi = 0; pi < ws; pi++)
+                    for (int pj = 0; pj < ws; pj++) {
+                        const int t = sad_subpix(imr, pitch_r, w, h, cipx, ipy, pi, pj, Wc);
+                        const int d = t - (int)patch[pi * ws + pj];
+                        sad += d < 0 ? -d : d;
+                    }
+                float e = (float)sad;
+                e /= (float)npx;
+                if (e < best_e) { best_e = e; best_k = k; best_c = c; }   // k ascending per lane: first minimum kept
+            }
+            if (!go_left) for (int t = 0; t < 64; t++) cr += 1.f;
+        }
+        // first minimum in scan order over the whole wavefront: smallest (e, k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float oe = __shfl_xor(best_e, off, 64);
+            const int ok = __shfl_xor(best_k, off, 64);
+            const float oc = __shfl_xor(best_c, off, 64);
+            if (oe < best_e || (oe == best_e && ok < best_k)) { best_e = oe; best_k = ok; best_c = oc; }
+        }
+    }
+    if (lane == 0) { xprior[i] = best_c; l1err[i] = best_e; }
+}
+
+// float Sampson distance exactly as MultiViewGeometry::computeSampsonDistance narrows its doubles
+__device__ __forceinline__ float sampson(const double *F, float lx, float ly, float rx, float ry)
+{
+    const double l[3] = {(double)lx, (double)ly, 1.}, r[3] = {(double)rx, (double)ry, 1.};
+    double rtF[3], Fl[3], Ftr[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) rtF[j] = (r[0] * F[j] + r[1] * F[3 + j]) + r[2] * F[6 + j];
+    float num = (float)((rtF[0] * l[0] + rtF[1] * l[1]) + rtF[2] * l[2]);
+    num *= num;
+#pragma unroll
+    for (int k = 0; k < 3; k++) Fl[k] = (F[3 * k] * l[0] + F[3 * k + 1] * l[1]) + F[3 * k + 2] * l[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Ftr[j] = (F[j] * r[0] + F[3 + j] * r[1]) + F[6 + j] * r[2];
+    const float x1 = (float)Ftr[0], x2 = (float)Fl[0], y1 = (float)Ftr[1], y2 = (float)Fl[1];
+    const float den = x1 * x1 + y1 * y1 + x2 * x2 + y2 * y2;
+    return sqrtf(num / den);
+}
+
+struct EpiParams { double F[9]; int rect; };
+
+__global__ __launch_bounds__(256) void k_epipolar_check(EpiParams E, KpCalib c, const float2 *__restrict__ lunpx, float2 *__restrict__ rkps,
+                                                        int n, float2 *__restrict__ runpx, float *__restrict__ epi_err, uint8_t *__restrict__ ok)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 l = lunpx[i];
+    float2 rk = rkps[i];
+    const float2 ru = kp_undistort_image_point(c, rk);
+    float e;
+    if (E.rect) {
+        e = fabsf(l.y - ru.y);
+        rk.y = l.y;                                      // map_manager.cpp:578
+        rkps[i] = rk;
+    } else e = sampson(E.F, l.x, l.y, ru.x, ru.y);
+    runpx[i] = ru;
+    epi_err[i] = e;
+    ok[i] = e <= 2.f ? 1 : 0;
+}
+
+extern "C" {
+
+int ov2_line_min_sad(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int level, int nwinsize, int go_left,
+                     const float *pts_xy_h, int n, float *xprior_h, float *l1err_h)
+{
+    OV2_REQUIRE(ctx && left && right, OV2_EINVAL, "NULL argument");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(pts_xy_h && xprior_h && l1err_h, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(left->d.batch == 1 && right->d.batch == 1, OV2_EINVAL, "host-buffer entry point takes batch=1 pyramids");
+    OV2_REQUIRE(level >= 0 && level < left->d.n_levels && level < right->d.n_levels, OV2_EINVAL, "level not in the pyramid");
+    OV2_REQUIRE(left->d.lv[level].w == right->d.lv[level].w && left->d.lv[level].h == right->d.lv[level].h, OV2_EINVAL,
+                "left/right level size differs");
+    OV2_REQUIRE(nwinsize > 0 && nwinsize <= 9, OV2_EUNSUPPORTED, "getLineMinSAD window up to 9 (the reference uses 7)");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    // layout: [pts 8n][xprior 4n][l1err 4n]
+    const size_t total = 16 * (size_t)n;
+    int rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(total);        if (rc) return rc;
+    uint8_t *hs = (uint8_t *)ctx->h_scratch, *ds = (uint8_t *)ctx->d_scratch;
+    memcpy(hs, pts_xy_h, 8 * (size_t)n);
+    OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_line_min_sad, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, left->d, right->d, level, nwinsize, go_left ? 1 : 0,
+                       (const float2 *)ds, n, (float *)(ds + 8 * (size_t)n), (float *)(ds + 12 * (size_t)n));
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + 8 * (size_t)n, ds + 8 * (size_t)n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(xprior_h, hs + 8 * (size_t)n, 4 * (size_t)n);
+    memcpy(l1err_h, hs + 12 * (size_t)n, 4 * (size_t)n);
+    return OV2_OK;
+}
+
+int ov2_stereo_epipolar_check(ov2_ctx *ctx, int rect, const double Frl[9], int model, const double K[4], const double *D, int nD,
+                              const float *lunpx_xy_h, float *rkps_xy_inout_h, int n, float *runpx_xy_h, float *epi_err_h, uint8_t *ok_h)
+{
+    OV2_REQUIRE(ctx, OV2_EINVAL, "ctx == NULL");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(lunpx_xy_h && rkps_xy_inout_h && ok_h, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(rect || Frl, OV2_EINVAL, "Frl == NULL for a non-rectified pair");
+    KpCalib c;
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int rc = ov2_kp_calib(model, K, D, nD, I3, c);
+    if (rc != OV2_OK) return rc;
+    EpiParams E;
+    for (int i = 0; i < 9; i++) E.F[i] = Frl ? Frl[i] : 0.;
+    E.rect = rect ? 1 : 0;
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    // layout: [lunpx 8n][rkps 8n][runpx 8n][err 4n][ok n]
+    const size_t N = (size_t)n, o_l = 0, o_r = 8 * N, o_u = 16 * N, o_e = 24 * N, o_k = 28 * N, total = 29 * N;
+    rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(total);    if (rc) return rc;
+    uint8_t *hs = (uint8_t *)ctx->h_scratch, *ds = (uint8_t *)ctx->d_scratch;
+    memcpy(hs + o_l, lunpx_xy_h, 8 * N);
+    memcpy(hs + o_r, rkps_xy_inout_h, 8 * N);
+    OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, 16 * N, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_epipolar_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_l),
+                       (float2 *)(ds + o_r), n, (float2 *)(ds + o_u), (float *)(ds + o_e), ds + o_k);
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_r, ds + o_r, total - o_r, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(rkps_xy_inout_h, hs + o_r, 8 * N);
+    if (runpx_xy_h) memcpy(runpx_xy_h, hs + o_u, 8 * N);
+    if (epi_err_h) memcpy(epi_err_h, hs + o_e, 4 * N);
+    memcpy(ok_h, hs + o_k, N);
+    return OV2_OK;
+}
+
+} // extern "C"

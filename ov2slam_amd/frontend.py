@@ -171,6 +171,17 @@ class FeatureTracker:
             return pri, status.astype(bool), (int(stats[0]), int(stats[1]))
         return pri, status.astype(bool)
 
+    def getLineMinSAD(self, leftpyr, rightpyr, level, pts, nwinsize=7, bgoleft=True):
+        """src/feature_tracker.cpp:138-206 for an (n,2) array of points already scaled to `level`
+        (the reference passes vleftpyr.at(2 * nklt_pyr_lvl_) and kp.px_ * downpyrcoef, map_manager.cpp:427-431).
+        Returns (xprior (n,) float32, -1 = none; l1err (n,) float32)."""
+        pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 2)
+        n = len(pts)
+        xp = np.full(n, -1, np.float32); err = np.full(n, 255, np.float32)
+        L.check(self.lib.ov2_line_min_sad(self.ctx.h, leftpyr.h_pyr, rightpyr.h_pyr, int(level), int(nwinsize), int(bool(bgoleft)),
+                                          _ptr(pts), n, _ptr(xp), _ptr(err)))
+        return xp, err
+
     def calcOpticalFlowPyrLK(self, prevpyr, nextpyr, prevpts, nextpts, nwinsize, maxlevel,
                              flags=L.OV2_LK_USE_INITIAL_FLOW | L.OV2_LK_GET_MIN_EIGENVALS):
         """One cv::calcOpticalFlowPyrLK call (src/feature_tracker.cpp:66-69)."""

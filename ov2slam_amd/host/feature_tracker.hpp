@@ -32,6 +32,21 @@ public:
         for (size_t i = 0; i < n; i++) vkpstatus.push_back(rc == OV2_OK && st[i] != 0);
     }
 
+    // reference: void getLineMinSAD(const cv::Mat &iml, const cv::Mat &imr, const cv::Point2f &pt, const int nwinsize,
+    //                float &xprior, float &l1err, bool bgoleft) const                              (:138-206)
+    // -- here for a whole vector of points on pyramid level `level` in one launch (the reference loops over the
+    // keypoints and calls it per point, src/map_manager.cpp:421-439).  xprior[i] = -1 when nothing qualified.
+    void getLineMinSAD(Context &ctx, const Pyramid &leftpyr, const Pyramid &rightpyr, int level, const std::vector<Point2f> &vpts,
+                       int nwinsize, std::vector<float> &vxprior, std::vector<float> &vl1err, bool bgoleft) const
+    {
+        vxprior.assign(vpts.size(), -1.f);
+        vl1err.assign(vpts.size(), 255.f);
+        if (vpts.empty()) return;
+        const int rc = ov2_line_min_sad(ctx.get(), leftpyr.get(), rightpyr.get(), level, nwinsize, bgoleft ? 1 : 0, &vpts[0].x,
+                                        (int)vpts.size(), vxprior.data(), vl1err.data());
+        if (rc != OV2_OK) vxprior.assign(vpts.size(), -1.f);       // degrade to "no prior", like an early return
+    }
+
     // reference: bool inBorder(const cv::Point2f &pt, const cv::Mat &im) const  (:216-221)
     bool inBorder(const Point2f &pt, int cols, int rows) const
     {
