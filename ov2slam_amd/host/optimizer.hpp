@@ -98,7 +98,66 @@ public:
         return R;
     }
 
+    // Optimizer::looseBA (src/optimizer.cpp:900-1672): same residual blocks, ONE solve (5 it, function_tolerance
+    // 1e-4, :1297-1310), then the chi2 / depth test over all three residual lists (:1327-1430).
+    LocalBAResult solveLooseBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost) const
+    {
+        return solveOnce(ctx, fp, buse_robust_cost, 5, 1e-4, /*test_anchor_right*/ true);
+    }
+
+    // Optimizer::fullBA (src/optimizer.cpp:1674-2332): pass 1 with max 100 iterations and Ceres' default
+    // tolerances (:2055-2061); outlier test over the left / right lists (:2067-2138); if apply_l2_after_robust and
+    // outliers were found, pass 2 with the loss reset to L2 when the left list is non-empty (:2143-2149); test again.
+    LocalBAResult solveFullBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost) const
+    {
+        LocalBAResult R = solveOnce(ctx, fp, buse_robust_cost, 100, 1e-6, /*test_anchor_right*/ false);
+        if (!R.ok) return R;
+        const size_t n_res = fp.res_type.size();
+        std::vector<uint8_t> active(n_res, 1);
+        size_t nbbad = 0; bool left_rem = false;
+        for (size_t i = 0; i < n_res; i++) {
+            nbbad += R.bad_obs[i];
+            if (R.bad_obs[i] && apply_l2_after_robust_) active[i] = 0;
+            if (!R.bad_obs[i] && fp.res_type[i] == OV2_RES_LEFT) left_rem = true;
+        }
+        if (apply_l2_after_robust_ && nbbad > 0) {
+            ov2_ba_options opt; ov2_ba_default_options(&opt);
+            opt.max_iter = 100; opt.function_tolerance = 1e-6;
+            opt.huber_delta = (buse_robust_cost && !left_rem) ? std::sqrt(robust_mono_th_) : -1.0;
+            ov2_ba_result res{};
+            res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
+            fp.poses = R.poses; fp.invdepth = R.invdepth;
+            ov2_ba_problem p = fp.view(active.data());
+            if (ov2_ba_solve(ctx.get(), &p, &opt, &res) == OV2_OK) { R.l2_done = true; R.iterations[1] = res.iterations; R.solve_ms[1] = res.solve_ms; }
+        }
+        for (size_t i = 0; i < n_res; i++)
+            if (active[i] && (fp.res_type[i] == OV2_RES_LEFT || fp.res_type[i] == OV2_RES_RIGHT) && (R.chi2[i] > robust_mono_th_ || !R.depthpos[i]))
+                R.bad_obs[i] = 1;
+        return R;
+    }
+
 private:
+    LocalBAResult solveOnce(Context &ctx, FlatProblem &fp, bool buse_robust_cost, int max_iter, double ftol, bool test_anchor_right) const
+    {
+        LocalBAResult R;
+        const size_t n_res = fp.res_type.size();
+        R.poses.resize(fp.poses.size()); R.invdepth.resize(fp.invdepth.size());
+        R.chi2.assign(n_res, 0.0); R.depthpos.assign(n_res, 1); R.bad_obs.assign(n_res, 0);
+        ov2_ba_options opt; ov2_ba_default_options(&opt);
+        opt.max_iter = max_iter; opt.function_tolerance = ftol;
+        opt.huber_delta = buse_robust_cost ? std::sqrt(robust_mono_th_) : -1.0;
+        ov2_ba_result res{};
+        res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
+        ov2_ba_problem p = fp.view(nullptr);
+        if (ov2_ba_solve(ctx.get(), &p, &opt, &res) != OV2_OK) return R;
+        R.ok = true; R.iterations[0] = res.iterations; R.solve_ms[0] = res.solve_ms;
+        for (size_t i = 0; i < n_res; i++) {
+            const bool tested = fp.res_type[i] == OV2_RES_LEFT || fp.res_type[i] == OV2_RES_RIGHT || (test_anchor_right && fp.res_type[i] == OV2_RES_RIGHT_ANCH);
+            R.bad_obs[i] = tested && (R.chi2[i] > robust_mono_th_ || !R.depthpos[i]);
+        }
+        return R;
+    }
+
     double robust_mono_th_;
     bool apply_l2_after_robust_;
     bool bstop_localba_ = false;

@@ -115,7 +115,8 @@ class ResidentProblem:
 
 
 class Optimizer:
-    """Mirror of /root/reference/include/optimizer.hpp:36-60 restricted to localBA.
+    """Mirror of /root/reference/include/optimizer.hpp:36-60: localBA, looseBA, fullBA (structureOnlyBA: see
+    structure_only_ba below; the two pose-graph solvers are out of scope).
 
     localBA(problem, buse_robust_cost) runs optimizer.cpp:436-627 on a flat problem:
       pass 1  Huber(sqrt(robust_mono_th)), 5 iterations, function_tolerance 1e-3          (:436-485)
@@ -170,6 +171,54 @@ class Optimizer:
             # second outlier test on the residual blocks that are still in the problem (:637-735)
             bad2 = (active == 1) & ((chi2 > th) | (dpos == 0))
             bad = bad | bad2
+        out.update(poses=poses, invdepth=lam, chi2=chi2, depthpos=dpos, bad_obs=bad)
+        return out
+
+
+    def looseBA(self, prob, buse_robust_cost=True):
+        """Optimizer::looseBA (src/optimizer.cpp:900-1672) on a flat problem -- the loop-closure BA over the KFs
+        between the loop KF and the new KF.  Same residual blocks as localBA (buse_inv_depth_: 1 in every shipped
+        parameter file), ONE solve: Huber(sqrt(robust_mono_th)) unless !buse_robust_cost, 5 iterations,
+        function_tolerance 1e-4, no time limit (:1297-1310); then the chi2 / depth outlier test over the left,
+        right and anchor-right residual lists (:1327-1430)."""
+        th = self.robust_mono_th
+        huber = math.sqrt(th) if buse_robust_cost else -1.0
+        p1 = self._solve(prob, None, None, None, max_iter=5, function_tolerance=1e-4, huber_delta=huber)
+        bad = (p1["chi2"] > th) | (p1["depthpos"] == 0)
+        return dict(pass1=p1, poses=p1["poses"], invdepth=p1["invdepth"], chi2=p1["chi2"], depthpos=p1["depthpos"], bad_obs=bad)
+
+    def fullBA(self, prob, buse_robust_cost=True):
+        """Optimizer::fullBA (src/optimizer.cpp:1674-2332) on a flat problem -- every KF and map point, run offline
+        after the sequence (src/mapper.cpp:780).
+          pass 1  Huber unless !buse_robust_cost, max 100 iterations, Ceres' default tolerances (function 1e-6,
+                  gradient 1e-10, parameter 1e-8)                                                   (:2055-2061)
+          outliers  chi2 / depth test over the left and right-camera lists (the anchor-right blocks are never
+                    tested here); residual blocks removed if apply_l2_after_robust                   (:2067-2138)
+          pass 2  if apply_l2_after_robust and outliers were found: loss reset to L2 when the left list is
+                  non-empty, same options; then the outlier test again                              (:2143-2232)"""
+        th = self.robust_mono_th
+        huber = math.sqrt(th) if buse_robust_cost else -1.0
+        n_res = int(prob["n_res"])
+        rtype = np.asarray(prob["res_type"])
+        tested = (rtype == RES_LEFT) | (rtype == RES_RIGHT)
+        kw = dict(max_iter=100, function_tolerance=1e-6)
+        p1 = self._solve(prob, None, None, None, huber_delta=huber, **kw)
+        bad = tested & ((p1["chi2"] > th) | (p1["depthpos"] == 0))
+        out = dict(pass1=p1, bad_after_pass1=bad.copy(), l2_done=False)
+        poses, lam, chi2, dpos = p1["poses"], p1["invdepth"], p1["chi2"], p1["depthpos"]
+        active = np.ones(n_res, np.uint8)
+        if self.apply_l2_after_robust:
+            active[bad] = 0
+        if self.apply_l2_after_robust and int(bad.sum()) > 0:
+            left_remaining = bool(((rtype == RES_LEFT) & ~bad).any())
+            huber2 = -1.0 if left_remaining else huber                             # :2145-2147
+            prob2 = dict(prob)
+            prob2["poses"] = poses; prob2["invdepth"] = lam
+            p2 = self._solve(prob2, active, chi2, dpos, huber_delta=huber2, **kw)
+            out["pass2"] = p2; out["l2_done"] = True
+            poses, lam, chi2, dpos = p2["poses"], p2["invdepth"], p2["chi2"], p2["depthpos"]
+        bad2 = tested & (active == 1) & ((chi2 > th) | (dpos == 0))                # :2155-2232 (runs in both cases)
+        bad = bad | bad2
         out.update(poses=poses, invdepth=lam, chi2=chi2, depthpos=dpos, bad_obs=bad)
         return out
 

@@ -129,3 +129,27 @@ def test_mixed_problem_with_pose_only_blocks(gpu_ctx, oracle):
     mix["res_xyz"] = np.concatenate([np.zeros((n0, 3)), X])
     g = optimizer.solve(gpu_ctx, mix); r = oracle.ba_solve(mix)
     _cmp(g, r, mix)
+
+
+def test_looseba_fullba_protocols_match_oracle(gpu_ctx, oracle):
+    """Optimizer::looseBA (5 it, ftol 1e-4, one pass) and fullBA (100 it, Ceres default tolerances, optional L2 pass) on
+    the device vs the identical protocol on the oracle: same iteration counts / terminations, poses within 1e-6."""
+    def oracle_solver(prob, res_active, chi2_init, depthpos_init, **kw):
+        return oracle.ba_solve(prob, oracle.ba_default_options(**kw), res_active, chi2_init, depthpos_init)
+
+    for seed, stereo in ((3, True), (4, False)):
+        pb = synth.make_ba_problem(n_kf=12, n_lm=400, obs_per_lm=6, stereo=stereo, outlier_frac=0.04, seed=seed,
+                                    pose_noise=(0.15, np.deg2rad(3.0)), invdepth_noise=0.3)
+        for name in ("looseBA", "fullBA"):
+            g = getattr(ov2slam_amd.Optimizer(gpu_ctx), name)(pb)
+            r = getattr(ov2slam_amd.Optimizer(None, solver=oracle_solver), name)(pb)
+            assert g["pass1"]["iterations"] == r["pass1"]["iterations"], (name, seed)
+            assert g["pass1"]["termination"] == r["pass1"]["termination"]
+            assert np.array_equal(g["bad_obs"], r["bad_obs"]), (name, seed)
+            assert g.get("l2_done", False) == r.get("l2_done", False)
+            if g.get("l2_done"):
+                assert g["pass2"]["iterations"] == r["pass2"]["iterations"]
+            scale = max(1.0, np.abs(r["poses"]).max())
+            assert np.abs(g["poses"] - r["poses"]).max() <= 1e-6 * scale, (name, seed, np.abs(g["poses"] - r["poses"]).max())
+            assert np.abs(g["invdepth"] - r["invdepth"]).max() <= 1e-6 * max(1.0, np.abs(r["invdepth"]).max())
+        assert g["pass1"]["iterations"] > 5, g["pass1"]["iterations"]       # fullBA (last in the loop): the long run is exercised
