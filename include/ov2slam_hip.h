@@ -245,6 +245,44 @@ int  ov2_ba_solve_resident(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *
 void ov2_ba_destroy(ov2_ba_dev *dev);
 
 /* ------------------------------------------------------------------ */
+/* Optimizer::structureOnlyBA                                           */
+/* ------------------------------------------------------------------ */
+/* One ceres::Solve of Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781, called at
+ * src/loop_closer.cpp:353 on the map points merged by a loop closure): 3-D world points
+ * (PointXYZParametersBlock) are the only variables; every keyframe pose, both calibrations and the stereo
+ * extrinsic are constant blocks.  Residual blocks:
+ *   OV2_XYZ_LEFT   DirectLeftSE3::ReprojectionErrorKSE3XYZ          (left camera,  :2692-2702, :2719-2727)
+ *   OV2_XYZ_RIGHT  DirectLeftSE3::ReprojectionErrorRightCamKSE3XYZ  (right camera through T_rl, :2704-2715)
+ * Options: the reference uses DENSE_SCHUR / LM, max_num_iterations 10, function_tolerance 1e-3, Huber
+ * sqrt(robust_mono_th) (:2599-2601, :2742-2758) -- fill an ov2_ba_options accordingly; its 10-20 ms
+ * max_solver_time_in_seconds has no counterpart.  The function never changes poses.                    */
+enum { OV2_XYZ_LEFT = 0, OV2_XYZ_RIGHT = 1 };
+typedef struct {
+    int n_kf;
+    const double *poses;         /* 7*n_kf  [tx ty tz qx qy qz qw] of Twc (constant)          */
+    int n_pts;
+    const double *xyz;           /* 3*n_pts world points, initial values                      */
+    int n_res;
+    const uint8_t *res_type;     /* n_res   OV2_XYZ_*                                         */
+    const int *res_kf;           /* n_res   observing keyframe                                */
+    const int *res_pt;           /* n_res   observed point                                    */
+    const double *res_uv;        /* 2*n_res undistorted pixel (unpx_ / runpx_)                */
+    const double *res_sigma;     /* n_res   2^scale                                           */
+    const uint8_t *res_active;   /* n_res or NULL                                             */
+    double calib_l[4], calib_r[4], T_rl[7];
+} ov2_sba_problem;
+typedef struct {
+    double *xyz_out;             /* 3*n_pts                                                   */
+    double *chi2_last_eval;      /* n_res, in/out like ov2_ba_result (may be NULL)            */
+    uint8_t *depthpos_last_eval; /* n_res, in/out (may be NULL)                               */
+    int iterations, num_successful_steps;
+    double initial_cost, final_cost;
+    int termination;             /* OV2_TERM_*                                                */
+    double solve_ms;
+} ov2_sba_result;
+int ov2_structure_ba(ov2_ctx *ctx, const ov2_sba_problem *p, const ov2_ba_options *o, ov2_sba_result *r);
+
+/* ------------------------------------------------------------------ */
 /* Per-keypoint undistortion + bearing vector                           */
 /* ------------------------------------------------------------------ */
 /* Frame::computeKeypoint (src/frame.cpp:246-254) for n keypoints in one launch:

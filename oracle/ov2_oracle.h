@@ -260,6 +260,39 @@ float orc_sampson_distance(const double F[9], float lx, float ly, float rx, floa
 void orc_stereo_epipolar_check(int rect, const double Frl[9], int model, const double K[4], const double *D, int nD,
                                const float *lunpx, float *rkps, int n, float *runpx, float *epi_err, uint8_t *ok);
 
+/* ------------------------------------------------------------------ */
+/* Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781): 3-D points, */
+/* every pose constant -- see struct_ba.c                               */
+/* ------------------------------------------------------------------ */
+enum {
+    ORC_XYZ_LEFT  = 0,   /* DirectLeftSE3::ReprojectionErrorKSE3XYZ          */
+    ORC_XYZ_RIGHT = 1,   /* DirectLeftSE3::ReprojectionErrorRightCamKSE3XYZ  */
+};
+typedef struct {
+    int n_kf;
+    const double *poses;    /* 7*n_kf  [t, q(x,y,z,w)] of Twc, all constant   */
+    int n_pts;
+    const double *xyz;      /* 3*n_pts world points (initial values)          */
+    int n_res;
+    const uint8_t *res_type;/* ORC_XYZ_*                                      */
+    const int *res_kf, *res_pt;
+    const double *res_uv;   /* 2*n_res */
+    const double *res_sigma;
+    const uint8_t *res_active; /* or NULL */
+    double calib_l[4], calib_r[4], T_rl[7];
+} orc_sba_problem;
+typedef struct {
+    double *xyz_out;          /* 3*n_pts */
+    double *chi2_last_eval;   /* n_res   */
+    uint8_t *depthpos_last_eval;
+    int iterations, num_successful_steps;
+    double initial_cost, final_cost;
+    int termination;
+} orc_sba_result;
+int orc_xyz_residual(int type, const double calib_l[4], const double calib_r[4], const double T_rl[7], const double pose[7],
+                     const double X[3], const double uv[2], double sigma, double r[2], double *J, double *chi2);
+int orc_structure_ba(const orc_sba_problem *p, const orc_ba_options *o, orc_sba_result *r);
+
 #ifdef __cplusplus
 }
 #endif

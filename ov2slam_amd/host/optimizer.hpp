@@ -47,6 +47,22 @@ struct FlatProblem {
     }
 };
 
+// Flat form of the ceres::Problem Optimizer::structureOnlyBA builds (src/optimizer.cpp:2594-2781): constant
+// keyframes, 3-D points (PointXYZParametersBlock), ReprojectionErrorKSE3XYZ / RightCamKSE3XYZ blocks.
+struct FlatStructureProblem {
+    std::vector<double> poses, xyz;     // 7 per keyframe, 3 per point
+    std::vector<uint8_t> res_type;      // OV2_XYZ_*
+    std::vector<int> res_kf, res_pt;
+    std::vector<double> res_uv, res_sigma;
+    double calib_l[4] = {0, 0, 0, 0}, calib_r[4] = {0, 0, 0, 0}, T_rl[7] = {0, 0, 0, 0, 0, 0, 1};
+
+    int addKeyframe(const double pose[7]) { poses.insert(poses.end(), pose, pose + 7); return (int)poses.size() / 7 - 1; }          // :2660-2670
+    int addPoint(const double p[3]) { xyz.insert(xyz.end(), p, p + 3); return (int)xyz.size() / 3 - 1; }                              // :2641-2644
+    void addResidual(int type, int kf, int pt, double u, double v, double sigma) {                                                      // :2675-2727
+        res_type.push_back((uint8_t)type); res_kf.push_back(kf); res_pt.push_back(pt); res_uv.push_back(u); res_uv.push_back(v); res_sigma.push_back(sigma);
+    }
+};
+
 struct LocalBAResult {
     bool ok = false, l2_done = false;
     std::vector<double> poses, invdepth, chi2;
@@ -96,6 +112,25 @@ public:
             }
         }
         return R;
+    }
+
+    // Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781): Huber(sqrt(robust_mono_th)), 10 iterations, function_tolerance
+    // 1e-3 (:2742-2758).  On success `xyz_out` holds what the reference writes back through updateMapPoint (:2768-2779).
+    bool solveStructureOnlyBA(Context &ctx, const FlatStructureProblem &sp, std::vector<double> &xyz_out) const
+    {
+        ov2_sba_problem p{};
+        p.n_kf = (int)sp.poses.size() / 7; p.poses = sp.poses.data();
+        p.n_pts = (int)sp.xyz.size() / 3; p.xyz = sp.xyz.data();
+        p.n_res = (int)sp.res_type.size(); p.res_type = sp.res_type.data(); p.res_kf = sp.res_kf.data(); p.res_pt = sp.res_pt.data();
+        p.res_uv = sp.res_uv.data(); p.res_sigma = sp.res_sigma.data(); p.res_active = nullptr;
+        for (int i = 0; i < 4; i++) { p.calib_l[i] = sp.calib_l[i]; p.calib_r[i] = sp.calib_r[i]; }
+        for (int i = 0; i < 7; i++) p.T_rl[i] = sp.T_rl[i];
+        ov2_ba_options opt; ov2_ba_default_options(&opt);
+        opt.max_iter = 10; opt.function_tolerance = 1e-3; opt.huber_delta = std::sqrt(robust_mono_th_);
+        xyz_out.assign(sp.xyz.size(), 0.0);
+        ov2_sba_result res{};
+        res.xyz_out = xyz_out.data();
+        return ov2_structure_ba(ctx.get(), &p, &opt, &res) == OV2_OK;
     }
 
     // Optimizer::looseBA (src/optimizer.cpp:900-1672): same residual blocks, ONE solve (5 it, function_tolerance

@@ -79,6 +79,39 @@ def solve(ctx, prob, opts=None, res_active=None, chi2_init=None, depthpos_init=N
                 termination=R.termination, solve_ms=R.solve_ms)
 
 
+def structure_only_ba(ctx, prob, opts=None, res_active=None):
+    """One ceres::Solve of Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781) through ov2_structure_ba.
+    prob: dict in the layout of ov2slam_amd.synth.make_structure_problem.  Default options = the reference's
+    (10 iterations, function_tolerance 1e-3, Huber sqrt(5.9915))."""
+    lib = ctx.lib
+    opts = opts or default_options(lib, max_iter=10, function_tolerance=1e-3)
+    keep = []
+
+    def arr(name, dt, ct):
+        a = np.ascontiguousarray(prob[name], dt); keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+
+    P = L.SBAProblem()
+    P.n_kf, P.n_pts, P.n_res = int(prob["n_kf"]), int(prob["n_pts"]), int(prob["n_res"])
+    P.poses = arr("poses", np.float64, C.c_double); P.xyz = arr("xyz", np.float64, C.c_double)
+    P.res_type = arr("res_type", np.uint8, C.c_uint8); P.res_kf = arr("res_kf", np.int32, C.c_int); P.res_pt = arr("res_pt", np.int32, C.c_int)
+    P.res_uv = arr("res_uv", np.float64, C.c_double); P.res_sigma = arr("res_sigma", np.float64, C.c_double)
+    if res_active is not None:
+        ra = np.ascontiguousarray(res_active, np.uint8); keep.append(ra)
+        P.res_active = ra.ctypes.data_as(C.POINTER(C.c_uint8))
+    for i in range(4):
+        P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
+    for i in range(7):
+        P.T_rl[i] = float(prob["T_rl"][i])
+    xyz = np.zeros((max(1, P.n_pts), 3)); chi2 = np.full(max(1, P.n_res), np.nan); dpos = np.zeros(max(1, P.n_res), np.uint8)
+    R = L.SBAResult()
+    R.xyz_out = _dp(xyz); R.chi2_last_eval = _dp(chi2); R.depthpos_last_eval = _u8p(dpos)
+    L.check(lib.ov2_structure_ba(ctx.h, C.byref(P), C.byref(opts), C.byref(R)))
+    return dict(xyz=xyz[:P.n_pts], chi2=chi2[:P.n_res], depthpos=dpos[:P.n_res], iterations=R.iterations,
+                num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost, final_cost=R.final_cost,
+                termination=R.termination, solve_ms=R.solve_ms)
+
+
 class ResidentProblem:
     """ov2_ba_create / ov2_ba_solve_resident: the problem stays in HBM between solves."""
 
@@ -174,6 +207,12 @@ class Optimizer:
         out.update(poses=poses, invdepth=lam, chi2=chi2, depthpos=dpos, bad_obs=bad)
         return out
 
+
+    def structureOnlyBA(self, prob):
+        """Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781): Huber(sqrt(robust_mono_th)), 10 iterations,
+        function_tolerance 1e-3; the map points take the optimised positions (:2768-2779), no outlier handling."""
+        return structure_only_ba(self.ctx, prob, default_options(self.ctx.lib, max_iter=10, function_tolerance=1e-3,
+                                                                 huber_delta=math.sqrt(self.robust_mono_th)))
 
     def looseBA(self, prob, buse_robust_cost=True):
         """Optimizer::looseBA (src/optimizer.cpp:900-1672) on a flat problem -- the loop-closure BA over the KFs

@@ -216,3 +216,42 @@ def make_pnp_problem(n_pts=300, seed=7, px_noise=1.0, outlier_frac=0.05, pose_no
                 res_uv=np.ascontiguousarray(uv), res_sigma=np.ones(n_pts), res_xyz=np.ascontiguousarray(X),
                 calib_l=K.copy(), calib_r=K.copy(), T_rl=np.array([0, 0, 0, 0, 0, 0, 1.0]),
                 poses_gt=pose_gt[None].copy(), is_outlier=out)
+
+
+def make_structure_problem(n_kf=12, n_pts=500, obs_per_pt=5, stereo=True, seed=7, px_noise=1.0, outlier_frac=0.02, xyz_noise=0.15):
+    """Synthetic Optimizer::structureOnlyBA problem (src/optimizer.cpp:2594-2781): constant keyframes on an arc,
+    3-D points seen by `obs_per_pt` consecutive keyframes (left, plus right when stereo), perturbed initial
+    points.  Flat arrays in the layout of ov2_sba_problem."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.654; cx, cy = 367.215, 248.375
+    K = np.array([fx, fy, cx, cy])
+    obs_per_pt = min(obs_per_pt, n_kf)
+    th = np.deg2rad(3.0) * np.arange(n_kf)
+    poses = np.zeros((n_kf, 7)); Rs = []
+    for k in range(n_kf):
+        c, s = np.cos(th[k]), np.sin(th[k])
+        R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])           # camera-to-world
+        t = np.array([10 * np.sin(th[k]), 0.05 * k, 10 - 10 * np.cos(th[k])])
+        w = np.sqrt(max(0.0, 1 + np.trace(R))) / 2
+        q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+        poses[k] = np.concatenate([t, q]); Rs.append(R)
+    T_rl = np.array([-0.11, 0, 0, 0, 0, 0, 1.0])
+    xyz_gt = np.zeros((n_pts, 3)); first = rng.integers(0, n_kf - obs_per_pt + 1, n_pts)
+    rt, rk, rp, ruv, rs, is_out = [], [], [], [], [], []
+    for i in range(n_pts):
+        a = first[i] + obs_per_pt // 2
+        pc = np.array([rng.uniform(-2.5, 2.5), rng.uniform(-1.5, 1.5), rng.uniform(4, 12)])
+        xyz_gt[i] = Rs[a] @ pc + poses[a, :3]
+        for k in range(first[i], first[i] + obs_per_pt):
+            c = Rs[k].T @ (xyz_gt[i] - poses[k, :3])
+            for typ in ((0, 1) if stereo else (0,)):
+                cc = c + T_rl[:3] if typ == 1 else c
+                uv = np.array([fx * cc[0] / cc[2] + cx, fy * cc[1] / cc[2] + cy]) + rng.normal(0, px_noise, 2)
+                out = rng.random() < outlier_frac
+                if out:
+                    uv += rng.uniform(-40, 40, 2)
+                rt.append(typ); rk.append(k); rp.append(i); ruv.append(uv); rs.append(2.0 ** rng.integers(0, 2)); is_out.append(out)
+    xyz0 = xyz_gt + rng.normal(0, xyz_noise, xyz_gt.shape)
+    return dict(n_kf=n_kf, n_pts=n_pts, n_res=len(rt), poses=poses, xyz=xyz0, xyz_gt=xyz_gt, res_type=np.array(rt, np.uint8),
+                res_kf=np.array(rk, np.int32), res_pt=np.array(rp, np.int32), res_uv=np.array(ruv), res_sigma=np.array(rs, np.float64),
+                calib_l=K, calib_r=K.copy(), T_rl=T_rl, is_outlier=np.array(is_out))

@@ -153,3 +153,36 @@ def test_looseba_fullba_protocols_match_oracle(gpu_ctx, oracle):
             assert np.abs(g["poses"] - r["poses"]).max() <= 1e-6 * scale, (name, seed, np.abs(g["poses"] - r["poses"]).max())
             assert np.abs(g["invdepth"] - r["invdepth"]).max() <= 1e-6 * max(1.0, np.abs(r["invdepth"]).max())
         assert g["pass1"]["iterations"] > 5, g["pass1"]["iterations"]       # fullBA (last in the loop): the long run is exercised
+
+
+@pytest.mark.parametrize("n_kf,n_pts,obs,stereo,seed", [(6, 30, 3, False, 1), (12, 500, 5, True, 2), (20, 3000, 8, True, 3), (10, 1500, 6, False, 4)])
+def test_structure_only_ba_matches_oracle(gpu_ctx, oracle, n_kf, n_pts, obs, stereo, seed):
+    """Optimizer::structureOnlyBA (3-D points, constant poses) on the device vs the oracle: same LM trajectory."""
+    pb = synth.make_structure_problem(n_kf, n_pts, obs, stereo=stereo, seed=seed)
+    for kw in (dict(max_iter=10, function_tolerance=1e-3, huber_delta=float(np.sqrt(5.9915))),
+               dict(max_iter=30, function_tolerance=1e-9, huber_delta=-1.0)):
+        g = optimizer.structure_only_ba(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+        r = oracle.structure_ba(pb, oracle.ba_default_options(**kw))
+        assert g["iterations"] == r["iterations"] and g["termination"] == r["termination"], (g["iterations"], r["iterations"])
+        assert g["num_successful_steps"] == r["num_successful_steps"]
+        assert abs(g["initial_cost"] - r["initial_cost"]) <= 1e-10 * abs(r["initial_cost"])
+        assert abs(g["final_cost"] - r["final_cost"]) <= 1e-8 * abs(r["final_cost"])
+        assert np.abs(g["xyz"] - r["xyz"]).max() <= 1e-7 * max(1.0, np.abs(r["xyz"]).max())
+        assert np.allclose(g["chi2"], r["chi2"], rtol=1e-6, atol=1e-9) and np.array_equal(g["depthpos"], r["depthpos"])
+    o = ov2slam_amd.Optimizer(gpu_ctx).structureOnlyBA(pb)
+    assert o["final_cost"] < o["initial_cost"]
+
+
+def test_structure_only_ba_edge_cases(gpu_ctx, oracle):
+    pb = synth.make_structure_problem(8, 100, 4, seed=5)
+    act = np.ones(pb["n_res"], np.uint8); act[pb["res_pt"] == 7] = 0; act[::9] = 0
+    g = optimizer.structure_only_ba(gpu_ctx, pb, None, act); r = oracle.structure_ba(pb, None, act)
+    assert g["iterations"] == r["iterations"] and np.abs(g["xyz"] - r["xyz"]).max() < 1e-8
+    assert np.array_equal(g["xyz"][7], pb["xyz"][7]) and np.array_equal(np.isnan(g["chi2"]), np.isnan(r["chi2"]))
+    e = dict(pb); e.update(n_res=0, res_type=np.zeros(0, np.uint8), res_kf=np.zeros(0, np.int32), res_pt=np.zeros(0, np.int32),
+                           res_uv=np.zeros((0, 2)), res_sigma=np.zeros(0))
+    g0 = optimizer.structure_only_ba(gpu_ctx, e)
+    assert g0["iterations"] == 0 and np.array_equal(g0["xyz"], pb["xyz"])
+    bad = dict(pb); bad["res_pt"] = pb["res_pt"].copy(); bad["res_pt"][3] = 10 ** 6
+    with pytest.raises(ov2slam_amd.Ov2Error):
+        optimizer.structure_only_ba(gpu_ctx, bad)
