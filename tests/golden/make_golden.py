@@ -46,6 +46,21 @@ def compute():
     # BA is fp64 with libm calls: digest a rounded view (12 significant digits) to stay libm-version tolerant
     rnd = lambda a: np.array([float("%.10e" % v) for v in np.ravel(a)])
     out["ba_solve"] = dig(rnd(r["poses"]), rnd(r["invdepth"]), np.array([r["iterations"], r["termination"]]))
+    # round-1 additions: undistortion + bearing, stereo SAD scan / epipolar gate, structure-only BA
+    K = (458.654, 457.296, 367.215, 248.375); D = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+    iK = np.linalg.inv(np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1.0]]))
+    u, b = O.compute_keypoints(O.CAM_PINHOLE, K, D, iK, kps)
+    out["compute_keypoints_pinhole"] = dig(u, b)
+    right = np.roll(prev, -6, axis=1)
+    xp, err = O.line_min_sad(P.level(2)[0], O.Pyramid(right, 9, 3).level(2)[0], kps * np.float32(0.25), 7, True)
+    out["line_min_sad"] = dig(xp, err)
+    Frl = np.array([[0, 0, 0], [0, 0, -1e-2], [0, 1e-2, 0]])
+    rk = (kps + np.array([-6.0, 0.7], np.float32)).astype(np.float32)
+    o1 = O.stereo_epipolar_check(False, Frl, O.CAM_PINHOLE, K, D, u, rk)
+    out["epipolar_sampson"] = dig(o1[0], o1[1], o1[2], o1[3].astype(np.uint8))
+    sp = synth.make_structure_problem(8, 80, 4, seed=9)
+    r = O.structure_ba(sp)
+    out["structure_ba"] = dig(rnd(r["xyz"]), np.array([r["iterations"], r["termination"]]))
     return out
 
 
