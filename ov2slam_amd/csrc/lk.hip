@@ -456,8 +456,9 @@ int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int ma
 // the lower latency.  OV2_LK_IMPL=row|lane3 forces one of them (A/B measurements).
 static bool lk_use_row_kernel(long long points)
 {
-    static const int forced = [] { const char *e = getenv("OV2_LK_IMPL"); return !e ? 0 : (!strcmp(e, "row") ? 1 : (!strcmp(e, "lane3") ? 2 : 0)); }();
-    if (forced) return forced == 1;
+    const char *e = getenv("OV2_LK_IMPL");                 // read per call: the parity tests flip it between calls
+    if (e && !strcmp(e, "row")) return true;
+    if (e && !strcmp(e, "lane3")) return false;
     return points < 65536;
 }
 

@@ -195,59 +195,54 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
     int s11 = 0, s12 = 0, s22 = 0;
     {
         const int r0 = 3 * sub;
-        uint32_t E[6][6];                                           // E[m][i] = (p[2i], p[2i+1]) of image row m
-#pragma unroll
-        for (int m = 0; m < 6; m++) {
+        // Streaming order (keeps ~100 VGPRs live instead of ~140): image rows are unpacked from LDS as they are
+        // needed, derivative row d is formed from image rows d, d+1, d+2, and window row j = d-1 is finished as
+        // soon as derivative rows j, j+1 exist.  E[m][i] = (p[2i], p[2i+1]) of image row m;
+        // DX[d][i] = (dx[2i], dx[2i+1]) with column c <-> ipx + c.
+        auto load_row = [&](int m, uint32_t (&e)[6]) {
             const u32x4 w = *(const u32x4 *)(slot + 4 * (r0 + m));
             const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, ish), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, ish), d2 = __builtin_amdgcn_alignbyte(w.w, w.z, ish);
-            E[m][0] = bytes01(d0); E[m][1] = bytes23(d0); E[m][2] = bytes01(d1); E[m][3] = bytes23(d1); E[m][4] = bytes01(d2); E[m][5] = bytes23(d2);
-        }
-        // derivative rows d = 0..3 <-> image rows ipy+r0+d (E rows d, d+1, d+2); DX[d][i] = (dx[2i], dx[2i+1]), column c <-> ipx + c
-        uint32_t DX[4][5], DY[4][5];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
+            e[0] = bytes01(d0); e[1] = bytes23(d0); e[2] = bytes01(d1); e[3] = bytes23(d1); e[4] = bytes01(d2); e[5] = bytes23(d2);
+        };
+        // derivative positions outside the image are 0 (rare: only for windows overlapping the image border)
+        const bool border = ipx < 0 || ipx + WIN >= LI.w || ipy + r0 < 0 || ipy + r0 + 3 >= LI.h;
+        const bool any_border = __builtin_amdgcn_ballot_w64(border) != 0;
+        auto deriv_row = [&](int d, const uint32_t (&ea)[6], const uint32_t (&eb)[6], const uint32_t (&ec)[6], uint32_t (&dx)[5], uint32_t (&dy)[5]) {
             uint32_t T0[6], T1[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                T0[i] = pk_add(pk_mul(pk_add(E[d][i], E[d + 2][i]), 3), pk_mul(E[d + 1][i], 10));
-                T1[i] = pk_sub(E[d + 2][i], E[d][i]);
+                T0[i] = pk_add(pk_mul(pk_add(ea[i], ec[i]), 3), pk_mul(eb[i], 10));
+                T1[i] = pk_sub(ec[i], ea[i]);
             }
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-                DX[d][i] = pk_sub(T0[i + 1], T0[i]);
-                DY[d][i] = pk_add(pk_mul(pk_add(T1[i], T1[i + 1]), 3), pk_mul(odd_pair(T1[i + 1], T1[i]), 10));
+                dx[i] = pk_sub(T0[i + 1], T0[i]);
+                dy[i] = pk_add(pk_mul(pk_add(T1[i], T1[i + 1]), 3), pk_mul(odd_pair(T1[i + 1], T1[i]), 10));
             }
-        }
-        // derivative positions outside the image are 0 (rare: only for windows overlapping the image border)
-        const bool border = ipx < 0 || ipx + WIN >= LI.w || ipy + r0 < 0 || ipy + r0 + 3 >= LI.h;
-        if (__builtin_amdgcn_ballot_w64(border) != 0) {
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
+            if (any_border) {
                 const int Yd = ipy + r0 + d;
                 const bool yin = Yd >= 0 && Yd < LI.h;
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
                     const int X = ipx + 2 * i;
                     const uint32_t mk = ((yin && X >= 0 && X < LI.w) ? 0x0000FFFFu : 0u) | ((yin && X + 1 >= 0 && X + 1 < LI.w) ? 0xFFFF0000u : 0u);
-                    DX[d][i] &= mk; DY[d][i] &= mk;
+                    dx[i] &= mk; dy[i] &= mk;
                 }
             }
-        }
-#pragma unroll
-        for (int j = 0; j < L3_RPL; j++) {
+        };
+        auto window_row = [&](int j, const uint32_t (&et)[6], const uint32_t (&eb)[6], const uint32_t (&dxt)[5], const uint32_t (&dyt)[5],
+                              const uint32_t (&dxb)[5], const uint32_t (&dyb)[5]) {
             int iv[WIN + 1], xv[WIN + 1], yv[WIN + 1];
 #pragma unroll
             for (int x = 0; x < WIN; x++) {
-                // pixel pair (p[x+1], p[x+2]) of image rows j+1 (top) and j+2 (bottom)
-                const int k = x + 1;
-                const uint32_t pt = (k & 1) ? odd_pair(E[j + 1][(k >> 1) + 1], E[j + 1][k >> 1]) : E[j + 1][k >> 1];
-                const uint32_t pb = (k & 1) ? odd_pair(E[j + 2][(k >> 1) + 1], E[j + 2][k >> 1]) : E[j + 2][k >> 1];
+                const int k = x + 1;                                // pixel pair (p[x+1], p[x+2]) of image rows j+1 (top), j+2 (bottom)
+                const uint32_t pt = (k & 1) ? odd_pair(et[(k >> 1) + 1], et[k >> 1]) : et[k >> 1];
+                const uint32_t pb = (k & 1) ? odd_pair(eb[(k >> 1) + 1], eb[k >> 1]) : eb[k >> 1];
                 iv[x] = dot2(pt, W01, dot2(pb, W23, 1 << 8)) >> 9;
-                // derivative pair (d[x], d[x+1]) of derivative rows j (top) and j+1 (bottom)
-                const uint32_t xt = (x & 1) ? odd_pair(DX[j][(x >> 1) + 1], DX[j][x >> 1]) : DX[j][x >> 1];
-                const uint32_t xb = (x & 1) ? odd_pair(DX[j + 1][(x >> 1) + 1], DX[j + 1][x >> 1]) : DX[j + 1][x >> 1];
-                const uint32_t yt = (x & 1) ? odd_pair(DY[j][(x >> 1) + 1], DY[j][x >> 1]) : DY[j][x >> 1];
-                const uint32_t yb = (x & 1) ? odd_pair(DY[j + 1][(x >> 1) + 1], DY[j + 1][x >> 1]) : DY[j + 1][x >> 1];
+                const uint32_t xt = (x & 1) ? odd_pair(dxt[(x >> 1) + 1], dxt[x >> 1]) : dxt[x >> 1];   // (d[x], d[x+1]) of rows j, j+1
+                const uint32_t xb = (x & 1) ? odd_pair(dxb[(x >> 1) + 1], dxb[x >> 1]) : dxb[x >> 1];
+                const uint32_t yt = (x & 1) ? odd_pair(dyt[(x >> 1) + 1], dyt[x >> 1]) : dyt[x >> 1];
+                const uint32_t yb = (x & 1) ? odd_pair(dyb[(x >> 1) + 1], dyb[x >> 1]) : dyb[x >> 1];
                 xv[x] = dot2(xt, W01, dot2(xb, W23, 1 << 13)) >> 14;
                 yv[x] = dot2(yt, W01, dot2(yb, W23, 1 << 13)) >> 14;
             }
@@ -261,7 +256,19 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 s12 = dot2(T.X[j][t], T.Y[j][t], s12);
                 s22 = dot2(T.Y[j][t], T.Y[j][t], s22);
             }
-        }
+        };
+        uint32_t E0[6], E1[6], E2[6], E3[6], DXa[5], DYa[5], DXb[5], DYb[5];
+        load_row(0, E0); load_row(1, E1); load_row(2, E2);
+        deriv_row(0, E0, E1, E2, DXa, DYa);
+        load_row(3, E3);
+        deriv_row(1, E1, E2, E3, DXb, DYb);
+        window_row(0, E1, E2, DXa, DYa, DXb, DYb);                  // window row 0: image rows 1, 2; derivative rows 0, 1
+        load_row(4, E0);                                            // E0 <- image row 4
+        deriv_row(2, E2, E3, E0, DXa, DYa);
+        window_row(1, E2, E3, DXb, DYb, DXa, DYa);                  // image rows 2, 3; derivative rows 1, 2
+        load_row(5, E1);                                            // E1 <- image row 5
+        deriv_row(3, E3, E0, E1, DXb, DYb);
+        window_row(2, E3, E0, DXa, DYa, DXb, DYb);                  // image rows 3, 4; derivative rows 2, 3
     }
     // per-lane partials: 27 * 4080^2 = 4.5e8 < 2^31
     const float A11 = (float)l3_sum3_exact(s11, sub) * FLT_SCALE;

@@ -9,6 +9,14 @@ from ov2slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["row", "lane3"], autouse=True)
+def lk_impl(request, monkeypatch):
+    """Every test of this file runs with both LK kernels (lk.hip: row per lane, lk3.hip: 3 lanes per keypoint);
+    without the override the library picks by launch size and these small cases would only see the first one."""
+    monkeypatch.setenv("OV2_LK_IMPL", request.param)
+    return request.param
+
+
 def _pyr_pair(ctx, oracle, img, win=9, lvl=3):
     h, w = img.shape
     G = ov2slam_amd.Pyramid(ctx, w, h, win, lvl).build(img)
@@ -160,3 +168,57 @@ def test_fbklt_other_window_sizes_bit_exact(gpu_ctx, oracle, euroc_pair, win):
     rout, rst, _ = oracle.fb_klt(Rp, Rc, win, 3, 30., 0.5, d["kps"], far)
     assert np.array_equal(gst, rst)
     _assert_same_float_bits(gout, rout, "far priors win %d" % win)
+
+
+_BATCH_SCRIPT = r"""
+import ctypes as C, os, sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import ov2slam_amd
+from ov2slam_amd import synth, _lib as L
+from oracle import oracle as O
+ctx = ov2slam_amd.Context(0)
+B, NMAX, W, H = 11, 45, 376, 240            # 11 = 8 + 3: exercises the XCD-aware block map and its remainder path
+rng = np.random.default_rng(3)
+prevs, curs, kps, pri = [], [], np.zeros((B, NMAX, 2), np.float32), np.zeros((B, NMAX, 2), np.float32)
+n_item = np.array([45, 0, 1, 19, 20, 21, 40, 45, 7, 33, 45], np.int32)
+for b in range(B):
+    p, c, flow = synth.frame_pair(W, H, seed=50 + b, shift=(1.5 + b * 0.3, -1.0), theta=0.002 * b)
+    prevs.append(p); curs.append(c)
+    k = synth.grid_keypoints(W, H, 35, rng)[:NMAX]
+    kps[b, :len(k)] = k; pri[b, :len(k)] = (flow(k) + rng.normal(0, 1.0, k.shape)).astype(np.float32)
+Pp = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=B).build(np.stack(prevs))
+Pc = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=B).build(np.stack(curs))
+ctx.sync()
+vp = lambda t: C.c_void_p(t.data_ptr())
+for impl in ("row", "lane3"):
+    os.environ["OV2_LK_IMPL"] = impl
+    for lvl in (3, 1):
+        dk = torch.from_numpy(kps).cuda(); dp = torch.from_numpy(pri).cuda(); dn = torch.from_numpy(n_item).cuda()
+        st = torch.full((B, NMAX), 7, dtype=torch.uint8, device="cuda"); stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        L.check(ctx.lib.ov2_fb_klt_d(ctx.h, Pp.h_pyr, Pc.h_pyr, 9, lvl, 30, 0.01, 30.0, 0.5, vp(dk), vp(dp), NMAX, vp(dn), vp(st), vp(stats)))
+        ctx.sync()
+        gp, gs = dp.cpu().numpy(), st.cpu().numpy()
+        tot = 0
+        for b in range(B):
+            n = int(n_item[b])
+            rp, rs, rstats = O.fb_klt(O.Pyramid(prevs[b], 9, 3), O.Pyramid(curs[b], 9, 3), 9, lvl, 30.0, 0.5, kps[b, :n], pri[b, :n])
+            assert np.array_equal(gs[b, :n].astype(bool), rs), (impl, lvl, b)
+            assert np.array_equal(gp[b, :n].view(np.uint32), rp.view(np.uint32)), (impl, lvl, b)
+            assert np.all(gs[b, n:] == 7) and np.array_equal(gp[b, n:], pri[b, n:]), "slots beyond n_per_item must stay untouched"
+            tot += rstats[0]
+        assert int(stats[0].item()) == tot, (impl, lvl)
+print("BATCH_LK_OK")
+"""
+
+
+def test_fbklt_batched_device_path_both_kernels():
+    """ov2_fb_klt_d on a batch of 11 image pairs with ragged per-item keypoint counts, both kernels, in its own
+    process (torch owns the device buffers and has to initialise HIP first)."""
+    import os, subprocess, sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _BATCH_SCRIPT, root], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BATCH_LK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
