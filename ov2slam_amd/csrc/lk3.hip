@@ -99,28 +99,42 @@ __device__ __forceinline__ void l3_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// cooperative fetch (3 lanes) of the 16 x 16-byte search neighbourhood with origin (jx0, jy0) into slot[48..111]
-__device__ __forceinline__ void l3_fetch_J(uint32_t *slot, const uint8_t *jroi, const L3Lv &LJ, int jx0, int jy0, int sub)
+// cooperative fetch (3 lanes) of the 16 x 16-byte search neighbourhood with origin (jx0, jy0) into slot[48..111].
+// One row = one 16-byte + one 4-byte request (a lane's row never coalesces with its neighbours': the number of
+// L1 line look-ups, not bytes, bounds this phase).  Rows are addressed from one 64-bit base with a constant
+// stride; the clamp into the padded buffer is only evaluated when some keypoint of the wavefront needs it.
+template <bool CLAMP>
+__device__ __forceinline__ void l3_fetch_J_rows(uint32_t *slot, const uint8_t *jroi, const L3Lv &LJ, int xa, uint32_t sh, int jy0, int sub)
 {
-    const int xa = jx0 & ~3;
-    const uint32_t sh = (uint32_t)(jx0 - xa);
+    const uint8_t *p0 = jroi + (long long)(jy0 + sub) * LJ.img_pitch + xa;
+    const long long step = 3LL * LJ.img_pitch;
+    uint32_t *dst = slot + 48 + 4 * sub;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        const int row = sub + 3 * k;
-        if (row < L3_JROWS) {
-            int y = jy0 + row;
-            y = y < -LJ.pady ? -LJ.pady : (y > LJ.h + LJ.pady - 1 ? LJ.h + LJ.pady - 1 : y);      // rows beyond the buffer are never consumed
-            // one row = one 16-byte + one 4-byte request (a lane's row never coalesces with its neighbours': the
-            // number of L1 line look-ups, not bytes, bounds this phase)
-            const uint8_t *p = jroi + l3_m24(y, LJ.img_pitch) + xa;
+        if (k < 5 || sub == 0) {                                    // rows sub + 3k < 16
+            const uint8_t *p = p0 + k * step;
+            if (CLAMP) {
+                int y = jy0 + sub + 3 * k;
+                y = y < -LJ.pady ? -LJ.pady : (y > LJ.h + LJ.pady - 1 ? LJ.h + LJ.pady - 1 : y);   // rows beyond the buffer are never consumed
+                p = jroi + (long long)y * LJ.img_pitch + xa;
+            }
             const u32x4 lo = *(const u32x4_a4 *)p;
             const uint32_t hi = *(const uint32_t *)(p + 16);
             u32x4 o;
             o.x = __builtin_amdgcn_alignbyte(lo.y, lo.x, sh); o.y = __builtin_amdgcn_alignbyte(lo.z, lo.y, sh);
             o.z = __builtin_amdgcn_alignbyte(lo.w, lo.z, sh); o.w = __builtin_amdgcn_alignbyte(hi, lo.w, sh);
-            *(u32x4 *)(slot + 48 + 4 * row) = o;
+            *(u32x4 *)(dst + 12 * k) = o;
         }
     }
+}
+
+__device__ __forceinline__ void l3_fetch_J(uint32_t *slot, const uint8_t *jroi, const L3Lv &LJ, int jx0, int jy0, int sub)
+{
+    const int xa = jx0 & ~3;
+    const uint32_t sh = (uint32_t)(jx0 - xa);
+    const bool outside = jy0 < -LJ.pady || jy0 + L3_JROWS - 1 > LJ.h + LJ.pady - 1;
+    if (__builtin_amdgcn_ballot_w64(outside) == 0) l3_fetch_J_rows<false>(slot, jroi, LJ, xa, sh, jy0, sub);
+    else l3_fetch_J_rows<true>(slot, jroi, LJ, xa, sh, jy0, sub);
 }
 
 // the three window rows of a lane as 16-bit pairs: slots 0..3 = pixels (0,1)(2,3)(4,5)(6,7), slot 4 = (8, -)
@@ -170,12 +184,22 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
     const uint8_t *iroi = itemI + LI.img_roi, *jroi = itemJ + LJ.img_roi;
     const int ixa = (ipx - 1) & ~3;
     const uint32_t ish = (uint32_t)((ipx - 1) - ixa);
+    {
+        // 12 rows, one 16-byte request each, rows sub + 3k from one base pointer (clamp only near the image border)
+        const bool outside = ipy - 1 < -LI.pady || ipy - 1 + L3_IROWS - 1 > LI.h + LI.pady - 1;
+        const bool clamp_rows = __builtin_amdgcn_ballot_w64(outside) != 0;
+        const uint8_t *p0 = iroi + (long long)(ipy - 1 + sub) * LI.img_pitch + ixa;
+        const long long step = 3LL * LI.img_pitch;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {                                   // 12 rows, one 16-byte request each
-        const int row = sub + 3 * k;
-        int y = ipy - 1 + row;
-        y = y < -LI.pady ? -LI.pady : (y > LI.h + LI.pady - 1 ? LI.h + LI.pady - 1 : y);         // only feeds derivatives of out-of-image rows (= 0)
-        *(u32x4 *)(slot + 4 * row) = *(const u32x4_a4 *)(iroi + l3_m24(y, LI.img_pitch) + ixa);
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *p = p0 + k * step;
+            if (clamp_rows) {
+                int y = ipy - 1 + sub + 3 * k;
+                y = y < -LI.pady ? -LI.pady : (y > LI.h + LI.pady - 1 ? LI.h + LI.pady - 1 : y);     // only feeds derivatives of out-of-image rows (= 0)
+                p = iroi + (long long)y * LI.img_pitch + ixa;
+            }
+            *(u32x4 *)(slot + 4 * sub + 12 * k) = *(const u32x4_a4 *)p;
+        }
     }
     int jx0, jy0;
     {
@@ -283,67 +307,75 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
     }
     D = 1.f / D;
     nextx -= halfWin; nexty -= halfWin;
+    // Gauss-Newton loop in single-exit form: `active` per keypoint, one wave-uniform back edge (the four early
+    // exits of the reference loop -- out of bounds, eps, oscillation, max count -- only clear `active`)
     float pdx = 0.f, pdy = 0.f;
-    for (int it = 0; it < prm.max_iter; it++) {
-        const int inx = l3_floor(nextx), iny = l3_floor(nexty);
-        if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
-            if (level == 0) st.status = 0;
-            break;
-        }
-        st.iters++;
-        a = nextx - (float)inx; b = nexty - (float)iny;
-        iw00 = l3_round((1.f - a) * (1.f - b) * W14);
-        iw01 = l3_round(a * (1.f - b) * W14);
-        iw10 = l3_round((1.f - a) * b * W14);
-        iw11 = (1 << 14) - iw00 - iw01 - iw10;
-        W01 = pack_lo16(iw00, iw01); W23 = pack_lo16(iw10, iw11);
-        int ox = inx - jx0, oy = iny - jy0;
-        if ((unsigned)ox > (unsigned)(2 * L3_NBH_R) || (unsigned)oy > (unsigned)(2 * L3_NBH_R)) {
-            jx0 = inx - L3_NBH_R; jy0 = iny - L3_NBH_R;                // drifted: re-centre the block
-            l3_lds_sync();
-            l3_fetch_J(slot, jroi, LJ, jx0, jy0, sub);
-            l3_lds_sync();
-            ox = L3_NBH_R; oy = L3_NBH_R;
-        }
-        const uint32_t sh = (uint32_t)(ox & 3);
-        // source rows iny + 3 sub + m (m = 0..3), bytes [inx, inx + WIN]
-        const uint32_t *s0 = slot + 48 + 4 * (oy + 3 * sub) + (ox >> 2);
-        uint32_t P[4][9];                                              // P[m][x] = (p[x], p[x+1])
+    int it = 0;
+    bool active = prm.max_iter > 0;
+    while (__builtin_amdgcn_ballot_w64(active) != 0) {
+        if (active) {
+            const int inx = l3_floor(nextx), iny = l3_floor(nexty);
+            const bool oob = inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h;
+            if (oob) {
+                if (level == 0) st.status = 0;
+                active = false;
+            } else {
+                st.iters++;
+                a = nextx - (float)inx; b = nexty - (float)iny;
+                iw00 = l3_round((1.f - a) * (1.f - b) * W14);
+                iw01 = l3_round(a * (1.f - b) * W14);
+                iw10 = l3_round((1.f - a) * b * W14);
+                iw11 = (1 << 14) - iw00 - iw01 - iw10;
+                W01 = pack_lo16(iw00, iw01); W23 = pack_lo16(iw10, iw11);
+                int ox = inx - jx0, oy = iny - jy0;
+                if ((unsigned)ox > (unsigned)(2 * L3_NBH_R) || (unsigned)oy > (unsigned)(2 * L3_NBH_R)) {
+                    jx0 = inx - L3_NBH_R; jy0 = iny - L3_NBH_R;                // drifted: re-centre the block
+                    l3_lds_sync();
+                    l3_fetch_J(slot, jroi, LJ, jx0, jy0, sub);
+                    l3_lds_sync();
+                    ox = L3_NBH_R; oy = L3_NBH_R;
+                }
+                const uint32_t sh = (uint32_t)(ox & 3);
+                // source rows iny + 3 sub + m (m = 0..3), bytes [inx, inx + WIN]
+                const uint32_t *s0 = slot + 48 + 4 * (oy + 3 * sub) + (ox >> 2);
+                uint32_t P[4][9];                                              // P[m][x] = (p[x], p[x+1])
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const uint32_t a0 = s0[4 * m], a1 = s0[4 * m + 1], a2 = s0[4 * m + 2], a3 = s0[4 * m + 3];
-            const uint32_t d0 = __builtin_amdgcn_alignbyte(a1, a0, sh), d1 = __builtin_amdgcn_alignbyte(a2, a1, sh), d2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
-            P[m][0] = bytes01(d0); P[m][2] = bytes23(d0); P[m][4] = bytes01(d1); P[m][6] = bytes23(d1); P[m][8] = bytes01(d2);
-            P[m][1] = odd_pair(P[m][2], P[m][0]); P[m][3] = odd_pair(P[m][4], P[m][2]);
-            P[m][5] = odd_pair(P[m][6], P[m][4]); P[m][7] = odd_pair(P[m][8], P[m][6]);
-        }
-        int sb1 = 0, sb2 = 0;
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t a0 = s0[4 * m], a1 = s0[4 * m + 1], a2 = s0[4 * m + 2], a3 = s0[4 * m + 3];
+                    const uint32_t d0 = __builtin_amdgcn_alignbyte(a1, a0, sh), d1 = __builtin_amdgcn_alignbyte(a2, a1, sh), d2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
+                    P[m][0] = bytes01(d0); P[m][2] = bytes23(d0); P[m][4] = bytes01(d1); P[m][6] = bytes23(d1); P[m][8] = bytes01(d2);
+                    P[m][1] = odd_pair(P[m][2], P[m][0]); P[m][3] = odd_pair(P[m][4], P[m][2]);
+                    P[m][5] = odd_pair(P[m][6], P[m][4]); P[m][7] = odd_pair(P[m][8], P[m][6]);
+                }
+                int sb1 = 0, sb2 = 0;
 #pragma unroll
-        for (int j = 0; j < L3_RPL; j++) {
-            int v[WIN + 1];
+                for (int j = 0; j < L3_RPL; j++) {
+                    int v[WIN + 1];
 #pragma unroll
-            for (int x = 0; x < WIN; x++) v[x] = dot2(P[j][x], W01, dot2(P[j + 1][x], W23, 1 << 8)) >> 9;
-            v[WIN] = 0;
+                    for (int x = 0; x < WIN; x++) v[x] = dot2(P[j][x], W01, dot2(P[j + 1][x], W23, 1 << 8)) >> 9;
+                    v[WIN] = 0;
 #pragma unroll
-            for (int t = 0; t < 5; t++) {
-                const uint32_t diff = pk_sub(pack_lo16(v[2 * t], v[2 * t + 1]), T.I[j][t]);
-                sb1 = dot2(diff, T.X[j][t], sb1);
-                sb2 = dot2(diff, T.Y[j][t], sb2);
+                    for (int t = 0; t < 5; t++) {
+                        const uint32_t diff = pk_sub(pack_lo16(v[2 * t], v[2 * t + 1]), T.I[j][t]);
+                        sb1 = dot2(diff, T.X[j][t], sb1);
+                        sb2 = dot2(diff, T.Y[j][t], sb2);
+                    }
+                }
+                // |diff * dI| <= 8160*4080 -> per-lane partial < 27 * 3.33e7 = 9e8 < 2^31
+                const float b1 = (float)l3_sum3_exact(sb1, sub) * FLT_SCALE;
+                const float b2 = (float)l3_sum3_exact(sb2, sub) * FLT_SCALE;
+                const float dx = (A12 * b2 - A22 * b1) * D;
+                const float dy = (A12 * b1 - A11 * b2) * D;
+                nextx += dx; nexty += dy;
+                const bool conv_eps = (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
+                const bool conv_osc = !conv_eps && it > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01;
+                st.nx = nextx + halfWin - (conv_osc ? dx * 0.5f : 0.f);
+                st.ny = nexty + halfWin - (conv_osc ? dy * 0.5f : 0.f);
+                pdx = dx; pdy = dy;
+                it++;
+                active = !conv_eps && !conv_osc && it < prm.max_iter;
             }
         }
-        // |diff * dI| <= 8160*4080 -> per-lane partial < 27 * 3.33e7 = 9e8 < 2^31
-        const float b1 = (float)l3_sum3_exact(sb1, sub) * FLT_SCALE;
-        const float b2 = (float)l3_sum3_exact(sb2, sub) * FLT_SCALE;
-        const float dx = (A12 * b2 - A22 * b1) * D;
-        const float dy = (A12 * b1 - A11 * b2) * D;
-        nextx += dx; nexty += dy;
-        st.nx = nextx + halfWin; st.ny = nexty + halfWin;
-        if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
-        if (it > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
-            st.nx -= dx * 0.5f; st.ny -= dy * 0.5f;
-            break;
-        }
-        pdx = dx; pdy = dy;
     }
 }
 
