@@ -789,42 +789,57 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             if (j < nb) S[(long long)(k0 + nb + t) * ld + k0 + j] = P[t * CH_LDP + j];
         }
         CH_TICK(2);
-        // (d) trailing update  A22 -= P P^T  (lower triangle), 32x32 thread tiles, loads batched 4 tiles deep
+        // (d) trailing update  A22 -= P P^T  (lower triangle) on the fp64 matrix cores: one wavefront per 16x16 tile,
+        //     8 x v_mfma_f64_16x16x4_f64 over the 32 panel columns.  Operand layout (cdna_hip_programming.md, f64 MFMA):
+        //     A: lane holds A[lane & 15][lane >> 4], B: lane holds B[lane >> 4][lane & 15] -- both are rows of the LDS
+        //     panel --, C/D: col = lane & 15, row = (lane >> 4) + 4 * reg.  S stays in HBM/L2; a tile is read, updated
+        //     and written once per panel step.
         {
-            const int ty = tid >> 5, tx = tid & 31, rpt = nt >> 5;       // rpt rows of 32 columns per pass
-            const int nrb = (m + rpt - 1) / rpt;
-            for (int rb = 0; rb < nrb; rb++) {
-                const int i = rb * rpt + ty;
-                const int bi = i >> 5;                                   // last column tile that intersects the lower triangle
-                double pi[CH_NB];
-                if (i < m) {
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            const int mb = (m + 15) >> 4, nwv = nt >> 6;
+            const int lr = lane & 15, lk = lane >> 4;
+            // a wavefront takes tiles wave, wave + nwv, ... of the row-major lower-triangle enumeration, two at a time:
+            // the old S values of both tiles are requested first, then the two independent MFMA chains interleave
+            const int ntile = mb * (mb + 1) / 2;
+            auto tile_of = [&](int t, int &bi, int &bj) {            // t -> (bi, bj), bj <= bi
+                bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                while (bi * (bi + 1) / 2 > t) bi--;
+                while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
+                bj = t - bi * (bi + 1) / 2;
+            };
+            for (int t0 = wave; t0 < ntile; t0 += 2 * nwv) {
+                const int t1 = t0 + nwv;
+                const bool has1 = t1 < ntile;
+                int bi0, bj0, bi1 = 0, bj1 = 0;
+                tile_of(t0, bi0, bj0);
+                if (has1) tile_of(t1, bi1, bj1);
+                double old0[4], old1[4];
+                double *dst0[4], *dst1[4];
+                bool ok0[4], ok1[4];
 #pragma unroll
-                    for (int k = 0; k < CH_NB; k++) pi[k] = P[i * CH_LDP + k];
+                for (int r = 0; r < 4; r++) {
+                    const int i0 = bi0 * 16 + lk + 4 * r, j0 = bj0 * 16 + lr;
+                    ok0[r] = i0 < m && j0 <= i0;
+                    dst0[r] = S + (long long)(k0 + nb + i0) * ld + k0 + nb + j0;
+                    old0[r] = ok0[r] ? *dst0[r] : 0.0;
+                    const int i1 = bi1 * 16 + lk + 4 * r, j1 = bj1 * 16 + lr;
+                    ok1[r] = has1 && i1 < m && j1 <= i1;
+                    dst1[r] = S + (long long)(k0 + nb + i1) * ld + k0 + nb + j1;
+                    old1[r] = ok1[r] ? *dst1[r] : 0.0;
                 }
-                const int bimax = min((rb * rpt + rpt - 1) >> 5, (m - 1) >> 5);   // uniform loop bound for the whole pass
-                // software pipeline: the S values of the next 4 tiles are in flight while the current 4 are computed
-                double sv[4], svn[4];
-                auto tile_ok = [&](int bj) { const int j = bj * 32 + tx; return bj <= bi && i < m && j <= i; };
+                const int ra0 = bi0 * 16 + lr, rb0 = bj0 * 16 + lr, ra1 = bi1 * 16 + lr, rb1 = bj1 * 16 + lr;
+                d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
 #pragma unroll
-                for (int q = 0; q < 4; q++) sv[q] = tile_ok(q) ? S[(long long)(k0 + nb + i) * ld + k0 + nb + q * 32 + tx] : 0.0;
-                for (int bj0 = 0; bj0 <= bimax; bj0 += 4) {
+                for (int kk = 0; kk < CH_NB / 4; kk++) {
+                    const double a0 = ra0 < m ? P[ra0 * CH_LDP + 4 * kk + lk] : 0.0, b0 = rb0 < m ? P[rb0 * CH_LDP + 4 * kk + lk] : 0.0;
+                    const double a1 = (has1 && ra1 < m) ? P[ra1 * CH_LDP + 4 * kk + lk] : 0.0, b1 = (has1 && rb1 < m) ? P[rb1 * CH_LDP + 4 * kk + lk] : 0.0;
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+                }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int bj = bj0 + 4 + q;
-                        svn[q] = (bj <= bimax && tile_ok(bj)) ? S[(long long)(k0 + nb + i) * ld + k0 + nb + bj * 32 + tx] : 0.0;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int bj = bj0 + q, j = bj * 32 + tx;
-                        if (tile_ok(bj)) {
-                            double t = 0;
-#pragma unroll
-                            for (int k = 0; k < CH_NB; k++) t += pi[k] * P[j * CH_LDP + k];
-                            S[(long long)(k0 + nb + i) * ld + k0 + nb + j] = sv[q] - t;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) sv[q] = svn[q];
+                for (int r = 0; r < 4; r++) {
+                    if (ok0[r]) *dst0[r] = old0[r] - c0[r];
+                    if (ok1[r]) *dst1[r] = old1[r] - c1[r];
                 }
             }
         }
