@@ -298,9 +298,8 @@ def main():
                 det = fx.detectSingleScale(views[0], CELL, np.zeros((0, 2), np.float32), roi)
             det_ms = (time.perf_counter() - t1) / 20 * 1e3
             t1 = time.perf_counter()
-            cl = ov2slam_amd.CLAHE(ctx1, CLAHE_CLIP, CLAHE_TILES)
             for _ in range(50):
-                P1.build(cl.apply(views[1]))
+                P1.build_clahe(views[1], CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1])            # preprocessImage
                 trk.fbKltTracking(P0, P1, WIN, 1, 30., 0.5, kps[0, 0][:N_PASS_A], pri[0, 0][:N_PASS_A])
                 trk.fbKltTracking(P0, P1, WIN, LEVELS, 30., 0.5, kps[0, 0][N_PASS_A:], pri[0, 0][N_PASS_A:])
             trk_ms = (time.perf_counter() - t1) / 50 * 1e3

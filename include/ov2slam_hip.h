@@ -95,6 +95,9 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
  * available as level 0 of the pyramid.                                                            */
 int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
                           double clip_limit, int tiles_x, int tiles_y);
+/* same from a host image (batch-1 pyramid): one H2D of the raw frame, asynchronous on ctx's stream -- the
+ * single-sequence form of VisualFrontEnd::preprocessImage (the host buffer must stay valid until the next sync) */
+int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, double clip_limit, int tiles_x, int tiles_y);
 
 /* ---- Lucas-Kanade --------------------------------------------------
  * ov2_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts,

@@ -359,6 +359,25 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
     return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
 }
 
+// host-image form of ov2_pyr_build_clahe_d (batch-1 pyramids): one H2D of the raw frame, nothing comes back
+int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, double clip_limit, int tiles_x, int tiles_y)
+{
+    OV2_REQUIRE(ctx && p && img_h, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(p->d.batch == 1, OV2_EINVAL, "host-buffer entry point takes batch=1 pyramids");
+    OV2_REQUIRE(stride >= p->w && tiles_x > 0 && tiles_y > 0 && tiles_x <= p->w && tiles_y <= p->h, OV2_EINVAL, "bad geometry");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t img = ((size_t)p->w * p->h + 255) & ~(size_t)255, lut_bytes = (size_t)tiles_x * tiles_y * 256;
+    int rc = ctx->reserve_device(img + lut_bytes);
+    if (rc != OV2_OK) return rc;
+    uint8_t *ds = (uint8_t *)ctx->d_scratch;
+    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, (size_t)p->w, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
+    const PyrLevelDesc &L0 = p->d.lv[0];
+    rc = clahe_launch(ctx, ds, p->w, p->h, p->w, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
+                      (size_t)p->d.item_stride, ds + img, p->d.win);
+    if (rc != OV2_OK) return rc;
+    return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+}
+
 int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
                 uint8_t *dst_h, int dst_stride)
 {

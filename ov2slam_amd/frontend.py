@@ -90,6 +90,14 @@ class Pyramid:
         L.check(self.lib.ov2_pyr_build_d(self.ctx.h, self.h_pyr, C.c_void_p(dev_ptr), stride, batch_stride))
         return self
 
+    def build_clahe(self, img, clip_limit, tiles_x, tiles_y):
+        """preprocessImage from a host image (batch 1): CLAHE written straight into level 0 + coarser levels."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        assert img.shape == (self.h, self.w) and self.batch == 1
+        self._keep = img
+        L.check(self.lib.ov2_pyr_build_clahe_h(self.ctx.h, self.h_pyr, _ptr(img), self.w, float(clip_limit), int(tiles_x), int(tiles_y)))
+        return self
+
     def build_clahe_from_device(self, dev_ptr, clip_limit, tiles_x, tiles_y, stride=None, batch_stride=None):
         """preprocessImage: CLAHE written straight into level 0, then the coarser levels (one call)."""
         stride = stride or self.w

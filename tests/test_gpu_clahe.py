@@ -64,3 +64,14 @@ def test_clahe_batched_device_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _DEVICE_PATH_SCRIPT, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DEVICE_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_preprocess_from_host_image(gpu_ctx, oracle):
+    """ov2_pyr_build_clahe_h == CLAHE (oracle) followed by the pyramid (oracle), borders included."""
+    for (w, h), tiles in (((752, 480), (15, 9)), ((1241, 376), (24, 7)), ((103, 57), (3, 2))):
+        img, _, _ = synth.frame_pair(w, h, seed=w + h)
+        P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(img, 3.0, tiles[0], tiles[1])
+        ref = oracle.Pyramid(oracle.clahe(img, 3.0, tiles[0], tiles[1]), 9, 3)
+        assert P.levels == ref.levels
+        for lvl in range(P.levels):
+            assert np.array_equal(P.download(lvl, padded=True)[0], ref.level(lvl, padded=True)[0]), (w, h, lvl)

@@ -16,5 +16,6 @@ def t(f, n=100):
 eq = cl.apply(views[1])
 print("clahe_h       %.3f ms" % t(lambda: cl.apply(views[1])))
 print("pyr build_h   %.3f ms" % t(lambda: (P1.build(eq), ctx1.sync())))
+print("preprocess (clahe+pyr fused, host image) %.3f ms" % t(lambda: (P1.build_clahe(views[1], bench.CLAHE_CLIP, bench.CLAHE_TILES[0], bench.CLAHE_TILES[1]), ctx1.sync())))
 print("fbklt A       %.3f ms" % t(lambda: trk.fbKltTracking(P0, P1, WIN, 1, 30., 0.5, kps[0,0][:NA], pri[0,0][:NA])))
 print("fbklt B       %.3f ms" % t(lambda: trk.fbKltTracking(P0, P1, WIN, LEVELS, 30., 0.5, kps[0,0][NA:], pri[0,0][NA:])))
