@@ -198,6 +198,7 @@ struct SelectParams {
 struct SelectOut {
     int n;               // points written to out_xy
     int nboccup, nbempty, nbkps;
+    unsigned long long dbg[4];   // wall_clock64 ticks (100 MHz): init, prologue, sweep, compaction
 };
 
 __device__ __forceinline__ void mask_clear_span(unsigned *mask, int wpr, int y, int xa, int xb)
@@ -245,6 +246,8 @@ __device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
     }
 }
 
+#define SEL_PREF 10                   // response values per lane and chunk (loads of a chunk are in flight together)
+
 __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
                                                       const float *__restrict__ hmaps,
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
 
+    unsigned long long tk0 = wall_clock64();
     for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
     for (int i = tid; i < ncells; i += nthreads) { prim[i] = -1; sec[i] = -1; }
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
         }
     }
     __syncthreads();
+    const unsigned long long tk1 = wall_clock64();
     // prologue (:296-319 / :451-474): occupancy + exclusion discs of the current keypoints
     for (int i = tid; i < P.ncur; i += nthreads) {
         const float2 p = cur_xy[i];
@@ -292,7 +297,9 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     }
     __syncthreads();
 
+    const unsigned long long tk2 = wall_clock64();
     const int npx = P.cs * P.cs;
+    const int q64 = 64 / P.cs, r64 = 64 - q64 * P.cs;               // (lx, ly) advance of 64 pixels without a division
     const int nsteps = 2 * (P.nhcells - 1) + P.nwcells;
     for (int t = 0; t < nsteps; t++) {
         // cells on this anti-diagonal: (r, c = t - 2r)
@@ -307,21 +314,27 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 // best response among the mask-surviving FAST corners, raster order on ties
                 const uint8_t *m = nms_maps + (long long)cell * npx;
                 float bv = -1.f; int bi = 0x7FFFFFFF;
-                for (int p = lane; p < npx; p += 64) {
-                    const int s = m[p];
-                    if (!s) continue;
-                    const int ly = p / P.cs, lx = p - ly * P.cs;
-                    int keep;
-                    if (P.mask_mode == OV2_MASK_AS_EXECUTED)
-                        keep = ((lx & 3) >= 2) && mask_test(mask, P.mask_words_per_row, x0 + (lx >> 2), y0 + ly);
-                    else
-                        keep = mask_test(mask, P.mask_words_per_row, x0 + lx, y0 + ly);
-                    if (keep && ((float)s > bv)) { bv = (float)s; bi = p; }   // p increases per lane: first max kept
+                int ly = lane / P.cs, lx = lane - ly * P.cs;
+                for (int pb = 0; pb < npx; pb += 64 * SEL_PREF) {
+#pragma unroll
+                    for (int q = 0; q < SEL_PREF; q++) {
+                        const int p = pb + lane + 64 * q;
+                        const float sf = p < npx ? (float)m[p] : 0.f;
+                        if (sf != 0.f) {
+                            int keep;
+                            if (P.mask_mode == OV2_MASK_AS_EXECUTED)
+                                keep = ((lx & 3) >= 2) && mask_test(mask, P.mask_words_per_row, x0 + (lx >> 2), y0 + ly);
+                            else
+                                keep = mask_test(mask, P.mask_words_per_row, x0 + lx, y0 + ly);
+                            if (keep && (sf > bv)) { bv = sf; bi = p; }   // p increases per lane: first max kept
+                        }
+                        lx += r64; ly += q64; { const bool wrap = lx >= P.cs; lx -= wrap ? P.cs : 0; ly += wrap ? 1 : 0; }
+                    }
                 }
                 wave_argmax_f(bv, bi);
                 if (bv >= 20.f) {                                         // :521
-                    const int ly = bi / P.cs, lx = bi - ly * P.cs;
-                    const int px = x0 + lx, py = y0 + ly;
+                    const int my = bi / P.cs, mx = bi - my * P.cs;
+                    const int px = x0 + mx, py = y0 + my;
                     if (lane == 0) prim[cell] = px | (py << 16);
                     mask_draw_circle(mask, P, hw, px, py, lane, 64);      // :527
                 }
@@ -331,10 +344,18 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 for (int pass = 0; pass < 2 && !stop; pass++) {
                     float bv = -FLT_MAX; int bi = 0;                      // minMaxLoc: first maximum, row-major
                     bool any = false;
-                    for (int p = lane; p < npx; p += 64) {
-                        const int ly = p / P.cs, lx = p - ly * P.cs;
-                        const float v = hm[p] * (mask_test(mask, P.mask_words_per_row, x0 + lx, y0 + ly) ? 1.f : 0.f);
-                        if (!any || v > bv) { bv = v; bi = p; any = true; }
+                    int py = lane / P.cs, px = lane - py * P.cs;
+                    for (int pb = 0; pb < npx; pb += 64 * SEL_PREF) {
+#pragma unroll
+                        for (int q = 0; q < SEL_PREF; q++) {
+                            const int p = pb + lane + 64 * q;
+                            if (p < npx) {
+                                const float h = hm[p];
+                                const float v = h * (mask_test(mask, P.mask_words_per_row, x0 + px, y0 + py) ? 1.f : 0.f);
+                                if (!any || v > bv) { bv = v; bi = p; any = true; }
+                            }
+                            px += r64; py += q64; { const bool wrap = px >= P.cs; px -= wrap ? P.cs : 0; py += wrap ? 1 : 0; }
+                        }
                     }
                     if (!any) { bv = -FLT_MAX; bi = 0x7FFFFFFF; }
                     wave_argmax_f(bv, bi);
@@ -355,22 +376,40 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
         __syncthreads();
     }
 
-    // compaction in cell order by one thread (<= a few hundred cells)
-    if (tid == 0) {
-        int n = 0, nboccup = 0, nbempty = 0;
-        for (int i = 0; i < ncells; i++) {
-            const int r = i / P.nwcells, c = i - r * P.nwcells;
-            if (occ[r * (P.nwcells + 1) + c]) nboccup++; else nbempty++;
-            if (prim[i] >= 0) { out_xy[n] = make_float2((float)(prim[i] & 0xFFFF), (float)(prim[i] >> 16)); n++; }
+    const unsigned long long tk3 = wall_clock64();
+    // compaction in cell order by wavefront 0: 64 cells per trip, positions from ballot prefix counts
+    if (wave == 0) {
+        int n = 0, nboccup = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int base = 0; base < ncells; base += 64) {
+            const int i = base + lane;
+            const bool in = i < ncells;
+            const int r = in ? i / P.nwcells : 0, c = in ? i - r * P.nwcells : 0;
+            const bool oc = in && occ[r * (P.nwcells + 1) + c];
+            nboccup += __popcll(__builtin_amdgcn_ballot_w64(oc));
+            const int pv = in ? prim[i] : -1;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pv >= 0);
+            if (pv >= 0) out_xy[n + __popcll(m & lt)] = make_float2((float)(pv & 0xFFFF), (float)(pv >> 16));
+            n += __popcll(m);
         }
-        const int nbprim = n;
-        if (P.mode == 1 && nbprim + nboccup < ncells) {                    // :400-414
+        const int nbprim = n, nbempty = ncells - nboccup;
+        if (P.mode == 1 && nbprim + nboccup < ncells) {                    // :400-414: the first nbsec secondaries in cell order
             const int nbsec = ncells - (nbprim + nboccup);
             int k = 0;
-            for (int i = 0; i < ncells && k < nbsec; i++)
-                if (sec[i] >= 0) { out_xy[n] = make_float2((float)(sec[i] & 0xFFFF), (float)(sec[i] >> 16)); n++; k++; }
+            for (int base = 0; base < ncells && k < nbsec; base += 64) {
+                const int i = base + lane;
+                const int sv = i < ncells ? sec[i] : -1;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(sv >= 0);
+                const int pos = k + __popcll(m & lt);
+                if (sv >= 0 && pos < nbsec) out_xy[nbprim + pos] = make_float2((float)(sv & 0xFFFF), (float)(sv >> 16));
+                k += __popcll(m);
+            }
+            n = nbprim + (k < nbsec ? k : nbsec);
         }
+      if (lane == 0) {
         out->n = n; out->nboccup = nboccup; out->nbempty = nbempty; out->nbkps = nbprim;
+        out->dbg[0] = tk1 - tk0; out->dbg[1] = tk2 - tk1; out->dbg[2] = tk3 - tk2; out->dbg[3] = wall_clock64() - tk3;
+      }
     }
 }
 
@@ -443,45 +482,98 @@ __device__ void d_get_rect_subpix(const uint8_t *__restrict__ src, int src_step,
     }
 }
 
+// one pixel (i, j) of getRectSubPix(u8 -> f32), patch PW x PW around (cx, cy): the same three code paths as
+// d_get_rect_subpix, evaluated per pixel (the fast path's `prev` recurrence only couples neighbouring columns:
+// dst[j] = (j ? float(t[j-1] * s) : (1-a)(b1 p[0] + b2 p'[0])) + t[j],  t[j] = a12 p[j+1] + a22 p'[j+1])
+template <int PW>
+__device__ __forceinline__ float d_rect_subpix_px(const uint8_t *__restrict__ src, int src_step, int sw, int sh, float cx_f, float cy_f, int i, int j)
+{
+    const int pw = PW, ph = PW;
+    const double cxd = (double)cx_f - (pw - 1) * 0.5, cyd = (double)cy_f - (ph - 1) * 0.5;
+    int ipx = (int)floor(cxd), ipy = (int)floor(cyd);
+    if (0 <= ipx && ipx + pw < sw && 0 <= ipy && ipy + ph < sh) {
+        float a = (float)(cxd - ipx), b = (float)(cyd - ipy);
+        a = a > 0.0001f ? a : 0.0001f;
+        const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+        const double s = (1. - (double)a) / (double)a;
+        const uint8_t *p = src + (long long)(ipy + i) * src_step + ipx;
+        const float t = a12 * p[j + 1] + a22 * p[j + 1 + src_step];
+        float prev;
+        if (j == 0) prev = (1 - a) * (b1 * p[0] + b2 * p[src_step]);
+        else { const float tp = a12 * p[j] + a22 * p[j + src_step]; prev = (float)(tp * s); }
+        return prev + t;
+    }
+    const float cx = cx_f - (pw - 1) * 0.5f, cy = cy_f - (ph - 1) * 0.5f;
+    ipx = (int)floorf(cx); ipy = (int)floorf(cy);
+    const float a = cx - ipx, b = cy - ipy;
+    const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+    const float b1 = 1.f - b, b2 = b;
+    // rows / columns of adjustRect == replicated border; columns left of the image or without a right neighbour
+    // use the vertical-only weights
+    int y0 = ipy + i, y1 = y0 + 1;
+    y0 = min(max(y0, 0), sh - 1); y1 = min(max(y1, 0), sh - 1);
+    const uint8_t *r0 = src + (long long)y0 * src_step, *r1 = src + (long long)y1 * src_step;
+    const int x = ipx + j;
+    if (0 <= ipx && ipx < sw - pw && 0 <= ipy && ipy < sh - ph)
+        return r0[x] * a11 + r0[x + 1] * a12 + r1[x] * a21 + r1[x + 1] * a22;
+    if (x < 0) return r0[0] * b1 + r1[0] * b2;
+    if (x >= sw - 1) return r0[sw - 1] * b1 + r1[sw - 1] * b2;
+    return r0[x] * a11 + r0[x + 1] * a12 + r1[x] * a21 + r1[x + 1] * a22;
+}
+
+// One WAVEFRONT per point: the (WINW+2)^2 patch and the per-pixel gradient products are evaluated by all lanes,
+// the five sums are accumulated by lane 0 in the reference's raster order (double), so the result is bit-identical
+// to the serial loop while an iteration costs ~1 us instead of ~10.
 template <int HALF>
 __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint8_t *__restrict__ img, float2 *__restrict__ xy)
 {
-    constexpr int WINW = 2 * HALF + 1, SW = WINW + 2;
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int WINW = 2 * HALF + 1, SW = WINW + 2, NPIX = WINW * WINW;
+    __shared__ float sub[SW * SW];
+    __shared__ double prod[NPIX][5];
+    const int pt = blockIdx.x, lane = threadIdx.x;
     if (pt >= P.n) return;
-    float sub[SW * SW];
     const float2 cT = xy[pt];
     float cIx = cT.x, cIy = cT.y;
     int iter = 0;
-    double err = 0;
-    do {
-        double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-        d_get_rect_subpix<SW>(img, P.stride, P.w, P.h, sub, cIx, cIy);
-        for (int i = 0; i < WINW; i++) {
+    bool go = true;
+    while (go) {
+        for (int e = lane; e < SW * SW; e += 64) { const int i = e / SW, j = e - i * SW; sub[e] = d_rect_subpix_px<SW>(img, P.stride, P.w, P.h, cIx, cIy, i, j); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int e = lane; e < NPIX; e += 64) {
+            const int i = e / WINW, j = e - i * WINW;
             const float *sp = sub + (i + 1) * SW + 1;
-            const double py = i - HALF;
-            for (int j = 0; j < WINW; j++) {
-                const double m = (double)(float)(P.e[i] * P.e[j]);
-                const double tgx = sp[j + 1] - sp[j - 1];
-                const double tgy = sp[j + SW] - sp[j - SW];
-                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                const double px = j - HALF;
-                a += gxx; b += gxy; c += gyy;
-                bb1 += gxx * px + gxy * py;
-                bb2 += gxy * px + gyy * py;
+            const double py = i - HALF, px = j - HALF;
+            const double m = (double)(float)(P.e[i] * P.e[j]);
+            const double tgx = sp[j + 1] - sp[j - 1];
+            const double tgy = sp[j + SW] - sp[j - SW];
+            const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+            prod[e][0] = gxx; prod[e][1] = gxy; prod[e][2] = gyy;
+            prod[e][3] = gxx * px + gxy * py;
+            prod[e][4] = gxy * px + gyy * py;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float nx = cIx, ny = cIy;
+        int cont = 0;
+        if (lane == 0) {
+            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            for (int e = 0; e < NPIX; e++) { a += prod[e][0]; b += prod[e][1]; c += prod[e][2]; bb1 += prod[e][3]; bb2 += prod[e][4]; }
+            const double det = a * c - b * b;
+            if (!(fabs(det) <= DBL_EPSILON * DBL_EPSILON)) {
+                const double scale = 1.0 / det;
+                const float c2x = (float)(cIx + c * scale * bb1 - b * scale * bb2);
+                const float c2y = (float)(cIy - b * scale * bb1 + a * scale * bb2);
+                const double err = (double)((c2x - cIx) * (c2x - cIx) + (c2y - cIy) * (c2y - cIy));
+                nx = c2x; ny = c2y;
+                const bool outside = nx < 0 || nx >= P.w || ny < 0 || ny >= P.h;
+                cont = (!outside && ++iter < P.max_iters && err > P.eps2) ? 1 : 0;
             }
         }
-        const double det = a * c - b * b;
-        if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
-        const double scale = 1.0 / det;
-        const float c2x = (float)(cIx + c * scale * bb1 - b * scale * bb2);
-        const float c2y = (float)(cIy - b * scale * bb1 + a * scale * bb2);
-        err = (double)((c2x - cIx) * (c2x - cIx) + (c2y - cIy) * (c2y - cIy));
-        cIx = c2x; cIy = c2y;
-        if (cIx < 0 || cIx >= P.w || cIy < 0 || cIy >= P.h) break;
-    } while (++iter < P.max_iters && err > P.eps2);
+        cIx = __shfl(nx, 0, 64); cIy = __shfl(ny, 0, 64);
+        go = __shfl(cont, 0, 64) != 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     if (fabs((double)(cIx - cT.x)) > HALF || fabs((double)(cIy - cT.y)) > HALF) { cIx = cT.x; cIy = cT.y; }
-    xy[pt] = make_float2(cIx, cIy);
+    if (lane == 0) xy[pt] = make_float2(cIx, cIy);
 }
 
 // ---------------------------------------------------------------------------------
@@ -502,7 +594,7 @@ static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int s
         const float x = (float)(i - half_win) / half_win;
         P.e[i] = expf(-x * x);
     }
-    dim3 grid((n + 63) / 64), block(64);
+    dim3 grid(n), block(64);                                  // one wavefront per point
     switch (half_win) {
     case 1: hipLaunchKernelGGL(k_corner_subpix<1>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
     case 2: hipLaunchKernelGGL(k_corner_subpix<2>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
@@ -571,6 +663,8 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     OV2_HIP_CHECK(hipMemcpyAsync(hs + 16 * (size_t)ncells, ds + o_so, sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(so_h, hs + 16 * (size_t)ncells, sizeof(SelectOut));
+    if (getenv("OV2_DET_DEBUG"))
+        fprintf(stderr, "[ov2 det] select ticks (100MHz): init %llu prologue %llu sweep %llu compaction %llu\n", so_h->dbg[0], so_h->dbg[1], so_h->dbg[2], so_h->dbg[3]);
     const int n = so_h->n;
     if (n > 0) {
         if (do_subpix) {
