@@ -14,7 +14,10 @@
 //      so cell (r,c) depends on (r,c-1), (r-1,c-1), (r-1,c), (r-1,c+1) only: cells with equal
 //      2r+c are independent.  One wavefront per cell sweeps the anti-diagonals (2*rows+cols steps
 //      instead of rows*cols), giving bit-identical results to the serial raster order.
-//   3. k_corner_subpix : cv::cornerSubPix, one lane per point (<= 2 points per cell).
+//      A lane owns one row of the cell (its mask slice is one 64-bit string, its responses sit in registers,
+//      the maps are stored column-major so that column loads coalesce); the response maps are pulled into this
+//      XCD's L2 once at kernel start.
+//   3. k_corner_subpix : cv::cornerSubPix, one wavefront per point (parallel patch, ordered accumulation).
 #include "common.hpp"
 #include <float.h>
 #include <math.h>
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             keep = s > score[p - 1] && s > score[p + 1] && s > score[p - cs - 1] && s > score[p - cs] &&
                    s > score[p - cs + 1] && s > score[p + cs - 1] && s > score[p + cs] && s > score[p + cs + 1];
         }
-        out[p] = keep ? (uint8_t)s : 0;
+        out[lx * cs + ly] = keep ? (uint8_t)s : 0;            // column-major: k_grid_select reads a row per lane, coalesced
     }
 }
 
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict_
     float *out = hmap_out + (long long)cell * npx;
     for (int p = threadIdx.x; p < npx; p += blockDim.x) {
         const float a = cov[3 * p] * 0.5f, b = cov[3 * p + 1], c = cov[3 * p + 2] * 0.5f;
-        out[p] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        const int ly = p / cs, lx = p - ly * cs;
+        out[lx * cs + ly] = (a + c) - sqrtf((a - c) * (a - c) + b * b);            // column-major (see k_fast_cells)
     }
 }
 
@@ -246,8 +250,7 @@ __device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
     }
 }
 
-#define SEL_PREF 10                   // response values per lane and chunk (loads of a chunk are in flight together)
-
+template <int MAXROW>                 // widest cell (pixels) this instance holds in registers: 36 / 52 / 64
 __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
                                                       const float *__restrict__ hmaps,
@@ -268,6 +271,15 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
 
     unsigned long long tk0 = wall_clock64();
+    // Warm this XCD's L2 with the response maps: they were written by workgroups on all 8 XCDs, so every cell the sweep
+    // touches would otherwise be a fabric / HBM round trip sitting on the dependent chain of steps (1.3 MB for EuRoC).
+    {
+        const size_t map_bytes = (size_t)ncells * P.cs * P.cs * (P.mode == 0 ? 1 : 4);
+        const uint4 *mp = (const uint4 *)(P.mode == 0 ? (const void *)nms_maps : (const void *)hmaps);
+        unsigned acc = 0;
+        for (size_t i = tid; i < map_bytes / 16; i += nthreads) { const uint4 v = mp[i]; acc |= v.x ^ v.y ^ v.z ^ v.w; }
+        if (acc == 0x9E3779B9u && P.w < 0) out->n = (int)acc;            // never true: keeps the loads alive
+    }
     for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
     for (int i = tid; i < ncells; i += nthreads) { prim[i] = -1; sec[i] = -1; }
@@ -299,7 +311,6 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
 
     const unsigned long long tk2 = wall_clock64();
     const int npx = P.cs * P.cs;
-    const int q64 = 64 / P.cs, r64 = 64 - q64 * P.cs;               // (lx, ly) advance of 64 pixels without a division
     const int nsteps = 2 * (P.nhcells - 1) + P.nwcells;
     for (int t = 0; t < nsteps; t++) {
         // cells on this anti-diagonal: (r, c = t - 2r)
@@ -310,27 +321,49 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
             if (occ[r * (P.nwcells + 1) + c]) continue;
             const int x0 = c * P.cs, y0 = r * P.cs;
             if (!(x0 + P.cs < P.w - 1 && y0 + P.cs < P.h - 1)) continue;  // :350 / :510
+            // Lane ly owns row ly of the cell (cs <= 64): its slice of the exclusion mask is ONE 64-bit string
+            // (bit j <-> pixel x0 + j), the response map is column-major so that the loads of a column are
+            // coalesced, and a pixel costs ~7 instructions instead of ~35 (the sweep is a dependent chain of
+            // single-CU steps: instruction count per cell is what it costs).  Raster-order tie-breaking: strict
+            // `>` along the row, then the smaller pixel index in the wave-wide arg-max.
+            const int ly = lane;
+            const bool row_ok = ly < P.cs;
+            const int rowbase = ly * P.cs;
+            auto row_mask = [&](int xfirst) -> unsigned long long {      // 64 mask bits starting at column xfirst, row y0 + ly
+                if (!row_ok) return 0ull;
+                const unsigned *mr = mask + (y0 + ly) * P.mask_words_per_row;
+                const int w0 = xfirst >> 5, sh = xfirst & 31, last = P.mask_words_per_row - 1;
+                const unsigned long long lo = (unsigned long long)mr[w0] | ((unsigned long long)mr[min(w0 + 1, last)] << 32);
+                const unsigned long long hi = (unsigned long long)mr[min(w0 + 2, last)];
+                return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+            };
+            // the whole row of responses goes to registers in ONE batch of loads (the sweep is a chain of dependent
+            // steps and a global round trip costs ~2 us: one per cell, none for the second arg-max pass)
+            // Columns >= cs (and lanes >= cs) hold NaN: every comparison with them is false, so the inner loops carry no
+            // per-pixel bounds predicates (36+ live scalar masks made the first version spill SGPRs).
+            float curv[MAXROW];
+            {
+                const float qnan = __builtin_nanf("");
+                const int lyc = row_ok ? ly : 0;
+                const long long base = (long long)cell * npx + lyc;
+#pragma unroll
+                for (int q = 0; q < MAXROW; q++) {
+                    const int qc = q < P.cs ? q : 0;                       // always a legal address
+                    const float v = P.mode == 0 ? (float)nms_maps[base + qc * P.cs] : hmaps[base + qc * P.cs];
+                    curv[q] = (row_ok && q < P.cs) ? v : qnan;
+                }
+            }
             if (P.mode == 0) {
                 // best response among the mask-surviving FAST corners, raster order on ties
-                const uint8_t *m = nms_maps + (long long)cell * npx;
-                float bv = -1.f; int bi = 0x7FFFFFFF;
-                int ly = lane / P.cs, lx = lane - ly * P.cs;
-                for (int pb = 0; pb < npx; pb += 64 * SEL_PREF) {
+                const unsigned long long mb = row_mask(x0);
+                float bv = 0.f; int bi = 0x7FFFFFFF;                      // score 0 = no corner: never selected (strict >)
+                auto fast_px = [&](int lx, float sc) {
+                    // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
+                    const bool keep = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) && ((mb >> (lx >> 2)) & 1ull)) : (((mb >> lx) & 1ull) != 0);
+                    if (keep && sc > bv) { bv = sc; bi = rowbase + lx; }       // NaN (padding) compares false
+                };
 #pragma unroll
-                    for (int q = 0; q < SEL_PREF; q++) {
-                        const int p = pb + lane + 64 * q;
-                        const float sf = p < npx ? (float)m[p] : 0.f;
-                        if (sf != 0.f) {
-                            int keep;
-                            if (P.mask_mode == OV2_MASK_AS_EXECUTED)
-                                keep = ((lx & 3) >= 2) && mask_test(mask, P.mask_words_per_row, x0 + (lx >> 2), y0 + ly);
-                            else
-                                keep = mask_test(mask, P.mask_words_per_row, x0 + lx, y0 + ly);
-                            if (keep && (sf > bv)) { bv = sf; bi = p; }   // p increases per lane: first max kept
-                        }
-                        lx += r64; ly += q64; { const bool wrap = lx >= P.cs; lx -= wrap ? P.cs : 0; ly += wrap ? 1 : 0; }
-                    }
-                }
+                for (int q = 0; q < MAXROW; q++) fast_px(q, curv[q]);
                 wave_argmax_f(bv, bi);
                 if (bv >= 20.f) {                                         // :521
                     const int my = bi / P.cs, mx = bi - my * P.cs;
@@ -339,28 +372,21 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                     mask_draw_circle(mask, P, hw, px, py, lane, 64);      // :527
                 }
             } else {
-                const float *hm = hmaps + (long long)cell * npx;
                 bool stop = false;
                 for (int pass = 0; pass < 2 && !stop; pass++) {
-                    float bv = -FLT_MAX; int bi = 0;                      // minMaxLoc: first maximum, row-major
-                    bool any = false;
-                    int py = lane / P.cs, px = lane - py * P.cs;
-                    for (int pb = 0; pb < npx; pb += 64 * SEL_PREF) {
+                    const unsigned long long mb = row_mask(x0);
+                    // minMaxLoc: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: NaN / no index)
+                    float bv = curv[0] * ((mb & 1ull) ? 1.f : 0.f);
+                    int bi = row_ok ? rowbase : 0x7FFFFFFF;
+                    if (!row_ok) bv = -FLT_MAX;
 #pragma unroll
-                        for (int q = 0; q < SEL_PREF; q++) {
-                            const int p = pb + lane + 64 * q;
-                            if (p < npx) {
-                                const float h = hm[p];
-                                const float v = h * (mask_test(mask, P.mask_words_per_row, x0 + px, y0 + py) ? 1.f : 0.f);
-                                if (!any || v > bv) { bv = v; bi = p; any = true; }
-                            }
-                            px += r64; py += q64; { const bool wrap = px >= P.cs; px -= wrap ? P.cs : 0; py += wrap ? 1 : 0; }
-                        }
+                    for (int q = 1; q < MAXROW; q++) {
+                        const float v = curv[q] * (((mb >> q) & 1ull) ? 1.f : 0.f);      // NaN (padding) compares false
+                        if (v > bv) { bv = v; bi = rowbase + q; }
                     }
-                    if (!any) { bv = -FLT_MAX; bi = 0x7FFFFFFF; }
                     wave_argmax_f(bv, bi);
-                    const int ly = bi / P.cs, lx = bi - ly * P.cs;
-                    const int mx = x0 + lx, my = y0 + ly;
+                    const int my_ = bi / P.cs, mx_ = bi - my_ * P.cs;
+                    const int mx = x0 + mx_, my = y0 + my_;
                     if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) {
                         stop = true;                                      // `continue` at :363-368 / :379-384
                     } else if ((double)bv >= P.quality) {
@@ -654,9 +680,14 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
     P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
     P.quality = quality;
-    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
-    hipLaunchKernelGGL(k_grid_select, dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),
-                       (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so));
+#define OV2_LAUNCH_SELECT(MR)                                                                                                        \
+    do {                                                                                                                            \
+        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
+        hipLaunchKernelGGL(k_grid_select<MR>, dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),              \
+                           (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so)); \
+    } while (0)
+    if (cell <= 36) OV2_LAUNCH_SELECT(36); else if (cell <= 52) OV2_LAUNCH_SELECT(52); else OV2_LAUNCH_SELECT(64);
+#undef OV2_LAUNCH_SELECT
     OV2_HIP_CHECK(hipGetLastError());
     // the count is needed on the host to size the sub-pixel launch
     uint8_t *hs = (uint8_t *)ctx->h_scratch;
