@@ -250,7 +250,7 @@ __device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
     }
 }
 
-template <int MAXROW>                 // widest cell (pixels) this instance holds in registers: 36 / 52 / 64
+template <int MODE, int MAXROW>       // MODE 0 = FAST scores (bytes), 1 = min-eigenvalue (floats); MAXROW: columns of a cell row held in registers at a time
 __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
                                                       const float *__restrict__ hmaps,
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     // Warm this XCD's L2 with the response maps: they were written by workgroups on all 8 XCDs, so every cell the sweep
     // touches would otherwise be a fabric / HBM round trip sitting on the dependent chain of steps (1.3 MB for EuRoC).
     {
-        const size_t map_bytes = (size_t)ncells * P.cs * P.cs * (P.mode == 0 ? 1 : 4);
-        const uint4 *mp = (const uint4 *)(P.mode == 0 ? (const void *)nms_maps : (const void *)hmaps);
+        const size_t map_bytes = (size_t)ncells * P.cs * P.cs * (MODE == 0 ? 1 : 4);
+        const uint4 *mp = (const uint4 *)(MODE == 0 ? (const void *)nms_maps : (const void *)hmaps);
         unsigned acc = 0;
         for (size_t i = tid; i < map_bytes / 16; i += nthreads) { const uint4 v = mp[i]; acc |= v.x ^ v.y ^ v.z ^ v.w; }
         if (acc == 0x9E3779B9u && P.w < 0) out->n = (int)acc;            // never true: keeps the loads alive
@@ -337,33 +337,36 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 const unsigned long long hi = (unsigned long long)mr[min(w0 + 2, last)];
                 return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
             };
-            // the whole row of responses goes to registers in ONE batch of loads (the sweep is a chain of dependent
-            // steps and a global round trip costs ~2 us: one per cell, none for the second arg-max pass)
-            // Columns >= cs (and lanes >= cs) hold NaN: every comparison with them is false, so the inner loops carry no
-            // per-pixel bounds predicates (36+ live scalar masks made the first version spill SGPRs).
+            // The row of responses goes to registers in ONE batch of loads per chunk of MAXROW columns (the sweep is a
+            // chain of dependent steps and a global round trip costs ~2 us).  Cells up to MAXROW pixels wide -- every
+            // reference configuration -- need one chunk, loaded once for both arg-max passes; wider cells (<= 64) take
+            // two chunks per pass.  Columns >= cs (and lanes >= cs) hold NaN: every comparison with them is false, so
+            // the inner loops carry no per-pixel bounds predicates.
             float curv[MAXROW];
-            {
-                const float qnan = __builtin_nanf("");
-                const int lyc = row_ok ? ly : 0;
-                const long long base = (long long)cell * npx + lyc;
-#pragma unroll
-                for (int q = 0; q < MAXROW; q++) {
-                    const int qc = q < P.cs ? q : 0;                       // always a legal address
-                    const float v = P.mode == 0 ? (float)nms_maps[base + qc * P.cs] : hmaps[base + qc * P.cs];
-                    curv[q] = (row_ok && q < P.cs) ? v : qnan;
-                }
+            const bool single = P.cs <= MAXROW;
+            const long long cbase = (long long)cell * npx + (row_ok ? ly : 0);
+            const float qnan = __builtin_nanf("");
+#define SEL_LOAD_CHUNK(JB)                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < MAXROW; q++) {                                                 \
+                const int col = (JB) + q, qc = col < P.cs ? col : 0;                                             \
+                const float v = MODE == 0 ? (float)nms_maps[cbase + qc * P.cs] : hmaps[cbase + qc * P.cs];       \
+                curv[q] = (row_ok && col < P.cs) ? v : qnan;                                                     \
             }
-            if (P.mode == 0) {
+            if (single) { SEL_LOAD_CHUNK(0) }
+            if (MODE == 0) {
                 // best response among the mask-surviving FAST corners, raster order on ties
                 const unsigned long long mb = row_mask(x0);
                 float bv = 0.f; int bi = 0x7FFFFFFF;                      // score 0 = no corner: never selected (strict >)
-                auto fast_px = [&](int lx, float sc) {
-                    // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
-                    const bool keep = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) && ((mb >> (lx >> 2)) & 1ull)) : (((mb >> lx) & 1ull) != 0);
-                    if (keep && sc > bv) { bv = sc; bi = rowbase + lx; }       // NaN (padding) compares false
-                };
+                for (int jb = 0; jb < P.cs; jb += MAXROW) {
+                    if (!single) { SEL_LOAD_CHUNK(jb) }
 #pragma unroll
-                for (int q = 0; q < MAXROW; q++) fast_px(q, curv[q]);
+                    for (int q = 0; q < MAXROW; q++) {
+                        const int lx = jb + q;
+                        // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
+                        const unsigned long long bit = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) ? (mb >> (lx >> 2)) : 0ull) : (mb >> (lx & 63));
+                        if ((bit & 1ull) && curv[q] > bv) { bv = curv[q]; bi = rowbase + lx; }   // NaN (padding) compares false
+                    }
+                }
                 wave_argmax_f(bv, bi);
                 if (bv >= 20.f) {                                         // :521
                     const int my = bi / P.cs, mx = bi - my * P.cs;
@@ -375,14 +378,17 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 bool stop = false;
                 for (int pass = 0; pass < 2 && !stop; pass++) {
                     const unsigned long long mb = row_mask(x0);
-                    // minMaxLoc: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: NaN / no index)
-                    float bv = curv[0] * ((mb & 1ull) ? 1.f : 0.f);
-                    int bi = row_ok ? rowbase : 0x7FFFFFFF;
-                    if (!row_ok) bv = -FLT_MAX;
+                    // minMaxLoc: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: no index)
+                    float bv = -FLT_MAX; int bi = 0x7FFFFFFF;
+                    for (int jb = 0; jb < P.cs; jb += MAXROW) {
+                        if (!single) { SEL_LOAD_CHUNK(jb) }
 #pragma unroll
-                    for (int q = 1; q < MAXROW; q++) {
-                        const float v = curv[q] * (((mb >> q) & 1ull) ? 1.f : 0.f);      // NaN (padding) compares false
-                        if (v > bv) { bv = v; bi = rowbase + q; }
+                        for (int q = 0; q < MAXROW; q++) {
+                            const int lx = jb + q;
+                            const float v = curv[q] * (((mb >> (lx & 63)) & 1ull) ? 1.f : 0.f);     // NaN (padding) compares false
+                            const bool take = lx == 0 ? row_ok : (v > bv);
+                            if (take) { bv = v; bi = rowbase + lx; }
+                        }
                     }
                     wave_argmax_f(bv, bi);
                     const int my_ = bi / P.cs, mx_ = bi - my_ * P.cs;
@@ -398,6 +404,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                     }
                 }
             }
+#undef SEL_LOAD_CHUNK
         }
         __syncthreads();
     }
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
             n += __popcll(m);
         }
         const int nbprim = n, nbempty = ncells - nboccup;
-        if (P.mode == 1 && nbprim + nboccup < ncells) {                    // :400-414: the first nbsec secondaries in cell order
+        if (MODE == 1 && nbprim + nboccup < ncells) {                    // :400-414: the first nbsec secondaries in cell order
             const int nbsec = ncells - (nbprim + nboccup);
             int k = 0;
             for (int base = 0; base < ncells && k < nbsec; base += 64) {
@@ -680,13 +687,15 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
     P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
     P.quality = quality;
-#define OV2_LAUNCH_SELECT(MR)                                                                                                        \
+#define OV2_LAUNCH_SELECT(MD, MR)                                                                                                       \
     do {                                                                                                                            \
-        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
-        hipLaunchKernelGGL(k_grid_select<MR>, dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),              \
+        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MD, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
+        hipLaunchKernelGGL((k_grid_select<MD, MR>), dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),        \
                            (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so)); \
     } while (0)
-    if (cell <= 36) OV2_LAUNCH_SELECT(36); else if (cell <= 52) OV2_LAUNCH_SELECT(52); else OV2_LAUNCH_SELECT(64);
+    // cells of 53..64 pixels: two chunks of 52 columns
+    if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36); else OV2_LAUNCH_SELECT(0, 52); }
+    else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36); else OV2_LAUNCH_SELECT(1, 52); }
 #undef OV2_LAUNCH_SELECT
     OV2_HIP_CHECK(hipGetLastError());
     // the count is needed on the host to size the sub-pixel launch

@@ -30,7 +30,7 @@ IMAGES = _images()
 
 
 @pytest.mark.parametrize("name", [n for n, _ in IMAGES])
-@pytest.mark.parametrize("cell", [50, 35])
+@pytest.mark.parametrize("cell", [50, 35, 58, 64])
 @pytest.mark.parametrize("mode", [L.OV2_MASK_AS_EXECUTED, L.OV2_MASK_INTENDED])
 def test_grid_fast_bit_exact(gpu_ctx, oracle, name, cell, mode):
     img = dict(IMAGES)[name]
@@ -48,7 +48,7 @@ def test_grid_fast_bit_exact(gpu_ctx, oracle, name, cell, mode):
 
 
 @pytest.mark.parametrize("name", [n for n, _ in IMAGES])
-@pytest.mark.parametrize("cell", [35, 45])
+@pytest.mark.parametrize("cell", [35, 45, 53, 58])
 def test_singlescale_bit_exact(gpu_ctx, oracle, name, cell):
     img = dict(IMAGES)[name]
     h, w = img.shape

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity campaign (run on the GPU box: python tools/fuzz_parity.py [n_cases] [seed]).
+Every case draws an image size, content, window / cell / tile parameters and point sets (including points on and
+beyond the borders) and demands bit-exact agreement for the integer/float32 front-end paths."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import ov2slam_amd
+from ov2slam_amd import synth, _lib as L
+from oracle import oracle as O
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(SEED)
+ctx = ov2slam_amd.Context(0)
+trk = ov2slam_amd.FeatureTracker(ctx, 30, 0.01)
+fails = []
+
+
+def rand_image(w, h, kind):
+    if kind == 0:
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    a, _, _ = synth.frame_pair(w, h, seed=int(rng.integers(1 << 30)))
+    if kind == 2:
+        a = (a.astype(np.float32) * 0.3 + 100).astype(np.uint8)          # low contrast
+    if kind == 3:
+        a[: h // 3] = 128                                                  # flat band
+    return a
+
+
+def check(name, ok, info):
+    if not ok:
+        fails.append((name, info)); print("MISMATCH", name, info, flush=True)
+
+
+t0 = time.time()
+for case in range(N):
+    w, h = int(rng.integers(64, 900)), int(rng.integers(48, 520))
+    kind = int(rng.integers(0, 4))
+    prev = rand_image(w, h, kind)
+    shift = rng.uniform(-6, 6, 2)
+    cur = np.roll(np.roll(prev, int(round(shift[1])), 0), int(round(shift[0])), 1)
+    cur = np.clip(cur.astype(np.int16) + rng.integers(-3, 4, cur.shape), 0, 255).astype(np.uint8)
+    info = dict(case=case, w=w, h=h, kind=kind)
+    # ---- pyramid (+ fused CLAHE) ----
+    lvl = int(rng.integers(0, 4))
+    Gp = ov2slam_amd.Pyramid(ctx, w, h, 9, lvl).build(prev); Rp = O.Pyramid(prev, 9, lvl)
+    Gc = ov2slam_amd.Pyramid(ctx, w, h, 9, lvl).build(cur); Rc = O.Pyramid(cur, 9, lvl)
+    check("pyr_levels", Gp.levels == Rp.levels, info)
+    for l in range(min(Gp.levels, Rp.levels)):
+        check("pyramid", np.array_equal(Gp.download(l, padded=True)[0], Rp.level(l, padded=True)[0]), dict(info, level=l))
+    tx, ty = int(rng.integers(1, max(2, w // 40))), int(rng.integers(1, max(2, h // 40)))
+    clip = float(rng.choice([0.0, 1.0, 2.0, 3.0, 8.0, 40.0]))
+    if tx + 1 <= 48:
+        g = ov2slam_amd.CLAHE(ctx, clip, (tx, ty)).apply(prev)
+        check("clahe", np.array_equal(g, O.clahe(prev, clip, tx, ty)), dict(info, tiles=(tx, ty), clip=clip))
+        Pf = ov2slam_amd.Pyramid(ctx, w, h, 9, lvl).build_clahe(prev, clip, tx, ty)
+        Rf = O.Pyramid(O.clahe(prev, clip, tx, ty), 9, lvl)
+        for l in range(Pf.levels):
+            check("clahe_pyr", np.array_equal(Pf.download(l, padded=True)[0], Rf.level(l, padded=True)[0]), dict(info, level=l))
+    # ---- LK, both kernels ----
+    n = int(rng.integers(1, 400))
+    kps = np.stack([rng.uniform(-12, w + 12, n), rng.uniform(-12, h + 12, n)], 1).astype(np.float32)
+    pri = (kps - shift + rng.normal(0, rng.choice([0.3, 2.0, 8.0]), kps.shape)).astype(np.float32)
+    nl = int(rng.integers(0, Gp.levels))
+    for impl in ("row", "lane3"):
+        os.environ["OV2_LK_IMPL"] = impl
+        go, gs, gst = trk.fbKltTracking(Gp, Gc, 9, nl, 30., 0.5, kps, pri, return_stats=True)
+        ro, rs, rst = O.fb_klt(Rp, Rc, 9, nl, 30., 0.5, kps, pri)
+        check("fbklt_" + impl, np.array_equal(gs, rs) and np.array_equal(go.view(np.uint32), ro.view(np.uint32)) and gst[0] == rst[0], dict(info, n=n, nl=nl))
+    os.environ.pop("OV2_LK_IMPL", None)
+    # ---- stereo SAD scan on a random level ----
+    sl = int(rng.integers(0, Gp.levels))
+    lw, lh = Gp.level_size(sl)
+    pts = np.stack([rng.uniform(0, lw - 1, 60), rng.uniform(0, lh - 1, 60)], 1).astype(np.float32)
+    for go_left in (True, False):
+        a = trk.getLineMinSAD(Gp, Gc, sl, pts, int(rng.choice([3, 5, 7])), go_left)
+    ws = int(rng.choice([3, 5, 7]))
+    a = trk.getLineMinSAD(Gp, Gc, sl, pts, ws, True); b = O.line_min_sad(Rp.level(sl)[0], Rc.level(sl)[0], pts, ws, True)
+    check("line_min_sad", np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), dict(info, level=sl, ws=ws))
+    # ---- detectors ----
+    if w >= 120 and h >= 120:
+        cell = int(rng.choice([20, 35, 45, 50, 53, 58]))
+        curk = kps[(kps[:, 0] > 0) & (kps[:, 0] < w - 1) & (kps[:, 1] > 0) & (kps[:, 1] < h - 1)][: int(rng.integers(0, 80))]
+        fx = ov2slam_amd.FeatureExtractor(ctx, nfast_th=int(rng.integers(5, 40)), dmaxquality=float(rng.choice([1e-4, 1e-3, 1e-2])))
+        th0, q0 = fx.nfast_th_, fx.dmaxquality_
+        g = fx.detectGridFAST(prev, cell, curk)
+        r, rth = O.detect_grid_fast(prev, cell, curk, th0, O.MASK_AS_EXECUTED, True)
+        check("grid_fast", np.array_equal(g.view(np.uint32), r.view(np.uint32)) and fx.nfast_th_ == rth, dict(info, cell=cell, th=th0))
+        roi = (int(rng.integers(0, 10)), int(rng.integers(0, 10)), w - int(rng.integers(10, 30)), h - int(rng.integers(10, 30)))
+        g = fx.detectSingleScale(prev, cell, curk, roi)
+        r, rq = O.detect_singlescale(prev, cell, curk, roi, q0, True)
+        check("singlescale", np.array_equal(g.view(np.uint32), r.view(np.uint32)) and fx.dmaxquality_ == rq, dict(info, cell=cell, q=q0))
+    if (case + 1) % 10 == 0:
+        print("case %d/%d  %.0f s  mismatches so far: %d" % (case + 1, N, time.time() - t0, len(fails)), flush=True)
+print("FUZZ DONE: %d cases, %d mismatches" % (N, len(fails)))
+sys.exit(1 if fails else 0)
