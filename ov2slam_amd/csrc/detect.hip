@@ -250,7 +250,9 @@ __device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
     }
 }
 
-template <int MODE, int MAXROW>       // MODE 0 = FAST scores (bytes), 1 = min-eigenvalue (floats); MAXROW: columns of a cell row held in registers at a time
+// MODE 0 = FAST scores (bytes), 1 = min-eigenvalue (floats); a cell row (<= MAXROW * CHUNKS columns) is held in registers
+// MAXROW columns at a time: (36,1) and (52,1) cover the reference cell sizes with compile-time column indices, (32,2) the rest
+template <int MODE, int MAXROW, int CHUNKS>
 __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
                                                       const float *__restrict__ hmaps,
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
             // two chunks per pass.  Columns >= cs (and lanes >= cs) hold NaN: every comparison with them is false, so
             // the inner loops carry no per-pixel bounds predicates.
             float curv[MAXROW];
-            const bool single = P.cs <= MAXROW;
+            constexpr bool single = CHUNKS == 1;
             const long long cbase = (long long)cell * npx + (row_ok ? ly : 0);
             const float qnan = __builtin_nanf("");
 #define SEL_LOAD_CHUNK(JB)                                                                                       \
@@ -357,7 +359,9 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 // best response among the mask-surviving FAST corners, raster order on ties
                 const unsigned long long mb = row_mask(x0);
                 float bv = 0.f; int bi = 0x7FFFFFFF;                      // score 0 = no corner: never selected (strict >)
-                for (int jb = 0; jb < P.cs; jb += MAXROW) {
+#pragma unroll
+                for (int ch = 0; ch < CHUNKS; ch++) {
+                    const int jb = ch * MAXROW;
                     if (!single) { SEL_LOAD_CHUNK(jb) }
 #pragma unroll
                     for (int q = 0; q < MAXROW; q++) {
@@ -380,7 +384,9 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                     const unsigned long long mb = row_mask(x0);
                     // minMaxLoc: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: no index)
                     float bv = -FLT_MAX; int bi = 0x7FFFFFFF;
-                    for (int jb = 0; jb < P.cs; jb += MAXROW) {
+#pragma unroll
+                    for (int ch = 0; ch < CHUNKS; ch++) {
+                        const int jb = ch * MAXROW;
                         if (!single) { SEL_LOAD_CHUNK(jb) }
 #pragma unroll
                         for (int q = 0; q < MAXROW; q++) {
@@ -687,15 +693,14 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
     P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
     P.quality = quality;
-#define OV2_LAUNCH_SELECT(MD, MR)                                                                                                       \
+#define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                                       \
     do {                                                                                                                            \
-        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MD, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
-        hipLaunchKernelGGL((k_grid_select<MD, MR>), dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),        \
+        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MD, MR, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
+        hipLaunchKernelGGL((k_grid_select<MD, MR, CH>), dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),        \
                            (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so)); \
     } while (0)
-    // cells of 53..64 pixels: two chunks of 52 columns
-    if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36); else OV2_LAUNCH_SELECT(0, 52); }
-    else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36); else OV2_LAUNCH_SELECT(1, 52); }
+    if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(0, 52, 1); else OV2_LAUNCH_SELECT(0, 32, 2); }
+    else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(1, 52, 1); else OV2_LAUNCH_SELECT(1, 32, 2); }
 #undef OV2_LAUNCH_SELECT
     OV2_HIP_CHECK(hipGetLastError());
     // the count is needed on the host to size the sub-pixel launch
