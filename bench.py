@@ -134,9 +134,18 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--seqs", type=int, default=1024, help="sequences processed in lock-step per GPU")
+    ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
+                    help="euroc = the headline configuration (BASELINE.json configs[1]); kitti = configs[2] "
+                         "(1241x376, wide-image stress) -- a side measurement, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the BA / detect / single-sequence sections")
     args = ap.parse_args()
+    if args.workload == "kitti":
+        # KITTI 00 stereo, accurate params: 1241x376, nmaxdist 35 -> nbmaxkps 36*11 = 396
+        global W, H, NKPS, N_PASS_A, N_PASS_B, CLAHE_TILES
+        W, H, NKPS = 1241, 376, 396
+        N_PASS_A = 277; N_PASS_B = NKPS - N_PASS_A
+        CLAHE_TILES = (W // 50, H // 50)
 
     import torch
     import torch.distributed as dist
@@ -245,7 +254,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))
-        if tj.get("seqs_per_gpu") == S:
+        if tj.get("seqs_per_gpu") == S and args.workload == "euroc":
             traffic = tj["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -258,9 +267,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 fixed point + f32 (LK), f64 (BA)", "data": "synthetic",
-            "config": {"workload": "EuRoC MH_01 stereo 'accurate' tracking step on synthetic 752x480 frames: CLAHE + pyramid "
-                                   "build (4 levels) + fbKltTracking pass A (216 kps, nbpyrlvl 1) + pass B "
-                                   "(92 kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px",
+            "config": {"workload": "%s stereo 'accurate' tracking step on synthetic %dx%d frames: CLAHE + pyramid "
+                                   "build (4 levels) + fbKltTracking pass A (%d kps, nbpyrlvl 1) + pass B "
+                                   "(%d kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px"
+                                   % ("EuRoC MH_01" if args.workload == "euroc" else "KITTI 00", W, H, N_PASS_A, N_PASS_B),
                        "seqs_per_gpu": S, "keypoints_per_frame": NKPS, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fb_klt3", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

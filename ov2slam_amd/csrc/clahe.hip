@@ -50,6 +50,7 @@ typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 template <int CTRL>
 __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // out-of-row sources read 0
 
+template <bool SRC_ALIGNED>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
 __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
 {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
@@ -61,58 +62,80 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
     const int sub = lane >> 4, l16 = lane & 15;
     uint32_t *hist = hw + ((sub << 1) | (l16 & 1)) * CH_STRIDE;
     uint32_t *trash = hw + CH_COPIES * CH_STRIDE;
-    const bool fast_geom = P.tw <= 61 && P.th <= 64 && ((P.stride | (int)(size_t)img) & 3) == 0;
+    const bool fast_geom = P.tw <= 61 && P.th <= 64;
+    // Rows are fetched as ALIGNED dwords whatever the alignment of the image (KITTI: 1241-byte rows): dword l16 of
+    // the row segment starts `ph` bytes before the first tile byte, ph = (address of that byte) & 3, per row.
+    const uint8_t *img_end = img + (long long)(P.h - 1) * P.stride + P.w;          // one past the last pixel of this image
+    const bool same_phase = SRC_ALIGNED || (P.stride & 3) == 0;
 
     // a wavefront walks over several tiles; the 16 row-dwords of the NEXT tile are requested before the
     // current one is histogrammed, so the global round trip hides behind the LDS work
     auto tile_fast = [&](int t) { const int tx = t % P.tiles_x; return fast_geom && (tx + 1) * P.tw <= P.w; };
-    auto tile_load = [&](int t, uint32_t (&vv)[16]) {
+    auto tile_load = [&](int t, uint32_t (&vv)[16], uint32_t &phs) {
         const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-        const int x_begin = tx * P.tw, x_end = x_begin + P.tw;
-        const int xa = (x_begin & ~3) + 4 * l16;                    // aligned dword l16 of a row segment
-        const bool any = xa + 3 >= x_begin && xa < x_end;
+        const int x_begin = tx * P.tw;
         const int ybase = ty * P.th + sub;
+        phs = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             int y = ybase + 4 * i;
             y = y >= P.h ? 2 * P.h - 2 - y : y;                     // bottom REFLECT_101 padding (< one tile high)
             y = y < 0 ? 0 : y;
-            vv[i] = 0;
-            if (any && 4 * i + sub < P.th) vv[i] = *(const uint32_t *)(img + y * P.stride + xa);
+            uint32_t v = 0;
+            if (SRC_ALIGNED) {
+                const uint32_t ph = (uint32_t)(x_begin & 3);          // rows and base aligned: the phase is the tile's column phase
+                phs |= ph << (2 * i);
+                if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph) v = *(const uint32_t *)(img + y * P.stride + (x_begin & ~3) + 4 * l16);
+            } else {
+                const uint8_t *rp = img + (long long)y * P.stride + x_begin;
+                const uint32_t ph = (uint32_t)((size_t)rp & 3);
+                phs |= ph << (2 * i);
+                const uint8_t *ap = rp - ph + 4 * l16;
+                if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph) {  // this dword holds at least one byte of the tile row
+                    if (ap + 4 <= img_end) v = *(const uint32_t *)ap;
+                    else for (int k = 0; k < 4; k++) if (ap + k < img_end) v |= (uint32_t)ap[k] << (8 * k);
+                }
+            }
+            vv[i] = v;
         }
     };
 
-    uint32_t cur[16], nxt[16];
+    uint32_t cur[16], nxt[16], cur_ph = 0, nxt_ph = 0;
     int t = blockIdx.x * 4 + wave;
-    if (t < ntiles && tile_fast(t)) tile_load(t, cur);
+    if (t < ntiles && tile_fast(t)) tile_load(t, cur, cur_ph);
 #pragma nounroll
     for (; t < ntiles; t += tstride) {
         const int tn = t + tstride;
-        if (tn < ntiles && tile_fast(tn)) tile_load(tn, nxt);
+        if (tn < ntiles && tile_fast(tn)) tile_load(tn, nxt, nxt_ph);
         const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-        const int x_begin = tx * P.tw, x_end = x_begin + P.tw;      // tile columns in padded coordinates
+        const int x_begin = tx * P.tw;                              // tile columns in padded coordinates
         for (int e = lane; e < CH_COPIES * CH_STRIDE / 4; e += 64) ((c_u32x4 *)hw)[e] = (c_u32x4)(0u);
         clahe_wave_sync();
         if (tile_fast(t)) {
-            // bytes of this lane's dword column outside the tile are counted into the scratch copy
-            const int xa = (x_begin & ~3) + 4 * l16;
-            uint32_t *h0 = (xa >= x_begin && xa < x_end) ? hist : trash, *h1 = (xa + 1 >= x_begin && xa + 1 < x_end) ? hist : trash;
-            uint32_t *h2 = (xa + 2 >= x_begin && xa + 2 < x_end) ? hist : trash, *h3 = (xa + 3 >= x_begin && xa + 3 < x_end) ? hist : trash;
-            if (xa + 3 >= x_begin && xa < x_end) {
+            // byte k of this lane's dword is tile column 4*l16 + k - ph; bytes outside [0, tw) are counted into the
+            // scratch copy instead of being branched around
+            auto sel = [&](int p) { return (unsigned)p < (unsigned)P.tw ? hist : trash; };
+            const int p_same = 4 * l16 - (int)(cur_ph & 3);
+            uint32_t *h0 = sel(p_same), *h1 = sel(p_same + 1), *h2 = sel(p_same + 2), *h3 = sel(p_same + 3);
+            bool mine = p_same < P.tw;                              // this lane's dword holds at least one tile byte
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    if (4 * i + sub < P.th) {
-                        const uint32_t v = cur[i];
-                        atomicAdd(&h0[v & 0xFF], 1u);
-                        atomicAdd(&h1[(v >> 8) & 0xFF], 1u);
-                        atomicAdd(&h2[(v >> 16) & 0xFF], 1u);
-                        atomicAdd(&h3[v >> 24], 1u);
-                    }
+            for (int i = 0; i < 16; i++) {
+                if (!same_phase) {                                   // wave-uniform: rows of an unaligned image differ in phase
+                    const int p0 = 4 * l16 - (int)((cur_ph >> (2 * i)) & 3);
+                    h0 = sel(p0); h1 = sel(p0 + 1); h2 = sel(p0 + 2); h3 = sel(p0 + 3);
+                    mine = p0 < P.tw;
+                }
+                if (mine && 4 * i + sub < P.th) {
+                    const uint32_t v = cur[i];
+                    atomicAdd(&h0[v & 0xFF], 1u);
+                    atomicAdd(&h1[(v >> 8) & 0xFF], 1u);
+                    atomicAdd(&h2[(v >> 16) & 0xFF], 1u);
+                    atomicAdd(&h3[v >> 24], 1u);
                 }
             }
         } else {
             for (int ly = sub; ly < P.th; ly += 4) {
-                const uint8_t *row = img + c_reflect101(ty * P.th + ly, P.h) * P.stride;
+                const uint8_t *row = img + (long long)c_reflect101(ty * P.th + ly, P.h) * P.stride;
                 for (int lx = l16; lx < P.tw; lx += 16) atomicAdd(&hist[row[c_reflect101(x_begin + lx, P.w)]], 1u);
             }
         }
@@ -161,6 +184,7 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
         *(uint32_t *)(lut + ((long long)b * ntiles + t) * 256 + 4 * lane) = packed;
 #pragma unroll
         for (int i = 0; i < 16; i++) cur[i] = nxt[i];
+        cur_ph = nxt_ph;
     }
 }
 
@@ -176,6 +200,7 @@ typedef float c_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float c_ub(uint32_t q, int k) { return (float)((q >> (8 * k)) & 0xFFu); }    // v_cvt_f32_ubyteK
 
+template <bool SRC_ALIGNED>
 __global__ __launch_bounds__(256) void k_clahe_apply(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
                                                      uint8_t *__restrict__ dst)
 {
@@ -206,7 +231,11 @@ __global__ __launch_bounds__(256) void k_clahe_apply(ClaheParams P, const uint8_
     while (y1 > y0 && (int)floorf((float)(y1 - 1) * P.inv_th - 0.5f) + 1 != cy) y1--;
     const uint8_t *simg = src + (long long)b * P.src_item_stride;
     uint8_t *dimg = dst + (long long)b * P.dst_item_stride;
-    const bool aligned = ((P.stride | P.dst_stride | (int)(size_t)simg | (int)(size_t)dimg) & 3) == 0;
+    // the source may have any alignment (KITTI: 1241-byte rows): rows are read as aligned dwords + v_alignbyte;
+    // only the destination decides between dword and byte stores
+    const bool dst_aligned = ((P.dst_stride | (int)(size_t)dimg) & 3) == 0;
+    constexpr bool src_aligned = SRC_ALIGNED;
+    const uint8_t *simg_end = simg + (long long)(P.h - 1) * P.stride + P.w;    // one past the last source pixel
     const int ndw = (P.w + 3) >> 2;
     for (int dwi = tid; dwi < ndw; dwi += nthr) {
         const int xb = 4 * dwi;
@@ -221,17 +250,24 @@ __global__ __launch_bounds__(256) void k_clahe_apply(ClaheParams P, const uint8_
             lutc[k] = lut4 + ((fx + 1) << 8);
         }
         const c_f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
-        const bool full = aligned && xb + 3 < P.w;
+        const bool full = dst_aligned && xb + 3 < P.w;
         for (int yb = y0; yb < y1; yb += CA_UNROLL) {
             // issue the loads of CA_UNROLL rows before consuming any (the row loop is latency-bound otherwise)
             uint32_t inr[CA_UNROLL];
 #pragma unroll
             for (int u = 0; u < CA_UNROLL; u++) {
                 const int y = min(yb + u, y1 - 1);
-                const uint8_t *srow = simg + y * P.stride;
+                const uint8_t *sp = simg + (long long)y * P.stride + xb;
                 uint32_t in = 0;
-                if (full) in = *(const uint32_t *)(srow + xb);
-                else for (int k = 0; k < 4; k++) if (xb + k < P.w) in |= (uint32_t)srow[xb + k] << (8 * k);
+                if (src_aligned && xb + 3 < P.w) in = *(const uint32_t *)sp;
+                else {
+                    const uint32_t ph = (uint32_t)((size_t)sp & 3);
+                    const uint8_t *ap = sp - ph;
+                    if (xb + 3 < P.w && ap + 8 <= simg_end) {
+                        const uint32_t lo = *(const uint32_t *)ap, hi = *(const uint32_t *)(ap + 4);
+                        in = __builtin_amdgcn_alignbyte(hi, lo, ph);
+                    } else for (int k = 0; k < 4; k++) if (xb + k < P.w) in |= (uint32_t)sp[k] << (8 * k);
+                }
                 inr[u] = in;
             }
 #pragma unroll
@@ -312,14 +348,16 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     P.src_item_stride = (long long)src_batch_stride; P.dst_item_stride = (long long)dst_batch_stride; P.dst_stride = dst_stride;
     // ~5 tiles per wavefront (prefetch pipeline) once the batch alone fills the GPU, one tile per wavefront otherwise (latency)
     const int tiles_per_wave = (long long)batch * tiles_x * tiles_y >= 32768 ? 5 : 1;
-    hipLaunchKernelGGL(k_clahe_lut, dim3((tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave), batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+    const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
+    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3((tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave), batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 1024 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 255) / 256;
     const int apply_threads = (((ndw + passes - 1) / passes) + 63) / 64 * 64;
     OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && apply_lds <= 160 * 1024, OV2_EUNSUPPORTED, "CLAHE: too many tile columns / too wide an image for the LDS tables");
-    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
-    hipLaunchKernelGGL(k_clahe_apply, dim3(tiles_y + 1, batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
+    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
+    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
+    hipLaunchKernelGGL(src_al ? k_clahe_apply<true> : k_clahe_apply<false>, dim3(tiles_y + 1, batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
