@@ -201,7 +201,7 @@ typedef float c_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float c_ub(uint32_t q, int k) { return (float)((q >> (8 * k)) & 0xFFu); }    // v_cvt_f32_ubyteK
 
 template <bool SRC_ALIGNED>
-__global__ __launch_bounds__(256) void k_clahe_apply(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
+__global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
                                                      uint8_t *__restrict__ dst)
 {
     extern __shared__ __align__(16) unsigned char clahe_smem[];
@@ -351,8 +351,8 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
     hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3((tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave), batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
-    // one thread per dword column; several column passes only for images wider than 1024 pixels
-    const int ndw = (w + 3) / 4, passes = (ndw + 255) / 256;
+    // one thread per dword column; several column passes only for images wider than 2048 pixels
+    const int ndw = (w + 3) / 4, passes = (ndw + 511) / 512;
     const int apply_threads = (((ndw + passes - 1) / passes) + 63) / 64 * 64;
     OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && apply_lds <= 160 * 1024, OV2_EUNSUPPORTED, "CLAHE: too many tile columns / too wide an image for the LDS tables");
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
