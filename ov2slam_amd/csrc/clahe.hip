@@ -404,13 +404,15 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     OV2_REQUIRE(p->d.batch == 1, OV2_EINVAL, "host-buffer entry point takes batch=1 pyramids");
     OV2_REQUIRE(stride >= p->w && tiles_x > 0 && tiles_y > 0 && tiles_x <= p->w && tiles_y <= p->h, OV2_EINVAL, "bad geometry");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t img = ((size_t)p->w * p->h + 255) & ~(size_t)255, lut_bytes = (size_t)tiles_x * tiles_y * 256;
+    // device staging copy with a 16-byte-aligned pitch (aligned-dword kernel instances whatever the width)
+    const size_t pitch = ((size_t)p->w + 15) & ~(size_t)15;
+    const size_t img = (pitch * p->h + 255) & ~(size_t)255, lut_bytes = (size_t)tiles_x * tiles_y * 256;
     int rc = ctx->reserve_device(img + lut_bytes);
     if (rc != OV2_OK) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, (size_t)p->w, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
+    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
     const PyrLevelDesc &L0 = p->d.lv[0];
-    rc = clahe_launch(ctx, ds, p->w, p->h, p->w, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
+    rc = clahe_launch(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
                       (size_t)p->d.item_stride, ds + img, p->d.win);
     if (rc != OV2_OK) return rc;
     return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
@@ -423,14 +425,15 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     OV2_REQUIRE(w > 0 && h > 0 && stride >= w && dst_stride >= w && tiles_x > 0 && tiles_y > 0, OV2_EINVAL, "bad geometry");
     OV2_REQUIRE(tiles_x <= w && tiles_y <= h, OV2_EINVAL, "more tiles than pixels");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t img = ((size_t)w * h + 255) & ~(size_t)255, lut_bytes = (size_t)tiles_x * tiles_y * 256;
+    const size_t pitch = ((size_t)w + 15) & ~(size_t)15;          // aligned staging pitch for both device images
+    const size_t img = (pitch * h + 255) & ~(size_t)255, lut_bytes = (size_t)tiles_x * tiles_y * 256;
     const int rc = ctx->reserve_device(2 * img + lut_bytes);
     if (rc != OV2_OK) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, (size_t)w, src_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
-    const int rc2 = clahe_launch(ctx, ds, w, h, w, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, w, 0, ds + 2 * img);
+    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    const int rc2 = clahe_launch(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img);
     if (rc2 != OV2_OK) return rc2;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(dst_h, (size_t)dst_stride, ds + img, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipMemcpy2DAsync(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OV2_OK;
 }

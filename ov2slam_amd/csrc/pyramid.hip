@@ -298,16 +298,17 @@ int ov2_pyr_build_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, 
     OV2_REQUIRE(ctx && p && img_h, OV2_EINVAL, "NULL argument");
     OV2_REQUIRE(stride >= p->w, OV2_EINVAL, "stride < width");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t item = (size_t)p->w * (size_t)p->h;
+    // device staging copy with a 16-byte-aligned pitch: the kernels then take their aligned-dword paths whatever the width
+    const size_t pitch = ((size_t)p->w + 15) & ~(size_t)15, item = pitch * (size_t)p->h;
     const int rc = ctx->reserve_device(item * (size_t)p->d.batch);
     if (rc != OV2_OK) return rc;
     if (p->d.batch > 1) OV2_REQUIRE(img_batch_stride >= (size_t)stride * (size_t)p->h, OV2_EINVAL, "img_batch_stride too small");
     for (int b = 0; b < p->d.batch; b++) {
-        OV2_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)ctx->d_scratch + item * b, (size_t)p->w,
+        OV2_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)ctx->d_scratch + item * b, pitch,
                                        img_h + img_batch_stride * b, (size_t)stride, (size_t)p->w, (size_t)p->h,
                                        hipMemcpyHostToDevice, ctx->stream));
     }
-    return ov2_launch_pyr_build(ctx, p, (const uint8_t *)ctx->d_scratch, p->w, item);
+    return ov2_launch_pyr_build(ctx, p, (const uint8_t *)ctx->d_scratch, (int)pitch, item);
 }
 
 static int pyr_download_impl(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h, int padded)

@@ -52,6 +52,24 @@ for b in range(3):
         a = pf.download(lvl, b, padded=True)[0]; c = ps.download(lvl, b, padded=True)[0]
         assert np.array_equal(a, c), (b, lvl)
         assert np.array_equal(pf.download(lvl, b, padded=True)[0], ref.level(lvl, padded=True)[0]), (b, lvl)
+# images whose rows are NOT 4-byte aligned (KITTI: 1241-byte rows; 103x57) through the device entry points: this is the
+# only way to reach the unaligned-source kernel instances (the host entry points stage with an aligned pitch)
+for (w, h), tiles in (((1241, 376), (24, 7)), ((103, 57), (3, 2)), ((751, 97), (15, 2))):
+    im = np.stack([synth.frame_pair(w, h, seed=s)[0] for s in (5, 6)] + [rng.integers(0, 256, (h, w), dtype=np.uint8)])
+    for off in (0, 1, 3):                                       # also a misaligned base address
+        buf = torch.zeros(im.size + 8, dtype=torch.uint8, device="cuda")
+        s_ = buf[off:off + im.size].view(3, h, w); s_.copy_(torch.from_numpy(im))
+        d_ = torch.empty((3, h, w), dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        L.check(ctx.lib.ov2_clahe_d(ctx.h, C.c_void_p(s_.data_ptr()), w, h, w, w * h, 3, 3.0, tiles[0], tiles[1], C.c_void_p(d_.data_ptr()), w, w * h))
+        pf = ov2slam_amd.Pyramid(ctx, w, h, 9, 3, batch=3).build_clahe_from_device(s_.data_ptr(), 3.0, tiles[0], tiles[1])
+        ctx.sync()
+        o = d_.cpu().numpy()
+        for b in range(3):
+            ref = O.clahe(im[b], 3.0, tiles[0], tiles[1])
+            assert np.array_equal(o[b], ref), (w, h, off, b)
+            rp = O.Pyramid(ref, 9, 3)
+            for lvl in range(pf.levels):
+                assert np.array_equal(pf.download(lvl, b, padded=True)[0], rp.level(lvl, padded=True)[0]), (w, h, off, b, lvl)
 print("DEVICE_PATH_OK")
 """
 
