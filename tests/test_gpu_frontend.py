@@ -222,3 +222,31 @@ def test_fbklt_batched_device_path_both_kernels():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _BATCH_SCRIPT, root], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BATCH_LK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_two_contexts_concurrently(oracle, euroc_pair):
+    """The library keeps no global mutable state: the SLAM thread and the mapper thread call fbKltTracking concurrently
+    (src/visual_front_end.cpp:196 / src/map_manager.cpp:510), each on its own context / HIP stream."""
+    import threading
+    d = euroc_pair
+    Rp, Rc = oracle.Pyramid(d["prev"], 9, 3), oracle.Pyramid(d["cur"], 9, 3)
+    ref = {lvl: oracle.fb_klt(Rp, Rc, 9, lvl, 30., 0.5, d["kps"], d["pri"])[:2] for lvl in (1, 3)}
+    errors = []
+
+    def worker(lvl):
+        try:
+            ctx = ov2slam_amd.Context(0)
+            trk = ov2slam_amd.FeatureTracker(ctx, 30, 0.01)
+            for _ in range(15):
+                Gp = ov2slam_amd.Pyramid(ctx, 752, 480, 9, 3).build(d["prev"])
+                Gc = ov2slam_amd.Pyramid(ctx, 752, 480, 9, 3).build(d["cur"])
+                out, st = trk.fbKltTracking(Gp, Gc, 9, lvl, 30., 0.5, d["kps"], d["pri"])
+                if not (np.array_equal(st, ref[lvl][1]) and np.array_equal(out.view(np.uint32), ref[lvl][0].view(np.uint32))):
+                    errors.append("mismatch in thread lvl=%d" % lvl)
+            ctx.close()
+        except Exception as e:                       # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(lvl,)) for lvl in (1, 3, 1, 3)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors[:3]
