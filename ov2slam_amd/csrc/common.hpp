@@ -40,9 +40,16 @@ struct ov2_ctx {
     // grow-only scratch (device + pinned host), reused across calls of this ctx
     void *d_scratch = nullptr;  size_t d_scratch_bytes = 0;
     void *h_scratch = nullptr;  size_t h_scratch_bytes = 0;
+    // LK statistics: work-groups add their (iterations, patch builds) into one of LK_STAT_SLOTS cache lines
+    // (same-address device atomics retire at ~6 ns each: 2 per work-group on one address would put a
+    // 200 us floor under a 16k-work-group launch); a one-block kernel folds the lines into the caller's pair.
+    unsigned long long *stat_slots = nullptr;
     int reserve_device(size_t bytes);
     int reserve_host(size_t bytes);
+    int reserve_stat_slots();
 };
+#define LK_STAT_SLOTS 256
+#define LK_STAT_STRIDE 16      // unsigned long long per slot (128 B)
 
 // ---- pyramid layout in HBM ---------------------------------------------------
 // One allocation per ov2_pyr holding `batch` items of identical layout.  Per

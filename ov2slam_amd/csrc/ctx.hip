@@ -65,6 +65,15 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, ov2_ctx *
     return OV2_OK;
 }
 
+int ov2_ctx::reserve_stat_slots()
+{
+    if (stat_slots) return OV2_OK;
+    const size_t bytes = (size_t)LK_STAT_SLOTS * LK_STAT_STRIDE * sizeof(unsigned long long);
+    OV2_HIP_CHECK(hipMalloc((void **)&stat_slots, bytes));
+    OV2_HIP_CHECK(hipMemsetAsync(stat_slots, 0, bytes, stream));
+    return OV2_OK;
+}
+
 int ov2_ctx_create(int device, ov2_ctx **out) { return ctx_create_common(device, nullptr, true, out); }
 
 int ov2_ctx_create_on_stream(int device, void *hip_stream, ov2_ctx **out)
@@ -78,6 +87,7 @@ void ov2_ctx_destroy(ov2_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->stat_slots) (void)hipFree(ctx->stat_slots);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
                                                 const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                 uint8_t *__restrict__ status, float *__restrict__ err_out,
                                                 int *__restrict__ iters_out, const int *__restrict__ n_per_item,
-                                                long long *__restrict__ stats)
+                                                unsigned long long *__restrict__ stats)
 {
     const int b = blockIdx.y;
     const int n = n_per_item ? n_per_item[b] : prm.n_max;
@@ -439,7 +439,25 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
     if (stats) {
         __syncthreads();
         if (threadIdx.x < 2 && s_stats[threadIdx.x])
-            atomicAdd((unsigned long long *)&stats[threadIdx.x], (unsigned long long)s_stats[threadIdx.x]);
+            atomicAdd(&stats[((blockIdx.y * gridDim.x + blockIdx.x) & (LK_STAT_SLOTS - 1)) * LK_STAT_STRIDE + threadIdx.x],
+                      (unsigned long long)s_stats[threadIdx.x]);
+    }
+}
+
+// folds (and clears) the per-slot partial sums of one LK launch into the caller's {iterations, patch builds}
+__global__ __launch_bounds__(LK_STAT_SLOTS) void k_lk_stats_fold(unsigned long long *__restrict__ slots, long long *__restrict__ stats)
+{
+    __shared__ unsigned long long s[2][LK_STAT_SLOTS / 64];
+    unsigned long long a = slots[threadIdx.x * LK_STAT_STRIDE], b = slots[threadIdx.x * LK_STAT_STRIDE + 1];
+    if (a) slots[threadIdx.x * LK_STAT_STRIDE] = 0;
+    if (b) slots[threadIdx.x * LK_STAT_STRIDE + 1] = 0;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = a; s[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long t = 0;
+        for (int w = 0; w < LK_STAT_SLOTS / 64; w++) t += s[threadIdx.x][w];
+        if (t) atomicAdd((unsigned long long *)&stats[threadIdx.x], t);
     }
 }
 
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
 int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int max_level, int max_iter, double eps2,
                        float min_eig_th, int flags, float err_th, float fb_dist, int do_fb, int n_max,
                        const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
-                       const int *n_per_item, long long *stats);
+                       const int *n_per_item, unsigned long long *stat_slots);
 
 // Kernel choice for the reference's window (9): the 3-lanes-per-keypoint kernel needs >= ~3000 wavefronts of
 // 20 keypoints to fill the 1024 SIMDs (offline batch-of-sequences mode); below that -- the single-sequence
@@ -465,7 +483,7 @@ static bool lk_use_row_kernel(long long points)
 template <int WIN>
 static void launch_fb_klt(hipStream_t s, dim3 grid, const PyrDesc &P, const PyrDesc &C, const LKParams &prm,
                           const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
-                          const int *n_per_item, long long *stats)
+                          const int *n_per_item, unsigned long long *stats)
 {
     hipLaunchKernelGGL(k_fb_klt<WIN>, grid, dim3(256), 0, s, P, C, prm, kps, priors, status, err, iters, n_per_item, stats);
 }
@@ -480,22 +498,29 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
     OV2_REQUIRE(P.lv[0].w == C.lv[0].w && P.lv[0].h == C.lv[0].h, OV2_EINVAL, "prev/cur image size differs");
     OV2_REQUIRE(prm.win == P.win, OV2_EINVAL, "LK window differs from the window the pyramid was padded for");
     dim3 grid((prm.n_max + 15) / 16, P.batch);
+    unsigned long long *slots = nullptr;
+    if (stats_d) {
+        if (int rc = ctx->reserve_stat_slots()) return rc;
+        slots = ctx->stat_slots;
+    }
     if (prm.win == 9 && !lk_use_row_kernel((long long)prm.n_max * P.batch)) {
         ov2_launch_fb_klt3(ctx->stream, P, C, prm.max_level, prm.max_iter, prm.eps2, prm.min_eig_th, prm.flags, prm.err_th,
-                           prm.fb_dist, prm.do_fb, prm.n_max, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d);
+                           prm.fb_dist, prm.do_fb, prm.n_max, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots);
+        if (slots) hipLaunchKernelGGL(k_lk_stats_fold, dim3(1), dim3(LK_STAT_SLOTS), 0, ctx->stream, slots, stats_d);
         OV2_HIP_CHECK(hipGetLastError());
         return OV2_OK;
     }
     switch (prm.win) {
-    case 5:  launch_fb_klt<5>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
-    case 7:  launch_fb_klt<7>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
-    case 9:  launch_fb_klt<9>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
-    case 11: launch_fb_klt<11>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
-    case 13: launch_fb_klt<13>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, stats_d); break;
+    case 5:  launch_fb_klt<5>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
+    case 7:  launch_fb_klt<7>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
+    case 9:  launch_fb_klt<9>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
+    case 11: launch_fb_klt<11>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
+    case 13: launch_fb_klt<13>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
     default:
         ov2_set_error("LK window %d has no kernel instance (supported: 5,7,9,11,13; the reference ships 9)", prm.win);
         return OV2_EUNSUPPORTED;
     }
+    if (slots) hipLaunchKernelGGL(k_lk_stats_fold, dim3(1), dim3(LK_STAT_SLOTS), 0, ctx->stream, slots, stats_d);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }

@@ -103,6 +103,9 @@ __device__ __forceinline__ void l3_lds_sync()
 // One row = one 16-byte + one 4-byte request (a lane's row never coalesces with its neighbours': the number of
 // L1 line look-ups, not bytes, bounds this phase).  Rows are addressed from one 64-bit base with a constant
 // stride; the clamp into the padded buffer is only evaluated when some keypoint of the wavefront needs it.
+#ifndef OV2_LK3_KO
+#define OV2_LK3_KO 0
+#endif
 template <bool CLAMP>
 __device__ __forceinline__ void l3_fetch_J_rows(uint32_t *slot, const uint8_t *jroi, const L3Lv &LJ, int xa, uint32_t sh, int jy0, int sub)
 {
@@ -118,6 +121,7 @@ __device__ __forceinline__ void l3_fetch_J_rows(uint32_t *slot, const uint8_t *j
                 y = y < -LJ.pady ? -LJ.pady : (y > LJ.h + LJ.pady - 1 ? LJ.h + LJ.pady - 1 : y);   // rows beyond the buffer are never consumed
                 p = jroi + (long long)y * LJ.img_pitch + xa;
             }
+            if (OV2_LK3_KO & 2) p = jroi + sub * 64 + k * 32;
             const u32x4 lo = *(const u32x4_a4 *)p;
             const uint32_t hi = *(const uint32_t *)(p + 16);
             u32x4 o;
@@ -133,6 +137,7 @@ __device__ __forceinline__ void l3_fetch_J(uint32_t *slot, const uint8_t *jroi, 
     const int xa = jx0 & ~3;
     const uint32_t sh = (uint32_t)(jx0 - xa);
     const bool outside = jy0 < -LJ.pady || jy0 + L3_JROWS - 1 > LJ.h + LJ.pady - 1;
+    if (OV2_LK3_KO & 16) return;
     if (__builtin_amdgcn_ballot_w64(outside) == 0) l3_fetch_J_rows<false>(slot, jroi, LJ, xa, sh, jy0, sub);
     else l3_fetch_J_rows<true>(slot, jroi, LJ, xa, sh, jy0, sub);
 }
@@ -145,13 +150,17 @@ struct L3State {
     int status;
     float err;
     int iters, visits;
+    // L3Slot -- what the keypoint's LDS slot holds after a level: region A (slot[0..47]) = 12 rows x 16 B of the level's
+    // template image from (ax0, ay0), region B (slot[48..111]) = 16 x 16 B of its search image from (bx0, by0)
 };
+// what the keypoint's LDS slot holds after a level (see L3State comment)
+struct L3Slot { int ax0, ay0, bx0, by0; };
 
 // One pyramid level for the keypoint owned by this 3-lane group; lane `sub` owns window rows 3 sub .. 3 sub + 2.
 __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, const L3Lv &LI,
                                          const uint8_t *__restrict__ itemJ, const L3Lv &LJ,
-                                         const LK3Params &prm, int level, bool scale_from_input,
-                                         float px0, float py0, int sub, uint32_t *slot, L3State &st)
+                                         const LK3Params &prm, int level, bool scale_from_input, bool reuse,
+                                         float px0, float py0, int sub, uint32_t *slot, L3State &st, L3Slot &sl)
 {
     constexpr int WIN = L3_WIN;
     const float halfWin = (float)(WIN - 1) * 0.5f;
@@ -182,10 +191,8 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
     // ---- stage both neighbourhoods (all global loads of this level are issued here) ----
     l3_lds_sync();                                                  // previous level's reads are done
     const uint8_t *iroi = itemI + LI.img_roi, *jroi = itemJ + LJ.img_roi;
-    const int ixa = (ipx - 1) & ~3;
-    const uint32_t ish = (uint32_t)((ipx - 1) - ixa);
-    {
-        // 12 rows, one 16-byte request each, rows sub + 3k from one base pointer (clamp only near the image border)
+    // 12 rows, one 16-byte request each, rows sub + 3k from one base pointer (clamp only near the image border)
+    auto fetch_I = [&](uint32_t *dst, int ixa) {
         const bool outside = ipy - 1 < -LI.pady || ipy - 1 + L3_IROWS - 1 > LI.h + LI.pady - 1;
         const bool clamp_rows = __builtin_amdgcn_ballot_w64(outside) != 0;
         const uint8_t *p0 = iroi + (long long)(ipy - 1 + sub) * LI.img_pitch + ixa;
@@ -198,16 +205,41 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 y = y < -LI.pady ? -LI.pady : (y > LI.h + LI.pady - 1 ? LI.h + LI.pady - 1 : y);     // only feeds derivatives of out-of-image rows (= 0)
                 p = iroi + (long long)y * LI.img_pitch + ixa;
             }
-            *(u32x4 *)(slot + 4 * sub + 12 * k) = *(const u32x4_a4 *)p;
+            if (OV2_LK3_KO & 1) p = iroi + sub * 64 + k * 16;
+            if (!(OV2_LK3_KO & 8)) *(u32x4 *)(dst + 4 * sub + 12 * k) = *(const u32x4_a4 *)p;
         }
-    }
-    int jx0, jy0;
-    {
+    };
+    const uint32_t *tsrc;                                           // template source rows (16 B each), first needed byte at `ish`
+    uint32_t ish;
+    int jx0, jy0, jb;                                               // search block: origin, LDS offset of its first row
+    if (!reuse) {
+        const int ixa = (ipx - 1) & ~3;
+        ish = (uint32_t)((ipx - 1) - ixa);
+        fetch_I(slot, ixa);
+        tsrc = slot;
+        sl.ax0 = ixa; sl.ay0 = ipy - 1;
         const float sx = nextx - halfWin, sy = nexty - halfWin;
         const int cx0 = l3_floor(fminf(fmaxf(sx, (float)(-WIN)), (float)(LJ.w - 1)));
         const int cy0 = l3_floor(fminf(fmaxf(sy, (float)(-WIN)), (float)(LJ.h - 1)));
-        jx0 = cx0 - L3_NBH_R; jy0 = cy0 - L3_NBH_R;
+        jx0 = cx0 - L3_NBH_R; jy0 = cy0 - L3_NBH_R; jb = 48;
         l3_fetch_J(slot, jroi, LJ, jx0, jy0, sub);
+    } else {
+        // Backward level 0 straight after forward level 0: the two images swap roles and the slot already holds
+        // them.  Region B (search block of the forward level, around the tracked position) contains the
+        // 12 x 12 template neighbourhood unless the last forward step left its 3-pixel margin; region A (template
+        // neighbourhood of the forward level, around the keypoint) is the search block of a backward track that
+        // stays within about a pixel of the keypoint -- the only tracks that pass the fb test.  No global load on
+        // the common path: the cache-line fills of these 28 rows were the larger part of a level-0 visit.
+        const int sx = ipx - 1 - sl.bx0, sy = ipy - 1 - sl.by0;
+        const bool inB = (unsigned)sx <= 3u && (unsigned)sy <= (unsigned)(L3_JROWS - L3_IROWS);
+        tsrc = slot + 48 + 4 * sy; ish = (uint32_t)sx;
+        if (!inB) {                                                 // refetch into region B (its content is of no use now)
+            const int ixa = (ipx - 1) & ~3;
+            ish = (uint32_t)((ipx - 1) - ixa);
+            fetch_I(slot + 48, ixa);
+            tsrc = slot + 48;
+        }
+        jx0 = sl.ax0; jy0 = sl.ay0; jb = 0;
     }
     l3_lds_sync();
 
@@ -224,7 +256,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         // soon as derivative rows j, j+1 exist.  E[m][i] = (p[2i], p[2i+1]) of image row m;
         // DX[d][i] = (dx[2i], dx[2i+1]) with column c <-> ipx + c.
         auto load_row = [&](int m, uint32_t (&e)[6]) {
-            const u32x4 w = *(const u32x4 *)(slot + 4 * (r0 + m));
+            const u32x4 w = *(const u32x4 *)(tsrc + 4 * (r0 + m));
             const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, ish), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, ish), d2 = __builtin_amdgcn_alignbyte(w.w, w.z, ish);
             e[0] = bytes01(d0); e[1] = bytes23(d0); e[2] = bytes01(d1); e[3] = bytes23(d1); e[4] = bytes01(d2); e[5] = bytes23(d2);
         };
@@ -282,6 +314,10 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
             }
         };
         uint32_t E0[6], E1[6], E2[6], E3[6], DXa[5], DYa[5], DXb[5], DYb[5];
+        if (OV2_LK3_KO & 4) {
+            for (int j = 0; j < L3_RPL; j++) for (int t = 0; t < 5; t++) { T.I[j][t] = slot[4 * r0 + j * 5 + t]; T.X[j][t] = T.I[j][t] >> 1; T.Y[j][t] = T.I[j][t] >> 2; }
+            s11 = s22 = 1 << 28; s12 = 0;
+        } else {
         load_row(0, E0); load_row(1, E1); load_row(2, E2);
         deriv_row(0, E0, E1, E2, DXa, DYa);
         load_row(3, E3);
@@ -293,6 +329,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         load_row(5, E1);                                            // E1 <- image row 5
         deriv_row(3, E3, E0, E1, DXb, DYb);
         window_row(2, E3, E0, DXa, DYa, DXb, DYb);                  // image rows 3, 4; derivative rows 2, 3
+        }
     }
     // per-lane partials: 27 * 4080^2 = 4.5e8 < 2^31
     const float A11 = (float)l3_sum3_exact(s11, sub) * FLT_SCALE;
@@ -328,8 +365,9 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 iw11 = (1 << 14) - iw00 - iw01 - iw10;
                 W01 = pack_lo16(iw00, iw01); W23 = pack_lo16(iw10, iw11);
                 int ox = inx - jx0, oy = iny - jy0;
-                if ((unsigned)ox > (unsigned)(2 * L3_NBH_R) || (unsigned)oy > (unsigned)(2 * L3_NBH_R)) {
-                    jx0 = inx - L3_NBH_R; jy0 = iny - L3_NBH_R;                // drifted: re-centre the block
+                // region B holds 16 rows (row offsets 0..6 leave the 10 the window needs), a reused region A 12 (0..2)
+                if ((unsigned)ox > (unsigned)(2 * L3_NBH_R) || (unsigned)oy > (jb ? (unsigned)(2 * L3_NBH_R) : (unsigned)(L3_IROWS - L3_WIN - 1))) {
+                    jx0 = inx - L3_NBH_R; jy0 = iny - L3_NBH_R; jb = 48;       // drifted: re-centre the block (always into region B)
                     l3_lds_sync();
                     l3_fetch_J(slot, jroi, LJ, jx0, jy0, sub);
                     l3_lds_sync();
@@ -337,7 +375,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 }
                 const uint32_t sh = (uint32_t)(ox & 3);
                 // source rows iny + 3 sub + m (m = 0..3), bytes [inx, inx + WIN]
-                const uint32_t *s0 = slot + 48 + 4 * (oy + 3 * sub) + (ox >> 2);
+                const uint32_t *s0 = slot + jb + 4 * (oy + 3 * sub) + (ox >> 2);
                 uint32_t P[4][9];                                              // P[m][x] = (p[x], p[x+1])
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
@@ -377,13 +415,14 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
             }
         }
     }
+    sl.bx0 = jx0; sl.by0 = jy0;
 }
 
 __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(PyrDesc P, PyrDesc C, LK3Params prm, int nbx,
                                                  const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                  uint8_t *__restrict__ status, float *__restrict__ err_out,
                                                  int *__restrict__ iters_out, const int *__restrict__ n_per_item,
-                                                 long long *__restrict__ stats)
+                                                 unsigned long long *__restrict__ stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[L3_KPB * L3_STRIDE];
     __shared__ unsigned int s_stats[2];
@@ -417,6 +456,7 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
         st.nx = (prm.flags & OV2_LK_USE_INITIAL_FLOW) ? pr.x : kp.x;
         st.ny = (prm.flags & OV2_LK_USE_INITIAL_FLOW) ? pr.y : kp.y;
         st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
+        L3Slot sl = {0, 0, 0, 0};
         int ok = 1;
         float fx = 0.f, fy = 0.f;
         int acc_iters = 0, acc_visits = 0;
@@ -435,6 +475,7 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
                 acc_iters = st.iters; acc_visits = st.visits; err_fwd = st.err;
                 if (!ok) break;
                 st.nx = kp.x; st.ny = kp.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
+                // (sl.ax0 .. sl.by0 keep describing the slot: forward level 0 staged both regions, or ok would be 0)
             }
             const int level = bwd ? 0 : prm.max_level - step;
             const bool top = bwd || step == 0;
@@ -447,7 +488,7 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
                 LJ.w = bwd ? a.w : c.w; LJ.h = bwd ? a.h : c.h; LJ.img_pitch = bwd ? a.img_pitch : c.img_pitch;
                 LJ.pady = bwd ? a.pady : c.pady; LJ.img_roi = bwd ? a.img_roi : c.img_roi;
             }
-            l3_level(itemI, LI, itemJ, LJ, prm, level, top, bwd ? fx : kp.x, bwd ? fy : kp.y, sub, slot, st);
+            l3_level(itemI, LI, itemJ, LJ, prm, level, top, bwd, bwd ? fx : kp.x, bwd ? fy : kp.y, sub, slot, st, sl);
         }
         if (prm.do_fb) {
             if (ok) {
@@ -476,7 +517,7 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
     if (stats) {
         __syncthreads();
         if (threadIdx.x < 2 && s_stats[threadIdx.x])
-            atomicAdd((unsigned long long *)&stats[threadIdx.x], (unsigned long long)s_stats[threadIdx.x]);
+            atomicAdd(&stats[(blockIdx.x & (LK_STAT_SLOTS - 1)) * LK_STAT_STRIDE + threadIdx.x], (unsigned long long)s_stats[threadIdx.x]);
     }
 }
 
@@ -484,7 +525,7 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
 int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int max_level, int max_iter, double eps2,
                        float min_eig_th, int flags, float err_th, float fb_dist, int do_fb, int n_max,
                        const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
-                       const int *n_per_item, long long *stats)
+                       const int *n_per_item, unsigned long long *stats)
 {
     LK3Params prm;
     prm.max_level = max_level; prm.max_iter = max_iter; prm.eps2 = eps2; prm.min_eig_th = min_eig_th; prm.flags = flags;

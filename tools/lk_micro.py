@@ -7,6 +7,8 @@ import torch
 import ov2slam_amd
 from ov2slam_amd import _lib as L
 import bench
+if os.environ.get("OV2_LK_MICRO_LIB"):          # knock-out experiments: time a variant build of the library
+    L.LIB_PATH = os.environ["OV2_LK_MICRO_LIB"]
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 views, kps, pri = bench.make_inputs(S, 1234)
@@ -28,7 +30,7 @@ for lvl, mi in ((3, 30), (3, 1), (3, 0), (0, 30), (0, 1), (0, 0), (1, 30)):
         p.copy_(p0); stats.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        L.check(lib.ov2_fb_klt_d(ctx.h, P0.h_pyr, P1.h_pyr, 9, lvl, mi, 0.01, 30.0, 0.5, vp(k), vp(p), NK, None, vp(st), vp(stats)))
+        L.check(lib.ov2_fb_klt_d(ctx.h, P0.h_pyr, P1.h_pyr, 9, lvl, mi, 0.01, 30.0, 0.5, vp(k), vp(p), NK, None, vp(st), None if os.environ.get('OV2_LK_MICRO_NOSTATS') else vp(stats)))
         e1.record(stream); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     it, vis = stats.tolist()
