@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libov2slam_hip.so")
+LIB_PATH = os.environ.get("OV2SLAM_HIP_LIB") or os.path.join(_HERE, "libov2slam_hip.so")   # override: A/B builds
 
 OV2_OK = 0
 OV2_EINVAL, OV2_EHIP, OV2_ENOMEM, OV2_EUNSUPPORTED, OV2_ENODEVICE = -1, -2, -3, -4, -5

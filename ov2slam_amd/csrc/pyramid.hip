@@ -13,6 +13,7 @@
 // read legal memory exactly like OpenCV's padded Mats and (b) the 5x5 / 3x3
 // stencils of the next kernel need no border logic when reading.
 #include "common.hpp"
+#include <limits.h>
 
 #pragma clang fp contract(off)
 
@@ -24,23 +25,37 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 // ---- level kernel ----------------------------------------------------------------------------
-// One launch per level L: a 128x32 tile of level L (+2 halo) is staged in LDS with aligned dword
-// loads; each thread then owns 4 pixels x 4 rows:
-//   (i)   L == 0 only: the level-0 copy (four aligned dword stores straight from the tile),
-//   (iii) level L+1 = pyrDown(level L): a 2x2 block of outputs (two 2-byte stores).
+// One launch per level L: a 256x32 tile of level L (+2 halo) is staged in LDS with aligned 8-byte
+// loads; each thread then owns 8 pixels x 4 rows:
+//   (i)   L == 0 only: the level-0 copy (aligned dword stores straight from the tile),
+//   (iii) level L+1 = pyrDown(level L): a 4x2 block of outputs (two dword stores).
 // Only ROI pixels are written here; the REFLECT_101 borders are filled by k_pyr_border (tiny).
 // HBM traffic per level-0 pixel: 1 B read, 1 B + 0.25 B written -- the reference's pyramid also
 // stores 4 B/px of derivatives, which this design never materialises.
-#define PT_W 128
+// Knock-out timing (PYR_KO) of the first version (128x32 tiles, 4x4 pixels per thread, 2-byte stores) showed
+// three additive costs -- load misses 80 us, 2-byte stores 50 us, LDS traffic + launch 46 us of 176 us at
+// 1024 x 752x480 -- and no arithmetic cost at all: a latency-bound kernel.  Hence wider work per thread (twice
+// the bytes in flight, dword stores, 3.5 instead of 5.25 LDS dwords per output).
+#ifndef PYR_KO
+#define PYR_KO 0                     // knock-out timing experiments (1: loads hit one line, 2: no stores, 4: no arithmetic)
+#endif
+#define PT_W 256
 #define PT_H 32
-#define PT_LDS_DW 34                 // (PT_W + 8) / 4 dwords per tile row: columns x0-4 .. x0+131
+#define PT_LDS_DW 66                 // (PT_W + 8) / 4 dwords per tile row: columns x0-4 .. x0+259
 #define PT_ROWS (PT_H + 4)           // rows y0-2 .. y0+33
 
-template <bool FROM_RAW>
+typedef uint32_t pyr_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t pyr_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// FUSE_BORDER: the work-group also writes the part of level L+1's REFLECT_101 border that mirrors its own outputs
+// (rows: every thread stores its dwords a second time at the mirrored row; columns: the first / last work-group of
+// a row rebuilds the left / right border dwords from the output tile kept in LDS).  The host falls back to
+// k_pyr_border when the last work-group column holds fewer than win + 1 output columns.
+template <bool FROM_RAW, bool FUSE_BORDER>
 __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const uint8_t *__restrict__ raw, int raw_stride,
                                                    long long raw_item_stride)
 {
-    __shared__ uint32_t tile[PT_ROWS][PT_LDS_DW];
+    __shared__ __attribute__((aligned(8))) uint32_t tile[PT_ROWS][PT_LDS_DW];
     const PyrLevelDesc L = P.lv[level];
     const int b = blockIdx.z;
     uint8_t *item = P.base + (long long)b * P.item_stride;
@@ -51,28 +66,35 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
     const uint8_t *src = FROM_RAW ? raw + (long long)b * raw_item_stride : item + L.img_roi;
     const bool aligned_src = FROM_RAW ? (((raw_stride | (int)(size_t)src) & 3) == 0) : true;
     // all loads of the tile are in flight before the first LDS store (a load -> store loop is latency-bound)
-    constexpr int NE = PT_ROWS * PT_LDS_DW, NPT = (NE + 255) / 256;
-    uint32_t stage[NPT];
+    constexpr int NE = PT_ROWS * (PT_LDS_DW / 2), NPT = (NE + 255) / 256;
+    pyr_u32x2 stage[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         const int e = tid + 256 * i;
-        const int row = e / PT_LDS_DW, dc = e - row * PT_LDS_DW;
-        const int gy = y0 - 2 + row, gx = x0 - 4 + 4 * dc;
-        uint32_t v = 0;
+        const int row = e / (PT_LDS_DW / 2), dc = e - row * (PT_LDS_DW / 2);
+        const int gy = y0 - 2 + row, gx = x0 - 4 + 8 * dc;
+        pyr_u32x2 v = {0u, 0u};
         if (e < NE) {
             if (FROM_RAW) {
                 const int sy = reflect101(gy, L.h);
                 const uint8_t *rp = src + sy * raw_stride;
-                if (aligned_src && gx >= 0 && gx + 3 < L.w) v = *(const uint32_t *)(rp + gx);
+                if (aligned_src && gx >= 0 && gx + 7 < L.w) v = *(const pyr_u32x2_a4 *)(rp + gx);
                 else {
+                    uint32_t lo = 0, hi = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v |= (uint32_t)rp[reflect101(gx + k, L.w)] << (8 * k);
+                    for (int k = 0; k < 4; k++) {
+                        lo |= (uint32_t)rp[reflect101(gx + k, L.w)] << (8 * k);
+                        hi |= (uint32_t)rp[reflect101(gx + 4 + k, L.w)] << (8 * k);
+                    }
+                    v.x = lo; v.y = hi;
                 }
             } else {
-                // padded source: its REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed)
+                // padded source: its REFLECT_101 border supplies the halo; clamp what lies beyond it (never consumed:
+                // the stencils reach 2 columns / rows past the ROI, the clamps start at win >= 3)
                 const int cy = min(max(gy, -P.win), L.h + P.win - 1);
-                const int cx = min(gx, L.w + P.win + 4) & ~3;
-                v = *(const uint32_t *)(src + cy * L.img_pitch + cx);
+                const int cx = min(gx, L.w + P.win) & ~3;                       // [cx, cx+8) stays inside the row (pitch slack 8)
+                if (PYR_KO & 1) v = *(const pyr_u32x2_a4 *)(src + (tid & 15) * 8);
+                else v = *(const pyr_u32x2_a4 *)(src + cy * L.img_pitch + cx);
             }
         }
         stage[i] = v;
@@ -80,52 +102,117 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
 #pragma unroll
     for (int i = 0; i < NPT; i++) {
         const int e = tid + 256 * i;
-        if (e < NE) (&tile[0][0])[e] = stage[i];
+        if (e < NE) ((pyr_u32x2 *)&tile[0][0])[e] = stage[i];
     }
     __syncthreads();
 
     const int ty = tid >> 5, tx = tid & 31;
-    const int x = x0 + 4 * tx, y = y0 + 4 * ty;          // this thread: pixels (x..x+3, y..y+3); tile rows 4ty+2 ..
-    if (x >= L.w || y >= L.h) return;
+    const int x = x0 + 8 * tx, y = y0 + 4 * ty;          // this thread: pixels (x..x+7, y..y+3); tile rows 4ty+2 .., dwords 2tx+1, 2tx+2
+    const bool inside = x < L.w && y < L.h;
+    if (!FUSE_BORDER && !inside) return;
 
     // ---- (i) level-0 copy ----
-    if (FROM_RAW) {
+    if (FROM_RAW && inside) {
         uint8_t *roi = item + L.img_roi;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int yy = y + rr;
             if (yy >= L.h) break;
-            const uint32_t v = tile[4 * ty + 2 + rr][tx + 1];
-            uint8_t *d = roi + yy * L.img_pitch + x;
-            if (x + 3 < L.w) *(uint32_t *)d = v;
-            else for (int j = 0; j < 4 && x + j < L.w; j++) d[j] = (uint8_t)(v >> (8 * j));
+#pragma unroll
+            for (int hx = 0; hx < 2; hx++) {
+                const int xx = x + 4 * hx;
+                const uint32_t v = tile[4 * ty + 2 + rr][2 * tx + 1 + hx];
+                uint8_t *d = roi + yy * L.img_pitch + xx;
+                if (xx + 3 < L.w) *(uint32_t *)d = v;
+                else for (int j = 0; j < 4 && xx + j < L.w; j++) d[j] = (uint8_t)(v >> (8 * j));
+            }
         }
     }
-    // ---- (iii) next level: 2x2 outputs (X..X+1, Y..Y+1), X = x/2, Y = y/2 ----
-    if (level + 1 < P.n_levels) {
-        const PyrLevelDesc N = P.lv[level + 1];
+    // ---- (iii) next level: 4x2 outputs (X..X+3, Y..Y+1), X = x/2, Y = y/2 ----
+    if (level + 1 >= P.n_levels) return;
+    const PyrLevelDesc N = P.lv[level + 1];
+    const int win = P.win;
+    __shared__ uint32_t otile[FUSE_BORDER ? PT_H / 2 : 1][FUSE_BORDER ? PT_W / 8 + 1 : 1];      // the work-group's outputs (border source)
+    uint8_t *nroi = item + N.img_roi;
+    // rows of the top / bottom border that mirror ROI row Y: -Y for 1 <= Y <= win, 2 (h-1) - Y for h-1-win <= Y <= h-2
+    auto mirror_rows = [&](int Yo, int &m0, int &m1) {
+        m0 = (Yo >= 1 && Yo <= win) ? -Yo : INT_MIN;
+        m1 = (Yo >= N.h - 1 - win && Yo <= N.h - 2) ? 2 * (N.h - 1) - Yo : INT_MIN;
+    };
+    if (inside) {
         const int X = x >> 1, Y = y >> 1;
-        // horizontal 5-tap sums of the seven rows y-2 .. y+4 at centre columns x and x+2
-        int h0[7], h1[7];
+        // horizontal 5-tap sums of the seven rows y-2 .. y+4 at centre columns x, x+2, x+4, x+6, on packed bytes:
+        // v_dot4_u32_u8 with the weights (1,4,6,4) over the 4 leftmost taps, a second one (weight 1) for the fifth.
+        // hp[r][k] = (h[2k], h[2k+1]) as two u16 (<= 16 * 255); the vertical pass stays in packed 16 bits:
+        // 16 * 4080 + 128 < 2^16.
+        uint32_t hp[7][2];
 #pragma unroll
         for (int r = 0; r < 7; r++) {
-            const uint32_t a = tile[4 * ty + r][tx], q = tile[4 * ty + r][tx + 1], c = tile[4 * ty + r][tx + 2];
-            const int m2 = (a >> 16) & 0xFF, m1 = a >> 24;                         // columns x-2, x-1
-            const int p0 = q & 0xFF, p1 = (q >> 8) & 0xFF, p2 = (q >> 16) & 0xFF, p3 = q >> 24;   // x .. x+3
-            const int p4 = c & 0xFF;                                               // x+4
-            h0[r] = p0 * 6 + (m1 + p1) * 4 + m2 + p2;
-            h1[r] = p2 * 6 + (p1 + p3) * 4 + p0 + p4;
+            const pyr_u32x2 w0 = *(const pyr_u32x2 *)&tile[4 * ty + r][2 * tx], w1 = *(const pyr_u32x2 *)&tile[4 * ty + r][2 * tx + 2];
+            const uint32_t a = w0.x, q0 = w0.y, q1 = w1.x, c = w1.y;              // columns x-4.., x.., x+4.., x+8..
+            const uint32_t l0 = __builtin_amdgcn_alignbyte(q0, a, 2), l2 = __builtin_amdgcn_alignbyte(q1, q0, 2);
+            const uint32_t h0 = __builtin_amdgcn_udot4(l0, 0x04060401u, __builtin_amdgcn_udot4(q0, 0x00010000u, 0u, false), false);
+            const uint32_t h1 = __builtin_amdgcn_udot4(q0, 0x04060401u, __builtin_amdgcn_udot4(q1, 0x00000001u, 0u, false), false);
+            const uint32_t h2 = __builtin_amdgcn_udot4(l2, 0x04060401u, __builtin_amdgcn_udot4(q1, 0x00010000u, 0u, false), false);
+            const uint32_t h3 = __builtin_amdgcn_udot4(q1, 0x04060401u, __builtin_amdgcn_udot4(c, 0x00000001u, 0u, false), false);
+            hp[r][0] = (PYR_KO & 4) ? q0 : (h0 | (h1 << 16));
+            hp[r][1] = (PYR_KO & 4) ? q1 : (h2 | (h3 << 16));
         }
-        uint8_t *nroi = item + N.img_roi;
+        typedef unsigned short pu16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int oy = 0; oy < 2; oy++) {
             if (Y + oy >= N.h) break;
             const int r = 2 * oy;                                                  // rows y-2+2oy .. y+2+2oy
-            const int v0 = (h0[r + 2] * 6 + (h0[r + 1] + h0[r + 3]) * 4 + h0[r] + h0[r + 4] + 128) >> 8;
-            const int v1 = (h1[r + 2] * 6 + (h1[r + 1] + h1[r + 3]) * 4 + h1[r] + h1[r + 4] + 128) >> 8;
-            uint8_t *d = nroi + (Y + oy) * N.img_pitch + X;
-            if (X + 1 < N.w) *(uint16_t *)d = (uint16_t)(v0 | (v1 << 8));         // X even, ROI origin / pitch even
-            else d[0] = (uint8_t)v0;
+            uint32_t vv[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const pu16x2 c2 = __builtin_bit_cast(pu16x2, hp[r + 2][k]), c1 = __builtin_bit_cast(pu16x2, hp[r + 1][k]), c3 = __builtin_bit_cast(pu16x2, hp[r + 3][k]);
+                const pu16x2 c0 = __builtin_bit_cast(pu16x2, hp[r][k]), c4 = __builtin_bit_cast(pu16x2, hp[r + 4][k]);
+                const pu16x2 v = (c2 * (unsigned short)6 + (c1 + c3) * (unsigned short)4 + c0 + c4 + (unsigned short)128) >> (unsigned short)8;
+                vv[k] = (PYR_KO & 4) ? hp[r][k] ^ hp[r + 4][k] : __builtin_bit_cast(uint32_t, v);
+            }
+            const uint32_t out = __builtin_amdgcn_perm(vv[1], vv[0], 0x06040200u);    // bytes (v0, v1, v2, v3)
+            if (FUSE_BORDER) otile[2 * ty + oy][tx] = out;
+            if ((PYR_KO & 2) && out != 0x12345678u) continue;
+            uint8_t *d = nroi + (Y + oy) * N.img_pitch + X;                         // X % 4 == 0, ROI origin 16-byte aligned
+            if (X + 3 < N.w) {
+                *(uint32_t *)d = out;
+                if (FUSE_BORDER) {
+                    int m0, m1;
+                    mirror_rows(Y + oy, m0, m1);
+                    if (m0 != INT_MIN) *(uint32_t *)(nroi + m0 * N.img_pitch + X) = out;
+                    if (m1 != INT_MIN) *(uint32_t *)(nroi + m1 * N.img_pitch + X) = out;
+                }
+            } else for (int j = 0; j < 4 && X + j < N.w; j++) d[j] = (uint8_t)(out >> (8 * j));    // (its mirrors: right-border items below)
+        }
+    }
+    if (FUSE_BORDER) {
+        // left / right border dwords of this work-group's output rows (and of the border rows mirroring them), same
+        // dword set as k_pyr_border: columns [-PB_LEFT, 0) and [w & ~3, (w + win + 3) & ~3)
+        const bool first = blockIdx.x == 0, last = blockIdx.x == gridDim.x - 1;
+        if (!first && !last) return;
+        __syncthreads();
+        const int PB_LEFT = (win + 3) & ~3, nl = first ? PB_LEFT >> 2 : 0;
+        const int rbeg = N.w & ~3, nr = last ? (((N.w + win + 3) & ~3) - rbeg) >> 2 : 0;
+        const int X0 = x0 >> 1, Y0 = y0 >> 1;
+        for (int e = tid; e < (PT_H / 2) * (nl + nr); e += 256) {
+            const int row = e / (nl + nr), dw = e - row * (nl + nr);
+            const int Yo = Y0 + row;
+            if (Yo >= N.h) break;
+            const int c0 = dw < nl ? 4 * dw - PB_LEFT : rbeg + 4 * (dw - nl);
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int c = c0 + k;
+                c = c < -win ? -win : (c > N.w + win - 1 ? N.w + win - 1 : c);            // padding bytes: any value
+                const int sc = reflect101(c, N.w) - X0;                                      // 0 <= sc < PT_W / 2 (host-checked)
+                v |= ((otile[row][sc >> 2] >> (8 * (sc & 3))) & 0xFFu) << (8 * k);
+            }
+            int m0, m1;
+            mirror_rows(Yo, m0, m1);
+            *(uint32_t *)(nroi + Yo * N.img_pitch + c0) = v;
+            if (m0 != INT_MIN) *(uint32_t *)(nroi + m0 * N.img_pitch + c0) = v;
+            if (m1 != INT_MIN) *(uint32_t *)(nroi + m1 * N.img_pitch + c0) = v;
         }
     }
 }
@@ -205,16 +292,19 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
     for (int l = 0; l < P.n_levels; l++) {
         const PyrLevelDesc &L = P.lv[l];
         dim3 grid((L.w + PT_W - 1) / PT_W, (L.h + PT_H - 1) / PT_H, P.batch);
+        // the level kernel writes level l+1's border itself when the last work-group column owns >= win + 1 output columns
+        const bool has_next = l + 1 < P.n_levels;
+        const bool fuse = has_next && P.lv[l + 1].w - (PT_W / 2) * ((int)grid.x - 1) >= P.win + 1;
         if (l == 0 && img_d) {
-            hipLaunchKernelGGL(k_pyr_level<true>, grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
+            if (fuse) hipLaunchKernelGGL((k_pyr_level<true, true>), grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
+            else hipLaunchKernelGGL((k_pyr_level<true, false>), grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
             border(0);
-        } else if (l == 0) {
-            // level 0 and its border were written in place by the producer (ov2_pyr_build_clahe_d): pyrDown from the padded image
-            if (P.n_levels > 1) hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, 0, (const uint8_t *)nullptr, 0, 0LL);
-        } else if (l + 1 < P.n_levels) {
-            hipLaunchKernelGGL(k_pyr_level<false>, grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
+        } else if (has_next) {
+            // l == 0: level 0 and its border were written in place by the producer (ov2_pyr_build_clahe_d): pyrDown from the padded image
+            if (fuse) hipLaunchKernelGGL((k_pyr_level<false, true>), grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
+            else hipLaunchKernelGGL((k_pyr_level<false, false>), grid, dim3(256), 0, ctx->stream, P, l, (const uint8_t *)nullptr, 0, 0LL);
         }
-        if (l + 1 < P.n_levels) border(l + 1);       // level l+1 was just produced
+        if (has_next && !fuse) border(l + 1);        // level l+1 was just produced
     }
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
