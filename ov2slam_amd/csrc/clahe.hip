@@ -42,6 +42,9 @@ __device__ __forceinline__ void clahe_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef CLAHE_KO
+#define CLAHE_KO 0        // knock-out timing experiments. lut: 1 loads hit one line, 2 no ds_add, 4 no clip/scan tail;
+#endif                    // apply: 8 loads hit, 16 no stores, 32 no LUT look-ups, 64 no blend
 #define CH_COPIES 8
 #define CH_STRIDE 260                 // dwords per copy: 256 + 4 (bank stagger, keeps 16-byte alignment)
 #define CH_WAVE_DW (CH_COPIES * CH_STRIDE + 256)      // + scratch copy for out-of-tile bytes
@@ -54,14 +57,13 @@ template <bool SRC_ALIGNED>          // true: rows and base are 4-byte aligned (
 __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
 {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
     const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * gridDim.x;
     const int b = blockIdx.y;
     uint32_t *hw = hist_all[wave];
     const uint8_t *img = src + (long long)b * P.src_item_stride;
     const int sub = lane >> 4, l16 = lane & 15;
     uint32_t *hist = hw + ((sub << 1) | (l16 & 1)) * CH_STRIDE;
-    uint32_t *trash = hw + CH_COPIES * CH_STRIDE;
     const bool fast_geom = P.tw <= 61 && P.th <= 64;
     // Rows are fetched as ALIGNED dwords whatever the alignment of the image (KITTI: 1241-byte rows): dword l16 of
     // the row segment starts `ph` bytes before the first tile byte, ph = (address of that byte) & 3, per row.
@@ -70,10 +72,34 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
 
     // a wavefront walks over several tiles; the 16 row-dwords of the NEXT tile are requested before the
     // current one is histogrammed, so the global round trip hides behind the LDS work
-    auto tile_fast = [&](int t) { const int tx = t % P.tiles_x; return fast_geom && (tx + 1) * P.tw <= P.w; };
+    // Tiles of the last column hang over the right image edge (REFLECT_101 padding of the reference's copyMakeBorder):
+    // padded column w + k is column w - 2 - k, i.e. the columns (2w - 2 - x_end, w - 2] of such a tile count TWICE and
+    // the columns >= w not at all -- per-byte weights 0 / 1 / 2 instead of a byte-wise walk (which, at 1/15 of the
+    // tiles, took half of this kernel's time: ~56 dependent byte loads per lane).
+    // (needs the mirror sources of a tile's padded columns inside the same tile: x_begin + x_end <= 2w - 1)
+    auto tile_fast = [&](int t) { const int xb = (t % P.tiles_x) * P.tw; return fast_geom && 2 * xb + P.tw <= 2 * P.w - 1; };
+    // (knock-out timing: with the loads hitting one cache line AND without the ds_adds the kernel still took 80 % of
+    // its time -- it is bound by the ~1000 instructions a wavefront issues per tile, a third of them the address
+    // arithmetic and predicates of these 16 loads; hence the wave-uniform fast path below)
+    const uint32_t lane_off = (uint32_t)(sub * P.stride + 4 * l16);
     auto tile_load = [&](int t, uint32_t (&vv)[16], uint32_t &phs) {
         const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
         const int x_begin = tx * P.tw;
+        if (SRC_ALIGNED && !(CLAHE_KO & 1) && (ty * P.th + 64 <= P.h) && (long long)P.h * P.stride < (1ll << 31)) {
+            // all 64 candidate rows lie inside the image: one scalar base, one 32-bit lane offset, no per-row tests
+            // (rows >= th are fetched and ignored; lanes right of the tile stay masked: the row may end there)
+            const uint32_t ph = (uint32_t)(x_begin & 3);
+            phs = ph * 0x55555555u;
+            const uint8_t *tp = img + (long long)(ty * P.th) * P.stride + (x_begin & ~3);
+            // lanes right of the tile re-read the row's first dword (the row may end at the tile edge); never counted
+            uint32_t off = (4 * l16 < P.tw + (int)ph && (x_begin & ~3) + 4 * l16 < P.w) ? lane_off : (uint32_t)(sub * P.stride);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                vv[i] = *(const uint32_t *)(tp + off);
+                off += 4u * (uint32_t)P.stride;
+            }
+            return;
+        }
         const int ybase = ty * P.th + sub;
         phs = 0;
 #pragma unroll
@@ -85,13 +111,15 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
             if (SRC_ALIGNED) {
                 const uint32_t ph = (uint32_t)(x_begin & 3);          // rows and base aligned: the phase is the tile's column phase
                 phs |= ph << (2 * i);
-                if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph) v = *(const uint32_t *)(img + y * P.stride + (x_begin & ~3) + 4 * l16);
+                if (CLAHE_KO & 1) { if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph && (x_begin & ~3) + 4 * l16 < P.w) v = *(const uint32_t *)(img + 4 * l16); }
+                else
+                if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph && (x_begin & ~3) + 4 * l16 < P.w) v = *(const uint32_t *)(img + y * P.stride + (x_begin & ~3) + 4 * l16);
             } else {
                 const uint8_t *rp = img + (long long)y * P.stride + x_begin;
                 const uint32_t ph = (uint32_t)((size_t)rp & 3);
                 phs |= ph << (2 * i);
                 const uint8_t *ap = rp - ph + 4 * l16;
-                if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph) {  // this dword holds at least one byte of the tile row
+                if (4 * i + sub < P.th && 4 * l16 < P.tw + (int)ph && x_begin - (int)ph + 4 * l16 < P.w) {  // this dword holds at least one byte of the tile row
                     if (ap + 4 <= img_end) v = *(const uint32_t *)ap;
                     else for (int k = 0; k < 4; k++) if (ap + k < img_end) v |= (uint32_t)ap[k] << (8 * k);
                 }
@@ -114,23 +142,30 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
         if (tile_fast(t)) {
             // byte k of this lane's dword is tile column 4*l16 + k - ph; bytes outside [0, tw) are counted into the
             // scratch copy instead of being branched around
-            auto sel = [&](int p) { return (unsigned)p < (unsigned)P.tw ? hist : trash; };
+            // weight of tile column p (image column x_begin + p): see tile_fast
+            const int dbl_lo = 2 * P.w - 2 - (x_begin + P.tw);      // columns in (dbl_lo, w - 2] also stand for a padded column
+            auto wgt = [&](int p) { const int c = x_begin + p; return ((unsigned)p < (unsigned)P.tw && c < P.w) ? ((c > dbl_lo && c <= P.w - 2) ? 2u : 1u) : 0u; };
+            const uint32_t hist_o = (uint32_t)(((sub << 1) | (l16 & 1)) * CH_STRIDE), trash_o = CH_COPIES * CH_STRIDE;   // dword offsets in hw
+            auto sel = [&](int p) { return wgt(p) ? hist_o : trash_o; };
             const int p_same = 4 * l16 - (int)(cur_ph & 3);
-            uint32_t *h0 = sel(p_same), *h1 = sel(p_same + 1), *h2 = sel(p_same + 2), *h3 = sel(p_same + 3);
+            uint32_t h0 = sel(p_same), h1 = sel(p_same + 1), h2 = sel(p_same + 2), h3 = sel(p_same + 3);
+            uint32_t w0 = wgt(p_same), w1 = wgt(p_same + 1), w2 = wgt(p_same + 2), w3 = wgt(p_same + 3);
             bool mine = p_same < P.tw;                              // this lane's dword holds at least one tile byte
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (!same_phase) {                                   // wave-uniform: rows of an unaligned image differ in phase
                     const int p0 = 4 * l16 - (int)((cur_ph >> (2 * i)) & 3);
                     h0 = sel(p0); h1 = sel(p0 + 1); h2 = sel(p0 + 2); h3 = sel(p0 + 3);
+                    w0 = wgt(p0); w1 = wgt(p0 + 1); w2 = wgt(p0 + 2); w3 = wgt(p0 + 3);
                     mine = p0 < P.tw;
                 }
                 if (mine && 4 * i + sub < P.th) {
                     const uint32_t v = cur[i];
-                    atomicAdd(&h0[v & 0xFF], 1u);
-                    atomicAdd(&h1[(v >> 8) & 0xFF], 1u);
-                    atomicAdd(&h2[(v >> 16) & 0xFF], 1u);
-                    atomicAdd(&h3[v >> 24], 1u);
+                    if (CLAHE_KO & 2) { if (v == 0x12345678u) hw[h0] = 1; continue; }
+                    atomicAdd(&hw[h0 + (v & 0xFF)], w0);
+                    atomicAdd(&hw[h1 + ((v >> 8) & 0xFF)], w1);
+                    atomicAdd(&hw[h2 + ((v >> 16) & 0xFF)], w2);
+                    atomicAdd(&hw[h3 + (v >> 24)], w3);
                 }
             }
         } else {
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
             hv[0] += (int)q.x; hv[1] += (int)q.y; hv[2] += (int)q.z; hv[3] += (int)q.w;
         }
         clahe_wave_sync();                                            // the copies may be cleared for the next tile
-        if (P.clip > 0) {
+        if (P.clip > 0 && !(CLAHE_KO & 4)) {
             int over = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) { over += max(hv[k] - P.clip, 0); hv[k] = min(hv[k], P.clip); }
@@ -251,14 +286,16 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
         }
         const c_f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
         const bool full = dst_aligned && xb + 3 < P.w;
-        for (int yb = y0; yb < y1; yb += CA_UNROLL) {
-            // issue the loads of CA_UNROLL rows before consuming any (the row loop is latency-bound otherwise)
-            uint32_t inr[CA_UNROLL];
+        // the loads of the NEXT CA_UNROLL rows are issued before the current ones are consumed: with ~8 waves per
+        // SIMD the loaded HBM round trip (several us at this traffic) is not covered by the other waves alone
+        auto load_rows = [&](int yb, uint32_t (&inr)[CA_UNROLL]) {
 #pragma unroll
             for (int u = 0; u < CA_UNROLL; u++) {
                 const int y = min(yb + u, y1 - 1);
                 const uint8_t *sp = simg + (long long)y * P.stride + xb;
                 uint32_t in = 0;
+                if (CLAHE_KO & 8) in = *(const uint32_t *)(simg + (tid & 15) * 4);
+                else
                 if (src_aligned && xb + 3 < P.w) in = *(const uint32_t *)sp;
                 else {
                     const uint32_t ph = (uint32_t)((size_t)sp & 3);
@@ -270,6 +307,11 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
                 }
                 inr[u] = in;
             }
+        };
+        uint32_t inr[CA_UNROLL], nxt[CA_UNROLL];
+        if (y0 < y1) load_rows(y0, inr);
+        for (int yb = y0; yb < y1; yb += CA_UNROLL) {
+            if (yb + CA_UNROLL < y1) load_rows(yb + CA_UNROLL, nxt);
 #pragma unroll
             for (int u = 0; u < CA_UNROLL; u++) {
                 const int y = yb + u;
@@ -279,7 +321,9 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
                 const c_f32x2 YA = {ya, ya}, YB = {ya1, ya1};
                 uint8_t *drow = dimg + y * P.dst_stride;
                 const uint32_t in = inr[u];
-                const uint32_t q0 = lutc[0][in & 0xFF], q1 = lutc[1][(in >> 8) & 0xFF], q2 = lutc[2][(in >> 16) & 0xFF], q3 = lutc[3][in >> 24];
+                uint32_t q0, q1, q2, q3;
+                if (CLAHE_KO & 32) { q0 = in; q1 = in >> 1; q2 = in >> 2; q3 = in >> 3; }
+                else { q0 = lutc[0][in & 0xFF]; q1 = lutc[1][(in >> 8) & 0xFF]; q2 = lutc[2][(in >> 16) & 0xFF]; q3 = lutc[3][in >> 24]; }
                 // res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya, pixels (0,1) and (2,3) side by side
                 const c_f32x2 A11 = {c_ub(q0, 0), c_ub(q1, 0)}, A12 = {c_ub(q0, 1), c_ub(q1, 1)}, A21 = {c_ub(q0, 2), c_ub(q1, 2)}, A22 = {c_ub(q0, 3), c_ub(q1, 3)};
                 const c_f32x2 B11 = {c_ub(q2, 0), c_ub(q3, 0)}, B12 = {c_ub(q2, 1), c_ub(q3, 1)}, B21 = {c_ub(q2, 2), c_ub(q3, 2)}, B22 = {c_ub(q2, 3), c_ub(q3, 3)};
@@ -290,9 +334,13 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
                 out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.y), 1, out);
                 out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.x), 2, out);
                 out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.y), 3, out);
+                if (CLAHE_KO & 64) out = q0 ^ q1 ^ q2 ^ q3;
+                if ((CLAHE_KO & 16) && out != 0x12345678u) continue;
                 if (full) *(uint32_t *)(drow + xb) = out;
                 else for (int k = 0; k < 4; k++) if (xb + k < P.w) drow[xb + k] = (uint8_t)(out >> (8 * k));
             }
+#pragma unroll
+            for (int u = 0; u < CA_UNROLL; u++) inr[u] = nxt[u];
         }
     }
     if (P.border > 0) {
