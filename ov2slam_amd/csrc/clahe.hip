@@ -296,7 +296,9 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
                 uint32_t in = 0;
                 if (CLAHE_KO & 8) in = *(const uint32_t *)(simg + (tid & 15) * 4);
                 else
-                if (src_aligned && xb + 3 < P.w) in = *(const uint32_t *)sp;
+                // aligned rows: the dword at xb lies inside the row's stride even when w % 4 != 0 (stride % 4 == 0 > w); no
+                // branch here, so that the compiler can count the loads in flight (vmcnt(CA_UNROLL) instead of vmcnt(0))
+                if (src_aligned) in = *(const uint32_t *)sp;
                 else {
                     const uint32_t ph = (uint32_t)((size_t)sp & 3);
                     const uint8_t *ap = sp - ph;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
         uint32_t inr[CA_UNROLL], nxt[CA_UNROLL];
         if (y0 < y1) load_rows(y0, inr);
         for (int yb = y0; yb < y1; yb += CA_UNROLL) {
-            if (yb + CA_UNROLL < y1) load_rows(yb + CA_UNROLL, nxt);
+            load_rows(yb + CA_UNROLL, nxt);                         // unconditional (row index clamped): one path, exact vmcnt
 #pragma unroll
             for (int u = 0; u < CA_UNROLL; u++) {
                 const int y = yb + u;
