@@ -62,7 +62,18 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __bu
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)); }
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a, short c) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) * c); }
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false); }
+// a.lo * b.lo + a.hi * b.hi without an accumulator: the VOP3P encoding with the inline constant 0 (the compiler
+// only selects the two-address v_dot2c form, which costs a v_mov to clear the destination first)
+__device__ __forceinline__ int dot2z(uint32_t a, uint32_t b) { int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint32_t pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }   // (lo & 0xFFFF) | (hi << 16)
+// ((S0 + 256) >> 9, (S1 + 256) >> 9) as two u16 for bilinear sums S (-256 <= S < 2^23): (S + 256) >> 9 == ((S >> 8) + 1) >> 1,
+// so one byte permute (S >> 8 of both), one packed add and one packed shift replace two 32-bit shifts, a pack and
+// the two accumulator initialisations (v_dot2c needs its rounding constant moved into the destination first)
+__device__ __forceinline__ uint32_t round9_pair(int s0, int s1)
+{
+    const uint32_t hi8 = __builtin_amdgcn_perm((uint32_t)s1, (uint32_t)s0, 0x06050201u);
+    return __builtin_bit_cast(uint32_t, (u16x2)((__builtin_bit_cast(u16x2, hi8) + (unsigned short)1) >> (unsigned short)1));
+}
 __device__ __forceinline__ uint32_t odd_pair(uint32_t e_next, uint32_t e) { return __builtin_amdgcn_alignbyte(e_next, e, 2); }             // (e.hi, e_next.lo)
 __device__ __forceinline__ uint32_t bytes01(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); }                                 // (b0, b1) as two u16
 __device__ __forceinline__ uint32_t bytes23(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }                                 // (b2, b3)
@@ -294,7 +305,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 const int k = x + 1;                                // pixel pair (p[x+1], p[x+2]) of image rows j+1 (top), j+2 (bottom)
                 const uint32_t pt = (k & 1) ? odd_pair(et[(k >> 1) + 1], et[k >> 1]) : et[k >> 1];
                 const uint32_t pb = (k & 1) ? odd_pair(eb[(k >> 1) + 1], eb[k >> 1]) : eb[k >> 1];
-                iv[x] = dot2(pt, W01, dot2(pb, W23, 1 << 8)) >> 9;
+                iv[x] = dot2(pt, W01, dot2z(pb, W23));             // rounded and packed by round9_pair below
                 const uint32_t xt = (x & 1) ? odd_pair(dxt[(x >> 1) + 1], dxt[x >> 1]) : dxt[x >> 1];   // (d[x], d[x+1]) of rows j, j+1
                 const uint32_t xb = (x & 1) ? odd_pair(dxb[(x >> 1) + 1], dxb[x >> 1]) : dxb[x >> 1];
                 const uint32_t yt = (x & 1) ? odd_pair(dyt[(x >> 1) + 1], dyt[x >> 1]) : dyt[x >> 1];
@@ -305,7 +316,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
             iv[WIN] = 0; xv[WIN] = 0; yv[WIN] = 0;
 #pragma unroll
             for (int t = 0; t < 5; t++) {
-                T.I[j][t] = pack_lo16(iv[2 * t], iv[2 * t + 1]);
+                T.I[j][t] = round9_pair(iv[2 * t], iv[2 * t + 1]);
                 T.X[j][t] = pack_lo16(xv[2 * t], xv[2 * t + 1]);
                 T.Y[j][t] = pack_lo16(yv[2 * t], yv[2 * t + 1]);
                 s11 = dot2(T.X[j][t], T.X[j][t], s11);
@@ -390,11 +401,11 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 for (int j = 0; j < L3_RPL; j++) {
                     int v[WIN + 1];
 #pragma unroll
-                    for (int x = 0; x < WIN; x++) v[x] = dot2(P[j][x], W01, dot2(P[j + 1][x], W23, 1 << 8)) >> 9;
+                    for (int x = 0; x < WIN; x++) v[x] = dot2(P[j][x], W01, dot2z(P[j + 1][x], W23));
                     v[WIN] = 0;
 #pragma unroll
                     for (int t = 0; t < 5; t++) {
-                        const uint32_t diff = pk_sub(pack_lo16(v[2 * t], v[2 * t + 1]), T.I[j][t]);
+                        const uint32_t diff = pk_sub(round9_pair(v[2 * t], v[2 * t + 1]), T.I[j][t]);
                         sb1 = dot2(diff, T.X[j][t], sb1);
                         sb2 = dot2(diff, T.Y[j][t], sb2);
                     }
