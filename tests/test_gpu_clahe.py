@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("wh,tiles,clip", [((752, 480), (15, 9), 3.0), ((1241, 376), (24, 7), 2.0), ((640, 480), (12, 9), 3.0),
-                                            ((96, 64), (4, 4), 40.0), ((100, 50), (2, 1), 0.0), ((103, 57), (3, 2), 1.0)])
+                                            ((96, 64), (4, 4), 40.0), ((100, 50), (2, 1), 0.0), ((103, 57), (3, 2), 1.0),
+                                            # 41 padded columns over 3-pixel tiles: tiles whose mirror sources lie in OTHER tiles (byte-wise path)
+                                            ((100, 50), (47, 3), 2.0), ((333, 90), (10, 4), 4.0)])
 def test_clahe_bit_exact(gpu_ctx, oracle, wh, tiles, clip):
     w, h = wh
     img, _, _ = synth.frame_pair(w, h, seed=w * 3 + h)

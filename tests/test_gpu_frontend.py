@@ -24,7 +24,9 @@ def _pyr_pair(ctx, oracle, img, win=9, lvl=3):
     return G, R
 
 
-@pytest.mark.parametrize("wh", [(752, 480), (1241, 376), (95, 61), (40, 40)])
+# (264, 100) and (530, 70): the last work-group column of level 1 owns fewer than win + 1 columns, so the level kernel
+# cannot mirror the right border itself and the stand-alone border kernel runs (pyramid.hip: fuse condition)
+@pytest.mark.parametrize("wh", [(752, 480), (1241, 376), (95, 61), (40, 40), (264, 100), (530, 70)])
 def test_pyramid_bit_exact(gpu_ctx, oracle, wh):
     w, h = wh
     rng = np.random.default_rng(11)
@@ -104,6 +106,32 @@ def test_fbklt_edge_cases(gpu_ctx, oracle):
         rout, rst, _ = oracle.fb_klt(Rp, Rc, 9, lvl, 30., 0.5, kps, pri)
         assert np.array_equal(gst, rst)
         _assert_same_float_bits(gout, rout, "edge-case positions (lvl %d)" % lvl)
+
+
+@pytest.mark.parametrize("nbpyrlvl", [0, 1])
+def test_fbklt_backward_reuse_and_refetch_paths(gpu_ctx, oracle, nbpyrlvl):
+    """lk3.hip runs the backward level 0 from the neighbourhoods the forward level left in LDS.  Cover the common
+    path (small forward motion) together with the ones that leave it: forward Gauss-Newton walks of several pixels
+    at level 0 (search block re-centred, template neighbourhood no longer inside it -> refetch), and a current
+    image whose content near some keypoints is shifted back so that the backward track drifts off the reused block."""
+    rng = np.random.default_rng(5)
+    prev, cur, flow = synth.frame_pair(752, 480, seed=31, shift=(1.3, -0.8), theta=0.002)
+    cur = cur.copy()
+    cur[200:260, 300:420] = np.roll(cur[200:260, 300:420], 3, axis=1)      # locally inconsistent motion
+    Gp, Rp = _pyr_pair(gpu_ctx, oracle, prev)
+    Gc, Rc = _pyr_pair(gpu_ctx, oracle, cur)
+    kps = synth.grid_keypoints(752, 480, 25, rng)
+    trk = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01)
+    travelled = 0
+    for sigma in (0.2, 2.5, 6.0):
+        pri = (flow(kps) + rng.normal(0, sigma, kps.shape)).astype(np.float32)
+        gout, gst, gstats = trk.fbKltTracking(Gp, Gc, 9, nbpyrlvl, 30., 0.5, kps, pri, return_stats=True)
+        rout, rst, rstats = oracle.fb_klt(Rp, Rc, 9, nbpyrlvl, 30., 0.5, kps, pri)
+        assert np.array_equal(gst, rst)
+        _assert_same_float_bits(gout, rout, "positions (prior sigma %.1f)" % sigma)
+        assert gstats[0] == rstats[0] and gstats[1] == rstats[1]
+        travelled += int((np.abs(gout - pri).max(axis=1)[gst > 0] > 4.0).sum())
+    assert travelled > 20            # some tracked points did walk more than the 3-pixel margin of the search block
 
 
 def test_fbklt_empty_is_noop(gpu_ctx, oracle):
