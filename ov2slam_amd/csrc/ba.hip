@@ -678,6 +678,21 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #define CH_NB 32
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
 
+// lower triangle of S, one thread per entry, many workgroups (latency-bound gathers from H and G)
+__global__ __launch_bounds__(256) void k_ba_assemble(BADev D)
+{
+    const BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    const int n = D.nf, ld = D.nfp;
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j > i) return;                                      // lower triangle only
+    const int gi = (i / BA_TILE <= j / BA_TILE) ? i : j, gj = (i / BA_TILE <= j / BA_TILE) ? j : i;   // G holds upper tiles
+    double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)j * ld + i] - D.G[(long long)gi * ld + gj]);   // H: upper triangle (j <= i)
+    if (i == j) val += D.diag_f[i] / ctl->radius;
+    D.S[(long long)i * ld + j] = val;
+    (void)n;
+}
+
 __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 {
     BACtl *ctl = D.ctl;
@@ -690,17 +705,10 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     const int wave = tid >> 6, lane = tid & 63;
     __shared__ int s_fail;
     __shared__ double s_red[32][33];
-    const double radius = ctl->radius;
+    __shared__ double s_rdiag[CH_NB];                        // 1 / L11[j][j] of the current diagonal block
     double *S = D.S;
     double *Linv = D.Linv;                                  // (nfp / 32) blocks of 32 x 32 (row-major), inverse diagonal blocks
-    for (int e = tid; e < n * n; e += nt) {
-        const int i = e / n, j = e - i * n;
-        if (j > i) continue;                               // lower triangle only
-        const int gi = (i / BA_TILE <= j / BA_TILE) ? i : j, gj = (i / BA_TILE <= j / BA_TILE) ? j : i;   // G holds upper tiles
-        double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)j * ld + i] - D.G[(long long)gi * ld + gj]);   // H: upper triangle (j <= i)
-        if (i == j) val += D.diag_f[i] / radius;
-        S[(long long)i * ld + j] = val;
-    }
+    // (S was assembled by k_ba_assemble: in here, one workgroup walking the n^2 entries took 85 us of latency)
     for (int i = tid; i < D.nfp; i += nt) yv[i] = i < n ? D.scale_f[i] * (D.bf[i] - D.v[i]) : 0.0;
     if (tid == 0) s_fail = 0;
     __syncthreads();
@@ -717,9 +725,19 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
             L11[i * CH_LDP + j] = v;
         }
-        for (int e = tid; e < m * CH_NB; e += nt) {
-            const int t = e >> 5, j = e & 31;
-            P[t * CH_LDP + j] = j < nb ? S[(long long)(k0 + nb + t) * ld + k0 + j] : 0.0;
+        // (eight loads in flight per thread: a load -> LDS store loop pays one L2 round trip per element)
+        for (int e0 = tid; e0 < m * CH_NB; e0 += 8 * nt) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * nt, t = e >> 5, j = e & 31;
+                v[u] = (e < m * CH_NB && j < nb) ? S[(long long)(k0 + nb + t) * ld + k0 + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * nt;
+                if (e < m * CH_NB) P[(e >> 5) * CH_LDP + (e & 31)] = v[u];
+            }
         }
         __syncthreads();
         // (b) wavefront 0: left-looking factorisation, lane i owns row i in registers; one LDS sync per column
@@ -742,6 +760,9 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                 wave_lds_sync();
             }
             if (fail && lane == 0) s_fail = 1;
+            // reciprocal pivots for the panel solve and the block inverse: one division per pivot instead of one per
+            // (row, pivot) -- an fp64 division is ~30 instructions, and 32 of them were half of the panel solve
+            if (lane < CH_NB) s_rdiag[lane] = 1.0 / L11[lane * CH_LDP + lane];
         }
         __syncthreads();
         CH_TICK(1);
@@ -756,7 +777,7 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                     double acc = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
                     for (int k = 0; k < i; k++) acc -= L11[i * CH_LDP + k] * x[k];
-                    x[i] = i < lane ? 0.0 : acc / L11[i * CH_LDP + i];
+                    x[i] = i < lane ? 0.0 : acc * s_rdiag[i];
                 }
                 double *dst = Linv + (long long)(k0 / CH_NB) * CH_NB * CH_NB;
 #pragma unroll
@@ -772,7 +793,7 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                     double acc = x[j];
 #pragma unroll
                     for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
-                    x[j] = acc / L11[j * CH_LDP + j];
+                    x[j] = acc * s_rdiag[j];
                 }
 #pragma unroll
                 for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
@@ -1305,6 +1326,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, D, ntiles, lm_per_split);
+        if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
