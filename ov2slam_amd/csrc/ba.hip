@@ -740,18 +740,27 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             }
         }
         __syncthreads();
+        CH_TICK(0);
         // (b) wavefront 0: left-looking factorisation, lane i owns row i in registers; one LDS sync per column
         if (wave == 0) {
             double a[CH_NB];
 #pragma unroll
             for (int j = 0; j < CH_NB; j++) a[j] = lane < CH_NB ? L11[lane * CH_LDP + j] : 0.0;
             bool fail = false;
+            // Column c needs  a[c] - sum_{k<c} a[k] L[c][k]  of every row.  All terms but the last (k = c-1) are known one
+            // column earlier: they are accumulated -- in the same order, so bit-identically -- while the previous pivot's
+            // sqrt / divide chain is in flight; the pivot itself is broadcast with v_readlane instead of ds_bpermute.
+            double pnext = a[0];
 #pragma unroll
             for (int c = 0; c < CH_NB; c++) {
-                double sacc = a[c];
+                double sacc = pnext;
+                if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];              // row c of L, final for k < c (broadcast read)
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
+                if (c + 1 < CH_NB) {
+                    pnext = a[c + 1];
 #pragma unroll
-                for (int k = 0; k < c; k++) sacc -= a[k] * L11[c * CH_LDP + k];     // row c of L, final for k < c (broadcast read)
-                const double d = __shfl(sacc, c, 64);
+                    for (int k = 0; k < c; k++) pnext -= a[k] * L11[(c + 1) * CH_LDP + k];
+                }
                 if (!(d > 0.0) || !isfinite(d)) fail = true;
                 const double dj = sqrt(d);
                 const double l = lane == c ? dj : sacc / dj;
@@ -1351,7 +1360,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
     r->solve_ms = ms;
     if (getenv("OV2_BA_DEBUG"))
-        fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): assemble %llu diag %llu panel %llu trail %llu solve %llu\n",
+        fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): copy-in %llu diag %llu panel %llu trail %llu solve %llu\n",
                 h_ctl.dbg[0], h_ctl.dbg[1], h_ctl.dbg[2], h_ctl.dbg[3], h_ctl.dbg[4]);
     return OV2_OK;
 }
