@@ -32,6 +32,9 @@
 #include <stdlib.h>
 #include <vector>
 
+#ifndef BA_KO
+#define BA_KO 0      // knock-out timing of the lineariser: 1 no global Hao atomics, 2 no LDS atomics, 4 no wave sums
+#endif
 #pragma clang fp contract(fast)   // BA parity is 1e-4 relative in fp64: FMA contraction is fine here
 
 #define BA_TILE 32
@@ -292,7 +295,13 @@ __device__ __forceinline__ double block_sum(double v, double *s_part)
 //   per-wave regs Haa[21], ba[6]                      (anchor diagonal block, flushed when the anchor changes)
 // and reach HBM as a few thousand atomics per workgroup instead of ~60 per residual block.
 // H is stored as its UPPER triangle only (row <= col).
-// dynamic LDS: 4*nfp (W rows) + n_opt*27 + 4*n_opt*36 doubles
+// The 35 per-landmark sums over the residual lanes (Haa[21], F_a^T b [6], E^T F_a [6], E^T E, E^T b) go through a
+// per-wave 35 x 33 LDS transpose -- every lane parks its partials, lane q adds up row q -- instead of 35 six-step
+// shuffle butterflies (420 ds_bpermute per landmark: a third of this kernel, knock-out timing BA_KO=4); lane q keeps
+// the running anchor sums q < 27 in ONE register until the anchor changes.
+// dynamic LDS: 4*nfp (W rows) + n_opt*27 + 4*n_opt*36 + 4*LIN_RED doubles
+#define LIN_NRED 35
+#define LIN_RED (LIN_NRED * 33)
 __device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, double v)
 {
     if (r <= c) atomicAdd(&H[(long long)r * ld + c], v); else atomicAdd(&H[(long long)c * ld + r], v);
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     double *Hoo = (double *)smem_raw + 4 * D.nfp;
     double *bo = Hoo + n_opt * 21;
     double *Hao = bo + n_opt * 6 + wave * n_opt * 36;
+    double *red = bo + n_opt * 6 + 4 * n_opt * 36 + wave * LIN_RED;
     for (int e = threadIdx.x; e < n_opt * 27 + 4 * n_opt * 36; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
 
@@ -317,36 +327,29 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     const int i0 = gw * chunk, i1 = min(D.n_lm, i0 + chunk);
     double cost = 0;
     int cur_ca = -1;
-    double HaaAcc[21], baAcc[6];
-    for (int k = 0; k < 21; k++) HaaAcc[k] = 0;
-    for (int k = 0; k < 6; k++) baAcc[k] = 0;
+    double dacc = 0;                                        // lane q < 21: Haa entry q, lane 21..26: (F_a^T b)[q - 21] of the current anchor
 
     auto flush_anchor = [&](int ca) {
         if (ca < 0) return;
-        // anchor diagonal block + F^T b (uniform values in every lane; lanes 0..26 issue one atomic each)
+        // anchor diagonal block + F^T b: lanes 0..26 hold one entry each
         if (lane < 21) {
             int c = 0, d = 0, t = lane;
             for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
-            double v = 0;
-#pragma unroll
-            for (int q = 0; q < 21; q++) if (q == lane) v = HaaAcc[q];
-            if (v != 0.0) atomicAdd(&D.H[(long long)(ca + c) * D.nfp + ca + d], v);
+            if (dacc != 0.0) atomicAdd(&D.H[(long long)(ca + c) * D.nfp + ca + d], dacc);
         } else if (lane < 27) {
-            double v = 0;
-#pragma unroll
-            for (int q = 0; q < 6; q++) if (q == lane - 21) v = baAcc[q];
-            if (v != 0.0) atomicAdd(&D.bf[ca + lane - 21], v);
+            if (dacc != 0.0) atomicAdd(&D.bf[ca + lane - 21], dacc);
         }
         for (int e = lane; e < n_opt * 36; e += 64) {
             const double v = Hao[e];
             if (v != 0.0) {
                 const int ob = e / 36, r = e - ob * 36, d = r / 6, c = r - d * 6;     // (Ja^T Jo)[d][c]
+#if !(BA_KO & 1)
                 h_add_upper(D.H, D.nfp, ca + d, ob * 6 + c, v);
+#endif
                 Hao[e] = 0;
             }
         }
-        for (int k = 0; k < 21; k++) HaaAcc[k] = 0;
-        for (int k = 0; k < 6; k++) baAcc[k] = 0;
+        dacc = 0;
     };
 
     for (int idx = i0; idx < i1; idx++) {
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                 if (co >= 0) {
                     const int ob = co / 6;
                     int t = 0;
+#if !(BA_KO & 2)
                     for (int c = 0; c < 6; c++) {
                         atomicAdd(&wrow[co + c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);      // LDS fp64 atomics
                         atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
@@ -401,22 +405,40 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                         if (cae >= 0)
                             for (int d = 0; d < 6; d++) atomicAdd(&Hao[ob * 36 + d * 6 + c], Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c]);
                     }
+#else
+                    if (Jo[0] == 1.2345) wrow[co] = Jo[1] + Ja[3] + (double)ob + (double)t;
+#endif
                 }
             }
         }
-        ete = wave_sum(ete); etb = wave_sum(etb);
-        if (ca >= 0) {
-            for (int c = 0; c < 6; c++) { wa[c] = wave_sum(wa[c]); baAcc[c] += wave_sum(ba[c]); }
-            for (int k = 0; k < 21; k++) HaaAcc[k] += wave_sum(Haa[k]);
-        }
-        wave_lds_sync();
-        if (lane == 0) { D.ete[lm] = ete; D.etb[lm] = etb; }
-        if (ca >= 0 && lane < 6) {
-            double v = 0;
+        // transpose-reduce: slots 0..20 Haa, 21..26 ba, 27..32 wa, 33 E^T E, 34 E^T b; lanes 32..63 only hold
+        // something when the landmark has more than 32 residual blocks
+        double tot = 0;
+#if !(BA_KO & 4)
+        for (int p = 0; p < ((end - beg > 32) ? 2 : 1); p++) {
+            if ((lane >> 5) == p) {
+                double *col = red + (lane & 31);
 #pragma unroll
-            for (int q = 0; q < 6; q++) if (q == lane) v = wa[q];
-            wrow[ca + lane] += v;
+                for (int k = 0; k < 21; k++) col[k * 33] = Haa[k];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { col[(21 + c) * 33] = ba[c]; col[(27 + c) * 33] = wa[c]; }
+                col[33 * 33] = ete; col[34 * 33] = etb;
+            }
+            wave_lds_sync();
+            if (lane < LIN_NRED) {
+                const double *row = red + lane * 33;
+#pragma unroll
+                for (int j = 0; j < 32; j++) tot += row[j];
+            }
+            wave_lds_sync();
         }
+#else
+        tot = Haa[lane % 21] + ba[lane % 6] + wa[lane % 6] + ete + etb;
+#endif
+        if (ca >= 0 && lane < 27) dacc += tot;
+        if (lane == 33) D.ete[lm] = tot;
+        if (lane == 34) D.etb[lm] = tot;
+        if (ca >= 0 && lane >= 27 && lane < 33) wrow[ca + lane - 27] += tot;
         wave_lds_sync();
         double *Wg = D.W + (long long)lm * D.nfp;
         for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
@@ -1318,8 +1340,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     hipLaunchKernelGGL(k_ba_init, dim3((D.n_kf + 255) / 256), dim3(256), 0, s, D);
 
     const int n_opt = D.nf / 6;
-    const int lin_blocks = std::max(1, std::min(256, (D.n_lm + 15) / 16));
-    const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36) + 64;
+    const int lin_blocks = std::max(1, std::min(256, (D.n_lm + 15) / 16));   // (512: two workgroups per CU -- measured 15 % slower)
+    const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     OV2_REQUIRE(lin_lds <= 160 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
