@@ -352,30 +352,56 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         dacc = 0;
     };
 
+    // Two-stage software pipeline over the landmarks of this wavefront (one wavefront per SIMD: nothing else hides the
+    // dependent global round trips order -> header -> residual records -> poses): the header of landmark idx+2 and the
+    // residual records of the first 64 blocks of landmark idx+1 are requested before landmark idx is processed.
+    struct LmHdr { int lm, beg, end, a, ca; double lam, au, av; };
+    struct ResRec { int type, kf, orig; double u, v, sigma; };
+    auto load_hdr = [&](int idx) {
+        LmHdr h;
+        h.lm = lm_order[min(idx, i1 - 1)];
+        h.beg = D.lm_ptr[h.lm]; h.end = D.lm_ptr[h.lm + 1];
+        h.a = D.lm_anchor[h.lm]; h.ca = D.pose_col[h.a];
+        h.lam = D.x_lam[h.lm]; h.au = D.lm_auv[2 * h.lm]; h.av = D.lm_auv[2 * h.lm + 1];
+        return h;
+    };
+    auto load_rec = [&](const LmHdr &h) {
+        ResRec r;
+        const int k = max(0, min(h.beg + lane, h.end - 1));       // (a landmark without residual blocks: nothing is consumed)
+        r.type = D.res_type[k]; r.kf = D.res_kf[k]; r.orig = D.res_orig[k];
+        r.u = D.res_uv[2 * k]; r.v = D.res_uv[2 * k + 1]; r.sigma = D.res_sigma[k];
+        return r;
+    };
+    LmHdr h_cur, h_nxt;
+    ResRec r_cur;
+    if (i0 < i1) { h_cur = load_hdr(i0); h_nxt = load_hdr(i0 + 1); r_cur = load_rec(h_cur); }
     for (int idx = i0; idx < i1; idx++) {
-        const int lm = lm_order[idx];
-        const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
-        const int a = D.lm_anchor[lm];
-        const int ca = D.pose_col[a];
+        const ResRec r_nxt = load_rec(h_nxt);
+        const LmHdr h_n2 = load_hdr(idx + 2);
+        const int lm = h_cur.lm;
+        const int beg = h_cur.beg, end = h_cur.end;
+        const int a = h_cur.a;
+        const int ca = h_cur.ca;
         if (ca != cur_ca) { wave_lds_sync(); flush_anchor(cur_ca); wave_lds_sync(); cur_ca = ca; }
         for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
         wave_lds_sync();
-        const double lam = D.x_lam[lm];
-        const double auv[2] = {D.lm_auv[2 * lm], D.lm_auv[2 * lm + 1]};
+        const double lam = h_cur.lam;
+        const double auv[2] = {h_cur.au, h_cur.av};
         double ete = 0, etb = 0, wa[6] = {0, 0, 0, 0, 0, 0}, ba[6] = {0, 0, 0, 0, 0, 0}, Haa[21];
         for (int k = 0; k < 21; k++) Haa[k] = 0;
         for (int base = beg; base < end; base += 64) {
             const int k = base + lane;
             if (k < end) {
-                const int type = D.res_type[k];
-                const int o = type == OV2_RES_RIGHT_ANCH ? a : D.res_kf[k];
+                const bool first = base == beg;                               // (wave-uniform) records of the first batch were prefetched
+                const int type = first ? r_cur.type : D.res_type[k];
+                const int o = type == OV2_RES_RIGHT_ANCH ? a : (first ? r_cur.kf : D.res_kf[k]);
                 const int co = type == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[o];
                 const int cae = type == OV2_RES_RIGHT_ANCH ? -1 : ca;
-                const double uv[2] = {D.res_uv[2 * k], D.res_uv[2 * k + 1]};
+                const double uv[2] = {first ? r_cur.u : D.res_uv[2 * k], first ? r_cur.v : D.res_uv[2 * k + 1]};
                 double r[2], Ja[12], Jo[12], Jl[2];
-                const int dp = d_residual<true>(D, type, D.x_RT + 12 * a, D.x_RT + 12 * o, lam, auv, uv, D.res_sigma[k], r, Ja, Jo, Jl);
+                const int dp = d_residual<true>(D, type, D.x_RT + 12 * a, D.x_RT + 12 * o, lam, auv, uv, first ? r_cur.sigma : D.res_sigma[k], r, Ja, Jo, Jl);
                 const double s = r[0] * r[0] + r[1] * r[1];
-                const int orig = D.res_orig[k];
+                const int orig = first ? r_cur.orig : D.res_orig[k];
                 D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
                 double rho0, rho1;
                 d_huber(D.huber, s, rho0, rho1);
@@ -443,6 +469,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         double *Wg = D.W + (long long)lm * D.nfp;
         for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
         wave_lds_sync();
+        h_cur = h_nxt; h_nxt = h_n2; r_cur = r_nxt;
     }
     wave_lds_sync();
     flush_anchor(cur_ca);
