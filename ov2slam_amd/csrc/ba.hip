@@ -681,10 +681,16 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
     const int tj = ti + t;
     __shared__ double As[BA_TILE][BA_TILE + 1], Bs[BA_TILE][BA_TILE + 1];
     __shared__ double ces[BA_TILE];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x;
     const int l0 = blockIdx.y * lm_per_split;
     const int l1 = min(D.n_lm, l0 + lm_per_split);
-    double acc[2][2] = {{0, 0}, {0, 0}};
+    // each of the 4 wavefronts owns a 16x16 quadrant of the tile on the fp64 matrix cores: per 4 landmarks one
+    // v_mfma_f64_16x16x4_f64 fed by two LDS reads per lane (the VALU version read 4 doubles per 4 FMAs: LDS-bound).
+    // Operands: A[i][k] = As[k][i] (lane: i = lane & 15, k = lane >> 4), B[k][j] = Bs[k][j]; D: col = lane & 15,
+    // row = (lane >> 4) + 4 reg.
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int wv = tid >> 6, lane = tid & 63, qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
+    d4 acc = {0., 0., 0., 0.};
     double vacc = 0;                                        // threads 0..31 of diagonal tiles accumulate v
     for (int lb = l0; lb < l1; lb += BA_TILE) {
         // load 32 landmarks x 32 columns of both panels; A is pre-multiplied by c_l
@@ -701,21 +707,18 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
         }
         if (tid < BA_TILE) ces[tid] = (lb + tid < l1) ? D.etb[lb + tid] : 0.0;
         __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < BA_TILE; kk++) {
-            const double a0 = As[kk][2 * ty], a1 = As[kk][2 * ty + 1];
-            const double b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
-            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-        }
+#pragma unroll
+        for (int g = 0; g < BA_TILE / 4; g++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[4 * g + lk][16 * qi + lr], Bs[4 * g + lk][16 * qj + lr], acc, 0, 0, 0);
         if (ti == tj && tid < BA_TILE)
             for (int kk = 0; kk < BA_TILE; kk++) vacc += As[kk][tid] * ces[kk];
         __syncthreads();
     }
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++) {
-            const int gi = ti * BA_TILE + 2 * ty + i, gj = tj * BA_TILE + 2 * tx + j;
-            if (acc[i][j] != 0.0) atomicAdd(&D.G[(long long)gi * D.nfp + gj], acc[i][j]);
-        }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int gi = ti * BA_TILE + 16 * qi + lk + 4 * r, gj = tj * BA_TILE + 16 * qj + lr;
+        if (acc[r] != 0.0) atomicAdd(&D.G[(long long)gi * D.nfp + gj], acc[r]);
+    }
     if (ti == tj && tid < BA_TILE && vacc != 0.0) atomicAdd(&D.v[ti * BA_TILE + tid], vacc);
 }
 
