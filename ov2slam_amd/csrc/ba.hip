@@ -692,10 +692,13 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
     const int wv = tid >> 6, lane = tid & 63, qi = wv >> 1, qj = wv & 1, lr = lane & 15, lk = lane >> 4;
     d4 acc = {0., 0., 0., 0.};
     double vacc = 0;                                        // threads 0..31 of diagonal tiles accumulate v
-    for (int lb = l0; lb < l1; lb += BA_TILE) {
-        // load 32 landmarks x 32 columns of both panels; A is pre-multiplied by c_l
-        for (int e = tid; e < BA_TILE * BA_TILE; e += 256) {
-            const int kk = e >> 5, cc = e & 31;
+    // 32 landmarks x 32 columns of both panels per step (A pre-multiplied by c_l); the loads of step s+1 are in flight
+    // while step s is multiplied
+    double ra[4], rb[4], rc = 0;
+    auto fetch = [&](int lb) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = tid + 256 * u, kk = e >> 5, cc = e & 31;
             const int l = lb + kk;
             double a = 0, b = 0;
             if (l < l1) {
@@ -703,10 +706,20 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
                 a = wr[ti * BA_TILE + cc] * D.cl[l];
                 b = wr[tj * BA_TILE + cc];
             }
-            As[kk][cc] = a; Bs[kk][cc] = b;
+            ra[u] = a; rb[u] = b;
         }
-        if (tid < BA_TILE) ces[tid] = (lb + tid < l1) ? D.etb[lb + tid] : 0.0;
+        rc = (tid < BA_TILE && lb + tid < l1) ? D.etb[lb + tid] : 0.0;
+    };
+    fetch(l0);
+    for (int lb = l0; lb < l1; lb += BA_TILE) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = tid + 256 * u;
+            As[e >> 5][e & 31] = ra[u]; Bs[e >> 5][e & 31] = rb[u];
+        }
+        if (tid < BA_TILE) ces[tid] = rc;
         __syncthreads();
+        if (lb + BA_TILE < l1) fetch(lb + BA_TILE);
 #pragma unroll
         for (int g = 0; g < BA_TILE / 4; g++)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[4 * g + lk][16 * qi + lr], Bs[4 * g + lk][16 * qj + lr], acc, 0, 0, 0);
