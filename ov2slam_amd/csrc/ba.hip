@@ -287,6 +287,27 @@ __device__ __forceinline__ double block_sum(double v, double *s_part)
     return t;
 }
 
+// three sums (or, MAX = true, maxima) over the workgroup with two barriers; results valid in thread 0.  The
+// single-workgroup bookkeeping kernels used 10-step LDS trees per value: ~11 barriers of 16 wavefronts each.
+template <bool MAX>
+__device__ __forceinline__ void block_reduce3(double &a, double &b, double &c, double (*s_part)[16])
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ta = __shfl_xor(a, off, 64), tb = __shfl_xor(b, off, 64), tc = __shfl_xor(c, off, 64);
+        if (MAX) { a = fmax(a, ta); b = fmax(b, tb); c = fmax(c, tc); } else { a += ta; b += tb; c += tc; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { s_part[0][wave] = a; s_part[1][wave] = b; s_part[2][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < nw; w++) {
+            if (MAX) { a = fmax(a, s_part[0][w]); b = fmax(b, s_part[1][w]); c = fmax(c, s_part[2][w]); }
+            else { a += s_part[0][w]; b += s_part[1][w]; c += s_part[2][w]; }
+        }
+}
+
 // ---------------------------------------------------------------------------------- linearize
 // Persistent wavefronts: wave w owns a contiguous chunk of the anchor-sorted landmark order, one lane
 // per residual block.  Pose-side sums are pre-aggregated in LDS (fp64 ds_add):
@@ -587,7 +608,8 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
-    __shared__ double s_red[1024];
+    __shared__ double s_part[3][16];
+    __shared__ double s_gmax;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int fresh = ctl->fresh_lin;
     if (fresh) {
@@ -606,16 +628,21 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
             d_se3_left_plus(D.x_pose + 7 * k, d, out);
             for (int c = 0; c < 7; c++) gm = fmax(gm, fabs(D.x_pose[7 * k + c] - out[c]));
         }
+#pragma unroll 4
         for (int l = tid; l < D.n_lm; l += nt)
             if (D.lm_ptr[l] != D.lm_ptr[l + 1]) gm = fmax(gm, fabs(D.etb[l]));
-        s_red[tid] = gm;
-        __syncthreads();
-        for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
+        double z0 = 0, z1 = 0;
+        block_reduce3<true>(gm, z0, z1, s_part);
+        if (tid == 0) s_gmax = gm;
     }
     __syncthreads();
     if (tid == 0) {
+        // the control block is worked on in registers: one load batch, one store batch (every ctl-> access used to be a
+        // dependent global round trip of thread 0)
+        BACtl cl = *ctl;
+        BACtl *ctl = &cl;
         if (fresh) {
-            ctl->gmax = s_red[0];
+            ctl->gmax = s_gmax;
             ctl->x_cost = ctl->cost_acc;
             ctl->cost_acc = 0;
             if (!ctl->scaled) {             // iteration zero
@@ -643,6 +670,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
             ctl->n_steps++;
             ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0;
         }
+        *D.ctl = cl;
     }
     __syncthreads();
     if (ctl->done) return;
@@ -658,13 +686,22 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         }
         D.v[c] = 0;
     }
-    for (int l = tid; l < D.n_lm; l += nt) {
-        if (D.lm_ptr[l] == D.lm_ptr[l + 1]) { D.cl[l] = 0; D.ce[l] = 0; continue; }
-        const double s = D.scale_l[l];
-        if (!reuse) D.diag_l[l] = fmin(fmax(s * s * D.ete[l], O.min_diag), O.max_diag);
-        const double etep = s * s * D.ete[l] + D.diag_l[l] / radius;     // scaled E^T E + D_e^2
-        const double c = s * s / etep;
-        D.cl[l] = c; D.ce[l] = c * D.etb[l];
+    {
+        // one workgroup walks all landmarks: the loads of four iterations are issued together (restrict-qualified views:
+        // without them every store fences the next iteration's loads -- ten dependent L2 round trips per thread)
+        const int *__restrict__ lm_ptr = D.lm_ptr;
+        const double *__restrict__ scale_l = D.scale_l, *__restrict__ ete = D.ete, *__restrict__ etb = D.etb;
+        double *__restrict__ diag_l = D.diag_l, *__restrict__ cl = D.cl, *__restrict__ ce = D.ce;
+#pragma unroll 4
+        for (int l = tid; l < D.n_lm; l += nt) {
+            const bool has = lm_ptr[l] != lm_ptr[l + 1];
+            const double s = scale_l[l], e = ete[l], b = etb[l];
+            const double dg = reuse ? diag_l[l] : fmin(fmax(s * s * e, O.min_diag), O.max_diag);
+            const double etep = s * s * e + dg / radius;                  // scaled E^T E + D_e^2
+            const double c = has ? s * s / etep : 0.0;
+            if (has && !reuse) diag_l[l] = dg;
+            cl[l] = c; ce[l] = has ? c * b : 0.0;
+        }
     }
     __syncthreads();
     if (tid == 0) ctl->reuse_diag = 1;
@@ -1046,7 +1083,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
-    __shared__ double s_red[1024];
+    __shared__ double s_part[3][16];
     __shared__ int s_flag;
     const int tid = threadIdx.x, nt = blockDim.x;
     int ok = !ctl->lin_fail;
@@ -1061,19 +1098,15 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
             p1 += yi * si * D.bf[i];
             p2 += yi * si * (D.bf[i] - D.v[i]) - (D.diag_f[i] / radius) * yi * yi;
         }
+#pragma unroll 4
         for (int l = tid; l < D.n_lm; l += nt) if (!isfinite(D.yl[l])) bad = 1;
     }
-    s_red[tid] = p1; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    const double P1 = s_red[0]; __syncthreads();
-    s_red[tid] = p2; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    const double P2 = s_red[0]; __syncthreads();
-    s_red[tid] = (double)bad; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    if (s_red[0] > 0) ok = 0;
-    __syncthreads();
+    double P1 = p1, P2 = p2, nbad = (double)bad;
+    block_reduce3<false>(P1, P2, nbad, s_part);
+    if (nbad > 0) ok = 0;                                  // (thread 0 only: the only consumer)
     if (tid == 0) {
+        BACtl cl = *ctl;
+        BACtl *ctl = &cl;
         int valid = 0;
         if (ok) {
             // model_cost_change = -(J step).(r + J step / 2) with step = -y  ==  y.g' - y^T H' y / 2
@@ -1091,6 +1124,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
             ctl->step_valid = 1;
         }
         s_flag = valid;
+        *D.ctl = cl;
     }
     __syncthreads();
     if (!s_flag) return;
@@ -1106,7 +1140,11 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
         for (int c = 0; c < 7; c++) D.c_pose[7 * k + c] = out[c];
         d_pose_to_RT(out, D.c_RT + 12 * k);
     }
-    for (int l = tid; l < D.n_lm; l += nt) D.c_lam[l] = D.x_lam[l] - D.yl[l] * D.scale_l[l];
+    {
+        double *__restrict__ c_lam = D.c_lam; const double *__restrict__ x_lam = D.x_lam, *__restrict__ yl = D.yl, *__restrict__ scale_l = D.scale_l;
+#pragma unroll 4
+        for (int l = tid; l < D.n_lm; l += nt) c_lam[l] = x_lam[l] - yl[l] * scale_l[l];
+    }
 }
 
 // ---------------------------------------------------------------------------------- decision (1 block)
@@ -1114,7 +1152,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->step_valid) return;
-    __shared__ double s_red[1024];
+    __shared__ double s_part[3][16];
     __shared__ int s_accept;
     const int tid = threadIdx.x, nt = blockDim.x;
     // |x - candidate|^2 and |candidate|^2 over the variable blocks
@@ -1126,18 +1164,17 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
             sn += d * d; xn += D.c_pose[7 * k + c] * D.c_pose[7 * k + c];
         }
     }
+#pragma unroll 4
     for (int l = tid; l < D.n_lm; l += nt) {
         if (D.lm_ptr[l] == D.lm_ptr[l + 1]) continue;
         const double d = D.x_lam[l] - D.c_lam[l];
         sn += d * d; xn += D.c_lam[l] * D.c_lam[l];
     }
-    s_red[tid] = sn; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    const double SN = s_red[0]; __syncthreads();
-    s_red[tid] = xn; __syncthreads();
-    for (int s = nt / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    const double XN = s_red[0]; __syncthreads();
+    double SN = sn, XN = xn, z = 0;
+    block_reduce3<false>(SN, XN, z, s_part);
     if (tid == 0) {
+        BACtl cl = *ctl;
+        BACtl *ctl = &cl;
         s_accept = 0;
         const double cand = ctl->cost_acc;
         ctl->cost_acc = 0;
@@ -1166,13 +1203,18 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
                 ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1;
             }
         }
+        *D.ctl = cl;
     }
     __syncthreads();
     if (!s_accept) return;
     // x <- candidate ; clear the pose-side accumulators for the re-linearisation
     for (int e = tid; e < 7 * D.n_kf; e += nt) D.x_pose[e] = D.c_pose[e];
     for (int e = tid; e < 12 * D.n_kf; e += nt) D.x_RT[e] = D.c_RT[e];
-    for (int l = tid; l < D.n_lm; l += nt) D.x_lam[l] = D.c_lam[l];
+    {
+        double *__restrict__ x_lam = D.x_lam; const double *__restrict__ c_lam = D.c_lam;
+#pragma unroll 8
+        for (int l = tid; l < D.n_lm; l += nt) x_lam[l] = c_lam[l];
+    }
     for (int e = tid; e < D.nfp * D.nfp; e += nt) D.H[e] = 0;
     for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
 }
