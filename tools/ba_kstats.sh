@@ -1,3 +1,5 @@
+#!/bin/bash
+# Per-kernel durations of six config-4 local-BA solves (rocprofv3 --kernel-trace --stats); run through gpurun.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/ksba; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 cat > /tmp/ba_run.py <<'PY'
 import os, sys

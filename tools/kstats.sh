@@ -1,3 +1,6 @@
+#!/bin/bash
+# Per-kernel durations of a short bench run (rocprofv3 --kernel-trace --stats), top rows printed; run through gpurun.
+# With OV2SLAM_HIP_LIB=<variant .so> it times an A/B or knock-out build of the library.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/ks; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOT/bench.py --steps 40 --warmup 10 --no-extras --no-cpu-baseline > $OUT/b.json 2> $OUT/err
 python - <<'PY'
