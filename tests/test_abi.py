@@ -45,3 +45,17 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "liboracle" not in txt and "ov2_oracle.h" not in txt and "orc_" not in txt, os.path.join(dp, f)
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_library_path_override_and_missing_library_fail_loudly(tmp_path):
+    """OV2SLAM_HIP_LIB selects the build to load (A/B timing builds); a path without a library is an ImportError
+    that names the build command -- never a silent CPU path."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import ov2slam_amd; from ov2slam_amd import _lib; "
+            "print(_lib.LIB_PATH); ov2slam_amd.load(); print('loaded')" % ROOT)
+    good = os.path.join(ROOT, "ov2slam_amd", "libov2slam_hip.so")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OV2SLAM_HIP_LIB=good), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[0] == good and "loaded" in r.stdout, r.stderr
+    missing = str(tmp_path / "nope.so")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OV2SLAM_HIP_LIB=missing), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "ImportError" in r.stderr and "no CPU fallback" in r.stderr.replace("\n", " "), r.stderr
