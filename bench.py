@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--seqs", type=int, default=1024, help="sequences processed in lock-step per GPU")
+    ap.add_argument("--seqs", type=int, default=4096, help="sequences processed in lock-step per GPU (16.5 GB of HBM at 4096)")
     ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
                     help="euroc = the headline configuration (BASELINE.json configs[1]); kitti = configs[2] "
                          "(1241x376, wide-image stress) -- a side measurement, not the headline")
