@@ -57,9 +57,19 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
 {
     __shared__ __attribute__((aligned(8))) uint32_t tile[PT_ROWS][PT_LDS_DW];
     const PyrLevelDesc L = P.lv[level];
-    const int b = blockIdx.z;
+    // XCD-aware work-group -> (image, tile) map (1-D launch; consecutive ids are dealt round-robin over the 8 XCDs): all
+    // tiles of an image get ids of one residue mod 8 and consecutive rank, so that the halo rows / columns neighbouring
+    // tiles share and the two halves of the output lines they split meet in ONE L2
+    const int gx = (L.w + PT_W - 1) / PT_W, gy = (L.h + PT_H - 1) / PT_H, tiles = gx * gy;
+    int b, tno;
+    {
+        const int Lid = blockIdx.x, B8 = P.batch & ~7;
+        if (Lid < tiles * B8) { const int idx = Lid >> 3, q = idx / tiles; b = q * 8 + (Lid & 7); tno = idx - q * tiles; }
+        else { const int r = Lid - tiles * B8, q = r / tiles; b = B8 + q; tno = r - q * tiles; }
+    }
+    const int tby = tno / gx, tbx = tno - tby * gx;
     uint8_t *item = P.base + (long long)b * P.item_stride;
-    const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
+    const int x0 = tbx * PT_W, y0 = tby * PT_H;
     const int tid = threadIdx.x;
 
     // ---- stage the tile ----
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
     if (FUSE_BORDER) {
         // left / right border dwords of this work-group's output rows (and of the border rows mirroring them), same
         // dword set as k_pyr_border: columns [-PB_LEFT, 0) and [w & ~3, (w + win + 3) & ~3)
-        const bool first = blockIdx.x == 0, last = blockIdx.x == gridDim.x - 1;
+        const bool first = tbx == 0, last = tbx == gx - 1;
         if (!first && !last) return;
         __syncthreads();
         const int PB_LEFT = (win + 3) & ~3, nl = first ? PB_LEFT >> 2 : 0;
@@ -294,10 +304,11 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
     };
     for (int l = 0; l < P.n_levels; l++) {
         const PyrLevelDesc &L = P.lv[l];
-        dim3 grid((L.w + PT_W - 1) / PT_W, (L.h + PT_H - 1) / PT_H, P.batch);
+        const int gx = (L.w + PT_W - 1) / PT_W, gy = (L.h + PT_H - 1) / PT_H;
+        dim3 grid(gx * gy * P.batch);                       // 1-D: the kernel decodes (image, tile) XCD-aware
         // the level kernel writes level l+1's border itself when the last work-group column owns >= win + 1 output columns
         const bool has_next = l + 1 < P.n_levels;
-        const bool fuse = has_next && P.lv[l + 1].w - (PT_W / 2) * ((int)grid.x - 1) >= P.win + 1;
+        const bool fuse = has_next && P.lv[l + 1].w - (PT_W / 2) * (gx - 1) >= P.win + 1;
         if (l == 0 && img_d) {
             if (fuse) hipLaunchKernelGGL((k_pyr_level<true, true>), grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
             else hipLaunchKernelGGL((k_pyr_level<true, false>), grid, dim3(256), 0, ctx->stream, P, 0, img_d, stride, (long long)img_batch_stride);
