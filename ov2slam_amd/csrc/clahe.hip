@@ -24,7 +24,18 @@ struct ClaheParams {
     long long src_item_stride, dst_item_stride;
     int dst_stride;
     int border;          // > 0: dst is a padded pyramid level -- also write its REFLECT_101 border of this many pixels
+    int batch, gx_lut;   // images in the launch, work-groups per image of the LUT kernel (1-D XCD-aware launches)
 };
+
+// XCD-aware 1-D work-group map (consecutive ids are dealt round-robin over the 8 XCDs): the `per_item` work-groups of
+// an image get ids of one residue mod 8 and consecutive rank, so that what they share (image lines split between
+// neighbouring tiles, the image's LUTs) is fetched into ONE L2
+__device__ __forceinline__ void c_xcd_map(int id, int per_item, int batch, int &b, int &k)
+{
+    const int B8 = batch & ~7;
+    if (id < per_item * B8) { const int idx = id >> 3, q = idx / per_item; b = q * 8 + (id & 7); k = idx - q * per_item; }
+    else { const int r = id - per_item * B8, q = r / per_item; b = B8 + q; k = r - q * per_item; }
+}
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
 // tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
@@ -58,8 +69,9 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
 {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
-    const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * gridDim.x;
-    const int b = blockIdx.y;
+    const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * P.gx_lut;
+    int b, bx;
+    c_xcd_map(blockIdx.x, P.gx_lut, P.batch, b, bx);
     uint32_t *hw = hist_all[wave];
     const uint8_t *img = src + (long long)b * P.src_item_stride;
     const int sub = lane >> 4, l16 = lane & 15;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
     };
 
     uint32_t cur[16], nxt[16], cur_ph = 0, nxt_ph = 0;
-    int t = blockIdx.x * 4 + wave;
+    int t = bx * 4 + wave;
     if (t < ntiles && tile_fast(t)) tile_load(t, cur, cur_ph);
 #pragma nounroll
     for (; t < ntiles; t += tstride) {
@@ -242,7 +254,9 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
     extern __shared__ __align__(16) unsigned char clahe_smem[];
     const int ncx = P.tiles_x + 1;
     uint32_t *lut4 = (uint32_t *)clahe_smem;                            // ncx * 256
-    const int cy = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+    int cy, b;
+    c_xcd_map(blockIdx.x, P.tiles_y + 1, P.batch, b, cy);
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int ty1 = max(cy - 1, 0), ty2 = min(cy, P.tiles_y - 1);
     const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;
     // stage: item = (cell column, 4 consecutive gray values): four dword loads, a 4x4 byte transpose, one b128 store
@@ -399,7 +413,8 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     // ~5 tiles per wavefront (prefetch pipeline) once the batch alone fills the GPU, one tile per wavefront otherwise (latency)
     const int tiles_per_wave = (long long)batch * tiles_x * tiles_y >= 32768 ? 5 : 1;
     const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
-    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3((tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave), batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+    P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
+    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 2048 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 511) / 512;
@@ -407,7 +422,7 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && apply_lds <= 160 * 1024, OV2_EUNSUPPORTED, "CLAHE: too many tile columns / too wide an image for the LDS tables");
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
     OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
-    hipLaunchKernelGGL(src_al ? k_clahe_apply<true> : k_clahe_apply<false>, dim3(tiles_y + 1, batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
+    hipLaunchKernelGGL(src_al ? k_clahe_apply<true> : k_clahe_apply<false>, dim3((tiles_y + 1) * batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
