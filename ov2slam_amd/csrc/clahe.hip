@@ -7,6 +7,7 @@
 //                   redistribution, inclusive scan, LUT = saturate(cvRound(cdf * 255 / tile_area))
 //   k_clahe_apply : 4 pixels per thread (dword load/store), bilinear blend of the four tile LUTs
 #include "common.hpp"
+#include "xcd_map.hpp"
 #include <math.h>
 
 #pragma clang fp contract(off)
@@ -26,16 +27,6 @@ struct ClaheParams {
     int border;          // > 0: dst is a padded pyramid level -- also write its REFLECT_101 border of this many pixels
     int batch, gx_lut;   // images in the launch, work-groups per image of the LUT kernel (1-D XCD-aware launches)
 };
-
-// XCD-aware 1-D work-group map (consecutive ids are dealt round-robin over the 8 XCDs): the `per_item` work-groups of
-// an image get ids of one residue mod 8 and consecutive rank, so that what they share (image lines split between
-// neighbouring tiles, the image's LUTs) is fetched into ONE L2
-__device__ __forceinline__ void c_xcd_map(int id, int per_item, int batch, int &b, int &k)
-{
-    const int B8 = batch & ~7;
-    if (id < per_item * B8) { const int idx = id >> 3, q = idx / per_item; b = q * 8 + (id & 7); k = idx - q * per_item; }
-    else { const int r = id - per_item * B8, q = r / per_item; b = B8 + q; k = r - q * per_item; }
-}
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
 // tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
@@ -71,7 +62,7 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
     const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * P.gx_lut;
     int b, bx;
-    c_xcd_map(blockIdx.x, P.gx_lut, P.batch, b, bx);
+    ov2_xcd_map(blockIdx.x, P.gx_lut, P.batch, &b, &bx);    // the work-groups of an image share image lines and its LUTs
     uint32_t *hw = hist_all[wave];
     const uint8_t *img = src + (long long)b * P.src_item_stride;
     const int sub = lane >> 4, l16 = lane & 15;
@@ -255,7 +246,7 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
     const int ncx = P.tiles_x + 1;
     uint32_t *lut4 = (uint32_t *)clahe_smem;                            // ncx * 256
     int cy, b;
-    c_xcd_map(blockIdx.x, P.tiles_y + 1, P.batch, b, cy);
+    ov2_xcd_map(blockIdx.x, P.tiles_y + 1, P.batch, &b, &cy);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int ty1 = max(cy - 1, 0), ty2 = min(cy, P.tiles_y - 1);
     const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;

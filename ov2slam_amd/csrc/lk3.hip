@@ -16,6 +16,7 @@
 //   * Forward levels and the backward level run through ONE inlined instance of the level body
 //     (a small step machine) to keep the code inside the instruction cache.
 #include "common.hpp"
+#include "xcd_map.hpp"
 #include <float.h>
 #include <math.h>
 
@@ -442,11 +443,7 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
     // given ids of the same residue mod 8 and consecutive rank, so the image lines they share are fetched
     // into one L2 only, and at about the same time.
     int b, bx;
-    {
-        const int L = blockIdx.x, B8 = P.batch & ~7;
-        if (L < nbx * B8) { const int idx = L >> 3, q = idx / nbx; b = q * 8 + (L & 7); bx = idx - q * nbx; }
-        else { const int r = L - nbx * B8, q = r / nbx; b = B8 + q; bx = r - q * nbx; }
-    }
+    ov2_xcd_map(blockIdx.x, nbx, P.batch, &b, &bx);
     const int n = n_per_item ? n_per_item[b] : prm.n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, g = l16 / 3, sub = l16 - 3 * g;

@@ -13,6 +13,7 @@
 // read legal memory exactly like OpenCV's padded Mats and (b) the 5x5 / 3x3
 // stencils of the next kernel need no border logic when reading.
 #include "common.hpp"
+#include "xcd_map.hpp"
 #include <limits.h>
 
 #pragma clang fp contract(off)
@@ -62,11 +63,7 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
     // tiles share and the two halves of the output lines they split meet in ONE L2
     const int gx = (L.w + PT_W - 1) / PT_W, gy = (L.h + PT_H - 1) / PT_H, tiles = gx * gy;
     int b, tno;
-    {
-        const int Lid = blockIdx.x, B8 = P.batch & ~7;
-        if (Lid < tiles * B8) { const int idx = Lid >> 3, q = idx / tiles; b = q * 8 + (Lid & 7); tno = idx - q * tiles; }
-        else { const int r = Lid - tiles * B8, q = r / tiles; b = B8 + q; tno = r - q * tiles; }
-    }
+    ov2_xcd_map(blockIdx.x, tiles, P.batch, &b, &tno);
     const int tby = tno / gx, tbx = tno - tby * gx;
     uint8_t *item = P.base + (long long)b * P.item_stride;
     const int x0 = tbx * PT_W, y0 = tby * PT_H;
