@@ -6,7 +6,8 @@ Metric (BASELINE.json): "frames/sec tracking + local-BA iters/sec, EuRoC MH_01 s
 One timed "step" = one camera frame of config[1] (EuRoC MH_01 stereo, 'accurate' parameters:
 752x480, LK 9x9, 3+1 pyramid levels, 30 it / 0.01 px, 308 keypoints) pushed through the HIP hot
 path for each of the `--seqs` sequences this GPU processes in lock-step (offline
-batch-of-sequences mode of config[4]; `--seqs 1` is the single-sequence drop-in case):
+batch-of-sequences mode of config[4]; default 4096 = 16.5 GB of HBM per GPU, `--seqs 1` is the single-sequence
+drop-in case; the per-frame work does not depend on it, the fill of the GPU does -- DESIGN.md section 6):
     preprocessImage : CLAHE (clip 3.0, 15x9 tiles: use_clahe 1 in parameters_files/accurate) of the new left
                       image + device-resident pyramid build (/root/reference/src/visual_front_end.cpp:1143-1177)
     kltTracking     : fbKltTracking pass A (nbpyrlvl=1) on the keypoints that carry a 3-D prior,
