@@ -138,6 +138,61 @@ int ov2_fb_klt_d(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur,
                  const float *kps_xy_d, float *prior_xy_inout_d, int n_max, const int *n_per_item_d,
                  uint8_t *status_d, long long *stats_d);
 
+/* ---- single-sequence tracker: preprocessImage + kltTracking ----------------------------------
+ * One object per camera stream that owns what VisualFrontEnd keeps between frames -- prev_pyr_ / cur_pyr_
+ * (src/visual_front_end.hpp) -- plus pinned staging buffers and, optionally, a captured hipGraph of the whole
+ * per-frame enqueue.  It replaces, per frame, on the SLAM thread:
+ *   VisualFrontEnd::preprocessImage  src/visual_front_end.cpp:1143-1177  (pyramid swap :1169, CLAHE :1159,
+ *                                                                         cv::buildOpticalFlowPyramid :1172)
+ *   VisualFrontEnd::kltTracking      src/visual_front_end.cpp:132-275    (both fbKltTracking calls :196 / :242, the
+ *                                                                         retry of lost prior tracks :213-217 and the
+ *                                                                         "motion model is wrong" rule :225-230)
+ * with ONE H2D of the frame, ONE H2D of the keypoint block, five small kernels, ONE LK launch, ONE D2H and ONE
+ * host synchronisation.  Results are identical to calling ov2_pyr_build_clahe_h + ov2_fb_klt twice.           */
+typedef struct ov2_tracker ov2_tracker;
+typedef struct {
+    int w, h;                    /* image size                                                          */
+    int win;                     /* nklt_win_size (9)                                                   */
+    int nklt_pyr_lvl;            /* pyramid levels above 0 (3): full-pyramid pass                       */
+    int prior_pyr_lvl;           /* nbpyrlvl of the 3-D-prior pass (1, visual_front_end.cpp:188)        */
+    int max_iter; float eps;     /* klt_convg_crit_: nmax_iter (30), fmax_px_precision (0.01)           */
+    float err_th, fb_dist;       /* nklt_err (30), fmax_fbklt_dist (0.5)                                */
+    int use_clahe; double clahe_clip; int tiles_x, tiles_y;   /* use_clahe, fclahe_val, (w/50, h/50)    */
+    int n_max;                   /* keypoint capacity (nbmaxkps)                                        */
+    int use_graph;               /* 1: replay a captured hipGraph per frame (falls back to plain enqueue
+                                    when the context's stream cannot be captured)                       */
+} ov2_tracker_config;
+
+int  ov2_tracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, ov2_tracker **out);
+void ov2_tracker_destroy(ov2_tracker *t);
+/* Pinned staging image the next frame may be written into directly (camera driver / decoder / cv::Mat header
+ * over it): a frame passed from there skips the host-side copy.  *stride receives its pitch.               */
+uint8_t *ov2_tracker_image_buffer(ov2_tracker *t, int *stride);
+/* preprocessImage: swap prev/cur, H2D of the frame, CLAHE (if configured) + pyramid build.  ASYNCHRONOUS: returns
+ * after the enqueue so the host can run its motion model while the GPU works; the image is staged through the
+ * pinned buffer first, so img_h may be reused immediately.                                                 */
+int  ov2_tracker_preprocess(ov2_tracker *t, const uint8_t *img_h, int stride);
+/* kltTracking on (prev, cur) of the tracker.  has_prior_h[i] != 0: keypoint i carries a 3-D prior
+ * (prior_xy_h[i] = projected map point) and is tracked on prior_pyr_lvl levels first; otherwise pass
+ * prior_xy_h[i] = kps_xy_h[i] like the reference (:180-182).  klt_use_prior = 0 ignores has_prior_h.
+ * out_xy_h[i]: tracked position (the value the reference hands to updateKeypoint, :204 / :256);
+ * status_h[i]: bit 0 = tracked, bit 1 = lost on the prior pass and re-tracked on the full pyramid;
+ * *p3p_req (may be NULL): 1 when fewer than a third of the prior tracks were good (bp3preq_, :225-230) -- the lost
+ * prior tracks are then re-run from the keypoints themselves in a second launch, exactly like the reference.
+ * Blocking (one synchronisation).  n == 0 returns OV2_OK.                                                    */
+int  ov2_tracker_klt(ov2_tracker *t, const float *kps_xy_h, const float *prior_xy_h, const uint8_t *has_prior_h, int n,
+                     int klt_use_prior, float *out_xy_h, uint8_t *status_h, int *p3p_req);
+/* preprocess + klt in one enqueue (one graph launch when use_graph): the per-frame call of the drop-in.
+ * The first frame after creation only builds the pyramid (nothing to track against): status_h is zeroed.   */
+int  ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, const float *kps_xy_h,
+                             const float *prior_xy_h, const uint8_t *has_prior_h, int n, int klt_use_prior,
+                             float *out_xy_h, uint8_t *status_h, int *p3p_req);
+/* the tracker's pyramids (valid until the next preprocess), e.g. for createKeyframe / stereo matching / detection */
+const ov2_pyr *ov2_tracker_cur_pyr(const ov2_tracker *t);
+const ov2_pyr *ov2_tracker_prev_pyr(const ov2_tracker *t);
+int  ov2_tracker_frames(const ov2_tracker *t);     /* frames preprocessed so far */
+int  ov2_tracker_uses_graph(const ov2_tracker *t); /* 1 when the graph path is active */
+
 /* ---- keypoint detection ---------------------------------------------
  * mask_mode for the FAST grid detector: the reference passes a
  * CV_32F mask to cv::FastFeatureDetector::detect, which reads it as bytes.     */

@@ -126,6 +126,48 @@ def fb_klt(prev, cur, win, nbpyrlvl, ferr, fbdist, kps, priors, max_iter=30, eps
 
 
 # ---------------------------------------------------------------- detection
+def klt_tracking(prev, cur, kps, priors, has_prior, win=9, nklt_pyr_lvl=3, ferr=30., fbdist=0.5, klt_use_prior=True,
+                 max_iter=30, eps=0.01):
+    """Control flow of VisualFrontEnd::kltTracking (/root/reference/src/visual_front_end.cpp:132-275) on top of
+    fb_klt: keypoints with a 3-D prior are tracked on 2 levels first (:186-199), the lost ones join the second call
+    with the first call's forward result as prior (:213-217), and when fewer than a third were good every prior of
+    the second call is reset to its keypoint (:225-230).  Test infrastructure (the reference composes its list by
+    push_back; keypoints are independent inside fbKltTracking, so results are reported per input index).
+    Returns (px (n,2) float32: value handed to updateKeypoint / last forward result, ok (n,) bool,
+             retried (n,) bool: went through the second call after losing the first, bp3preq)."""
+    kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 2)
+    pri = np.array(priors, np.float32, copy=True).reshape(-1, 2)
+    n = len(kps)
+    hp = np.zeros(n, bool) if (has_prior is None or not klt_use_prior) else np.asarray(has_prior).astype(bool)
+    out = pri.copy()
+    ok = np.zeros(n, bool)
+    retried = np.zeros(n, bool)
+    p3p = False
+    ia = np.nonzero(hp)[0]
+    ib = list(np.nonzero(~hp)[0])
+    pri_b = {int(i): pri[i].copy() for i in ib}
+    if len(ia):
+        o, st, _ = fb_klt(prev, cur, win, 1, ferr, fbdist, kps[ia], pri[ia], max_iter, eps)
+        st = np.asarray(st).astype(bool)
+        for j, i in enumerate(ia):
+            out[i] = o[j]
+            if st[j]:
+                ok[i] = True
+            else:
+                ib.append(int(i)); pri_b[int(i)] = o[j].copy(); retried[i] = True
+        if st.sum() < 0.33 * len(ia):
+            p3p = True
+            for i in ib:
+                pri_b[i] = kps[i].copy()
+    if len(ib):
+        ib = np.array(ib)
+        o, st, _ = fb_klt(prev, cur, win, nklt_pyr_lvl, ferr, fbdist, kps[ib], np.stack([pri_b[int(i)] for i in ib]), max_iter, eps)
+        st = np.asarray(st).astype(bool)
+        out[ib] = o
+        ok[ib] = st
+    return out, ok, retried, p3p
+
+
 def fast9_16(img, threshold, nonmax=True):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape

@@ -74,6 +74,15 @@ class SBAResult(C.Structure):
     ]
 
 
+class TrackerConfig(C.Structure):
+    _fields_ = [
+        ("w", C.c_int), ("h", C.c_int), ("win", C.c_int), ("nklt_pyr_lvl", C.c_int), ("prior_pyr_lvl", C.c_int),
+        ("max_iter", C.c_int), ("eps", C.c_float), ("err_th", C.c_float), ("fb_dist", C.c_float),
+        ("use_clahe", C.c_int), ("clahe_clip", C.c_double), ("tiles_x", C.c_int), ("tiles_y", C.c_int),
+        ("n_max", C.c_int), ("use_graph", C.c_int),
+    ]
+
+
 _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 _pp = C.POINTER(C.c_void_p)
 
@@ -105,6 +114,16 @@ SIGNATURES = {
     "ov2_stereo_epipolar_check": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_pyr_build_clahe_d": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _d, _i, _i]),
     "ov2_pyr_build_clahe_h": (_i, [_vp, _vp, _vp, _i, _d, _i, _i]),
+    "ov2_tracker_create": (_i, [_vp, C.POINTER(TrackerConfig), _pp]),
+    "ov2_tracker_destroy": (None, [_vp]),
+    "ov2_tracker_image_buffer": (_vp, [_vp, C.POINTER(_i)]),
+    "ov2_tracker_preprocess": (_i, [_vp, _vp, _i]),
+    "ov2_tracker_klt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "ov2_tracker_track_frame": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "ov2_tracker_cur_pyr": (_vp, [_vp]),
+    "ov2_tracker_prev_pyr": (_vp, [_vp]),
+    "ov2_tracker_frames": (_i, [_vp]),
+    "ov2_tracker_uses_graph": (_i, [_vp]),
     "ov2_lk_track": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_fb_klt": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
     "ov2_fb_klt_d": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),

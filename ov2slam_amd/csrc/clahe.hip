@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "xcd_map.hpp"
 #include <math.h>
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -26,6 +27,8 @@ struct ClaheParams {
     int dst_stride;
     int border;          // > 0: dst is a padded pyramid level -- also write its REFLECT_101 border of this many pixels
     int batch, gx_lut;   // images in the launch, work-groups per image of the LUT kernel (1-D XCD-aware launches)
+    int ysplit;          // apply kernel: work-groups per row of interpolation cells (1 in batch mode; a single image is cut
+                         // into ~60 short row bands so that it does not run on 10 CUs only -- latency)
 };
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
@@ -246,7 +249,9 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
     const int ncx = P.tiles_x + 1;
     uint32_t *lut4 = (uint32_t *)clahe_smem;                            // ncx * 256
     int cy, b;
-    ov2_xcd_map(blockIdx.x, P.tiles_y + 1, P.batch, &b, &cy);
+    ov2_xcd_map(blockIdx.x, (P.tiles_y + 1) * P.ysplit, P.batch, &b, &cy);
+    const int part = cy % P.ysplit;
+    cy /= P.ysplit;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int ty1 = max(cy - 1, 0), ty2 = min(cy, P.tiles_y - 1);
     const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;
@@ -269,6 +274,11 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
     int y0 = max(0, (int)floorf(((float)cy - 0.5f) * (float)P.th) - 1), y1 = min(P.h, (int)ceilf(((float)cy + 0.5f) * (float)P.th) + 2);
     while (y0 < y1 && (int)floorf((float)y0 * P.inv_th - 0.5f) + 1 != cy) y0++;
     while (y1 > y0 && (int)floorf((float)(y1 - 1) * P.inv_th - 0.5f) + 1 != cy) y1--;
+    if (P.ysplit > 1) {                                                 // this work-group's band of the cell row
+        const int chunk = (y1 - y0 + P.ysplit - 1) / P.ysplit;
+        y0 = min(y1, y0 + part * chunk);
+        y1 = min(y1, y0 + chunk);
+    }
     const uint8_t *simg = src + (long long)b * P.src_item_stride;
     uint8_t *dimg = dst + (long long)b * P.dst_item_stride;
     // the source may have any alignment (KITTI: 1241-byte rows): rows are read as aligned dwords + v_alignbyte;
@@ -385,10 +395,23 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
     }
 }
 
-static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
-                        double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                        uint8_t *lut_d, int border = 0)
+int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
+                     double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
+                     uint8_t *lut_d, int border)
 {
+    // geometry checks first: nothing is enqueued when the call is going to fail
+    OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && (size_t)(tiles_x + 1) * 1024 <= 160 * 1024, OV2_EUNSUPPORTED,
+                "CLAHE: too many tile columns / too wide an image for the LDS tables");
+    // the dynamic-LDS limit is a per-function, process-wide attribute: raise it ONCE to the hardware maximum instead of
+    // per call to that call's need (two contexts on two threads would otherwise race on it)
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute((const void *)k_clahe_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute((const void *)k_clahe_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    OV2_HIP_CHECK(attr_err);
     ClaheParams P;
     P.border = border;
     int ew = w, eh = h;
@@ -404,16 +427,14 @@ static int clahe_launch(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int st
     // ~5 tiles per wavefront (prefetch pipeline) once the batch alone fills the GPU, one tile per wavefront otherwise (latency)
     const int tiles_per_wave = (long long)batch * tiles_x * tiles_y >= 32768 ? 5 : 1;
     const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
+    P.ysplit = (long long)batch * (tiles_y + 1) >= 256 ? 1 : (P.th >= 48 ? 6 : (P.th >= 16 ? 3 : 1));
     P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
     hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 2048 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 511) / 512;
     const int apply_threads = (((ndw + passes - 1) / passes) + 63) / 64 * 64;
-    OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && apply_lds <= 160 * 1024, OV2_EUNSUPPORTED, "CLAHE: too many tile columns / too wide an image for the LDS tables");
-    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
-    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_clahe_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)apply_lds));
-    hipLaunchKernelGGL(src_al ? k_clahe_apply<true> : k_clahe_apply<false>, dim3((tiles_y + 1) * batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
+    hipLaunchKernelGGL(src_al ? k_clahe_apply<true> : k_clahe_apply<false>, dim3((tiles_y + 1) * P.ysplit * batch), dim3(apply_threads), apply_lds, ctx->stream, P, src_d, lut_d, dst_d);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
@@ -430,8 +451,8 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
     const size_t lut_bytes = (size_t)batch * tiles_x * tiles_y * 256;
     const int rc = ctx->reserve_device(lut_bytes);
     if (rc != OV2_OK) return rc;
-    return clahe_launch(ctx, src_d, w, h, stride, src_batch_stride, batch, clip_limit, tiles_x, tiles_y, dst_d, dst_stride,
-                        dst_batch_stride, (uint8_t *)ctx->d_scratch);
+    return ov2_launch_clahe(ctx, src_d, w, h, stride, src_batch_stride, batch, clip_limit, tiles_x, tiles_y, dst_d, dst_stride,
+                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0);
 }
 
 int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
@@ -447,10 +468,12 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
     // the equalised image is written straight into the pyramid's padded level-0 slot (no intermediate image,
     // no level-0 copy); borders and the coarser levels follow from there
     const PyrLevelDesc &L0 = p->d.lv[0];
-    rc = clahe_launch(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
-                      p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win);
+    rc = ov2_launch_clahe(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
+                          p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win);
     if (rc != OV2_OK) return rc;
-    return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+    rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+    if (rc != OV2_OK) return rc;
+    return ov2_pyr_mark_ready(ctx, p);
 }
 
 // host-image form of ov2_pyr_build_clahe_d (batch-1 pyramids): one H2D of the raw frame, nothing comes back
@@ -468,10 +491,12 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
     OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
     const PyrLevelDesc &L0 = p->d.lv[0];
-    rc = clahe_launch(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
-                      (size_t)p->d.item_stride, ds + img, p->d.win);
+    rc = ov2_launch_clahe(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
+                          (size_t)p->d.item_stride, ds + img, p->d.win);
     if (rc != OV2_OK) return rc;
-    return ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+    rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+    if (rc != OV2_OK) return rc;
+    return ov2_pyr_mark_ready(ctx, p);
 }
 
 int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
@@ -487,7 +512,7 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     if (rc != OV2_OK) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
     OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
-    const int rc2 = clahe_launch(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img);
+    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0);
     if (rc2 != OV2_OK) return rc2;
     OV2_HIP_CHECK(hipMemcpy2DAsync(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -78,7 +78,23 @@ struct ov2_pyr {
     int w = 0, h = 0, max_level = 0;
     size_t bytes = 0;
     int device = 0;
+    // Cross-context hand-off (the front-end's pyramid is read by the mapper thread's context):
+    // every (re)build records `ready` on the producing stream; a consumer entry point running on another stream
+    // waits on it before its first kernel (ov2_pyr_wait_ready).  Same-stream use costs nothing.
+    hipEvent_t ready = nullptr;
+    hipStream_t producer = nullptr;
+    bool built = false;
 };
+int ov2_pyr_mark_ready(ov2_ctx *ctx, ov2_pyr *p);              // after the last kernel of a build was enqueued
+int ov2_pyr_wait_ready(ov2_ctx *ctx, const ov2_pyr *p);        // before the first kernel of a consumer
 
 // kernels' host launchers (defined in the .hip files)
 int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride);
+// cv::CLAHE::apply on `batch` device images; border > 0: dst is a padded pyramid level, its REFLECT_101 border is written too
+int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
+                     double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
+                     uint8_t *lut_d, int border);
+// fused VisualFrontEnd::kltTracking launch (lk.hip), device pointers only
+int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
+                         int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
+                         const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters);

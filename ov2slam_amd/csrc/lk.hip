@@ -373,6 +373,43 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
     }
 }
 
+// fbKltTracking for the keypoint owned by this 16-lane row: forward levels max_level..0 (feature_tracker.cpp:66-69),
+// the status / err / border filter (:79-101), the backward track at level 0 from the original keypoint (:113-116) and
+// the forward-backward distance test (:119-134).  Returns the status; (fx, fy) = vpriorkps[i] after the forward call.
+template <int WIN>
+__device__ __forceinline__ int fb_track_point(const uint8_t *__restrict__ itemP, const uint8_t *__restrict__ itemC,
+                                              const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int max_level,
+                                              float2 kp, float2 pr, int r, float &fx, float &fy, LKPointState &st)
+{
+    st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
+    // forward: prev -> cur, levels max_level..0   (feature_tracker.cpp:66-69)
+    for (int level = max_level; level >= 0; level--)
+        lk_level<WIN>(itemP, P.lv[level], itemC, C.lv[level], prm, level, max_level,
+                      (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, r, st);
+    fx = st.nx; fy = st.ny;
+    int ok = st.status;
+    if (prm.do_fb) {
+        // feature_tracker.cpp:79-101
+        if (ok && st.err > prm.err_th) ok = 0;
+        const float W0 = (float)C.lv[0].w, H0 = (float)C.lv[0].h;
+        if (ok && !(1.f <= fx && fx < W0 - 1.f && 1.f <= fy && fy < H0 - 1.f)) ok = 0;   // inBorder :216-221
+        if (ok) {
+            // backward: cur -> prev at level 0, initial guess = original keypoint (:113-116)
+            LKPointState sb;
+            sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0; sb.visits = 0;
+            lk_level<WIN>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
+            st.iters += sb.iters; st.visits += sb.visits;
+            if (!sb.status) ok = 0;
+            else {
+                const float ddx = kp.x - sb.nx, ddy = kp.y - sb.ny;      // cv::norm(Point2f) (:128)
+                const double nrm = sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
+                if (nrm > (double)prm.fb_dist) ok = 0;
+            }
+        }
+    }
+    return ok;
+}
+
 template <int WIN>
 __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams prm,
                                                 const float2 *__restrict__ kps, float2 *__restrict__ priors,
@@ -393,38 +430,9 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
         const long long gi = (long long)b * prm.n_max + i;
         const uint8_t *itemP = P.base + (long long)b * P.item_stride;
         const uint8_t *itemC = C.base + (long long)b * C.item_stride;
-
-        const float2 kp = kps[gi];
-        const float2 pr = priors[gi];
         LKPointState st;
-        st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
-
-        // forward: prev -> cur, levels max_level..0   (feature_tracker.cpp:66-69)
-        for (int level = prm.max_level; level >= 0; level--)
-            lk_level<WIN>(itemP, P.lv[level], itemC, C.lv[level], prm, level, prm.max_level,
-                          (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, r, st);
-
-        const float fx = st.nx, fy = st.ny;
-        int ok = st.status;
-        if (prm.do_fb) {
-            // feature_tracker.cpp:79-101
-            if (ok && st.err > prm.err_th) ok = 0;
-            const float W0 = (float)C.lv[0].w, H0 = (float)C.lv[0].h;
-            if (ok && !(1.f <= fx && fx < W0 - 1.f && 1.f <= fy && fy < H0 - 1.f)) ok = 0;   // inBorder :216-221
-            if (ok) {
-                // backward: cur -> prev at level 0, initial guess = original keypoint (:113-116)
-                LKPointState sb;
-                sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0; sb.visits = 0;
-                lk_level<WIN>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
-                st.iters += sb.iters; st.visits += sb.visits;
-                if (!sb.status) ok = 0;
-                else {
-                    const float ddx = kp.x - sb.nx, ddy = kp.y - sb.ny;      // cv::norm(Point2f) (:128)
-                    const double nrm = sqrt((double)ddx * (double)ddx + (double)ddy * (double)ddy);
-                    if (nrm > (double)prm.fb_dist) ok = 0;
-                }
-            }
-        }
+        float fx, fy;
+        const int ok = fb_track_point<WIN>(itemP, itemC, P, C, prm, prm.max_level, kps[gi], priors[gi], r, fx, fy, st);
         if (r == 0) {
             priors[gi] = make_float2(fx, fy);
             status[gi] = (uint8_t)ok;
@@ -441,6 +449,47 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
         if (threadIdx.x < 2 && s_stats[threadIdx.x])
             atomicAdd(&stats[((blockIdx.y * gridDim.x + blockIdx.x) & (LK_STAT_SLOTS - 1)) * LK_STAT_STRIDE + threadIdx.x],
                       (unsigned long long)s_stats[threadIdx.x]);
+    }
+}
+
+// ---- VisualFrontEnd::kltTracking in ONE launch (src/visual_front_end.cpp:132-275) ------------------------------
+// The reference tracks the keypoints that carry a 3-D prior on `lvl_prior` (= 1) pyramid levels first (:186-218),
+// then everything else on `lvl_full` (= nklt_pyr_lvl_) levels (:239-268) -- and every keypoint the first call lost is
+// appended to the second call with the forward result of the first call as its prior (:213-217: v3dpriors was
+// updated in place by fbKltTracking, feature_tracker.cpp:66).  Keypoints are independent inside fbKltTracking, so
+// the two calls and the retry are one pass over the keypoints: flag bit 0 = "has a 3-D prior".
+// status bit 0 = tracked, bit 1 = the prior-pass failed and the result comes from the full-pyramid retry.  The one
+// cross-keypoint decision of the reference (:225-230: fewer than a third of the prior tracks good -> retry from the
+// keypoints themselves) is taken by the host from the bit-1 count (ov2_tracker_klt, track.hip).
+// One wavefront per work-group (4 keypoints): a single frame has ~300 keypoints, so every wavefront gets a CU of its own.
+template <int WIN>
+__global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams prm, int lvl_prior, int lvl_full,
+                                                  const int *__restrict__ n_dev, const float2 *__restrict__ kps,
+                                                  const float2 *__restrict__ priors, const uint8_t *__restrict__ flags,
+                                                  float2 *__restrict__ out_xy, uint8_t *__restrict__ status,
+                                                  int *__restrict__ iters_out)
+{
+    const int n = *n_dev;
+    const int r = threadIdx.x & 15;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (i >= n) return;
+    const float2 kp = kps[i];
+    float2 pr = priors[i];
+    const bool has_prior = (flags[i] & 1) != 0;
+    int max_level = has_prior ? lvl_prior : lvl_full;
+    int ok = 0, retried = 0, iters = 0;
+    float fx = 0.f, fy = 0.f;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        LKPointState st;
+        ok = fb_track_point<WIN>(P.base, C.base, P, C, prm, max_level, kp, pr, r, fx, fy, st);
+        iters += st.iters;
+        if (ok || !has_prior || attempt == 1) break;
+        pr = make_float2(fx, fy); max_level = lvl_full; retried = 1;      // :213-217
+    }
+    if (r == 0) {
+        out_xy[i] = make_float2(fx, fy);
+        status[i] = (uint8_t)(ok | (retried << 1));
+        if (iters_out) iters_out[i] = iters;
     }
 }
 
@@ -497,6 +546,8 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
                 "prev/cur pyramids differ in geometry");
     OV2_REQUIRE(P.lv[0].w == C.lv[0].w && P.lv[0].h == C.lv[0].h, OV2_EINVAL, "prev/cur image size differs");
     OV2_REQUIRE(prm.win == P.win, OV2_EINVAL, "LK window differs from the window the pyramid was padded for");
+    if (int rcw = ov2_pyr_wait_ready(ctx, prev)) return rcw;      // pyramids built on another context's stream
+    if (int rcw = ov2_pyr_wait_ready(ctx, cur)) return rcw;
     dim3 grid((prm.n_max + 15) / 16, P.batch);
     unsigned long long *slots = nullptr;
     if (stats_d) {
@@ -542,6 +593,36 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
     prm.flags = flags;
     prm.err_th = err_th; prm.fb_dist = fb_dist; prm.do_fb = do_fb; prm.n_max = n_max;
     return prm;
+}
+
+// launcher of the fused kltTracking kernel (used by track.hip); all pointers are device memory, *n_dev <= n_max
+int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
+                         int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
+                         const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters)
+{
+    const PyrDesc &P = prev->d, &C = cur->d;
+    OV2_REQUIRE(P.n_levels == C.n_levels && P.batch == 1 && C.batch == 1 && P.win == C.win && win == P.win, OV2_EINVAL,
+                "tracker pyramids differ in geometry");
+    LKParams prm = make_params(prev, win, lvl_full, max_iter, eps, OV2_LK_USE_INITIAL_FLOW | OV2_LK_GET_MIN_EIGENVALS,
+                               err_th, fb_dist, 1, n_max);
+    const int lf = prm.max_level;                                  // clamped to the pyramid like feature_tracker.cpp:50-52
+    const int lp = lvl_prior > P.n_levels - 1 ? P.n_levels - 1 : (lvl_prior < 0 ? 0 : lvl_prior);
+    dim3 grid((n_max + 3) / 4), block(64);
+#define OV2_TK(W) hipLaunchKernelGGL(k_track_klt<W>, grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
+                                     (const float2 *)priors, flags, (float2 *)out_xy, status, iters)
+    switch (win) {
+    case 5:  OV2_TK(5); break;
+    case 7:  OV2_TK(7); break;
+    case 9:  OV2_TK(9); break;
+    case 11: OV2_TK(11); break;
+    case 13: OV2_TK(13); break;
+    default:
+        ov2_set_error("LK window %d has no kernel instance (supported: 5,7,9,11,13; the reference ships 9)", win);
+        return OV2_EUNSUPPORTED;
+    }
+#undef OV2_TK
+    OV2_HIP_CHECK(hipGetLastError());
+    return OV2_OK;
 }
 
 extern "C" {

@@ -321,6 +321,21 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
     return OV2_OK;
 }
 
+// ---- producer / consumer ordering across contexts ---------------------------------
+int ov2_pyr_mark_ready(ov2_ctx *ctx, ov2_pyr *p)
+{
+    OV2_HIP_CHECK(hipEventRecord(p->ready, ctx->stream));
+    p->producer = ctx->stream;
+    p->built = true;
+    return OV2_OK;
+}
+
+int ov2_pyr_wait_ready(ov2_ctx *ctx, const ov2_pyr *p)
+{
+    if (p->producer != ctx->stream && p->ready) OV2_HIP_CHECK(hipStreamWaitEvent(ctx->stream, p->ready, 0));
+    return OV2_OK;
+}
+
 // ---- C ABI ----------------------------------------------------------------------
 static inline long long round_up(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -362,7 +377,12 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
     if (e != hipSuccess) { delete p; ov2_set_error("hipMalloc(%zu): %s", p->bytes, hipGetErrorString(e)); return OV2_ENOMEM; }
     // alignment slack around the borders is read (never consumed) by the dword row loads: keep it defined
     e = hipMemsetAsync(D.base, 0, p->bytes, ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(D.base); delete p; ov2_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return OV2_EHIP; }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming);
+    if (e == hipSuccess) { e = hipEventRecord(p->ready, ctx->stream); p->producer = ctx->stream; }
+    if (e != hipSuccess) {
+        if (p->ready) (void)hipEventDestroy(p->ready);
+        (void)hipFree(D.base); delete p; ov2_set_error("ov2_pyr_create: %s", hipGetErrorString(e)); return OV2_EHIP;
+    }
     *out = p;
     return OV2_OK;
 }
@@ -371,6 +391,7 @@ void ov2_pyr_destroy(ov2_pyr *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    if (p->ready) { (void)hipEventSynchronize(p->ready); (void)hipEventDestroy(p->ready); }   // a consumer may still be reading
     if (p->d.base) (void)hipFree(p->d.base);
     delete p;
 }
@@ -391,7 +412,8 @@ int ov2_pyr_build_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, 
     OV2_REQUIRE(stride >= p->w, OV2_EINVAL, "stride < width");
     OV2_REQUIRE(p->d.batch == 1 || img_batch_stride >= (size_t)stride * (size_t)p->h, OV2_EINVAL, "img_batch_stride too small");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
-    return ov2_launch_pyr_build(ctx, p, img_d, stride, img_batch_stride);
+    const int rc = ov2_launch_pyr_build(ctx, p, img_d, stride, img_batch_stride);
+    return rc != OV2_OK ? rc : ov2_pyr_mark_ready(ctx, p);
 }
 
 int ov2_pyr_build_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, size_t img_batch_stride)
@@ -409,7 +431,8 @@ int ov2_pyr_build_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, 
                                        img_h + img_batch_stride * b, (size_t)stride, (size_t)p->w, (size_t)p->h,
                                        hipMemcpyHostToDevice, ctx->stream));
     }
-    return ov2_launch_pyr_build(ctx, p, (const uint8_t *)ctx->d_scratch, (int)pitch, item);
+    const int rc2 = ov2_launch_pyr_build(ctx, p, (const uint8_t *)ctx->d_scratch, (int)pitch, item);
+    return rc2 != OV2_OK ? rc2 : ov2_pyr_mark_ready(ctx, p);
 }
 
 static int pyr_download_impl(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h, int padded)
@@ -417,6 +440,7 @@ static int pyr_download_impl(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, u
     OV2_REQUIRE(ctx && p, OV2_EINVAL, "NULL argument");
     OV2_REQUIRE(level >= 0 && level < p->d.n_levels && b >= 0 && b < p->d.batch, OV2_EINVAL, "bad level/batch index");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rcw = ov2_pyr_wait_ready(ctx, p)) return rcw;
     const PyrLevelDesc &L = p->d.lv[level];
     const int pad = padded ? p->d.win : 0;
     const int ow = L.w + 2 * pad, oh = L.h + 2 * pad;

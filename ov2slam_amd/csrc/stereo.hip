@@ -171,6 +171,8 @@ int ov2_line_min_sad(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
                 "left/right level size differs");
     OV2_REQUIRE(nwinsize > 0 && nwinsize <= 9, OV2_EUNSUPPORTED, "getLineMinSAD window up to 9 (the reference uses 7)");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rcw = ov2_pyr_wait_ready(ctx, left)) return rcw;       // e.g. the front-end's left pyramid read by the mapper's context
+    if (int rcw = ov2_pyr_wait_ready(ctx, right)) return rcw;
     // layout: [pts 8n][xprior 4n][l1err 4n]
     const size_t total = 16 * (size_t)n;
     int rc = ctx->reserve_device(total);  if (rc) return rc;

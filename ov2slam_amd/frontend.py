@@ -13,6 +13,8 @@ parity tests read like calls into the reference:
 numpy arrays are the host buffers; nothing here computes on the CPU.
 """
 import ctypes as C
+import weakref
+
 import numpy as np
 
 from . import _lib as L
@@ -34,6 +36,8 @@ class Context:
             L.check(self.lib.ov2_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
         self.h = h
         self.device = device
+        # objects that hold device memory / streams of this context: closed before the context itself
+        self._children = weakref.WeakSet()
 
     def sync(self):
         L.check(self.lib.ov2_ctx_sync(self.h))
@@ -44,6 +48,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for c in list(self._children):
+                c.close()
             self.lib.ov2_ctx_destroy(self.h)
             self.h = None
 
@@ -64,6 +70,7 @@ class Pyramid:
         hp = C.c_void_p()
         L.check(self.lib.ov2_pyr_create(ctx.h, w, h, win, max_level, batch, C.byref(hp)))
         self.h_pyr = hp
+        ctx._children.add(self)
 
     @property
     def levels(self):
@@ -203,6 +210,98 @@ class FeatureTracker:
                                       self.nmax_iter, self.fmax_px_precision, int(flags),
                                       _ptr(p0), _ptr(p1), n, _ptr(status), _ptr(err), _ptr(iters)))
         return p1, status, err, iters
+
+
+class _PyrView:
+    """Borrowed ov2_pyr handle (owned by a Tracker): usable wherever a Pyramid is expected."""
+
+    def __init__(self, ctx, h_pyr, w, h, win):
+        self.ctx, self.lib, self.h_pyr, self.w, self.h, self.win, self.batch = ctx, ctx.lib, h_pyr, w, h, win, 1
+
+    levels = Pyramid.levels
+    level_size = Pyramid.level_size
+    download = Pyramid.download
+
+
+class VisualFrontEndTracker:
+    """The per-frame GPU half of the reference's VisualFrontEnd (src/visual_front_end.cpp): it owns prev_pyr_ / cur_pyr_
+    and performs preprocessImage (:1143-1177) + kltTracking (:132-275) per frame -- one H2D of the frame, one H2D of the
+    keypoint block, ONE LK launch for both fbKltTracking calls and the retry of lost prior tracks, one D2H, one sync
+    (ov2_tracker_*).  Parameters are the SlamParams fields of the same names."""
+
+    def __init__(self, ctx, w, h, nklt_win_size=9, nklt_pyr_lvl=3, nmax_iter=30, fmax_px_precision=0.01, nklt_err=30.0,
+                 fmax_fbklt_dist=0.5, use_clahe=True, fclahe_val=3.0, nbmaxkps=512, use_graph=True, prior_pyr_lvl=1):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.w, self.h, self.win = int(w), int(h), int(nklt_win_size)
+        cfg = L.TrackerConfig(self.w, self.h, self.win, int(nklt_pyr_lvl), int(prior_pyr_lvl), int(nmax_iter),
+                              float(np.float32(fmax_px_precision)), float(nklt_err), float(fmax_fbklt_dist),
+                              int(bool(use_clahe)), float(fclahe_val), self.w // 50, self.h // 50, int(nbmaxkps),
+                              int(bool(use_graph)))
+        ht = C.c_void_p()
+        L.check(self.lib.ov2_tracker_create(ctx.h, C.byref(cfg), C.byref(ht)))
+        self.h_trk = ht
+        ctx._children.add(self)
+        self.nbmaxkps = int(nbmaxkps)
+        stride = C.c_int()
+        ptr = self.lib.ov2_tracker_image_buffer(ht, C.byref(stride))
+        self.stride = stride.value
+        # numpy view of the pinned staging image: write the next frame here to skip the host-side copy
+        self.image_buffer = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(self.h, self.stride))
+
+    def _pts(self, vkps, vpriors, vhasprior):
+        kps = np.ascontiguousarray(vkps, dtype=np.float32).reshape(-1, 2)
+        pri = np.ascontiguousarray(vpriors, dtype=np.float32).reshape(-1, 2)
+        n = len(kps)
+        assert len(pri) == n
+        hp = None if vhasprior is None else np.ascontiguousarray(vhasprior, dtype=np.uint8)
+        return kps, pri, hp, n
+
+    def preprocessImage(self, img_raw):
+        """Asynchronous (returns after the enqueue)."""
+        img = np.ascontiguousarray(img_raw, dtype=np.uint8)
+        assert img.shape[0] == self.h and img.shape[1] >= self.w
+        L.check(self.lib.ov2_tracker_preprocess(self.h_trk, _ptr(img), img.strides[0]))
+
+    def kltTracking(self, vkps, vpriors, vhasprior, klt_use_prior=True):
+        """-> (tracked px (n,2), status bits (n,) uint8 [bit0 tracked, bit1 re-tracked on the full pyramid], bp3preq)."""
+        kps, pri, hp, n = self._pts(vkps, vpriors, vhasprior)
+        out = np.zeros((n, 2), np.float32); st = np.zeros(n, np.uint8); p3p = C.c_int(0)
+        L.check(self.lib.ov2_tracker_klt(self.h_trk, _ptr(kps), _ptr(pri), _ptr(hp), n, int(bool(klt_use_prior)),
+                                         _ptr(out), _ptr(st), C.byref(p3p)))
+        return out, st, bool(p3p.value)
+
+    def trackFrame(self, img_raw, vkps, vpriors, vhasprior, klt_use_prior=True):
+        """preprocessImage + kltTracking in one enqueue (graph replay when enabled)."""
+        img = img_raw if img_raw is self.image_buffer else np.ascontiguousarray(img_raw, dtype=np.uint8)
+        kps, pri, hp, n = self._pts(vkps, vpriors, vhasprior)
+        out = np.zeros((n, 2), np.float32); st = np.zeros(n, np.uint8); p3p = C.c_int(0)
+        L.check(self.lib.ov2_tracker_track_frame(self.h_trk, _ptr(img), img.strides[0], _ptr(kps), _ptr(pri), _ptr(hp), n,
+                                                 int(bool(klt_use_prior)), _ptr(out), _ptr(st), C.byref(p3p)))
+        return out, st, bool(p3p.value)
+
+    @property
+    def cur_pyr(self):
+        return _PyrView(self.ctx, C.c_void_p(self.lib.ov2_tracker_cur_pyr(self.h_trk)), self.w, self.h, self.win)
+
+    @property
+    def prev_pyr(self):
+        return _PyrView(self.ctx, C.c_void_p(self.lib.ov2_tracker_prev_pyr(self.h_trk)), self.w, self.h, self.win)
+
+    @property
+    def uses_graph(self):
+        return bool(self.lib.ov2_tracker_uses_graph(self.h_trk))
+
+    def close(self):
+        if getattr(self, "h_trk", None):
+            self.image_buffer = None
+            self.lib.ov2_tracker_destroy(self.h_trk)
+            self.h_trk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FeatureExtractor:
