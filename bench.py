@@ -3,27 +3,37 @@
 
 Metric (BASELINE.json): "frames/sec tracking + local-BA iters/sec, EuRoC MH_01 stereo 'accurate'".
 
-One timed "step" = one camera frame of config[1] (EuRoC MH_01 stereo, 'accurate' parameters:
-752x480, LK 9x9, 3+1 pyramid levels, 30 it / 0.01 px, 308 keypoints) pushed through the HIP hot
-path for each of the `--seqs` sequences this GPU processes in lock-step (offline
-batch-of-sequences mode of config[4]; default 4096 = 16.5 GB of HBM per GPU, `--seqs 1` is the single-sequence
-drop-in case; the per-frame work does not depend on it, the fill of the GPU does -- DESIGN.md section 6):
-    preprocessImage : CLAHE (clip 3.0, 15x9 tiles: use_clahe 1 in parameters_files/accurate) of the new left
-                      image + device-resident pyramid build (/root/reference/src/visual_front_end.cpp:1143-1177)
-    kltTracking     : fbKltTracking pass A (nbpyrlvl=1) on the keypoints that carry a 3-D prior,
-                      pass B (nbpyrlvl=3) on the others (src/visual_front_end.cpp:186-268)
-`value` = tracked frames/s over all sequences and ranks (max-over-ranks time).  Images, keypoints
-and priors are synthetic (ov2slam_amd/synth.py; no dataset offline) and already resident in HBM.
+    python bench.py --gpus N --steps K --warmup W
 
-Outside the K timed steps (rank 0, N=1 only) the same line also reports
-    ba     : local-BA LM iterations/s on config[3] (50 KF x 10k landmarks x 30 obs, resident in HBM)
-    detect : detectSingleScale (273 cells) + fbKltTracking through the host-buffer drop-in API
-    cpu_baseline : the oracle (CPU port of the reference arithmetic) on the box's host cores.
+`--gpus N` with N > 1 and no RANK in the environment makes this process the LAUNCHER: it checks that N GPUs are
+visible (fails loudly otherwise), picks a free port on 127.0.0.1 and spawns N ranks of itself (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), exactly what `python -m torch.distributed.run --nproc-per-node N`
+does; under torchrun (RANK already set) it is a rank.  Ranks talk RCCL (`--backend nccl`, default) or gloo
+(`--backend gloo --dry`: launcher + collective path only, no GPU -- the CPU test of the N>1 plumbing).
+
+One timed "step" = one camera frame of config[1] (EuRoC MH_01 stereo, 'accurate' parameters: 752x480, CLAHE, LK 9x9,
+3+1 pyramid levels, 30 it / 0.01 px, 308 keypoints) pushed through the HIP hot path for each of the `--seqs` sequences
+this GPU processes in lock-step (offline batch-of-sequences mode; default 4096 = 16.5 GB of HBM per GPU):
+    preprocessImage : CLAHE + device-resident pyramid (/root/reference/src/visual_front_end.cpp:1143-1177)
+    kltTracking     : fbKltTracking pass A (nbpyrlvl 1, keypoints with a 3-D prior) + pass B (nbpyrlvl 3)  (:132-275)
+`value` = tracked frames/s over all sequences and ranks (max-over-ranks time), inputs resident in HBM.
+
+The same line also carries:
+    single_sequence : ONE camera stream through the drop-in entry (ov2_tracker_track_frame: one H2D of the frame, one
+                      LK launch, one sync, hipGraph replay) -- PCIe-inclusive per-frame latency and frames/s; this is the
+                      mode configs[1], [2] and [4] of BASELINE.json actually use
+    config5         : the 11 synthetic EuRoC-length sequences sharded longest-first over the ranks, each run frame by
+                      frame through the single-sequence path (+ detection at keyframes); aggregate over RCCL all-gather
+    ba              : local-BA LM iterations/s on config[3] (50 KF x 10k landmarks x 30 obs) and variants (rank 0, N=1)
+    parity          : the tracker's output on one frame vs the oracle (bit-exact) and the BA poses vs the oracle
+    cpu_baseline    : the oracle (CPU port of the reference arithmetic) rebuilt -O3 -march=native on this host
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,6 +49,7 @@ N_PASS_B = NKPS - N_PASS_A  # pass B (4 levels)
 NF = 6                      # distinct synthetic views per sequence (cycled)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 CLAHE_CLIP, CLAHE_TILES = 3.0, (W // 50, H // 50)   # ov2slam.cpp:85-89, accurate/euroc: fclahe_val 3
+METRIC = "frames/sec tracking + local-BA iters/sec, EuRoC MH_01 stereo 'accurate', 1 GPU vs CPU ref"
 
 
 def make_inputs(seqs, seed):
@@ -84,49 +95,270 @@ def lk_algorithmic_bytes(iters, visits, npts):
     return 500 * visits + 100 * iters + 29 * npts
 
 
-def cpu_baseline(views, kps, pri, ba_problem, budget_s=10.0):
-    """Oracle ('port') on the host cores: the same tracking step, and the same BA problem."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(views, kps, pri, ba_problem, budget_s=8.0):
+    """Oracle ('port') on the host cores, rebuilt -O3 -march=native here; per slice of the reference's Profiler names
+    (BASELINE.md section 2): CLAHE + pyramid over rows / tiles on the pool (cv::parallel_for_), LK over keypoints on the
+    pool, BA single-threaded like options.num_threads = 1 (optimizer.cpp:460)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    # pick the thread count that is fastest for this step on this host (cv::parallel_for_ would use a pool)
-    p0, p1 = O.Pyramid(views[0], WIN, LEVELS), O.Pyramid(views[1], WIN, LEVELS)
-    best_nt, best_t = 1, 1e9
-    for nt in (1, 2, 4, 8, 16, 32, 64):
-        if nt > cores:
-            break
-        t0 = time.perf_counter()
-        for _ in range(5):
-            O.fb_klt(p0, p1, WIN, LEVELS, 30., 0.5, kps[0, 0], pri[0, 0], nthreads=nt)
-        t = time.perf_counter() - t0
-        if t < best_t:
-            best_nt, best_t = nt, t
-    t0 = time.perf_counter()
-    frames = 0
+    flags = O.use_native() or "-O3 -march=x86-64-v2 -ffp-contract=off (native rebuild failed: portable build)"
+    p0 = O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+    hp = np.zeros(NKPS, bool); hp[:N_PASS_A] = True
+
+    def pre():
+        return O.Pyramid(O.clahe(views[1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+
+    def lk(p1, nt):
+        O.fb_klt(p0, p1, WIN, 1, 30., 0.5, kps[0, 0][:N_PASS_A], pri[0, 0][:N_PASS_A], nthreads=nt)
+        O.fb_klt(p0, p1, WIN, LEVELS, 30., 0.5, kps[0, 0][N_PASS_A:], pri[0, 0][N_PASS_A:], nthreads=nt)
+
+    def best(fn, reps=6):
+        fn(); ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    # thread count per slice: whatever is fastest on this host (OpenCV would use its pool = all cores)
+    cand = [n for n in (1, 2, 4, 8, 16, 32, 64, 128) if n <= cores]
+    pre_t, lk_t = {}, {}
+    p1 = pre()
+    for nt in cand:
+        O.set_num_threads(nt)
+        pre_t[nt] = best(pre)
+        lk_t[nt] = best(lambda: lk(p1, nt))
+    nt_pre = min(pre_t, key=pre_t.get); nt_lk = min(lk_t, key=lk_t.get)
+    # bounded sample of the whole step
+    t0 = time.perf_counter(); frames = 0; t_pre = t_lk = 0.0
     prevp = p0
     while True:
         f = frames % NF
+        a = time.perf_counter()
+        O.set_num_threads(nt_pre)
         if f == 0:
             prevp = O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+            a = time.perf_counter()
         curp = O.Pyramid(O.clahe(views[f + 1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+        b = time.perf_counter()
+        O.set_num_threads(nt_lk)
         k, p = kps[f, 0], pri[f, 0]
-        O.fb_klt(prevp, curp, WIN, 1, 30., 0.5, k[:N_PASS_A], p[:N_PASS_A], nthreads=best_nt)
-        O.fb_klt(prevp, curp, WIN, LEVELS, 30., 0.5, k[N_PASS_A:], p[N_PASS_A:], nthreads=best_nt)
+        O.fb_klt(prevp, curp, WIN, 1, 30., 0.5, k[:N_PASS_A], p[:N_PASS_A], nthreads=nt_lk)
+        O.fb_klt(prevp, curp, WIN, LEVELS, 30., 0.5, k[N_PASS_A:], p[N_PASS_A:], nthreads=nt_lk)
+        c = time.perf_counter()
+        t_pre += b - a; t_lk += c - b
         prevp = curp
         frames += 1
-        el = time.perf_counter() - t0
-        if el > budget_s and frames >= 20:
+        if c - t0 > budget_s and frames >= 20:
             break
-    out = {"value": frames / el, "unit": "frames/s", "cores": best_nt, "kind": "port", "host_cores": cores,
-           "sample": "%d frames of the same synthetic 752x480 step (CLAHE + pyramid build + LK pass A/B) through "
-                     "oracle/liboracle.so, LK over keypoints on %d pthreads (best of 1..64)" % (frames, best_nt)}
+    el = t_pre + t_lk
+    out = {"value": frames / el, "unit": "frames/s", "cores": max(nt_pre, nt_lk), "kind": "port", "host_cores": cores,
+           "build": flags,
+           "slices_ms": {"2.FE_TM_preprocessImage": t_pre / frames * 1e3, "2.FE_TM_KLT-Tracking": t_lk / frames * 1e3},
+           "threads": {"2.FE_TM_preprocessImage": nt_pre, "2.FE_TM_KLT-Tracking": nt_lk, "2.BA_Optimize": 1},
+           "sample": "%d frames of the same synthetic 752x480 step through the oracle (a C restatement of the OpenCV / Ceres "
+                     "arithmetic the reference calls -- NOT OpenCV / Ceres themselves, which are absent from this image), "
+                     "persistent thread pool, CLAHE + pyramid over tiles / rows on %d threads, LK over keypoints on %d threads "
+                     "(fastest of %s each)" % (frames, nt_pre, nt_lk, cand)}
     if ba_problem is not None:
+        O.set_num_threads(1)
         t0 = time.perf_counter()
         r = O.ba_solve(ba_problem)
-        el = time.perf_counter() - t0
-        out["ba"] = {"iters_per_s": r["iterations"] / el, "iterations": r["iterations"], "seconds": el, "cores": 1,
-                     "sample": "one robust pass (<=5 LM iterations) of the 50 KF x 10k landmark x 30 obs problem, "
-                               "single thread like options.num_threads = 1 (optimizer.cpp:460)"}
+        el_ba = time.perf_counter() - t0
+        out["ba"] = {"iters_per_s": r["iterations"] / el_ba, "iterations": r["iterations"], "seconds": el_ba, "cores": 1,
+                     "slice": "2.BA_Optimize",
+                     "sample": "one robust pass (<=5 LM iterations) of the 50 KF x 10k landmark x 30 obs problem, dense Schur "
+                               "complement, single thread like options.num_threads = 1 (optimizer.cpp:460)"}
+        out["_ba_result"] = r
     return out
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args):
+    """Spawn args.gpus ranks of this script (one per GPU) and relay rank 0's JSON line."""
+    n = args.gpus
+    if not args.dry:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible -- refusing to run fewer ranks than requested\n" % (n, have))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, c))
+            rc = rc or c
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def config5_plan(world, scale):
+    from ov2slam_amd import batch
+    counts = {k: max(12, v // scale) for k, v in batch.EUROC_FRAMES.items()}
+    return counts, batch.assign_sequences(counts, world)
+
+
+def run_config5(ctx, rank, world, scale, dry=False):
+    """This rank's share of the 11 EuRoC-length synthetic sequences through the single-sequence path; all-gather of
+    (frames, seconds, tracked, attempted, squared tracking error) over torch.distributed -- the only collective."""
+    from ov2slam_amd import batch
+    counts, plan = config5_plan(world, scale)
+    mine = plan[rank]
+    loc = dict(frames=0.0, seconds=0.0, tracked=0.0, attempted=0.0, ate_sq_sum=0.0, ate_n=0.0, sequences=float(len(mine)))
+    if dry:
+        loc["frames"] = float(sum(counts[s] for s in mine)); loc["seconds"] = 1.0 + 0.25 * rank
+        loc["tracked"] = loc["attempted"] = 300.0 * loc["frames"]
+    else:
+        from ov2slam_amd import synth
+        tex = synth.base_texture(1400, 1234)
+        names = sorted(batch.EUROC_FRAMES)
+        seqs = [batch.SyntheticSequence(s, counts[s], seed=1000 + names.index(s), tex=tex) for s in mine]   # generation untimed
+        for sq in seqs:
+            st = batch.run_sequence(ctx, sq)
+            loc["frames"] += st["frames"]; loc["seconds"] += st["seconds"]; loc["tracked"] += st["tracked"]
+            loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
+    stats = batch.gather_stats(loc)
+    agg = batch.aggregate(stats)
+    return {"workload": "11 synthetic sequences with EuRoC frame counts / %d (%d frames), longest-first over %d rank(s); per frame "
+                        "ov2_tracker_track_frame, every 5th frame detectSingleScale" % (scale, int(sum(counts.values())), world),
+            "fps": agg["fps"], "frames": agg["frames"], "seconds_slowest_rank": agg["seconds"],
+            "frames_per_rank": stats["frames"], "seconds_per_rank": stats["seconds"], "sequences_per_rank": stats["sequences"],
+            "tracked_fraction": sum(stats["tracked"]) / max(1.0, sum(stats["attempted"])),
+            "track_rmse_px": agg.get("ate_rmse", 0.0), "assignment": plan}
+
+
+# ------------------------------------------------------------------------------------------------ extras (rank 0, N = 1)
+def single_sequence(dev_index, views, kps, pri, n_frames=600):
+    """ONE camera stream through the drop-in entry point, host buffers in, host buffers out, PCIe and the sync included.
+    `pageable`: the frame comes from an ordinary numpy array (the library stages it through its pinned buffer);
+    `pinned`: the frame was written into ov2_tracker_image_buffer() by its producer (no host-side copy)."""
+    import ov2slam_amd
+    from ov2slam_amd import _lib as L
+    ctx = ov2slam_amd.Context(dev_index)
+    lib = ctx.lib
+    hp = np.zeros(NKPS, np.uint8); hp[:N_PASS_A] = 1
+    res = {}
+    for mode in ("pageable", "pinned"):
+        trk = ov2slam_amd.VisualFrontEndTracker(ctx, W, H, fclahe_val=CLAHE_CLIP, nbmaxkps=512, use_graph=True)
+        pris = [np.ascontiguousarray(np.where(hp[:, None] > 0, pri[f, 0], kps[f, 0]), np.float32) for f in range(NF)]
+        out = np.zeros((NKPS, 2), np.float32); st = np.zeros(NKPS, np.uint8); p3p = C.c_int(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        a_k = [vp(kps[f, 0]) for f in range(NF)]; a_p = [vp(p) for p in pris]
+        a_hp, a_out, a_st, a_p3p = vp(hp), vp(out), vp(st), C.byref(p3p)
+        imgs = [np.ascontiguousarray(v) for v in views]
+        a_img = [vp(v) for v in imgs]
+        buf = trk.image_buffer
+        a_buf = vp(buf)
+        fn, h = lib.ov2_tracker_track_frame, trk.h_trk
+        ts, tracked = [], 0
+        for i in range(n_frames + 30):
+            f = i % NF
+            if f == 0:                                                     # restart the cycle: (re)build the pyramid of view 0
+                L.check(fn(h, a_img[0], W, None, None, None, 0, 1, None, None, None))
+            if mode == "pinned":
+                buf[:, :W] = imgs[f + 1]                                   # the producer's write, not part of the call
+                t0 = time.perf_counter()
+                rc = fn(h, a_buf, trk.stride, a_k[f], a_p[f], a_hp, NKPS, 1, a_out, a_st, a_p3p)
+            else:
+                t0 = time.perf_counter()
+                rc = fn(h, a_img[f + 1], W, a_k[f], a_p[f], a_hp, NKPS, 1, a_out, a_st, a_p3p)
+            t1 = time.perf_counter()
+            L.check(rc)
+            if i >= 30:
+                ts.append(t1 - t0); tracked += int((st & 1).sum())
+        ts = np.array(ts)
+        res[mode] = {"fps_incl_pcie": float(1.0 / ts.mean()), "ms_per_frame_mean": float(ts.mean() * 1e3),
+                     "ms_per_frame_median": float(np.median(ts) * 1e3), "ms_per_frame_p99": float(np.percentile(ts, 99) * 1e3),
+                     "tracked_fraction": tracked / (len(ts) * NKPS), "hip_graph": trk.uses_graph}
+        trk.close()
+    ctx.close()
+    res["entry"] = "ov2_tracker_track_frame: preprocessImage + kltTracking, 1 H2D (361 KB) + 5 kernels + 1 fused LK launch, 1 sync"
+    res["frames"] = n_frames
+    return res
+
+
+def parity_check(dev_index, views, kps, pri):
+    """In-bench parity: the tracker's output for two frames vs the oracle's preprocessImage + kltTracking (bit-exact)."""
+    import ov2slam_amd
+    from oracle import oracle as O
+    O.build()
+    ctx = ov2slam_amd.Context(dev_index)
+    trk = ov2slam_amd.VisualFrontEndTracker(ctx, W, H, fclahe_val=CLAHE_CLIP, nbmaxkps=512, use_graph=True)
+    hp = np.zeros(NKPS, np.uint8); hp[:N_PASS_A] = 1
+    empty = np.zeros((0, 2), np.float32)
+    trk.trackFrame(views[0], empty, empty, None)
+    ok_all, n = True, 0
+    prevp = O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+    for f in range(2):
+        k = kps[f, 0]; p = np.where(hp[:, None] > 0, pri[f, 0], k).astype(np.float32)
+        gout, gst, _ = trk.trackFrame(views[f + 1], k, p, hp)
+        curp = O.Pyramid(O.clahe(views[f + 1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+        rout, rok, rret, _ = O.klt_tracking(prevp, curp, k, p, hp)
+        ok_all &= bool(np.array_equal((gst & 1).astype(bool), rok) and np.array_equal((gst & 2).astype(bool), rret)
+                       and np.array_equal(gout.view(np.uint32), rout.view(np.uint32)))
+        n += len(k); prevp = curp
+    trk.close(); ctx.close()
+    return {"lk_bit_exact_vs_oracle": ok_all, "lk_points_compared": n}
+
+
+def ba_section(ctx):
+    """local-BA timings: config[3] (mono, robust pass, resident) is the figure comparable across rounds; the others are the
+    stereo variant, the full two-pass localBA protocol (robust + L2, host buffers) and a realistic window."""
+    from ov2slam_amd import optimizer, synth
+    out = {}
+
+    def resident(label, pb, desc, reps=5):
+        rp = optimizer.ResidentProblem(ctx, pb)
+        rp.solve()
+        its, ms, wall0 = 0, 0.0, time.perf_counter()
+        for _ in range(reps):
+            r = rp.solve()
+            its += r["iterations"]; ms += r["solve_ms"]
+        wall = time.perf_counter() - wall0
+        res = {"iters_per_s": its / (ms * 1e-3), "iters_per_s_wall_incl_d2h": its / wall, "iterations_per_solve": its / reps,
+               "solve_ms": ms / reps, "us_per_iteration": ms / max(1, its) * 1e3, "workload": desc,
+               "termination": optimizer.TERMINATION.get(r["termination"])}
+        poses = r["poses"].copy()
+        rp.close()
+        return res, poses
+
+    pb = synth.make_ba_problem(50, 10000, 30, stereo=False, seed=42)
+    out, gpu_poses = resident("config3_mono", pb, "50 KF x 10000 inverse-depth landmarks x 30 obs (290000 residual blocks), Huber "
+                              "sqrt(5.9915), max 5 LM iterations, function_tolerance 1e-3, problem resident in HBM")
+    pbs = synth.make_ba_problem(50, 10000, 30, stereo=True, seed=42)
+    out["config3_stereo"], _ = resident("config3_stereo", pbs, "same, stereo: + 290000 right + 10000 right-anchor residual blocks", reps=3)
+    pbw = synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7)
+    out["window_25kf_3k_stereo"], _ = resident("window", pbw, "realistic local-BA window: 25 KF x 3000 landmarks x 12 obs, stereo "
+                                               "(optimizer.cpp:150-188)", reps=5)
+    # the whole localBA protocol of optimizer.cpp:436-627 (robust pass, outlier removal, L2 pass), host buffers in / out
+    opt = optimizer.Optimizer(ctx)
+    opt.localBA(pbs)
+    t0 = time.perf_counter()
+    r = opt.localBA(pbs)
+    wall = time.perf_counter() - t0
+    it1 = r["pass1"]["iterations"]; it2 = r["pass2"]["iterations"] if r["l2_done"] else 0
+    ms = r["pass1"]["solve_ms"] + (r["pass2"]["solve_ms"] if r["l2_done"] else 0.0)
+    out["localba_two_pass_stereo"] = {"wall_ms_incl_h2d_d2h": wall * 1e3, "device_ms": ms, "iterations_robust": it1, "iterations_l2": it2,
+                                      "iters_per_s_device": (it1 + it2) / (ms * 1e-3), "outliers_removed": int(r["bad_obs"].sum()),
+                                      "workload": "Optimizer.localBA on the stereo config[3] problem: robust pass (<=5 it) + outlier "
+                                                  "removal + L2 pass (<=10 it), two ov2_ba_solve calls"}
+    return out, pb, gpu_poses
 
 
 def main():
@@ -138,9 +370,16 @@ def main():
     ap.add_argument("--workload", choices=["euroc", "kitti"], default="euroc",
                     help="euroc = the headline configuration (BASELINE.json configs[1]); kitti = configs[2] "
                          "(1241x376, wide-image stress) -- a side measurement, not the headline")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--dry", action="store_true", help="no GPU work: launcher + process group + config-5 plan / all-gather only (CPU test)")
+    ap.add_argument("--config5-scale", type=int, default=16, help="EuRoC frame counts are divided by this for the config-5 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the BA / detect / single-sequence sections")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-sequence / config-5 / BA / detect / parity sections")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args))
+
     if args.workload == "kitti":
         # KITTI 00 stereo, accurate params: 1241x376, nmaxdist 35 -> nbmaxkps 36*11 = 396
         global W, H, NKPS, N_PASS_A, N_PASS_B, CLAHE_TILES
@@ -150,8 +389,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    import ov2slam_amd
-    from ov2slam_amd import _lib as L, optimizer, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,9 +396,30 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    else:
+        if not args.dry:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    if args.dry:
+        # the N>1 plumbing without a GPU: barrier, max-reduce of the elapsed time, config-5 plan + all-gather
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([1.0 + 0.1 * rank], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c5 = run_config5(None, rank, world, args.config5_scale, dry=True)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "dry": True, "backend": args.backend, "elapsed_max_over_ranks": float(t.item()),
+                              "config5": c5}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import ov2slam_amd
+    from ov2slam_amd import _lib as L
+
+    if world == 1:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
@@ -252,78 +510,82 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; they come
     # from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of tools/profile.sh whose summary
     # is committed under profiles/ (same workload and seqs_per_gpu, else null)
-    traffic = None
+    traffic, traffic_note = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))
         if tj.get("seqs_per_gpu") == S and args.workload == "euroc":
-            traffic = tj["hbm_bytes_per_launch"]
+            traffic = tj["hbm_bytes_per_launch"]; traffic_note = tj.get("limiter")
     except Exception:
         pass
+
+    # free the batch buffers before the single-sequence / BA sections
+    del frames_d, kps_d, pri_d, pri_work, status_d
+    for p in pyrs:
+        p.close()
+    torch.cuda.empty_cache()
+
+    c5 = None
+    if not args.no_extras and args.workload == "euroc":
+        ctx5 = ov2slam_amd.Context(dev.index)
+        c5 = run_config5(ctx5, rank, world, args.config5_scale)
+        ctx5.close()
 
     if rank == 0:
         frames = args.steps * S * world
         out = {
-            "metric": "frames/sec tracking + local-BA iters/sec, EuRoC MH_01 stereo 'accurate', 1 GPU vs CPU ref",
+            "metric": METRIC,
             "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 fixed point + f32 (LK), f64 (BA)", "data": "synthetic",
             "config": {"workload": "%s stereo 'accurate' tracking step on synthetic %dx%d frames: CLAHE + pyramid "
                                    "build (4 levels) + fbKltTracking pass A (%d kps, nbpyrlvl 1) + pass B "
-                                   "(%d kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px"
+                                   "(%d kps, nbpyrlvl 3), 9x9 window, 30 it / 0.01 px; offline batch-of-sequences mode "
+                                   "(the single-camera figure is `single_sequence`)"
                                    % ("EuRoC MH_01" if args.workload == "euroc" else "KITTI 00", W, H, N_PASS_A, N_PASS_B),
                        "seqs_per_gpu": S, "keypoints_per_frame": NKPS, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fb_klt3", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_total / max(1, n_launch),
                          "gn_iterations": iters, "patch_builds": visits},
             "lk_ms_per_step": (ms_A + ms_B) / args.steps, "tracked_fraction": tracked,
         }
+        if c5 is not None:
+            out["config5"] = c5
         if world == 1 and not args.no_extras:
-            # ---- local BA: config[3], problem resident in HBM, robust pass of optimizer.cpp:436-485 --
-            pb = synth.make_ba_problem(50, 10000, 30, stereo=False, seed=42)
-            rp = optimizer.ResidentProblem(ctx, pb)
-            rp.solve()                                               # warm-up
-            its, ms, wall0 = 0, 0.0, time.perf_counter()
-            for _ in range(5):
-                r = rp.solve()
-                its += r["iterations"]; ms += r["solve_ms"]
-            wall = time.perf_counter() - wall0
-            out["ba"] = {"iters_per_s": its / (ms * 1e-3), "iters_per_s_wall_incl_d2h": its / wall,
-                         "iterations_per_solve": its / 5, "solve_ms": ms / 5,
-                         "workload": "50 KF x 10000 inverse-depth landmarks x 30 obs (290000 residual blocks), Huber "
-                                     "sqrt(5.9915), max 5 LM iterations, function_tolerance 1e-3",
-                         "termination": optimizer.TERMINATION.get(r["termination"])}
-            rp.close()
-            # ---- drop-in (host buffer) API on ONE sequence: per-call latency incl. PCIe -------------
+            ss = single_sequence(dev.index, views, kps, pri)
+            out["single_sequence"] = ss
+            out["single_sequence_fps"] = ss["pageable"]["fps_incl_pcie"]
             ctx1 = ov2slam_amd.Context(dev.index)
+            out["ba"], pb, gpu_poses = ba_section(ctx1)
+            # ---- detection through the host-buffer drop-in API on ONE image: per-call latency incl. PCIe -----
             fx = ov2slam_amd.FeatureExtractor(ctx1, dmaxquality=0.001)
-            trk = ov2slam_amd.FeatureTracker(ctx1, 30, 0.01)
-            P0 = ov2slam_amd.Pyramid(ctx1, W, H, WIN, LEVELS).build(views[0]); ctx1.sync()
-            P1 = ov2slam_amd.Pyramid(ctx1, W, H, WIN, LEVELS)
             roi = (5, 5, W - 10, H - 10)
             fx.detectSingleScale(views[0], CELL, np.zeros((0, 2), np.float32), roi)
             t1 = time.perf_counter()
             for _ in range(20):
                 det = fx.detectSingleScale(views[0], CELL, np.zeros((0, 2), np.float32), roi)
-            det_ms = (time.perf_counter() - t1) / 20 * 1e3
-            t1 = time.perf_counter()
-            for _ in range(50):
-                P1.build_clahe(views[1], CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1])            # preprocessImage
-                trk.fbKltTracking(P0, P1, WIN, 1, 30., 0.5, kps[0, 0][:N_PASS_A], pri[0, 0][:N_PASS_A])
-                trk.fbKltTracking(P0, P1, WIN, LEVELS, 30., 0.5, kps[0, 0][N_PASS_A:], pri[0, 0][N_PASS_A:])
-            trk_ms = (time.perf_counter() - t1) / 50 * 1e3
-            out["drop_in_single_sequence"] = {"track_ms_per_frame_incl_pcie": trk_ms, "detect_singlescale_ms_incl_pcie": det_ms,
-                                              "detected_points": int(len(det))}
+            out["detect"] = {"detect_singlescale_ms_incl_pcie": (time.perf_counter() - t1) / 20 * 1e3, "detected_points": int(len(det))}
+            ctx1.close()
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(views, kps, pri, pb)
-                cb = out["cpu_baseline"]
-                if "ba" in cb:
-                    # combined LK-track + local-BA wall-clock per keyframe cycle (5 frames + 1 robust BA pass), CPU / GPU
+                out["parity"] = parity_check(dev.index, views, kps, pri)
+                cb = cpu_baseline(views, kps, pri, pb)
+                rb = cb.pop("_ba_result", None)
+                out["cpu_baseline"] = cb
+                if rb is not None:
+                    rel = float(np.abs(gpu_poses - rb["poses"]).max() / max(1e-30, np.abs(rb["poses"]).max()))
+                    out["parity"]["ba_pose_max_rel_err_vs_oracle"] = rel
+                    out["parity"]["ba_within_1e-4"] = bool(rel <= 1e-4)
+                    # combined LK-track + local-BA wall-clock per keyframe cycle (5 frames + 1 robust BA pass), CPU / GPU,
+                    # on the SINGLE-SEQUENCE basis (one camera, PCIe and syncs included) -- the 4096-replica amortised
+                    # ratio is reported beside it for continuity with round 1
                     cpu_s = 5.0 / cb["value"] + cb["ba"]["seconds"]
-                    gpu_s = 5.0 / out["value"] + out["ba"]["solve_ms"] * 1e-3      # amortised over the S lock-step sequences
-                    out["combined_speedup_vs_cpu"] = cpu_s / gpu_s
+                    gpu_single = 5.0 * ss["pageable"]["ms_per_frame_mean"] * 1e-3 + out["ba"]["solve_ms"] * 1e-3
+                    gpu_batch = 5.0 / out["value"] + out["ba"]["solve_ms"] * 1e-3
+                    out["combined_speedup_vs_cpu"] = cpu_s / gpu_single
+                    out["combined_speedup_vs_cpu_batch_amortised"] = cpu_s / gpu_batch
+                    out["tracking_speedup_vs_cpu_single_sequence"] = ss["pageable"]["fps_incl_pcie"] / cb["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -48,14 +48,18 @@ static inline int cv_floor_f(float v) { return (int)floorf(v); }
 /* ---- pyrDown -------------------------------------------------------- */
 /* cv::pyrDown for CV_8UC1, BORDER_REFLECT_101: separable [1 4 6 4 1],
  * dst = (sum + 128) >> 8  (imgproc/src/pyramids.cpp, PyrDownInvoker / FixPtCast<uchar,8>) */
-void orc_pyr_down_u8(const uint8_t *src, int sw, int sh, int sstride,
-                     uint8_t *dst, int dw, int dh, int dstride)
+typedef struct { const uint8_t *src; int sw, sh, sstride; uint8_t *dst; int dw, dh, dstride; } pyrdown_job;
+
+static void pyr_down_rows(int y0, int y1, void *ctx)
 {
+    const pyrdown_job *jb = (const pyrdown_job *)ctx;
+    const uint8_t *src = jb->src; uint8_t *dst = jb->dst;
+    const int sw = jb->sw, sh = jb->sh, sstride = jb->sstride, dw = jb->dw, dstride = jb->dstride;
     int *rows = (int *)malloc(sizeof(int) * (size_t)dw * 5);
     /* interior columns need no border handling: 2x-2 >= 0 and 2x+2 <= sw-1 */
     int xi0 = 1, xi1 = (sw - 3) / 2;           /* inclusive range of interior x */
     if (xi1 > dw - 1) xi1 = dw - 1;
-    for (int y = 0; y < dh; y++) {
+    for (int y = y0; y < y1; y++) {
         for (int k = 0; k < 5; k++) {
             int sy = reflect101(2 * y - 2 + k, sh);
             const uint8_t *s = src + (size_t)sy * sstride;
@@ -81,13 +85,24 @@ void orc_pyr_down_u8(const uint8_t *src, int sw, int sh, int sstride,
     free(rows);
 }
 
-/* ---- Scharr derivative (calcSharrDeriv in video/src/lkpyramid.cpp) ---- */
-void orc_scharr_u8(const uint8_t *src, int w, int h, int sstride,
-                   int16_t *dst, int dstride_elems)
+void orc_pyr_down_u8(const uint8_t *src, int sw, int sh, int sstride,
+                     uint8_t *dst, int dw, int dh, int dstride)
 {
+    pyrdown_job jb = {src, sw, sh, sstride, dst, dw, dh, dstride};
+    orc_parallel_for(dh, pyr_down_rows, &jb, 8);          /* rows in parallel, like cv::pyrDown's ParallelLoopBody */
+}
+
+/* ---- Scharr derivative (calcSharrDeriv in video/src/lkpyramid.cpp) ---- */
+typedef struct { const uint8_t *src; int w, h, sstride; int16_t *dst; int dstride_elems; } scharr_job;
+
+static void scharr_rows(int y0, int y1, void *ctx)
+{
+    const scharr_job *jb = (const scharr_job *)ctx;
+    const uint8_t *src = jb->src; int16_t *dst = jb->dst;
+    const int w = jb->w, h = jb->h, sstride = jb->sstride, dstride_elems = jb->dstride_elems;
     int *t0 = (int *)malloc(sizeof(int) * (size_t)(w + 2) * 2);
     int *t1 = t0 + (w + 2);
-    for (int y = 0; y < h; y++) {
+    for (int y = y0; y < y1; y++) {
         const uint8_t *r0 = src + (size_t)(y > 0 ? y - 1 : (h > 1 ? 1 : 0)) * sstride;
         const uint8_t *r1 = src + (size_t)y * sstride;
         const uint8_t *r2 = src + (size_t)(y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0)) * sstride;
@@ -105,6 +120,13 @@ void orc_scharr_u8(const uint8_t *src, int w, int h, int sstride,
         }
     }
     free(t0);
+}
+
+void orc_scharr_u8(const uint8_t *src, int w, int h, int sstride,
+                   int16_t *dst, int dstride_elems)
+{
+    scharr_job jb = {src, w, h, sstride, dst, dstride_elems};
+    orc_parallel_for(h, scharr_rows, &jb, 16);            /* calcSharrDeriv runs under cv::parallel_for_ too */
 }
 
 /* ---- buildOpticalFlowPyramid(img, pyr, win, maxLevel, withDerivatives=true,
@@ -324,6 +346,14 @@ static void lk_level_range(const lk_job *jb)
     }
 }
 
+static void *lk_thread(void *arg);
+static void lk_points(int b, int e, void *ctx)
+{
+    lk_job jb = *(const lk_job *)ctx;
+    jb.begin = b; jb.end = e;
+    lk_thread(&jb);
+}
+
 static void *lk_thread(void *arg)
 {
     /* points are independent across levels, so a thread walks all levels for its own range */
@@ -350,25 +380,17 @@ int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
     if (epsilon > 10.) epsilon = 10.;
     epsilon *= epsilon;
     for (int i = 0; i < n; i++) { status[i] = 1; if (err) err[i] = 0.f; if (iters_out) iters_out[i] = 0; }
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > 64) nthreads = 64;
-    lk_job jobs[64]; pthread_t th[64];
-    int per = (n + nthreads - 1) / nthreads, nt = 0;
-    for (int t = 0; t < nthreads; t++) {
-        int b = t * per, e = b + per; if (e > n) e = n;
-        if (b >= e) break;
-        lk_job *jb = &jobs[nt++];
-        jb->prev = prev; jb->next = next; jb->prev_xy = prev_xy; jb->next_xy = next_xy;
-        jb->status = status; jb->err = err; jb->win = win; jb->max_level = max_level;
-        jb->max_count = max_count; jb->epsilon = epsilon; jb->flags = flags;
-        jb->min_eig_threshold = min_eig_threshold; jb->iters_out = iters_out;
-        jb->level = max_level; jb->begin = b; jb->end = e;
-    }
-    if (nt == 1) lk_thread(&jobs[0]);
+    lk_job jb;
+    jb.prev = prev; jb.next = next; jb.prev_xy = prev_xy; jb.next_xy = next_xy;
+    jb.status = status; jb.err = err; jb.win = win; jb.max_level = max_level;
+    jb.max_count = max_count; jb.epsilon = epsilon; jb.flags = flags;
+    jb.min_eig_threshold = min_eig_threshold; jb.iters_out = iters_out;
+    jb.level = max_level; jb.begin = 0; jb.end = n;
+    if (nthreads <= 1) lk_thread(&jb);
     else {
-        for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, lk_thread, &jobs[t]);
-        lk_thread(&jobs[0]);
-        for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+        /* points over the persistent pool (cv::parallel_for_ in LKTrackerInvoker); the pool is grown on demand */
+        if (orc_get_num_threads() < nthreads) orc_set_num_threads(nthreads);
+        orc_parallel_for(n, lk_points, &jb, 4);
     }
     return 0;
 }

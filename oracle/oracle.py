@@ -42,6 +42,28 @@ def lib():
     return _lib
 
 
+def use_native():
+    """Switch this module to oracle/_native/liboracle.so, built here and now with -O3 -march=native (`make native`):
+    the CPU baseline of bench.py runs the same restatement compiled for the host it is timed on.
+    Returns the compiler flags used, or None when the native build failed (the portable build stays loaded)."""
+    global _lib
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nl = C.CDLL(os.path.join(_HERE, "_native", "liboracle.so"))
+    except Exception:
+        return None
+    nl.orc_fb_klt.restype = C.c_int
+    nl.orc_lk_track.restype = C.c_int
+    _lib = nl
+    return "-O3 -march=native -ffp-contract=off"
+
+
+def set_num_threads(n):
+    """Threads of the persistent pool behind CLAHE / pyrDown / Scharr / LK (cv::setNumThreads)."""
+    lib().orc_set_num_threads(int(n))
+    return lib().orc_get_num_threads()
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

@@ -52,6 +52,14 @@ typedef struct {
 } orc_pyr;
 
 /* returns 0 on success. img is u8 row-major, `stride` bytes per row. */
+/* ---- worker pool (pool.c): stand-in for cv::parallel_for_ -------------------------------------------
+ * orc_set_num_threads(n): threads used by the parallel loops of CLAHE / pyrDown / Scharr / LK (default 1);
+ * loops are split into ranges whose results do not depend on the split.                                */
+typedef void (*orc_range_fn)(int begin, int end, void *ctx);
+void orc_set_num_threads(int n);
+int  orc_get_num_threads(void);
+void orc_parallel_for(int n, orc_range_fn fn, void *ctx, int min_grain);
+
 int  orc_pyr_build(const uint8_t *img, int w, int h, int stride, int win,
                    int max_level, orc_pyr *out);
 void orc_pyr_free(orc_pyr *p);

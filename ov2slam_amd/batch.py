@@ -68,3 +68,87 @@ def ate_rmse(est_xyz, gt_xyz):
     err = (R @ (est - mu_e).T).T + mu_g - gt
     sq = float((err ** 2).sum())
     return (sq / len(est)) ** 0.5, sq, len(est)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 5 runner: whole sequences through the single-sequence hot path, one process per GPU
+# ---------------------------------------------------------------------------------------------------------
+class SyntheticSequence:
+    """Synthetic stand-in of one EuRoC sequence (no dataset offline): `n_frames` 752x480 views of a
+    seeded texture under a smooth similarity motion (a short cycle of distinct views, replayed back and forth, so that a
+    sequence costs 0.2 s to generate instead of 30 ms per frame), with the ground-truth flow between consecutive frames."""
+
+    def __init__(self, name, n_frames, seed, w=752, h=480, n_views=7, tex=None):
+        from . import synth
+        self.name, self.n_frames, self.w, self.h = name, int(n_frames), w, h
+        rng = np.random.default_rng(seed)
+        tex = synth.base_texture(1400, 1234) if tex is None else tex
+        ox, oy, th = float(rng.uniform(100, 400)), float(rng.uniform(100, 400)), 0.0
+        self.views, self.offs = [], []
+        for _ in range(n_views):
+            self.views.append(synth.warp(tex, w, h, ox, oy, th)); self.offs.append((ox, oy, th))
+            ox += rng.uniform(-5, 5); oy += rng.uniform(-4, 4); th += rng.uniform(-0.006, 0.006)
+        self.seed = seed
+
+    def view_index(self, f):
+        n = len(self.views)
+        k = f % (2 * n - 2)
+        return k if k < n else 2 * n - 2 - k
+
+    def frame(self, f):
+        return self.views[self.view_index(f)]
+
+    def flow(self, pts, fa, fb):
+        """ground-truth position in frame fb of pixels `pts` of frame fa"""
+        w, h = self.w, self.h
+        cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+        (ox0, oy0, t0), (ox1, oy1, t1) = self.offs[self.view_index(fa)], self.offs[self.view_index(fb)]
+        pts = np.asarray(pts, np.float64)
+        dx, dy = pts[:, 0] - cx, pts[:, 1] - cy
+        c, s = np.cos(t0), np.sin(t0)
+        tx, ty = c * dx - s * dy + cx + ox0, s * dx + c * dy + cy + oy0
+        dx, dy = tx - cx - ox1, ty - cy - oy1
+        c, s = np.cos(-t1), np.sin(-t1)
+        return np.stack([c * dx - s * dy + cx, s * dx + c * dy + cy], 1)
+
+
+def run_sequence(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use_graph=True):
+    """One sequence through the GPU hot path the way the reference's front-end drives it: per frame preprocessImage +
+    kltTracking (ov2_tracker_track_frame); every `kf_every`-th frame is a keyframe: the min-eigenvalue grid detector tops
+    the keypoint set up (MapManager::extractKeypoints, map_manager.cpp:286-341).  Keypoints that were tracked before carry
+    a prior (true flow + noise, standing in for the motion model's projection of their map point).
+    Returns dict(frames, seconds, tracked, attempted, err_sq_sum, err_n, detect_calls)."""
+    import time
+    from . import frontend
+    rng = np.random.default_rng(seq.seed + 17)
+    w, h = seq.w, seq.h
+    trk = frontend.VisualFrontEndTracker(ctx, w, h, nbmaxkps=max(512, 2 * nbmaxkps), use_graph=use_graph)
+    fx = frontend.FeatureExtractor(ctx, dmaxquality=0.001)
+    roi = (5, 5, w - 10, h - 10)
+    empty = np.zeros((0, 2), np.float32)
+    t0 = time.perf_counter()
+    trk.trackFrame(seq.frame(0), empty, empty, None)
+    kps = fx.detectSingleScale(seq.frame(0), cell, empty, roi)[:nbmaxkps]      # frame 0 is a keyframe (visual_front_end.cpp:87-95)
+    age = np.zeros(len(kps), np.int32)
+    st = dict(frames=1, tracked=0, attempted=0, err_sq_sum=0.0, err_n=0, detect_calls=1)
+    for f in range(1, seq.n_frames):
+        gt = seq.flow(kps, f - 1, f)
+        has_prior = (age > 0).astype(np.uint8)                                   # tracked at least once: "3-D" keypoint
+        pri = np.where(has_prior[:, None] > 0, gt + rng.normal(0, prior_sigma, gt.shape), kps).astype(np.float32)
+        out, sb, _ = trk.trackFrame(seq.frame(f), kps, pri, has_prior)
+        ok = (sb & 1).astype(bool)
+        st["frames"] += 1; st["attempted"] += len(kps); st["tracked"] += int(ok.sum())
+        if ok.any():
+            d = out[ok].astype(np.float64) - gt[ok]
+            st["err_sq_sum"] += float((d ** 2).sum()); st["err_n"] += int(ok.sum())
+        kps, age = out[ok], age[ok] + 1
+        inside = (kps[:, 0] > 8) & (kps[:, 0] < w - 9) & (kps[:, 1] > 8) & (kps[:, 1] < h - 9)
+        kps, age = kps[inside], age[inside]
+        if f % kf_every == 0 and len(kps) < nbmaxkps:
+            new = fx.detectSingleScale(seq.frame(f), cell, kps, roi)[:nbmaxkps - len(kps)]
+            st["detect_calls"] += 1
+            kps = np.concatenate([kps, new]); age = np.concatenate([age, np.zeros(len(new), np.int32)])
+    ctx.sync()
+    st["seconds"] = time.perf_counter() - t0
+    trk.close()
+    return st

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <vector>
+#include <mutex>
 
 #ifndef BA_KO
 #define BA_KO 0      // knock-out timing of the lineariser: 1 no global Hao atomics, 2 no LDS atomics, 4 no wave sums
@@ -1396,9 +1397,31 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     O.max_radius = o->max_radius; O.min_radius = o->min_radius; O.min_diag = o->min_lm_diagonal; O.max_diag = o->max_lm_diagonal;
     O.min_rel_decrease = o->min_relative_decrease; O.jacobi = o->jacobi_scaling; O.max_invalid = o->max_consecutive_invalid_steps;
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    OV2_HIP_CHECK(hipEventCreate(&e0));
-    OV2_HIP_CHECK(hipEventCreate(&e1));
+    // size limits first: nothing is created or enqueued for a problem this path cannot solve
+    const int n_opt = D.nf / 6;
+    const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+    const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
+    OV2_REQUIRE(lin_lds <= 160 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95)");
+    OV2_REQUIRE(chol_lds <= 160 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~95 optimised keyframes)");
+    {   // dynamic-LDS limits are per-function, process-wide attributes: raise them once to the hardware maximum (two
+        // contexts solving problems of different size on two threads would otherwise race on them)
+        static std::once_flag attr_once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once, [] {
+            attr_err = hipFuncSetAttribute((const void *)k_ba_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void *)k_ba_cholesky, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        OV2_HIP_CHECK(attr_err);
+    }
+    struct EvPair {                                        // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr, chunk[2] = {nullptr, nullptr};
+        ~EvPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); for (auto c : chunk) if (c) (void)hipEventDestroy(c); }
+    } ev;
+    OV2_HIP_CHECK(hipEventCreate(&ev.e0));
+    OV2_HIP_CHECK(hipEventCreate(&ev.e1));
+    OV2_HIP_CHECK(hipEventCreateWithFlags(&ev.chunk[0], hipEventDisableTiming));
+    OV2_HIP_CHECK(hipEventCreateWithFlags(&ev.chunk[1], hipEventDisableTiming));
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     // state reset: x = initial parameters, everything else zero, scales one
     OV2_HIP_CHECK(hipMemcpyAsync(D.x_pose, dev->h_poses0.data(), 56 * (size_t)D.n_kf, hipMemcpyHostToDevice, s));
     if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.x_lam, dev->h_lam0.data(), 8 * (size_t)D.n_lm, hipMemcpyHostToDevice, s));
@@ -1424,20 +1447,13 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     }
     hipLaunchKernelGGL(k_ba_init, dim3((D.n_kf + 255) / 256), dim3(256), 0, s, D);
 
-    const int n_opt = D.nf / 6;
     const int lin_blocks = std::max(1, std::min(256, (D.n_lm + 15) / 16));   // (512: two workgroups per CU -- measured 15 % slower)
-    const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
-    OV2_REQUIRE(lin_lds <= 160 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
-    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
     int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
     int lm_per_split = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
     ksplit = std::max(1, (D.n_lm + lm_per_split - 1) / lm_per_split);
     const int ws_blocks = std::max(1, std::min(512, std::max((D.n_lm + 3) / 4, (D.n_po + 255) / 256)));
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
-    const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
-    OV2_REQUIRE(chol_lds <= 160 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (max ~95 optimised keyframes)");
-    OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ba_cholesky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
 
     auto linearize = [&]() {
         if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
@@ -1445,7 +1461,26 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
     linearize();
+    // The LM loop is enqueued in chunks of BA_CHUNK iterations.  After each chunk the control block's `done` flag is
+    // copied to pinned memory and an event recorded; before enqueuing chunk c+2 the host looks at the flag of chunk c
+    // (one chunk of look-ahead, so the stream never drains).  A solve that converges after 3 iterations of a
+    // 100-iteration fullBA budget no longer pays ~900 empty launches (every kernel starts with `if (ctl->done) return`).
+    constexpr int BA_CHUNK = 2;
+    int rc_h = ctx->reserve_host(2 * sizeof(int));
+    if (rc_h != OV2_OK) return rc_h;
+    volatile int *done_h = (volatile int *)ctx->h_scratch;
+    done_h[0] = done_h[1] = 0;
+    int chunks = 0;
     for (int it = 0; it < o->max_iter; it++) {
+        if (it % BA_CHUNK == 0 && it > 0) {
+            const int c = chunks++;                                           // chunk that was just enqueued
+            OV2_HIP_CHECK(hipMemcpyAsync((void *)&done_h[c & 1], &D.ctl->done, sizeof(int), hipMemcpyDeviceToHost, s));
+            OV2_HIP_CHECK(hipEventRecord(ev.chunk[c & 1], s));
+            if (c >= 1) {                                                     // verdict of the chunk before it
+                OV2_HIP_CHECK(hipEventSynchronize(ev.chunk[(c - 1) & 1]));
+                if (done_h[(c - 1) & 1]) break;
+            }
+        }
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, D, ntiles, lm_per_split);
@@ -1469,7 +1504,6 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     OV2_HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;
     OV2_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     r->iterations = h_ctl.n_steps; r->num_successful_steps = h_ctl.n_success;
     r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
     r->solve_ms = ms;

@@ -76,3 +76,38 @@ def test_assign_sequences_is_balanced():
 def test_gather_stats_single_process():
     s = batch.gather_stats({"frames": 5, "seconds": 2.0})
     assert s == {"frames": [5.0], "seconds": [2.0]} and batch.aggregate(s)["fps"] == 2.5
+
+
+def test_bench_launcher_dry_gloo():
+    """bench.py's own launcher: `--gpus 2 --backend gloo --dry` spawns two ranks from ONE command and rank 0 reports
+    n_gpus: 2; the config-5 plan covers every sequence once and the aggregate uses the slowest rank's time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["dry"] is True
+    c5 = out["config5"]
+    assert sorted(sum(c5["assignment"], [])) == sorted(batch.EUROC_FRAMES)
+    assert len(c5["frames_per_rank"]) == 2 and c5["frames"] == sum(c5["frames_per_rank"])
+    assert abs(c5["seconds_slowest_rank"] - max(c5["seconds_per_rank"])) < 1e-12
+    assert abs(out["elapsed_max_over_ranks"] - 1.1) < 1e-12                # max over ranks of (1.0, 1.1)
+
+
+def test_bench_launcher_refuses_missing_gpus():
+    """`--gpus 2` without two visible GPUs must fail loudly instead of silently running one rank."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 2 and "GPU(s) visible" in p.stderr

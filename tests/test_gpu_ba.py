@@ -186,3 +186,36 @@ def test_structure_only_ba_edge_cases(gpu_ctx, oracle):
     bad = dict(pb); bad["res_pt"] = pb["res_pt"].copy(); bad["res_pt"][3] = 10 ** 6
     with pytest.raises(ov2slam_amd.Ov2Error):
         optimizer.structure_only_ba(gpu_ctx, bad)
+
+
+def test_config4_full_size_matches_oracle(gpu_ctx, oracle):
+    """BASELINE.json configs[3] at its stated size: 50 KF x 10000 landmarks x 30 observations (290000 residual blocks),
+    robust pass of optimizer.cpp:436-485 -- the problem bench.py times -- against the oracle (~0.5 s of CPU)."""
+    pb = synth.make_ba_problem(50, 10000, 30, stereo=False, seed=42)
+    assert pb["n_res"] == 290000
+    g = optimizer.solve(gpu_ctx, pb)
+    r = oracle.ba_solve(pb)
+    _cmp(g, r, pb)
+    assert g["final_cost"] < 0.5 * g["initial_cost"]
+
+
+def test_long_budget_stops_enqueuing_after_convergence(gpu_ctx, oracle):
+    """fullBA-style budget (100 iterations) on a problem that converges in a few: the chunked enqueue must return the same
+    result as the oracle (and as a run whose budget equals the iterations actually needed)."""
+    pb = synth.make_ba_problem(12, 400, 8, stereo=True, seed=3)
+    kw = dict(max_iter=100, function_tolerance=1e-6)
+    g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+    r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
+    _cmp(g, r, pb)
+    assert g["iterations"] < 40
+    g2 = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, max_iter=g["iterations"], function_tolerance=1e-6))
+    assert np.allclose(g2["poses"], g["poses"], atol=1e-12)
+
+
+def test_too_many_keyframes_is_reported(gpu_ctx):
+    """More optimised keyframes than the LDS-resident reduced system holds (~95): OV2_EUNSUPPORTED with a message, never a
+    silent skip (include/ov2slam_hip.h, DESIGN.md 'limits')."""
+    pb = synth.make_ba_problem(120, 600, 6, stereo=False, seed=1)
+    with pytest.raises(ov2slam_amd.Ov2Error) as e:
+        optimizer.solve(gpu_ctx, pb)
+    assert e.value.code == -4 and "keyframes" in str(e.value)
