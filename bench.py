@@ -106,8 +106,10 @@ def cpu_baseline(views, kps, pri, ba_problem, budget_s=8.0):
     p0 = O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
     hp = np.zeros(NKPS, bool); hp[:N_PASS_A] = True
 
-    def pre():
-        return O.Pyramid(O.clahe(views[1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+    pbuf = [O.Pyramid(views[0], WIN, LEVELS), O.Pyramid(views[0], WIN, LEVELS)]     # cur_pyr_ / prev_pyr_: Mats re-used every frame
+
+    def pre(slot=1, v=1):
+        return pbuf[slot].rebuild(O.clahe(views[v], CLAHE_CLIP, *CLAHE_TILES))
 
     def lk(p1, nt):
         O.fb_klt(p0, p1, WIN, 1, 30., 0.5, kps[0, 0][:N_PASS_A], pri[0, 0][:N_PASS_A], nthreads=nt)
@@ -136,9 +138,9 @@ def cpu_baseline(views, kps, pri, ba_problem, budget_s=8.0):
         a = time.perf_counter()
         O.set_num_threads(nt_pre)
         if f == 0:
-            prevp = O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+            prevp = pre(frames % 2, 0)
             a = time.perf_counter()
-        curp = O.Pyramid(O.clahe(views[f + 1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS)
+        curp = pre((frames + 1) % 2, f + 1)
         b = time.perf_counter()
         O.set_num_threads(nt_lk)
         k, p = kps[f, 0], pri[f, 0]

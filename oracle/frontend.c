@@ -145,23 +145,24 @@ static void fill_border_reflect101(orc_level *L)
     }
 }
 
-int orc_pyr_build(const uint8_t *img, int w, int h, int stride, int win,
-                  int max_level, orc_pyr *out)
+static int pyr_build_impl(const uint8_t *img, int w, int h, int stride, int win, int max_level, orc_pyr *out, int reuse)
 {
     if (!img || !out || w <= 0 || h <= 0 || win <= 2 || max_level < 0 ||
         max_level >= ORC_MAX_LEVELS)
         return -1;
-    memset(out, 0, sizeof(*out));
+    if (!reuse) memset(out, 0, sizeof(*out));
     out->win = win;
     int lw = w, lh = h;
     for (int level = 0; level <= max_level; level++) {
         orc_level *L = &out->lv[level];
-        L->w = lw; L->h = lh; L->pad = win;
-        L->img_pitch = lw + 2 * win;
-        L->der_pitch = (lw + 2 * win) * 2;
-        L->img = (uint8_t *)calloc((size_t)(lh + 2 * win) * L->img_pitch, 1);
-        L->der = (int16_t *)calloc((size_t)(lh + 2 * win) * L->der_pitch, sizeof(int16_t));
-        if (!L->img || !L->der) { orc_pyr_free(out); return -2; }
+        if (!reuse) {
+            L->w = lw; L->h = lh; L->pad = win;
+            L->img_pitch = lw + 2 * win;
+            L->der_pitch = (lw + 2 * win) * 2;
+            L->img = (uint8_t *)calloc((size_t)(lh + 2 * win) * L->img_pitch, 1);
+            L->der = (int16_t *)calloc((size_t)(lh + 2 * win) * L->der_pitch, sizeof(int16_t));
+            if (!L->img || !L->der) { orc_pyr_free(out); return -2; }
+        }
         uint8_t *roi = L->img + (size_t)win * L->img_pitch + win;
         if (level == 0) {
             for (int y = 0; y < lh; y++) memcpy(roi + (size_t)y * L->img_pitch, img + (size_t)y * stride, (size_t)lw);
@@ -179,6 +180,22 @@ int orc_pyr_build(const uint8_t *img, int w, int h, int stride, int win,
         if (lw <= win || lh <= win) break;
     }
     return 0;
+}
+
+int orc_pyr_build(const uint8_t *img, int w, int h, int stride, int win,
+                  int max_level, orc_pyr *out)
+{
+    return pyr_build_impl(img, w, h, stride, win, max_level, out, 0);
+}
+
+/* Rebuild into the buffers of a pyramid of the same geometry: cv::buildOpticalFlowPyramid re-uses the Mats of the
+ * output vector when their sizes match (Mat::create is a no-op), which is the per-frame case of the reference
+ * (cur_pyr_ / prev_pyr_ are swapped, visual_front_end.cpp:1169-1172).  The derivative border stays zero: only the
+ * ROI is rewritten.                                                                                             */
+int orc_pyr_rebuild(const uint8_t *img, int w, int h, int stride, orc_pyr *p)
+{
+    if (!p || p->n_levels <= 0 || p->lv[0].w != w || p->lv[0].h != h) return -1;
+    return pyr_build_impl(img, w, h, stride, p->win, p->n_levels - 1, p, 1);
 }
 
 void orc_pyr_free(orc_pyr *p)

@@ -78,6 +78,14 @@ class Pyramid:
         if rc != 0:
             raise RuntimeError("orc_pyr_build failed: %d" % rc)
 
+    def rebuild(self, img):
+        """cv::buildOpticalFlowPyramid into the existing Mats (same geometry): what the reference does every frame."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        rc = lib().orc_pyr_rebuild(_p(img), w, h, w, C.byref(self.p))
+        assert rc == 0, rc
+        return self
+
     @property
     def levels(self):
         return self.p.n_levels

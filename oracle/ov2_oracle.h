@@ -62,6 +62,7 @@ void orc_parallel_for(int n, orc_range_fn fn, void *ctx, int min_grain);
 
 int  orc_pyr_build(const uint8_t *img, int w, int h, int stride, int win,
                    int max_level, orc_pyr *out);
+int  orc_pyr_rebuild(const uint8_t *img, int w, int h, int stride, orc_pyr *p);   /* same geometry, buffers re-used */
 void orc_pyr_free(orc_pyr *p);
 /* accessors used by the python tests (copy out the un-padded ROI) */
 int  orc_pyr_level_size(const orc_pyr *p, int level, int *w, int *h);

@@ -1401,15 +1401,27 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int n_opt = D.nf / 6;
     const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
-    OV2_REQUIRE(lin_lds <= 160 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95)");
-    OV2_REQUIRE(chol_lds <= 160 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~95 optimised keyframes)");
+    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95)");
+    OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~95 optimised keyframes)");
     {   // dynamic-LDS limits are per-function, process-wide attributes: raise them once to the hardware maximum (two
         // contexts solving problems of different size on two threads would otherwise race on them)
         static std::once_flag attr_once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(attr_once, [] {
-            attr_err = hipFuncSetAttribute((const void *)k_ba_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute((const void *)k_ba_cholesky, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // the attribute bounds static + dynamic LDS together: leave room for each kernel's __shared__ arrays
+            auto raise = [](const void *fn) {
+                hipFuncAttributes fa;
+                hipError_t e = hipFuncGetAttributes(&fa, fn);
+                if (e != hipSuccess) return e;
+                for (int kb = 160; kb >= 64; kb -= 32) {             // 160 KB per work-group on gfx950; smaller steps only if refused
+                    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kb * 1024 - (int)fa.sharedSizeBytes);
+                    if (e == hipSuccess) return e;
+                    (void)hipGetLastError();
+                }
+                return e;
+            };
+            attr_err = raise((const void *)k_ba_linearize);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky);
         });
         OV2_HIP_CHECK(attr_err);
     }

@@ -149,3 +149,31 @@ def test_fbklt_empty_and_threads(oracle, euroc_pair):
     # nbpyrlvl larger than the pyramid is clamped (feature_tracker.cpp:50-52)
     c = oracle.fb_klt(P, Cq, 9, 7, 30., 0.5, d["kps"], d["pri"])
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_pool_and_rebuild_do_not_change_results(oracle):
+    """The persistent worker pool (oracle/pool.c, stand-in for cv::parallel_for_) and the buffer-reusing pyramid rebuild
+    are pure scheduling: CLAHE, pyramid and LK results are identical for 1 and 5 threads."""
+    from ov2slam_amd import synth
+    prev, cur, flow = synth.frame_pair(376, 240, seed=4, shift=(2.0, -1.0), theta=0.002)
+    rng = np.random.default_rng(3)
+    kps = synth.grid_keypoints(376, 240, 35, rng)
+    pri = (flow(kps) + rng.normal(0, 1.0, kps.shape)).astype(np.float32)
+    res = []
+    for nt in (1, 5):
+        assert oracle.set_num_threads(nt) == nt
+        eq = oracle.clahe(cur, 3.0, 7, 4)
+        P0 = oracle.Pyramid(oracle.clahe(prev, 3.0, 7, 4), 9, 3)
+        P1 = oracle.Pyramid(prev, 9, 3).rebuild(eq)                    # buffers re-used, other content before
+        out, st, stats = oracle.fb_klt(P0, P1, 9, 3, 30., 0.5, kps, pri, nthreads=nt)
+        res.append((eq, [P1.level(l, padded=True) for l in range(P1.levels)], out, st, stats))
+    oracle.set_num_threads(1)
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert np.array_equal(a[3], b[3]) and a[4] == b[4]
+    for (ia, da), (ib, db) in zip(a[1], b[1]):
+        assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    fresh = oracle.Pyramid(a[0], 9, 3)
+    for l in range(fresh.levels):
+        fi, fd = fresh.level(l, padded=True)
+        assert np.array_equal(fi, a[1][l][0]) and np.array_equal(fd, a[1][l][1])
