@@ -51,6 +51,16 @@ int  ov2_ctx_create_on_stream(int device, void *hip_stream, ov2_ctx **out);
 void ov2_ctx_destroy(ov2_ctx *ctx);
 int  ov2_ctx_sync(ov2_ctx *ctx);
 void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing */
+/* Per-context options.
+ * OV2_OPT_SOBEL_DY_ORDER: evaluation order of cv::Sobel(dx = 0, dy = 1, scale) inside cv::cornerMinEigenVal
+ * (detectSingleScale, src/feature_extractor.cpp:354).  OpenCV multiplies the SMOOTHING kernel by the scale when dx == 0,
+ * so its 8U -> 32F row pass rounds ((p[x-1] k0 + p[x] k1) + p[x+1] k2) per pixel and the column pass subtracts two
+ * rounded rows: OV2_SOBEL_DY_OPENCV_ROWFILTER, the default.  OV2_SOBEL_DY_EXACT_SUM scales the exact integer difference
+ * instead (<= 1 ulp apart per pixel; can flip arg-max ties).  Neither is pinned against a real OpenCV build.           */
+#define OV2_OPT_SOBEL_DY_ORDER         1
+#define OV2_SOBEL_DY_OPENCV_ROWFILTER  0
+#define OV2_SOBEL_DY_EXACT_SUM         1
+int  ov2_ctx_set_option(ov2_ctx *ctx, int option, int value);
 
 /* ---- image pyramid -------------------------------------------------
  * Replaces cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), max_level)

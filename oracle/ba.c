@@ -171,6 +171,89 @@ void orc_lm_step_rejected(double *radius, double *decrease_factor)
     *decrease_factor *= 2.0;
 }
 
+/* LevenbergMarquardtStrategy::ComputeStep (levenberg_marquardt_strategy.cc:76-88): the regulariser handed to the linear
+ * solver is  D_i = sqrt( clamp(diag(J^T J)_i, min_diagonal, max_diagonal) / radius ).  jtj_diag is clamped IN PLACE (Ceres
+ * keeps the clamped diagonal_ and re-uses it while reuse_diagonal is set).  Pinned by the vendored unit test
+ * LevenbergMarquardtStrategy.CorrectDiagonalToLinearSolver (levenberg_marquardt_strategy_test.cc:112-135).          */
+void orc_lm_diagonal(double *jtj_diag, int n, double radius, double min_diagonal, double max_diagonal, int clamp, double *D_out)
+{
+    for (int i = 0; i < n; i++) {
+        if (clamp) jtj_diag[i] = fmin(fmax(jtj_diag[i], min_diagonal), max_diagonal);
+        D_out[i] = sqrt(jtj_diag[i] / radius);
+    }
+}
+
+/* Generic dense restatement of SchurEliminator::Eliminate + BackSubstitute (schur_eliminator_impl.h:179-377) for scalar
+ * e-blocks, used to pin the elimination algebra against Ceres' own fixed problems (schur_eliminator_test.cc:82-225 on
+ * linear_least_squares_problems.cc problem 2) and to cross-check ba_schur_solve on small BA problems.
+ *   J: m x n row-major, columns [0, n_e) are the eliminated (e) columns, every row touches at most ONE e column
+ *   (row_e[r] = that column or -1: a row without e-block, NoEBlockRowsUpdate), D: n regulariser entries (or NULL = 0).
+ *   lhs (s x s, s = n - n_e, full symmetric), rhs (s):  S = F^T F + D_f^2 - sum_e (E^T F)^T (E^T E + D_e^2)^-1 (E^T F)
+ *   sol (n): solution of (J^T J + D^2) x = J^T b through the reduced system + back substitution.  Returns 0 / -1.    */
+static int chol_lower(double *A, int n);
+static void chol_solve(const double *L, int n, double *b);
+int orc_schur_eliminate_dense(const double *J, const double *b, const double *D, int m, int n, int n_e, const int *row_e,
+                              double *lhs, double *rhs, double *sol)
+{
+    const int s = n - n_e;
+    if (m <= 0 || n <= 0 || n_e < 0 || s < 0) return -1;
+    memset(lhs, 0, sizeof(double) * (size_t)s * s);
+    memset(rhs, 0, sizeof(double) * (size_t)s);
+    for (int c = 0; c < s; c++) lhs[(size_t)c * s + c] = D ? D[n_e + c] * D[n_e + c] : 0.0;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)(s + 1));
+    double *ete_inv = (double *)calloc((size_t)n_e + 1, sizeof(double)), *g_e = (double *)calloc((size_t)n_e + 1, sizeof(double));
+    for (int e = 0; e < n_e; e++) {                              /* one chunk per e-block */
+        double ete = D ? D[e] * D[e] : 0.0, g = 0;
+        memset(buf, 0, sizeof(double) * (size_t)s);
+        for (int r = 0; r < m; r++) {
+            if (row_e[r] != e) continue;
+            const double *row = J + (size_t)r * n;
+            ete += row[e] * row[e]; g += row[e] * b[r];
+            for (int c = 0; c < s; c++) {
+                buf[c] += row[e] * row[n_e + c];                 /* E^T F */
+                rhs[c] += row[n_e + c] * b[r];                   /* F^T b */
+                for (int d = 0; d < s; d++) lhs[(size_t)c * s + d] += row[n_e + c] * row[n_e + d];
+            }
+        }
+        if (!(ete > 0)) { free(buf); free(ete_inv); free(g_e); return -1; }
+        ete_inv[e] = 1.0 / ete; g_e[e] = g;
+        for (int c = 0; c < s; c++) {
+            rhs[c] -= buf[c] * ete_inv[e] * g;
+            for (int d = 0; d < s; d++) lhs[(size_t)c * s + d] -= buf[c] * ete_inv[e] * buf[d];
+        }
+    }
+    for (int r = 0; r < m; r++) {                                /* rows without an e-block */
+        if (row_e[r] >= 0) continue;
+        const double *row = J + (size_t)r * n;
+        for (int c = 0; c < s; c++) {
+            rhs[c] += row[n_e + c] * b[r];
+            for (int d = 0; d < s; d++) lhs[(size_t)c * s + d] += row[n_e + c] * row[n_e + d];
+        }
+    }
+    int rc = 0;
+    if (sol) {
+        double *L = (double *)malloc(sizeof(double) * (size_t)(s * s + 1));
+        memcpy(L, lhs, sizeof(double) * (size_t)s * s);
+        rc = s > 0 ? chol_lower(L, s) : 0;
+        if (rc == 0) {
+            memcpy(sol + n_e, rhs, sizeof(double) * (size_t)s);
+            if (s > 0) chol_solve(L, s, sol + n_e);
+            for (int e = 0; e < n_e; e++) {                      /* y_e = (E^T b - E^T F y_f) / (E^T E + D_e^2) */
+                double acc = g_e[e];
+                for (int r = 0; r < m; r++) {
+                    if (row_e[r] != e) continue;
+                    const double *row = J + (size_t)r * n;
+                    for (int c = 0; c < s; c++) acc -= row[e] * row[n_e + c] * sol[n_e + c];
+                }
+                sol[e] = acc * ete_inv[e];
+            }
+        }
+        free(L);
+    }
+    free(buf); free(ete_inv); free(g_e);
+    return rc;
+}
+
 void orc_ba_default_options(orc_ba_options *o)
 {
     o->max_iter = 5; o->function_tolerance = 1e-3; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
@@ -672,13 +755,9 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
         step_successful = 0;
 
         /* ComputeTrustRegionStep (LevenbergMarquardtStrategy::ComputeStep) */
-        if (!reuse_diagonal) {
-            ba_col_sqnorm(&w, diag_f, diag_l);
-            for (int c = 0; c < w.nf; c++) diag_f[c] = fmin(fmax(diag_f[c], o->min_lm_diagonal), o->max_lm_diagonal);
-            for (int l = 0; l < p->n_lm; l++) diag_l[l] = fmin(fmax(diag_l[l], o->min_lm_diagonal), o->max_lm_diagonal);
-        }
-        for (int c = 0; c < w.nf; c++) Df[c] = sqrt(diag_f[c] / radius);
-        for (int l = 0; l < p->n_lm; l++) Dl[l] = sqrt(diag_l[l] / radius);
+        if (!reuse_diagonal) ba_col_sqnorm(&w, diag_f, diag_l);
+        orc_lm_diagonal(diag_f, w.nf, radius, o->min_lm_diagonal, o->max_lm_diagonal, !reuse_diagonal, Df);
+        orc_lm_diagonal(diag_l, p->n_lm, radius, o->min_lm_diagonal, o->max_lm_diagonal, !reuse_diagonal, Dl);
         n_steps++;
         int lin_ok = ba_schur_solve(&w, Df, Dl, yf, yl) == 0;
         reuse_diagonal = 1;

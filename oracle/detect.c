@@ -350,6 +350,18 @@ int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
     return 0;
 }
 
+/* ---- Sobel dy evaluation order (canonical choice 7) ------------------------------------
+ * cv::Sobel(src, dy, CV_32F, 0, 1, 3, scale) applies `scale` to the SMOOTHING kernel when dx == 0 ("kx *= scale",
+ * imgproc/src/deriv.cpp), so the row pass of the 8U -> 32F separable filter is the generic RowFilter<uchar, float>
+ *   s(x) = ((p[x-1] * k0 + p[x] * k1) + p[x+1] * k2),  k = scale * (1, 2, 1),   every operation rounded to float,
+ * and the column pass (-1, 0, 1) is the exact difference of two such rounded rows.  ORC_SOBEL_DY_OPENCV_ROWFILTER (the
+ * default) restates that; ORC_SOBEL_DY_EXACT_SUM is round 1's order ((s2 - s0) * scale on exact integer row sums),
+ * which differs from it by <= 1 ulp per pixel and can flip arg-max ties in the min-eigenvalue map.  Neither is pinned
+ * against a real OpenCV build (none available): the switch exists so that a capture run can decide (tools/ref_capture). */
+static int g_sobel_dy_order = ORC_SOBEL_DY_OPENCV_ROWFILTER;
+void orc_set_sobel_dy_order(int order) { g_sobel_dy_order = order == ORC_SOBEL_DY_EXACT_SUM ? ORC_SOBEL_DY_EXACT_SUM : ORC_SOBEL_DY_OPENCV_ROWFILTER; }
+int orc_get_sobel_dy_order(void) { return g_sobel_dy_order; }
+
 /* ---- min-eigenvalue response of one cell ----------------------------------- */
 void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,
                      int x0, int y0, int cell, float *hmap)
@@ -379,9 +391,15 @@ void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,
             float r1 = (float)(B(y, x + 1) - B(y, x - 1));
             float r2 = (float)(B(y + 1, x + 1) - B(y + 1, x - 1));
             dxm[y * cs + x] = (r0 + r2) * f1 + r1 * f0;
-            float s0 = (float)(B(y - 1, x - 1) + 2 * B(y - 1, x) + B(y - 1, x + 1));
-            float s2 = (float)(B(y + 1, x - 1) + 2 * B(y + 1, x) + B(y + 1, x + 1));
-            dym[y * cs + x] = (s2 - s0) * f1;
+            if (g_sobel_dy_order == ORC_SOBEL_DY_EXACT_SUM) {
+                float s0 = (float)(B(y - 1, x - 1) + 2 * B(y - 1, x) + B(y - 1, x + 1));
+                float s2 = (float)(B(y + 1, x - 1) + 2 * B(y + 1, x) + B(y + 1, x + 1));
+                dym[y * cs + x] = (s2 - s0) * f1;
+            } else {
+                float s0 = ((float)B(y - 1, x - 1) * f1 + (float)B(y - 1, x) * f0) + (float)B(y - 1, x + 1) * f1;
+                float s2 = ((float)B(y + 1, x - 1) * f1 + (float)B(y + 1, x) * f0) + (float)B(y + 1, x + 1) * f1;
+                dym[y * cs + x] = s2 - s0;
+            }
         }
 #undef B
     /* cov = (dx*dx, dx*dy, dy*dy) in float; boxFilter 3x3 un-normalised, REFLECT_101, sums in double

@@ -214,6 +214,16 @@ def circle_fill0(mask, cx, cy, r):
     return mask
 
 
+SOBEL_DY_OPENCV_ROWFILTER, SOBEL_DY_EXACT_SUM = 0, 1
+
+
+def set_sobel_dy_order(order):
+    """Evaluation order of cv::Sobel(dx=0, dy=1, scale) inside cornerMinEigenVal (oracle/detect.c); returns the previous one."""
+    prev = lib().orc_get_sobel_dy_order()
+    lib().orc_set_sobel_dy_order(int(order))
+    return prev
+
+
 def cell_mineig(img, x0, y0, cell):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape

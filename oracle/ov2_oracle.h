@@ -138,6 +138,9 @@ int orc_detect_singlescale(const uint8_t *img, int w, int h, int stride, int cel
 
 /* min-eigenvalue response map of one cell (blur w/ parent pixels + isolated
  * cornerMinEigenVal); exposed for unit tests. hmap is cell*cell floats.      */
+enum { ORC_SOBEL_DY_OPENCV_ROWFILTER = 0, ORC_SOBEL_DY_EXACT_SUM = 1 };
+void orc_set_sobel_dy_order(int order);      /* evaluation order of cv::Sobel(dx=0, dy=1, scale) in the min-eigenvalue map */
+int  orc_get_sobel_dy_order(void);
 void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,
                      int x0, int y0, int cell, float *hmap);
 
@@ -229,6 +232,11 @@ void orc_corrector(double sq_norm, const double rho[3], int n_rows, int n_cols,
 /* levenberg_marquardt_strategy.cc:147-160 */
 void orc_lm_step_accepted(double step_quality, double *radius, double *decrease_factor, double max_radius);
 void orc_lm_step_rejected(double *radius, double *decrease_factor);
+/* D_i = sqrt(clamp(diag(J^T J)_i, min, max) / radius), levenberg_marquardt_strategy.cc:76-88 (the routine orc_ba_solve uses) */
+void orc_lm_diagonal(double *jtj_diag, int n, double radius, double min_diagonal, double max_diagonal, int clamp, double *D_out);
+/* dense restatement of SchurEliminator::Eliminate / BackSubstitute for scalar e-blocks (schur_eliminator_impl.h:179-377) */
+int  orc_schur_eliminate_dense(const double *J, const double *b, const double *D, int m, int n, int n_e, const int *row_e,
+                               double *lhs, double *rhs, double *sol);
 /* Sophus SE3 exp (se3.hpp:763-784), tangent [v, w] -> (t, q=[x y z w])          */
 void orc_se3_exp(const double tangent[6], double t_out[3], double q_out[4]);
 /* left-multiplicative update  T' = Exp(delta) * T  (se3left_parametrization.hpp:45-57) */

@@ -16,6 +16,8 @@ OV2_LK_USE_INITIAL_FLOW = 4
 OV2_LK_GET_MIN_EIGENVALS = 8
 OV2_MASK_AS_EXECUTED, OV2_MASK_INTENDED = 0, 1
 OV2_CAM_PINHOLE, OV2_CAM_FISHEYE = 0, 1
+OV2_OPT_SOBEL_DY_ORDER = 1
+OV2_SOBEL_DY_OPENCV_ROWFILTER, OV2_SOBEL_DY_EXACT_SUM = 0, 1
 OV2_RES_LEFT, OV2_RES_RIGHT, OV2_RES_RIGHT_ANCH, OV2_RES_PNP = 0, 1, 2, 3
 
 
@@ -96,6 +98,7 @@ SIGNATURES = {
     "ov2_ctx_destroy": (None, [_vp]),
     "ov2_ctx_sync": (_i, [_vp]),
     "ov2_ctx_stream": (_vp, [_vp]),
+    "ov2_ctx_set_option": (_i, [_vp, _i, _i]),
     "ov2_pyr_create": (_i, [_vp, _i, _i, _i, _i, _i, _pp]),
     "ov2_pyr_destroy": (None, [_vp]),
     "ov2_pyr_levels": (_i, [_vp]),

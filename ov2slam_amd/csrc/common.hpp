@@ -44,6 +44,7 @@ struct ov2_ctx {
     // (same-address device atomics retire at ~6 ns each: 2 per work-group on one address would put a
     // 200 us floor under a 16k-work-group launch); a one-block kernel folds the lines into the caller's pair.
     unsigned long long *stat_slots = nullptr;
+    int sobel_dy_order = OV2_SOBEL_DY_OPENCV_ROWFILTER;   // ov2_ctx_set_option(OV2_OPT_SOBEL_DY_ORDER)
     int reserve_device(size_t bytes);
     int reserve_host(size_t bytes);
     int reserve_stat_slots();

@@ -100,6 +100,20 @@ int ov2_ctx_sync(ov2_ctx *ctx)
     return OV2_OK;
 }
 
+int ov2_ctx_set_option(ov2_ctx *ctx, int option, int value)
+{
+    OV2_REQUIRE(ctx != nullptr, OV2_EINVAL, "ctx == NULL");
+    switch (option) {
+    case OV2_OPT_SOBEL_DY_ORDER:
+        OV2_REQUIRE(value == OV2_SOBEL_DY_OPENCV_ROWFILTER || value == OV2_SOBEL_DY_EXACT_SUM, OV2_EINVAL, "unknown Sobel dy order");
+        ctx->sobel_dy_order = value;
+        return OV2_OK;
+    default:
+        ov2_set_error("unknown context option %d", option);
+        return OV2_EINVAL;
+    }
+}
+
 void *ov2_ctx_stream(ov2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 } // extern "C"

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 // Sobel/3060 -> (dx^2, dxdy, dy^2) -> 3x3 box (double sums, sliding column) -> lambda_min
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
-                                                      int cs, int nwcells, float *__restrict__ hmap_out)
+                                                      int cs, int nwcells, float *__restrict__ hmap_out, int dy_order)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int npx = cs * cs;
@@ -146,9 +146,18 @@ __global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict_
         const float r1 = (float)(BL(y, x + 1) - BL(y, x - 1));
         const float r2 = (float)(BL(y + 1, x + 1) - BL(y + 1, x - 1));
         dxm[p] = (r0 + r2) * f1 + r1 * f0;
-        const float s0 = (float)(BL(y - 1, x - 1) + 2 * BL(y - 1, x) + BL(y - 1, x + 1));
-        const float s2 = (float)(BL(y + 1, x - 1) + 2 * BL(y + 1, x) + BL(y + 1, x + 1));
-        dym[p] = (s2 - s0) * f1;
+        if (dy_order == OV2_SOBEL_DY_EXACT_SUM) {          // round 1's order: scale applied to the exact integer difference
+            const float s0 = (float)(BL(y - 1, x - 1) + 2 * BL(y - 1, x) + BL(y - 1, x + 1));
+            const float s2 = (float)(BL(y + 1, x - 1) + 2 * BL(y + 1, x) + BL(y + 1, x + 1));
+            dym[p] = (s2 - s0) * f1;
+        } else {
+            // cv::Sobel(dx = 0, dy = 1, scale): the scale goes into the smoothing kernel, the row pass is the generic
+            // RowFilter<uchar, float> ((p[x-1] k0 + p[x] k1) + p[x+1] k2, every operation rounded), the column pass the exact
+            // difference of two rounded rows (include/ov2slam_hip.h: OV2_OPT_SOBEL_DY_ORDER)
+            const float s0 = ((float)BL(y - 1, x - 1) * f1 + (float)BL(y - 1, x) * f0) + (float)BL(y - 1, x + 1) * f1;
+            const float s2 = ((float)BL(y + 1, x - 1) * f1 + (float)BL(y + 1, x) * f0) + (float)BL(y + 1, x + 1) * f1;
+            dym[p] = s2 - s0;
+        }
     }
 #undef BL
     __syncthreads();
@@ -686,7 +695,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
         const size_t lds = (size_t)npx * (3 * 8 + 4 + 4 + 3 * 4 + 1) + 16;
         OV2_REQUIRE(lds <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 58)");
         OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_mineig_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, ds + o_img, w, h, w, cell, nw, (float *)(ds + o_map));
+        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, ds + o_img, w, h, w, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order);
     }
     SelectParams P;
     P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;

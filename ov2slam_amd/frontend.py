@@ -42,6 +42,10 @@ class Context:
     def sync(self):
         L.check(self.lib.ov2_ctx_sync(self.h))
 
+    def set_option(self, option, value):
+        """ov2_ctx_set_option, e.g. (L.OV2_OPT_SOBEL_DY_ORDER, L.OV2_SOBEL_DY_EXACT_SUM)."""
+        L.check(self.lib.ov2_ctx_set_option(self.h, int(option), int(value)))
+
     @property
     def stream(self):
         return self.lib.ov2_ctx_stream(self.h)

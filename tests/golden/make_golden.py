@@ -41,6 +41,11 @@ def compute():
     out["detect_grid_fast"] = dig(pts, np.array([th]))
     pts, q = O.detect_singlescale(prev, 35, kps[::5], (5, 5, 366, 230), 0.001, True)
     out["detect_singlescale"] = dig(pts, np.array([q]))
+    # the min-eigenvalue map under both Sobel-dy evaluation orders (oracle/detect.c: default = OpenCV's row-filter order)
+    out["cell_mineig_opencv_rowfilter"] = dig(O.cell_mineig(prev, 105, 70, 35))
+    O.set_sobel_dy_order(O.SOBEL_DY_EXACT_SUM)
+    out["cell_mineig_exact_sum"] = dig(O.cell_mineig(prev, 105, 70, 35))
+    O.set_sobel_dy_order(O.SOBEL_DY_OPENCV_ROWFILTER)
     pb = synth.make_ba_problem(8, 120, 5, stereo=True, seed=3)
     r = O.ba_solve(pb)
     # BA is fp64 with libm calls: digest a rounded view (12 significant digits) to stay libm-version tolerant

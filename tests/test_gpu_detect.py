@@ -117,3 +117,30 @@ def test_corner_subpix_bit_exact_including_border(gpu_ctx, oracle):
     r = oracle.corner_subpix(img, pts)
     assert np.array_equal(_bits(g), _bits(r))
     assert np.abs(g - pts).max() <= 3.0 + 1e-6
+
+
+@pytest.mark.parametrize("order", [L.OV2_SOBEL_DY_OPENCV_ROWFILTER, L.OV2_SOBEL_DY_EXACT_SUM])
+def test_singlescale_sobel_dy_orders_bit_exact(oracle, order):
+    """Both evaluation orders of cv::Sobel(dx=0, dy=1, scale) (ov2_ctx_set_option / oracle.set_sobel_dy_order): the HIP
+    detector follows the oracle bit for bit in either, on the noise image (the one with the most arg-max near-ties)."""
+    ctx = ov2slam_amd.Context(0)
+    ctx.set_option(L.OV2_OPT_SOBEL_DY_ORDER, order)
+    prev = oracle.set_sobel_dy_order(order)
+    try:
+        for name, img in IMAGES:
+            h, w = img.shape
+            roi = (5, 5, w - 10, h - 10)
+            fx = ov2slam_amd.FeatureExtractor(ctx, dmaxquality=0.001)
+            g = fx.detectSingleScale(img, 35, np.zeros((0, 2), np.float32), roi)
+            r, q = oracle.detect_singlescale(img, 35, np.zeros((0, 2), np.float32), roi, 0.001)
+            assert len(g) == len(r) and np.array_equal(_bits(g), _bits(r)), name
+            assert fx.dmaxquality_ == q
+    finally:
+        oracle.set_sobel_dy_order(prev)
+        ctx.close()
+    with pytest.raises(ov2slam_amd.Ov2Error):
+        c2 = ov2slam_amd.Context(0)
+        try:
+            c2.set_option(L.OV2_OPT_SOBEL_DY_ORDER, 7)
+        finally:
+            c2.close()

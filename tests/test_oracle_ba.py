@@ -372,3 +372,88 @@ def test_ceres_pnp_protocol(oracle):
     bad_uv = pb["res_uv"] + 500.0
     ok2, _, outl2 = mvg.ceresPnP(bad_uv, pb["res_xyz"], np.zeros(300), pb["poses_gt"][0], 5, 5.9915, True, True, *K)
     assert not ok2 and len(outl2) == 300
+
+
+# ----------------------------------------------------------------------------- more reference-held known answers (round 2)
+def _ceres_problem2():
+    """LinearLeastSquaresProblem1/2 (linear_least_squares_problems.cc:135-285): the fixed 6 x 5 problem of
+    schur_eliminator_test.cc, two scalar e-blocks, b = (0..5), D = 1."""
+    A = np.array([[1, 0, 2, 0, 0], [3, 0, 0, 4, 0], [0, 5, 0, 0, 6], [0, 7, 8, 0, 0], [0, 9, 1, 0, 0], [0, 0, 1, 1, 1]], np.float64)
+    b = np.arange(6, dtype=np.float64)
+    row_e = np.array([0, 0, 1, 1, 1, -1], np.int32)
+    return A, b, np.ones(5), row_e
+
+
+def _schur(oracle, A, b, D, row_e, n_e):
+    import ctypes as C
+    m, n = A.shape
+    s = n - n_e
+    lhs = np.zeros((s, s)); rhs = np.zeros(s); sol = np.zeros(n)
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    A = np.ascontiguousarray(A); Dc = None if D is None else np.ascontiguousarray(D, np.float64)
+    rc = oracle.lib().orc_schur_eliminate_dense(p(A), p(b), p(Dc), m, n, n_e, p(row_e), p(lhs), p(rhs), p(sol))
+    assert rc == 0
+    return lhs, rhs, sol
+
+
+def test_schur_eliminator_ceres_problem2_published_values(oracle):
+    """The numbers Ceres prints next to its fixed problem (linear_least_squares_problems.cc:150-181): A'A, S (upper triangle),
+    S \\ r and A \\ b.  Two entries of that comment are inconsistent with its own A'A / S \\ r / A \\ b and are not used: the
+    sign of S[2][0] (+11.5806; S is symmetric) and r[2] (printed 5.0323, is 4.0323)."""
+    A, b, _, row_e = _ceres_problem2()
+    assert np.array_equal(A.T @ A, [[10, 0, 2, 12, 0], [0, 155, 65, 0, 30], [2, 65, 70, 1, 1], [12, 0, 1, 17, 1], [0, 30, 1, 1, 37]])
+    assert np.array_equal(A.T @ b, [3, 67, 33, 9, 17])
+    S, r, sol = _schur(oracle, A, b, None, row_e, 2)
+    assert np.allclose(S[np.triu_indices(3)], [42.3419, -1.4, -11.5806, 2.6, 1.0, 31.1935], atol=5e-5)
+    assert np.allclose(S, S.T, atol=1e-13)
+    assert np.allclose(r[:2], [4.3032, 5.4], atol=5e-5)
+    assert np.allclose(np.linalg.solve(S, r), [0.2102, 2.1367, 0.1388], atol=5e-5)
+    assert np.allclose(sol, [-2.3061, 0.3172, 0.2102, 2.1367, 0.1388], atol=5e-5)
+
+
+@pytest.mark.parametrize("regularised", [False, True])
+def test_schur_eliminator_matches_dense_normal_equations(oracle, regularised):
+    """SchurEliminatorTest.ScalarProblem{No,With}Regularization (schur_eliminator_test.cc:82-225): reduced system, its
+    right-hand side and the back-substituted solution against dense linear algebra, relative tolerance 1e-14."""
+    A, b, D, row_e = _ceres_problem2()
+    D = D if regularised else np.zeros(5)
+    S, r, sol = _schur(oracle, A, b, D, row_e, 2)
+    H = A.T @ A + np.diag(D * D); g = A.T @ b
+    P, Q, R = H[:2, :2], H[:2, 2:], H[2:, 2:]
+    Pinv = np.diag(1.0 / np.diag(P))
+    S_exp = R - Q.T @ Pinv @ Q; r_exp = g[2:] - Q.T @ Pinv @ g[:2]
+    assert np.linalg.norm(S - S_exp) / np.linalg.norm(S_exp) < 1e-14
+    assert np.linalg.norm(r - r_exp) / np.linalg.norm(r_exp) < 1e-14
+    sol_exp = np.linalg.solve(H, g)
+    assert np.linalg.norm(sol - sol_exp) / np.linalg.norm(sol_exp) < 1e-13
+
+
+def test_lm_diagonal_is_clamped_and_scaled_by_radius(oracle):
+    """LevenbergMarquardtStrategy.CorrectDiagonalToLinearSolver (levenberg_marquardt_strategy_test.cc:112-135): J = [[0, 1,
+    100], [0, 1, 0]], radius 2, min / max LM diagonal 1e-2 / 1e2 -> the solver receives sqrt((1e-2, 2, 1e2) / 2)."""
+    import ctypes as C
+    J = np.array([[0.0, 1.0, 100.0], [0.0, 1.0, 0.0]])
+    jtj = (J * J).sum(0).copy()
+    D = np.zeros(3)
+    oracle.lib().orc_lm_diagonal(jtj.ctypes.data_as(C.c_void_p), 3, C.c_double(2.0), C.c_double(1e-2), C.c_double(1e2), 1,
+                                 D.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(D, np.sqrt(np.array([1e-2, 2.0, 1e2]) / 2.0))
+    assert np.array_equal(jtj, [1e-2, 2.0, 1e2])                       # the clamped diagonal is kept (reuse_diagonal)
+
+
+def test_se3_exp_axis_rotations_and_translations(oracle):
+    """Sophus test_se3.cpp:136-153: exp of a pure rotation tangent (0,0,0, w) is rotX / rotY / rotZ, of a pure translation
+    tangent transX / transY / transZ -- pins the tangent order [upsilon, omega] (N6) and the quaternion order [x y z w]."""
+    for axis, ang in ((0, 0.2), (1, -0.2), (2, 1.1)):
+        t = np.zeros(6); t[3 + axis] = ang
+        pose = oracle.se3_left_plus(np.array([0, 0, 0, 0, 0, 0, 1.0]), t)
+        q_exp = np.zeros(4); q_exp[axis] = np.sin(ang / 2); q_exp[3] = np.cos(ang / 2)
+        assert np.allclose(pose[:3], 0, atol=1e-16) and np.allclose(pose[3:], q_exp, atol=1e-15)
+    for axis, d in ((0, 0.2), (1, 0.7), (2, -0.2)):
+        t = np.zeros(6); t[axis] = d
+        pose = oracle.se3_left_plus(np.array([0, 0, 0, 0, 0, 0, 1.0]), t)
+        exp_t = np.zeros(3); exp_t[axis] = d
+        assert np.allclose(pose[:3], exp_t, atol=1e-16) and np.allclose(pose[3:], [0, 0, 0, 1], atol=1e-16)
+    # left-multiplicative update (se3left_parametrization.hpp:45-57): T' = exp(delta) * T -- a rotation about z moves the translation
+    pose = oracle.se3_left_plus(np.array([1.0, 0, 0, 0, 0, 0, 1.0]), np.array([0, 0, 0, 0, 0, np.pi / 2]))
+    assert np.allclose(pose[:3], [0, 1, 0], atol=1e-15)

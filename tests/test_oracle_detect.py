@@ -183,3 +183,25 @@ def test_detect_singlescale_properties(oracle):
     # sub-pixel refinement moves points by less than the 3-px window
     pts3, _ = oracle.detect_singlescale(prev, 35, np.zeros((0, 2), np.float32), roi, 0.001, subpix=True)
     assert len(pts3) == len(pts) and np.abs(pts3 - pts).max() <= 3.0 + 1e-6
+
+
+def test_sobel_dy_order_switch(oracle):
+    """cv::Sobel(dx=0, dy=1, scale) scales the smoothing kernel: OpenCV's row-filter order is the default, round 1's
+    exact-sum order the alternative; they agree to <= 1e-6 relative on the min-eigenvalue map (and normally select the
+    same keypoints), and each is reproducible."""
+    from ov2slam_amd import synth
+    prev, _, _ = synth.frame_pair(376, 240, seed=6)
+    assert oracle.lib().orc_get_sobel_dy_order() == oracle.SOBEL_DY_OPENCV_ROWFILTER
+    a = oracle.cell_mineig(prev, 70, 35, 35)
+    assert oracle.set_sobel_dy_order(oracle.SOBEL_DY_EXACT_SUM) == oracle.SOBEL_DY_OPENCV_ROWFILTER
+    try:
+        b = oracle.cell_mineig(prev, 70, 35, 35)
+    finally:
+        oracle.set_sobel_dy_order(oracle.SOBEL_DY_OPENCV_ROWFILTER)
+    assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))          # the orders are really different ...
+    assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()                      # ... by rounding only
+    assert np.array_equal(a, oracle.cell_mineig(prev, 70, 35, 35))
+    # dy of a horizontal step edge: both orders must see the same sign / magnitude to 1e-6
+    img = np.zeros((35, 35), np.uint8); img[18:] = 200
+    m = oracle.cell_mineig(img, 0, 0, 35)
+    assert np.isfinite(m).all()
