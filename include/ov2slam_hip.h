@@ -223,6 +223,16 @@ int ov2_detect_singlescale(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int
                            const float *cur_xy_h, int ncur, const int roi[4], double *quality_inout,
                            int do_subpix, float *out_xy_h, int *out_n);
 
+/* Device-resident forms of the two detectors: the image is level 0 of batch item `item` of a pyramid that already lives in
+ * HBM.  At a keyframe the reference passes cur_img_ -- the CLAHE'd frame preprocessImage also built cur_pyr_ from -- to
+ * MapManager::extractKeypoints (src/map_manager.cpp:286-341, detector choice :312-320): that image IS level 0 of the
+ * tracker's current pyramid (ov2_tracker_cur_pyr), so a keyframe costs no upload.  Results are identical to the host-image
+ * forms on the same pixels.  One host synchronisation per call.                                                          */
+int ov2_detect_grid_fast_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cell, const float *cur_xy_h, int ncur,
+                           int *fast_th_inout, int mask_mode, int do_subpix, float *out_xy_h, int *out_n);
+int ov2_detect_singlescale_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cell, const float *cur_xy_h, int ncur,
+                             const int roi[4], double *quality_inout, int do_subpix, float *out_xy_h, int *out_n);
+
 /* cv::cornerSubPix(im, pts, Size(hw,hw), Size(-1,-1), TermCriteria(EPS+MAX_ITER, max_iter, eps))
  * src/feature_extractor.cpp:434, :564 (hw = 3, 30, 0.01).  In place.             */
 int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride,

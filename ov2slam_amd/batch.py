@@ -128,7 +128,8 @@ def run_sequence(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, u
     empty = np.zeros((0, 2), np.float32)
     t0 = time.perf_counter()
     trk.trackFrame(seq.frame(0), empty, empty, None)
-    kps = fx.detectSingleScale(seq.frame(0), cell, empty, roi)[:nbmaxkps]      # frame 0 is a keyframe (visual_front_end.cpp:87-95)
+    # frame 0 is a keyframe (visual_front_end.cpp:87-95); the detector reads the CLAHE'd frame = level 0 of cur_pyr_ (no upload)
+    kps = fx.detectSingleScalePyr(trk.cur_pyr, cell, empty, roi)[:nbmaxkps]
     age = np.zeros(len(kps), np.int32)
     st = dict(frames=1, tracked=0, attempted=0, err_sq_sum=0.0, err_n=0, detect_calls=1)
     for f in range(1, seq.n_frames):
@@ -145,7 +146,7 @@ def run_sequence(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, u
         inside = (kps[:, 0] > 8) & (kps[:, 0] < w - 9) & (kps[:, 1] > 8) & (kps[:, 1] < h - 9)
         kps, age = kps[inside], age[inside]
         if f % kf_every == 0 and len(kps) < nbmaxkps:
-            new = fx.detectSingleScale(seq.frame(f), cell, kps, roi)[:nbmaxkps - len(kps)]
+            new = fx.detectSingleScalePyr(trk.cur_pyr, cell, kps, roi)[:nbmaxkps - len(kps)]
             st["detect_calls"] += 1
             kps = np.concatenate([kps, new]); age = np.concatenate([age, np.zeros(len(new), np.int32)])
     ctx.sync()

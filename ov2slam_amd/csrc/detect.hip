@@ -573,13 +573,16 @@ __device__ __forceinline__ float d_rect_subpix_px(const uint8_t *__restrict__ sr
 // the five sums are accumulated by lane 0 in the reference's raster order (double), so the result is bit-identical
 // to the serial loop while an iteration costs ~1 us instead of ~10.
 template <int HALF>
-__global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint8_t *__restrict__ img, float2 *__restrict__ xy)
+__global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint8_t *__restrict__ img, float2 *__restrict__ xy,
+                                                      const int *__restrict__ n_dev)
 {
     constexpr int WINW = 2 * HALF + 1, SW = WINW + 2, NPIX = WINW * WINW;
     __shared__ float sub[SW * SW];
     __shared__ double prod[NPIX][5];
     const int pt = blockIdx.x, lane = threadIdx.x;
-    if (pt >= P.n) return;
+    // n_dev: the point count still lives on the device (written by k_grid_select): the launch covers the capacity and the
+    // surplus wavefronts leave here -- the detectors then need ONE host synchronisation instead of two
+    if (pt >= (n_dev ? *n_dev : P.n)) return;
     const float2 cT = xy[pt];
     float cIx = cT.x, cIy = cT.y;
     int iter = 0;
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
 // host side
 // ---------------------------------------------------------------------------------
 static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int stride, float2 *xy_d, int n,
-                         int half_win, int max_iter, double eps)
+                         int half_win, int max_iter, double eps, const int *n_dev = nullptr)
 {
     if (n <= 0) return OV2_OK;
     OV2_REQUIRE(half_win >= 1 && half_win <= SP_MAX_HALF, OV2_EUNSUPPORTED, "cornerSubPix half window must be in [1,5]");
@@ -644,24 +647,25 @@ static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int s
     }
     dim3 grid(n), block(64);                                  // one wavefront per point
     switch (half_win) {
-    case 1: hipLaunchKernelGGL(k_corner_subpix<1>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
-    case 2: hipLaunchKernelGGL(k_corner_subpix<2>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
-    case 3: hipLaunchKernelGGL(k_corner_subpix<3>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
-    case 4: hipLaunchKernelGGL(k_corner_subpix<4>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
-    default: hipLaunchKernelGGL(k_corner_subpix<5>, grid, block, 0, ctx->stream, P, img_d, xy_d); break;
+    case 1: hipLaunchKernelGGL(k_corner_subpix<1>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
+    case 2: hipLaunchKernelGGL(k_corner_subpix<2>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
+    case 3: hipLaunchKernelGGL(k_corner_subpix<3>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
+    case 4: hipLaunchKernelGGL(k_corner_subpix<4>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
+    default: hipLaunchKernelGGL(k_corner_subpix<5>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
     }
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
 
-static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, int h, int stride, int cell,
+// img_h: host image (uploaded first) -- or img_d: an image already in HBM (pyramid level 0: no upload), row pitch `stride`
+static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uint8_t *img_d, int w, int h, int stride, int cell,
                          const float *cur_xy_h, int ncur, int fast_th, int mask_mode, const int roi[4], double quality,
                          int do_subpix, float *out_xy_h, int *out_n, SelectOut *so_h)
 {
     OV2_REQUIRE(ctx && out_xy_h && out_n, OV2_EINVAL, "NULL argument");
     *out_n = 0;
     memset(so_h, 0, sizeof(*so_h));
-    if (!img_h || w <= 0 || h <= 0) return OV2_OK;            // empty image -> empty vector (:291-294 / :446-449)
+    if ((!img_h && !img_d) || w <= 0 || h <= 0) return OV2_OK;            // empty image -> empty vector (:291-294 / :446-449)
     OV2_REQUIRE(stride >= w, OV2_EINVAL, "stride < width");
     OV2_REQUIRE(cell >= 8 && cell <= DET_MAX_CELL, OV2_EUNSUPPORTED, "cell size must be in [8,64]");
     OV2_REQUIRE(ncur >= 0 && (ncur == 0 || cur_xy_h), OV2_EINVAL, "bad current keypoints");
@@ -677,7 +681,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     // device scratch: [img w*h][maps][cur 8*ncur][out 8*2*ncells][SelectOut]
     const size_t o_img = 0;
     const size_t map_bytes = (size_t)ncells * npx * (mode == 0 ? 1 : 4);
-    const size_t o_map = ((size_t)w * h + 255) & ~(size_t)255;
+    const size_t o_map = img_d ? 0 : (((size_t)w * h + 255) & ~(size_t)255);
     const size_t o_cur = (o_map + map_bytes + 255) & ~(size_t)255;
     const size_t o_out = (o_cur + 8 * (size_t)(ncur > 0 ? ncur : 1) + 255) & ~(size_t)255;
     const size_t o_so = o_out + 16 * (size_t)ncells;
@@ -685,17 +689,22 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     int rc = ctx->reserve_device(total);  if (rc) return rc;
     rc = ctx->reserve_host(16 * (size_t)ncells + sizeof(SelectOut)); if (rc) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(ds + o_img, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *im = img_d;                                  // what the kernels read, and its pitch
+    int im_stride = stride;
+    if (!img_d) {
+        OV2_HIP_CHECK(hipMemcpy2DAsync(ds + o_img, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+        im = ds + o_img; im_stride = w;
+    }
     if (ncur > 0) OV2_HIP_CHECK(hipMemcpyAsync(ds + o_cur, cur_xy_h, 8 * (size_t)ncur, hipMemcpyHostToDevice, ctx->stream));
 
     if (mode == 0) {
         int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
-        hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, ds + o_img, w, h, w, cell, nw, th, ds + o_map);
+        hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, ds + o_map);
     } else {
         const size_t lds = (size_t)npx * (3 * 8 + 4 + 4 + 3 * 4 + 1) + 16;
         OV2_REQUIRE(lds <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 58)");
         OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_mineig_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, ds + o_img, w, h, w, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order);
+        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order);
     }
     SelectParams P;
     P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
@@ -712,23 +721,21 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, int w, in
     else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(1, 52, 1); else OV2_LAUNCH_SELECT(1, 32, 2); }
 #undef OV2_LAUNCH_SELECT
     OV2_HIP_CHECK(hipGetLastError());
-    // the count is needed on the host to size the sub-pixel launch
+    // sub-pixel refinement over the CAPACITY of the output list (the kernel reads the count on the device and the
+    // surplus wavefronts leave at once), then ONE copy of (points, counters) and ONE synchronisation
     uint8_t *hs = (uint8_t *)ctx->h_scratch;
-    OV2_HIP_CHECK(hipMemcpyAsync(hs + 16 * (size_t)ncells, ds + o_so, sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
+    const int cap = mode == 0 ? ncells : 2 * ncells;
+    if (do_subpix) {
+        rc = launch_subpix(ctx, im, w, h, im_stride, (float2 *)(ds + o_out), cap, 3, 30, 0.01, (const int *)(ds + o_so));
+        if (rc) return rc;
+    }
+    OV2_HIP_CHECK(hipMemcpyAsync(hs, ds + o_out, 16 * (size_t)ncells + sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(so_h, hs + 16 * (size_t)ncells, sizeof(SelectOut));
     if (getenv("OV2_DET_DEBUG"))
         fprintf(stderr, "[ov2 det] select ticks (100MHz): init %llu prologue %llu sweep %llu compaction %llu\n", so_h->dbg[0], so_h->dbg[1], so_h->dbg[2], so_h->dbg[3]);
     const int n = so_h->n;
-    if (n > 0) {
-        if (do_subpix) {
-            rc = launch_subpix(ctx, ds + o_img, w, h, w, (float2 *)(ds + o_out), n, 3, 30, 0.01);
-            if (rc) return rc;
-        }
-        OV2_HIP_CHECK(hipMemcpyAsync(hs, ds + o_out, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-        OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        memcpy(out_xy_h, hs, 8 * (size_t)n);
-    }
+    if (n > 0) memcpy(out_xy_h, hs, 8 * (size_t)n);
     *out_n = n;
     return OV2_OK;
 }
@@ -743,7 +750,7 @@ int ov2_detect_grid_fast(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int s
     OV2_REQUIRE(mask_mode == OV2_MASK_AS_EXECUTED || mask_mode == OV2_MASK_INTENDED, OV2_EINVAL, "bad mask_mode");
     SelectOut so;
     const int th = *fast_th_inout;
-    const int rc = detect_common(ctx, 0, img_h, w, h, stride, cell, cur_xy_h, ncur, th, mask_mode, nullptr, 0.0,
+    const int rc = detect_common(ctx, 0, img_h, nullptr, w, h, stride, cell, cur_xy_h, ncur, th, mask_mode, nullptr, 0.0,
                                  do_subpix, out_xy_h, out_n, &so);
     if (rc != OV2_OK) return rc;
     if (!img_h || w <= 0 || h <= 0) return OV2_OK;
@@ -760,13 +767,60 @@ int ov2_detect_singlescale(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int
     OV2_REQUIRE(quality_inout != nullptr && roi != nullptr, OV2_EINVAL, "quality_inout / roi == NULL");
     SelectOut so;
     const double q = *quality_inout;
-    const int rc = detect_common(ctx, 1, img_h, w, h, stride, cell, cur_xy_h, ncur, 0, 0, roi, q,
+    const int rc = detect_common(ctx, 1, img_h, nullptr, w, h, stride, cell, cur_xy_h, ncur, 0, 0, roi, q,
                                  do_subpix, out_xy_h, out_n, &so);
     if (rc != OV2_OK) return rc;
     if (!img_h || w <= 0 || h <= 0) return OV2_OK;
     // :418-423 (nbkps there is the size after the secondary top-up)
     const int ncells = (w / cell) * (h / cell);
     if ((double)so.n < 0.33 * (double)(ncells - so.nboccup)) *quality_inout = q / 2.;
+    else if ((double)so.n > 0.9 * (double)(ncells - so.nboccup)) *quality_inout = q * 1.5;
+    return OV2_OK;
+}
+
+// Device-resident forms: the image is level 0 of batch item `item` of a pyramid that is already in HBM -- the (equalised)
+// cur_img_ the reference hands to extractKeypoints at a keyframe (src/map_manager.cpp:312-320) is exactly what
+// preprocessImage left in level 0 of cur_pyr_, so a keyframe costs no image upload.
+static int pyr_level0(ov2_ctx *ctx, const ov2_pyr *pyr, int item, const uint8_t **img, int *w, int *h, int *stride)
+{
+    OV2_REQUIRE(ctx && pyr, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(item >= 0 && item < pyr->d.batch, OV2_EINVAL, "batch item out of range");
+    const PyrLevelDesc &L0 = pyr->d.lv[0];
+    *img = pyr->d.base + (long long)item * pyr->d.item_stride + L0.img_roi;
+    *w = L0.w; *h = L0.h; *stride = L0.img_pitch;
+    return ov2_pyr_wait_ready(ctx, pyr);
+}
+
+int ov2_detect_grid_fast_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cell, const float *cur_xy_h, int ncur,
+                           int *fast_th_inout, int mask_mode, int do_subpix, float *out_xy_h, int *out_n)
+{
+    OV2_REQUIRE(fast_th_inout != nullptr, OV2_EINVAL, "fast_th_inout == NULL");
+    OV2_REQUIRE(mask_mode == OV2_MASK_AS_EXECUTED || mask_mode == OV2_MASK_INTENDED, OV2_EINVAL, "bad mask_mode");
+    const uint8_t *img; int w, h, stride;
+    int rc = pyr_level0(ctx, pyr, item, &img, &w, &h, &stride);
+    if (rc != OV2_OK) return rc;
+    SelectOut so;
+    const int th = *fast_th_inout;
+    rc = detect_common(ctx, 0, nullptr, img, w, h, stride, cell, cur_xy_h, ncur, th, mask_mode, nullptr, 0.0, do_subpix, out_xy_h, out_n, &so);
+    if (rc != OV2_OK) return rc;
+    if ((double)so.nbkps < 0.5 * (double)so.nbempty && so.nbempty > 10) *fast_th_inout = (int)(th * 0.66);     // :546-552
+    else if (so.nbkps == so.nbempty) *fast_th_inout = (int)(th * 1.5);
+    return OV2_OK;
+}
+
+int ov2_detect_singlescale_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cell, const float *cur_xy_h, int ncur,
+                             const int roi[4], double *quality_inout, int do_subpix, float *out_xy_h, int *out_n)
+{
+    OV2_REQUIRE(quality_inout != nullptr && roi != nullptr, OV2_EINVAL, "quality_inout / roi == NULL");
+    const uint8_t *img; int w, h, stride;
+    int rc = pyr_level0(ctx, pyr, item, &img, &w, &h, &stride);
+    if (rc != OV2_OK) return rc;
+    SelectOut so;
+    const double q = *quality_inout;
+    rc = detect_common(ctx, 1, nullptr, img, w, h, stride, cell, cur_xy_h, ncur, 0, 0, roi, q, do_subpix, out_xy_h, out_n, &so);
+    if (rc != OV2_OK) return rc;
+    const int ncells = (w / cell) * (h / cell);
+    if ((double)so.n < 0.33 * (double)(ncells - so.nboccup)) *quality_inout = q / 2.;                         // :418-423
     else if ((double)so.n > 0.9 * (double)(ncells - so.nboccup)) *quality_inout = q * 1.5;
     return OV2_OK;
 }

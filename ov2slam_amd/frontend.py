@@ -351,6 +351,30 @@ class FeatureExtractor:
         self.dmaxquality_ = q.value
         return out[:n.value].copy()
 
+    def detectSingleScalePyr(self, pyr, ncellsize, vcurkps, roi, subpix=True, item=0):
+        """detectSingleScale on level 0 of a device-resident pyramid (e.g. VisualFrontEndTracker.cur_pyr: the CLAHE'd
+        cur_img_ of the keyframe, src/map_manager.cpp:312-320) -- no image upload."""
+        cur = np.ascontiguousarray(vcurkps, dtype=np.float32).reshape(-1, 2)
+        w, h = pyr.level_size(0)
+        out = np.zeros((max(1, 2 * (w // ncellsize) * (h // ncellsize)), 2), np.float32)
+        n = C.c_int(0); q = C.c_double(self.dmaxquality_)
+        roi_a = (C.c_int * 4)(*[int(v) for v in roi])
+        L.check(self.lib.ov2_detect_singlescale_d(self.ctx.h, pyr.h_pyr, int(item), int(ncellsize), _ptr(cur), cur.shape[0],
+                                                  roi_a, C.byref(q), int(bool(subpix)), _ptr(out), C.byref(n)))
+        self.dmaxquality_ = q.value
+        return out[:n.value].copy()
+
+    def detectGridFASTPyr(self, pyr, ncellsize, vcurkps, subpix=True, item=0):
+        """detectGridFAST on level 0 of a device-resident pyramid."""
+        cur = np.ascontiguousarray(vcurkps, dtype=np.float32).reshape(-1, 2)
+        w, h = pyr.level_size(0)
+        out = np.zeros((max(1, (w // ncellsize) * (h // ncellsize)), 2), np.float32)
+        n = C.c_int(0); th = C.c_int(self.nfast_th_)
+        L.check(self.lib.ov2_detect_grid_fast_d(self.ctx.h, pyr.h_pyr, int(item), int(ncellsize), _ptr(cur), cur.shape[0],
+                                                C.byref(th), self.mask_mode, int(bool(subpix)), _ptr(out), C.byref(n)))
+        self.nfast_th_ = th.value
+        return out[:n.value].copy()
+
     def cornerSubPix(self, im, pts, half_win=3, max_iter=30, eps=0.01):
         im = np.ascontiguousarray(im, dtype=np.uint8)
         h, w = im.shape

@@ -144,3 +144,29 @@ def test_singlescale_sobel_dy_orders_bit_exact(oracle, order):
             c2.set_option(L.OV2_OPT_SOBEL_DY_ORDER, 7)
         finally:
             c2.close()
+
+
+@pytest.mark.parametrize("wh", [(752, 480), (1241, 376)])
+def test_device_resident_detectors_read_pyramid_level0(gpu_ctx, oracle, wh):
+    """ov2_detect_*_d on level 0 of the tracker's current pyramid (the CLAHE'd keyframe image, map_manager.cpp:312-320):
+    same points as the host-image entry points and as the oracle on the equalised image; thresholds adapt identically."""
+    w, h = wh
+    img, _, _ = synth.frame_pair(w, h, seed=17)
+    trk = ov2slam_amd.VisualFrontEndTracker(gpu_ctx, w, h, use_clahe=True, fclahe_val=3.0, nbmaxkps=64)
+    trk.trackFrame(img, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+    eq = oracle.clahe(img, 3.0, w // 50, h // 50)
+    roi = (5, 5, w - 10, h - 10)
+    rng = np.random.default_rng(4)
+    cur = synth.grid_keypoints(w, h, 35, rng)[::3]
+    for curkps in (np.zeros((0, 2), np.float32), cur):
+        fa, fb = ov2slam_amd.FeatureExtractor(gpu_ctx, dmaxquality=0.001), ov2slam_amd.FeatureExtractor(gpu_ctx, dmaxquality=0.001)
+        g = fa.detectSingleScalePyr(trk.cur_pyr, 35, curkps, roi)
+        hst = fb.detectSingleScale(eq, 35, curkps, roi)
+        r, q = oracle.detect_singlescale(eq, 35, curkps, roi, 0.001)
+        assert len(g) == len(r) and np.array_equal(_bits(g), _bits(r)) and np.array_equal(_bits(g), _bits(hst))
+        assert fa.dmaxquality_ == q == fb.dmaxquality_
+        fa = ov2slam_amd.FeatureExtractor(gpu_ctx, nfast_th=10)
+        g = fa.detectGridFASTPyr(trk.cur_pyr, 50, curkps)
+        r, th = oracle.detect_grid_fast(eq, 50, curkps, 10)
+        assert len(g) == len(r) and np.array_equal(_bits(g), _bits(r)) and fa.nfast_th_ == th
+    trk.close()
