@@ -568,7 +568,18 @@ def main():
             t1 = time.perf_counter()
             for _ in range(20):
                 det = fx.detectSingleScale(views[0], CELL, np.zeros((0, 2), np.float32), roi)
-            out["detect"] = {"detect_singlescale_ms_incl_pcie": (time.perf_counter() - t1) / 20 * 1e3, "detected_points": int(len(det))}
+            det_ms = (time.perf_counter() - t1) / 20 * 1e3
+            # the keyframe case of the drop-in: the detector reads the CLAHE'd frame from level 0 of the tracker's pyramid
+            trk = ov2slam_amd.VisualFrontEndTracker(ctx1, W, H, fclahe_val=CLAHE_CLIP, nbmaxkps=512)
+            trk.trackFrame(views[0], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+            fx.detectSingleScalePyr(trk.cur_pyr, CELL, np.zeros((0, 2), np.float32), roi)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                det_d = fx.detectSingleScalePyr(trk.cur_pyr, CELL, np.zeros((0, 2), np.float32), roi)
+            det_d_ms = (time.perf_counter() - t1) / 20 * 1e3
+            trk.close()
+            out["detect"] = {"detect_singlescale_ms_incl_pcie": det_ms, "detected_points": int(len(det)),
+                             "detect_singlescale_pyramid_resident_ms": det_d_ms, "detected_points_pyramid_resident": int(len(det_d))}
             ctx1.close()
             if not args.no_cpu_baseline:
                 out["parity"] = parity_check(dev.index, views, kps, pri)

@@ -516,3 +516,60 @@ def xyz_residual(rtype, calib_l, calib_r, T_rl, pose, X, uv, sigma, want_jac=Tru
     cl, cr, T, p, x, u = a(calib_l), a(calib_r), a(T_rl), a(pose), a(X), a(uv)
     dp = f(int(rtype), _p(cl), _p(cr), _p(T), _p(p), _p(x), _p(u), C.c_double(sigma), _p(r), _p(J) if want_jac else None, C.byref(chi2))
     return r, J, chi2.value, bool(dp)
+
+
+# ---------------------------------------------------------------- BA over 3-D points with variable poses (xyz_ba.c)
+class _XYZBAProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int), ("poses", C.c_void_p), ("kf_const", C.c_void_p), ("n_pts", C.c_int), ("xyz", C.c_void_p),
+                ("n_res", C.c_int), ("res_type", C.c_void_p), ("res_kf", C.c_void_p), ("res_pt", C.c_void_p),
+                ("res_uv", C.c_void_p), ("res_sigma", C.c_void_p), ("res_active", C.c_void_p),
+                ("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7)]
+
+
+class _XYZBAResult(C.Structure):
+    _fields_ = [("poses_out", C.c_void_p), ("xyz_out", C.c_void_p), ("chi2_last_eval", C.c_void_p), ("depthpos_last_eval", C.c_void_p),
+                ("iterations", C.c_int), ("num_successful_steps", C.c_int), ("initial_cost", C.c_double),
+                ("final_cost", C.c_double), ("termination", C.c_int)]
+
+
+def xyz_ba_solve(prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None):
+    """prob: dict from ov2slam_amd.synth.make_xyz_ba_problem.  One ceres::Solve of the buse_inv_depth: 0 branch."""
+    opts = opts or ba_default_options()
+    keep = {}
+
+    def arr(name, dt):
+        a = np.ascontiguousarray(prob[name], dt); keep[name] = a
+        return a.ctypes.data
+
+    P = _XYZBAProblem()
+    P.n_kf, P.n_pts, P.n_res = int(prob["n_kf"]), int(prob["n_pts"]), int(prob["n_res"])
+    P.poses = arr("poses", np.float64); P.xyz = arr("xyz", np.float64); P.kf_const = arr("kf_const", np.uint8)
+    P.res_type = arr("res_type", np.uint8); P.res_kf = arr("res_kf", np.int32); P.res_pt = arr("res_pt", np.int32)
+    P.res_uv = arr("res_uv", np.float64); P.res_sigma = arr("res_sigma", np.float64)
+    if res_active is not None:
+        ra = np.ascontiguousarray(res_active, np.uint8); keep["ra"] = ra
+        P.res_active = ra.ctypes.data
+    for i in range(4):
+        P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
+    for i in range(7):
+        P.T_rl[i] = float(prob["T_rl"][i])
+    poses = np.zeros((P.n_kf, 7)); xyz = np.zeros((P.n_pts, 3))
+    chi2 = np.full(P.n_res, np.nan) if chi2_init is None else np.array(chi2_init, np.float64, copy=True)
+    dpos = np.zeros(P.n_res, np.uint8) if depthpos_init is None else np.array(depthpos_init, np.uint8, copy=True)
+    R = _XYZBAResult()
+    R.poses_out = poses.ctypes.data; R.xyz_out = xyz.ctypes.data; R.chi2_last_eval = chi2.ctypes.data; R.depthpos_last_eval = dpos.ctypes.data
+    rc = lib().orc_xyzba_solve(C.byref(P), C.byref(opts), C.byref(R))
+    assert rc == 0, rc
+    return dict(poses=poses, xyz=xyz, chi2=chi2, depthpos=dpos, iterations=R.iterations, num_successful_steps=R.num_successful_steps,
+                initial_cost=R.initial_cost, final_cost=R.final_cost, termination=R.termination)
+
+
+def xyzba_residual(rtype, calib_l, calib_r, T_rl, pose, X, uv, sigma):
+    """-> (r (2,), Jp (2,6), Jx (2,3), chi2, depth positive)"""
+    r = np.zeros(2); Jp = np.zeros((2, 6)); Jx = np.zeros((2, 3)); chi2 = C.c_double(0)
+    f = lib().orc_xyzba_residual
+    f.restype = C.c_int
+    a = lambda v: np.ascontiguousarray(v, np.float64)
+    cl, cr, T, p, x, u = a(calib_l), a(calib_r), a(T_rl), a(pose), a(X), a(uv)
+    dp = f(int(rtype), _p(cl), _p(cr), _p(T), _p(p), _p(x), _p(u), C.c_double(sigma), _p(r), _p(Jp), _p(Jx), C.byref(chi2))
+    return r, Jp, Jx, chi2.value, bool(dp)

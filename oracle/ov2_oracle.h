@@ -306,6 +306,34 @@ typedef struct {
     double initial_cost, final_cost;
     int termination;
 } orc_sba_result;
+/* ---- BA over 3-D points with variable poses (buse_inv_depth: 0, src/optimizer.cpp:207-209, :333-384) -- xyz_ba.c ---- */
+typedef struct {
+    int n_kf;
+    const double *poses;       /* 7*n_kf  [t, q(x,y,z,w)] of Twc, initial values          */
+    const uint8_t *kf_const;   /* n_kf    1 = constant block (NULL: all variable)          */
+    int n_pts;
+    const double *xyz;         /* 3*n_pts world points, initial values                     */
+    int n_res;
+    const uint8_t *res_type;   /* ORC_XYZ_LEFT / ORC_XYZ_RIGHT                             */
+    const int *res_kf, *res_pt;
+    const double *res_uv;      /* 2*n_res */
+    const double *res_sigma;
+    const uint8_t *res_active; /* or NULL */
+    double calib_l[4], calib_r[4], T_rl[7];
+} orc_xyzba_problem;
+typedef struct {
+    double *poses_out;         /* 7*n_kf  */
+    double *xyz_out;           /* 3*n_pts */
+    double *chi2_last_eval;    /* n_res (N4) */
+    uint8_t *depthpos_last_eval;
+    int iterations, num_successful_steps;
+    double initial_cost, final_cost;
+    int termination;
+} orc_xyzba_result;
+int orc_xyzba_residual(int type, const double calib_l[4], const double calib_r[4], const double T_rl[7], const double pose[7],
+                       const double X[3], const double uv[2], double sigma, double r[2], double *Jp, double *Jx, double *chi2);
+int orc_xyzba_solve(const orc_xyzba_problem *p, const orc_ba_options *o, orc_xyzba_result *r);
+
 int orc_xyz_residual(int type, const double calib_l[4], const double calib_r[4], const double T_rl[7], const double pose[7],
                      const double X[3], const double uv[2], double sigma, double r[2], double *J, double *chi2);
 int orc_structure_ba(const orc_sba_problem *p, const orc_ba_options *o, orc_sba_result *r);

@@ -255,3 +255,25 @@ def make_structure_problem(n_kf=12, n_pts=500, obs_per_pt=5, stereo=True, seed=7
     return dict(n_kf=n_kf, n_pts=n_pts, n_res=len(rt), poses=poses, xyz=xyz0, xyz_gt=xyz_gt, res_type=np.array(rt, np.uint8),
                 res_kf=np.array(rk, np.int32), res_pt=np.array(rp, np.int32), res_uv=np.array(ruv), res_sigma=np.array(rs, np.float64),
                 calib_l=K, calib_r=K.copy(), T_rl=T_rl, is_outlier=np.array(is_out))
+
+
+def make_xyz_ba_problem(n_kf=12, n_pts=500, obs_per_pt=5, stereo=True, seed=7, px_noise=1.0, outlier_frac=0.02, xyz_noise=0.1,
+                        pose_noise=(0.02, np.deg2rad(0.5))):
+    """Bundle adjustment over 3-D points AND keyframe poses: the `buse_inv_depth: 0` branch of Optimizer::localBA
+    (src/optimizer.cpp:207-209, :333-384).  make_structure_problem's scene with perturbed, variable poses (keyframe 0 --
+    and keyframe 1 for mono -- constant, :397-407).  Layout = ov2_xyzba_problem (ov2_sba_problem + kf_const)."""
+    pb = make_structure_problem(n_kf, n_pts, obs_per_pt, stereo, seed, px_noise, outlier_frac, xyz_noise)
+    rng = np.random.default_rng(seed + 1000)
+    poses_gt = pb["poses"].copy()
+    poses0 = poses_gt.copy()
+    kf_const = np.zeros(n_kf, np.uint8); kf_const[0] = 1
+    if not stereo and n_kf > 1:
+        kf_const[1] = 1
+    for k in range(n_kf):
+        if kf_const[k]:
+            continue
+        R = _R_from_quat(poses_gt[k, 3:])
+        poses0[k, :3] = poses_gt[k, :3] + rng.normal(0, pose_noise[0], 3)
+        poses0[k, 3:] = _quat_from_R(_so3_exp(rng.normal(0, pose_noise[1], 3)) @ R)
+    pb.update(poses=np.ascontiguousarray(poses0), poses_gt=poses_gt, kf_const=kf_const)
+    return pb
