@@ -361,6 +361,44 @@ typedef struct {
 int ov2_structure_ba(ov2_ctx *ctx, const ov2_sba_problem *p, const ov2_ba_options *o, ov2_sba_result *r);
 
 /* ------------------------------------------------------------------ */
+/* Bundle adjustment over 3-D points with variable poses (buse_inv_depth: 0) */
+/* ------------------------------------------------------------------ */
+/* One ceres::Solve of Optimizer::localBA / looseBA / fullBA when `buse_inv_depth: 0`: map points enter as
+ * PointXYZParametersBlock (3 doubles, elimination group 0, src/optimizer.cpp:207-209) and every observation is a
+ *   OV2_XYZ_LEFT   DirectLeftSE3::ReprojectionErrorKSE3XYZ          {calib, pose, X}            (:333-384, :366-375)
+ *   OV2_XYZ_RIGHT  DirectLeftSE3::ReprojectionErrorRightCamKSE3XYZ  {calib_r, pose, T_rl, X}    (:347-357)
+ * residual block with a VARIABLE keyframe pose (factors src/ceres_parametrization.cpp:107-298); kf_const marks the
+ * SetParameterBlockConstant keyframes (:397-407).  Same options, termination codes and N4 outputs as ov2_ba_solve; the
+ * Schur complement eliminates 3x3 point blocks.  No shipped parameter file selects this branch; the inverse-depth form
+ * (ov2_ba_solve) is what every preset runs.  The same ~95 optimised-keyframe limit applies (OV2_EUNSUPPORTED).      */
+typedef struct {
+    int n_kf;
+    const double *poses;         /* 7*n_kf  [tx ty tz qx qy qz qw] of Twc, initial values      */
+    const uint8_t *kf_const;     /* n_kf; 1 = constant block (NULL: every pose variable)       */
+    int n_pts;
+    const double *xyz;           /* 3*n_pts world points, initial values                       */
+    int n_res;
+    const uint8_t *res_type;     /* n_res   OV2_XYZ_*                                          */
+    const int *res_kf;           /* n_res   observing keyframe                                 */
+    const int *res_pt;           /* n_res   observed point                                     */
+    const double *res_uv;        /* 2*n_res undistorted pixel (unpx_ / runpx_)                 */
+    const double *res_sigma;     /* n_res   2^scale                                            */
+    const uint8_t *res_active;   /* n_res or NULL                                              */
+    double calib_l[4], calib_r[4], T_rl[7];
+} ov2_xyzba_problem;
+typedef struct {
+    double *poses_out;           /* 7*n_kf                                                     */
+    double *xyz_out;             /* 3*n_pts                                                    */
+    double *chi2_last_eval;      /* n_res, in/out like ov2_ba_result                           */
+    uint8_t *depthpos_last_eval; /* n_res, in/out                                              */
+    int iterations, num_successful_steps;
+    double initial_cost, final_cost;
+    int termination;             /* OV2_TERM_*                                                 */
+    double solve_ms;
+} ov2_xyzba_result;
+int ov2_xyz_ba_solve(ov2_ctx *ctx, const ov2_xyzba_problem *p, const ov2_ba_options *o, ov2_xyzba_result *r);
+
+/* ------------------------------------------------------------------ */
 /* Per-keypoint undistortion + bearing vector                           */
 /* ------------------------------------------------------------------ */
 /* Frame::computeKeypoint (src/frame.cpp:246-254) for n keypoints in one launch:

@@ -85,6 +85,23 @@ class TrackerConfig(C.Structure):
     ]
 
 
+class XYZBAProblem(C.Structure):
+    _fields_ = [
+        ("n_kf", C.c_int), ("poses", C.POINTER(C.c_double)), ("kf_const", C.POINTER(C.c_uint8)), ("n_pts", C.c_int),
+        ("xyz", C.POINTER(C.c_double)), ("n_res", C.c_int), ("res_type", C.POINTER(C.c_uint8)), ("res_kf", C.POINTER(C.c_int)),
+        ("res_pt", C.POINTER(C.c_int)), ("res_uv", C.POINTER(C.c_double)), ("res_sigma", C.POINTER(C.c_double)),
+        ("res_active", C.POINTER(C.c_uint8)), ("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7),
+    ]
+
+
+class XYZBAResult(C.Structure):
+    _fields_ = [
+        ("poses_out", C.POINTER(C.c_double)), ("xyz_out", C.POINTER(C.c_double)), ("chi2_last_eval", C.POINTER(C.c_double)),
+        ("depthpos_last_eval", C.POINTER(C.c_uint8)), ("iterations", C.c_int), ("num_successful_steps", C.c_int),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("termination", C.c_int), ("solve_ms", C.c_double),
+    ]
+
+
 _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 _pp = C.POINTER(C.c_void_p)
 
@@ -137,6 +154,7 @@ SIGNATURES = {
     "ov2_corner_subpix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _d]),
     "ov2_ba_default_options": (None, [C.POINTER(BAOptions)]),
     "ov2_structure_ba": (_i, [_vp, C.POINTER(SBAProblem), C.POINTER(BAOptions), C.POINTER(SBAResult)]),
+    "ov2_xyz_ba_solve": (_i, [_vp, C.POINTER(XYZBAProblem), C.POINTER(BAOptions), C.POINTER(XYZBAResult)]),
     "ov2_ba_solve": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(BAOptions), C.POINTER(BAResult)]),
     "ov2_ba_create": (_i, [_vp, C.POINTER(BAProblem), _pp]),
     "ov2_ba_solve_resident": (_i, [_vp, _vp, C.POINTER(BAOptions), C.POINTER(BAResult)]),

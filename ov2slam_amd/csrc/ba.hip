@@ -57,6 +57,16 @@ struct BACtl {
 
 struct BADev {                    // device pointers + sizes (passed by value to kernels)
     int n_kf, n_lm, n_act, nf, nfp;
+    // ldim = 1: anchored inverse depth (one scalar per landmark); ldim = 3: 3-D point landmarks with variable poses
+    // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
+    // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
+    int ldim;
+    double *ete6;                 // 6*n_lm   unscaled E^T E, upper triangle (xx xy xz yy yz zz)            [ldim 3]
+    double *minv6;                // 6*n_lm   (S E^T E S + D^2)^-1, upper triangle                          [ldim 3]
+    double *Wp;                   // 3*n_lm * nfp : rows L_c^T W_l with C_l = S M^-1 S = L_c L_c^T, so that
+                                  //   sum_l W_l^T C_l W_l = Wp^T Wp  -- k_ba_schur_gemm runs on it unchanged   [ldim 3]
+    double *ep;                   // 3*n_lm   L_c^T E^T b                                                    [ldim 3]
+    double *ones;                 // 3*n_lm   the "c_l" of the pseudo-rows of Wp                              [ldim 3]
     // problem (landmark-sorted residuals)
     const int *pose_col;          // n_kf  (-1 = constant)
     const int *lm_ptr;            // n_lm+1
@@ -266,6 +276,47 @@ __device__ __forceinline__ int d_residual_pnp(const BADev &D, const double *RTo,
             }
     }
     return c[2] > 0;
+}
+
+// DirectLeftSE3::ReprojectionErrorKSE3XYZ / ReprojectionErrorRightCamKSE3XYZ (ceres_parametrization.cpp:107-195, :198-298):
+// world point X seen by the left (type 0) or right (type 1, through T_rl) camera of keyframe RTo = (Rwc | t).
+// Jp: 2x6 w.r.t. the left-multiplicative pose tangent [-J_R, J_R hat(X)], Jx: 2x3 = J_R.
+template <bool JAC>
+__device__ __forceinline__ int d_residual_xyz(const BADev &D, int type, const double *RTo, const double *X, const double *uv, double sigma,
+                                              double *r, double *Jp, double *Jx)
+{
+    const double sqrt_info = 1.0 / sigma;
+    const double d[3] = {X[0] - RTo[9], X[1] - RTo[10], X[2] - RTo[11]};
+    double lc[3], cam[3];
+    for (int i = 0; i < 3; i++) lc[i] = RTo[i] * d[0] + RTo[3 + i] * d[1] + RTo[6 + i] * d[2];      // Rcw = Rwc^T
+    const double *K = D.calib_l;
+    if (type == OV2_XYZ_RIGHT) {
+        for (int i = 0; i < 3; i++) cam[i] = D.Rrl[3 * i] * lc[0] + D.Rrl[3 * i + 1] * lc[1] + D.Rrl[3 * i + 2] * lc[2] + D.trl[i];
+        K = D.calib_r;
+    } else { cam[0] = lc[0]; cam[1] = lc[1]; cam[2] = lc[2]; }
+    const double invz = 1.0 / cam[2];
+    r[0] = sqrt_info * (K[0] * cam[0] * invz + K[2] - uv[0]);
+    r[1] = sqrt_info * (K[1] * cam[1] * invz + K[3] - uv[1]);
+    const int dp = cam[2] > 0;
+    if (!JAC) return dp;
+    const double invz2 = invz * invz;
+    const double Jc[6] = {invz * K[0], 0, -cam[0] * invz2 * K[0], 0, invz * K[1], -cam[1] * invz2 * K[1]};
+    double M[9];
+    if (type == OV2_XYZ_RIGHT) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+            M[3 * i + j] = D.Rrl[3 * i] * RTo[3 * j] + D.Rrl[3 * i + 1] * RTo[3 * j + 1] + D.Rrl[3 * i + 2] * RTo[3 * j + 2];
+    } else for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = RTo[3 * j + i];
+    double JR[6];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) JR[3 * i + j] = sqrt_info * (Jc[3 * i] * M[j] + Jc[3 * i + 1] * M[3 + j] + Jc[3 * i + 2] * M[6 + j]);
+    for (int i = 0; i < 2; i++) {
+        const double a = JR[3 * i], b = JR[3 * i + 1], c = JR[3 * i + 2];
+        Jx[3 * i] = a; Jx[3 * i + 1] = b; Jx[3 * i + 2] = c;
+        Jp[6 * i] = -a; Jp[6 * i + 1] = -b; Jp[6 * i + 2] = -c;
+        Jp[6 * i + 3] = b * X[2] - c * X[1];                  // J_R hat(X)
+        Jp[6 * i + 4] = c * X[0] - a * X[2];
+        Jp[6 * i + 5] = a * X[1] - b * X[0];
+    }
+    return dp;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -617,7 +668,8 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         // a new linearisation at x is available: jacobi scaling (iteration 0 only), gradient max-norm
         if (O.jacobi && !ctl->scaled) {
             for (int c = tid; c < D.nf; c += nt) D.scale_f[c] = 1.0 / (1.0 + sqrt(D.H[(long long)c * D.nfp + c]));
-            for (int l = tid; l < D.n_lm; l += nt) D.scale_l[l] = 1.0 / (1.0 + sqrt(D.ete[l]));
+            if (D.ldim == 1) for (int l = tid; l < D.n_lm; l += nt) D.scale_l[l] = 1.0 / (1.0 + sqrt(D.ete[l]));
+            else for (int l = tid; l < 3 * D.n_lm; l += nt) { const int k = l % 3; D.scale_l[l] = 1.0 / (1.0 + sqrt(D.ete6[6 * (l / 3) + (k == 0 ? 0 : (k == 1 ? 3 : 5))])); }
         }
         // |x - Plus(x, -g)|_inf  (trust_region_minimizer.cc:283-297)
         double gm = 0;
@@ -629,9 +681,14 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
             d_se3_left_plus(D.x_pose + 7 * k, d, out);
             for (int c = 0; c < 7; c++) gm = fmax(gm, fabs(D.x_pose[7 * k + c] - out[c]));
         }
+        if (D.ldim == 1) {
 #pragma unroll 4
-        for (int l = tid; l < D.n_lm; l += nt)
-            if (D.lm_ptr[l] != D.lm_ptr[l + 1]) gm = fmax(gm, fabs(D.etb[l]));
+            for (int l = tid; l < D.n_lm; l += nt)
+                if (D.lm_ptr[l] != D.lm_ptr[l + 1]) gm = fmax(gm, fabs(D.etb[l]));
+        } else {
+            for (int l = tid; l < 3 * D.n_lm; l += nt)
+                if (D.lm_ptr[l / 3] != D.lm_ptr[l / 3 + 1]) gm = fmax(gm, fabs(D.etb[l]));      // Plus(x, -g) - x = -g for a Euclidean block
+        }
         double z0 = 0, z1 = 0;
         block_reduce3<true>(gm, z0, z1, s_part);
         if (tid == 0) s_gmax = gm;
@@ -687,7 +744,16 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         }
         D.v[c] = 0;
     }
-    {
+    if (D.ldim == 3) {
+        // 3-D point landmarks: only the clamped LM diagonal is formed here; the 3x3 inverses, the rows of Wp and L_c^T E^T b are the
+        // work of k_ba_xyz_prep (many work-groups) right after this kernel
+        if (!reuse)
+            for (int l = tid; l < 3 * D.n_lm; l += nt) {
+                const int k = l % 3;
+                const double s = D.scale_l[l];
+                D.diag_l[l] = fmin(fmax(s * s * D.ete6[6 * (l / 3) + (k == 0 ? 0 : (k == 1 ? 3 : 5))], O.min_diag), O.max_diag);
+            }
+    } else {
         // one workgroup walks all landmarks: the loads of four iterations are issued together (restrict-qualified views:
         // without them every store fences the next iteration's loads -- ten dependent L2 round trips per thread)
         const int *__restrict__ lm_ptr = D.lm_ptr;
@@ -1100,7 +1166,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
             p2 += yi * si * (D.bf[i] - D.v[i]) - (D.diag_f[i] / radius) * yi * yi;
         }
 #pragma unroll 4
-        for (int l = tid; l < D.n_lm; l += nt) if (!isfinite(D.yl[l])) bad = 1;
+        for (int l = tid; l < D.n_lm * D.ldim; l += nt) if (!isfinite(D.yl[l])) bad = 1;
     }
     double P1 = p1, P2 = p2, nbad = (double)bad;
     block_reduce3<false>(P1, P2, nbad, s_part);
@@ -1144,7 +1210,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
     {
         double *__restrict__ c_lam = D.c_lam; const double *__restrict__ x_lam = D.x_lam, *__restrict__ yl = D.yl, *__restrict__ scale_l = D.scale_l;
 #pragma unroll 4
-        for (int l = tid; l < D.n_lm; l += nt) c_lam[l] = x_lam[l] - yl[l] * scale_l[l];
+        for (int l = tid; l < D.n_lm * D.ldim; l += nt) c_lam[l] = x_lam[l] - yl[l] * scale_l[l];
     }
 }
 
@@ -1166,8 +1232,9 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
         }
     }
 #pragma unroll 4
-    for (int l = tid; l < D.n_lm; l += nt) {
-        if (D.lm_ptr[l] == D.lm_ptr[l + 1]) continue;
+    for (int l = tid; l < D.n_lm * D.ldim; l += nt) {
+        const int lm = D.ldim == 1 ? l : l / 3;
+        if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) continue;
         const double d = D.x_lam[l] - D.c_lam[l];
         sn += d * d; xn += D.c_lam[l] * D.c_lam[l];
     }
@@ -1214,10 +1281,233 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
     {
         double *__restrict__ x_lam = D.x_lam; const double *__restrict__ c_lam = D.c_lam;
 #pragma unroll 8
-        for (int l = tid; l < D.n_lm; l += nt) x_lam[l] = c_lam[l];
+        for (int l = tid; l < D.n_lm * D.ldim; l += nt) x_lam[l] = c_lam[l];
     }
     for (int e = tid; e < D.nfp * D.nfp; e += nt) D.H[e] = 0;
     for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
+}
+
+// ================================================================================== 3-D point landmarks (ldim = 3)
+// Optimizer::localBA / looseBA / fullBA with buse_inv_depth: 0 (src/optimizer.cpp:207-209, :333-384): every observation is
+// a {pose, X} residual block, no anchors.  Same trust-region loop, same reduced system, same Cholesky; what changes is
+// the e-block: 3x3 instead of a scalar.  Per iteration
+//   k_ba_linearize_xyz : wavefront per point, lane per residual block: E^T E (6), E^T b (3), three rows of W = E^T F,
+//                        observer blocks of H / F^T b pre-aggregated in LDS
+//   k_ba_iter_begin    : (shared) bookkeeping + clamped LM diagonal
+//   k_ba_xyz_prep      : per point M = S E^T E S + D^2, M^-1 (Cholesky), C = S M^-1 S = L_c L_c^T, Wp rows = L_c^T W,
+//                        ep = L_c^T E^T b  ->  W^T C W = Wp^T Wp and W^T C E^T b = Wp^T ep: k_ba_schur_gemm runs unchanged
+//   k_ba_backsub_xyz   : y_l = M^-1 S (E^T b - W_l (s . y_f)) and the landmark part of the model cost change
+//   k_ba_cost_xyz      : robustified cost at the candidate + the N4 outputs
+// dynamic LDS of the lineariser: 4 * 3 * nfp (W rows per wavefront) + n_opt * 27 doubles
+__global__ __launch_bounds__(256) void k_ba_linearize_xyz(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->need_lin) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int n_opt = D.nf / 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *wrow = (double *)smem_raw + wave * 3 * D.nfp;
+    double *Hoo = (double *)smem_raw + 4 * 3 * D.nfp;
+    double *bo = Hoo + n_opt * 21;
+    for (int e = threadIdx.x; e < n_opt * 27; e += blockDim.x) Hoo[e] = 0;
+    __syncthreads();
+    const int total_waves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int chunk = (D.n_lm + total_waves - 1) / total_waves;
+    const int i0 = gw * chunk, i1 = min(D.n_lm, i0 + chunk);
+    double cost = 0;
+    for (int pt = i0; pt < i1; pt++) {
+        const int beg = D.lm_ptr[pt], end = D.lm_ptr[pt + 1];
+        const double X[3] = {D.x_lam[3 * pt], D.x_lam[3 * pt + 1], D.x_lam[3 * pt + 2]};
+        for (int c = lane; c < 3 * D.nfp; c += 64) wrow[c] = 0;
+        wave_lds_sync();
+        double ee[6] = {0, 0, 0, 0, 0, 0}, eb[3] = {0, 0, 0};
+        for (int base = beg; base < end; base += 64) {
+            const int k = base + lane;
+            if (k < end) {
+                const int type = D.res_type[k], o = D.res_kf[k], co = D.pose_col[o];
+                const double uv[2] = {D.res_uv[2 * k], D.res_uv[2 * k + 1]};
+                double r[2], Jp[12], Jx[6];
+                const int dp = d_residual_xyz<true>(D, type, D.x_RT + 12 * o, X, uv, D.res_sigma[k], r, Jp, Jx);
+                const double s = r[0] * r[0] + r[1] * r[1];
+                const int orig = D.res_orig[k];
+                D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
+                double rho0, rho1;
+                d_huber(D.huber, s, rho0, rho1);
+                cost += 0.5 * rho0;
+                const double sc = sqrt(rho1);                 // corrector.cc: rho'' <= 0 -> scale by sqrt(rho')
+                r[0] *= sc; r[1] *= sc;
+                for (int q = 0; q < 12; q++) Jp[q] *= sc;
+                for (int q = 0; q < 6; q++) Jx[q] *= sc;
+                ee[0] += Jx[0] * Jx[0] + Jx[3] * Jx[3]; ee[1] += Jx[0] * Jx[1] + Jx[3] * Jx[4]; ee[2] += Jx[0] * Jx[2] + Jx[3] * Jx[5];
+                ee[3] += Jx[1] * Jx[1] + Jx[4] * Jx[4]; ee[4] += Jx[1] * Jx[2] + Jx[4] * Jx[5]; ee[5] += Jx[2] * Jx[2] + Jx[5] * Jx[5];
+                for (int a = 0; a < 3; a++) eb[a] += Jx[a] * r[0] + Jx[3 + a] * r[1];
+                if (co >= 0) {
+                    const int ob = co / 6;
+                    int t = 0;
+                    for (int c = 0; c < 6; c++) {
+                        for (int a = 0; a < 3; a++) atomicAdd(&wrow[a * D.nfp + co + c], Jx[a] * Jp[c] + Jx[3 + a] * Jp[6 + c]);
+                        atomicAdd(&bo[ob * 6 + c], Jp[c] * r[0] + Jp[6 + c] * r[1]);
+                        for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jp[c] * Jp[d] + Jp[6 + c] * Jp[6 + d]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) ee[q] = wave_sum(ee[q]);
+#pragma unroll
+        for (int a = 0; a < 3; a++) eb[a] = wave_sum(eb[a]);
+        if (lane < 6) D.ete6[6 * pt + lane] = ee[lane];
+        if (lane < 3) D.etb[3 * pt + lane] = eb[lane];
+        wave_lds_sync();
+        double *Wg = D.W + (long long)3 * pt * D.nfp;
+        for (int c = lane; c < 3 * D.nfp; c += 64) Wg[c] = wrow[c];
+        wave_lds_sync();
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_opt * 21; e += blockDim.x) {
+        const double v = Hoo[e];
+        if (v != 0.0) {
+            const int ob = e / 21;
+            int t = e - ob * 21, c = 0, d = 0;
+            for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
+            atomicAdd(&D.H[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
+        }
+    }
+    for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
+    __shared__ double s_part[4];
+    cost = block_sum(cost, s_part);
+    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+}
+
+// lower Cholesky factor of the symmetric 3x3 (a0 a1 a2; . a3 a4; . . a5); returns false if not positive definite
+__device__ __forceinline__ bool d_chol3(const double a[6], double L[6])      // L: (l00, l10, l11, l20, l21, l22)
+{
+    if (!(a[0] > 0.0)) return false;
+    L[0] = sqrt(a[0]);
+    L[1] = a[1] / L[0];
+    const double d1 = a[3] - L[1] * L[1];
+    if (!(d1 > 0.0)) return false;
+    L[2] = sqrt(d1);
+    L[3] = a[2] / L[0];
+    L[4] = (a[4] - L[3] * L[1]) / L[2];
+    const double d2 = a[5] - L[3] * L[3] - L[4] * L[4];
+    if (!(d2 > 0.0)) return false;
+    L[5] = sqrt(d2);
+    return true;
+}
+
+// one wavefront per point (see the block comment above)
+__global__ __launch_bounds__(256) void k_ba_xyz_prep(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    const int lane = threadIdx.x & 63;
+    const double radius = ctl->radius;
+    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < D.n_lm; pt += gridDim.x * 4) {
+        double *wp = D.Wp + (long long)3 * pt * D.nfp;
+        if (D.lm_ptr[pt] == D.lm_ptr[pt + 1]) {                       // a point without residual blocks is not part of the program
+            for (int c = lane; c < 3 * D.nfp; c += 64) wp[c] = 0;
+            if (lane < 3) D.ep[3 * pt + lane] = 0;
+            if (lane < 6) D.minv6[6 * pt + lane] = 0;
+            continue;
+        }
+        const double s0 = D.scale_l[3 * pt], s1 = D.scale_l[3 * pt + 1], s2 = D.scale_l[3 * pt + 2];
+        const double *e = D.ete6 + 6 * pt;
+        const double M[6] = {s0 * s0 * e[0] + D.diag_l[3 * pt] / radius, s0 * s1 * e[1], s0 * s2 * e[2],
+                             s1 * s1 * e[3] + D.diag_l[3 * pt + 1] / radius, s1 * s2 * e[4], s2 * s2 * e[5] + D.diag_l[3 * pt + 2] / radius};
+        double L[6];
+        bool ok = d_chol3(M, L);
+        // M^-1 = L^-T L^-1 ; Li = L^-1 (lower)
+        double mi[6] = {0, 0, 0, 0, 0, 0}, Lc[6] = {0, 0, 0, 0, 0, 0};
+        if (ok) {
+            const double i00 = 1.0 / L[0], i11 = 1.0 / L[2], i22 = 1.0 / L[5];
+            const double i10 = -L[1] * i00 * i11, i21 = -L[4] * i11 * i22, i20 = -(L[3] * i00 + L[4] * i10) * i22;
+            mi[0] = i00 * i00 + i10 * i10 + i20 * i20; mi[1] = i10 * i11 + i20 * i21; mi[2] = i20 * i22;
+            mi[3] = i11 * i11 + i21 * i21; mi[4] = i21 * i22; mi[5] = i22 * i22;
+            const double C[6] = {s0 * s0 * mi[0], s0 * s1 * mi[1], s0 * s2 * mi[2], s1 * s1 * mi[3], s1 * s2 * mi[4], s2 * s2 * mi[5]};
+            ok = d_chol3(C, Lc);
+        }
+        if (!ok) { if (lane == 0) ctl->lin_fail = 1; for (int q = 0; q < 6; q++) { mi[q] = 0; Lc[q] = 0; } }
+        if (lane < 6) D.minv6[6 * pt + lane] = mi[lane];
+        // ep = L_c^T E^T b ; Wp rows r = sum_a L_c[a][r] W[a]
+        const double b0 = D.etb[3 * pt], b1 = D.etb[3 * pt + 1], b2 = D.etb[3 * pt + 2];
+        if (lane == 0) { D.ep[3 * pt] = Lc[0] * b0 + Lc[1] * b1 + Lc[3] * b2; D.ep[3 * pt + 1] = Lc[2] * b1 + Lc[4] * b2; D.ep[3 * pt + 2] = Lc[5] * b2; }
+        const double *w = D.W + (long long)3 * pt * D.nfp;
+        for (int c = lane; c < D.nfp; c += 64) {
+            const double w0 = w[c], w1 = w[D.nfp + c], w2 = w[2 * D.nfp + c];
+            wp[c] = Lc[0] * w0 + Lc[1] * w1 + Lc[3] * w2;
+            wp[D.nfp + c] = Lc[2] * w1 + Lc[4] * w2;
+            wp[2 * D.nfp + c] = Lc[5] * w2;
+        }
+    }
+}
+
+// one wavefront per point: t = W_l (s . y_f) (3 dot products), y_l = M^-1 S (E^T b - t)
+__global__ __launch_bounds__(256) void k_ba_backsub_xyz(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || ctl->lin_fail) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *sy = (double *)smem_raw;                        // s_j * yf_j
+    for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    double a1 = 0, a2 = 0, a3 = 0;
+    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < D.n_lm; pt += gridDim.x * 4) {
+        if (D.lm_ptr[pt] == D.lm_ptr[pt + 1]) { if (lane < 3) D.yl[3 * pt + lane] = 0; continue; }
+        const double *w = D.W + (long long)3 * pt * D.nfp;
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int c = lane; c < D.nfp; c += 64) { const double v = sy[c]; t0 += w[c] * v; t1 += w[D.nfp + c] * v; t2 += w[2 * D.nfp + c] * v; }
+        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+        if (lane == 0) {
+            const double s[3] = {D.scale_l[3 * pt], D.scale_l[3 * pt + 1], D.scale_l[3 * pt + 2]};
+            const double b[3] = {D.etb[3 * pt], D.etb[3 * pt + 1], D.etb[3 * pt + 2]}, t[3] = {t0, t1, t2};
+            const double *mi = D.minv6 + 6 * pt, *e = D.ete6 + 6 * pt;
+            const double u[3] = {s[0] * (b[0] - t[0]), s[1] * (b[1] - t[1]), s[2] * (b[2] - t[2])};
+            const double y[3] = {mi[0] * u[0] + mi[1] * u[1] + mi[2] * u[2], mi[1] * u[0] + mi[3] * u[1] + mi[4] * u[2],
+                                 mi[2] * u[0] + mi[4] * u[1] + mi[5] * u[2]};
+            D.yl[3 * pt] = y[0]; D.yl[3 * pt + 1] = y[1]; D.yl[3 * pt + 2] = y[2];
+            const double z[3] = {s[0] * y[0], s[1] * y[1], s[2] * y[2]};                  // S y
+            a1 += z[0] * b[0] + z[1] * b[1] + z[2] * b[2];
+            a2 += 2.0 * (z[0] * t[0] + z[1] * t[1] + z[2] * t[2])
+                + z[0] * (e[0] * z[0] + e[1] * z[1] + e[2] * z[2]) + z[1] * (e[1] * z[0] + e[3] * z[1] + e[4] * z[2]) + z[2] * (e[2] * z[0] + e[4] * z[1] + e[5] * z[2]);
+            const double q[3] = {s[0] * t[0], s[1] * t[1], s[2] * t[2]};                  // t^T C t, C = S M^-1 S
+            a3 += q[0] * (mi[0] * q[0] + mi[1] * q[1] + mi[2] * q[2]) + q[1] * (mi[1] * q[0] + mi[3] * q[1] + mi[4] * q[2]) + q[2] * (mi[2] * q[0] + mi[4] * q[1] + mi[5] * q[2]);
+        }
+    }
+    __shared__ double s_part[4];
+    a1 = block_sum(a1, s_part); a2 = block_sum(a2, s_part); a3 = block_sum(a3, s_part);
+    if (threadIdx.x == 0) {
+        if (a1 != 0.0) atomicAdd(&ctl->acc1, a1);
+        if (a2 != 0.0) atomicAdd(&ctl->acc2, a2);
+        if (a3 != 0.0) atomicAdd(&ctl->acc3, a3);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ba_cost_xyz(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->step_valid) return;
+    const int lane = threadIdx.x & 63;
+    double cost = 0;
+    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < D.n_lm; pt += gridDim.x * 4) {
+        const int beg = D.lm_ptr[pt], end = D.lm_ptr[pt + 1];
+        const double X[3] = {D.c_lam[3 * pt], D.c_lam[3 * pt + 1], D.c_lam[3 * pt + 2]};
+        for (int k = beg + lane; k < end; k += 64) {
+            const double uv[2] = {D.res_uv[2 * k], D.res_uv[2 * k + 1]};
+            double r[2];
+            const int dp = d_residual_xyz<false>(D, D.res_type[k], D.c_RT + 12 * D.res_kf[k], X, uv, D.res_sigma[k], r, nullptr, nullptr);
+            const double s = r[0] * r[0] + r[1] * r[1];
+            const int orig = D.res_orig[k];
+            D.chi2[orig] = s; D.dpos[orig] = (uint8_t)dp;
+            double rho0, rho1;
+            d_huber(D.huber, s, rho0, rho1);
+            cost += 0.5 * rho0;
+        }
+    }
+    __shared__ double s_part[4];
+    cost = block_sum(cost, s_part);
+    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
 }
 
 // marks that k_ba_linearize has produced a linearisation (1 thread; keeps the flag flip race-free)
@@ -1308,7 +1598,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     dev->h_lam0.assign(p->invdepth, p->invdepth + (p->n_lm > 0 ? p->n_lm : 0));
     BADev &D = dev->D;
     memset(&D, 0, sizeof(D));
-    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po;
+    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
     const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
@@ -1374,6 +1664,102 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     return OV2_OK;
 }
 
+// 3-D point landmarks with variable poses (ldim = 3): same device object, point-sorted residual blocks
+static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **out)
+{
+    OV2_REQUIRE(p && out, OV2_EINVAL, "NULL problem");
+    OV2_REQUIRE(p->n_kf > 0 && p->n_pts >= 0 && p->n_res >= 0, OV2_EINVAL, "bad problem sizes");
+    OV2_REQUIRE(p->poses, OV2_EINVAL, "NULL pose array");
+    OV2_REQUIRE(p->n_pts == 0 || p->xyz, OV2_EINVAL, "NULL point array");
+    OV2_REQUIRE(p->n_res == 0 || (p->res_type && p->res_kf && p->res_pt && p->res_uv && p->res_sigma), OV2_EINVAL, "NULL residual arrays");
+    std::vector<int> cnt(p->n_pts + 1, 0);
+    int n_act = 0;
+    for (int i = 0; i < p->n_res; i++) {
+        if (p->res_active && !p->res_active[i]) continue;
+        OV2_REQUIRE(p->res_type[i] <= OV2_XYZ_RIGHT, OV2_EINVAL, "unknown residual type");
+        OV2_REQUIRE(p->res_sigma[i] > 0, OV2_EINVAL, "res_sigma must be positive");
+        OV2_REQUIRE(p->res_pt[i] >= 0 && p->res_pt[i] < p->n_pts, OV2_EINVAL, "res_pt out of range");
+        OV2_REQUIRE(p->res_kf[i] >= 0 && p->res_kf[i] < p->n_kf, OV2_EINVAL, "res_kf out of range");
+        cnt[p->res_pt[i] + 1]++; n_act++;
+    }
+    for (int l = 0; l < p->n_pts; l++) cnt[l + 1] += cnt[l];
+    std::vector<int> pose_col(p->n_kf);
+    int n_opt = 0;
+    for (int k = 0; k < p->n_kf; k++) pose_col[k] = (p->kf_const && p->kf_const[k]) ? -1 : 6 * n_opt++;
+    const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
+    OV2_REQUIRE(nfp <= 2048, OV2_EUNSUPPORTED, "more than 341 optimised keyframes: dense reduced system too large");
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
+    std::vector<uint8_t> res_type(n_act);
+    std::vector<double> res_uv(2 * (size_t)n_act), res_sigma(n_act);
+    for (int i = 0; i < p->n_res; i++) {
+        if (p->res_active && !p->res_active[i]) continue;
+        const int k = fill[p->res_pt[i]]++;
+        res_type[k] = p->res_type[i]; res_kf[k] = p->res_kf[i]; res_orig[k] = i;
+        res_uv[2 * k] = p->res_uv[2 * i]; res_uv[2 * k + 1] = p->res_uv[2 * i + 1]; res_sigma[k] = p->res_sigma[i];
+    }
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    ov2_ba_dev *dev = new (std::nothrow) ov2_ba_dev();
+    OV2_REQUIRE(dev != nullptr, OV2_ENOMEM, "out of host memory");
+    dev->device = ctx->device; dev->n_res = p->n_res;
+    dev->h_poses0.assign(p->poses, p->poses + 7 * (size_t)p->n_kf);
+    dev->h_lam0.assign(p->xyz, p->xyz + 3 * (size_t)(p->n_pts > 0 ? p->n_pts : 0));
+    BADev &D = dev->D;
+    memset(&D, 0, sizeof(D));
+    D.n_kf = p->n_kf; D.n_lm = p->n_pts; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = 0; D.ldim = 3;
+    const size_t nl = (size_t)std::max(1, p->n_pts), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
+    const size_t o_pose_col = take(4 * (size_t)p->n_kf), o_lm_ptr = take(4 * (nl + 1));
+    const size_t o_res_type = take(na), o_res_kf = take(4 * na), o_res_orig = take(4 * na), o_res_uv = take(16 * na), o_res_sigma = take(8 * na);
+    const size_t o_x_pose = take(56 * (size_t)p->n_kf), o_c_pose = take(56 * (size_t)p->n_kf), o_x_RT = take(96 * (size_t)p->n_kf), o_c_RT = take(96 * (size_t)p->n_kf);
+    const size_t o_x_lam = take(24 * nl), o_c_lam = take(24 * nl), o_scale_f = take(8 * (size_t)nfp), o_diag_f = take(8 * (size_t)nfp);
+    const size_t o_scale_l = take(24 * nl), o_diag_l = take(24 * nl), o_etb = take(24 * nl), o_yl = take(24 * nl), o_ep = take(24 * nl), o_ones = take(24 * nl);
+    const size_t o_ete6 = take(48 * nl), o_minv6 = take(48 * nl);
+    const size_t o_W = take(24 * nl * nfp), o_Wp = take(24 * nl * nfp);
+    const size_t o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
+    const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_Linv = take(8 * (size_t)nfp * 32);
+    const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl));
+    dev->pool_bytes = off;
+    hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
+    if (e != hipSuccess) { delete dev; ov2_set_error("hipMalloc(%zu): %s", off, hipGetErrorString(e)); return OV2_ENOMEM; }
+    uint8_t *b = (uint8_t *)dev->pool;
+    D.pose_col = (int *)(b + o_pose_col); D.lm_ptr = (int *)(b + o_lm_ptr);
+    D.res_type = b + o_res_type; D.res_kf = (int *)(b + o_res_kf); D.res_orig = (int *)(b + o_res_orig); D.res_uv = (double *)(b + o_res_uv); D.res_sigma = (double *)(b + o_res_sigma);
+    D.x_pose = (double *)(b + o_x_pose); D.c_pose = (double *)(b + o_c_pose); D.x_RT = (double *)(b + o_x_RT); D.c_RT = (double *)(b + o_c_RT);
+    D.x_lam = (double *)(b + o_x_lam); D.c_lam = (double *)(b + o_c_lam); D.scale_f = (double *)(b + o_scale_f); D.diag_f = (double *)(b + o_diag_f);
+    D.scale_l = (double *)(b + o_scale_l); D.diag_l = (double *)(b + o_diag_l); D.etb = (double *)(b + o_etb); D.yl = (double *)(b + o_yl);
+    D.ep = (double *)(b + o_ep); D.ones = (double *)(b + o_ones); D.ete6 = (double *)(b + o_ete6); D.minv6 = (double *)(b + o_minv6);
+    D.W = (double *)(b + o_W); D.Wp = (double *)(b + o_Wp); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
+    D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.Linv = (double *)(b + o_Linv);
+    D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
+    D.cl = D.ones; D.ce = D.ep; D.ete = D.ete6;              // (scalar-landmark views, unused when ldim == 3)
+    for (int i = 0; i < 4; i++) { D.calib_l[i] = p->calib_l[i]; D.calib_r[i] = p->calib_r[i]; }
+    {
+        double q[4] = {p->T_rl[3], p->T_rl[4], p->T_rl[5], p->T_rl[6]};
+        const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n > 0) { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; } else { q[0] = q[1] = q[2] = 0; q[3] = 1; }
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        D.Rrl[0] = 1 - 2 * (y * y + z * z); D.Rrl[1] = 2 * (x * y - z * w); D.Rrl[2] = 2 * (x * z + y * w);
+        D.Rrl[3] = 2 * (x * y + z * w); D.Rrl[4] = 1 - 2 * (x * x + z * z); D.Rrl[5] = 2 * (y * z - x * w);
+        D.Rrl[6] = 2 * (x * z - y * w); D.Rrl[7] = 2 * (y * z + x * w); D.Rrl[8] = 1 - 2 * (x * x + y * y);
+        D.trl[0] = p->T_rl[0]; D.trl[1] = p->T_rl[1]; D.trl[2] = p->T_rl[2];
+    }
+    hipStream_t s = ctx->stream;
+#define UPX(dst, src, bytes) do { if ((bytes) > 0) { hipError_t _e = hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, s); \
+        if (_e != hipSuccess) { (void)hipFree(dev->pool); delete dev; ov2_set_error("H2D: %s", hipGetErrorString(_e)); return OV2_EHIP; } } } while (0)
+    UPX(D.pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
+    UPX(D.lm_ptr, cnt.data(), 4 * ((size_t)p->n_pts + 1));
+    UPX(D.res_type, res_type.data(), (size_t)n_act);
+    UPX(D.res_kf, res_kf.data(), 4 * (size_t)n_act);
+    UPX(D.res_orig, res_orig.data(), 4 * (size_t)n_act);
+    UPX(D.res_uv, res_uv.data(), 16 * (size_t)n_act);
+    UPX(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
+#undef UPX
+    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    *out = dev;
+    return OV2_OK;
+}
+
 static void ba_destroy(ov2_ba_dev *dev)
 {
     if (!dev) return;
@@ -1399,7 +1785,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
 
     // size limits first: nothing is created or enqueued for a problem this path cannot solve
     const int n_opt = D.nf / 6;
-    const size_t lin_lds = 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+    const size_t lin_lds = D.ldim == 3 ? 8 * (12 * (size_t)D.nfp + (size_t)n_opt * 27) + 64
+                                       : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
     OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95)");
     OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~95 optimised keyframes)");
@@ -1421,6 +1808,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
                 return e;
             };
             attr_err = raise((const void *)k_ba_linearize);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize_xyz);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky);
         });
         OV2_HIP_CHECK(attr_err);
@@ -1436,7 +1824,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     hipEvent_t e0 = ev.e0, e1 = ev.e1;
     // state reset: x = initial parameters, everything else zero, scales one
     OV2_HIP_CHECK(hipMemcpyAsync(D.x_pose, dev->h_poses0.data(), 56 * (size_t)D.n_kf, hipMemcpyHostToDevice, s));
-    if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.x_lam, dev->h_lam0.data(), 8 * (size_t)D.n_lm, hipMemcpyHostToDevice, s));
+    const size_t NL = (size_t)D.n_lm * D.ldim;               // per-landmark state entries (1 inverse depth or 3 coordinates each)
+    if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.x_lam, dev->h_lam0.data(), 8 * NL, hipMemcpyHostToDevice, s));
     if (chi2_init) OV2_HIP_CHECK(hipMemcpyAsync(D.chi2, chi2_init, 8 * (size_t)dev->n_res, hipMemcpyHostToDevice, s));
     else OV2_HIP_CHECK(hipMemsetAsync(D.chi2, 0xFF, 8 * (size_t)std::max(1, dev->n_res), s));     // NaN pattern
     if (dpos_init) OV2_HIP_CHECK(hipMemcpyAsync(D.dpos, dpos_init, (size_t)dev->n_res, hipMemcpyHostToDevice, s));
@@ -1452,23 +1841,28 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     OV2_HIP_CHECK(hipMemsetAsync(D.bf, 0, 8 * (size_t)D.nfp, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.yf, 0, 8 * (size_t)D.nfp, s));
     {   // scales = 1 (jacobi off) : fill through a tiny staging vector
-        std::vector<double> ones((size_t)std::max(D.nfp, std::max(1, D.n_lm)), 1.0);
+        std::vector<double> ones(std::max((size_t)D.nfp, std::max((size_t)1, NL)), 1.0);
         OV2_HIP_CHECK(hipMemcpyAsync(D.scale_f, ones.data(), 8 * (size_t)D.nfp, hipMemcpyHostToDevice, s));
-        if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.scale_l, ones.data(), 8 * (size_t)D.n_lm, hipMemcpyHostToDevice, s));
+        if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.scale_l, ones.data(), 8 * NL, hipMemcpyHostToDevice, s));
+        if (D.ldim == 3 && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.ones, ones.data(), 8 * NL, hipMemcpyHostToDevice, s));
         OV2_HIP_CHECK(hipStreamSynchronize(s));
     }
     hipLaunchKernelGGL(k_ba_init, dim3((D.n_kf + 255) / 256), dim3(256), 0, s, D);
 
     const int lin_blocks = std::max(1, std::min(256, (D.n_lm + 15) / 16));   // (512: two workgroups per CU -- measured 15 % slower)
     const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
+    // rows of the W^T C W contraction: landmarks, or the 3 pseudo-rows per point of Wp (ldim 3)
+    BADev DG = D;
+    if (D.ldim == 3) { DG.W = D.Wp; DG.n_lm = 3 * D.n_lm; DG.cl = D.ones; DG.etb = D.ep; }
     int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
-    int lm_per_split = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
-    ksplit = std::max(1, (D.n_lm + lm_per_split - 1) / lm_per_split);
+    int lm_per_split = std::max(BA_TILE, ((DG.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
+    ksplit = std::max(1, (DG.n_lm + lm_per_split - 1) / lm_per_split);
     const int ws_blocks = std::max(1, std::min(512, std::max((D.n_lm + 3) / 4, (D.n_po + 255) / 256)));
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
 
     auto linearize = [&]() {
-        if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks), dim3(256), lin_lds, s, D);
+        else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (size_t)n_opt * 27 * 8 + 16, s, D);
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
@@ -1495,12 +1889,15 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         }
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
-        if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, D, ntiles, lm_per_split);
+        if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
+        if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
         if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
-        hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
+        if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
+        else hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
-        hipLaunchKernelGGL(k_ba_cost, dim3(ws_blocks), dim3(256), 0, s, D);
+        if (D.ldim == 3) hipLaunchKernelGGL(k_ba_cost_xyz, dim3(ws_blocks), dim3(256), 0, s, D);
+        else hipLaunchKernelGGL(k_ba_cost, dim3(ws_blocks), dim3(256), 0, s, D);
         hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D, O);
         linearize();
     }
@@ -1510,7 +1907,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     // results
     OV2_HIP_CHECK(hipMemcpyAsync(&h_ctl, D.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
     if (r->poses_out) OV2_HIP_CHECK(hipMemcpyAsync(r->poses_out, D.x_pose, 56 * (size_t)D.n_kf, hipMemcpyDeviceToHost, s));
-    if (r->invdepth_out && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->invdepth_out, D.x_lam, 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost, s));
+    if (r->invdepth_out && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->invdepth_out, D.x_lam, 8 * NL, hipMemcpyDeviceToHost, s));
     if (r->chi2_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->chi2_last_eval, D.chi2, 8 * (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
     if (r->depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
     OV2_HIP_CHECK(hipStreamSynchronize(s));
@@ -1563,5 +1960,21 @@ int ov2_ba_solve_resident(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o
 }
 
 void ov2_ba_destroy(ov2_ba_dev *dev) { ba_destroy(dev); }
+
+int ov2_xyz_ba_solve(ov2_ctx *ctx, const ov2_xyzba_problem *p, const ov2_ba_options *o, ov2_xyzba_result *r)
+{
+    OV2_REQUIRE(ctx && p && o && r, OV2_EINVAL, "NULL argument");
+    ov2_ba_dev *dev = nullptr;
+    int rc = xyzba_create(ctx, p, &dev);
+    if (rc != OV2_OK) return rc;
+    ov2_ba_result br;
+    memset(&br, 0, sizeof(br));
+    br.poses_out = r->poses_out; br.invdepth_out = r->xyz_out; br.chi2_last_eval = r->chi2_last_eval; br.depthpos_last_eval = r->depthpos_last_eval;
+    rc = ba_run(ctx, dev, o, &br, p->res_active ? r->chi2_last_eval : nullptr, p->res_active ? r->depthpos_last_eval : nullptr);
+    ba_destroy(dev);
+    r->iterations = br.iterations; r->num_successful_steps = br.num_successful_steps; r->initial_cost = br.initial_cost;
+    r->final_cost = br.final_cost; r->termination = br.termination; r->solve_ms = br.solve_ms;
+    return rc;
+}
 
 } // extern "C"

@@ -79,6 +79,44 @@ def solve(ctx, prob, opts=None, res_active=None, chi2_init=None, depthpos_init=N
                 termination=R.termination, solve_ms=R.solve_ms)
 
 
+def is_xyz_problem(prob):
+    """3-D point landmarks with variable poses (ov2slam_amd.synth.make_xyz_ba_problem layout: `xyz` + `res_pt` + `kf_const`)"""
+    return "res_pt" in prob and "kf_const" in prob
+
+
+def solve_xyz(ctx, prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None):
+    """One ceres::Solve of the buse_inv_depth: 0 branch (ov2_xyz_ba_solve).  Returns a dict like oracle.xyz_ba_solve."""
+    lib = ctx.lib
+    opts = opts or default_options(lib)
+    keep = []
+
+    def arr(name, dt, ct):
+        a = np.ascontiguousarray(prob[name], dt); keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+
+    P = L.XYZBAProblem()
+    P.n_kf, P.n_pts, P.n_res = int(prob["n_kf"]), int(prob["n_pts"]), int(prob["n_res"])
+    P.poses = arr("poses", np.float64, C.c_double); P.xyz = arr("xyz", np.float64, C.c_double); P.kf_const = arr("kf_const", np.uint8, C.c_uint8)
+    P.res_type = arr("res_type", np.uint8, C.c_uint8); P.res_kf = arr("res_kf", np.int32, C.c_int); P.res_pt = arr("res_pt", np.int32, C.c_int)
+    P.res_uv = arr("res_uv", np.float64, C.c_double); P.res_sigma = arr("res_sigma", np.float64, C.c_double)
+    if res_active is not None:
+        ra = np.ascontiguousarray(res_active, np.uint8); keep.append(ra)
+        P.res_active = _u8p(ra)
+    for i in range(4):
+        P.calib_l[i] = float(prob["calib_l"][i]); P.calib_r[i] = float(prob["calib_r"][i])
+    for i in range(7):
+        P.T_rl[i] = float(prob["T_rl"][i])
+    poses = np.zeros((P.n_kf, 7)); xyz = np.zeros((max(1, P.n_pts), 3))
+    chi2 = np.full(max(1, P.n_res), np.nan) if chi2_init is None else np.array(chi2_init, np.float64, copy=True)
+    dpos = np.zeros(max(1, P.n_res), np.uint8) if depthpos_init is None else np.array(depthpos_init, np.uint8, copy=True)
+    R = L.XYZBAResult()
+    R.poses_out = _dp(poses); R.xyz_out = _dp(xyz); R.chi2_last_eval = _dp(chi2); R.depthpos_last_eval = _u8p(dpos)
+    L.check(lib.ov2_xyz_ba_solve(ctx.h, C.byref(P), C.byref(opts), C.byref(R)))
+    return dict(poses=poses, xyz=xyz[:P.n_pts], chi2=chi2[:P.n_res], depthpos=dpos[:P.n_res], iterations=R.iterations,
+                num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost, final_cost=R.final_cost,
+                termination=R.termination, solve_ms=R.solve_ms)
+
+
 def structure_only_ba(ctx, prob, opts=None, res_active=None):
     """One ceres::Solve of Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781) through ov2_structure_ba.
     prob: dict in the layout of ov2slam_amd.synth.make_structure_problem.  Default options = the reference's
@@ -177,9 +215,14 @@ class Optimizer:
         if self._solver is not None:
             return self._solver(prob, res_active, chi2_init, depthpos_init, **opt_kw)
         opts = default_options(self.ctx.lib, **opt_kw)
+        if is_xyz_problem(prob):                              # buse_inv_depth: 0 (optimizer.cpp:207-209, :333-384)
+            return solve_xyz(self.ctx, prob, opts, res_active, chi2_init, depthpos_init)
         return solve(self.ctx, prob, opts, res_active, chi2_init, depthpos_init)
 
     def localBA(self, prob, buse_robust_cost=True):
+        """Inverse-depth problems (make_ba_problem layout) or, with buse_inv_depth: 0, 3-D point problems
+        (make_xyz_ba_problem layout): the protocol is the same, the landmark state is `invdepth` resp. `xyz`."""
+        lmk = "xyz" if is_xyz_problem(prob) else "invdepth"
         th = self.robust_mono_th
         huber = math.sqrt(th) if buse_robust_cost else -1.0
         n_res = int(prob["n_res"])
@@ -188,7 +231,7 @@ class Optimizer:
         rtype = np.asarray(prob["res_type"])
         nbbadobs = int(bad.sum())
         out = dict(pass1=p1, bad_after_pass1=bad.copy(), l2_done=False)
-        poses, lam, chi2, dpos = p1["poses"], p1["invdepth"], p1["chi2"], p1["depthpos"]
+        poses, lam, chi2, dpos = p1["poses"], p1[lmk], p1["chi2"], p1["depthpos"]
         active = np.ones(n_res, np.uint8)
         if self.apply_l2_after_robust:
             active[bad] = 0
@@ -197,14 +240,15 @@ class Optimizer:
             right_remaining = bool(((rtype == RES_RIGHT) & ~bad).any())
             huber2 = -1.0 if (left_remaining and right_remaining) else huber       # :606-608
             prob2 = dict(prob)
-            prob2["poses"] = poses; prob2["invdepth"] = lam
+            prob2["poses"] = poses; prob2[lmk] = lam
             p2 = self._solve(prob2, active, chi2, dpos, max_iter=10, function_tolerance=1e-3, huber_delta=huber2)
             out["pass2"] = p2; out["l2_done"] = True
-            poses, lam, chi2, dpos = p2["poses"], p2["invdepth"], p2["chi2"], p2["depthpos"]
+            poses, lam, chi2, dpos = p2["poses"], p2[lmk], p2["chi2"], p2["depthpos"]
             # second outlier test on the residual blocks that are still in the problem (:637-735)
             bad2 = (active == 1) & ((chi2 > th) | (dpos == 0))
             bad = bad | bad2
-        out.update(poses=poses, invdepth=lam, chi2=chi2, depthpos=dpos, bad_obs=bad)
+        out.update(poses=poses, chi2=chi2, depthpos=dpos, bad_obs=bad)
+        out[lmk] = lam
         return out
 
 
