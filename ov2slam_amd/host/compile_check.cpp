@@ -3,4 +3,5 @@
 #include "feature_extractor.hpp"
 #include "optimizer.hpp"
 #include "camera_calibration.hpp"
+#include "visual_front_end.hpp"
 int main() { return 0; }

@@ -44,6 +44,32 @@ public:
         return out;
     }
 
+    // the same detectors on level 0 of a device-resident pyramid (FrameTracker::curPyr(): the CLAHE'd cur_img_ of the keyframe,
+    // src/map_manager.cpp:312-320) -- no image upload
+    std::vector<Point2f> detectSingleScale(Context &ctx, const ov2_pyr *pyr, const int ncellsize, const std::vector<Point2f> &vcurkps, const Rect &roi)
+    {
+        int w = 0, h = 0;
+        if (!pyr || ov2_pyr_level_size(pyr, 0, &w, &h) != OV2_OK) return std::vector<Point2f>();
+        std::vector<Point2f> out(2 * (size_t)(w / ncellsize) * (h / ncellsize) + 1);
+        int n = 0;
+        const int r[4] = {roi.x, roi.y, roi.width, roi.height};
+        const int rc = ov2_detect_singlescale_d(ctx.get(), pyr, 0, ncellsize, vcurkps.empty() ? nullptr : &vcurkps[0].x, (int)vcurkps.size(),
+                                                r, &dmaxquality_, 1, &out[0].x, &n);
+        out.resize(rc == OV2_OK ? (size_t)n : 0);
+        return out;
+    }
+    std::vector<Point2f> detectGridFAST(Context &ctx, const ov2_pyr *pyr, const int ncellsize, const std::vector<Point2f> &vcurkps, const Rect &)
+    {
+        int w = 0, h = 0;
+        if (!pyr || ov2_pyr_level_size(pyr, 0, &w, &h) != OV2_OK) return std::vector<Point2f>();
+        std::vector<Point2f> out((size_t)(w / ncellsize) * (h / ncellsize) + 1);
+        int n = 0;
+        const int rc = ov2_detect_grid_fast_d(ctx.get(), pyr, 0, ncellsize, vcurkps.empty() ? nullptr : &vcurkps[0].x, (int)vcurkps.size(),
+                                              &nfast_th_, mask_mode_, 1, &out[0].x, &n);
+        out.resize(rc == OV2_OK ? (size_t)n : 0);
+        return out;
+    }
+
     size_t nmaxpts_, nmaxdist_;
     double dmaxquality_;       // feature_extractor.hpp:50
     int nfast_th_;             // feature_extractor.hpp:52

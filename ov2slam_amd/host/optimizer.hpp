@@ -63,8 +63,29 @@ struct FlatStructureProblem {
     }
 };
 
+// Flat form of the buse_inv_depth: 0 problem (src/optimizer.cpp:207-209 PointXYZParametersBlock, :333-384 XYZ residual blocks
+// with variable poses): FlatStructureProblem + SetParameterBlockConstant flags.
+struct FlatXYZProblem : FlatStructureProblem {
+    std::vector<uint8_t> kf_const;
+    int addKeyframe(const double pose[7], bool constant) { kf_const.push_back(constant); return FlatStructureProblem::addKeyframe(pose); }
+    ov2_xyzba_problem view(const uint8_t *res_active) const {
+        ov2_xyzba_problem p{};
+        p.n_kf = (int)poses.size() / 7; p.poses = poses.data(); p.kf_const = kf_const.data();
+        p.n_pts = (int)xyz.size() / 3; p.xyz = xyz.data();
+        p.n_res = (int)res_type.size(); p.res_type = res_type.data(); p.res_kf = res_kf.data(); p.res_pt = res_pt.data();
+        p.res_uv = res_uv.data(); p.res_sigma = res_sigma.data(); p.res_active = res_active;
+        for (int i = 0; i < 4; i++) { p.calib_l[i] = calib_l[i]; p.calib_r[i] = calib_r[i]; }
+        for (int i = 0; i < 7; i++) p.T_rl[i] = T_rl[i];
+        return p;
+    }
+};
+
 struct LocalBAResult {
     bool ok = false, l2_done = false;
+    // why a solve was skipped (ok == false): the library's return code and message, e.g. OV2_EUNSUPPORTED "reduced system too
+    // large ..." when more than ~95 keyframes are optimised (fullBA after a long loop) -- log it, do not drop it
+    int error_code = OV2_OK;
+    std::string error;
     std::vector<double> poses, invdepth, chi2;
     std::vector<uint8_t> depthpos, bad_obs;     // bad_obs[i] = 1: observation i is an outlier (:500-592, :637-735)
     int iterations[2] = {0, 0};
@@ -89,7 +110,7 @@ public:
         ov2_ba_result res{};
         res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
         ov2_ba_problem p = fp.view(nullptr);
-        if (ov2_ba_solve(ctx.get(), &p, &opt, &res) != OV2_OK) return R;        // BA skipped
+        if ((R.error_code = ov2_ba_solve(ctx.get(), &p, &opt, &res)) != OV2_OK) { R.error = ov2_last_error(); return R; }        // BA skipped: caller logs R.error
         R.ok = true; R.iterations[0] = res.iterations; R.solve_ms[0] = res.solve_ms;
         std::vector<uint8_t> active(n_res, 1);
         size_t nbbad = 0; bool left_rem = false, right_rem = false;
@@ -106,6 +127,45 @@ public:
             fp.poses = R.poses; fp.invdepth = R.invdepth;                        // warm start from pass 1
             p = fp.view(active.data());
             if (ov2_ba_solve(ctx.get(), &p, &opt, &res) == OV2_OK) {
+                R.l2_done = true; R.iterations[1] = res.iterations; R.solve_ms[1] = res.solve_ms;
+                for (size_t i = 0; i < n_res; i++)
+                    if (active[i] && (R.chi2[i] > robust_mono_th_ || !R.depthpos[i])) R.bad_obs[i] = 1;
+            }
+        }
+        return R;
+    }
+
+    // Optimizer::localBA with buse_inv_depth: 0 (src/optimizer.cpp:207-209, :333-384): the same two-pass protocol on 3-D point
+    // landmarks; R.invdepth holds the optimised points (3 per landmark).
+    LocalBAResult solveLocalBAXYZ(Context &ctx, FlatXYZProblem &fp, bool buse_robust_cost) const
+    {
+        LocalBAResult R;
+        const size_t n_res = fp.res_type.size();
+        R.poses.resize(fp.poses.size()); R.invdepth.resize(fp.xyz.size());
+        R.chi2.assign(n_res, 0.0); R.depthpos.assign(n_res, 1); R.bad_obs.assign(n_res, 0);
+        ov2_ba_options opt; ov2_ba_default_options(&opt);
+        opt.max_iter = 5; opt.function_tolerance = 1e-3;
+        opt.huber_delta = buse_robust_cost ? std::sqrt(robust_mono_th_) : -1.0;
+        ov2_xyzba_result res{};
+        res.poses_out = R.poses.data(); res.xyz_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
+        ov2_xyzba_problem p = fp.view(nullptr);
+        if ((R.error_code = ov2_xyz_ba_solve(ctx.get(), &p, &opt, &res)) != OV2_OK) { R.error = ov2_last_error(); return R; }
+        R.ok = true; R.iterations[0] = res.iterations; R.solve_ms[0] = res.solve_ms;
+        std::vector<uint8_t> active(n_res, 1);
+        size_t nbbad = 0; bool left_rem = false, right_rem = false;
+        for (size_t i = 0; i < n_res; i++) {
+            const bool bad = R.chi2[i] > robust_mono_th_ || !R.depthpos[i];
+            R.bad_obs[i] = bad; nbbad += bad;
+            if (bad && apply_l2_after_robust_) active[i] = 0;
+            if (!bad && fp.res_type[i] == OV2_XYZ_LEFT) left_rem = true;
+            if (!bad && fp.res_type[i] == OV2_XYZ_RIGHT) right_rem = true;
+        }
+        if (apply_l2_after_robust_ && buse_robust_cost && !stopLocalBA() && nbbad > 0) {
+            if (left_rem && right_rem) opt.huber_delta = -1.0;                   // :606-608
+            opt.max_iter = 10;
+            fp.poses = R.poses; fp.xyz = R.invdepth;
+            p = fp.view(active.data());
+            if (ov2_xyz_ba_solve(ctx.get(), &p, &opt, &res) == OV2_OK) {
                 R.l2_done = true; R.iterations[1] = res.iterations; R.solve_ms[1] = res.solve_ms;
                 for (size_t i = 0; i < n_res; i++)
                     if (active[i] && (R.chi2[i] > robust_mono_th_ || !R.depthpos[i])) R.bad_obs[i] = 1;
@@ -184,7 +244,7 @@ private:
         ov2_ba_result res{};
         res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
         ov2_ba_problem p = fp.view(nullptr);
-        if (ov2_ba_solve(ctx.get(), &p, &opt, &res) != OV2_OK) return R;
+        if ((R.error_code = ov2_ba_solve(ctx.get(), &p, &opt, &res)) != OV2_OK) { R.error = ov2_last_error(); return R; }
         R.ok = true; R.iterations[0] = res.iterations; R.solve_ms[0] = res.solve_ms;
         for (size_t i = 0; i < n_res; i++) {
             const bool tested = fp.res_type[i] == OV2_RES_LEFT || fp.res_type[i] == OV2_RES_RIGHT || (test_anchor_right && fp.res_type[i] == OV2_RES_RIGHT_ANCH);

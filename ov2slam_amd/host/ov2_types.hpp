@@ -6,19 +6,43 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/ov2slam_hip.h"
 
+#ifdef OV2_WITH_OPENCV
+// In an OV2SLAM tree (compile with -DOV2_WITH_OPENCV): the adapters below take the reference's own value types, so the
+// method bodies in INTEGRATION.md are these headers verbatim.  tests/test_golden.py syntax-checks this branch against a
+// minimal stand-in for <opencv2/core.hpp> (tests/fake_opencv: the members the adapters touch, nothing else), because the
+// build image has no OpenCV.
+#include <opencv2/core.hpp>
+#endif
+
 namespace ov2 {
 
+#ifdef OV2_WITH_OPENCV
+using Point2f = cv::Point2f;
+using Rect = cv::Rect;
+// non-owning view of a CV_8UC1 cv::Mat
+struct Image8 {
+    const uint8_t *data = nullptr; int cols = 0, rows = 0, step = 0;
+    Image8() = default;
+    Image8(const cv::Mat &m) : data(m.data), cols(m.cols), rows(m.rows), step((int)m.step) {}      // implicit on purpose: cv::Mat call sites stay unchanged
+    Image8(const uint8_t *d, int c, int r, int s) : data(d), cols(c), rows(r), step(s) {}
+    bool empty() const { return data == nullptr || cols <= 0 || rows <= 0; }
+};
+#else
 struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
 struct Rect { int x, y, width, height; };
 
 // non-owning 8-bit single-channel image view (cv::Mat CV_8UC1: data, cols, rows, step)
 struct Image8 {
     const uint8_t *data = nullptr; int cols = 0, rows = 0, step = 0;
+    Image8() = default;
+    Image8(const uint8_t *d, int c, int r, int s) : data(d), cols(c), rows(r), step(s) {}
     bool empty() const { return data == nullptr || cols <= 0 || rows <= 0; }
 };
+#endif
 
 // one ov2_ctx per thread that calls into the library (SLAM thread, mapper thread, estimator thread)
 class Context {
@@ -40,25 +64,30 @@ private:
 class Pyramid {
 public:
     Pyramid() = default;
-    Pyramid(Pyramid &&o) noexcept : p_(o.p_) { o.p_ = nullptr; }
-    Pyramid &operator=(Pyramid &&o) noexcept { if (this != &o) { ov2_pyr_destroy(p_); p_ = o.p_; o.p_ = nullptr; } return *this; }
+    Pyramid(Pyramid &&o) noexcept : p_(o.p_), win_(o.win_), max_level_(o.max_level_) { o.p_ = nullptr; }
+    Pyramid &operator=(Pyramid &&o) noexcept { if (this != &o) { ov2_pyr_destroy(p_); p_ = o.p_; win_ = o.win_; max_level_ = o.max_level_; o.p_ = nullptr; } return *this; }
     Pyramid(const Pyramid &) = delete;
     Pyramid &operator=(const Pyramid &) = delete;
     ~Pyramid() { ov2_pyr_destroy(p_); }
     bool empty() const { return p_ == nullptr; }
     size_t size() const { return p_ ? 2 * (size_t)ov2_pyr_levels(p_) : 0; }     // 2 Mats per level in the reference
-    void swap(Pyramid &o) { ov2_pyr *t = p_; p_ = o.p_; o.p_ = t; }
+    void swap(Pyramid &o) { std::swap(p_, o.p_); std::swap(win_, o.win_); std::swap(max_level_, o.max_level_); }
     ov2_pyr *get() const { return p_; }
     // cv::buildOpticalFlowPyramid(img, *this, Size(win,win), max_level)
     int build(Context &ctx, const Image8 &img, int win, int max_level) {
         if (img.empty()) return OV2_EINVAL;
         int w = 0, h = 0;
-        if (p_ && (ov2_pyr_level_size(p_, 0, &w, &h) != OV2_OK || w != img.cols || h != img.rows)) { ov2_pyr_destroy(p_); p_ = nullptr; }
-        if (!p_) { const int rc = ov2_pyr_create(ctx.get(), img.cols, img.rows, win, max_level, 1, &p_); if (rc != OV2_OK) return rc; }
+        // a different image size, window or level count needs a new device layout (the old geometry would make every
+        // later ov2_fb_klt fail with "LK window differs" / return fewer levels than asked for)
+        if (p_ && (ov2_pyr_level_size(p_, 0, &w, &h) != OV2_OK || w != img.cols || h != img.rows || win != win_ || max_level != max_level_)) { ov2_pyr_destroy(p_); p_ = nullptr; }
+        if (!p_) { const int rc = ov2_pyr_create(ctx.get(), img.cols, img.rows, win, max_level, 1, &p_); if (rc != OV2_OK) return rc; win_ = win; max_level_ = max_level; }
+        // asynchronous on ctx's stream: img.data must stay valid until the context's next synchronising call (every
+        // ov2_fb_klt / detector call is one).  Consumers on ANOTHER context wait on the pyramid's ready event themselves.
         return ov2_pyr_build_h(ctx.get(), p_, img.data, img.step, 0);
     }
 private:
     ov2_pyr *p_ = nullptr;
+    int win_ = 0, max_level_ = -1;
 };
 
 }  // namespace ov2

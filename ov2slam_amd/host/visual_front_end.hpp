@@ -1,0 +1,86 @@
+// visual_front_end.hpp -- C++ adapter for the GPU half of VisualFrontEnd (/root/reference/src/visual_front_end.cpp):
+// preprocessImage (:1143-1177) + kltTracking (:132-275) on ov2_tracker_* -- ONE enqueue, ONE synchronisation per frame.
+// The reference's members prev_pyr_ / cur_pyr_ live inside the tracker object; kltTracking's two fbKltTracking calls, the
+// retry of lost prior tracks and the bp3preq_ rule are reproduced by the library (include/ov2slam_hip.h).
+#pragma once
+#include "ov2_types.hpp"
+
+namespace ov2 {
+
+class FrameTracker {
+public:
+    // SlamParams fields of the same names (slam_params.hpp): nklt_win_size_, nklt_pyr_lvl_, nmax_iter_, fmax_px_precision_,
+    // nklt_err_, fmax_fbklt_dist_, use_clahe_, fclahe_val_, nbmaxkps_
+    FrameTracker(Context &ctx, int img_w, int img_h, int nklt_win_size, int nklt_pyr_lvl, int nmax_iter, float fmax_px_precision,
+                 float nklt_err, float fmax_fbklt_dist, bool use_clahe, double fclahe_val, int nbmaxkps, bool use_graph = true)
+    {
+        ov2_tracker_config c{};
+        c.w = img_w; c.h = img_h; c.win = nklt_win_size; c.nklt_pyr_lvl = nklt_pyr_lvl; c.prior_pyr_lvl = 1;
+        c.max_iter = nmax_iter; c.eps = fmax_px_precision; c.err_th = nklt_err; c.fb_dist = fmax_fbklt_dist;
+        c.use_clahe = use_clahe ? 1 : 0; c.clahe_clip = fclahe_val; c.tiles_x = img_w / 50; c.tiles_y = img_h / 50;   // ov2slam.cpp:85-89
+        c.n_max = nbmaxkps; c.use_graph = use_graph ? 1 : 0;
+        if (ov2_tracker_create(ctx.get(), &c, &t_) != OV2_OK) throw std::runtime_error(std::string("ov2_tracker_create: ") + ov2_last_error());
+    }
+    ~FrameTracker() { ov2_tracker_destroy(t_); }              // destroy before the Context it was created on
+    FrameTracker(const FrameTracker &) = delete;
+    FrameTracker &operator=(const FrameTracker &) = delete;
+
+    // pinned staging image: let the image source (ROS callback / decoder) write here to skip the host-side copy
+    uint8_t *imageBuffer(int *stride) { return ov2_tracker_image_buffer(t_, stride); }
+
+    // VisualFrontEnd::preprocessImage(img_raw): asynchronous
+    bool preprocessImage(const Image8 &img_raw) { return !img_raw.empty() && ov2_tracker_preprocess(t_, img_raw.data, img_raw.step) == OV2_OK; }
+
+    // VisualFrontEnd::kltTracking on the keypoints of pcurframe_: vkps[i] = kp.px_, vpriors[i] = projected map point for
+    // keypoints with a usable 3-D prior (vhasprior[i] = 1) and kp.px_ otherwise (:160-182).  On return vpriors[i] is the
+    // tracked pixel (what the reference passes to updateKeypoint), vkpstatus[i] whether the observation survives (false ->
+    // removeObsFromCurFrameById, :260), bp3preq mirrors bp3preq_ (:225-230).  Errors degrade to "nothing tracked".
+    void kltTracking(const std::vector<Point2f> &vkps, std::vector<Point2f> &vpriors, const std::vector<uint8_t> &vhasprior,
+                     bool klt_use_prior, std::vector<bool> &vkpstatus, bool &bp3preq)
+    {
+        const size_t n = vkps.size();
+        vkpstatus.assign(n, false);
+        bp3preq = false;
+        if (n == 0) return;
+        std::vector<Point2f> out(n);
+        std::vector<uint8_t> st(n, 0);
+        int p3p = 0;
+        const int rc = ov2_tracker_klt(t_, &vkps[0].x, &vpriors[0].x, vhasprior.empty() ? nullptr : vhasprior.data(), (int)n,
+                                       klt_use_prior ? 1 : 0, &out[0].x, st.data(), &p3p);
+        if (rc != OV2_OK) return;
+        vpriors.swap(out);
+        for (size_t i = 0; i < n; i++) vkpstatus[i] = (st[i] & 1) != 0;
+        bp3preq = p3p != 0;
+    }
+
+    // preprocessImage + kltTracking in one call (one graph launch): for callers whose priors do not depend on the new image
+    // (the constant-velocity motion model of the reference does not: it uses the frame time and the previous poses)
+    bool trackFrame(const Image8 &img_raw, const std::vector<Point2f> &vkps, std::vector<Point2f> &vpriors, const std::vector<uint8_t> &vhasprior,
+                    bool klt_use_prior, std::vector<bool> &vkpstatus, bool &bp3preq)
+    {
+        const size_t n = vkps.size();
+        vkpstatus.assign(n, false);
+        bp3preq = false;
+        if (img_raw.empty()) return false;
+        std::vector<Point2f> out(n);
+        std::vector<uint8_t> st(n, 0);
+        int p3p = 0;
+        const int rc = ov2_tracker_track_frame(t_, img_raw.data, img_raw.step, n ? &vkps[0].x : nullptr, n ? &vpriors[0].x : nullptr,
+                                               vhasprior.empty() ? nullptr : vhasprior.data(), (int)n, klt_use_prior ? 1 : 0,
+                                               n ? &out[0].x : nullptr, n ? st.data() : nullptr, &p3p);
+        if (rc != OV2_OK) return false;
+        if (n) vpriors.swap(out);
+        for (size_t i = 0; i < n; i++) vkpstatus[i] = (st[i] & 1) != 0;
+        bp3preq = p3p != 0;
+        return true;
+    }
+
+    // cur_pyr_ / prev_pyr_ for createKeyframe, stereo matching and the device-resident detectors (valid until the next frame)
+    const ov2_pyr *curPyr() const { return ov2_tracker_cur_pyr(t_); }
+    const ov2_pyr *prevPyr() const { return ov2_tracker_prev_pyr(t_); }
+
+private:
+    ov2_tracker *t_ = nullptr;
+};
+
+}  // namespace ov2

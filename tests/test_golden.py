@@ -23,3 +23,13 @@ def test_cpp_adapters_compile():
     src = os.path.join(root, "ov2slam_amd", "host", "compile_check.cpp")
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_cpp_adapters_compile_with_cv_types():
+    """The same adapters with the reference's own value types (-DOV2_WITH_OPENCV: cv::Point2f, cv::Rect, cv::Mat), checked
+    against a minimal stand-in for <opencv2/core.hpp> (tests/fake_opencv) because this image has no OpenCV."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "ov2slam_amd", "host", "compile_check.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DOV2_WITH_OPENCV",
+                        "-I" + os.path.join(HERE, "fake_opencv"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
