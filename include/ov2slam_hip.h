@@ -288,6 +288,11 @@ typedef struct {
     double min_relative_decrease;/* 1e-3                                          */
     int jacobi_scaling;          /* 1                                             */
     int max_consecutive_invalid_steps; /* 5                                       */
+    double max_solver_time_s;    /* Ceres max_solver_time_in_seconds: 0.2 / 0.1 s in localBA when force_realtime (optimizer.cpp:464-468,
+                                    :612), 5 ms in ceresPnP (multi_view_geometry.cpp:546), 10-20 ms in structureOnlyBA; <= 0 = no limit
+                                    (the default: results are then independent of machine load).  The limit is checked by the host
+                                    between chunks of 2 LM iterations; when it fires no further iteration is started and the solve
+                                    returns the last accepted state with OV2_TERM_NO_CONVERGENCE, like Ceres' "maximum solver time" exit */
 } ov2_ba_options;
 
 enum {

@@ -45,7 +45,7 @@ class BAOptions(C.Structure):
         ("parameter_tolerance", C.c_double), ("huber_delta", C.c_double), ("initial_radius", C.c_double),
         ("max_radius", C.c_double), ("min_radius", C.c_double), ("min_lm_diagonal", C.c_double),
         ("max_lm_diagonal", C.c_double), ("min_relative_decrease", C.c_double), ("jacobi_scaling", C.c_int),
-        ("max_consecutive_invalid_steps", C.c_int),
+        ("max_consecutive_invalid_steps", C.c_int), ("max_solver_time_s", C.c_double),
     ]
 
 

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <mutex>
+#include <chrono>
 
 #ifndef BA_KO
 #define BA_KO 0      // knock-out timing of the lineariser: 1 no global Hao atomics, 2 no LDS atomics, 4 no wave sums
@@ -1877,7 +1878,22 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     volatile int *done_h = (volatile int *)ctx->h_scratch;
     done_h[0] = done_h[1] = 0;
     int chunks = 0;
+    const auto t_start = std::chrono::steady_clock::now();
     for (int it = 0; it < o->max_iter; it++) {
+        if (it % BA_CHUNK == 0 && it > 0 && o->max_solver_time_s > 0.0) {
+            // Ceres tests total_time >= max_solver_time_in_seconds at the top of every iteration; here between chunks, against
+            // the time the DEVICE has actually spent (wait for the previous chunk first, otherwise only the enqueue is timed)
+            OV2_HIP_CHECK(hipStreamSynchronize(s));
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            if (el >= o->max_solver_time_s) {
+                // the regular per-iteration bookkeeping with an iteration budget of zero: it finalises the last step (successful
+                // step count, minimum cost, cost of a fresh linearisation) and terminates with NO_CONVERGENCE
+                BAOpt Ostop = O;
+                Ostop.max_iter = 0;
+                hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, Ostop);
+                break;
+            }
+        }
         if (it % BA_CHUNK == 0 && it > 0) {
             const int c = chunks++;                                           // chunk that was just enqueued
             OV2_HIP_CHECK(hipMemcpyAsync((void *)&done_h[c & 1], &D.ctl->done, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1931,6 +1947,7 @@ void ov2_ba_default_options(ov2_ba_options *o)
     o->huber_delta = sqrt(5.9915); o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32;
     o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->min_relative_decrease = 1e-3; o->jacobi_scaling = 1;
     o->max_consecutive_invalid_steps = 5;
+    o->max_solver_time_s = 0.0;
 }
 
 int ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r)

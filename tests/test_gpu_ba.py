@@ -219,3 +219,17 @@ def test_too_many_keyframes_is_reported(gpu_ctx):
     with pytest.raises(ov2slam_amd.Ov2Error) as e:
         optimizer.solve(gpu_ctx, pb)
     assert e.value.code == -4 and "keyframes" in str(e.value)
+
+
+def test_max_solver_time_stops_between_chunks(gpu_ctx, oracle):
+    """max_solver_time_s (Ceres max_solver_time_in_seconds, optimizer.cpp:464-468): an impossible budget stops the solve after
+    the first chunk of iterations with NO_CONVERGENCE and a state that is one of the oracle's accepted iterates; no limit
+    (the default) reproduces the oracle."""
+    pb = synth.make_ba_problem(12, 400, 8, stereo=True, seed=3)
+    kw = dict(max_iter=50, function_tolerance=1e-12)
+    full = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+    cut = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, max_solver_time_s=1e-9, **kw))
+    assert cut["termination"] == 0 and 1 <= cut["iterations"] <= 4 and cut["iterations"] < full["iterations"]
+    ref = oracle.ba_solve(pb, oracle.ba_default_options(max_iter=cut["iterations"], function_tolerance=1e-12))
+    assert np.allclose(cut["poses"], ref["poses"], atol=1e-9) and abs(cut["final_cost"] - ref["final_cost"]) <= 1e-8 * ref["final_cost"]
+    assert cut["final_cost"] <= cut["initial_cost"] and full["final_cost"] <= cut["final_cost"]
