@@ -431,8 +431,12 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = ov2slam_amd.Context(dev.index, stream=stream.cuda_stream)
     lib = ctx.lib
-    frames_d = torch.from_numpy(views).to(dev)                   # (NF+1, H, W) shared by the S sequences of this rank
-    frames_d = frames_d[:, None].expand(NF + 1, S, H, W).contiguous()
+    # raw frames in HBM with a 16-byte-aligned row pitch (what ov2_pyr_build_h / the tracker stage host images into as well):
+    # 1241-byte KITTI rows would otherwise send every CLAHE kernel down its unaligned-row instance (2.3x slower, r2_kitti_*)
+    PITCH = (W + 15) & ~15
+    vpad = np.zeros((NF + 1, H, PITCH), np.uint8); vpad[:, :, :W] = views
+    frames_d = torch.from_numpy(vpad).to(dev)                    # (NF+1, H, PITCH) shared by the S sequences of this rank
+    frames_d = frames_d[:, None].expand(NF + 1, S, H, PITCH).contiguous()
     kps_d = torch.from_numpy(kps).to(dev)
     pri_d = torch.from_numpy(pri).to(dev)
     pri_work = pri_d.clone()
@@ -456,7 +460,7 @@ def main():
 
     def preprocess(pyr, img):
         # clahe->apply + buildOpticalFlowPyramid (visual_front_end.cpp:1159, :1172) in one call
-        L.check(build_clahe(ctx.h, pyr, img, W, W * H, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1]))
+        L.check(build_clahe(ctx.h, pyr, img, PITCH, PITCH * H, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1]))
 
     def step(i, timed):
         f = i % NF
