@@ -126,6 +126,8 @@ SIGNATURES = {
     "ov2_pyr_download": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ov2_pyr_download_padded": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ov2_pyr_algorithmic_bytes": (C.c_size_t, [_vp]),
+    "ov2_pyr_tiled": (_i, [_vp]),
+    "ov2_pyr_download_tiled": (_i, [_vp, _vp, _i, _i, _vp]),
     "ov2_clahe_h": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _i, _vp, _i]),
     "ov2_clahe_d": (_i, [_vp, _vp, _i, _i, _i, C.c_size_t, _i, _d, _i, _i, _vp, _i, C.c_size_t]),
     "ov2_compute_keypoints": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),

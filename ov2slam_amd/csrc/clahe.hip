@@ -27,6 +27,8 @@ struct ClaheParams {
     int dst_stride;
     int border;          // > 0: dst is a padded pyramid level -- also write its REFLECT_101 border of this many pixels
     int batch, gx_lut;   // images in the launch, work-groups per image of the LUT kernel (1-D XCD-aware launches)
+    long long til_delta; // != 0: dst is level 0 of a pyramid with a tiled LK copy: byte offset of that copy from the dst ROI pointer
+    int til_ntx;         //       tiles per row of it (common.hpp: ov2_til_offset)
     int ysplit;          // apply kernel: work-groups per row of interpolation cells (1 in batch mode; a single image is cut
                          // into ~60 short row bands so that it does not run on 10 CUs only -- latency)
 };
@@ -355,6 +357,13 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
                 if ((CLAHE_KO & 16) && out != 0x12345678u) continue;
                 if (full) *(uint32_t *)(drow + xb) = out;
                 else for (int k = 0; k < 4; k++) if (xb + k < P.w) drow[xb + k] = (uint8_t)(out >> (8 * k));
+                if (P.til_delta != 0) {
+                    // the same pixels in the tiled LK copy of level 0 (16 x 8-pixel tiles of 128 B; x, y offset by OV2_TIL_PAD)
+                    const int X = xb + OV2_TIL_PAD, Y = y + OV2_TIL_PAD;
+                    uint8_t *dt = dimg + P.til_delta + ((long long)((Y >> 3) * P.til_ntx + (X >> 4)) << 7) + ((Y & 7) << 4) + (X & 15);
+                    if (xb + 3 < P.w) *(uint32_t *)dt = out;
+                    else for (int k = 0; k < 4; k++) if (xb + k < P.w) dt[k] = (uint8_t)(out >> (8 * k));
+                }
             }
 #pragma unroll
             for (int u = 0; u < CA_UNROLL; u++) inr[u] = nxt[u];
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
 
 int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                      double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                     uint8_t *lut_d, int border)
+                     uint8_t *lut_d, int border, long long til_delta, int til_ntx)
 {
     // geometry checks first: nothing is enqueued when the call is going to fail
     OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && (size_t)(tiles_x + 1) * 1024 <= 160 * 1024, OV2_EUNSUPPORTED,
@@ -413,7 +422,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     });
     OV2_HIP_CHECK(attr_err);
     ClaheParams P;
-    P.border = border;
+    P.border = border; P.til_delta = til_delta; P.til_ntx = til_ntx;
     int ew = w, eh = h;
     if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
     P.w = w; P.h = h; P.stride = stride; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
@@ -452,7 +461,7 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
     const int rc = ctx->reserve_device(lut_bytes);
     if (rc != OV2_OK) return rc;
     return ov2_launch_clahe(ctx, src_d, w, h, stride, src_batch_stride, batch, clip_limit, tiles_x, tiles_y, dst_d, dst_stride,
-                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0);
+                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0, 0, 0);
 }
 
 int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
@@ -469,7 +478,8 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
     // no level-0 copy); borders and the coarser levels follow from there
     const PyrLevelDesc &L0 = p->d.lv[0];
     rc = ov2_launch_clahe(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
-                          p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win);
+                          p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win,
+                          p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
     if (rc != OV2_OK) return rc;
     rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
     if (rc != OV2_OK) return rc;
@@ -492,7 +502,7 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
     const PyrLevelDesc &L0 = p->d.lv[0];
     rc = ov2_launch_clahe(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
-                          (size_t)p->d.item_stride, ds + img, p->d.win);
+                          (size_t)p->d.item_stride, ds + img, p->d.win, p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
     if (rc != OV2_OK) return rc;
     rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
     if (rc != OV2_OK) return rc;
@@ -512,7 +522,7 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     if (rc != OV2_OK) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
     OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
-    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0);
+    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, 0, 0);
     if (rc2 != OV2_OK) return rc2;
     OV2_HIP_CHECK(hipMemcpy2DAsync(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));

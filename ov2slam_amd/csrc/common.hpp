@@ -63,7 +63,19 @@ struct PyrLevelDesc {
     long long img_roi;    // byte offset (from the item base) of image ROI pixel (0,0)
     long long der_roi;    // byte offset (from the item base) of derivative ROI element (0,0)
     int img_padx, der_padx, pady;
+    // Tiled copy for the batch LK kernel (k_fb_klt3): 16 x 8-pixel tiles of 128 bytes = one cache line each, covering the
+    // image plus 16 columns / rows of padding on the left / top (REFLECT_101 border inside it) and the slack LK's block
+    // fetches can touch on the right / bottom.  A 16-row block of 16-byte row segments then spans 4-6 lines instead of
+    // 12-18 (the kernel is bound by line fills).  til_base < 0: this pyramid has no tiled copy.
+    long long til_base;   // byte offset (from the item base) of tile (0, 0)
+    int til_ntx, til_nty; // tiles per row / tile rows
 };
+#define OV2_TIL_PAD 16        // pixel (x, y) lives at tile column (x + 16) >> 4, tile row (y + 16) >> 3
+__host__ __device__ __forceinline__ long long ov2_til_offset(const PyrLevelDesc &L, int x, int y)
+{
+    const int X = x + OV2_TIL_PAD, Y = y + OV2_TIL_PAD;
+    return L.til_base + ((long long)((Y >> 3) * L.til_ntx + (X >> 4)) << 7) + ((Y & 7) << 4) + (X & 15);
+}
 
 struct PyrDesc {
     uint8_t *base;            // device pointer of batch item 0
@@ -71,6 +83,7 @@ struct PyrDesc {
     int n_levels;
     int win;
     int batch;
+    int tiled;                // 1: every level also has its tiled copy (batch pyramids)
     PyrLevelDesc lv[OV2_MAX_LEVELS];
 };
 
@@ -94,7 +107,7 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
 // cv::CLAHE::apply on `batch` device images; border > 0: dst is a padded pyramid level, its REFLECT_101 border is written too
 int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                      double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                     uint8_t *lut_d, int border);
+                     uint8_t *lut_d, int border, long long til_delta = 0, int til_ntx = 0);
 // fused VisualFrontEnd::kltTracking launch (lk.hip), device pointers only
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,

@@ -39,7 +39,8 @@ static int enqueue_preprocess(ov2_tracker *t, ov2_pyr *dst)
     if (c.use_clahe) {
         const PyrLevelDesc &L0 = dst->d.lv[0];
         int rc = ov2_launch_clahe(ctx, t->dimg, c.w, c.h, (int)t->img_pitch, 0, 1, c.clahe_clip, c.tiles_x, c.tiles_y,
-                                  dst->d.base + L0.img_roi, L0.img_pitch, (size_t)dst->d.item_stride, t->lut, dst->d.win);
+                                  dst->d.base + L0.img_roi, L0.img_pitch, (size_t)dst->d.item_stride, t->lut, dst->d.win,
+                                  dst->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
         if (rc != OV2_OK) return rc;
         return ov2_launch_pyr_build(ctx, dst, nullptr, 0, 0);
     }

@@ -128,6 +128,17 @@ class Pyramid:
         return img, der
 
     @property
+    def tiled(self):
+        return bool(self.lib.ov2_pyr_tiled(self.h_pyr))
+
+    def download_tiled(self, level, b=0):
+        """the padded level image read back from the tiled LK copy (must equal download(level, padded=True)[0])"""
+        w, h = self.level_size(level)
+        img = np.empty((h + 2 * self.win, w + 2 * self.win), np.uint8)
+        L.check(self.lib.ov2_pyr_download_tiled(self.ctx.h, self.h_pyr, b, level, _ptr(img)))
+        return img
+
+    @property
     def algorithmic_bytes(self):
         return self.lib.ov2_pyr_algorithmic_bytes(self.h_pyr)
 

@@ -9,11 +9,16 @@ from ov2slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["row", "lane3"], autouse=True)
+@pytest.fixture(params=["row", "lane3", "lane3_tiled"], autouse=True)
 def lk_impl(request, monkeypatch):
-    """Every test of this file runs with both LK kernels (lk.hip: row per lane, lk3.hip: 3 lanes per keypoint);
-    without the override the library picks by launch size and these small cases would only see the first one."""
-    monkeypatch.setenv("OV2_LK_IMPL", request.param)
+    """Every test of this file runs with both LK kernels (lk.hip: row per lane, lk3.hip: 3 lanes per keypoint) and, for the
+    latter, with both fetch paths (row-major pyramid / the tiled LK copy that batch pyramids carry); without the overrides the
+    library picks by launch and batch size and these small cases would only see the first one."""
+    monkeypatch.setenv("OV2_LK_IMPL", "lane3" if request.param.startswith("lane3") else request.param)
+    if request.param == "lane3_tiled":
+        monkeypatch.setenv("OV2_PYR_TILED", "1")
+    else:
+        monkeypatch.delenv("OV2_PYR_TILED", raising=False)
     return request.param
 
 
@@ -39,6 +44,8 @@ def test_pyramid_bit_exact(gpu_ctx, oracle, wh):
         ri, rd = R.level(l, padded=True)
         assert np.array_equal(gi, ri), "image level %d" % l
         assert np.array_equal(gd, rd), "derivative level %d" % l
+        if G.tiled:                                        # the tiled LK copy holds the same padded image, ring included
+            assert np.array_equal(G.download_tiled(l), ri), "tiled copy level %d" % l
 
 
 def test_pyramid_batch_matches_single(gpu_ctx, oracle):
