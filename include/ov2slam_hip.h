@@ -85,9 +85,10 @@ int  ov2_pyr_build_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride,
 int  ov2_pyr_download(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h);
 /* same but including the `win` border on every side ((w+2win)*(h+2win))        */
 int  ov2_pyr_download_padded(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h);
-/* Batch pyramids (batch >= 64, win 9) also keep every level as 16 x 8-pixel tiles of 128 bytes (one cache line each): the
- * batch LK kernel fetches its 16-row blocks from that copy -- 4-6 cache lines per block instead of 12-18.
- * ov2_pyr_tiled: 1 if this pyramid has it; ov2_pyr_download_tiled: the padded level read back from the tiled copy
+/* Experimental, off unless the environment has OV2_PYR_TILED=1 when the pyramid is created: every level is ALSO kept as
+ * 16 x 8-pixel tiles of 128 bytes (one cache line each) and the batch LK kernel fetches its 16-row blocks from that copy --
+ * 4-6 cache lines per block instead of 12-18.  Measured: 3 % on the LK kernel, +1.5 ms of pre-processing per 4096 images
+ * (DESIGN.md 7), hence not the default.  ov2_pyr_tiled: 1 if this pyramid has it; ov2_pyr_download_tiled: the padded level read back from the tiled copy
  * (same layout as ov2_pyr_download_padded's image; test / debug).                                                       */
 int  ov2_pyr_tiled(const ov2_pyr *p);
 int  ov2_pyr_download_tiled(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h);

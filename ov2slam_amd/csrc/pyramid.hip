@@ -398,9 +398,11 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
     PyrDesc &D = p->d;
     memset(&D, 0, sizeof(D));
     D.win = win; D.batch = batch;
-    // the tiled LK copy only pays where the 3-lanes-per-keypoint kernel runs: batches of sequences (lk_dispatch picks it from
-    // 65536 point slots up); a single camera's pyramid stays row-major only.  OV2_PYR_TILED=0|1 overrides (A/B, tests).
-    D.tiled = batch >= 64 && win == 9 ? 1 : 0;
+    // Tiled LK copy: OFF by default.  Measured (gpurun_out/r2f, 4096 sequences): with it k_fb_klt3 fetches 3x fewer cache lines
+    // per level visit but gets only 2.9 % faster (1.839 -> 1.786 ms per step) -- the kernel is bound by the latency of its
+    // dependent phases at 3 waves per SIMD, not by line fills -- while the scattered dword stores of the second copy cost the
+    // pre-processing kernels +1.5 ms per step.  OV2_PYR_TILED=1 builds it (A/B runs, parity tests of the path).
+    D.tiled = 0;
     if (const char *e = getenv("OV2_PYR_TILED")) D.tiled = (e[0] == '1' && win == 9) ? 1 : 0;
     long long off = 0;
     int lw = w, lh = h;

@@ -99,27 +99,20 @@ def test_fused_preprocess_from_host_image(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("wh", [(752, 480), (1241, 376), (264, 100)])
 def test_tiled_lk_copy_equals_row_major_pyramid(gpu_ctx, wh, monkeypatch):
-    """Batch pyramids carry a second, tiled copy of every level for the batch LK kernel (16 x 8-pixel tiles of one cache line);
-    it is written by the producers themselves (CLAHE apply, level kernels, ring kernel).  It must hold exactly the padded
-    row-major image -- through the fused CLAHE path and the plain path, for every batch item."""
-    import torch
+    """OV2_PYR_TILED=1 (experimental): a second, tiled copy of every level for the batch LK kernel (16 x 8-pixel
+    tiles of one cache line), written by the producers themselves (CLAHE apply, level kernels, ring kernel).  It must hold
+    exactly the padded row-major image -- through the fused CLAHE path and the plain path, for every batch item."""
     monkeypatch.setenv("OV2_PYR_TILED", "1")
     w, h = wh
     rng = np.random.default_rng(21)
     imgs = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
-    for fused in (True, False):
-        P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3, batch=3)
-        assert P.tiled
-        if fused:
-            pitch = (w + 15) & ~15
-            pad = np.zeros((3, h, pitch), np.uint8); pad[:, :, :w] = imgs
-            d = torch.from_numpy(pad).cuda()
-            torch.cuda.synchronize()
-            P.build_clahe_from_device(d.data_ptr(), 3.0, max(1, w // 50), max(1, h // 50), stride=pitch, batch_stride=pitch * h)
-        else:
-            P.build(imgs)
-        for b in range(3):
-            for l in range(P.levels):
-                ref, _ = P.download(l, b=b, padded=True)
-                assert np.array_equal(P.download_tiled(l, b=b), ref), (fused, b, l)
-        P.close()
+    P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(imgs[0], 3.0, max(1, w // 50), max(1, h // 50))     # fused CLAHE path
+    assert P.tiled
+    for l in range(P.levels):
+        assert np.array_equal(P.download_tiled(l), P.download(l, padded=True)[0]), ("fused", l)
+    P.close()
+    P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3, batch=3).build(imgs)                                            # plain path, batch
+    for b in range(3):
+        for l in range(P.levels):
+            assert np.array_equal(P.download_tiled(l, b=b), P.download(l, b=b, padded=True)[0]), ("plain", b, l)
+    P.close()
