@@ -846,6 +846,12 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 // below it is solved row-per-thread against that block and parked in LDS, and the trailing update
 // reads the panel from LDS only (each S entry is touched once per panel).
 #define CH_NB 32
+#ifndef CH_GRP
+#define CH_GRP 4           // columns of the diagonal block published per work-group barrier (pipelined panel solve)
+#endif
+#ifndef CH_SKIP_W4
+#define CH_SKIP_W4 0        // 1: wavefront 4 (same SIMD as the factorising wavefront 0) owns no panel rows -- measured: no difference
+#endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
 
 // lower triangle of S, one thread per entry, many workgroups (latency-bound gathers from H and G)
@@ -911,7 +917,12 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
         }
         __syncthreads();
         CH_TICK(0);
-        // (b) wavefront 0: left-looking factorisation, lane i owns row i in registers; one LDS sync per column
+        // (b) + (c), pipelined through LDS.  Wavefront 0 factors the diagonal block (left-looking, lane i owns row i in
+        //     registers, one LDS sync per column) and PUBLISHES its columns in groups of four (L11[.][c], the reciprocal pivots,
+        //     then a work-group barrier; a per-column flag with spinning consumers made the register allocator spill the row
+        //     arrays).  The other wavefronts solve the panel X L11^T = A21 one row per thread and trail the
+        //     factorisation by one column instead of waiting for all 32: the panel solve (9 us per panel as a phase of its own)
+        //     hides behind the 5 us pivot chain.
         if (wave == 0) {
             double a[CH_NB];
 #pragma unroll
@@ -943,49 +954,60 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                 const double l = lane == c ? dj : sacc * r;
                 a[c] = lane >= c ? l : 0.0;
                 if (lane >= c && lane < CH_NB) L11[lane * CH_LDP + c] = a[c];
+                // reciprocal pivot 1 / L[c][c]: r refined by one Newton step of the reciprocal (two FMAs, no division)
+                if (lane == c) s_rdiag[c] = fma(r, fma(-dj, r, 1.0), r);
                 wave_lds_sync();
+                if ((c & (CH_GRP - 1)) == CH_GRP - 1) __syncthreads();   // columns c-CH_GRP+1 .. c are published: the panel wavefronts may use them
             }
             if (fail && lane == 0) s_fail = 1;
-            // reciprocal pivots for the panel solve and the block inverse: one division per pivot instead of one per
-            // (row, pivot) -- an fp64 division is ~30 instructions, and 32 of them were half of the panel solve
-            if (lane < CH_NB) s_rdiag[lane] = 1.0 / L11[lane * CH_LDP + lane];
-        }
-        __syncthreads();
-        CH_TICK(1);
-        if (s_fail) break;
-        // (c) last wavefront: inverse of the factored block (lane j solves L x = e_j), kept for the triangular solves;
-        //     all other threads: panel solve X L11^T = A21, one row per thread, operands in LDS
-        if (wave == (nt >> 6) - 1) {
-            if (lane < CH_NB) {
-                double x[CH_NB];
-#pragma unroll
-                for (int i = 0; i < CH_NB; i++) {
-                    double acc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; k++) acc -= L11[i * CH_LDP + k] * x[k];
-                    x[i] = i < lane ? 0.0 : acc * s_rdiag[i];
-                }
-                double *dst = Linv + (long long)(k0 / CH_NB) * CH_NB * CH_NB;
-#pragma unroll
-                for (int i = 0; i < CH_NB; i++) dst[i * CH_NB + lane] = x[i];            // Linv[i][j], coalesced over j
-            }
         } else {
-            for (int t = tid; t < m; t += nt - 64) {
-                double x[CH_NB];
+            // left-looking per row (x[32] in registers, row j of L read as one contiguous LDS row).  Every panel wavefront
+            // passes the same 8 work-group barriers as wavefront 0, whether its threads own a row or not.
+            // (wavefront 4 shares SIMD 0 with the factorising wavefront 0: it owns no rows, so that the pivot chain has that SIMD's
+            // issue slots to itself; wavefronts 1-3 and 5-7 take rows 0 .. 383)
+            const int t = CH_SKIP_W4 ? (wave < 4 ? tid - 64 : tid - 128) : tid - 64;
+            const bool has = t < m && !(CH_SKIP_W4 && wave == 4);
+            double x[CH_NB];
 #pragma unroll
-                for (int j = 0; j < CH_NB; j++) x[j] = P[t * CH_LDP + j];
+            for (int j = 0; j < CH_NB; j++) x[j] = has ? P[t * CH_LDP + j] : 0.0;
 #pragma unroll
-                for (int j = 0; j < CH_NB; j++) {
-                    double acc = x[j];
-#pragma unroll
-                    for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
-                    x[j] = acc * s_rdiag[j];
+            for (int j = 0; j < CH_NB; j++) {
+                if ((j & (CH_GRP - 1)) == 0) {
+                    // x[j-1] must be finished BEFORE the barrier: without this artificial use the scheduler drains all eight
+                    // barriers first -- loading the whole block into registers (992 VGPRs: spills) -- and computes afterwards,
+                    // which also serialises the panel solve behind the factorisation again
+                    if (j > 0) asm volatile("" ::"v"(x[j - 1]) : "memory");
+                    __syncthreads();                           // columns j .. j+3 of L11 and their reciprocal pivots are there
                 }
+                double acc = x[j];
+#pragma unroll
+                for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
+                x[j] = acc * s_rdiag[j];
+            }
+            if (has) {
 #pragma unroll
                 for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
             }
         }
         __syncthreads();
+        // rows beyond the pipelined ones (only for reduced systems of more than ~420 unknowns): plain pass, the block is complete
+        for (int t = tid + (CH_SKIP_W4 ? nt - 128 : nt - 64); t < m; t += nt) {
+            double x[CH_NB];
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) x[j] = P[t * CH_LDP + j];
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) {
+                double acc = x[j];
+#pragma unroll
+                for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
+                x[j] = acc * s_rdiag[j];
+            }
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
+        }
+        __syncthreads();
+        CH_TICK(1);
+        if (s_fail) break;
         // factored block and panel back to HBM (coalesced)
         for (int e = tid; e < nb * nb; e += nt) {
             const int i = e / nb, j = e - i * nb;
@@ -1054,6 +1076,43 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
         CH_TICK(3);
     }
     if (s_fail) { if (tid == 0) ctl->lin_fail = 1; return; }
+
+    // Inverses of the factored diagonal blocks (for the two triangular solves below), all blocks in parallel: a wavefront
+    // pulls one 32 x 32 block of L back from S into its own LDS scratch -- wavefront 0 the L11 area, wavefront w > 0 the
+    // w-th 1056-double chunk of the (now idle) panel area -- and lane j solves L x = e_j.  (Round 1 computed each inverse
+    // on one wavefront next to the panel solve; with the pipelined panel solve that wavefront would be the critical path.)
+    {
+        const int nblk = (n + CH_NB - 1) / CH_NB;
+        const int nwork = min(nt >> 6, max(1, n / CH_NB));                  // scratch areas that exist for this n
+        double *Lw = wave == 0 ? L11 : P + (long long)(wave - 1) * (CH_NB * CH_LDP);
+        for (int blk = wave; blk < nblk && wave < nwork; blk += nwork) {
+            const int k0 = blk * CH_NB, nb = min(CH_NB, n - k0);
+            for (int e = lane; e < CH_NB * CH_NB; e += 64) {
+                const int i = e >> 5, j = e & 31;
+                double v = (i == j) ? 1.0 : 0.0;
+                if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
+                Lw[i * CH_LDP + j] = v;
+            }
+            wave_lds_sync();
+            if (lane < CH_NB) Lw[lane * CH_LDP + CH_NB] = 1.0 / Lw[lane * CH_LDP + lane];      // reciprocal pivots in the padding column
+            wave_lds_sync();
+            if (lane < CH_NB) {
+                double x[CH_NB];
+#pragma unroll
+                for (int i = 0; i < CH_NB; i++) {
+                    double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; k++) acc -= Lw[i * CH_LDP + k] * x[k];
+                    x[i] = i < lane ? 0.0 : acc * Lw[i * CH_LDP + CH_NB];
+                }
+                double *dst = Linv + (long long)blk * CH_NB * CH_NB;
+#pragma unroll
+                for (int i = 0; i < CH_NB; i++) dst[i * CH_NB + lane] = x[i];            // Linv[i][j], coalesced over j
+            }
+            wave_lds_sync();
+        }
+    }
+    __syncthreads();
 
     // forward substitution  L y = rhs, left-looking by blocks:  y_blk = Linv_blk (b_blk - L[blk, 0:k0] y[0:k0])
     const int tr = tid >> 5, tcn = tid & 31, ngr = nt >> 5;  // ngr groups of 32 partial-sum threads
