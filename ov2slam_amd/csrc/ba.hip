@@ -62,6 +62,13 @@ struct BADev {                    // device pointers + sizes (passed by value to
     // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
     // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
     int ldim;
+    // big = 1: more optimised keyframes than the LDS-resident path holds (~95).  W = E^T F is then kept SPARSE -- 6 doubles per
+    // residual block (its observer block) in wres, 6 per landmark (the anchor block) in wanc -- instead of a dense n_lm x nfp
+    // matrix, H / F^T b are accumulated with global atomics, the Schur complement by per-landmark block outer products
+    // (k_ba_schur_sparse) and the reduced system is factored by a multi-kernel blocked Cholesky on HBM (k_chol_*).
+    int big;
+    double *wres;                 // 6*n_act  [big]
+    double *wanc;                 // 6*n_lm   [big]
     double *ete6;                 // 6*n_lm   unscaled E^T E, upper triangle (xx xy xz yy yz zz)            [ldim 3]
     double *minv6;                // 6*n_lm   (S E^T E S + D^2)^-1, upper triangle                          [ldim 3]
     double *Wp;                   // 3*n_lm * nfp : rows L_c^T W_l with C_l = S M^-1 S = L_c L_c^T, so that
@@ -381,15 +388,18 @@ __device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, dou
     if (r <= c) atomicAdd(&H[(long long)r * ld + c], v); else atomicAdd(&H[(long long)c * ld + r], v);
 }
 
+// BIG: the sparse-W variant for reduced systems beyond the LDS-resident limit (BADev::big): nothing is aggregated in LDS but
+// the per-wave reduction scratch; pose-side blocks go to H / F^T b with global atomics, the landmark's W entries to wres / wanc.
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__restrict__ lm_order)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->need_lin) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int n_opt = D.nf / 6;
+    const int n_opt = BIG ? 0 : D.nf / 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *wrow = (double *)smem_raw + wave * D.nfp;
-    double *Hoo = (double *)smem_raw + 4 * D.nfp;
+    double *wrow = (double *)smem_raw + wave * (BIG ? 0 : D.nfp);
+    double *Hoo = (double *)smem_raw + 4 * (BIG ? 0 : D.nfp);
     double *bo = Hoo + n_opt * 21;
     double *Hao = bo + n_opt * 6 + wave * n_opt * 36;
     double *red = bo + n_opt * 6 + 4 * n_opt * 36 + wave * LIN_RED;
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         const int a = h_cur.a;
         const int ca = h_cur.ca;
         if (ca != cur_ca) { wave_lds_sync(); flush_anchor(cur_ca); wave_lds_sync(); cur_ca = ca; }
-        for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
+        if (!BIG) for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
         wave_lds_sync();
         const double lam = h_cur.lam;
         const double auv[2] = {h_cur.au, h_cur.av};
@@ -494,6 +504,18 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                         for (int d = c; d < 6; d++) Haa[t++] += Ja[c] * Ja[d] + Ja[6 + c] * Ja[6 + d];
                     }
                 }
+                if (BIG) {
+                    // sparse W: this block's observer entry (zero when the observer is constant / absent), H and F^T b straight to HBM
+                    for (int c = 0; c < 6; c++) D.wres[(long long)6 * k + c] = co >= 0 ? Jl[0] * Jo[c] + Jl[1] * Jo[6 + c] : 0.0;
+                    if (co >= 0) {
+                        for (int c = 0; c < 6; c++) {
+                            atomicAdd(&D.bf[co + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+                            for (int d = c; d < 6; d++) atomicAdd(&D.H[(long long)(co + c) * D.nfp + co + d], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                            if (cae >= 0)
+                                for (int d = 0; d < 6; d++) h_add_upper(D.H, D.nfp, cae + d, co + c, Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c]);
+                        }
+                    }
+                } else
                 if (co >= 0) {
                     const int ob = co / 6;
                     int t = 0;
@@ -538,10 +560,14 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         if (ca >= 0 && lane < 27) dacc += tot;
         if (lane == 33) D.ete[lm] = tot;
         if (lane == 34) D.etb[lm] = tot;
-        if (ca >= 0 && lane >= 27 && lane < 33) wrow[ca + lane - 27] += tot;
-        wave_lds_sync();
-        double *Wg = D.W + (long long)lm * D.nfp;
-        for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
+        if (BIG) {
+            if (lane >= 27 && lane < 33) D.wanc[(long long)6 * lm + lane - 27] = ca >= 0 ? tot : 0.0;     // the landmark's anchor entry of W
+        } else {
+            if (ca >= 0 && lane >= 27 && lane < 33) wrow[ca + lane - 27] += tot;
+            wave_lds_sync();
+            double *Wg = D.W + (long long)lm * D.nfp;
+            for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
+        }
         wave_lds_sync();
         h_cur = h_nxt; h_nxt = h_n2; r_cur = r_nxt;
     }
@@ -854,6 +880,62 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
 
+// The two triangular solves L y = rhs, L^T x = y on the factor in S (HBM) with the inverse diagonal blocks in Linv; yv (LDS, nfp
+// doubles) holds rhs on entry and x on return, L11 is a CH_NB x CH_LDP LDS scratch.  One work-group.
+__device__ __forceinline__ void chol_trisolve(const BADev &D, double *L11, double *yv, double (*s_red)[33])
+{
+    const int n = D.nf, ld = D.nfp, tid = threadIdx.x, nt = blockDim.x;
+    const double *S = D.S, *Linv = D.Linv;
+    // forward substitution  L y = rhs, left-looking by blocks:  y_blk = Linv_blk (b_blk - L[blk, 0:k0] y[0:k0])
+    const int tr = tid >> 5, tcn = tid & 31, ngr = nt >> 5;  // ngr groups of 32 partial-sum threads
+    for (int k0 = 0; k0 < n; k0 += CH_NB) {
+        const int nb = min(CH_NB, n - k0);
+        for (int r = tr; r < CH_NB; r += ngr) {
+            double part = 0;
+            if (r < nb) for (int k = tcn; k < k0; k += 32) part += S[(long long)(k0 + r) * ld + k] * yv[k];
+            s_red[r][tcn] = part;
+        }
+        for (int e = tid; e < CH_NB * CH_NB; e += nt) L11[(e >> 5) * CH_LDP + (e & 31)] = Linv[(long long)(k0 / CH_NB) * CH_NB * CH_NB + e];
+        __syncthreads();
+        if (tid < CH_NB) {
+            double r = 0;
+            for (int q = 0; q < 32; q++) r += s_red[tid][q];
+            s_red[tid][32] = tid < nb ? yv[k0 + tid] - r : 0.0;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double r = 0;
+            for (int k = 0; k <= tid; k++) r += L11[tid * CH_LDP + k] * s_red[k][32];
+            yv[k0 + tid] = r;
+        }
+        __syncthreads();
+    }
+    // backward substitution  L^T x = y:  x_blk = Linv_blk^T (y_blk - L[below, blk]^T x[below])
+    for (int k0 = ((n - 1) / CH_NB) * CH_NB; k0 >= 0; k0 -= CH_NB) {
+        const int nb = min(CH_NB, n - k0);
+        // lanes along the block's columns (coalesced), thread groups along the rows below
+        for (int g = tr; g < 32; g += ngr) {
+            double part = 0;
+            if (tcn < nb) for (int i = k0 + nb + g; i < n; i += 32) part += S[(long long)i * ld + k0 + tcn] * yv[i];
+            s_red[tcn][g] = part;
+        }
+        for (int e = tid; e < CH_NB * CH_NB; e += nt) L11[(e >> 5) * CH_LDP + (e & 31)] = Linv[(long long)(k0 / CH_NB) * CH_NB * CH_NB + e];
+        __syncthreads();
+        if (tid < CH_NB) {
+            double r = 0;
+            for (int q = 0; q < 32; q++) r += s_red[tid][q];
+            s_red[tid][32] = tid < nb ? yv[k0 + tid] - r : 0.0;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double r = 0;
+            for (int k = tid; k < nb; k++) r += L11[k * CH_LDP + tid] * s_red[k][32];     // Linv^T
+            yv[k0 + tid] = r;
+        }
+        __syncthreads();
+    }
+}
+
 // lower triangle of S, one thread per entry, many workgroups (latency-bound gathers from H and G)
 __global__ __launch_bounds__(256) void k_ba_assemble(BADev D)
 {
@@ -1114,58 +1196,202 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     }
     __syncthreads();
 
-    // forward substitution  L y = rhs, left-looking by blocks:  y_blk = Linv_blk (b_blk - L[blk, 0:k0] y[0:k0])
-    const int tr = tid >> 5, tcn = tid & 31, ngr = nt >> 5;  // ngr groups of 32 partial-sum threads
-    for (int k0 = 0; k0 < n; k0 += CH_NB) {
-        const int nb = min(CH_NB, n - k0);
-        for (int r = tr; r < CH_NB; r += ngr) {
-            double part = 0;
-            if (r < nb) for (int k = tcn; k < k0; k += 32) part += S[(long long)(k0 + r) * ld + k] * yv[k];
-            s_red[r][tcn] = part;
-        }
-        for (int e = tid; e < CH_NB * CH_NB; e += nt) L11[(e >> 5) * CH_LDP + (e & 31)] = Linv[(long long)(k0 / CH_NB) * CH_NB * CH_NB + e];
-        __syncthreads();
-        if (tid < CH_NB) {
-            double r = 0;
-            for (int q = 0; q < 32; q++) r += s_red[tid][q];
-            s_red[tid][32] = tid < nb ? yv[k0 + tid] - r : 0.0;
-        }
-        __syncthreads();
-        if (tid < nb) {
-            double r = 0;
-            for (int k = 0; k <= tid; k++) r += L11[tid * CH_LDP + k] * s_red[k][32];
-            yv[k0 + tid] = r;
-        }
-        __syncthreads();
-    }
-    // backward substitution  L^T x = y:  x_blk = Linv_blk^T (y_blk - L[below, blk]^T x[below])
-    for (int k0 = ((n - 1) / CH_NB) * CH_NB; k0 >= 0; k0 -= CH_NB) {
-        const int nb = min(CH_NB, n - k0);
-        // lanes along the block's columns (coalesced), thread groups along the rows below
-        for (int g = tr; g < 32; g += ngr) {
-            double part = 0;
-            if (tcn < nb) for (int i = k0 + nb + g; i < n; i += 32) part += S[(long long)i * ld + k0 + tcn] * yv[i];
-            s_red[tcn][g] = part;
-        }
-        for (int e = tid; e < CH_NB * CH_NB; e += nt) L11[(e >> 5) * CH_LDP + (e & 31)] = Linv[(long long)(k0 / CH_NB) * CH_NB * CH_NB + e];
-        __syncthreads();
-        if (tid < CH_NB) {
-            double r = 0;
-            for (int q = 0; q < 32; q++) r += s_red[tid][q];
-            s_red[tid][32] = tid < nb ? yv[k0 + tid] - r : 0.0;
-        }
-        __syncthreads();
-        if (tid < nb) {
-            double r = 0;
-            for (int k = tid; k < nb; k++) r += L11[k * CH_LDP + tid] * s_red[k][32];     // Linv^T
-            yv[k0 + tid] = r;
-        }
-        __syncthreads();
-    }
+    chol_trisolve(D, L11, yv, s_red);
     for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
     CH_TICK(4);
     if (tid == 0) for (int i = 0; i < 6; i++) ctl->dbg[i] = tk[i];
 #undef CH_TICK
+}
+
+// ================================================================================== big path (BADev::big)
+// W^T C W and W^T (c E^T b) from the SPARSE W: one wavefront per landmark; its entries are the anchor block (wanc) and one
+// observer block per residual (wres).  Lane i owns entry i and walks over all entries j: G[col_i + a][col_j + b] += c w_i[a] w_j[b]
+// for every ordered pair, i.e. the full symmetric matrix (k_ba_assemble reads either triangle).  fp64 atomics into a dense
+// nfp x nfp G: ~36 E^2 per landmark -- the price of keeping the reduced system dense.
+__global__ __launch_bounds__(256) void k_ba_schur_sparse(BADev D)
+{
+    const BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    const int lane = threadIdx.x & 63;
+    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
+        const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
+        if (beg == end) continue;
+        const double c = D.cl[lm], ce = c * D.etb[lm];
+        const int ca = D.pose_col[D.lm_anchor[lm]];
+        const int E = 1 + end - beg;                                    // entry 0 = anchor, entry e = residual beg + e - 1
+        auto entry = [&](int e, int &col, double *w) {
+            if (e == 0) { col = ca; for (int q = 0; q < 6; q++) w[q] = D.wanc[(long long)6 * lm + q]; }
+            else {
+                const int k = beg + e - 1;
+                col = D.res_type[k] == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[D.res_kf[k]];
+                for (int q = 0; q < 6; q++) w[q] = D.wres[(long long)6 * k + q];
+            }
+        };
+        for (int i0 = 0; i0 < E; i0 += 64) {
+            const int i = i0 + lane;
+            int ci = -1; double wi[6] = {0, 0, 0, 0, 0, 0};
+            if (i < E) entry(i, ci, wi);
+            if (ci >= 0) for (int a = 0; a < 6; a++) if (wi[a] != 0.0) atomicAdd(&D.v[ci + a], ce * wi[a]);
+            for (int j = 0; j < E; j++) {
+                int cj; double wj[6];
+                entry(j, cj, wj);                                       // same address in every lane: one broadcast load each
+                if (ci < 0 || cj < 0) continue;
+                for (int a = 0; a < 6; a++) {
+                    const double ca_w = c * wi[a];
+                    if (ca_w == 0.0) continue;
+                    for (int b = 0; b < 6; b++) atomicAdd(&D.G[(long long)(ci + a) * D.nfp + cj + b], ca_w * wj[b]);
+                }
+            }
+        }
+    }
+}
+
+// Blocked right-looking Cholesky of the reduced system on HBM, three kernels per 32-column panel:
+//   k_chol_diag  (1 wavefront): factor the diagonal block in LDS (same register-row algorithm as k_ba_cholesky), write it back, and
+//                its inverse (for the triangular solves) to Linv
+//   k_chol_panel (64 rows per work-group): X L11^T = A21 by substitution, one row per thread
+//   k_chol_trail (one 32 x 32 tile per work-group, lower triangle): A22 -= X X^T
+// then k_chol_solve (1 work-group): the two triangular solves.  ~3 * nf / 32 launches per LM iteration: this path is for the
+// loop-closure / offline BAs (hundreds of keyframes), where a solve takes milliseconds either way.
+__global__ __launch_bounds__(64) void k_chol_diag(BADev D, int k0)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || ctl->lin_fail) return;
+    __shared__ double L11[CH_NB * CH_LDP];
+    const int n = D.nf, ld = D.nfp, lane = threadIdx.x;
+    const int nb = min(CH_NB, n - k0);
+    double *S = D.S;
+    for (int e = lane; e < CH_NB * CH_NB; e += 64) {
+        const int i = e >> 5, j = e & 31;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
+        L11[i * CH_LDP + j] = v;
+    }
+    wave_lds_sync();
+    double a[CH_NB];
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) a[j] = lane < CH_NB ? L11[lane * CH_LDP + j] : 0.0;
+    bool fail = false;
+    double pnext = a[0];
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) {
+        double sacc = pnext;
+        if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];
+        const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
+        if (c + 1 < CH_NB) {
+            pnext = a[c + 1];
+#pragma unroll
+            for (int k = 0; k < c; k++) pnext -= a[k] * L11[(c + 1) * CH_LDP + k];
+        }
+        if (!(d > 0.0) || !isfinite(d)) fail = true;
+        double r = __builtin_amdgcn_rsq(d);
+        r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
+        r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
+        double dj = d * r;
+        dj = fma(0.5 * r, fma(-dj, dj, d), dj);
+        const double l = lane == c ? dj : sacc * r;
+        a[c] = lane >= c ? l : 0.0;
+        if (lane >= c && lane < CH_NB) L11[lane * CH_LDP + c] = a[c];
+        if (lane == c) L11[c * CH_LDP + CH_NB] = fma(r, fma(-dj, r, 1.0), r);          // reciprocal pivot in the padding column
+        wave_lds_sync();
+    }
+    if (__builtin_amdgcn_ballot_w64(fail) != 0) { if (lane == 0) ctl->lin_fail = 1; return; }
+    for (int e = lane; e < nb * nb; e += 64) {
+        const int i = e / nb, j = e - i * nb;
+        if (j <= i) S[(long long)(k0 + i) * ld + k0 + j] = L11[i * CH_LDP + j];
+    }
+    if (lane < CH_NB) {                                                 // inverse block: lane j solves L x = e_j
+        double x[CH_NB];
+#pragma unroll
+        for (int i = 0; i < CH_NB; i++) {
+            double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; k++) acc -= L11[i * CH_LDP + k] * x[k];
+            x[i] = i < lane ? 0.0 : acc * L11[i * CH_LDP + CH_NB];
+        }
+        double *dst = D.Linv + (long long)(k0 / CH_NB) * CH_NB * CH_NB;
+#pragma unroll
+        for (int i = 0; i < CH_NB; i++) dst[i * CH_NB + lane] = x[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_chol_panel(BADev D, int k0)
+{
+    const BACtl *ctl = D.ctl;
+    if (ctl->done || ctl->lin_fail) return;
+    __shared__ double L11[CH_NB * CH_LDP];
+    const int n = D.nf, ld = D.nfp, lane = threadIdx.x;
+    const int nb = min(CH_NB, n - k0), m = n - k0 - nb;
+    double *S = D.S;
+    for (int e = lane; e < CH_NB * CH_NB; e += 64) {
+        const int i = e >> 5, j = e & 31;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
+        L11[i * CH_LDP + j] = v;
+    }
+    wave_lds_sync();
+    const int t = blockIdx.x * 64 + lane;
+    if (t >= m) return;
+    double *row = S + (long long)(k0 + nb + t) * ld + k0;
+    double x[CH_NB];
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) {
+        double acc = x[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
+        x[j] = acc / L11[j * CH_LDP + j];
+    }
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) if (j < nb) row[j] = x[j];
+}
+
+__global__ __launch_bounds__(256) void k_chol_trail(BADev D, int k0)
+{
+    const BACtl *ctl = D.ctl;
+    if (ctl->done || ctl->lin_fail) return;
+    __shared__ double A[32][33], B[32][33];
+    const int n = D.nf, ld = D.nfp, tid = threadIdx.x;
+    const int nb = min(CH_NB, n - k0), m = n - k0 - nb;
+    // lower-triangular tile index -> (bi, bj), bj <= bi
+    int t = blockIdx.x, bi = 0;
+    while (t > bi) { t -= bi + 1; bi++; }
+    const int bj = t;
+    double *S = D.S;
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const int ia = bi * 32 + r, ib = bj * 32 + r;
+        A[r][c] = (ia < m && c < nb) ? S[(long long)(k0 + nb + ia) * ld + k0 + c] : 0.0;
+        B[r][c] = (ib < m && c < nb) ? S[(long long)(k0 + nb + ib) * ld + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    const int r0 = (tid >> 4) * 2, c0 = (tid & 15) * 2;                 // 2 x 2 outputs per thread
+    double acc[2][2] = {{0, 0}, {0, 0}};
+    for (int k = 0; k < 32; k++) {
+        const double a0 = A[r0][k], a1 = A[r0 + 1][k], b0 = B[c0][k], b1 = B[c0 + 1][k];
+        acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+            const int gi = bi * 32 + r0 + i, gj = bj * 32 + c0 + j;
+            if (gi < m && gj <= gi) S[(long long)(k0 + nb + gi) * ld + k0 + nb + gj] -= acc[i][j];
+        }
+}
+
+__global__ __launch_bounds__(512) void k_chol_solve(BADev D)
+{
+    const BACtl *ctl = D.ctl;
+    if (ctl->done || ctl->lin_fail) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *L11 = (double *)smem_raw;                       // CH_NB x CH_LDP
+    double *yv = L11 + CH_NB * CH_LDP;                      // nfp
+    __shared__ double s_red[32][33];
+    const int n = D.nf, tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < D.nfp; i += nt) yv[i] = i < n ? D.scale_f[i] * (D.bf[i] - D.v[i]) : 0.0;
+    __syncthreads();
+    chol_trisolve(D, L11, yv, s_red);
+    for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
 }
 
 // ---------------------------------------------------------------------------------- back substitution
@@ -1182,9 +1408,20 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
     double a1 = 0, a2 = 0, a3 = 0;
     for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
         if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) { if (lane == 0) D.yl[lm] = 0; continue; }
-        const double *wr = D.W + (long long)lm * D.nfp;
         double t = 0;
-        for (int c = lane; c < D.nfp; c += 64) t += wr[c] * sy[c];
+        if (D.big) {
+            // sparse W: anchor entry + one observer entry per residual block
+            const int beg = D.lm_ptr[lm], E = 1 + D.lm_ptr[lm + 1] - beg;
+            for (int e = lane; e < E; e += 64) {
+                int col; const double *w;
+                if (e == 0) { col = D.pose_col[D.lm_anchor[lm]]; w = D.wanc + (long long)6 * lm; }
+                else { const int k = beg + e - 1; col = D.res_type[k] == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[D.res_kf[k]]; w = D.wres + (long long)6 * k; }
+                if (col >= 0) for (int q = 0; q < 6; q++) t += w[q] * sy[col + q];
+            }
+        } else {
+            const double *wr = D.W + (long long)lm * D.nfp;
+            for (int c = lane; c < D.nfp; c += 64) t += wr[c] * sy[c];
+        }
         t = wave_sum(t);
         if (lane == 0) {
             const double s = D.scale_l[lm], ete = D.ete[lm], etb = D.etb[lm];
@@ -1659,6 +1896,13 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     BADev &D = dev->D;
     memset(&D, 0, sizeof(D));
     D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
+    {   // beyond what the LDS-resident lineariser / Cholesky hold (~95 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
+        const size_t lin_lds = 8 * (4 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+        const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
+        D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) ? 1 : 0;
+        if (const char *e = getenv("OV2_BA_BIG")) D.big = e[0] == '1' ? 1 : D.big;       // force the path on small problems (tests)
+        if (n_po > 0) D.big = 0;                                                          // pose-only blocks: single-pose problems
+    }
     const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
@@ -1667,7 +1911,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     const size_t o_x_pose = take(56 * (size_t)p->n_kf), o_c_pose = take(56 * (size_t)p->n_kf), o_x_RT = take(96 * (size_t)p->n_kf), o_c_RT = take(96 * (size_t)p->n_kf);
     const size_t o_x_lam = take(8 * nl), o_c_lam = take(8 * nl), o_scale_f = take(8 * (size_t)nfp), o_diag_f = take(8 * (size_t)nfp);
     const size_t o_scale_l = take(8 * nl), o_diag_l = take(8 * nl), o_ete = take(8 * nl), o_etb = take(8 * nl), o_cl = take(8 * nl), o_ce = take(8 * nl);
-    const size_t o_W = take(8 * nl * nfp), o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
+    const size_t o_W = take(D.big ? 256 : 8 * nl * nfp), o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
+    const size_t o_wres = take(D.big ? 48 * na : 256), o_wanc = take(D.big ? 48 * nl : 256);
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
@@ -1684,6 +1929,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     D.scale_l = (double *)(b + o_scale_l); D.diag_l = (double *)(b + o_diag_l); D.ete = (double *)(b + o_ete); D.etb = (double *)(b + o_etb);
     D.cl = (double *)(b + o_cl); D.ce = (double *)(b + o_ce); D.W = (double *)(b + o_W); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
     D.Linv = (double *)(b + o_Linv);
+    D.wres = (double *)(b + o_wres); D.wanc = (double *)(b + o_wanc);
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
     dev->lm_order = (int *)(b + o_lm_order);
@@ -1845,10 +2091,12 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
 
     // size limits first: nothing is created or enqueued for a problem this path cannot solve
     const int n_opt = D.nf / 6;
-    const size_t lin_lds = D.ldim == 3 ? 8 * (12 * (size_t)D.nfp + (size_t)n_opt * 27) + 64
+    const size_t lin_lds = D.big ? 8 * (4 * (size_t)LIN_RED) + 64
+                         : D.ldim == 3 ? 8 * (12 * (size_t)D.nfp + (size_t)n_opt * 27) + 64
                                        : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
-    const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
-    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95)");
+    const size_t chol_lds = D.big ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64       // k_chol_solve: scratch block + the solution vector
+                                  : 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
+    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95; 3-D point landmarks have no large-problem path)");
     OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~95 optimised keyframes)");
     {   // dynamic-LDS limits are per-function, process-wide attributes: raise them once to the hardware maximum (two
         // contexts solving problems of different size on two threads would otherwise race on them)
@@ -1867,7 +2115,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
                 }
                 return e;
             };
-            attr_err = raise((const void *)k_ba_linearize);
+            attr_err = raise((const void *)k_ba_linearize<false>);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_chol_solve);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize_xyz);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky);
         });
@@ -1922,7 +2171,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
 
     auto linearize = [&]() {
         if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks), dim3(256), lin_lds, s, D);
-        else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        else if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (size_t)n_opt * 27 * 8 + 16, s, D);
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
@@ -1965,8 +2215,21 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
-        if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
+        if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(ws_blocks), dim3(256), 0, s, D);
+        else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
         if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
+        if (D.big) {
+            for (int k0 = 0; k0 < D.nf; k0 += CH_NB) {
+                const int m = D.nf - k0 - std::min(CH_NB, D.nf - k0);
+                hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, D, k0);
+                if (m > 0) {
+                    const int mb = (m + 31) / 32;
+                    hipLaunchKernelGGL(k_chol_panel, dim3((m + 63) / 64), dim3(64), 0, s, D, k0);
+                    hipLaunchKernelGGL(k_chol_trail, dim3(mb * (mb + 1) / 2), dim3(256), 0, s, D, k0);
+                }
+            }
+            hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
+        } else
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         else hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);

@@ -212,12 +212,35 @@ def test_long_budget_stops_enqueuing_after_convergence(gpu_ctx, oracle):
     assert np.allclose(g2["poses"], g["poses"], atol=1e-12)
 
 
-def test_too_many_keyframes_is_reported(gpu_ctx):
-    """More optimised keyframes than the LDS-resident reduced system holds (~95): OV2_EUNSUPPORTED with a message, never a
-    silent skip (include/ov2slam_hip.h, DESIGN.md 'limits')."""
-    pb = synth.make_ba_problem(120, 600, 6, stereo=False, seed=1)
+def test_large_problem_path_matches_oracle(gpu_ctx, oracle, monkeypatch):
+    """More optimised keyframes than the LDS-resident reduced system holds (~95): the sparse-W / HBM-Cholesky path (BADev::big)
+    takes over -- a loop-closure fullBA is the realistic case.  It must follow the oracle like the small path does; it is also
+    forced onto small problems (OV2_BA_BIG=1) so that both paths are compared on the same inputs."""
+    pb = synth.make_ba_problem(120, 1500, 8, stereo=True, seed=1)
+    g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, max_iter=6))
+    r = oracle.ba_solve(pb, oracle.ba_default_options(max_iter=6))
+    _cmp(g, r, pb)
+    assert g["final_cost"] < 0.5 * g["initial_cost"]
+    monkeypatch.setenv("OV2_BA_BIG", "1")
+    for n_kf, n_lm, obs, stereo, seed in ((6, 40, 4, False, 1), (12, 400, 8, True, 3), (40, 1200, 20, False, 5)):
+        pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
+        for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
+            g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+            r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
+            _cmp(g, r, pb)
+    pb = synth.make_ba_problem(15, 800, 8, stereo=True, seed=7)               # the whole localBA protocol on the big path
+    g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
+    monkeypatch.delenv("OV2_BA_BIG")
+    s = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
+    assert np.array_equal(g["bad_obs"], s["bad_obs"]) and np.allclose(g["poses"], s["poses"], atol=1e-9)
+
+
+def test_too_many_keyframes_is_reported_for_point_landmarks(gpu_ctx):
+    """The 3-D-point parameterisation has no large-problem path: beyond ~95 optimised keyframes ov2_xyz_ba_solve returns
+    OV2_EUNSUPPORTED with a message, never a silent skip."""
+    pb = synth.make_xyz_ba_problem(120, 600, 4, stereo=False, seed=1)
     with pytest.raises(ov2slam_amd.Ov2Error) as e:
-        optimizer.solve(gpu_ctx, pb)
+        optimizer.solve_xyz(gpu_ctx, pb)
     assert e.value.code == -4 and "keyframes" in str(e.value)
 
 
