@@ -62,13 +62,19 @@ struct BADev {                    // device pointers + sizes (passed by value to
     // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
     // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
     int ldim;
-    // big = 1: more optimised keyframes than the LDS-resident path holds (~95).  W = E^T F is then kept SPARSE -- 6 doubles per
-    // residual block (its observer block) in wres, 6 per landmark (the anchor block) in wanc -- instead of a dense n_lm x nfp
-    // matrix, H / F^T b are accumulated with global atomics, the Schur complement by per-landmark block outer products
+    // big = 1: more optimised keyframes than the LDS-resident path holds (~90).  W = E^T F is then kept SPARSE: one 6-double
+    // "slot" per (landmark, optimised keyframe that sees or anchors it) in cww -- the anchor block and the left / right observer
+    // blocks of one keyframe share a slot -- instead of a dense n_lm x nfp matrix.  The anchor-observer blocks of H go to HBM with
+    // global atomics, the Schur complement is accumulated row block by row block in LDS from per-keyframe slot lists
     // (k_ba_schur_sparse) and the reduced system is factored by a multi-kernel blocked Cholesky on HBM (k_chol_*).
-    int big;
-    double *wres;                 // 6*n_act  [big]
-    double *wanc;                 // 6*n_lm   [big]
+    int big, n_cw;
+    double *cww;                  // 6*n_cw   slot values (zeroed by k_ba_zero_lin, filled by the lineariser)          [big]
+    int *cw_ptr;                  // n_lm+1   slots of a landmark                                                      [big]
+    int *cw_col;                  // n_cw     pose column of the slot
+    int *cw_lm;                   // n_cw     landmark of the slot
+    int *res_cw;                  // n_act    slot of the residual block's observer (-1: constant observer / right-anchor block)
+    int *lm_cwa;                  // n_lm     slot of the landmark's anchor (-1: constant anchor or no residual blocks)
+    int *kfl_ptr, *kfl_idx;       // n_opt+1, n_cw : slots by optimised keyframe
     double *ete6;                 // 6*n_lm   unscaled E^T E, upper triangle (xx xy xz yy yz zz)            [ldim 3]
     double *minv6;                // 6*n_lm   (S E^T E S + D^2)^-1, upper triangle                          [ldim 3]
     double *Wp;                   // 3*n_lm * nfp : rows L_c^T W_l with C_l = S M^-1 S = L_c L_c^T, so that
@@ -389,21 +395,22 @@ __device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, dou
 }
 
 // BIG: the sparse-W variant for reduced systems beyond the LDS-resident limit (BADev::big): nothing is aggregated in LDS but
-// the per-wave reduction scratch; pose-side blocks go to H / F^T b with global atomics, the landmark's W entries to wres / wanc.
+// the per-wave reduction scratch and the observers' diagonal blocks / F^T b; anchor-observer blocks go to H with global atomics,
+// the landmark's W entries to their slots in cww.
 template <bool BIG>
 __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__restrict__ lm_order)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->need_lin) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int n_opt = BIG ? 0 : D.nf / 6;
+    const int n_opt = D.nf / 6, n_hao = BIG ? 0 : n_opt * 36;      // BIG: no per-wavefront anchor-observer cache, no dense W row
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *wrow = (double *)smem_raw + wave * (BIG ? 0 : D.nfp);
     double *Hoo = (double *)smem_raw + 4 * (BIG ? 0 : D.nfp);
     double *bo = Hoo + n_opt * 21;
-    double *Hao = bo + n_opt * 6 + wave * n_opt * 36;
-    double *red = bo + n_opt * 6 + 4 * n_opt * 36 + wave * LIN_RED;
-    for (int e = threadIdx.x; e < n_opt * 27 + 4 * n_opt * 36; e += blockDim.x) Hoo[e] = 0;
+    double *Hao = bo + n_opt * 6 + wave * n_hao;
+    double *red = bo + n_opt * 6 + 4 * n_hao + wave * LIN_RED;
+    for (int e = threadIdx.x; e < n_opt * 27 + 4 * n_hao; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
 
     const int total_waves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         } else if (lane < 27) {
             if (dacc != 0.0) atomicAdd(&D.bf[ca + lane - 21], dacc);
         }
-        for (int e = lane; e < n_opt * 36; e += 64) {
+        for (int e = lane; e < n_hao; e += 64) {
             const double v = Hao[e];
             if (v != 0.0) {
                 const int ob = e / 36, r = e - ob * 36, d = r / 6, c = r - d * 6;     // (Ja^T Jo)[d][c]
@@ -505,12 +512,16 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                     }
                 }
                 if (BIG) {
-                    // sparse W: this block's observer entry (zero when the observer is constant / absent), H and F^T b straight to HBM
-                    for (int c = 0; c < 6; c++) D.wres[(long long)6 * k + c] = co >= 0 ? Jl[0] * Jo[c] + Jl[1] * Jo[6 + c] : 0.0;
+                    // sparse W: this block's observer entry joins its (landmark, keyframe) slot; the observer's diagonal block and
+                    // F^T b are aggregated in LDS as in the small path, only the anchor-observer block goes straight to HBM
                     if (co >= 0) {
+                        const int ob = co / 6;
+                        double *slot = D.cww + (long long)6 * D.res_cw[k];
+                        int t = 0;
                         for (int c = 0; c < 6; c++) {
-                            atomicAdd(&D.bf[co + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
-                            for (int d = c; d < 6; d++) atomicAdd(&D.H[(long long)(co + c) * D.nfp + co + d], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                            atomicAdd(&slot[c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);
+                            atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+                            for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
                             if (cae >= 0)
                                 for (int d = 0; d < 6; d++) h_add_upper(D.H, D.nfp, cae + d, co + c, Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c]);
                         }
@@ -561,7 +572,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         if (lane == 33) D.ete[lm] = tot;
         if (lane == 34) D.etb[lm] = tot;
         if (BIG) {
-            if (lane >= 27 && lane < 33) D.wanc[(long long)6 * lm + lane - 27] = ca >= 0 ? tot : 0.0;     // the landmark's anchor entry of W
+            const int sa = D.lm_cwa[lm];                                                             // the landmark's anchor entry of W
+            if (sa >= 0 && lane >= 27 && lane < 33) atomicAdd(&D.cww[(long long)6 * sa + lane - 27], tot);
         } else {
             if (ca >= 0 && lane >= 27 && lane < 33) wrow[ca + lane - 27] += tot;
             wave_lds_sync();
@@ -1204,46 +1216,80 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 }
 
 // ================================================================================== big path (BADev::big)
-// W^T C W and W^T (c E^T b) from the SPARSE W: one wavefront per landmark; its entries are the anchor block (wanc) and one
-// observer block per residual (wres).  Lane i owns entry i and walks over all entries j: G[col_i + a][col_j + b] += c w_i[a] w_j[b]
-// for every ordered pair, i.e. the full symmetric matrix (k_ba_assemble reads either triangle).  fp64 atomics into a dense
-// nfp x nfp G: ~36 E^2 per landmark -- the price of keeping the reduced system dense.
-__global__ __launch_bounds__(256) void k_ba_schur_sparse(BADev D)
+// clears what the big-path lineariser accumulates into (k_ba_decide leaves H alone on this path: one work-group clearing
+// nfp^2 doubles took 150 us at 300 keyframes)
+__global__ __launch_bounds__(256) void k_ba_zero_lin(BADev D)
+{
+    const BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->need_lin) return;
+    const long long nh = (long long)D.nfp * D.nfp, nw = (long long)6 * D.n_cw, stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nh; e += stride) D.H[e] = 0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nw; e += stride) D.cww[e] = 0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < D.nfp; e += stride) D.bf[e] = 0;
+}
+
+// W^T C W and W^T (c E^T b) from the SPARSE W.  G = sum_l c_l w_l w_l^T with w_l the landmark's slots; the row block of one
+// keyframe (6 x nfp doubles, <= 96 KB) is accumulated in LDS by the work-group(s) that own the keyframe: a wavefront takes one
+// of the keyframe's slots (landmark l, block w_i), stages the landmark's slot list (columns + blocks, <= 64 at a time) in its
+// LDS scratch, and lane (j, b) adds c w_i[a] w_j[b] for a = 0..5 with LDS fp64 atomics.  Only the blocks k_ba_assemble reads
+// are computed (tile of the column >= tile of the row, i.e. roughly the upper half: work-groups are issued first rows first,
+// longest first).  nsplit > 1 (few keyframes): several work-groups share a row block and flush it with global atomics.
+// First version: one wavefront per landmark, lane per entry, 36 E^2 GLOBAL atomics per landmark -- 44 ms per iteration on the
+// 50 KF x 10 k x 30 stereo problem, 50 ms at 300 KF (profiles/r2_ba_big_*).
+#define SS_WAVES 8
+__global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int nsplit)
 {
     const BACtl *ctl = D.ctl;
     if (ctl->done) return;
-    const int lane = threadIdx.x & 63;
-    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
-        const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
-        if (beg == end) continue;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int nfp = D.nfp, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *R = (double *)smem_raw;                                       // 6 x nfp
+    double *wsc = R + 6 * nfp + wave * (64 * 6);                          // this wavefront's staged slot blocks
+    int *csc = (int *)(R + 6 * nfp + SS_WAVES * 64 * 6) + wave * 64;      // ... and their columns
+    __shared__ double vacc[6];
+    for (int e = threadIdx.x; e < 6 * nfp; e += blockDim.x) R[e] = 0;
+    if (threadIdx.x < 6) vacc[threadIdx.x] = 0;
+    __syncthreads();
+    const int ob = blockIdx.x / nsplit, sp = blockIdx.x - ob * nsplit, ci = 6 * ob;
+    const int b0 = D.kfl_ptr[ob], b1 = D.kfl_ptr[ob + 1];
+    const int len = (b1 - b0 + nsplit - 1) / nsplit, e0 = b0 + sp * len, e1 = min(b1, e0 + len);
+    const int cmin = (ci / BA_TILE) * BA_TILE - 5;                        // blocks entirely left of the row's first tile are never read
+    double dv = 0;
+    for (int e = e0 + wave; e < e1; e += SS_WAVES) {
+        const int slot = D.kfl_idx[e], lm = D.cw_lm[slot];
         const double c = D.cl[lm], ce = c * D.etb[lm];
-        const int ca = D.pose_col[D.lm_anchor[lm]];
-        const int E = 1 + end - beg;                                    // entry 0 = anchor, entry e = residual beg + e - 1
-        auto entry = [&](int e, int &col, double *w) {
-            if (e == 0) { col = ca; for (int q = 0; q < 6; q++) w[q] = D.wanc[(long long)6 * lm + q]; }
-            else {
-                const int k = beg + e - 1;
-                col = D.res_type[k] == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[D.res_kf[k]];
-                for (int q = 0; q < 6; q++) w[q] = D.wres[(long long)6 * k + q];
+        const int j0 = D.cw_ptr[lm], j1 = D.cw_ptr[lm + 1];
+        double wi[6];
+        for (int q = 0; q < 6; q++) wi[q] = D.cww[(long long)6 * slot + q];
+        if (lane < 6) dv += ce * D.cww[(long long)6 * slot + lane];
+        for (int jb = j0; jb < j1; jb += 64) {
+            const int j = jb + lane, nj = min(64, j1 - jb);
+            wave_lds_sync();
+            if (j < j1) {
+                csc[lane] = D.cw_col[j];
+                for (int q = 0; q < 6; q++) wsc[lane * 6 + q] = D.cww[(long long)6 * j + q];
             }
-        };
-        for (int i0 = 0; i0 < E; i0 += 64) {
-            const int i = i0 + lane;
-            int ci = -1; double wi[6] = {0, 0, 0, 0, 0, 0};
-            if (i < E) entry(i, ci, wi);
-            if (ci >= 0) for (int a = 0; a < 6; a++) if (wi[a] != 0.0) atomicAdd(&D.v[ci + a], ce * wi[a]);
-            for (int j = 0; j < E; j++) {
-                int cj; double wj[6];
-                entry(j, cj, wj);                                       // same address in every lane: one broadcast load each
-                if (ci < 0 || cj < 0) continue;
-                for (int a = 0; a < 6; a++) {
-                    const double ca_w = c * wi[a];
-                    if (ca_w == 0.0) continue;
-                    for (int b = 0; b < 6; b++) atomicAdd(&D.G[(long long)(ci + a) * D.nfp + cj + b], ca_w * wj[b]);
-                }
+            wave_lds_sync();
+            for (int t = lane; t < nj * 6; t += 64) {
+                const int jj = t / 6, b = t - jj * 6, cj = csc[jj];
+                if (cj < cmin) continue;
+                const double wjb = c * wsc[t];
+                double *dst = R + cj + b;
+#pragma unroll
+                for (int a = 0; a < 6; a++) atomicAdd(&dst[a * nfp], wi[a] * wjb);
             }
         }
     }
+    if (lane < 6 && dv != 0.0) atomicAdd(&vacc[lane], dv);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 6 * nfp; e += blockDim.x) {
+        const double v = R[e];
+        if (v == 0.0) continue;
+        const int a = e / nfp, col = e - a * nfp;
+        double *g = &D.G[(long long)(ci + a) * nfp + col];
+        if (nsplit == 1) *g = v; else atomicAdd(g, v);
+    }
+    if (threadIdx.x < 6 && vacc[threadIdx.x] != 0.0) atomicAdd(&D.v[ci + threadIdx.x], vacc[threadIdx.x]);
 }
 
 // Blocked right-looking Cholesky of the reduced system on HBM, three kernels per 32-column panel:
@@ -1320,6 +1366,9 @@ __global__ __launch_bounds__(64) void k_chol_panel(BADev D, int k0)
     const BACtl *ctl = D.ctl;
     if (ctl->done || ctl->lin_fail) return;
     __shared__ double L11[CH_NB * CH_LDP];
+    __shared__ double X[64 * CH_LDP];                                   // the work-group's 64 panel rows (a thread's row stays in LDS: the fully
+                                                                        // unrolled register version made the scheduler hoist all 496 loads of L11
+                                                                        // -- 512 VGPRs, 624 spills -- and miscomputed from column 12 on)
     const int n = D.nf, ld = D.nfp, lane = threadIdx.x;
     const int nb = min(CH_NB, n - k0), m = n - k0 - nb;
     double *S = D.S;
@@ -1329,22 +1378,24 @@ __global__ __launch_bounds__(64) void k_chol_panel(BADev D, int k0)
         if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
         L11[i * CH_LDP + j] = v;
     }
-    wave_lds_sync();
-    const int t = blockIdx.x * 64 + lane;
-    if (t >= m) return;
-    double *row = S + (long long)(k0 + nb + t) * ld + k0;
-    double x[CH_NB];
-#pragma unroll
-    for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.0;
-#pragma unroll
+    const int t0 = blockIdx.x * 64;
+    for (int e = lane; e < 64 * CH_NB; e += 64) {                       // coalesced: 32 consecutive columns of one row per half wavefront
+        const int r = e >> 5, j = e & 31;
+        X[r * CH_LDP + j] = (t0 + r < m && j < nb) ? S[(long long)(k0 + nb + t0 + r) * ld + k0 + j] : 0.0;
+    }
+    __syncthreads();
+    double *x = X + lane * CH_LDP;
     for (int j = 0; j < CH_NB; j++) {
         double acc = x[j];
-#pragma unroll
-        for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
-        x[j] = acc / L11[j * CH_LDP + j];
+        const double *lr = L11 + j * CH_LDP;
+        for (int k = 0; k < j; k++) acc -= x[k] * lr[k];
+        x[j] = acc / lr[j];
     }
-#pragma unroll
-    for (int j = 0; j < CH_NB; j++) if (j < nb) row[j] = x[j];
+    __syncthreads();
+    for (int e = lane; e < 64 * CH_NB; e += 64) {
+        const int r = e >> 5, j = e & 31;
+        if (t0 + r < m && j < nb) S[(long long)(k0 + nb + t0 + r) * ld + k0 + j] = X[r * CH_LDP + j];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_chol_trail(BADev D, int k0)
@@ -1410,13 +1461,11 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
         if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) { if (lane == 0) D.yl[lm] = 0; continue; }
         double t = 0;
         if (D.big) {
-            // sparse W: anchor entry + one observer entry per residual block
-            const int beg = D.lm_ptr[lm], E = 1 + D.lm_ptr[lm + 1] - beg;
-            for (int e = lane; e < E; e += 64) {
-                int col; const double *w;
-                if (e == 0) { col = D.pose_col[D.lm_anchor[lm]]; w = D.wanc + (long long)6 * lm; }
-                else { const int k = beg + e - 1; col = D.res_type[k] == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[D.res_kf[k]]; w = D.wres + (long long)6 * k; }
-                if (col >= 0) for (int q = 0; q < 6; q++) t += w[q] * sy[col + q];
+            // sparse W: the landmark's slots
+            for (int j = D.cw_ptr[lm] + lane; j < D.cw_ptr[lm + 1]; j += 64) {
+                const int col = D.cw_col[j];
+                const double *w = D.cww + (long long)6 * j;
+                for (int q = 0; q < 6; q++) t += w[q] * sy[col + q];
             }
         } else {
             const double *wr = D.W + (long long)lm * D.nfp;
@@ -1580,6 +1629,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
 #pragma unroll 8
         for (int l = tid; l < D.n_lm * D.ldim; l += nt) x_lam[l] = c_lam[l];
     }
+    if (D.big) return;                                      // k_ba_zero_lin
     for (int e = tid; e < D.nfp * D.nfp; e += nt) D.H[e] = 0;
     for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
 }
@@ -1903,7 +1953,40 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
         if (const char *e = getenv("OV2_BA_BIG")) D.big = e[0] == '1' ? 1 : D.big;       // force the path on small problems (tests)
         if (n_po > 0) D.big = 0;                                                          // pose-only blocks: single-pose problems
     }
+    // big path: the slots of the sparse W (one per landmark and optimised keyframe seeing or anchoring it) and their per-keyframe lists
+    std::vector<int> cw_ptr(p->n_lm + 1, 0), cw_col, cw_lm, res_cw, lm_cwa, kfl_ptr(n_opt + 1, 0), kfl_idx;
+    if (D.big) {
+        res_cw.assign(std::max(1, n_act), -1); lm_cwa.assign(std::max(1, p->n_lm), -1);
+        std::vector<int> slot_of(std::max(1, n_opt), -1), touched;
+        for (int l = 0; l < p->n_lm; l++) {
+            cw_ptr[l] = (int)cw_col.size();
+            touched.clear();
+            auto get = [&](int col) {
+                const int ob = col / 6;
+                if (slot_of[ob] < 0) { slot_of[ob] = (int)cw_col.size(); cw_col.push_back(col); cw_lm.push_back(l); touched.push_back(ob); }
+                return slot_of[ob];
+            };
+            if (cnt[l] != cnt[l + 1]) {
+                const int ca = pose_col[p->lm_anchor_kf[l]];
+                if (ca >= 0) lm_cwa[l] = get(ca);
+                for (int k = cnt[l]; k < cnt[l + 1]; k++) {
+                    if (res_type[k] == OV2_RES_RIGHT_ANCH) continue;
+                    const int co = pose_col[res_kf[k]];
+                    if (co >= 0) res_cw[k] = get(co);
+                }
+            }
+            for (int ob : touched) slot_of[ob] = -1;
+        }
+        cw_ptr[p->n_lm] = (int)cw_col.size();
+        for (int c : cw_col) kfl_ptr[c / 6 + 1]++;
+        for (int k = 0; k < n_opt; k++) kfl_ptr[k + 1] += kfl_ptr[k];
+        kfl_idx.resize(cw_col.size());
+        std::vector<int> kfill(kfl_ptr.begin(), kfl_ptr.end() - 1);
+        for (size_t j = 0; j < cw_col.size(); j++) kfl_idx[kfill[cw_col[j] / 6]++] = (int)j;
+    }
+    D.n_cw = (int)cw_col.size();
     const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
+    const size_t ncw = (size_t)std::max(1, D.n_cw);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
     const size_t o_pose_col = take(4 * (size_t)p->n_kf), o_lm_ptr = take(4 * (nl + 1)), o_lm_anchor = take(4 * nl), o_lm_auv = take(16 * nl);
@@ -1912,7 +1995,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     const size_t o_x_lam = take(8 * nl), o_c_lam = take(8 * nl), o_scale_f = take(8 * (size_t)nfp), o_diag_f = take(8 * (size_t)nfp);
     const size_t o_scale_l = take(8 * nl), o_diag_l = take(8 * nl), o_ete = take(8 * nl), o_etb = take(8 * nl), o_cl = take(8 * nl), o_ce = take(8 * nl);
     const size_t o_W = take(D.big ? 256 : 8 * nl * nfp), o_H = take(8 * (size_t)nfp * nfp), o_G = take(8 * (size_t)nfp * nfp), o_S = take(8 * (size_t)nfp * nfp);
-    const size_t o_wres = take(D.big ? 48 * na : 256), o_wanc = take(D.big ? 48 * nl : 256);
+    const size_t o_cww = take(48 * ncw), o_cw_ptr = take(4 * (nl + 1)), o_cw_col = take(4 * ncw), o_cw_lm = take(4 * ncw);
+    const size_t o_res_cw = take(4 * na), o_lm_cwa = take(4 * nl), o_kfl_ptr = take(4 * ((size_t)n_opt + 1)), o_kfl_idx = take(4 * ncw);
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
@@ -1929,7 +2013,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     D.scale_l = (double *)(b + o_scale_l); D.diag_l = (double *)(b + o_diag_l); D.ete = (double *)(b + o_ete); D.etb = (double *)(b + o_etb);
     D.cl = (double *)(b + o_cl); D.ce = (double *)(b + o_ce); D.W = (double *)(b + o_W); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
     D.Linv = (double *)(b + o_Linv);
-    D.wres = (double *)(b + o_wres); D.wanc = (double *)(b + o_wanc);
+    D.cww = (double *)(b + o_cww); D.cw_ptr = (int *)(b + o_cw_ptr); D.cw_col = (int *)(b + o_cw_col); D.cw_lm = (int *)(b + o_cw_lm);
+    D.res_cw = (int *)(b + o_res_cw); D.lm_cwa = (int *)(b + o_lm_cwa); D.kfl_ptr = (int *)(b + o_kfl_ptr); D.kfl_idx = (int *)(b + o_kfl_idx);
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
     dev->lm_order = (int *)(b + o_lm_order);
@@ -1963,6 +2048,11 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     UP(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
     UP(D.po_kf, po_kf.data(), 4 * (size_t)n_po); UP(D.po_orig, po_orig.data(), 4 * (size_t)n_po);
     UP(D.po_xyz, po_xyz.data(), 24 * (size_t)n_po); UP(D.po_uv, po_uv.data(), 16 * (size_t)n_po); UP(D.po_sigma, po_sigma.data(), 8 * (size_t)n_po);
+    if (D.big) {
+        UP(D.cw_ptr, cw_ptr.data(), 4 * ((size_t)p->n_lm + 1)); UP(D.cw_col, cw_col.data(), 4 * (size_t)D.n_cw); UP(D.cw_lm, cw_lm.data(), 4 * (size_t)D.n_cw);
+        UP(D.res_cw, res_cw.data(), 4 * (size_t)n_act); UP(D.lm_cwa, lm_cwa.data(), 4 * (size_t)p->n_lm);
+        UP(D.kfl_ptr, kfl_ptr.data(), 4 * ((size_t)n_opt + 1)); UP(D.kfl_idx, kfl_idx.data(), 4 * (size_t)D.n_cw);
+    }
 #undef UP
     // the staging vectors die at return: make sure the copies are done
     OV2_HIP_CHECK(hipStreamSynchronize(s));
@@ -2091,7 +2181,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
 
     // size limits first: nothing is created or enqueued for a problem this path cannot solve
     const int n_opt = D.nf / 6;
-    const size_t lin_lds = D.big ? 8 * (4 * (size_t)LIN_RED) + 64
+    const size_t lin_lds = D.big ? 8 * ((size_t)(D.nf / 6) * 27 + 4 * (size_t)LIN_RED) + 64
                          : D.ldim == 3 ? 8 * (12 * (size_t)D.nfp + (size_t)n_opt * 27) + 64
                                        : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = D.big ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64       // k_chol_solve: scratch block + the solution vector
@@ -2117,6 +2207,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             };
             attr_err = raise((const void *)k_ba_linearize<false>);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_chol_solve);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize<true>);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_schur_sparse);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize_xyz);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky);
         });
@@ -2168,10 +2260,16 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     ksplit = std::max(1, (DG.n_lm + lm_per_split - 1) / lm_per_split);
     const int ws_blocks = std::max(1, std::min(512, std::max((D.n_lm + 3) / 4, (D.n_po + 255) / 256)));
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
+    // k_ba_schur_sparse: ~512 work-groups; row block + per-wavefront staging (64 slot blocks + columns)
+    const int ss_split = std::max(1, (512 + std::max(1, n_opt) - 1) / std::max(1, n_opt));
+    const size_t ss_lds = 8 * (6 * (size_t)D.nfp + (size_t)SS_WAVES * 64 * 6) + 4 * (size_t)SS_WAVES * 64 + 64;
 
     auto linearize = [&]() {
         if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks), dim3(256), lin_lds, s, D);
-        else if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        else if (D.n_lm > 0 && D.big) {
+            hipLaunchKernelGGL(k_ba_zero_lin, dim3(1024), dim3(256), 0, s, D);
+            hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        }
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (size_t)n_opt * 27 * 8 + 16, s, D);
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
@@ -2215,20 +2313,21 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
-        if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(ws_blocks), dim3(256), 0, s, D);
+        if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split);
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
         if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
         if (D.big) {
+            int budget = getenv("OV2_BA_CHOL_STAGES") ? atoi(getenv("OV2_BA_CHOL_STAGES")) : 1 << 30;      // debugging: stop the factorisation early
             for (int k0 = 0; k0 < D.nf; k0 += CH_NB) {
                 const int m = D.nf - k0 - std::min(CH_NB, D.nf - k0);
-                hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, D, k0);
+                if (budget-- > 0) hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, D, k0);
                 if (m > 0) {
                     const int mb = (m + 31) / 32;
-                    hipLaunchKernelGGL(k_chol_panel, dim3((m + 63) / 64), dim3(64), 0, s, D, k0);
-                    hipLaunchKernelGGL(k_chol_trail, dim3(mb * (mb + 1) / 2), dim3(256), 0, s, D, k0);
+                    if (budget-- > 0) hipLaunchKernelGGL(k_chol_panel, dim3((m + 63) / 64), dim3(64), 0, s, D, k0);
+                    if (budget-- > 0) hipLaunchKernelGGL(k_chol_trail, dim3(mb * (mb + 1) / 2), dim3(256), 0, s, D, k0);
                 }
             }
-            hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
+            if (budget > 0) hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
         } else
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
@@ -2254,6 +2353,23 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     r->iterations = h_ctl.n_steps; r->num_successful_steps = h_ctl.n_success;
     r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
     r->solve_ms = ms;
+    if (const char *dump = getenv("OV2_BA_DUMP")) {
+        // debugging aid: H, G, S (factor), bf, v, yf, etb, cl of the LAST iteration as raw doubles (nfp, then the arrays)
+        FILE *f = fopen(dump, "wb");
+        if (f) {
+            const size_t nn = (size_t)D.nfp * D.nfp;
+            std::vector<double> buf(std::max(nn, (size_t)std::max(1, D.n_lm)));
+            const double hdr[4] = {(double)D.nfp, (double)D.nf, (double)D.n_lm, (double)D.big};
+            fwrite(hdr, 8, 4, f);
+            const double *arrs[3] = {D.H, D.G, D.S};
+            for (int a = 0; a < 3; a++) { (void)hipMemcpy(buf.data(), arrs[a], 8 * nn, hipMemcpyDeviceToHost); fwrite(buf.data(), 8, nn, f); }
+            const double *vecs[3] = {D.bf, D.v, D.yf};
+            for (int a = 0; a < 3; a++) { (void)hipMemcpy(buf.data(), vecs[a], 8 * (size_t)D.nfp, hipMemcpyDeviceToHost); fwrite(buf.data(), 8, (size_t)D.nfp, f); }
+            const double *lv[3] = {D.etb, D.cl, D.yl};
+            for (int a = 0; a < 3; a++) { (void)hipMemcpy(buf.data(), lv[a], 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost); fwrite(buf.data(), 8, (size_t)D.n_lm, f); }
+            fclose(f);
+        }
+    }
     if (getenv("OV2_BA_DEBUG"))
         fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): copy-in %llu diag %llu panel %llu trail %llu solve %llu\n",
                 h_ctl.dbg[0], h_ctl.dbg[1], h_ctl.dbg[2], h_ctl.dbg[3], h_ctl.dbg[4]);
