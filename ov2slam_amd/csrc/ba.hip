@@ -1946,7 +1946,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     BADev &D = dev->D;
     memset(&D, 0, sizeof(D));
     D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
-    {   // beyond what the LDS-resident lineariser / Cholesky hold (~95 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
+    {   // beyond what the LDS-resident lineariser / Cholesky hold (~90 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
         const size_t lin_lds = 8 * (4 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
         const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
         D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) ? 1 : 0;
@@ -2186,8 +2186,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
                                        : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = D.big ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64       // k_chol_solve: scratch block + the solution vector
                                   : 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
-    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~95; 3-D point landmarks have no large-problem path)");
-    OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~95 optimised keyframes)");
+    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~90; 3-D point landmarks and pose-only blocks have no large-problem path)");
+    OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~90 optimised keyframes)");
     {   // dynamic-LDS limits are per-function, process-wide attributes: raise them once to the hardware maximum (two
         // contexts solving problems of different size on two threads would otherwise race on them)
         static std::once_flag attr_once;

@@ -15,7 +15,7 @@ for _ in range(3): g = rp.solve(o)
 print(g["iterations"], g["solve_ms"])
 PY
 OUT=$ROOT/gpurun_out/r2k
-(cd /tmp && OV2_BA_BIG=1 rocprofv3 --kernel-trace --stats -d $OUT/p50 -o p50 -- python /tmp/t.py 50 10000 30 > $OUT/p50.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/p300 -o p300 -- python /tmp/t.py 300 30000 20 > $OUT/p300.log 2>&1)
-for n in p50 p300; do tail -2 $OUT/$n.log; f=$(find $OUT/$n -name "*kernel_stats.csv" | head -1); head -14 $f | cut -c1-150; done
+(cd /tmp && OV2_BA_BIG=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p50 -o p50 -- python /tmp/t.py 50 10000 30 > $OUT/p50.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p300 -o p300 -- python /tmp/t.py 300 30000 20 > $OUT/p300.log 2>&1)
+for n in p50 p300; do tail -2 $OUT/$n.log; f=$(find $OUT/$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-150; done
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete
