@@ -233,7 +233,10 @@ def make_structure_problem(n_kf=12, n_pts=500, obs_per_pt=5, stereo=True, seed=7
         R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])           # camera-to-world
         t = np.array([10 * np.sin(th[k]), 0.05 * k, 10 - 10 * np.cos(th[k])])
         w = np.sqrt(max(0.0, 1 + np.trace(R))) / 2
-        q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+        if w > 0.1:
+            q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+        else:                                                       # near half a turn (keyframe 60 of the arc): half-angle form
+            q = np.array([0.0, np.sin(0.5 * th[k]), 0.0, np.cos(0.5 * th[k])])
         poses[k] = np.concatenate([t, q]); Rs.append(R)
     T_rl = np.array([-0.11, 0, 0, 0, 0, 0, 1.0])
     xyz_gt = np.zeros((n_pts, 3)); first = rng.integers(0, n_kf - obs_per_pt + 1, n_pts)

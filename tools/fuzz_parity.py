@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity campaign (run on the GPU box: python tools/fuzz_parity.py [n_cases] [seed]).
 Every case draws an image size, content, window / cell / tile parameters and point sets (including points on and
-beyond the borders) and demands bit-exact agreement for the integer/float32 front-end paths."""
+beyond the borders) and demands bit-exact agreement for the integer/float32 front-end paths; every few cases the
+single-sequence tracker (ov2_tracker_*: preprocessImage + kltTracking), the pyramid-resident detectors and random bundle
+adjustments (inverse depth, 3-D points, the large-problem path) are compared as well (BA: the tolerances of tests/test_gpu_ba.py)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,7 +16,7 @@ SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(SEED)
 ctx = ov2slam_amd.Context(0)
 trk = ov2slam_amd.FeatureTracker(ctx, 30, 0.01)
-fails = []
+fails, loose = [], []
 
 
 def rand_image(w, h, kind):
@@ -91,7 +93,76 @@ for case in range(N):
         g = fx.detectSingleScale(prev, cell, curk, roi)
         r, rq = O.detect_singlescale(prev, cell, curk, roi, q0, True)
         check("singlescale", np.array_equal(g.view(np.uint32), r.view(np.uint32)) and fx.dmaxquality_ == rq, dict(info, cell=cell, q=q0))
+    # ---- pyramid-resident detectors: the same answer as on the host image ----
+    if w >= 120 and h >= 120 and case % 3 == 0:
+        P0 = ov2slam_amd.Pyramid(ctx, w, h, 9, 0).build(prev)
+        fa = ov2slam_amd.FeatureExtractor(ctx, nfast_th=th0, dmaxquality=q0); fb = ov2slam_amd.FeatureExtractor(ctx, nfast_th=th0, dmaxquality=q0)
+        ga, gb = fa.detectGridFAST(prev, cell, curk), fb.detectGridFASTPyr(P0, cell, curk)
+        check("grid_fast_d", np.array_equal(ga.view(np.uint32), gb.view(np.uint32)) and fa.nfast_th_ == fb.nfast_th_, dict(info, cell=cell))
+        ga, gb = fa.detectSingleScale(prev, cell, curk, roi), fb.detectSingleScalePyr(P0, cell, curk, roi)
+        check("singlescale_d", np.array_equal(ga.view(np.uint32), gb.view(np.uint32)) and fa.dmaxquality_ == fb.dmaxquality_, dict(info, cell=cell))
+    # ---- single-sequence tracker: preprocessImage + kltTracking (visual_front_end.cpp:1143-1177, :132-275) ----
+    if w >= 150 and h >= 150 and case % 2 == 0:
+        use_clahe = bool(rng.integers(0, 2)); clipv = float(rng.choice([1.0, 3.0, 8.0]))
+        t = ov2slam_amd.VisualFrontEndTracker(ctx, w, h, use_clahe=use_clahe, fclahe_val=clipv, nbmaxkps=512, use_graph=bool(rng.integers(0, 2)))
+        t.trackFrame(prev, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+        nk = int(rng.integers(1, 500))
+        tk = np.stack([rng.uniform(-4, w + 4, nk), rng.uniform(-4, h + 4, nk)], 1).astype(np.float32)
+        hp = (rng.uniform(size=nk) < rng.uniform(0, 1)).astype(np.uint8)
+        tp = np.where(hp[:, None] > 0, tk - shift + rng.normal(0, rng.choice([0.5, 3.0, 15.0]), tk.shape), tk).astype(np.float32)
+        use_prior = bool(rng.integers(0, 4))
+        if use_prior:
+            go, gs, gp3p = t.trackFrame(cur, tk, tp, hp)
+        else:
+            t.preprocessImage(cur); go, gs, gp3p = t.kltTracking(tk, tp, hp, klt_use_prior=False)
+        a, b = (O.clahe(prev, clipv, w // 50, h // 50), O.clahe(cur, clipv, w // 50, h // 50)) if use_clahe else (prev, cur)
+        ro, rok, rretry, rp3p = O.klt_tracking(O.Pyramid(a, 9, 3), O.Pyramid(b, 9, 3), tk, tp, hp, klt_use_prior=use_prior)
+        check("tracker", gp3p == rp3p and np.array_equal((gs & 1).astype(bool), rok) and np.array_equal((gs & 2).astype(bool), rretry)
+              and np.array_equal(np.ascontiguousarray(go, np.float32).view(np.uint32), np.ascontiguousarray(ro, np.float32).view(np.uint32)),
+              dict(info, n=nk, clahe=use_clahe, prior=use_prior))
+        t.close()
+    # ---- bundle adjustment: random small problems, both landmark forms, both problem-size paths ----
+    if case % 4 == 0:
+        from ov2slam_amd import optimizer
+        n_kf, obs = int(rng.integers(3, 30)), int(rng.integers(2, 12))
+        n_lm, stereo, bseed = int(rng.integers(20, 600)), bool(rng.integers(0, 2)), int(rng.integers(1 << 20))
+        kw = [dict(), dict(max_iter=10, huber_delta=-1.0), dict(max_iter=12, function_tolerance=1e-9)][int(rng.integers(0, 3))]
+        binfo = dict(case=case, n_kf=n_kf, n_lm=n_lm, obs=obs, stereo=stereo, seed=bseed, kw=kw)
+
+        def ba_diff(g, r, key):
+            return dict(it=(g["iterations"], r["iterations"]), term=(g["termination"], r["termination"]), ok_steps=(g["num_successful_steps"], r["num_successful_steps"]),
+                        cost0=r["initial_cost"], cost=(g["final_cost"], r["final_cost"]), dpos=float(np.abs(g["poses"][:, :3] - r["poses"][:, :3]).max()),
+                        dlm=float(np.abs(g[key] - r[key]).max()))
+
+        def ba_close(g, r, key, k=1.0):
+            scale = max(1e-9, np.abs(r["poses"][:, :3]).max())
+            qg = g["poses"][:, 3:] * np.sign((g["poses"][:, 3:] * r["poses"][:, 3:]).sum(1))[:, None]
+            m = np.isfinite(r["chi2"])
+            return (g["iterations"] == r["iterations"] and g["termination"] == r["termination"] and g["num_successful_steps"] == r["num_successful_steps"]
+                    and abs(g["final_cost"] - r["final_cost"]) <= k * 1e-8 * abs(r["final_cost"]) + 1e-12
+                    and np.abs(g["poses"][:, :3] - r["poses"][:, :3]).max() <= k * 1e-7 * scale and np.abs(qg - r["poses"][:, 3:]).max() <= k * 1e-7
+                    and np.allclose(g[key], r[key], rtol=k * 1e-6, atol=k * 1e-9) and np.array_equal(np.isfinite(g["chi2"]), m)
+                    and np.allclose(g["chi2"][m], r["chi2"][m], rtol=k * 1e-6, atol=k * 1e-9))
+
+        def ba_check(name, g, r, key):
+            # tight = the tolerances of tests/test_gpu_ba.py (well-posed problems); random draws include barely constrained ones
+            # (mono, 2 observations per point, not converged at max_iter) where summation order shows at 1e-7: those are
+            # counted separately against 100x the tolerance and listed, anything beyond that is a mismatch
+            if ba_close(g, r, key): return
+            if ba_close(g, r, key, 100.0):
+                loose.append((name, dict(binfo, **ba_diff(g, r, key)))); print("LOOSE", name, loose[-1][1], flush=True)
+            else: check(name, False, dict(binfo, **ba_diff(g, r, key)))
+        pb = synth.make_ba_problem(n_kf, n_lm, min(obs, n_kf), stereo=stereo, seed=bseed)
+        r = O.ba_solve(pb, O.ba_default_options(**kw))
+        for big in ("0", "1"):
+            os.environ["OV2_BA_BIG"] = big
+            g = optimizer.solve(ctx, pb, optimizer.default_options(ctx.lib, **kw))
+            ba_check("ba_invdepth_big" + big, g, r, "invdepth")
+        os.environ.pop("OV2_BA_BIG", None)
+        pb = synth.make_xyz_ba_problem(n_kf, n_lm, min(obs, n_kf), stereo=stereo, seed=bseed)
+        g = optimizer.solve_xyz(ctx, pb, optimizer.default_options(ctx.lib, **kw)); r = O.xyz_ba_solve(pb, O.ba_default_options(**kw))
+        ba_check("ba_xyz", g, r, "xyz")
     if (case + 1) % 10 == 0:
         print("case %d/%d  %.0f s  mismatches so far: %d" % (case + 1, N, time.time() - t0, len(fails)), flush=True)
-print("FUZZ DONE: %d cases, %d mismatches" % (N, len(fails)))
+print("FUZZ DONE: %d cases, %d mismatches, %d BA solves within 100x but not 1x the test tolerance" % (N, len(fails), len(loose)))
 sys.exit(1 if fails else 0)
