@@ -34,6 +34,57 @@ __device__ __forceinline__ int d_reflect101(int p, int len)
 }
 
 // ---------------------------------------------------------------------------------
+// per-cell selection candidates (computed by the cell kernels while the response map is still in LDS)
+// ---------------------------------------------------------------------------------
+// The selection sweep (k_grid_select) is a dependent chain over the cells; what a cell would select if NO earlier disc
+// reached into it does not depend on the chain and is computed here, in parallel over all cells:
+//   p1 / v1 : first maximum of the response in raster order (minMaxLoc; FAST: among the corners the mask mode can select at all)
+//   p2 / v2 : [single scale] first maximum outside the disc cv::circle would draw around p1
+// An exclusion mask only ever removes candidates (masked responses become 0), so when p1 (p2) is positive and its mask bit is
+// still set when the sweep reaches the cell, it IS the masked arg-max -- the sweep then costs two LDS bit tests per cell instead
+// of a load batch and two arg-max passes, and falls back to the full scan otherwise.
+struct CellCand { int p1; float v1; int p2; float v2; };      // p = ly * cs + lx, -1: none
+
+// wave-wide arg-max of (value, smaller index wins ties); all 64 lanes participate
+__device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// midpoint circle half-widths (drawing.cpp Circle()): rows +-dy get dx, rows +-dx get dy; hw[0..63], -1 = row not touched
+__device__ __forceinline__ void d_circle_halfwidths(int *hw, int radius)
+{
+    for (int k = 0; k < 64; k++) hw[k] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > hw[dy]) hw[dy] = dx;
+        if (dy > hw[dx]) hw[dx] = dy;
+        dy++; err += plus; plus += 2;
+        const int m = (err <= 0) - 1;
+        err -= minus & m; dx += m; minus -= m & 2;
+    }
+}
+
+__device__ __forceinline__ void block_argmax_f(float &v, int &idx, float *s_v, int *s_i)
+{
+    wave_argmax_f(v, idx);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) { s_v[wave] = v; s_i[wave] = idx; }
+    __syncthreads();
+    v = s_v[0]; idx = s_i[0];
+    for (int k = 1; k < nw; k++) {
+        const float ov = s_v[k]; const int oi = s_i[k];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // FAST-9/16 + score + 3x3 NMS on the cs x cs sub-image of every cell (cv::FAST semantics)
 // out: per cell cs*cs bytes, NMS-surviving corners hold their score (>0), everything else 0
 // ---------------------------------------------------------------------------------
@@ -41,10 +92,13 @@ __constant__ int c_fast_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3,
 __constant__ int c_fast_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
-                                                    int cs, int nwcells, int threshold, uint8_t *__restrict__ nms_out)
+                                                    int cs, int nwcells, int threshold, uint8_t *__restrict__ nms_out,
+                                                    int mask_mode, CellCand *__restrict__ cand_out)
 {
     __shared__ uint8_t tile[DET_MAX_CELL * DET_MAX_CELL];
     __shared__ uint8_t score[DET_MAX_CELL * DET_MAX_CELL];
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
     const int cell = blockIdx.x;
     const int x0 = (cell % nwcells) * cs, y0 = (cell / nwcells) * cs;
     const int npx = cs * cs;
@@ -104,7 +158,19 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
                    s > score[p - cs + 1] && s > score[p + cs - 1] && s > score[p + cs] && s > score[p + cs + 1];
         }
         out[lx * cs + ly] = keep ? (uint8_t)s : 0;            // column-major: k_grid_select reads a row per lane, coalesced
+        tile[p] = keep ? (uint8_t)s : 0;                      // (the cell's pixels are no longer needed)
     }
+    __syncthreads();
+    // candidate: the best corner the selection could take from an untouched mask.  AS_EXECUTED reads the CV_32F ones-mask
+    // as bytes (N3): only pixels with (lx & 3) >= 2 ever see a non-zero byte
+    float bv = 0.f; int bi = 0x7FFFFFFF;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int ly = p / cs, lx = p - ly * cs;
+        const float v = (float)tile[p];
+        if ((mask_mode != OV2_MASK_AS_EXECUTED || (lx & 3) >= 2) && v > bv) { bv = v; bi = p; }
+    }
+    block_argmax_f(bv, bi, s_v, s_i);
+    if (threadIdx.x == 0) { CellCand cd; cd.p1 = bv > 0.f ? bi : -1; cd.v1 = bv; cd.p2 = -1; cd.v2 = 0.f; cand_out[cell] = cd; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -112,9 +178,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 // Sobel/3060 -> (dx^2, dxdy, dy^2) -> 3x3 box (double sums, sliding column) -> lambda_min
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
-                                                      int cs, int nwcells, float *__restrict__ hmap_out, int dy_order)
+                                                      int cs, int nwcells, float *__restrict__ hmap_out, int dy_order,
+                                                      int radius, CellCand *__restrict__ cand_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ int s_hw[64];
     const int npx = cs * cs;
     // carve: rows (double 3*npx) | dxm (float npx) | dym (float npx) | cov (float 3*npx) | blur (u8 npx)
     double *rows = (double *)smem;
@@ -192,8 +262,27 @@ __global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict_
     for (int p = threadIdx.x; p < npx; p += blockDim.x) {
         const float a = cov[3 * p] * 0.5f, b = cov[3 * p + 1], c = cov[3 * p + 2] * 0.5f;
         const int ly = p / cs, lx = p - ly * cs;
-        out[lx * cs + ly] = (a + c) - sqrtf((a - c) * (a - c) + b * b);            // column-major (see k_fast_cells)
+        const float lam = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        out[lx * cs + ly] = lam;                                                   // column-major (see k_fast_cells)
+        dxm[p] = lam;                                                              // row-major copy for the candidates below
     }
+    if (threadIdx.x == 0) d_circle_halfwidths(s_hw, radius);
+    __syncthreads();
+    // candidates: first maximum (raster order), and first maximum outside the disc around it
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) { const float v = dxm[p]; if (v > bv) { bv = v; bi = p; } }
+    block_argmax_f(bv, bi, s_v, s_i);
+    const int p1y = bi / cs, p1x = bi - p1y * cs;
+    float bv2 = -INFINITY; int bi2 = 0x7FFFFFFF;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int ly = p / cs, lx = p - ly * cs;
+        const int ady = ly > p1y ? ly - p1y : p1y - ly, adx = lx > p1x ? lx - p1x : p1x - lx;
+        const bool in_disc = ady <= radius && s_hw[ady < 64 ? ady : 63] >= 0 && adx <= s_hw[ady < 64 ? ady : 63];
+        const float v = dxm[p];
+        if (!in_disc && v > bv2) { bv2 = v; bi2 = p; }
+    }
+    block_argmax_f(bv2, bi2, s_v, s_i);
+    if (threadIdx.x == 0) { CellCand cd; cd.p1 = bi; cd.v1 = bv; cd.p2 = bi2 == 0x7FFFFFFF ? -1 : bi2; cd.v2 = bv2; cand_out[cell] = cd; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -248,32 +337,23 @@ __device__ __forceinline__ int mask_test(const unsigned *mask, int wpr, int x, i
     return (mask[y * wpr + (x >> 5)] >> (x & 31)) & 1u;
 }
 
-// wave-wide arg-max of (value, smaller index wins ties); all 64 lanes participate
-__device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(idx, off, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-}
-
 // MODE 0 = FAST scores (bytes), 1 = min-eigenvalue (floats); a cell row (<= MAXROW * CHUNKS columns) is held in registers
 // MAXROW columns at a time: (36,1) and (52,1) cover the reference cell sizes with compile-time column indices, (32,2) the rest
 template <int MODE, int MAXROW, int CHUNKS>
 __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
-                                                      const float *__restrict__ hmaps,
+                                                      const float *__restrict__ hmaps, const CellCand *__restrict__ cand,
                                                       float2 *__restrict__ out_xy, SelectOut *__restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned *mask = (unsigned *)smem;                                   // h * wpr words
     const int mask_words = P.h * P.mask_words_per_row;
-    int *hw = (int *)(mask + mask_words);                                // radius+1 (padded to 64)
-    uint8_t *occ = (uint8_t *)(hw + 64);                                 // (nh+1)*(nw+1)
-    const int nocc = (P.nhcells + 1) * (P.nwcells + 1);
     const int ncells = P.nhcells * P.nwcells;
+    int *hw = (int *)(mask + mask_words);                                // radius+1 (padded to 64)
+    int *s_cand = hw + 64;                                               // 4 * ncells: the cells' candidates (CellCand as 4 dwords)
+    int *progress = s_cand + 4 * ncells;                                 // nhcells: cells completed in each row of cells
+    uint8_t *occ = (uint8_t *)(progress + P.nhcells);                    // (nh+1)*(nw+1)
+    const int nocc = (P.nhcells + 1) * (P.nwcells + 1);
     // per-cell results (cell order): prim/sec as packed (x | y << 16), -1 = none
     int *prim = (int *)(occ + ((nocc + 3) & ~3));
     int *sec = prim + ncells;
@@ -282,30 +362,12 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
 
     unsigned long long tk0 = wall_clock64();
-    // Warm this XCD's L2 with the response maps: they were written by workgroups on all 8 XCDs, so every cell the sweep
-    // touches would otherwise be a fabric / HBM round trip sitting on the dependent chain of steps (1.3 MB for EuRoC).
-    {
-        const size_t map_bytes = (size_t)ncells * P.cs * P.cs * (MODE == 0 ? 1 : 4);
-        const uint4 *mp = (const uint4 *)(MODE == 0 ? (const void *)nms_maps : (const void *)hmaps);
-        unsigned acc = 0;
-        for (size_t i = tid; i < map_bytes / 16; i += nthreads) { const uint4 v = mp[i]; acc |= v.x ^ v.y ^ v.z ^ v.w; }
-        if (acc == 0x9E3779B9u && P.w < 0) out->n = (int)acc;            // never true: keeps the loads alive
-    }
+    for (int i = tid; i < 4 * ncells; i += nthreads) s_cand[i] = ((const int *)cand)[i];
+    for (int i = tid; i < P.nhcells; i += nthreads) progress[i] = 0;
     for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
     for (int i = tid; i < ncells; i += nthreads) { prim[i] = -1; sec[i] = -1; }
-    if (tid == 0) {
-        // midpoint circle half-widths (drawing.cpp Circle()): rows +-dy get dx, rows +-dx get dy
-        for (int k = 0; k < 64; k++) hw[k] = -1;
-        int err = 0, dx = P.radius, dy = 0, plus = 1, minus = (P.radius << 1) - 1;
-        while (dx >= dy) {
-            if (dx > hw[dy]) hw[dy] = dx;
-            if (dy > hw[dx]) hw[dx] = dy;
-            dy++; err += plus; plus += 2;
-            const int m = (err <= 0) - 1;
-            err -= minus & m; dx += m; minus -= m & 2;
-        }
-    }
+    if (tid == 0) d_circle_halfwidths(hw, P.radius);
     __syncthreads();
     const unsigned long long tk1 = wall_clock64();
     // prologue (:296-319 / :451-474): occupancy + exclusion discs of the current keypoints
@@ -322,21 +384,31 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
 
     const unsigned long long tk2 = wall_clock64();
     const int npx = P.cs * P.cs;
-    const int nsteps = 2 * (P.nhcells - 1) + P.nwcells;
-    for (int t = 0; t < nsteps; t++) {
-        // cells on this anti-diagonal: (r, c = t - 2r)
-        for (int r = wave; r < P.nhcells; r += nwaves) {
-            const int c = t - 2 * r;
-            if (c < 0 || c >= P.nwcells) continue;                       // wave-uniform
+    // The sweep.  Wavefront w walks along cell rows w, w + 16, ...; cell (r, c) may start when cells (r - 1, <= c + 1) are done
+    // (the discs of an accepted point reach the 8 neighbouring cells only) -- a per-row progress counter in LDS, no
+    // work-group barrier: a cell that needs the full scan delays its dependants only.  Bit-identical to raster order.
+    for (int r = wave; r < P.nhcells; r += nwaves) {
+        for (int c = 0; c < P.nwcells; c++) {
+            if (r > 0) {
+                const int need = min(c + 2, P.nwcells);
+                while (__hip_atomic_load(&progress[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            do {
             const int cell = r * P.nwcells + c;
-            if (occ[r * (P.nwcells + 1) + c]) continue;
+            if (occ[r * (P.nwcells + 1) + c]) break;
             const int x0 = c * P.cs, y0 = r * P.cs;
-            if (!(x0 + P.cs < P.w - 1 && y0 + P.cs < P.h - 1)) continue;  // :350 / :510
-            // Lane ly owns row ly of the cell (cs <= 64): its slice of the exclusion mask is ONE 64-bit string
-            // (bit j <-> pixel x0 + j), the response map is column-major so that the loads of a column are
-            // coalesced, and a pixel costs ~7 instructions instead of ~35 (the sweep is a dependent chain of
-            // single-CU steps: instruction count per cell is what it costs).  Raster-order tie-breaking: strict
-            // `>` along the row, then the smaller pixel index in the wave-wide arg-max.
+            if (!(x0 + P.cs < P.w - 1 && y0 + P.cs < P.h - 1)) break;    // :350 / :510
+            // the cell's candidates (wave-uniform)
+            const int c_p1 = __builtin_amdgcn_readfirstlane(s_cand[4 * cell]), c_p2 = __builtin_amdgcn_readfirstlane(s_cand[4 * cell + 2]);
+            const float c_v1 = __int_as_float(__builtin_amdgcn_readfirstlane(s_cand[4 * cell + 1]));
+            const float c_v2 = __int_as_float(__builtin_amdgcn_readfirstlane(s_cand[4 * cell + 3]));
+            const int p1y = c_p1 >= 0 ? c_p1 / P.cs : 0, p1x = c_p1 >= 0 ? c_p1 - p1y * P.cs : 0;
+            const int p2y = c_p2 >= 0 ? c_p2 / P.cs : 0, p2x = c_p2 >= 0 ? c_p2 - p2y * P.cs : 0;
+            // Full scan (a candidate was masked): lane ly owns row ly of the cell (cs <= 64): its slice of the exclusion
+            // mask is ONE 64-bit string (bit j <-> pixel x0 + j), the response map is column-major so that the loads of a
+            // column are coalesced.  Raster-order tie-breaking: strict `>` along the row, then the smaller pixel index in
+            // the wave-wide arg-max.
             const int ly = lane;
             const bool row_ok = ly < P.cs;
             const int rowbase = ly * P.cs;
@@ -348,13 +420,13 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 const unsigned long long hi = (unsigned long long)mr[min(w0 + 2, last)];
                 return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
             };
-            // The row of responses goes to registers in ONE batch of loads per chunk of MAXROW columns (the sweep is a
-            // chain of dependent steps and a global round trip costs ~2 us).  Cells up to MAXROW pixels wide -- every
-            // reference configuration -- need one chunk, loaded once for both arg-max passes; wider cells (<= 64) take
-            // two chunks per pass.  Columns >= cs (and lanes >= cs) hold NaN: every comparison with them is false, so
-            // the inner loops carry no per-pixel bounds predicates.
+            // The row of responses goes to registers in ONE batch of loads per chunk of MAXROW columns.  Cells up to MAXROW
+            // pixels wide -- every reference configuration -- need one chunk, loaded once for both arg-max passes; wider
+            // cells (<= 64) take two chunks per pass.  Columns >= cs (and lanes >= cs) hold NaN: every comparison with
+            // them is false, so the inner loops carry no per-pixel bounds predicates.
             float curv[MAXROW];
             constexpr bool single = CHUNKS == 1;
+            bool have = false;
             const long long cbase = (long long)cell * npx + (row_ok ? ly : 0);
             const float qnan = __builtin_nanf("");
 #define SEL_LOAD_CHUNK(JB)                                                                                       \
@@ -363,24 +435,29 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 const float v = MODE == 0 ? (float)nms_maps[cbase + qc * P.cs] : hmaps[cbase + qc * P.cs];       \
                 curv[q] = (row_ok && col < P.cs) ? v : qnan;                                                     \
             }
-            if (single) { SEL_LOAD_CHUNK(0) }
             if (MODE == 0) {
-                // best response among the mask-surviving FAST corners, raster order on ties
-                const unsigned long long mb = row_mask(x0);
-                float bv = 0.f; int bi = 0x7FFFFFFF;                      // score 0 = no corner: never selected (strict >)
+                if (c_p1 < 0) break;                                      // no selectable corner whatever the mask says
+                float bv = 0.f; int bi = 0x7FFFFFFF;
+                // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
+                const int mcol = P.mask_mode == OV2_MASK_AS_EXECUTED ? (p1x >> 2) : p1x;
+                if (mask_test(mask, P.mask_words_per_row, x0 + mcol, y0 + p1y)) { bv = c_v1; bi = c_p1; }
+                else {
+                    // best response among the mask-surviving FAST corners, raster order on ties
+                    const unsigned long long mb = row_mask(x0);
+                    if (single) { SEL_LOAD_CHUNK(0) }
 #pragma unroll
-                for (int ch = 0; ch < CHUNKS; ch++) {
-                    const int jb = ch * MAXROW;
-                    if (!single) { SEL_LOAD_CHUNK(jb) }
+                    for (int ch = 0; ch < CHUNKS; ch++) {
+                        const int jb = ch * MAXROW;
+                        if (!single) { SEL_LOAD_CHUNK(jb) }
 #pragma unroll
-                    for (int q = 0; q < MAXROW; q++) {
-                        const int lx = jb + q;
-                        // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
-                        const unsigned long long bit = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) ? (mb >> (lx >> 2)) : 0ull) : (mb >> (lx & 63));
-                        if ((bit & 1ull) && curv[q] > bv) { bv = curv[q]; bi = rowbase + lx; }   // NaN (padding) compares false
+                        for (int q = 0; q < MAXROW; q++) {
+                            const int lx = jb + q;
+                            const unsigned long long bit = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) ? (mb >> (lx >> 2)) : 0ull) : (mb >> (lx & 63));
+                            if ((bit & 1ull) && curv[q] > bv) { bv = curv[q]; bi = rowbase + lx; }   // NaN (padding) compares false
+                        }
                     }
+                    wave_argmax_f(bv, bi);
                 }
-                wave_argmax_f(bv, bi);
                 if (bv >= 20.f) {                                         // :521
                     const int my = bi / P.cs, mx = bi - my * P.cs;
                     const int px = x0 + mx, py = y0 + my;
@@ -388,11 +465,11 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                     mask_draw_circle(mask, P, hw, px, py, lane, 64);      // :527
                 }
             } else {
-                bool stop = false;
-                for (int pass = 0; pass < 2 && !stop; pass++) {
+                // minMaxLoc of response * mask: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: no index)
+                auto scan = [&](float &bv, int &bi) {
                     const unsigned long long mb = row_mask(x0);
-                    // minMaxLoc: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: no index)
-                    float bv = -FLT_MAX; int bi = 0x7FFFFFFF;
+                    bv = -FLT_MAX; bi = 0x7FFFFFFF;
+                    if (single && !have) { SEL_LOAD_CHUNK(0) have = true; }
 #pragma unroll
                     for (int ch = 0; ch < CHUNKS; ch++) {
                         const int jb = ch * MAXROW;
@@ -406,23 +483,38 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                         }
                     }
                     wave_argmax_f(bv, bi);
-                    const int my_ = bi / P.cs, mx_ = bi - my_ * P.cs;
-                    const int mx = x0 + mx_, my = y0 + my_;
-                    if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) {
-                        stop = true;                                      // `continue` at :363-368 / :379-384
-                    } else if ((double)bv >= P.quality) {
-                        if (lane == 0) { if (pass == 0) prim[cell] = mx | (my << 16); else sec[cell] = mx | (my << 16); }
-                        mask_draw_circle(mask, P, hw, mx, my, lane, 64);
-                        // make the disc visible to this wave's second pass
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    }
+                };
+                float bv; int bi;
+                // pass 0
+                const bool f0 = c_v1 > 0.f && mask_test(mask, P.mask_words_per_row, x0 + p1x, y0 + p1y);
+                if (f0) { bv = c_v1; bi = c_p1; } else scan(bv, bi);
+                int my_ = bi / P.cs, mx_ = bi - my_ * P.cs;
+                int mx = x0 + mx_, my = y0 + my_;
+                if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) break;   // `continue` at :363-368
+                if (!((double)bv >= P.quality)) break;                    // nothing accepted: the second minMaxLoc sees the same mask and value
+                if (lane == 0) prim[cell] = mx | (my << 16);
+                mask_draw_circle(mask, P, hw, mx, my, lane, 64);
+                // make the disc visible to this wave's second pass
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // pass 1: the candidate outside the disc just drawn, if the first pass took its candidate
+                const bool f1 = f0 && c_p2 >= 0 && c_v2 > 0.f && mask_test(mask, P.mask_words_per_row, x0 + p2x, y0 + p2y);
+                if (f1) { bv = c_v2; bi = c_p2; } else scan(bv, bi);
+                my_ = bi / P.cs; mx_ = bi - my_ * P.cs;
+                mx = x0 + mx_; my = y0 + my_;
+                if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) break;   // :379-384
+                if ((double)bv >= P.quality) {
+                    if (lane == 0) sec[cell] = mx | (my << 16);
+                    mask_draw_circle(mask, P, hw, mx, my, lane, 64);
                 }
             }
 #undef SEL_LOAD_CHUNK
+            } while (0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&progress[r], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     const unsigned long long tk3 = wall_clock64();
     // compaction in cell order by wavefront 0: 64 cells per trip, positions from ballot prefix counts
@@ -675,7 +767,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     if (ncells == 0) return OV2_OK;
     const int npx = cell * cell;
     const int wpr = (w + 31) / 32;
-    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
+    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
     OV2_REQUIRE(sel_lds <= 160 * 1024, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask");
 
     // device scratch: [img w*h][maps][cur 8*ncur][out 8*2*ncells][SelectOut]
@@ -685,7 +777,8 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     const size_t o_cur = (o_map + map_bytes + 255) & ~(size_t)255;
     const size_t o_out = (o_cur + 8 * (size_t)(ncur > 0 ? ncur : 1) + 255) & ~(size_t)255;
     const size_t o_so = o_out + 16 * (size_t)ncells;
-    const size_t total = o_so + sizeof(SelectOut);
+    const size_t o_cand = (o_so + sizeof(SelectOut) + 255) & ~(size_t)255;
+    const size_t total = o_cand + sizeof(CellCand) * (size_t)ncells;
     int rc = ctx->reserve_device(total);  if (rc) return rc;
     rc = ctx->reserve_host(16 * (size_t)ncells + sizeof(SelectOut)); if (rc) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
@@ -699,12 +792,12 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
 
     if (mode == 0) {
         int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
-        hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, ds + o_map);
+        hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, ds + o_map, mask_mode, (CellCand *)(ds + o_cand));
     } else {
         const size_t lds = (size_t)npx * (3 * 8 + 4 + 4 + 3 * 4 + 1) + 16;
         OV2_REQUIRE(lds <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 58)");
         OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_mineig_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order);
+        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order, cell / 4, (CellCand *)(ds + o_cand));
     }
     SelectParams P;
     P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
@@ -715,7 +808,8 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     do {                                                                                                                            \
         OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MD, MR, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
         hipLaunchKernelGGL((k_grid_select<MD, MR, CH>), dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),        \
-                           (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so)); \
+                           (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (const CellCand *)(ds + o_cand),                    \
+                           (float2 *)(ds + o_out), (SelectOut *)(ds + o_so));                                                      \
     } while (0)
     if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(0, 52, 1); else OV2_LAUNCH_SELECT(0, 32, 2); }
     else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(1, 52, 1); else OV2_LAUNCH_SELECT(1, 32, 2); }
