@@ -8,15 +8,15 @@
 // Structure (per image):
 //   1. k_fast_cells / k_mineig_cells : one workgroup per grid cell, cell tile staged in LDS,
 //      produces the cell's response map (NMS'ed FAST score bytes / min-eigenvalue floats).
+//      Each also leaves the cell's selection CANDIDATES (CellCand): what the selection would take from an untouched mask.
 //   2. k_grid_select : ONE workgroup.  The exclusion mask (the reference's CV_32F ones image with
 //      zeroed discs) lives in LDS as a bitmask.  The reference walks the cells serially and every
 //      accepted point zeroes a disc of radius cell/4 that can only reach the 8 neighbouring cells,
-//      so cell (r,c) depends on (r,c-1), (r-1,c-1), (r-1,c), (r-1,c+1) only: cells with equal
-//      2r+c are independent.  One wavefront per cell sweeps the anti-diagonals (2*rows+cols steps
-//      instead of rows*cols), giving bit-identical results to the serial raster order.
-//      A lane owns one row of the cell (its mask slice is one 64-bit string, its responses sit in registers,
-//      the maps are stored column-major so that column loads coalesce); the response maps are pulled into this
-//      XCD's L2 once at kernel start.
+//      so cell (r,c) depends on (r,c-1), (r-1,c-1), (r-1,c), (r-1,c+1) only.  Wavefront w walks along cell row w
+//      behind a per-row progress counter (no work-group barrier); a cell whose candidates are still unmasked costs two
+//      LDS bit tests, any other cell the full masked scan (a lane owns one row of the cell: its mask slice is one 64-bit
+//      string, its responses sit in registers, the maps are stored column-major so that column loads coalesce).
+//      Bit-identical results to the serial raster order.
 //   3. k_corner_subpix : cv::cornerSubPix, one wavefront per point (parallel patch, ordered accumulation).
 #include "common.hpp"
 #include <float.h>
