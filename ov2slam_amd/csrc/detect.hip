@@ -662,8 +662,8 @@ __device__ __forceinline__ float d_rect_subpix_px(const uint8_t *__restrict__ sr
 }
 
 // One WAVEFRONT per point: the (WINW+2)^2 patch and the per-pixel gradient products are evaluated by all lanes,
-// the five sums are accumulated by lane 0 in the reference's raster order (double), so the result is bit-identical
-// to the serial loop while an iteration costs ~1 us instead of ~10.
+// the five sums are accumulated by lanes 0..4 (one sum each) in the reference's raster order (double), so the result is
+// bit-identical to the serial loop while an iteration costs ~1 us instead of ~10.
 template <int HALF>
 __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint8_t *__restrict__ img, float2 *__restrict__ xy,
                                                       const int *__restrict__ n_dev)
@@ -697,9 +697,12 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float nx = cIx, ny = cIy;
         int cont = 0;
+        // the five sums in the reference's raster order, one lane each (a wave64 fp64 add occupies the SIMD for 8 cycles
+        // whether one lane is active or five: 49 dependent adds instead of 245)
+        double acc = 0;
+        if (lane < 5) for (int e = 0; e < NPIX; e++) acc += prod[e][lane];
+        const double a = __shfl(acc, 0, 64), b = __shfl(acc, 1, 64), c = __shfl(acc, 2, 64), bb1 = __shfl(acc, 3, 64), bb2 = __shfl(acc, 4, 64);
         if (lane == 0) {
-            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-            for (int e = 0; e < NPIX; e++) { a += prod[e][0]; b += prod[e][1]; c += prod[e][2]; bb1 += prod[e][3]; bb2 += prod[e][4]; }
             const double det = a * c - b * b;
             if (!(fabs(det) <= DBL_EPSILON * DBL_EPSILON)) {
                 const double scale = 1.0 / det;
