@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include <float.h>
 #include <math.h>
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -752,6 +753,27 @@ static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int s
     return OV2_OK;
 }
 
+// The dynamic-LDS limit is a per-function, process-wide attribute: raise it ONCE for every instance to the hardware maximum
+// (less the kernel's static LDS) instead of per call to that call's need -- two contexts on two threads would race on it.
+static hipError_t det_raise_lds_limits()
+{
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        auto raise = [](const void *fn) {
+            hipFuncAttributes fa;
+            hipError_t e = hipFuncGetAttributes(&fa, fn);
+            if (e != hipSuccess) return e;
+            return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+        };
+        const void *fns[] = {(const void *)k_mineig_cells,
+                             (const void *)k_grid_select<0, 36, 1>, (const void *)k_grid_select<0, 52, 1>, (const void *)k_grid_select<0, 32, 2>,
+                             (const void *)k_grid_select<1, 36, 1>, (const void *)k_grid_select<1, 52, 1>, (const void *)k_grid_select<1, 32, 2>};
+        for (const void *fn : fns) if (err == hipSuccess) err = raise(fn);
+    });
+    return err;
+}
+
 // img_h: host image (uploaded first) -- or img_d: an image already in HBM (pyramid level 0: no upload), row pitch `stride`
 static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uint8_t *img_d, int w, int h, int stride, int cell,
                          const float *cur_xy_h, int ncur, int fast_th, int mask_mode, const int roi[4], double quality,
@@ -766,6 +788,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     OV2_REQUIRE(ncur >= 0 && (ncur == 0 || cur_xy_h), OV2_EINVAL, "bad current keypoints");
     OV2_REQUIRE(w < 65536 && h < 32768, OV2_EUNSUPPORTED, "image too large");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    OV2_HIP_CHECK(det_raise_lds_limits());
     const int nw = w / cell, nh = h / cell, ncells = nw * nh;
     if (ncells == 0) return OV2_OK;
     const int npx = cell * cell;
@@ -798,8 +821,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
         hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, ds + o_map, mask_mode, (CellCand *)(ds + o_cand));
     } else {
         const size_t lds = (size_t)npx * (3 * 8 + 4 + 4 + 3 * 4 + 1) + 16;
-        OV2_REQUIRE(lds <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 58)");
-        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_mineig_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        OV2_REQUIRE(lds + 512 <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 60)");
         hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order, cell / 4, (CellCand *)(ds + o_cand));
     }
     SelectParams P;
@@ -809,7 +831,6 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     P.quality = quality;
 #define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                                       \
     do {                                                                                                                            \
-        OV2_HIP_CHECK(hipFuncSetAttribute((const void *)k_grid_select<MD, MR, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds)); \
         hipLaunchKernelGGL((k_grid_select<MD, MR, CH>), dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),        \
                            (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (const CellCand *)(ds + o_cand),                    \
                            (float2 *)(ds + o_out), (SelectOut *)(ds + o_so));                                                      \
