@@ -525,6 +525,25 @@ def main():
         pass
 
     # free the batch buffers before the single-sequence / BA sections
+    # ---- keyframe detection for the whole batch: every sequence's detector on level 0 of its pyramid, one call -------------
+    det_batch = None
+    if not args.no_extras and world == 1:
+        ncells = (W // CELL) * (H // CELL)
+        cap = 2 * ncells
+        det_out = torch.zeros((S, cap, 2), dtype=torch.float32, device=dev)
+        qual = np.full(S, 1e-3)
+        roi = (5, 5, W - 10, H - 10)
+        torch.cuda.synchronize()
+        n_det = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[0], CELL, 0, 0, 0, roi, qual, det_out.data_ptr(), cap)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            qual[:] = 1e-3
+            n_det = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[0], CELL, 0, 0, 0, roi, qual, det_out.data_ptr(), cap)
+        det_ms = (time.perf_counter() - t1) / 3 * 1e3
+        det_batch = {"detect_singlescale_batch_ms": det_ms, "images": S, "us_per_image": det_ms * 1e3 / S,
+                     "points_per_image": float(n_det.mean()),
+                     "entry": "ov2_detect_singlescale_batch_d on level 0 of the batch pyramid (device-resident lists, one sync)"}
+        del det_out
     del frames_d, kps_d, pri_d, pri_work, status_d
     for p in pyrs:
         p.close()
@@ -559,6 +578,8 @@ def main():
         }
         if c5 is not None:
             out["config5"] = c5
+        if det_batch is not None:
+            out["detect_batch"] = det_batch
         if world == 1 and not args.no_extras:
             ss = single_sequence(dev.index, views, kps, pri)
             out["single_sequence"] = ss

@@ -240,6 +240,18 @@ int ov2_detect_grid_fast_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cell,
 int ov2_detect_singlescale_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cell, const float *cur_xy_h, int ncur,
                              const int roi[4], double *quality_inout, int do_subpix, float *out_xy_h, int *out_n);
 
+/* The same detectors on EVERY batch item of the pyramid in one call (the offline batch-of-sequences mode: all sequences reach
+ * a keyframe together).  Everything but the adaptive per-sequence state stays on the device:
+ *   cur_xy_d   device, batch x cur_cap points (x, y): the items' current keypoints; ncur_d device, batch counts (NULL: none)
+ *   out_xy_d   device, batch x out_cap points; out_cap >= (w/cell)*(h/cell) for FAST, twice that for single scale
+ *   quality_inout / fast_th_inout   host, one entry per item (dmaxquality_ / nfast_th_ of that sequence), updated like the
+ *              single-image forms; out_n_h host, points written per item.
+ * Results per item are identical to the single-image forms.  One host synchronisation per call.                        */
+int ov2_detect_singlescale_batch_d(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                                   const int roi[4], double *quality_inout, int do_subpix, float *out_xy_d, int out_cap, int *out_n_h);
+int ov2_detect_grid_fast_batch_d(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                                 int *fast_th_inout, int mask_mode, int do_subpix, float *out_xy_d, int out_cap, int *out_n_h);
+
 /* cv::cornerSubPix(im, pts, Size(hw,hw), Size(-1,-1), TermCriteria(EPS+MAX_ITER, max_iter, eps))
  * src/feature_extractor.cpp:434, :564 (hw = 3, 30, 0.01).  In place.             */
 int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride,

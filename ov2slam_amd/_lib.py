@@ -153,6 +153,8 @@ SIGNATURES = {
     "ov2_detect_singlescale": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.POINTER(_i), C.POINTER(_d), _i, _vp, C.POINTER(_i)]),
     "ov2_detect_grid_fast_d": (_i, [_vp, _vp, _i, _i, _vp, _i, C.POINTER(_i), _i, _i, _vp, C.POINTER(_i)]),
     "ov2_detect_singlescale_d": (_i, [_vp, _vp, _i, _i, _vp, _i, C.POINTER(_i), C.POINTER(_d), _i, _vp, C.POINTER(_i)]),
+    "ov2_detect_singlescale_batch_d": (_i, [_vp, _vp, _i, _vp, _i, _vp, C.POINTER(_i), _vp, _i, _vp, _i, _vp]),
+    "ov2_detect_grid_fast_batch_d": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "ov2_corner_subpix": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _d]),
     "ov2_ba_default_options": (None, [C.POINTER(BAOptions)]),
     "ov2_structure_ba": (_i, [_vp, C.POINTER(SBAProblem), C.POINTER(BAOptions), C.POINTER(SBAResult)]),

@@ -6,7 +6,7 @@
 // cornerMinEigenVal(3,3), minMaxLoc, circle(FILLED), cornerSubPix).
 //
 // Structure (per image):
-//   1. k_fast_cells / k_mineig_cells : one workgroup per grid cell, cell tile staged in LDS,
+//   1. k_fast_cells / k_mineig_cells : one workgroup (FAST) / one wavefront (min-eigenvalue) per grid cell,
 //      produces the cell's response map (NMS'ed FAST score bytes / min-eigenvalue floats).
 //      Each also leaves the cell's selection CANDIDATES (CellCand): what the selection would take from an untouched mask.
 //   2. k_grid_select : ONE workgroup.  The exclusion mask (the reference's CV_32F ones image with
@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include <float.h>
 #include <math.h>
+#include <algorithm>
 #include <mutex>
 
 #pragma clang fp contract(off)
@@ -45,6 +46,19 @@ __device__ __forceinline__ int d_reflect101(int p, int len)
 // still set when the sweep reaches the cell, it IS the masked arg-max -- the sweep then costs two LDS bit tests per cell instead
 // of a load batch and two arg-max passes, and falls back to the full scan otherwise.
 struct CellCand { int p1; float v1; int p2; float v2; };      // p = ly * cs + lx, -1: none
+
+// Batched launches (one image per batch item of a pyramid, ov2_detect_*_batch_d): per-item strides and parameters; everything
+// zero / NULL for a single image.  The cell kernels run ncells work-groups per item, the selection one work-group per item,
+// the sub-pixel refinement a wavefront per (output slot, item).
+struct DetBatch {
+    long long img_stride;      // bytes between the items' images
+    int ncells;                // cells per image
+    int cur_stride;            // float2 entries between the items' current-keypoint lists
+    int out_stride;            // float2 entries between the items' output lists
+    const int *ncur;           // per-item number of current keypoints   (NULL: SelectParams::ncur)
+    const int *fast_th;        // per-item FAST threshold                (NULL: the scalar argument)
+    const double *quality;     // per-item quality level                 (NULL: SelectParams::quality)
+};
 
 // wave-wide arg-max of (value, smaller index wins ties); all 64 lanes participate
 __device__ __forceinline__ void wave_argmax_f(float &v, int &idx)
@@ -94,15 +108,19 @@ __constant__ int c_fast_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
                                                     int cs, int nwcells, int threshold, uint8_t *__restrict__ nms_out,
-                                                    int mask_mode, CellCand *__restrict__ cand_out)
+                                                    int mask_mode, CellCand *__restrict__ cand_out, DetBatch B)
 {
     __shared__ uint8_t tile[DET_MAX_CELL * DET_MAX_CELL];
     __shared__ uint8_t score[DET_MAX_CELL * DET_MAX_CELL];
     __shared__ float s_v[4];
     __shared__ int s_i[4];
-    const int cell = blockIdx.x;
+    const int item = blockIdx.x / B.ncells, cell = blockIdx.x - item * B.ncells;
     const int x0 = (cell % nwcells) * cs, y0 = (cell / nwcells) * cs;
     const int npx = cs * cs;
+    img += (long long)item * B.img_stride;
+    nms_out += (long long)item * B.ncells * npx;
+    cand_out += (long long)item * B.ncells;
+    if (B.fast_th) { const int t = B.fast_th[item]; threshold = t < 0 ? 0 : (t > 255 ? 255 : t); }
     for (int p = threadIdx.x; p < npx; p += blockDim.x) {
         const int ly = p / cs, lx = p - ly * cs;
         tile[p] = img[(long long)(y0 + ly) * stride + x0 + lx];
@@ -178,112 +196,125 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 // min-eigenvalue response of every cell: GaussianBlur 3x3 (parent pixels, fixed point) ->
 // Sobel/3060 -> (dx^2, dxdy, dy^2) -> 3x3 box (double sums, sliding column) -> lambda_min
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mineig_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
-                                                      int cs, int nwcells, float *__restrict__ hmap_out, int dy_order,
-                                                      int radius, CellCand *__restrict__ cand_out)
+// ONE WAVEFRONT per cell, lane = cell column, marching down the rows: the blurred cell goes to LDS (bytes), everything after
+// it stays in registers -- Sobel of a row from nine LDS bytes, the neighbouring columns' products through ds_bpermute, the
+// three double row sums of rows y-1, y, y+1 as a sliding window, ColumnSum's recurrence (SUM + row[y+1], then - row[y-1],
+// REFLECT_101 at the cell's edges) exactly as the serial code runs it.  lambda_min is staged row-major in LDS for the
+// candidates and the coalesced column-major store.  5 bytes of LDS per pixel and no work-group barrier (round 1 / early round 2:
+// 256 threads per cell, five barrier-separated phases over 45 bytes of LDS per pixel -- 2 work-groups per CU, 13 us per image
+// in a batch, 24 us for one image).
+__global__ __launch_bounds__(64) void k_mineig_cells(const uint8_t *__restrict__ img, int w, int h, int stride,
+                                                     int cs, int nwcells, float *__restrict__ hmap_out, int dy_order,
+                                                     int radius, CellCand *__restrict__ cand_out, DetBatch B)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ float s_v[4];
-    __shared__ int s_i[4];
     __shared__ int s_hw[64];
     const int npx = cs * cs;
-    // carve: rows (double 3*npx) | dxm (float npx) | dym (float npx) | cov (float 3*npx) | blur (u8 npx)
-    double *rows = (double *)smem;
-    float *dxm = (float *)(rows + 3 * npx);
-    float *dym = dxm + npx;
-    float *cov = dym + npx;
-    uint8_t *blur = (uint8_t *)(cov + 3 * npx);
-    const int cell = blockIdx.x;
+    float *lam = (float *)smem;                               // npx, row-major
+    uint8_t *blur = (uint8_t *)(lam + npx);                   // npx
+    const int item = blockIdx.x / B.ncells, cell = blockIdx.x - item * B.ncells;
     const int x0 = (cell % nwcells) * cs, y0 = (cell / nwcells) * cs;
+    img += (long long)item * B.img_stride;
+    hmap_out += (long long)item * B.ncells * npx;
+    cand_out += (long long)item * B.ncells;
+    const int lane = threadIdx.x;
+    const bool act = lane < cs;
+    const int x = act ? lane : cs - 1;                        // idle lanes shadow the last column (their results are never stored)
+    if (lane == 0) d_circle_halfwidths(s_hw, radius);
 
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        const int j = p / cs, i = p - j * cs;
-        int s = 0;
+    // ---- GaussianBlur 3x3 on the parent image (REFLECT_101 at the IMAGE border), (1 2 1) x (1 2 1), (s + 8) >> 4 ----
+    {
+        const int gx0 = d_reflect101(x0 + x - 1, w), gx1 = d_reflect101(x0 + x, w), gx2 = d_reflect101(x0 + x + 1, w);
+        auto hrow = [&](int gy) {
+            const uint8_t *row = img + (long long)d_reflect101(gy, h) * stride;
+            return (int)row[gx0] + 2 * (int)row[gx1] + (int)row[gx2];
+        };
+        // eight rows per trip, their ten source rows (30 byte loads per lane) in flight together: one row per trip made the
+        // stage a chain of cs + 2 dependent L2 round trips -- most of the kernel's latency for a single image
+        for (int j0 = 0; j0 < cs; j0 += 8) {
+            int hv[10];
 #pragma unroll
-        for (int dy = -1; dy <= 1; dy++) {
-            const uint8_t *row = img + (long long)d_reflect101(y0 + j + dy, h) * stride;
-            const int wy = dy == 0 ? 2 : 1;
-            s += wy * ((int)row[d_reflect101(x0 + i - 1, w)] + 2 * (int)row[d_reflect101(x0 + i, w)] +
-                       (int)row[d_reflect101(x0 + i + 1, w)]);
+            for (int u = 0; u < 10; u++) hv[u] = hrow(y0 + j0 - 1 + u);          // (rows past the cell: valid image rows, never stored)
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (act && j0 + u < cs) blur[(j0 + u) * cs + x] = (uint8_t)((hv[u] + 2 * hv[u + 1] + hv[u + 2] + 8) >> 4);
         }
-        blur[p] = (uint8_t)((s + 8) >> 4);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- Sobel (REFLECT_101 at the CELL's edges: the blurred cell is a Mat of its own), products, row sums ----
     const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
-#define BL(yy, xx) ((int)blur[d_reflect101((yy), cs) * cs + d_reflect101((xx), cs)])
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        const int y = p / cs, x = p - y * cs;
-        const float r0 = (float)(BL(y - 1, x + 1) - BL(y - 1, x - 1));
-        const float r1 = (float)(BL(y, x + 1) - BL(y, x - 1));
-        const float r2 = (float)(BL(y + 1, x + 1) - BL(y + 1, x - 1));
-        dxm[p] = (r0 + r2) * f1 + r1 * f0;
+    const int xl = x == 0 ? 1 : x - 1, xr = x == cs - 1 ? cs - 2 : x + 1;
+    auto rowsum = [&](int yy, double (&sum)[3]) {
+        const int ym = yy == 0 ? 1 : yy - 1, yp = yy == cs - 1 ? cs - 2 : yy + 1;
+        const uint8_t *bm = blur + ym * cs, *bc = blur + yy * cs, *bp = blur + yp * cs;
+        const int a00 = bm[xl], a01 = bm[x], a02 = bm[xr], a10 = bc[xl], a12 = bc[xr], a20 = bp[xl], a21 = bp[x], a22 = bp[xr];
+        const float r0 = (float)(a02 - a00), r1 = (float)(a12 - a10), r2 = (float)(a22 - a20);
+        const float dx = (r0 + r2) * f1 + r1 * f0;
+        float dy;
         if (dy_order == OV2_SOBEL_DY_EXACT_SUM) {          // round 1's order: scale applied to the exact integer difference
-            const float s0 = (float)(BL(y - 1, x - 1) + 2 * BL(y - 1, x) + BL(y - 1, x + 1));
-            const float s2 = (float)(BL(y + 1, x - 1) + 2 * BL(y + 1, x) + BL(y + 1, x + 1));
-            dym[p] = (s2 - s0) * f1;
+            const float s0 = (float)(a00 + 2 * a01 + a02), s2 = (float)(a20 + 2 * a21 + a22);
+            dy = (s2 - s0) * f1;
         } else {
             // cv::Sobel(dx = 0, dy = 1, scale): the scale goes into the smoothing kernel, the row pass is the generic
             // RowFilter<uchar, float> ((p[x-1] k0 + p[x] k1) + p[x+1] k2, every operation rounded), the column pass the exact
             // difference of two rounded rows (include/ov2slam_hip.h: OV2_OPT_SOBEL_DY_ORDER)
-            const float s0 = ((float)BL(y - 1, x - 1) * f1 + (float)BL(y - 1, x) * f0) + (float)BL(y - 1, x + 1) * f1;
-            const float s2 = ((float)BL(y + 1, x - 1) * f1 + (float)BL(y + 1, x) * f0) + (float)BL(y + 1, x + 1) * f1;
-            dym[p] = s2 - s0;
+            const float s0 = ((float)a00 * f1 + (float)a01 * f0) + (float)a02 * f1;
+            const float s2 = ((float)a20 * f1 + (float)a21 * f0) + (float)a22 * f1;
+            dy = s2 - s0;
         }
-    }
-#undef BL
-    __syncthreads();
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        const int y = p / cs, x = p - y * cs;
-        double s[3];
+        const float v0 = dx * dx, v1 = dx * dy, v2 = dy * dy;
+        // RowSum<float, double> over columns x-1, x, x+1 (REFLECT_101): the neighbours' products come from their lanes
+        const float l0 = __shfl(v0, xl, 64), l1 = __shfl(v1, xl, 64), l2 = __shfl(v2, xl, 64);
+        const float q0 = __shfl(v0, xr, 64), q1 = __shfl(v1, xr, 64), q2 = __shfl(v2, xr, 64);
+        sum[0] = (double)l0; sum[0] = sum[0] + (double)v0; sum[0] = sum[0] + (double)q0;
+        sum[1] = (double)l1; sum[1] = sum[1] + (double)v1; sum[1] = sum[1] + (double)q1;
+        sum[2] = (double)l2; sum[2] = sum[2] + (double)v2; sum[2] = sum[2] + (double)q2;
+    };
+    double rp[3] = {0, 0, 0}, rc[3], rn[3], SUM[3];
+    rowsum(0, rc); rowsum(1, rn);
 #pragma unroll
-        for (int k = -1; k <= 1; k++) {
-            const int xx = d_reflect101(x + k, cs);
-            const float dx = dxm[y * cs + xx], dy = dym[y * cs + xx];
-            const float v0 = dx * dx, v1 = dx * dy, v2 = dy * dy;
-            if (k == -1) { s[0] = (double)v0; s[1] = (double)v1; s[2] = (double)v2; }
-            else { s[0] = s[0] + (double)v0; s[1] = s[1] + (double)v1; s[2] = s[2] + (double)v2; }
-        }
-        rows[3 * p] = s[0]; rows[3 * p + 1] = s[1]; rows[3 * p + 2] = s[2];
-    }
-    __syncthreads();
-    // sliding column sums, one lane per (column, channel), exactly ColumnSum's recurrence
-    for (int t = threadIdx.x; t < cs * 3; t += blockDim.x) {
-        const int x = t / 3, ch = t - x * 3;
-        double SUM = 0;
-        SUM += rows[(d_reflect101(-1, cs) * cs + x) * 3 + ch];
-        SUM += rows[(0 * cs + x) * 3 + ch];
-        for (int y = 0; y < cs; y++) {
-            const double s0 = SUM + rows[(d_reflect101(y + 1, cs) * cs + x) * 3 + ch];
-            cov[(y * cs + x) * 3 + ch] = (float)s0;
-            SUM = s0 - rows[(d_reflect101(y - 1, cs) * cs + x) * 3 + ch];
-        }
-    }
-    __syncthreads();
-    float *out = hmap_out + (long long)cell * npx;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        const float a = cov[3 * p] * 0.5f, b = cov[3 * p + 1], c = cov[3 * p + 2] * 0.5f;
-        const int ly = p / cs, lx = p - ly * cs;
-        const float lam = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-        out[lx * cs + ly] = lam;                                                   // column-major (see k_fast_cells)
-        dxm[p] = lam;                                                              // row-major copy for the candidates below
-    }
-    if (threadIdx.x == 0) d_circle_halfwidths(s_hw, radius);
-    __syncthreads();
-    // candidates: first maximum (raster order), and first maximum outside the disc around it
+    for (int ch = 0; ch < 3; ch++) { SUM[ch] = 0; SUM[ch] += rn[ch]; SUM[ch] += rc[ch]; }      // rows[-1 -> 1], rows[0]
     float bv = -INFINITY; int bi = 0x7FFFFFFF;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) { const float v = dxm[p]; if (v > bv) { bv = v; bi = p; } }
-    block_argmax_f(bv, bi, s_v, s_i);
+    for (int y = 0; y < cs; y++) {
+        float cov[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double nxt = (y + 1 <= cs - 1) ? rn[ch] : rp[ch];     // rows[reflect(y + 1)]
+            const double prv = (y == 0) ? rn[ch] : rp[ch];             // rows[reflect(y - 1)]
+            const double s0 = SUM[ch] + nxt;
+            cov[ch] = (float)s0;
+            SUM[ch] = s0 - prv;
+        }
+        const float a = cov[0] * 0.5f, b = cov[1], c = cov[2] * 0.5f;
+        const float lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        if (act) {
+            lam[y * cs + x] = lm;
+            if (lm > bv) { bv = lm; bi = y * cs + x; }                  // first maximum of this column; raster order across lanes below
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { rp[ch] = rc[ch]; rc[ch] = rn[ch]; }
+        if (y + 2 <= cs - 1) rowsum(y + 2, rn);                          // (wave-uniform)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // column-major map (k_grid_select's full scan reads a row per lane, coalesced), written with coalesced stores
+    float *out = hmap_out + (long long)cell * npx;
+    for (int e = lane; e < npx; e += 64) { const int lx = e / cs, ly = e - lx * cs; out[e] = lam[ly * cs + lx]; }
+    // candidates: first maximum (raster order), and first maximum outside the disc around it
+    wave_argmax_f(bv, bi);
     const int p1y = bi / cs, p1x = bi - p1y * cs;
     float bv2 = -INFINITY; int bi2 = 0x7FFFFFFF;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        const int ly = p / cs, lx = p - ly * cs;
-        const int ady = ly > p1y ? ly - p1y : p1y - ly, adx = lx > p1x ? lx - p1x : p1x - lx;
-        const bool in_disc = ady <= radius && s_hw[ady < 64 ? ady : 63] >= 0 && adx <= s_hw[ady < 64 ? ady : 63];
-        const float v = dxm[p];
-        if (!in_disc && v > bv2) { bv2 = v; bi2 = p; }
+    if (act) {
+        const int adx = x > p1x ? x - p1x : p1x - x;
+        for (int y = 0; y < cs; y++) {
+            const int ady = y > p1y ? y - p1y : p1y - y;
+            const bool in_disc = ady <= radius && s_hw[ady < 64 ? ady : 63] >= 0 && adx <= s_hw[ady < 64 ? ady : 63];
+            const float v = lam[y * cs + x];
+            if (!in_disc && v > bv2) { bv2 = v; bi2 = y * cs + x; }
+        }
     }
-    block_argmax_f(bv2, bi2, s_v, s_i);
-    if (threadIdx.x == 0) { CellCand cd; cd.p1 = bi; cd.v1 = bv; cd.p2 = bi2 == 0x7FFFFFFF ? -1 : bi2; cd.v2 = bv2; cand_out[cell] = cd; }
+    wave_argmax_f(bv2, bi2);
+    if (lane == 0) { CellCand cd; cd.p1 = bi; cd.v1 = bv; cd.p2 = bi2 == 0x7FFFFFFF ? -1 : bi2; cd.v2 = bv2; cand_out[cell] = cd; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -344,9 +375,17 @@ template <int MODE, int MAXROW, int CHUNKS>
 __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
                                                       const float *__restrict__ hmaps, const CellCand *__restrict__ cand,
-                                                      float2 *__restrict__ out_xy, SelectOut *__restrict__ out)
+                                                      float2 *__restrict__ out_xy, SelectOut *__restrict__ out, DetBatch B)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    {   // batch item of this work-group
+        const int item = blockIdx.x;
+        const long long map_items = (long long)item * B.ncells * P.cs * P.cs;
+        cur_xy += (long long)item * B.cur_stride; nms_maps += map_items; hmaps += map_items; cand += (long long)item * B.ncells;
+        out_xy += (long long)item * B.out_stride; out += item;
+        if (B.ncur) P.ncur = B.ncur[item];
+        if (B.quality) P.quality = B.quality[item];
+    }
     unsigned *mask = (unsigned *)smem;                                   // h * wpr words
     const int mask_words = P.h * P.mask_words_per_row;
     const int ncells = P.nhcells * P.nwcells;
@@ -559,6 +598,8 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
 // ---------------------------------------------------------------------------------
 #define SP_MAX_HALF 5
 struct SubpixParams {
+    long long img_item_stride;          // batched launches (blockIdx.y = item): bytes between images,
+    int xy_item_stride, ndev_item_stride;   // float2 entries between point lists, ints between the device-side counts
     int w, h, stride, n, half_win, max_iters;
     double eps2;
     float e[2 * SP_MAX_HALF + 1];       // exp(-((i-hw)/hw)^2) computed by the host libm (like the reference)
@@ -673,9 +714,10 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
     __shared__ float sub[SW * SW];
     __shared__ double prod[NPIX][5];
     const int pt = blockIdx.x, lane = threadIdx.x;
+    img += (long long)blockIdx.y * P.img_item_stride; xy += (long long)blockIdx.y * P.xy_item_stride;
     // n_dev: the point count still lives on the device (written by k_grid_select): the launch covers the capacity and the
     // surplus wavefronts leave here -- the detectors then need ONE host synchronisation instead of two
-    if (pt >= (n_dev ? *n_dev : P.n)) return;
+    if (pt >= (n_dev ? n_dev[(long long)blockIdx.y * P.ndev_item_stride] : P.n)) return;
     const float2 cT = xy[pt];
     float cIx = cT.x, cIy = cT.y;
     int iter = 0;
@@ -727,13 +769,15 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
 // host side
 // ---------------------------------------------------------------------------------
 static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int stride, float2 *xy_d, int n,
-                         int half_win, int max_iter, double eps, const int *n_dev = nullptr)
+                         int half_win, int max_iter, double eps, const int *n_dev = nullptr,
+                         int items = 1, long long img_item_stride = 0, int xy_item_stride = 0, int ndev_item_stride = 0)
 {
     if (n <= 0) return OV2_OK;
     OV2_REQUIRE(half_win >= 1 && half_win <= SP_MAX_HALF, OV2_EUNSUPPORTED, "cornerSubPix half window must be in [1,5]");
     OV2_REQUIRE(w >= half_win * 2 + 5 && h >= half_win * 2 + 5, OV2_EINVAL, "image too small for cornerSubPix");
     SubpixParams P;
     P.w = w; P.h = h; P.stride = stride; P.n = n; P.half_win = half_win;
+    P.img_item_stride = img_item_stride; P.xy_item_stride = xy_item_stride; P.ndev_item_stride = ndev_item_stride;
     P.max_iters = max_iter < 1 ? 1 : (max_iter > 100 ? 100 : max_iter);
     if (eps < 0.) eps = 0.;
     P.eps2 = eps * eps;
@@ -741,7 +785,7 @@ static int launch_subpix(ov2_ctx *ctx, const uint8_t *img_d, int w, int h, int s
         const float x = (float)(i - half_win) / half_win;
         P.e[i] = expf(-x * x);
     }
-    dim3 grid(n), block(64);                                  // one wavefront per point
+    dim3 grid(n, items), block(64);                           // one wavefront per point (and batch item)
     switch (half_win) {
     case 1: hipLaunchKernelGGL(k_corner_subpix<1>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
     case 2: hipLaunchKernelGGL(k_corner_subpix<2>, grid, block, 0, ctx->stream, P, img_d, xy_d, n_dev); break;
@@ -772,6 +816,45 @@ static hipError_t det_raise_lds_limits()
         for (const void *fn : fns) if (err == hipSuccess) err = raise(fn);
     });
     return err;
+}
+
+// The three launches of a detection (response + candidates per cell, selection, sub-pixel refinement) for `items` images
+// that lie `B.img_stride` bytes apart; every pointer addresses item 0.  Asynchronous on the context's stream.
+static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int h, int im_stride, int cell, int items, DetBatch B,
+                          int fast_th, int mask_mode, const int roi[4], double quality, int ncur, const float2 *cur_d,
+                          uint8_t *maps_d, CellCand *cand_d, float2 *out_d, SelectOut *so_d, int do_subpix)
+{
+    const int nw = w / cell, nh = h / cell, ncells = nw * nh, npx = cell * cell, wpr = (w + 31) / 32;
+    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
+    B.ncells = ncells;
+    if (mode == 0) {
+        int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
+        hipLaunchKernelGGL(k_fast_cells, dim3(ncells * items), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, maps_d, mask_mode, cand_d, B);
+    } else {
+        const size_t lds = (size_t)npx * 5 + 16;                      // lambda_min (float) + blurred cell (byte) per pixel
+        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells * items), dim3(64), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)maps_d, ctx->sobel_dy_order, cell / 4, cand_d, B);
+    }
+    SelectParams P;
+    P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
+    P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
+    P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
+    P.quality = quality;
+#define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                               \
+    hipLaunchKernelGGL((k_grid_select<MD, MR, CH>), dim3(items), dim3(1024), sel_lds, ctx->stream, P, cur_d, (const uint8_t *)maps_d,     \
+                       (const float *)maps_d, (const CellCand *)cand_d, out_d, so_d, B)
+    if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(0, 52, 1); else OV2_LAUNCH_SELECT(0, 32, 2); }
+    else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(1, 52, 1); else OV2_LAUNCH_SELECT(1, 32, 2); }
+#undef OV2_LAUNCH_SELECT
+    OV2_HIP_CHECK(hipGetLastError());
+    // sub-pixel refinement over the CAPACITY of the output list (the kernel reads the count on the device and the
+    // surplus wavefronts leave at once)
+    if (do_subpix) {
+        const int cap = mode == 0 ? ncells : 2 * ncells;
+        const int rc = launch_subpix(ctx, im, w, h, im_stride, out_d, cap, 3, 30, 0.01, (const int *)so_d,
+                                     items, B.img_stride, B.out_stride, (int)(sizeof(SelectOut) / sizeof(int)));
+        if (rc) return rc;
+    }
+    return OV2_OK;
 }
 
 // img_h: host image (uploaded first) -- or img_d: an image already in HBM (pyramid level 0: no upload), row pitch `stride`
@@ -816,37 +899,13 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     }
     if (ncur > 0) OV2_HIP_CHECK(hipMemcpyAsync(ds + o_cur, cur_xy_h, 8 * (size_t)ncur, hipMemcpyHostToDevice, ctx->stream));
 
-    if (mode == 0) {
-        int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
-        hipLaunchKernelGGL(k_fast_cells, dim3(ncells), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, ds + o_map, mask_mode, (CellCand *)(ds + o_cand));
-    } else {
-        const size_t lds = (size_t)npx * (3 * 8 + 4 + 4 + 3 * 4 + 1) + 16;
-        OV2_REQUIRE(lds + 512 <= 160 * 1024, OV2_EUNSUPPORTED, "cell size too large for the LDS-staged min-eigenvalue kernel (max 60)");
-        hipLaunchKernelGGL(k_mineig_cells, dim3(ncells), dim3(256), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)(ds + o_map), ctx->sobel_dy_order, cell / 4, (CellCand *)(ds + o_cand));
-    }
-    SelectParams P;
-    P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
-    P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
-    P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
-    P.quality = quality;
-#define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                                       \
-    do {                                                                                                                            \
-        hipLaunchKernelGGL((k_grid_select<MD, MR, CH>), dim3(1), dim3(1024), sel_lds, ctx->stream, P, (const float2 *)(ds + o_cur),        \
-                           (const uint8_t *)(ds + o_map), (const float *)(ds + o_map), (const CellCand *)(ds + o_cand),                    \
-                           (float2 *)(ds + o_out), (SelectOut *)(ds + o_so));                                                      \
-    } while (0)
-    if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(0, 52, 1); else OV2_LAUNCH_SELECT(0, 32, 2); }
-    else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(1, 52, 1); else OV2_LAUNCH_SELECT(1, 32, 2); }
-#undef OV2_LAUNCH_SELECT
-    OV2_HIP_CHECK(hipGetLastError());
-    // sub-pixel refinement over the CAPACITY of the output list (the kernel reads the count on the device and the
-    // surplus wavefronts leave at once), then ONE copy of (points, counters) and ONE synchronisation
+    DetBatch B;
+    memset(&B, 0, sizeof(B));
+    rc = enqueue_detect(ctx, mode, im, w, h, im_stride, cell, 1, B, fast_th, mask_mode, roi, quality, ncur, (const float2 *)(ds + o_cur),
+                        ds + o_map, (CellCand *)(ds + o_cand), (float2 *)(ds + o_out), (SelectOut *)(ds + o_so), do_subpix);
+    if (rc) return rc;
+    // ONE copy of (points, counters) and ONE synchronisation
     uint8_t *hs = (uint8_t *)ctx->h_scratch;
-    const int cap = mode == 0 ? ncells : 2 * ncells;
-    if (do_subpix) {
-        rc = launch_subpix(ctx, im, w, h, im_stride, (float2 *)(ds + o_out), cap, 3, 30, 0.01, (const int *)(ds + o_so));
-        if (rc) return rc;
-    }
     OV2_HIP_CHECK(hipMemcpyAsync(hs, ds + o_out, 16 * (size_t)ncells + sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(so_h, hs + 16 * (size_t)ncells, sizeof(SelectOut));
@@ -941,6 +1000,85 @@ int ov2_detect_singlescale_d(ov2_ctx *ctx, const ov2_pyr *pyr, int item, int cel
     if ((double)so.n < 0.33 * (double)(ncells - so.nboccup)) *quality_inout = q / 2.;                         // :418-423
     else if ((double)so.n > 0.9 * (double)(ncells - so.nboccup)) *quality_inout = q * 1.5;
     return OV2_OK;
+}
+
+// Batched device-resident detection: every batch item of the pyramid in ONE call (chunks of 256 items share the response /
+// candidate scratch; launches of successive chunks are stream-ordered, one host synchronisation at the end).
+static int detect_batch(ov2_ctx *ctx, int mode, const ov2_pyr *pyr, int cell, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                        int *fast_th_inout, int mask_mode, const int roi[4], double *quality_inout, int do_subpix,
+                        float *out_xy_d, int out_cap, int *out_n_h)
+{
+    OV2_REQUIRE(ctx && pyr && out_xy_d && out_n_h, OV2_EINVAL, "NULL argument");
+    const uint8_t *img; int w, h, stride;
+    int rc = pyr_level0(ctx, pyr, 0, &img, &w, &h, &stride);
+    if (rc != OV2_OK) return rc;
+    const int items = pyr->d.batch;
+    OV2_REQUIRE(cell >= 8 && cell <= DET_MAX_CELL, OV2_EUNSUPPORTED, "cell size must be in [8,64]");
+    OV2_REQUIRE(w < 65536 && h < 32768, OV2_EUNSUPPORTED, "image too large");
+    OV2_REQUIRE(cur_cap >= 0 && (ncur_d == nullptr || cur_xy_d != nullptr), OV2_EINVAL, "bad current keypoints");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    OV2_HIP_CHECK(det_raise_lds_limits());
+    const int nw = w / cell, nh = h / cell, ncells = nw * nh, npx = cell * cell, wpr = (w + 31) / 32;
+    for (int i = 0; i < items; i++) out_n_h[i] = 0;
+    if (ncells == 0) return OV2_OK;
+    const int cap = mode == 0 ? ncells : 2 * ncells;
+    OV2_REQUIRE(out_cap >= cap, OV2_EINVAL, "out_cap too small: (w/cell)*(h/cell) points per item for FAST, twice that for single scale");
+    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
+    OV2_REQUIRE(sel_lds <= 160 * 1024, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask");
+    const int chunk = std::min(items, 256);
+    const size_t map_bytes = (size_t)ncells * npx * (mode == 0 ? 1 : 4);
+    const size_t o_map = 0, o_cand = (o_map + (size_t)chunk * map_bytes + 255) & ~(size_t)255;
+    const size_t o_so = (o_cand + (size_t)chunk * ncells * sizeof(CellCand) + 255) & ~(size_t)255;
+    const size_t o_par = (o_so + (size_t)items * sizeof(SelectOut) + 255) & ~(size_t)255;       // per-item threshold / quality
+    const size_t total = o_par + (size_t)items * 8;
+    rc = ctx->reserve_device(total); if (rc) return rc;
+    rc = ctx->reserve_host((size_t)items * sizeof(SelectOut)); if (rc) return rc;
+    uint8_t *ds = (uint8_t *)ctx->d_scratch;
+    if (mode == 0) OV2_HIP_CHECK(hipMemcpyAsync(ds + o_par, fast_th_inout, 4 * (size_t)items, hipMemcpyHostToDevice, ctx->stream));
+    else OV2_HIP_CHECK(hipMemcpyAsync(ds + o_par, quality_inout, 8 * (size_t)items, hipMemcpyHostToDevice, ctx->stream));
+    for (int c0 = 0; c0 < items; c0 += chunk) {
+        const int n = std::min(chunk, items - c0);
+        DetBatch B;
+        memset(&B, 0, sizeof(B));
+        B.img_stride = (long long)pyr->d.item_stride; B.cur_stride = cur_cap; B.out_stride = out_cap;
+        B.ncur = ncur_d ? ncur_d + c0 : nullptr;
+        if (mode == 0) B.fast_th = (const int *)(ds + o_par) + c0; else B.quality = (const double *)(ds + o_par) + c0;
+        rc = enqueue_detect(ctx, mode, img + (long long)c0 * pyr->d.item_stride, w, h, stride, cell, n, B, 0, mask_mode, roi, 0.0, 0,
+                            (const float2 *)cur_xy_d + (long long)c0 * cur_cap, ds + o_map, (CellCand *)(ds + o_cand),
+                            (float2 *)out_xy_d + (long long)c0 * out_cap, (SelectOut *)(ds + o_so) + c0, do_subpix);
+        if (rc) return rc;
+    }
+    SelectOut *so = (SelectOut *)ctx->h_scratch;
+    OV2_HIP_CHECK(hipMemcpyAsync(so, ds + o_so, (size_t)items * sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < items; i++) {
+        out_n_h[i] = so[i].n;
+        if (mode == 0) {                                                 // threshold adaptation (:546-552), int *= double truncates
+            const int th = fast_th_inout[i];
+            if ((double)so[i].nbkps < 0.5 * (double)so[i].nbempty && so[i].nbempty > 10) fast_th_inout[i] = (int)(th * 0.66);
+            else if (so[i].nbkps == so[i].nbempty) fast_th_inout[i] = (int)(th * 1.5);
+        } else {                                                         // :418-423
+            const double q = quality_inout[i];
+            if ((double)so[i].n < 0.33 * (double)(ncells - so[i].nboccup)) quality_inout[i] = q / 2.;
+            else if ((double)so[i].n > 0.9 * (double)(ncells - so[i].nboccup)) quality_inout[i] = q * 1.5;
+        }
+    }
+    return OV2_OK;
+}
+
+int ov2_detect_singlescale_batch_d(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                                   const int roi[4], double *quality_inout, int do_subpix, float *out_xy_d, int out_cap, int *out_n_h)
+{
+    OV2_REQUIRE(quality_inout != nullptr && roi != nullptr, OV2_EINVAL, "quality_inout / roi == NULL");
+    return detect_batch(ctx, 1, pyr, cell, cur_xy_d, cur_cap, ncur_d, nullptr, 0, roi, quality_inout, do_subpix, out_xy_d, out_cap, out_n_h);
+}
+
+int ov2_detect_grid_fast_batch_d(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                                 int *fast_th_inout, int mask_mode, int do_subpix, float *out_xy_d, int out_cap, int *out_n_h)
+{
+    OV2_REQUIRE(fast_th_inout != nullptr, OV2_EINVAL, "fast_th_inout == NULL");
+    OV2_REQUIRE(mask_mode == OV2_MASK_AS_EXECUTED || mask_mode == OV2_MASK_INTENDED, OV2_EINVAL, "bad mask_mode");
+    return detect_batch(ctx, 0, pyr, cell, cur_xy_d, cur_cap, ncur_d, fast_th_inout, mask_mode, nullptr, nullptr, do_subpix, out_xy_d, out_cap, out_n_h);
 }
 
 int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stride,

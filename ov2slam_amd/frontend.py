@@ -375,6 +375,31 @@ class FeatureExtractor:
         self.dmaxquality_ = q.value
         return out[:n.value].copy()
 
+    @staticmethod
+    def detectSingleScaleBatch(ctx, pyr, ncellsize, cur_xy_d, cur_cap, ncur_d, roi, quality, out_xy_d, out_cap, subpix=True):
+        """ov2_detect_singlescale_batch_d: detectSingleScale on EVERY batch item of `pyr` in one call.  cur_xy_d / ncur_d /
+        out_xy_d are device addresses (ints; 0 = NULL for the first two), `quality` a float64 array with one dmaxquality_ per
+        item (updated in place like the member).  Returns the per-item point counts (int32 array)."""
+        q = np.ascontiguousarray(quality, np.float64)
+        assert q is quality or np.shares_memory(q, quality), "quality must be a contiguous float64 array (updated in place)"
+        n = np.zeros(pyr.batch, np.int32)
+        r = (C.c_int * 4)(*[int(v) for v in roi])
+        L.check(ctx.lib.ov2_detect_singlescale_batch_d(ctx.h, pyr.h_pyr, int(ncellsize), C.c_void_p(cur_xy_d or None), int(cur_cap),
+                                                       C.c_void_p(ncur_d or None), r, q.ctypes.data_as(C.c_void_p), 1 if subpix else 0,
+                                                       C.c_void_p(out_xy_d), int(out_cap), n.ctypes.data_as(C.c_void_p)))
+        return n
+
+    @staticmethod
+    def detectGridFASTBatch(ctx, pyr, ncellsize, cur_xy_d, cur_cap, ncur_d, fast_th, out_xy_d, out_cap, mask_mode=L.OV2_MASK_AS_EXECUTED, subpix=True):
+        """ov2_detect_grid_fast_batch_d; `fast_th` an int32 array with one nfast_th_ per item (updated in place)."""
+        t = np.ascontiguousarray(fast_th, np.int32)
+        assert t is fast_th or np.shares_memory(t, fast_th), "fast_th must be a contiguous int32 array (updated in place)"
+        n = np.zeros(pyr.batch, np.int32)
+        L.check(ctx.lib.ov2_detect_grid_fast_batch_d(ctx.h, pyr.h_pyr, int(ncellsize), C.c_void_p(cur_xy_d or None), int(cur_cap),
+                                                     C.c_void_p(ncur_d or None), t.ctypes.data_as(C.c_void_p), int(mask_mode), 1 if subpix else 0,
+                                                     C.c_void_p(out_xy_d), int(out_cap), n.ctypes.data_as(C.c_void_p)))
+        return n
+
     def detectGridFASTPyr(self, pyr, ncellsize, vcurkps, subpix=True, item=0):
         """detectGridFAST on level 0 of a device-resident pyramid."""
         cur = np.ascontiguousarray(vcurkps, dtype=np.float32).reshape(-1, 2)

@@ -170,3 +170,92 @@ def test_device_resident_detectors_read_pyramid_level0(gpu_ctx, oracle, wh):
         r, th = oracle.detect_grid_fast(eq, 50, curkps, 10)
         assert len(g) == len(r) and np.array_equal(_bits(g), _bits(r)) and fa.nfast_th_ == th
     trk.close()
+
+
+_BATCH_DETECT_SCRIPT = r"""
+import ctypes as C, os, sys, numpy as np
+import torch
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import ov2slam_amd
+from ov2slam_amd import synth
+ctx = ov2slam_amd.Context(0)
+B, W, H, CELL, NCUR = 11, 376, 240, 35, 48            # 11 items; with chunk = 256 one chunk -- OV2 tests the chunk loop below with B > 256
+rng = np.random.default_rng(5)
+imgs, curs, ncur = [], np.zeros((B, NCUR, 2), np.float32), np.zeros(B, np.int32)
+for b in range(B):
+    img, _, _ = synth.frame_pair(W, H, seed=90 + b)
+    if b == 3: img = np.full_like(img, 128)                       # a flat image: nothing to detect
+    imgs.append(img)
+    k = synth.grid_keypoints(W, H, CELL, rng)
+    n = [0, 5, 48, 17][b % 4]
+    curs[b, :n] = k[:n]; ncur[b] = n
+P = ov2slam_amd.Pyramid(ctx, W, H, 9, 0, batch=B).build(np.stack(imgs))
+ctx.sync()
+ncells = (W // CELL) * (H // CELL)
+roi = (5, 5, W - 10, H - 10)
+d_cur = torch.from_numpy(curs).cuda(); d_n = torch.from_numpy(ncur).cuda()
+for subpix in (True, False):
+    # ---- single scale ----
+    cap = 2 * ncells + 3
+    d_out = torch.full((B, cap, 2), -7.0, dtype=torch.float32, device="cuda")
+    q = np.array([1e-3, 1e-2, 1e-4, 1e-3, 0.5, 1e-3, 1e-3, 1e-5, 1e-3, 1e-3, 1e-2], np.float64)
+    q0 = q.copy()
+    torch.cuda.synchronize()
+    n = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P, CELL, d_cur.data_ptr(), NCUR, d_n.data_ptr(), roi, q, d_out.data_ptr(), cap, subpix=subpix)
+    out = d_out.cpu().numpy()
+    for b in range(B):
+        fx = ov2slam_amd.FeatureExtractor(ctx, dmaxquality=float(q0[b]))
+        ref = fx.detectSingleScale(imgs[b], CELL, curs[b, :ncur[b]], roi, subpix=subpix)
+        assert n[b] == len(ref), ("singlescale count", b, n[b], len(ref))
+        assert np.array_equal(out[b, :n[b]].view(np.uint32), ref.view(np.uint32)), ("singlescale", b)
+        assert np.all(out[b, 2 * ncells:] == -7.0), "slots beyond the list capacity must stay untouched"
+        assert q[b] == fx.dmaxquality_, ("quality adaptation", b, q[b], fx.dmaxquality_)
+    assert n[3] == 0 and n.sum() > 100
+    # ---- FAST, both mask modes ----
+    for mode in (ov2slam_amd._lib.OV2_MASK_AS_EXECUTED, ov2slam_amd._lib.OV2_MASK_INTENDED):
+        cap = ncells
+        d_out = torch.full((B, cap, 2), -7.0, dtype=torch.float32, device="cuda")
+        th = np.array([10, 20, 5, 10, 40, 7, 10, 10, 3, 10, 60], np.int32)
+        th0 = th.copy()
+        torch.cuda.synchronize()
+        n = ov2slam_amd.FeatureExtractor.detectGridFASTBatch(ctx, P, CELL, d_cur.data_ptr(), NCUR, d_n.data_ptr(), th, d_out.data_ptr(), cap, mask_mode=mode, subpix=subpix)
+        out = d_out.cpu().numpy()
+        for b in range(B):
+            fx = ov2slam_amd.FeatureExtractor(ctx, nfast_th=int(th0[b]), mask_mode=mode)
+            ref = fx.detectGridFAST(imgs[b], CELL, curs[b, :ncur[b]], subpix=subpix)
+            assert n[b] == len(ref), ("fast count", b, n[b], len(ref))
+            assert np.array_equal(out[b, :n[b]].view(np.uint32), ref.view(np.uint32)), ("fast", b)
+            assert th[b] == fx.nfast_th_, ("threshold adaptation", b)
+# no current keypoints at all (NULL lists)
+cap = 2 * ncells
+d_out = torch.zeros((B, cap, 2), dtype=torch.float32, device="cuda"); q = np.full(B, 1e-3)
+torch.cuda.synchronize()
+n = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P, CELL, 0, 0, 0, roi, q, d_out.data_ptr(), cap)
+out = d_out.cpu().numpy()
+for b in (0, 7):
+    ref = ov2slam_amd.FeatureExtractor(ctx, dmaxquality=1e-3).detectSingleScale(imgs[b], CELL, np.zeros((0, 2), np.float32), roi)
+    assert n[b] == len(ref) and np.array_equal(out[b, :n[b]].view(np.uint32), ref.view(np.uint32))
+# more items than one scratch chunk holds (256): items 0..299 cycle through the 11 images
+B2 = 300
+P2 = ov2slam_amd.Pyramid(ctx, W, H, 9, 0, batch=B2).build(np.stack([imgs[i % B] for i in range(B2)]))
+d_out = torch.zeros((B2, cap, 2), dtype=torch.float32, device="cuda"); q = np.full(B2, 1e-3)
+torch.cuda.synchronize()
+n2 = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P2, CELL, 0, 0, 0, roi, q, d_out.data_ptr(), cap)
+out2 = d_out.cpu().numpy()
+for i in (0, 255, 256, 299):
+    assert n2[i] == n[i % B] and np.array_equal(out2[i, :n2[i]], out[i % B, :n2[i]]), ("chunked batch", i)
+print("BATCH_DETECT_OK")
+"""
+
+
+def test_batched_device_resident_detectors():
+    """ov2_detect_singlescale_batch_d / ov2_detect_grid_fast_batch_d: every batch item of a pyramid in one call, device-resident
+    keypoint lists in and out, per-item adaptive state -- identical, item by item, to the single-image forms (which the tests above
+    pin to the oracle).  Own process: torch owns the device buffers and has to initialise HIP first."""
+    import os, subprocess, sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _BATCH_DETECT_SCRIPT, root], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BATCH_DETECT_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
