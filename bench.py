@@ -533,16 +533,30 @@ def main():
         det_out = torch.zeros((S, cap, 2), dtype=torch.float32, device=dev)
         qual = np.full(S, 1e-3)
         roi = (5, 5, W - 10, H - 10)
-        torch.cuda.synchronize()
-        n_det = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[0], CELL, 0, 0, 0, roi, qual, det_out.data_ptr(), cap)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            qual[:] = 1e-3
-            n_det = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[0], CELL, 0, 0, 0, roi, qual, det_out.data_ptr(), cap)
-        det_ms = (time.perf_counter() - t1) / 3 * 1e3
+        def timed_detect(cur_ptr, cur_cap, n_ptr):
+            torch.cuda.synchronize()
+            nd = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[0], CELL, cur_ptr, cur_cap, n_ptr, roi, qual, det_out.data_ptr(), cap)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                qual[:] = 1e-3
+                nd = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[0], CELL, cur_ptr, cur_cap, n_ptr, roi, qual, det_out.data_ptr(), cap)
+            return (time.perf_counter() - t1) / 3 * 1e3, nd
+        det_ms, n_det = timed_detect(0, 0, 0)
+        # the keyframe case: the tracked keypoints of every sequence occupy their cells, the detector tops the set up
+        # (every second keypoint of the frame: about half of the cells stay occupied, the usual state at a keyframe request)
+        cur_half = kps_d[0][:, ::2].contiguous()
+        n_half = int(cur_half.shape[1])
+        ncur_d = torch.full((S,), n_half, dtype=torch.int32, device=dev)
+        top_ms, n_top = timed_detect(cur_half.data_ptr(), n_half, ncur_d.data_ptr())
+        step_ms = elapsed / args.steps * 1e3
         det_batch = {"detect_singlescale_batch_ms": det_ms, "images": S, "us_per_image": det_ms * 1e3 / S,
                      "points_per_image": float(n_det.mean()),
-                     "entry": "ov2_detect_singlescale_batch_d on level 0 of the batch pyramid (device-resident lists, one sync)"}
+                     "topup_ms": top_ms, "topup_us_per_image": top_ms * 1e3 / S, "topup_points_per_image": float(n_top.mean()),
+                     "topup_current_keypoints": n_half,
+                     "frames_per_s_with_keyframe_every_5th": S / ((step_ms + top_ms / 5.0) * 1e-3),
+                     "entry": "ov2_detect_singlescale_batch_d on level 0 of the batch pyramid (device-resident lists, one sync): "
+                              "no current keypoints / topping up %d tracked keypoints per sequence; the last figure adds a fifth of the "
+                              "top-up call to the tracking step (keyframe every 5th frame)" % n_half}
         del det_out
     del frames_d, kps_d, pri_d, pri_work, status_d
     for p in pyrs:

@@ -55,7 +55,9 @@ struct DetBatch {
     int ncells;                // cells per image
     int cur_stride;            // float2 entries between the items' current-keypoint lists
     int out_stride;            // float2 entries between the items' output lists
-    const int *ncur;           // per-item number of current keypoints   (NULL: SelectParams::ncur)
+    const int *ncur;           // per-item number of current keypoints   (NULL: ncur_all)
+    const float2 *cur;         // item 0's current keypoints (the cell kernels skip occupied cells like the reference's loop does)
+    int ncur_all;              // number of current keypoints when ncur == NULL
     const int *fast_th;        // per-item FAST threshold                (NULL: the scalar argument)
     const double *quality;     // per-item quality level                 (NULL: SelectParams::quality)
 };
@@ -99,6 +101,21 @@ __device__ __forceinline__ void block_argmax_f(float &v, int &idx, float *s_v, i
     }
 }
 
+// true when a current keypoint lies in cell (r, c): the reference's loops `continue` on such cells before computing anything
+// (voccupcells, :296-319 / :451-474: r = (int)(y / cs), c = (int)(x / cs)); all lanes of the calling wavefront get the answer
+__device__ __forceinline__ bool d_cell_occupied(const DetBatch &B, int item, int cs, int r, int c)
+{
+    const int n = B.ncur ? B.ncur[item] : B.ncur_all;
+    if (n <= 0 || B.cur == nullptr) return false;
+    const float2 *cur = B.cur + (long long)item * B.cur_stride;
+    bool hit = false;
+    for (int i = threadIdx.x & 63; i < n; i += 64) {
+        const float2 p = cur[i];
+        if ((int)(p.y / (float)cs) == r && (int)(p.x / (float)cs) == c) hit = true;
+    }
+    return __builtin_amdgcn_ballot_w64(hit) != 0;
+}
+
 // ---------------------------------------------------------------------------------
 // FAST-9/16 + score + 3x3 NMS on the cs x cs sub-image of every cell (cv::FAST semantics)
 // out: per cell cs*cs bytes, NMS-surviving corners hold their score (>0), everything else 0
@@ -121,6 +138,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     nms_out += (long long)item * B.ncells * npx;
     cand_out += (long long)item * B.ncells;
     if (B.fast_th) { const int t = B.fast_th[item]; threshold = t < 0 ? 0 : (t > 255 ? 255 : t); }
+    if (d_cell_occupied(B, item, cs, cell / nwcells, cell % nwcells)) return;      // (work-group-uniform: every wavefront scans the whole list)
     for (int p = threadIdx.x; p < npx; p += blockDim.x) {
         const int ly = p / cs, lx = p - ly * cs;
         tile[p] = img[(long long)(y0 + ly) * stride + x0 + lx];
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(64) void k_mineig_cells(const uint8_t *__restrict__
     hmap_out += (long long)item * B.ncells * npx;
     cand_out += (long long)item * B.ncells;
     const int lane = threadIdx.x;
+    if (d_cell_occupied(B, item, cs, cell / nwcells, cell % nwcells)) return;
     const bool act = lane < cs;
     const int x = act ? lane : cs - 1;                        // idle lanes shadow the last column (their results are never stored)
     if (lane == 0) d_circle_halfwidths(s_hw, radius);
@@ -826,7 +845,7 @@ static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int 
 {
     const int nw = w / cell, nh = h / cell, ncells = nw * nh, npx = cell * cell, wpr = (w + 31) / 32;
     const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
-    B.ncells = ncells;
+    B.ncells = ncells; B.cur = cur_d; B.ncur_all = ncur;
     if (mode == 0) {
         int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
         hipLaunchKernelGGL(k_fast_cells, dim3(ncells * items), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, maps_d, mask_mode, cand_d, B);
