@@ -516,11 +516,12 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; they come
     # from the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of tools/profile.sh whose summary
     # is committed under profiles/ (same workload and seqs_per_gpu, else null)
-    traffic, traffic_note = None, None
+    traffic, traffic_note, limiter_kind, valu_frac = None, None, None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))
         if tj.get("seqs_per_gpu") == S and args.workload == "euroc":
             traffic = tj["hbm_bytes_per_launch"]; traffic_note = tj.get("limiter")
+            limiter_kind, valu_frac = tj.get("limiter_kind"), tj.get("valu_issue_frac")
     except Exception:
         pass
 
@@ -585,6 +586,8 @@ def main():
                        "seqs_per_gpu": S, "keypoints_per_frame": NKPS, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fb_klt3", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         # what actually limits the kernel (SQ counters of the committed PMC pass): the fraction of SIMD issue slots in use
+                         "limiter": limiter_kind, "valu_issue_frac": valu_frac,
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_total / max(1, n_launch),
                          "gn_iterations": iters, "patch_builds": visits},
