@@ -19,3 +19,7 @@ timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 cd $ROOT
 ls $OUT
 python tools/summarize_profile.py $OUT
+# the per-dispatch traces are tens of MB (gpurun merges at most 64 MiB back): the stats, counters and the summary are what is kept
+find $OUT -name "*_kernel_trace.csv" -delete
+find $OUT -name "*.db" -delete
+
