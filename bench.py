@@ -622,6 +622,30 @@ def main():
             trk.close()
             out["detect"] = {"detect_singlescale_ms_incl_pcie": det_ms, "detected_points": int(len(det)),
                              "detect_singlescale_pyramid_resident_ms": det_d_ms, "detected_points_pyramid_resident": int(len(det_d))}
+            # ---- a stereo keyframe on the mapper's context: right image CLAHE + pyramid, then MapManager::stereoMatching's data path
+            #      (SAD priors, 1-level prior tracks + retry, full-pyramid tracks, epipolar gate) -- one call vs the call sequence
+            from ov2slam_amd import stereo as _st
+            left_img = views[0]; right_img = np.roll(views[0], -20, axis=1)
+            lp = ov2slam_amd.Pyramid(ctx1, W, H, WIN, LEVELS).build_clahe(left_img, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1])
+            rp = ov2slam_amd.Pyramid(ctx1, W, H, WIN, LEVELS)
+            ftrk = ov2slam_amd.FeatureTracker(ctx1, 30, 0.01)
+            rcal = ov2slam_amd.CameraCalibration(ctx1, "pinhole", 458.654, 457.296, 367.215, 248.375, D=None)
+            skps = kps[0, 0][:NKPS].astype(np.float32)
+            p3d = {i: (float(skps[i, 0] - 20.0), float(skps[i, 1])) for i in range(0, NKPS, 2)}
+            def stereo_kf(fn):
+                rp.build_clahe(right_img, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1])
+                return fn(ftrk, lp, rp, skps, skps, rcal, rect=True, priors3d=p3d)
+            res_ms = {}
+            for name, fn in (("fused", _st.stereo_matching_fused), ("call_sequence", _st.stereo_matching)):
+                ok_s, _ = stereo_kf(fn)
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    ok_s, _ = stereo_kf(fn)
+                res_ms[name] = (time.perf_counter() - t1) / 20 * 1e3
+            out["stereo_keyframe"] = {"fused_ms": res_ms["fused"], "call_sequence_ms": res_ms["call_sequence"], "keypoints": int(len(skps)),
+                                      "with_3d_prior": len(p3d), "stereo_ok_fraction": float(ok_s.mean()),
+                                      "entry": "right-image ov2_pyr_build_clahe_h (asynchronous) + ov2_stereo_match, host buffers, one sync; "
+                                               "call_sequence = ov2_line_min_sad + 2 x ov2_fb_klt + ov2_stereo_epipolar_check (4 syncs)"}
             ctx1.close()
             if not args.no_cpu_baseline:
                 out["parity"] = parity_check(dev.index, views, kps, pri)

@@ -466,6 +466,22 @@ int ov2_line_min_sad(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
 int ov2_stereo_epipolar_check(ov2_ctx *ctx, int rect, const double Frl[9], int model, const double K[4], const double *D, int nD,
                               const float *lunpx_xy_h, float *rkps_xy_inout_h, int n, float *runpx_xy_h, float *epi_err_h, uint8_t *ok_h);
 
+/* MapManager::stereoMatching's data path (src/map_manager.cpp:367-611) for the n keypoints of a keyframe in ONE enqueue and ONE
+ * synchronisation (the three calls above need one each, plus a second fbKltTracking):
+ *   rect != 0   getLineMinSAD on pyramid level nklt_pyr_lvl (window 7, searching left) gives the x prior of every keypoint
+ *               without a 3-D prior when it lies in [0, kp.x] (:421-439)
+ *   tracking    keypoints with has_prior3d_h[i] != 0 are tracked from priors3d_h[i] on 1 level first; the ones that fail join
+ *               the second call WITH THE SAME PRIOR (:533-538); everything else runs on nklt_pyr_lvl levels (:544-565)
+ *   gate        ov2_stereo_epipolar_check on the tracked right keypoints (model / K / D of the RIGHT camera, kps_unpx_h = the
+ *               left keypoints' undistorted pixels)
+ * Outputs: stereo_ok_h[i] (what decides updateKeypointStereo, :584) and right_px_h[i] (rect: y replaced by the left keypoint's,
+ * :578; (0, 0) where the tracking itself failed -- a tracked point that the gate rejects keeps its position, stereo_ok 0).  has_prior3d_h / priors3d_h may be NULL (no map-point priors).  The right pyramid may
+ * still be building on this context's stream (ov2_pyr_build_clahe_h is asynchronous).                                      */
+int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int nklt_win_size, int nklt_pyr_lvl, int max_iter,
+                     float eps, float nklt_err, float fmax_fbklt_dist, int rect, const double Frl[9], int model, const double K[4],
+                     const double *D, int nD, const float *kps_px_h, const float *kps_unpx_h, const float *priors3d_h,
+                     const uint8_t *has_prior3d_h, int n, float *right_px_h, uint8_t *stereo_ok_h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,4 +111,5 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
 // fused VisualFrontEnd::kltTracking launch (lk.hip), device pointers only
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
-                         const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters);
+                         const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
+                         const float *sad_x = nullptr, float sad_up = 0.f);      // sad_x: stereo mode (lk.hip: k_track_klt)

@@ -467,15 +467,25 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
                                                   const int *__restrict__ n_dev, const float2 *__restrict__ kps,
                                                   const float2 *__restrict__ priors, const uint8_t *__restrict__ flags,
                                                   float2 *__restrict__ out_xy, uint8_t *__restrict__ status,
-                                                  int *__restrict__ iters_out)
+                                                  int *__restrict__ iters_out, const float *__restrict__ sad_x, float sad_up)
 {
-    const int n = *n_dev;
+    const int n = n_dev ? *n_dev : prm.n_max;
     const int r = threadIdx.x & 15;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
     if (i >= n) return;
     const float2 kp = kps[i];
     float2 pr = priors[i];
     const bool has_prior = (flags[i] & 1) != 0;
+    // sad_x != NULL: MapManager::stereoMatching (src/map_manager.cpp:367-611) -- same two-call structure, but (i) a keypoint
+    // without a 3-D prior starts from its own position with x replaced by the getLineMinSAD prior of the coarsest level when
+    // that lies left of it (:433-437), (ii) a 3-D prior track that fails is retried from the SAME prior (:533-538), not from
+    // the first call's forward result
+    const bool stereo = sad_x != nullptr;
+    if (stereo && !has_prior) {
+        pr = kp;
+        const float xp = sad_x[i] * sad_up;
+        if (xp >= 0.f && xp <= kp.x) pr.x = xp;
+    }
     int max_level = has_prior ? lvl_prior : lvl_full;
     int ok = 0, retried = 0, iters = 0;
     float fx = 0.f, fy = 0.f;
@@ -484,7 +494,8 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
         ok = fb_track_point<WIN>(P.base, C.base, P, C, prm, max_level, kp, pr, r, fx, fy, st);
         iters += st.iters;
         if (ok || !has_prior || attempt == 1) break;
-        pr = make_float2(fx, fy); max_level = lvl_full; retried = 1;      // :213-217
+        if (!stereo) pr = make_float2(fx, fy);                            // :213-217
+        max_level = lvl_full; retried = 1;
     }
     if (r == 0) {
         out_xy[i] = make_float2(fx, fy);
@@ -598,7 +609,8 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
 // launcher of the fused kltTracking kernel (used by track.hip); all pointers are device memory, *n_dev <= n_max
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
-                         const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters)
+                         const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
+                         const float *sad_x, float sad_up)
 {
     const PyrDesc &P = prev->d, &C = cur->d;
     OV2_REQUIRE(P.n_levels == C.n_levels && P.batch == 1 && C.batch == 1 && P.win == C.win && win == P.win, OV2_EINVAL,
@@ -609,7 +621,7 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
     const int lp = lvl_prior > P.n_levels - 1 ? P.n_levels - 1 : (lvl_prior < 0 ? 0 : lvl_prior);
     dim3 grid((n_max + 3) / 4), block(64);
 #define OV2_TK(W) hipLaunchKernelGGL(k_track_klt<W>, grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
-                                     (const float2 *)priors, flags, (float2 *)out_xy, status, iters)
+                                     (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up)
     switch (win) {
     case 5:  OV2_TK(5); break;
     case 7:  OV2_TK(7); break;

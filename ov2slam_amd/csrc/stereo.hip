@@ -225,4 +225,77 @@ int ov2_stereo_epipolar_check(ov2_ctx *ctx, int rect, const double Frl[9], int m
     return OV2_OK;
 }
 
+// MapManager::stereoMatching's data path (src/map_manager.cpp:367-611) in ONE enqueue and ONE synchronisation: getLineMinSAD
+// priors on the coarsest level for every keypoint (rectified pairs, :421-439), both fbKltTracking calls and the retry of the
+// failed 3-D-prior tracks in one k_track_klt launch (:497-565), the epipolar gate on the tracked right keypoints (:568-590).
+int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int nklt_win_size, int nklt_pyr_lvl, int max_iter,
+                     float eps, float nklt_err, float fmax_fbklt_dist, int rect, const double Frl[9], int model, const double K[4],
+                     const double *D, int nD, const float *kps_px_h, const float *kps_unpx_h, const float *priors3d_h,
+                     const uint8_t *has_prior3d_h, int n, float *right_px_h, uint8_t *stereo_ok_h)
+{
+    OV2_REQUIRE(ctx && left && right, OV2_EINVAL, "NULL argument");
+    if (n <= 0) return OV2_OK;
+    OV2_REQUIRE(kps_px_h && kps_unpx_h && right_px_h && stereo_ok_h, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(has_prior3d_h == nullptr || priors3d_h != nullptr, OV2_EINVAL, "has_prior3d given without priors3d");
+    OV2_REQUIRE(rect || Frl, OV2_EINVAL, "Frl == NULL for a non-rectified pair");
+    OV2_REQUIRE(left->d.batch == 1 && right->d.batch == 1, OV2_EINVAL, "host-buffer entry point takes batch=1 pyramids");
+    KpCalib c;
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int rc = ov2_kp_calib(model, K, D, nD, I3, c);
+    if (rc != OV2_OK) return rc;
+    EpiParams E;
+    for (int i = 0; i < 9; i++) E.F[i] = Frl ? Frl[i] : 0.;
+    E.rect = rect ? 1 : 0;
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rcw = ov2_pyr_wait_ready(ctx, left)) return rcw;
+    if (int rcw = ov2_pyr_wait_ready(ctx, right)) return rcw;
+    const int lvl = nklt_pyr_lvl > left->d.n_levels - 1 ? left->d.n_levels - 1 : (nklt_pyr_lvl < 0 ? 0 : nklt_pyr_lvl);
+    // layout: [kps 8n][unpx 8n][pri 8n][pts_top 8n][out 8n][runpx 8n][sadx 4n][l1 4n][err 4n][flags n][st n][ok n]
+    const size_t N = (size_t)n, o_k = 0, o_u = 8 * N, o_p = 16 * N, o_t = 24 * N, o_o = 32 * N, o_r = 40 * N, o_s = 48 * N, o_l = 52 * N,
+                 o_e = 56 * N, o_f = 60 * N, o_st = 61 * N, o_ok = 62 * N, total = 63 * N;
+    rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(total);    if (rc) return rc;
+    uint8_t *hs = (uint8_t *)ctx->h_scratch, *ds = (uint8_t *)ctx->d_scratch;
+    memcpy(hs + o_k, kps_px_h, 8 * N);
+    memcpy(hs + o_u, kps_unpx_h, 8 * N);
+    const float up = (float)(1 << lvl), down = 1.f / up;                  // pow(2, nklt_pyr_lvl) and its inverse (:417-418)
+    for (int i = 0; i < n; i++) {
+        const bool hp = has_prior3d_h && has_prior3d_h[i];
+        hs[o_f + i] = hp ? 1 : 0;
+        ((float *)(hs + o_p))[2 * i] = hp ? priors3d_h[2 * i] : kps_px_h[2 * i];
+        ((float *)(hs + o_p))[2 * i + 1] = hp ? priors3d_h[2 * i + 1] : kps_px_h[2 * i + 1];
+        ((float *)(hs + o_t))[2 * i] = kps_px_h[2 * i] * down;             // the keypoint on the coarsest level (:427)
+        ((float *)(hs + o_t))[2 * i + 1] = kps_px_h[2 * i + 1] * down;
+    }
+    OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, 32 * N, hipMemcpyHostToDevice, ctx->stream));
+    OV2_HIP_CHECK(hipMemcpyAsync(ds + o_f, hs + o_f, N, hipMemcpyHostToDevice, ctx->stream));
+    const float *sad_d = nullptr;
+    if (rect) {
+        hipLaunchKernelGGL(k_line_min_sad, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, left->d, right->d, lvl, 7, 1,
+                           (const float2 *)(ds + o_t), n, (float *)(ds + o_s), (float *)(ds + o_l));
+        sad_d = (const float *)(ds + o_s);
+    } else {
+        // not rectified: no line search, every keypoint without a 3-D prior starts from its own position (:440-466): a prior
+        // of -1 is "nothing found" for k_track_klt
+        OV2_HIP_CHECK(hipMemsetAsync(ds + o_s, 0xBF, 4 * N, ctx->stream));                     // 0xBFBFBFBF = -1.498 < 0
+        sad_d = (const float *)(ds + o_s);
+    }
+    rc = ov2_launch_track_klt(ctx->stream, left, right, nklt_win_size, 1, lvl, max_iter, eps, nklt_err, fmax_fbklt_dist, n, nullptr,
+                              (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr, sad_d, up);
+    if (rc != OV2_OK) return rc;
+    hipLaunchKernelGGL(k_epipolar_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_u),
+                       (float2 *)(ds + o_o), n, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok);
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_o, ds + o_o, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_st, ds + o_st, 2 * N, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++) {
+        const bool tracked = (hs[o_st + i] & 1) != 0;
+        stereo_ok_h[i] = (tracked && hs[o_ok + i]) ? 1 : 0;
+        right_px_h[2 * i] = tracked ? ((const float *)(hs + o_o))[2 * i] : 0.f;
+        right_px_h[2 * i + 1] = tracked ? ((const float *)(hs + o_o))[2 * i + 1] : 0.f;
+    }
+    return OV2_OK;
+}
+
 } // extern "C"

@@ -47,6 +47,30 @@ public:
         if (rc != OV2_OK) vxprior.assign(vpts.size(), -1.f);       // degrade to "no prior", like an early return
     }
 
+    // MapManager::stereoMatching's data path (src/map_manager.cpp:367-611) for the keypoints of a keyframe in ONE enqueue and ONE
+    // synchronisation (ov2_stereo_match): SAD priors on the coarsest level (rectified pairs), both fbKltTracking calls with the
+    // retry of the failed 3-D-prior tracks, the epipolar gate.  vpriors3d[i] / vhasprior3d[i]: the projected map point of
+    // keypoint i where one exists (:402-413, :468-480).  On return vstereo_ok[i] decides updateKeypointStereo(id, vrightkps[i]).
+    // rmodel / rK / rD: the RIGHT camera (OV2_CAM_PINHOLE / OV2_CAM_FISHEYE, fx fy cx cy, distortion).
+    void stereoMatching(Context &ctx, const ov2_pyr *leftpyr, const ov2_pyr *rightpyr, int nklt_win_size, int nklt_pyr_lvl, float nklt_err,
+                        float fmax_fbklt_dist, bool rect, const double *Frl, int rmodel, const double rK[4], const std::vector<double> &rD,
+                        const std::vector<Point2f> &vleftkps, const std::vector<Point2f> &vleftunpx, const std::vector<Point2f> &vpriors3d,
+                        const std::vector<uint8_t> &vhasprior3d, std::vector<Point2f> &vrightkps, std::vector<bool> &vstereo_ok) const
+    {
+        const size_t n = vleftkps.size();
+        vrightkps.assign(n, Point2f());
+        vstereo_ok.assign(n, false);
+        if (n == 0) return;
+        std::vector<uint8_t> ok(n, 0);
+        const bool pri = vpriors3d.size() == n && vhasprior3d.size() == n;
+        const int rc = ov2_stereo_match(ctx.get(), leftpyr, rightpyr, nklt_win_size, nklt_pyr_lvl, nmax_iter_, fmax_px_precision_, nklt_err,
+                                        fmax_fbklt_dist, rect ? 1 : 0, Frl, rmodel, rK, rD.empty() ? nullptr : rD.data(), (int)rD.size(),
+                                        &vleftkps[0].x, &vleftunpx[0].x, pri ? &vpriors3d[0].x : nullptr, pri ? vhasprior3d.data() : nullptr,
+                                        (int)n, &vrightkps[0].x, ok.data());
+        if (rc != OV2_OK) return;                                   // degrade to "no stereo observation"
+        for (size_t i = 0; i < n; i++) vstereo_ok[i] = ok[i] != 0;
+    }
+
     // reference: bool inBorder(const cv::Point2f &pt, const cv::Mat &im) const  (:216-221)
     bool inBorder(const Point2f &pt, int cols, int rows) const
     {

@@ -62,3 +62,26 @@ def stereo_matching(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *
         rk, _, _, eok = epipolar_check(ctx, rect, Frl, right_calib, np.asarray(kps_unpx, np.float32)[gi], gr)
         ok[gi] = eok; right[gi] = rk
     return ok, right
+
+
+def stereo_matching_fused(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *, rect, Frl=None, nklt_win_size=9,
+                          nklt_pyr_lvl=3, nklt_err=30.0, fmax_fbklt_dist=0.5, priors3d=None):
+    """ov2_stereo_match: the same flow as stereo_matching() in ONE enqueue and ONE synchronisation (SAD priors, both
+    fbKltTracking calls with the retry of failed 3-D-prior tracks, epipolar gate).  Same arguments, same return."""
+    ctx = tracker.ctx
+    kps_px = np.ascontiguousarray(kps_px, dtype=np.float32).reshape(-1, 2)
+    kps_unpx = np.ascontiguousarray(kps_unpx, dtype=np.float32).reshape(-1, 2)
+    n = len(kps_px)
+    hp = np.zeros(n, np.uint8); p3 = kps_px.copy()
+    for i, xy in (priors3d or {}).items():
+        hp[i] = 1; p3[i] = xy
+    right = np.zeros((n, 2), np.float32); ok = np.zeros(n, np.uint8)
+    F = None if Frl is None else np.ascontiguousarray(Frl, dtype=np.float64).reshape(9)
+    D = right_calib.D
+    L.check(ctx.lib.ov2_stereo_match(ctx.h, leftpyr.h_pyr, rightpyr.h_pyr, int(nklt_win_size), int(nklt_pyr_lvl), int(tracker.nmax_iter),
+                                     float(tracker.fmax_px_precision), float(nklt_err), float(fmax_fbklt_dist), int(bool(rect)),
+                                     _ptr(F) if F is not None else None, right_calib.model, _ptr(right_calib.K),
+                                     _ptr(D) if D is not None else None, 0 if D is None else len(D), _ptr(kps_px), _ptr(kps_unpx),
+                                     _ptr(p3), _ptr(hp), n, _ptr(right), _ptr(ok)))
+    return ok.astype(bool), right
+

@@ -83,6 +83,13 @@ int main(int argc, char **argv)
             std::vector<bool> st;
             trk.fbKltTracking(ctx, p0, p1, 9, 3, 30.f, 0.5f, k, p, st);
             wr_pts(fo, p); wr_bools(fo, st);
+            // MapManager::stereoMatching's data path on the same two pyramids (left = frame 0, right = frame 1)
+            const double rK[4] = {458.654, 457.296, 367.215, 248.375};
+            std::vector<ov2::Point2f> right;
+            std::vector<bool> sok;
+            trk.stereoMatching(ctx, p0.get(), p1.get(), 9, 3, 30.f, 0.5f, true, nullptr, OV2_CAM_PINHOLE, rK, std::vector<double>(), kps, kps, pri,
+                               hasprior, right, sok);
+            wr_pts(fo, right); wr_bools(fo, sok);
         }
         // ---- Optimizer::localBA solve stage ----
         {

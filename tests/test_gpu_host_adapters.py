@@ -63,6 +63,7 @@ def test_cpp_adapters_run_and_match(gpu_ctx, oracle, tmp_path):
         c_fast, c_th = _rd(f, np.float32).reshape(-1, 2), int(_rd(f, np.int32)[0])
         c_ss = _rd(f, np.float32).reshape(-1, 2)
         c_fb, c_fbst = _rd(f, np.float32).reshape(-1, 2), _rd(f, np.uint8)
+        c_sr, c_sok = _rd(f, np.float32).reshape(-1, 2), _rd(f, np.uint8)
         c_flags, c_poses, c_lam, c_badobs = _rd(f, np.int32), _rd(f, np.float64), _rd(f, np.float64), _rd(f, np.uint8)
 
     # ---- FrameTracker vs the ctypes mirror and vs the oracle ----
@@ -93,6 +94,15 @@ def test_cpp_adapters_run_and_match(gpu_ctx, oracle, tmp_path):
     Gp = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(prev); Gc = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(cur)
     g_fb, g_fbst = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01).fbKltTracking(Gp, Gc, 9, 3, 30., 0.5, kps, pri)
     assert np.array_equal(_bits(c_fb), _bits(g_fb)) and np.array_equal(c_fbst.astype(bool), g_fbst.astype(bool)) and c_fbst.mean() > 0.5
+    # ---- FeatureTracker::stereoMatching (ov2_stereo_match) == the ctypes mirror's fused and multi-call flows ----
+    from ov2slam_amd import stereo
+    cal = ov2slam_amd.CameraCalibration(gpu_ctx, "pinhole", 458.654, 457.296, 367.215, 248.375, D=None)
+    p3d = {int(i): (float(pri[i, 0]), float(pri[i, 1])) for i in np.nonzero(hp)[0]}
+    ftrk = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01)
+    g_sok, g_sr = stereo.stereo_matching_fused(ftrk, Gp, Gc, kps, kps, cal, rect=True, priors3d=p3d)
+    m_sok, m_sr = stereo.stereo_matching(ftrk, Gp, Gc, kps, kps, cal, rect=True, priors3d=p3d)
+    assert np.array_equal(c_sok.astype(bool), g_sok) and np.array_equal(_bits(c_sr), _bits(g_sr))
+    assert np.array_equal(g_sok, m_sok) and np.array_equal(_bits(g_sr), _bits(m_sr))
     # ---- Optimizer::localBA: same protocol, same library ----
     g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
     assert c_flags[0] == 1 and bool(c_flags[1]) == bool(g["l2_done"])

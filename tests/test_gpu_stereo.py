@@ -97,3 +97,36 @@ def test_stereo_matching_flow(gpu_ctx, oracle):
     assert np.array_equal(ok, rok) and np.array_equal(right, rright)
     assert ok.mean() > 0.9
     assert np.abs((kps[ok, 0] - right[ok, 0]) - disp).max() < 0.5
+
+
+@pytest.mark.parametrize("rect", [True, False])
+def test_fused_stereo_match_equals_the_call_sequence(gpu_ctx, oracle, rect):
+    """ov2_stereo_match (SAD priors + both fbKltTracking calls + retry + gate in one enqueue, one sync) returns what the
+    sequence of separate calls returns -- which test_stereo_matching_flow pins to the oracle -- including the retry of failed
+    3-D-prior tracks from the SAME prior and, for a non-rectified pair, the Sampson gate."""
+    w, h, disp = 752, 480, 20
+    l, r = _pair(w, h, disp, 23)
+    pl = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(l)
+    pr = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(r)
+    trk = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01)
+    cal = ov2slam_amd.CameraCalibration(gpu_ctx, "pinhole", *K, D=None)
+    rng = np.random.default_rng(8)
+    kps = synth.grid_keypoints(w, h, 35, rng)[:300]
+    unpx = kps
+    pri3d = {i: (kps[i, 0] - disp + rng.normal(0, 1.0), kps[i, 1] + rng.normal(0, 0.3)) for i in range(0, 90)}
+    for i in range(0, 90, 4):                                     # a quarter of the 3-D priors far off: lost on 2 levels, retried on 4
+        pri3d[i] = (pri3d[i][0] + 14.0, pri3d[i][1] - 9.0)
+    # fundamental matrix of a pure x-translation between identical pinhole cameras: rows of equal y are the epipolar lines
+    F = None if rect else np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
+    ok_a, right_a = stereo.stereo_matching(trk, pl, pr, kps, unpx, cal, rect=rect, Frl=F, priors3d=pri3d)
+    ok_b, right_b = stereo.stereo_matching_fused(trk, pl, pr, kps, unpx, cal, rect=rect, Frl=F, priors3d=pri3d)
+    assert np.array_equal(ok_a, ok_b)
+    assert np.array_equal(right_a.view(np.uint32), right_b.view(np.uint32))
+    assert ok_b.mean() > 0.85
+    # the right pyramid may still be building when the call is made (asynchronous build on the same context)
+    pr2 = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3)
+    pr2.build(r)
+    ok_c, right_c = stereo.stereo_matching_fused(trk, pl, pr2, kps, unpx, cal, rect=rect, Frl=F)
+    ok_d, right_d = stereo.stereo_matching(trk, pl, pr, kps, unpx, cal, rect=rect, Frl=F)
+    assert np.array_equal(ok_c, ok_d) and np.array_equal(right_c.view(np.uint32), right_d.view(np.uint32))
+
