@@ -124,6 +124,101 @@ struct BAOpt {
     int jacobi, max_invalid;
 };
 
+// ---------------------------------------------------------------------------------- trust-region bookkeeping (one thread)
+// The three scalar state machines of Ceres' TrustRegionMinimizer as pure functions on the control block, shared by the
+// multi-kernel solver (k_ba_iter_begin / k_ba_candidate / k_ba_decide) and the single-kernel pose-only solver (k_pnp_solve).
+__device__ __forceinline__ void d_ctl_iter_begin(BACtl &cl, const BAOpt &O, int fresh, double gmax)
+{
+    BACtl *ctl = &cl;
+    if (fresh) {
+        ctl->gmax = gmax;
+        ctl->x_cost = ctl->cost_acc;
+        ctl->cost_acc = 0;
+        if (!ctl->scaled) {             // iteration zero
+            ctl->scaled = 1;
+            ctl->initial_cost = ctl->x_cost; ctl->minimum_cost = ctl->x_cost;
+            ctl->ev_min = ctl->ev_cur = ctl->ev_ref = ctl->ev_cand = ctl->x_cost;
+            ctl->ev_acc_ref = ctl->ev_acc_cand = 0; ctl->ev_nonmono = 0;
+        }
+        ctl->fresh_lin = 0;
+        ctl->reuse_diag = 0;
+    }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (ctl->step_successful) {
+        ctl->n_success++;
+        if (ctl->x_cost < ctl->minimum_cost) ctl->minimum_cost = ctl->x_cost;
+    }
+    if (ctl->iteration >= O.max_iter) { ctl->termination = OV2_TERM_NO_CONVERGENCE; ctl->done = 1; }
+    else if (ctl->step_successful && ctl->gmax <= O.gtol) { ctl->termination = OV2_TERM_GRADIENT_TOL; ctl->done = 1; }
+    else if (ctl->radius <= O.min_radius) { ctl->termination = OV2_TERM_MIN_RADIUS; ctl->done = 1; }
+    else {
+        ctl->iteration++;
+        ctl->step_successful = 0;
+        ctl->step_valid = 0;
+        ctl->lin_fail = 0;
+        ctl->n_steps++;
+        ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0;
+    }
+}
+
+// returns 1 when the step is valid (model cost change > 0); P1 = y . g'_f, P2 = y^T H'_pp y of the pose part
+__device__ __forceinline__ int d_ctl_candidate(BACtl &cl, const BAOpt &O, int ok, double P1, double P2)
+{
+    BACtl *ctl = &cl;
+    int valid = 0;
+    if (ok) {
+        // model_cost_change = -(J step).(r + J step / 2) with step = -y  ==  y.g' - y^T H' y / 2
+        const double mcc = (P1 + ctl->acc1) - 0.5 * (P2 + ctl->acc3 + ctl->acc2);
+        ctl->model_cost_change = mcc;
+        valid = mcc > 0.0;
+    }
+    if (!valid) {
+        // HandleInvalidStep (trust_region_minimizer.cc:436-459)
+        if (++ctl->num_invalid >= O.max_invalid) { ctl->termination = OV2_TERM_INVALID_STEPS; ctl->done = 1; }
+        else { ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1; }
+        ctl->step_valid = 0;
+    } else {
+        ctl->num_invalid = 0;
+        ctl->step_valid = 1;
+    }
+    return valid;
+}
+
+// returns 1 when the candidate is accepted; SN = |x - candidate|^2, XN = |candidate|^2 over the variable blocks
+__device__ __forceinline__ int d_ctl_decide(BACtl &cl, const BAOpt &O, double SN, double XN)
+{
+    BACtl *ctl = &cl;
+    int accept = 0;
+    const double cand = ctl->cost_acc;
+    ctl->cost_acc = 0;
+    ctl->cand_cost = cand;
+    if (sqrt(SN) <= O.ptol * (ctl->x_norm + O.ptol)) { ctl->termination = OV2_TERM_PARAMETER_TOL; ctl->done = 1; }
+    else if (fabs(ctl->x_cost - cand) <= O.ftol * ctl->x_cost) { ctl->termination = OV2_TERM_FUNCTION_TOL; ctl->done = 1; }
+    else {
+        const double mcc = ctl->model_cost_change;
+        const double r1 = (ctl->ev_cur - cand) / mcc, r2 = (ctl->ev_ref - cand) / (ctl->ev_acc_ref + mcc);
+        const double rel = fmax(r1, r2);
+        if (rel > O.min_rel_decrease) {
+            accept = 1;
+            ctl->x_norm = sqrt(XN);
+            ctl->step_successful = 1;
+            ctl->need_lin = 1;
+            // LevenbergMarquardtStrategy::StepAccepted
+            const double t = 2.0 * rel - 1.0;
+            ctl->radius = fmin(O.max_radius, ctl->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            ctl->decrease_factor = 2.0; ctl->reuse_diag = 0;
+            // TrustRegionStepEvaluator::StepAccepted (max_consecutive_nonmonotonic_steps = 0)
+            ctl->ev_cur = cand; ctl->ev_acc_cand += mcc; ctl->ev_acc_ref += mcc;
+            if (ctl->ev_cur < ctl->ev_min) { ctl->ev_min = ctl->ev_cur; ctl->ev_nonmono = 0; ctl->ev_cand = ctl->ev_cur; ctl->ev_acc_cand = 0; }
+            else { ctl->ev_nonmono++; if (ctl->ev_cur > ctl->ev_cand) { ctl->ev_cand = ctl->ev_cur; ctl->ev_acc_cand = 0; } }
+            if (ctl->ev_nonmono == 0) { ctl->ev_ref = ctl->ev_cand; ctl->ev_acc_ref = ctl->ev_acc_cand; }
+        } else {
+            ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1;
+        }
+    }
+    return accept;
+}
+
 // ---------------------------------------------------------------------------------- algebra
 __device__ __forceinline__ void d_quat_to_R(const double *q, double *R)
 {
@@ -737,36 +832,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         // the control block is worked on in registers: one load batch, one store batch (every ctl-> access used to be a
         // dependent global round trip of thread 0)
         BACtl cl = *ctl;
-        BACtl *ctl = &cl;
-        if (fresh) {
-            ctl->gmax = s_gmax;
-            ctl->x_cost = ctl->cost_acc;
-            ctl->cost_acc = 0;
-            if (!ctl->scaled) {             // iteration zero
-                ctl->scaled = 1;
-                ctl->initial_cost = ctl->x_cost; ctl->minimum_cost = ctl->x_cost;
-                ctl->ev_min = ctl->ev_cur = ctl->ev_ref = ctl->ev_cand = ctl->x_cost;
-                ctl->ev_acc_ref = ctl->ev_acc_cand = 0; ctl->ev_nonmono = 0;
-            }
-            ctl->fresh_lin = 0;
-            ctl->reuse_diag = 0;
-        }
-        // FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (ctl->step_successful) {
-            ctl->n_success++;
-            if (ctl->x_cost < ctl->minimum_cost) ctl->minimum_cost = ctl->x_cost;
-        }
-        if (ctl->iteration >= O.max_iter) { ctl->termination = OV2_TERM_NO_CONVERGENCE; ctl->done = 1; }
-        else if (ctl->step_successful && ctl->gmax <= O.gtol) { ctl->termination = OV2_TERM_GRADIENT_TOL; ctl->done = 1; }
-        else if (ctl->radius <= O.min_radius) { ctl->termination = OV2_TERM_MIN_RADIUS; ctl->done = 1; }
-        else {
-            ctl->iteration++;
-            ctl->step_successful = 0;
-            ctl->step_valid = 0;
-            ctl->lin_fail = 0;
-            ctl->n_steps++;
-            ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0;
-        }
+        d_ctl_iter_begin(cl, O, fresh, s_gmax);
         *D.ctl = cl;
     }
     __syncthreads();
@@ -1215,6 +1281,175 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 #undef CH_TICK
 }
 
+// ================================================================================== pose-only problems in ONE kernel
+// MultiViewGeometry::ceresPnP (src/multi_view_geometry.cpp:492-586): one free pose, a few hundred fixed world points.  The
+// multi-kernel loop above costs ~10 launches of ~6 us per LM iteration whatever the problem size -- 0.45 ms per solve, four times
+// what one CPU core needs.  Here the whole trust-region loop runs in ONE work-group: residual blocks over the threads, the
+// 6 x 6 normal equations in LDS, the scalar bookkeeping through the same d_ctl_* functions as the multi-kernel path.
+// Used when the problem has no landmarks, pose-only residual blocks and exactly one optimised keyframe (ba_run).
+__global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ctl0)
+{
+    __shared__ BACtl cl;
+    __shared__ double s_H[21], s_b[6], s_cost, s_scale[6], s_diag[6], s_y[6], s_red[3][16];
+    __shared__ int s_kf, s_flag;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        cl = ctl0;
+        int kf = 0;
+        for (int k = 0; k < D.n_kf; k++) if (D.pose_col[k] == 0) kf = k;
+        s_kf = kf;
+    }
+    if (tid < 6) { s_scale[tid] = 1.0; s_diag[tid] = 0.0; s_y[tid] = 0.0; }
+    for (int k = tid; k < D.n_kf; k += nt) d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);
+    __threadfence_block();
+    __syncthreads();
+    const int kf = s_kf;
+    double *xp = D.x_pose + 7 * kf, *cp = D.c_pose + 7 * kf;
+
+    // J^T J (upper triangle, 21), J^T r (6) and the robustified cost at x (k_ba_linearize_po)
+    auto linearize = [&]() {
+        if (tid < 21) s_H[tid] = 0;
+        if (tid < 6) s_b[tid] = 0;
+        if (tid == 0) s_cost = 0;
+        __syncthreads();
+        double cost = 0, h[21], b[6];
+        for (int q = 0; q < 21; q++) h[q] = 0;
+        for (int q = 0; q < 6; q++) b[q] = 0;
+        for (int k = tid; k < D.n_po; k += nt) {
+            const int o = D.po_kf[k], co = D.pose_col[o];
+            double r[2], Jo[12];
+            const int dp = d_residual_pnp<true>(D, D.x_RT + 12 * o, D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, Jo);
+            const double sq = r[0] * r[0] + r[1] * r[1];
+            const int orig = D.po_orig[k];
+            D.chi2[orig] = sq; D.dpos[orig] = (uint8_t)dp;
+            double rho0, rho1;
+            d_huber(D.huber, sq, rho0, rho1);
+            cost += 0.5 * rho0;
+            if (co < 0) continue;
+            const double sc = sqrt(rho1);
+            r[0] *= sc; r[1] *= sc;
+            for (int q = 0; q < 12; q++) Jo[q] *= sc;
+            int t = 0;
+            for (int c = 0; c < 6; c++) {
+                b[c] += Jo[c] * r[0] + Jo[6 + c] * r[1];
+                for (int d = c; d < 6; d++) h[t++] += Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d];
+            }
+        }
+        // wavefront sums first (27 + 1 values), then one LDS atomic per wavefront and value
+        for (int q = 0; q < 21; q++) { const double v = wave_sum(h[q]); if ((tid & 63) == 0 && v != 0.0) atomicAdd(&s_H[q], v); }
+        for (int q = 0; q < 6; q++) { const double v = wave_sum(b[q]); if ((tid & 63) == 0 && v != 0.0) atomicAdd(&s_b[q], v); }
+        cost = wave_sum(cost);
+        if ((tid & 63) == 0 && cost != 0.0) atomicAdd(&s_cost, cost);
+        __syncthreads();
+        if (tid == 0) { cl.cost_acc += s_cost; cl.need_lin = 0; cl.fresh_lin = 1; }       // (k_ba_lin_done)
+        __syncthreads();
+    };
+    auto Hd = [&](int i, int j) { const int a = i < j ? i : j, bq = i < j ? j : i; return s_H[a * 6 - a * (a - 1) / 2 + (bq - a)]; };   // upper-packed
+
+    linearize();
+    for (int it = 0; it <= O.max_iter; it++) {
+        // ---- k_ba_iter_begin ----
+        if (tid == 0) {
+            const int fresh = cl.fresh_lin;
+            double gm = 0;
+            if (fresh) {
+                if (O.jacobi && !cl.scaled) for (int c = 0; c < 6; c++) s_scale[c] = 1.0 / (1.0 + sqrt(Hd(c, c)));
+                double d[6], out[7];
+                for (int c = 0; c < 6; c++) d[c] = -s_b[c];
+                d_se3_left_plus(xp, d, out);
+                for (int c = 0; c < 7; c++) gm = fmax(gm, fabs(xp[c] - out[c]));
+            }
+            d_ctl_iter_begin(cl, O, fresh, gm);
+            if (!cl.done) {
+                if (!cl.reuse_diag) for (int c = 0; c < 6; c++) s_diag[c] = fmin(fmax(s_scale[c] * s_scale[c] * Hd(c, c), O.min_diag), O.max_diag);
+                cl.reuse_diag = 1;
+                // ---- k_ba_assemble + Cholesky + the two triangular solves on the 6 x 6 system ----
+                double L[6][6], y[6];
+                bool fail = false;
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j <= i; j++) L[i][j] = s_scale[i] * s_scale[j] * Hd(i, j) + (i == j ? s_diag[i] / cl.radius : 0.0);
+                for (int j = 0; j < 6; j++) {
+                    double dsum = L[j][j];
+                    for (int k = 0; k < j; k++) dsum -= L[j][k] * L[j][k];
+                    if (!(dsum > 0.0) || !isfinite(dsum)) { fail = true; break; }
+                    const double ljj = sqrt(dsum);
+                    L[j][j] = ljj;
+                    for (int i = j + 1; i < 6; i++) {
+                        double v = L[i][j];
+                        for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+                        L[i][j] = v / ljj;
+                    }
+                }
+                if (fail) cl.lin_fail = 1;
+                else {
+                    for (int i = 0; i < 6; i++) { double v = s_scale[i] * s_b[i]; for (int k = 0; k < i; k++) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
+                    for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v -= L[k][i] * y[k]; y[i] = v / L[i][i]; }
+                    for (int i = 0; i < 6; i++) s_y[i] = y[i];
+                }
+                // ---- k_ba_candidate ----
+                int ok = !cl.lin_fail;
+                double P1 = 0, P2 = 0;
+                if (ok)
+                    for (int i = 0; i < 6; i++) {
+                        const double yi = s_y[i], si = s_scale[i];
+                        if (!isfinite(yi)) ok = 0;
+                        P1 += yi * si * s_b[i];
+                        P2 += yi * si * s_b[i] - (s_diag[i] / cl.radius) * yi * yi;
+                    }
+                const int valid = d_ctl_candidate(cl, O, ok, P1, P2);
+                if (valid) {
+                    double d[6], out[7];
+                    for (int c = 0; c < 6; c++) d[c] = -s_y[c] * s_scale[c];
+                    d_se3_left_plus(xp, d, out);
+                    for (int c = 0; c < 7; c++) cp[c] = out[c];
+                    d_pose_to_RT(out, D.c_RT + 12 * kf);
+                }
+                s_flag = valid;
+            } else s_flag = -1;
+            s_cost = 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (s_flag < 0) break;                                  // terminated in the bookkeeping
+        if (s_flag == 0) continue;                              // invalid step: radius already shrunk, same linearisation
+        // constant keyframes keep their pose in the candidate
+        for (int k = tid; k < D.n_kf; k += nt)
+            if (k != kf) { for (int c = 0; c < 7; c++) D.c_pose[7 * k + c] = D.x_pose[7 * k + c]; for (int c = 0; c < 12; c++) D.c_RT[12 * k + c] = D.x_RT[12 * k + c]; }
+        __threadfence_block();
+        __syncthreads();
+        // ---- k_ba_cost at the candidate (also the N4 outputs) ----
+        double cost = 0;
+        for (int k = tid; k < D.n_po; k += nt) {
+            double r[2];
+            const int dp = d_residual_pnp<false>(D, D.c_RT + 12 * D.po_kf[k], D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, nullptr);
+            const double sq = r[0] * r[0] + r[1] * r[1];
+            const int orig = D.po_orig[k];
+            D.chi2[orig] = sq; D.dpos[orig] = (uint8_t)dp;
+            double rho0, rho1;
+            d_huber(D.huber, sq, rho0, rho1);
+            cost += 0.5 * rho0;
+        }
+        cost = wave_sum(cost);
+        if ((tid & 63) == 0 && cost != 0.0) atomicAdd(&s_cost, cost);
+        __syncthreads();
+        // ---- k_ba_decide ----
+        if (tid == 0) {
+            cl.cost_acc += s_cost;
+            double SN = 0, XN = 0;
+            for (int c = 0; c < 7; c++) { const double d = xp[c] - cp[c]; SN += d * d; XN += cp[c] * cp[c]; }
+            const int accept = d_ctl_decide(cl, O, SN, XN);
+            if (accept) { for (int c = 0; c < 7; c++) xp[c] = cp[c]; for (int c = 0; c < 12; c++) D.x_RT[12 * kf + c] = D.c_RT[12 * kf + c]; }
+            s_flag = cl.done ? -1 : (cl.need_lin ? 1 : 0);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (s_flag < 0) break;
+        if (s_flag == 1) linearize();
+    }
+    (void)s_red;
+    if (tid == 0) *D.ctl = cl;
+}
+
 // ================================================================================== big path (BADev::big)
 // clears what the big-path lineariser accumulates into (k_ba_decide leaves H alone on this path: one work-group clearing
 // nfp^2 doubles took 150 us at 300 keyframes)
@@ -1519,24 +1754,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
     if (nbad > 0) ok = 0;                                  // (thread 0 only: the only consumer)
     if (tid == 0) {
         BACtl cl = *ctl;
-        BACtl *ctl = &cl;
-        int valid = 0;
-        if (ok) {
-            // model_cost_change = -(J step).(r + J step / 2) with step = -y  ==  y.g' - y^T H' y / 2
-            const double mcc = (P1 + ctl->acc1) - 0.5 * (P2 + ctl->acc3 + ctl->acc2);
-            ctl->model_cost_change = mcc;
-            valid = mcc > 0.0;
-        }
-        if (!valid) {
-            // HandleInvalidStep (trust_region_minimizer.cc:436-459)
-            if (++ctl->num_invalid >= O.max_invalid) { ctl->termination = OV2_TERM_INVALID_STEPS; ctl->done = 1; }
-            else { ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1; }
-            ctl->step_valid = 0;
-        } else {
-            ctl->num_invalid = 0;
-            ctl->step_valid = 1;
-        }
-        s_flag = valid;
+        s_flag = d_ctl_candidate(cl, O, ok, P1, P2);
         *D.ctl = cl;
     }
     __syncthreads();
@@ -1588,35 +1806,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
     block_reduce3<false>(SN, XN, z, s_part);
     if (tid == 0) {
         BACtl cl = *ctl;
-        BACtl *ctl = &cl;
-        s_accept = 0;
-        const double cand = ctl->cost_acc;
-        ctl->cost_acc = 0;
-        ctl->cand_cost = cand;
-        if (sqrt(SN) <= O.ptol * (ctl->x_norm + O.ptol)) { ctl->termination = OV2_TERM_PARAMETER_TOL; ctl->done = 1; }
-        else if (fabs(ctl->x_cost - cand) <= O.ftol * ctl->x_cost) { ctl->termination = OV2_TERM_FUNCTION_TOL; ctl->done = 1; }
-        else {
-            const double mcc = ctl->model_cost_change;
-            const double r1 = (ctl->ev_cur - cand) / mcc, r2 = (ctl->ev_ref - cand) / (ctl->ev_acc_ref + mcc);
-            const double rel = fmax(r1, r2);
-            if (rel > O.min_rel_decrease) {
-                s_accept = 1;
-                ctl->x_norm = sqrt(XN);
-                ctl->step_successful = 1;
-                ctl->need_lin = 1;
-                // LevenbergMarquardtStrategy::StepAccepted
-                const double t = 2.0 * rel - 1.0;
-                ctl->radius = fmin(O.max_radius, ctl->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                ctl->decrease_factor = 2.0; ctl->reuse_diag = 0;
-                // TrustRegionStepEvaluator::StepAccepted (max_consecutive_nonmonotonic_steps = 0)
-                ctl->ev_cur = cand; ctl->ev_acc_cand += mcc; ctl->ev_acc_ref += mcc;
-                if (ctl->ev_cur < ctl->ev_min) { ctl->ev_min = ctl->ev_cur; ctl->ev_nonmono = 0; ctl->ev_cand = ctl->ev_cur; ctl->ev_acc_cand = 0; }
-                else { ctl->ev_nonmono++; if (ctl->ev_cur > ctl->ev_cand) { ctl->ev_cand = ctl->ev_cur; ctl->ev_acc_cand = 0; } }
-                if (ctl->ev_nonmono == 0) { ctl->ev_ref = ctl->ev_cand; ctl->ev_acc_ref = ctl->ev_acc_cand; }
-            } else {
-                ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1;
-            }
-        }
+        s_accept = d_ctl_decide(cl, O, SN, XN);
         *D.ctl = cl;
     }
     __syncthreads();
@@ -1875,6 +2065,7 @@ __global__ __launch_bounds__(256) void k_ba_init(BADev D)
 struct ov2_ba_dev {
     BADev D;
     void *pool = nullptr; size_t pool_bytes = 0;
+    bool pool_owned = true;             // false: the pool lives in the context's grow-only device scratch (transient small problems)
     int n_res = 0;
     int *lm_order = nullptr;            // landmarks sorted by anchor keyframe (device)
     std::vector<double> h_poses0, h_lam0;
@@ -1883,7 +2074,9 @@ struct ov2_ba_dev {
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
+// transient: the problem lives for one ov2_ba_solve call -- small pools then come out of the context's device scratch instead of
+// a hipMalloc / hipFree pair (~100 us, more than a whole ceresPnP solve)
+static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bool transient = false)
 {
     OV2_REQUIRE(p && out, OV2_EINVAL, "NULL problem");
     OV2_REQUIRE(p->n_kf > 0 && p->n_lm >= 0 && p->n_res >= 0, OV2_EINVAL, "bad problem sizes");
@@ -2003,8 +2196,14 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
-    hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
-    if (e != hipSuccess) { delete dev; ov2_set_error("hipMalloc(%zu): %s", off, hipGetErrorString(e)); return OV2_ENOMEM; }
+    if (transient && off <= ((size_t)8 << 20)) {
+        const int rcs = ctx->reserve_device(off);
+        if (rcs != OV2_OK) { delete dev; return rcs; }
+        dev->pool = ctx->d_scratch; dev->pool_owned = false;
+    } else {
+        hipError_t e = hipMalloc(&dev->pool, dev->pool_bytes);
+        if (e != hipSuccess) { delete dev; ov2_set_error("hipMalloc(%zu): %s", off, hipGetErrorString(e)); return OV2_ENOMEM; }
+    }
     uint8_t *b = (uint8_t *)dev->pool;
     D.pose_col = (int *)(b + o_pose_col); D.lm_ptr = (int *)(b + o_lm_ptr); D.lm_anchor = (int *)(b + o_lm_anchor); D.lm_auv = (double *)(b + o_lm_auv);
     D.res_type = b + o_res_type; D.res_kf = (int *)(b + o_res_kf); D.res_orig = (int *)(b + o_res_orig); D.res_uv = (double *)(b + o_res_uv); D.res_sigma = (double *)(b + o_res_sigma);
@@ -2032,7 +2231,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out)
     }
     hipStream_t s = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) { hipError_t _e = hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, s); \
-        if (_e != hipSuccess) { (void)hipFree(dev->pool); delete dev; ov2_set_error("H2D: %s", hipGetErrorString(_e)); return OV2_EHIP; } } } while (0)
+        if (_e != hipSuccess) { if (dev->pool_owned) (void)hipFree(dev->pool); delete dev; ov2_set_error("H2D: %s", hipGetErrorString(_e)); return OV2_EHIP; } } } while (0)
     std::vector<int> lm_order(p->n_lm);
     for (int l = 0; l < p->n_lm; l++) lm_order[l] = l;
     std::stable_sort(lm_order.begin(), lm_order.end(), [&](int x, int y) { return p->lm_anchor_kf[x] < p->lm_anchor_kf[y]; });
@@ -2160,7 +2359,7 @@ static void ba_destroy(ov2_ba_dev *dev)
 {
     if (!dev) return;
     (void)hipSetDevice(dev->device);
-    if (dev->pool) (void)hipFree(dev->pool);
+    if (dev->pool && dev->pool_owned) (void)hipFree(dev->pool);
     delete dev;
 }
 
@@ -2237,6 +2436,14 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     h_ctl.radius = o->initial_radius; h_ctl.decrease_factor = 2.0; h_ctl.x_norm = -1.0;
     h_ctl.need_lin = 1; h_ctl.step_successful = 1;
     h_ctl.termination = OV2_TERM_NO_CONVERGENCE;
+    // one optimised pose, pose-only residual blocks, no landmarks (ceresPnP): the whole loop in one kernel (OV2_BA_POSE_ONLY_FUSED=0
+    // keeps the multi-kernel path for A/B runs)
+    const char *env_po = getenv("OV2_BA_POSE_ONLY_FUSED");
+    const bool fused_po = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && !(env_po && env_po[0] == '0') && !(o->max_solver_time_s > 0.0);
+    if (fused_po) {
+        hipLaunchKernelGGL(k_ba_pose_only, dim3(1), dim3(256), 0, s, D, O, h_ctl);
+        OV2_HIP_CHECK(hipGetLastError());
+    } else {
     OV2_HIP_CHECK(hipMemcpyAsync(D.ctl, &h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.H, 0, 8 * (size_t)D.nfp * D.nfp, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.bf, 0, 8 * (size_t)D.nfp, s));
@@ -2340,6 +2547,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     }
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);    // final bookkeeping
     OV2_HIP_CHECK(hipGetLastError());
+    }
     OV2_HIP_CHECK(hipEventRecord(e1, s));
     // results
     OV2_HIP_CHECK(hipMemcpyAsync(&h_ctl, D.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
@@ -2392,7 +2600,7 @@ int ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o,
 {
     OV2_REQUIRE(ctx && p && o && r, OV2_EINVAL, "NULL argument");
     ov2_ba_dev *dev = nullptr;
-    int rc = ba_create(ctx, p, &dev);
+    int rc = ba_create(ctx, p, &dev, /*transient*/ true);
     if (rc != OV2_OK) return rc;
     // chi2 / depth flags of inactive residual blocks keep the caller's values (the reference's removed
     // residual blocks keep their cached chi2err_): seed the device arrays with them
