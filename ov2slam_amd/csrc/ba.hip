@@ -2196,7 +2196,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
-    if (transient && off <= ((size_t)8 << 20)) {
+    if (transient && off <= ((size_t)64 << 20)) {                      // (the context keeps the largest pool it has seen: grow-only scratch)
         const int rcs = ctx->reserve_device(off);
         if (rcs != OV2_OK) { delete dev; return rcs; }
         dev->pool = ctx->d_scratch; dev->pool_owned = false;
