@@ -80,6 +80,20 @@ for case in range(N):
     ws = int(rng.choice([3, 5, 7]))
     a = trk.getLineMinSAD(Gp, Gc, sl, pts, ws, True); b = O.line_min_sad(Rp.level(sl)[0], Rc.level(sl)[0], pts, ws, True)
     check("line_min_sad", np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), dict(info, level=sl, ws=ws))
+    # ---- stereo matching: the fused entry (ov2_stereo_match) against the call sequence, random 3-D priors ----
+    if case % 3 == 1:
+        from ov2slam_amd import stereo as _st
+        cal = ov2slam_amd.CameraCalibration(ctx, "pinhole", 458.654, 457.296, w / 2.0, h / 2.0, D=None)
+        inside = (kps[:, 0] >= 0) & (kps[:, 0] < w) & (kps[:, 1] >= 0) & (kps[:, 1] < h)
+        sk = kps[inside][:200]                                           # getLineMinSAD needs points inside the image
+        if len(sk):
+            p3 = {int(i): (float(sk[i, 0] - shift[0] + rng.normal(0, 4.0)), float(sk[i, 1] - shift[1] + rng.normal(0, 2.0)))
+                  for i in np.nonzero(rng.uniform(size=len(sk)) < 0.5)[0]}
+            rect = bool(rng.integers(0, 2))
+            F = None if rect else np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
+            a_ok, a_r = _st.stereo_matching(trk, Gp, Gc, sk, sk, cal, rect=rect, Frl=F, nklt_pyr_lvl=lvl, priors3d=p3)
+            b_ok, b_r = _st.stereo_matching_fused(trk, Gp, Gc, sk, sk, cal, rect=rect, Frl=F, nklt_pyr_lvl=lvl, priors3d=p3)
+            check("stereo_fused", np.array_equal(a_ok, b_ok) and np.array_equal(a_r.view(np.uint32), b_r.view(np.uint32)), dict(info, n=len(sk), rect=rect, lvl=lvl))
     # ---- detectors ----
     if w >= 120 and h >= 120:
         cell = int(rng.choice([20, 35, 45, 50, 53, 58]))
