@@ -1290,7 +1290,8 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ctl0)
 {
     __shared__ BACtl cl;
-    __shared__ double s_H[21], s_b[6], s_cost, s_scale[6], s_diag[6], s_y[6], s_red[3][16];
+    __shared__ double s_H[21], s_b[6], s_cost, s_scale[6], s_diag[6], s_y[6];
+    __shared__ double s_x[7], s_xRT[12], s_c[7], s_cRT[12];      // the optimised pose and its candidate stay in LDS (+ cached R | t)
     __shared__ int s_kf, s_flag;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) {
@@ -1300,11 +1301,15 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
         s_kf = kf;
     }
     if (tid < 6) { s_scale[tid] = 1.0; s_diag[tid] = 0.0; s_y[tid] = 0.0; }
-    for (int k = tid; k < D.n_kf; k += nt) d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);
+    for (int k = tid; k < D.n_kf; k += nt) d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);      // (constant keyframes are read from here)
     __threadfence_block();
     __syncthreads();
     const int kf = s_kf;
-    double *xp = D.x_pose + 7 * kf, *cp = D.c_pose + 7 * kf;
+    if (tid == 0) { for (int c = 0; c < 7; c++) s_x[c] = D.x_pose[7 * kf + c]; d_pose_to_RT(s_x, s_xRT); }
+    __syncthreads();
+    double *xp = s_x, *cp = s_c;
+    auto RTx = [&](int o) -> const double * { return o == kf ? s_xRT : D.x_RT + 12 * o; };
+    auto RTc = [&](int o) -> const double * { return o == kf ? s_cRT : D.x_RT + 12 * o; };      // constant keyframes: candidate = x
 
     // J^T J (upper triangle, 21), J^T r (6) and the robustified cost at x (k_ba_linearize_po)
     auto linearize = [&]() {
@@ -1318,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
         for (int k = tid; k < D.n_po; k += nt) {
             const int o = D.po_kf[k], co = D.pose_col[o];
             double r[2], Jo[12];
-            const int dp = d_residual_pnp<true>(D, D.x_RT + 12 * o, D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, Jo);
+            const int dp = d_residual_pnp<true>(D, RTx(o), D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, Jo);
             const double sq = r[0] * r[0] + r[1] * r[1];
             const int orig = D.po_orig[k];
             D.chi2[orig] = sq; D.dpos[orig] = (uint8_t)dp;
@@ -1402,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
                     for (int c = 0; c < 6; c++) d[c] = -s_y[c] * s_scale[c];
                     d_se3_left_plus(xp, d, out);
                     for (int c = 0; c < 7; c++) cp[c] = out[c];
-                    d_pose_to_RT(out, D.c_RT + 12 * kf);
+                    d_pose_to_RT(out, s_cRT);
                 }
                 s_flag = valid;
             } else s_flag = -1;
@@ -1412,16 +1417,11 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
         __syncthreads();
         if (s_flag < 0) break;                                  // terminated in the bookkeeping
         if (s_flag == 0) continue;                              // invalid step: radius already shrunk, same linearisation
-        // constant keyframes keep their pose in the candidate
-        for (int k = tid; k < D.n_kf; k += nt)
-            if (k != kf) { for (int c = 0; c < 7; c++) D.c_pose[7 * k + c] = D.x_pose[7 * k + c]; for (int c = 0; c < 12; c++) D.c_RT[12 * k + c] = D.x_RT[12 * k + c]; }
-        __threadfence_block();
-        __syncthreads();
         // ---- k_ba_cost at the candidate (also the N4 outputs) ----
         double cost = 0;
         for (int k = tid; k < D.n_po; k += nt) {
             double r[2];
-            const int dp = d_residual_pnp<false>(D, D.c_RT + 12 * D.po_kf[k], D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, nullptr);
+            const int dp = d_residual_pnp<false>(D, RTc(D.po_kf[k]), D.po_xyz + 3 * k, D.po_uv + 2 * k, D.po_sigma[k], r, nullptr);
             const double sq = r[0] * r[0] + r[1] * r[1];
             const int orig = D.po_orig[k];
             D.chi2[orig] = sq; D.dpos[orig] = (uint8_t)dp;
@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
             double SN = 0, XN = 0;
             for (int c = 0; c < 7; c++) { const double d = xp[c] - cp[c]; SN += d * d; XN += cp[c] * cp[c]; }
             const int accept = d_ctl_decide(cl, O, SN, XN);
-            if (accept) { for (int c = 0; c < 7; c++) xp[c] = cp[c]; for (int c = 0; c < 12; c++) D.x_RT[12 * kf + c] = D.c_RT[12 * kf + c]; }
+            if (accept) { for (int c = 0; c < 7; c++) xp[c] = cp[c]; for (int c = 0; c < 12; c++) s_xRT[c] = s_cRT[c]; }
             s_flag = cl.done ? -1 : (cl.need_lin ? 1 : 0);
         }
         __threadfence_block();
@@ -1446,8 +1446,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
         if (s_flag < 0) break;
         if (s_flag == 1) linearize();
     }
-    (void)s_red;
-    if (tid == 0) *D.ctl = cl;
+    if (tid == 0) { *D.ctl = cl; for (int c = 0; c < 7; c++) D.x_pose[7 * kf + c] = s_x[c]; }
 }
 
 // ================================================================================== big path (BADev::big)
@@ -2055,10 +2054,14 @@ __global__ void k_ba_lin_done(BADev D)
     ctl->need_lin = 0; ctl->fresh_lin = 1;
 }
 
+// cached R | t of every pose; scales = 1 (Jacobi scaling, when on, overwrites them at the first k_ba_iter_begin)
 __global__ __launch_bounds__(256) void k_ba_init(BADev D)
 {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.n_kf; k += gridDim.x * blockDim.x)
-        d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = i0; k < D.n_kf; k += stride) d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);
+    for (long long c = i0; c < D.nfp; c += stride) D.scale_f[c] = 1.0;
+    const long long NL = (long long)D.n_lm * D.ldim;
+    for (long long l = i0; l < NL; l += stride) { D.scale_l[l] = 1.0; if (D.ldim == 3) D.ones[l] = 1.0; }
 }
 
 // ---------------------------------------------------------------------------------- host
@@ -2448,14 +2451,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     OV2_HIP_CHECK(hipMemsetAsync(D.H, 0, 8 * (size_t)D.nfp * D.nfp, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.bf, 0, 8 * (size_t)D.nfp, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.yf, 0, 8 * (size_t)D.nfp, s));
-    {   // scales = 1 (jacobi off) : fill through a tiny staging vector
-        std::vector<double> ones(std::max((size_t)D.nfp, std::max((size_t)1, NL)), 1.0);
-        OV2_HIP_CHECK(hipMemcpyAsync(D.scale_f, ones.data(), 8 * (size_t)D.nfp, hipMemcpyHostToDevice, s));
-        if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.scale_l, ones.data(), 8 * NL, hipMemcpyHostToDevice, s));
-        if (D.ldim == 3 && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.ones, ones.data(), 8 * NL, hipMemcpyHostToDevice, s));
-        OV2_HIP_CHECK(hipStreamSynchronize(s));
-    }
-    hipLaunchKernelGGL(k_ba_init, dim3((D.n_kf + 255) / 256), dim3(256), 0, s, D);
+    // poses -> R | t, scales = 1 (round 1 filled the scales through a host staging vector: three copies and a synchronisation)
+    hipLaunchKernelGGL(k_ba_init, dim3((int)std::min<size_t>(1024, (std::max<size_t>(std::max<size_t>(D.n_kf, D.nfp), NL) + 255) / 256)), dim3(256), 0, s, D);
 
     const int lin_blocks = std::max(1, std::min(256, (D.n_lm + 15) / 16));   // (512: two workgroups per CU -- measured 15 % slower)
     const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;

@@ -70,6 +70,26 @@ public:
         return out;
     }
 
+    // Offline batch mode: detectSingleScale / detectGridFAST on EVERY batch item of a pyramid in one call
+    // (ov2_detect_singlescale_batch_d / ov2_detect_grid_fast_batch_d).  cur_xy_d / ncur_d / out_xy_d are device buffers
+    // (batch x cur_cap points, batch counts, batch x out_cap points); vquality / vfast_th hold one dmaxquality_ / nfast_th_ per
+    // sequence and are updated like the members; vout_n receives the number of points written per item.  Returns the C ABI code.
+    static int detectSingleScaleBatch(Context &ctx, const ov2_pyr *pyr, int ncellsize, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                                      const Rect &roi, std::vector<double> &vquality, float *out_xy_d, int out_cap, std::vector<int> &vout_n)
+    {
+        const int r[4] = {roi.x, roi.y, roi.width, roi.height};
+        vout_n.assign(vquality.size(), 0);
+        if (vquality.empty()) return OV2_EINVAL;
+        return ov2_detect_singlescale_batch_d(ctx.get(), pyr, ncellsize, cur_xy_d, cur_cap, ncur_d, r, vquality.data(), 1, out_xy_d, out_cap, vout_n.data());
+    }
+    static int detectGridFASTBatch(Context &ctx, const ov2_pyr *pyr, int ncellsize, const float *cur_xy_d, int cur_cap, const int *ncur_d,
+                                   std::vector<int> &vfast_th, int mask_mode, float *out_xy_d, int out_cap, std::vector<int> &vout_n)
+    {
+        vout_n.assign(vfast_th.size(), 0);
+        if (vfast_th.empty()) return OV2_EINVAL;
+        return ov2_detect_grid_fast_batch_d(ctx.get(), pyr, ncellsize, cur_xy_d, cur_cap, ncur_d, vfast_th.data(), mask_mode, 1, out_xy_d, out_cap, vout_n.data());
+    }
+
     size_t nmaxpts_, nmaxdist_;
     double dmaxquality_;       // feature_extractor.hpp:50
     int nfast_th_;             // feature_extractor.hpp:52

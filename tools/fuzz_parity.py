@@ -90,10 +90,11 @@ for case in range(N):
             p3 = {int(i): (float(sk[i, 0] - shift[0] + rng.normal(0, 4.0)), float(sk[i, 1] - shift[1] + rng.normal(0, 2.0)))
                   for i in np.nonzero(rng.uniform(size=len(sk)) < 0.5)[0]}
             rect = bool(rng.integers(0, 2))
+            slv = min(lvl, Gp.levels - 1)                                  # small images have fewer levels than asked for
             F = None if rect else np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
-            a_ok, a_r = _st.stereo_matching(trk, Gp, Gc, sk, sk, cal, rect=rect, Frl=F, nklt_pyr_lvl=lvl, priors3d=p3)
-            b_ok, b_r = _st.stereo_matching_fused(trk, Gp, Gc, sk, sk, cal, rect=rect, Frl=F, nklt_pyr_lvl=lvl, priors3d=p3)
-            check("stereo_fused", np.array_equal(a_ok, b_ok) and np.array_equal(a_r.view(np.uint32), b_r.view(np.uint32)), dict(info, n=len(sk), rect=rect, lvl=lvl))
+            a_ok, a_r = _st.stereo_matching(trk, Gp, Gc, sk, sk, cal, rect=rect, Frl=F, nklt_pyr_lvl=slv, priors3d=p3)
+            b_ok, b_r = _st.stereo_matching_fused(trk, Gp, Gc, sk, sk, cal, rect=rect, Frl=F, nklt_pyr_lvl=slv, priors3d=p3)
+            check("stereo_fused", np.array_equal(a_ok, b_ok) and np.array_equal(a_r.view(np.uint32), b_r.view(np.uint32)), dict(info, n=len(sk), rect=rect, lvl=slv))
     # ---- detectors ----
     if w >= 120 and h >= 120:
         cell = int(rng.choice([20, 35, 45, 50, 53, 58]))
