@@ -960,13 +960,14 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 
 // The two triangular solves L y = rhs, L^T x = y on the factor in S (HBM) with the inverse diagonal blocks in Linv; yv (LDS, nfp
 // doubles) holds rhs on entry and x on return, L11 is a CH_NB x CH_LDP LDS scratch.  One work-group.
-__device__ __forceinline__ void chol_trisolve(const BADev &D, double *L11, double *yv, double (*s_red)[33])
+__device__ __forceinline__ void chol_trisolve(const BADev &D, double *L11, double *yv, double (*s_red)[33], bool forward_done = false)
 {
     const int n = D.nf, ld = D.nfp, tid = threadIdx.x, nt = blockDim.x;
     const double *S = D.S, *Linv = D.Linv;
     // forward substitution  L y = rhs, left-looking by blocks:  y_blk = Linv_blk (b_blk - L[blk, 0:k0] y[0:k0])
+    // (forward_done: yv already holds y -- k_ba_cholesky carries the right-hand side through the factorisation as one more panel row)
     const int tr = tid >> 5, tcn = tid & 31, ngr = nt >> 5;  // ngr groups of 32 partial-sum threads
-    for (int k0 = 0; k0 < n; k0 += CH_NB) {
+    for (int k0 = 0; k0 < n && !forward_done; k0 += CH_NB) {
         const int nb = min(CH_NB, n - k0);
         for (int r = tr; r < CH_NB; r += ngr) {
             double part = 0;
@@ -1042,8 +1043,13 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     __shared__ int s_fail;
     __shared__ double s_red[32][33];
     __shared__ double s_rdiag[CH_NB];                        // 1 / L11[j][j] of the current diagonal block
+    __shared__ double s_yk[CH_NB];                           // the block's part of the forward solution (the right-hand side as a panel row)
     double *S = D.S;
     double *Linv = D.Linv;                                  // (nfp / 32) blocks of 32 x 32 (row-major), inverse diagonal blocks
+    // The right-hand side rides through the factorisation as one more row of the panel: solving its block against L11 IS the
+    // forward substitution of that block, and its trailing update (rhs_rest -= P y_blk) replaces the forward pass of the
+    // triangular solves (ten blocks of partial sums over L in L2, three barriers each).  Needs a free panel thread.
+    const bool rhs_row = n - CH_NB + 1 <= nt - 64;
     // (S was assembled by k_ba_assemble: in here, one workgroup walking the n^2 entries took 85 us of latency)
     for (int i = tid; i < D.nfp; i += nt) yv[i] = i < n ? D.scale_f[i] * (D.bf[i] - D.v[i]) : 0.0;
     if (tid == 0) s_fail = 0;
@@ -1127,9 +1133,10 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             // issue slots to itself; wavefronts 1-3 and 5-7 take rows 0 .. 383)
             const int t = CH_SKIP_W4 ? (wave < 4 ? tid - 64 : tid - 128) : tid - 64;
             const bool has = t < m && !(CH_SKIP_W4 && wave == 4);
+            const bool rhs = rhs_row && t == m;                 // the thread after the last panel row takes the right-hand side
             double x[CH_NB];
 #pragma unroll
-            for (int j = 0; j < CH_NB; j++) x[j] = has ? P[t * CH_LDP + j] : 0.0;
+            for (int j = 0; j < CH_NB; j++) x[j] = has ? P[t * CH_LDP + j] : (rhs ? yv[k0 + j] : 0.0);
 #pragma unroll
             for (int j = 0; j < CH_NB; j++) {
                 if ((j & (CH_GRP - 1)) == 0) {
@@ -1147,6 +1154,10 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             if (has) {
 #pragma unroll
                 for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
+            }
+            if (rhs) {
+#pragma unroll
+                for (int j = 0; j < CH_NB; j++) { s_yk[j] = x[j]; if (j < nb) yv[k0 + j] = x[j]; }
             }
         }
         __syncthreads();
@@ -1166,6 +1177,15 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
         }
         __syncthreads();
+        if (rhs_row) {
+            // trailing update of the right-hand side: rhs[below] -= P y_blk
+            for (int i = tid; i < m; i += nt) {
+                double acc = yv[k0 + nb + i];
+#pragma unroll
+                for (int j = 0; j < CH_NB; j++) acc -= P[i * CH_LDP + j] * s_yk[j];
+                yv[k0 + nb + i] = acc;
+            }
+        }
         CH_TICK(1);
         if (s_fail) break;
         // factored block and panel back to HBM (coalesced)
@@ -1274,7 +1294,7 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     }
     __syncthreads();
 
-    chol_trisolve(D, L11, yv, s_red);
+    chol_trisolve(D, L11, yv, s_red, rhs_row);
     for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
     CH_TICK(4);
     if (tid == 0) for (int i = 0; i < 6; i++) ctl->dbg[i] = tk[i];
