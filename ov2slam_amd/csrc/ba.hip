@@ -1839,7 +1839,13 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
         for (int l = tid; l < D.n_lm * D.ldim; l += nt) x_lam[l] = c_lam[l];
     }
     if (D.big) return;                                      // k_ba_zero_lin
-    for (int e = tid; e < D.nfp * D.nfp; e += nt) D.H[e] = 0;
+    {   // 32-byte stores: this one work-group clears nfp^2 doubles (820 KB for 50 keyframes) on the iteration's critical path
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 *H4 = (d4 *)D.H;                                 // (nfp is a multiple of 32, the pool is 256-byte aligned)
+        const int n4 = D.nfp * D.nfp / 4;
+        const d4 z = {0., 0., 0., 0.};
+        for (int e = tid; e < n4; e += nt) H4[e] = z;
+    }
     for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
 }
 
