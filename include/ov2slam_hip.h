@@ -75,8 +75,9 @@ void ov2_pyr_destroy(ov2_pyr *p);
 int  ov2_pyr_levels(const ov2_pyr *p);                 /* levels actually built */
 int  ov2_pyr_level_size(const ov2_pyr *p, int level, int *w, int *h);
 int  ov2_pyr_batch(const ov2_pyr *p);
-/* (re)build from host images: H2D copy + kernels, asynchronous on ctx's stream
- * (the host buffer must stay valid until ov2_ctx_sync / a later blocking call) */
+/* (re)build from host images: H2D copy + kernels, asynchronous on ctx's stream.  A batch-1 image is repacked into the context's
+ * pinned staging buffer before the call returns (one contiguous DMA whatever the row stride; the caller's buffer is free at
+ * once); for batch > 1 the host buffer must stay valid until ov2_ctx_sync / a later blocking call */
 int  ov2_pyr_build_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, size_t img_batch_stride);
 /* (re)build from images already resident in HBM */
 int  ov2_pyr_build_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride);
@@ -113,7 +114,7 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
 int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
                           double clip_limit, int tiles_x, int tiles_y);
 /* same from a host image (batch-1 pyramid): one H2D of the raw frame, asynchronous on ctx's stream -- the
- * single-sequence form of VisualFrontEnd::preprocessImage (the host buffer must stay valid until the next sync) */
+ * single-sequence form of VisualFrontEnd::preprocessImage (the image is staged in pinned memory before the call returns) */
 int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, double clip_limit, int tiles_x, int tiles_y);
 
 /* ---- Lucas-Kanade --------------------------------------------------

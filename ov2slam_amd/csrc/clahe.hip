@@ -499,7 +499,8 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     int rc = ctx->reserve_device(img + lut_bytes);
     if (rc != OV2_OK) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
+    rc = ctx->upload_image(ds, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h);
+    if (rc != OV2_OK) return rc;
     const PyrLevelDesc &L0 = p->d.lv[0];
     rc = ov2_launch_clahe(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
                           (size_t)p->d.item_stride, ds + img, p->d.win, p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
@@ -518,10 +519,11 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t pitch = ((size_t)w + 15) & ~(size_t)15;          // aligned staging pitch for both device images
     const size_t img = (pitch * h + 255) & ~(size_t)255, lut_bytes = (size_t)tiles_x * tiles_y * 256;
-    const int rc = ctx->reserve_device(2 * img + lut_bytes);
+    int rc = ctx->reserve_device(2 * img + lut_bytes);
     if (rc != OV2_OK) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    rc = ctx->upload_image(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h);
+    if (rc != OV2_OK) return rc;
     const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, 0, 0);
     if (rc2 != OV2_OK) return rc2;
     OV2_HIP_CHECK(hipMemcpy2DAsync(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));

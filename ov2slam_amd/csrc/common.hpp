@@ -45,9 +45,16 @@ struct ov2_ctx {
     // 200 us floor under a 16k-work-group launch); a one-block kernel folds the lines into the caller's pair.
     unsigned long long *stat_slots = nullptr;
     int sobel_dy_order = OV2_SOBEL_DY_OPENCV_ROWFILTER;   // ov2_ctx_set_option(OV2_OPT_SOBEL_DY_ORDER)
+    // pinned staging of host images on their way to the device: its own buffer (h_scratch is rewritten by the next call's small
+    // arrays while an asynchronous image upload may still be in flight) and an event that says when it may be refilled
+    void *h_img = nullptr;  size_t h_img_bytes = 0;
+    hipEvent_t img_ev = nullptr;  bool img_pending = false;
     int reserve_device(size_t bytes);
     int reserve_host(size_t bytes);
     int reserve_stat_slots();
+    // host image (any row stride, pageable or pinned) -> device buffer with pitch dst_pitch, asynchronous on the stream; the
+    // caller's buffer is free again when this returns
+    int upload_image(void *dst_d, size_t dst_pitch, const uint8_t *src_h, size_t src_stride, size_t w, size_t h);
 };
 #define LK_STAT_SLOTS 256
 #define LK_STAT_STRIDE 16      // unsigned long long per slot (128 B)

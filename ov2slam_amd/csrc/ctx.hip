@@ -1,6 +1,7 @@
 // ctx.hip -- context / error handling of libov2slam_hip.so
 #include "common.hpp"
 #include <stdarg.h>
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -29,6 +30,28 @@ int ov2_ctx::reserve_host(size_t bytes)
     size_t cap = bytes + bytes / 2 + 4096;
     OV2_HIP_CHECK(hipHostMalloc(&h_scratch, cap, hipHostMallocDefault));
     h_scratch_bytes = cap;
+    return OV2_OK;
+}
+
+// Row-pitched upload through pinned memory: hipMemcpy2DAsync from a pageable image whose width is not a multiple of the pitches
+// (KITTI: 1241-byte rows into a 1248-byte pitch) took 2.8 ms per frame -- 376 row transfers; staged, it is one host-side repack
+// (rows of w bytes, ~25 us) and ONE contiguous DMA.  The staging buffer is refilled only after the previous upload's event.
+int ov2_ctx::upload_image(void *dst_d, size_t dst_pitch, const uint8_t *src_h, size_t src_stride, size_t w, size_t h)
+{
+    const size_t bytes = dst_pitch * h;
+    if (img_pending) { OV2_HIP_CHECK(hipEventSynchronize(img_ev)); img_pending = false; }
+    if (!img_ev) OV2_HIP_CHECK(hipEventCreateWithFlags(&img_ev, hipEventDisableTiming));
+    if (bytes > h_img_bytes) {
+        if (h_img) { OV2_HIP_CHECK(hipHostFree(h_img)); h_img = nullptr; h_img_bytes = 0; }
+        OV2_HIP_CHECK(hipHostMalloc(&h_img, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        h_img_bytes = bytes + bytes / 4 + 4096;
+    }
+    uint8_t *st = (uint8_t *)h_img;
+    if (src_stride == dst_pitch) memcpy(st, src_h, dst_pitch * (h - 1) + w);
+    else for (size_t y = 0; y < h; y++) memcpy(st + y * dst_pitch, src_h + y * src_stride, w);
+    OV2_HIP_CHECK(hipMemcpyAsync(dst_d, st, bytes, hipMemcpyHostToDevice, stream));
+    OV2_HIP_CHECK(hipEventRecord(img_ev, stream));
+    img_pending = true;
     return OV2_OK;
 }
 
@@ -89,6 +112,8 @@ void ov2_ctx_destroy(ov2_ctx *ctx)
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->stat_slots) (void)hipFree(ctx->stat_slots);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->h_img) (void)hipHostFree(ctx->h_img);
+    if (ctx->img_ev) (void)hipEventDestroy(ctx->img_ev);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

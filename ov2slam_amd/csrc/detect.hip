@@ -913,7 +913,8 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     const uint8_t *im = img_d;                                  // what the kernels read, and its pitch
     int im_stride = stride;
     if (!img_d) {
-        OV2_HIP_CHECK(hipMemcpy2DAsync(ds + o_img, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+        rc = ctx->upload_image(ds + o_img, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h);
+        if (rc) return rc;
         im = ds + o_img; im_stride = w;
     }
     if (ncur > 0) OV2_HIP_CHECK(hipMemcpyAsync(ds + o_cur, cur_xy_h, 8 * (size_t)ncur, hipMemcpyHostToDevice, ctx->stream));
@@ -1110,7 +1111,7 @@ int ov2_corner_subpix(ov2_ctx *ctx, const uint8_t *img_h, int w, int h, int stri
     const size_t o_xy = ((size_t)w * h + 255) & ~(size_t)255;
     int rc = ctx->reserve_device(o_xy + 8 * (size_t)n); if (rc) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(ds, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    rc = ctx->upload_image(ds, (size_t)w, img_h, (size_t)stride, (size_t)w, (size_t)h); if (rc) return rc;
     OV2_HIP_CHECK(hipMemcpyAsync(ds + o_xy, xy_inout_h, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_subpix(ctx, ds, w, h, w, (float2 *)(ds + o_xy), n, half_win, max_iter, eps);
     if (rc) return rc;

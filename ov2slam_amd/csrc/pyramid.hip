@@ -484,6 +484,10 @@ int ov2_pyr_build_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, 
     const int rc = ctx->reserve_device(item * (size_t)p->d.batch);
     if (rc != OV2_OK) return rc;
     if (p->d.batch > 1) OV2_REQUIRE(img_batch_stride >= (size_t)stride * (size_t)p->h, OV2_EINVAL, "img_batch_stride too small");
+    if (p->d.batch == 1) {
+        const int rcu = ctx->upload_image(ctx->d_scratch, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h);
+        if (rcu != OV2_OK) return rcu;
+    } else
     for (int b = 0; b < p->d.batch; b++) {
         OV2_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)ctx->d_scratch + item * b, pitch,
                                        img_h + img_batch_stride * b, (size_t)stride, (size_t)p->w, (size_t)p->h,

@@ -81,8 +81,8 @@ public:
         // later ov2_fb_klt fail with "LK window differs" / return fewer levels than asked for)
         if (p_ && (ov2_pyr_level_size(p_, 0, &w, &h) != OV2_OK || w != img.cols || h != img.rows || win != win_ || max_level != max_level_)) { ov2_pyr_destroy(p_); p_ = nullptr; }
         if (!p_) { const int rc = ov2_pyr_create(ctx.get(), img.cols, img.rows, win, max_level, 1, &p_); if (rc != OV2_OK) return rc; win_ = win; max_level_ = max_level; }
-        // asynchronous on ctx's stream: img.data must stay valid until the context's next synchronising call (every
-        // ov2_fb_klt / detector call is one).  Consumers on ANOTHER context wait on the pyramid's ready event themselves.
+        // asynchronous on ctx's stream; the image is staged in the context's pinned buffer before this returns (img.data may be
+        // released at once).  Consumers on ANOTHER context wait on the pyramid's ready event themselves.
         return ov2_pyr_build_h(ctx.get(), p_, img.data, img.step, 0);
     }
 private:
