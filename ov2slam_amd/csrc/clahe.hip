@@ -526,8 +526,8 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     if (rc != OV2_OK) return rc;
     const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, 0, 0);
     if (rc2 != OV2_OK) return rc2;
-    OV2_HIP_CHECK(hipMemcpy2DAsync(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
-    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    rc = ctx->download_image(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h);      // (synchronises)
+    if (rc != OV2_OK) return rc;
     return OV2_OK;
 }
 

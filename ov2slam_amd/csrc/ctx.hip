@@ -55,6 +55,24 @@ int ov2_ctx::upload_image(void *dst_d, size_t dst_pitch, const uint8_t *src_h, s
     return OV2_OK;
 }
 
+int ov2_ctx::download_image(uint8_t *dst_h, size_t dst_stride, const void *src_d, size_t src_pitch, size_t w, size_t h)
+{
+    if (w == 0 || h == 0) return OV2_OK;
+    const size_t bytes = src_pitch * (h - 1) + w;
+    if (img_pending) { OV2_HIP_CHECK(hipEventSynchronize(img_ev)); img_pending = false; }
+    if (bytes > h_img_bytes) {
+        if (h_img) { OV2_HIP_CHECK(hipHostFree(h_img)); h_img = nullptr; h_img_bytes = 0; }
+        OV2_HIP_CHECK(hipHostMalloc(&h_img, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        h_img_bytes = bytes + bytes / 4 + 4096;
+    }
+    OV2_HIP_CHECK(hipMemcpyAsync(h_img, src_d, bytes, hipMemcpyDeviceToHost, stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint8_t *st = (const uint8_t *)h_img;
+    if (src_pitch == dst_stride) memcpy(dst_h, st, bytes);
+    else for (size_t y = 0; y < h; y++) memcpy(dst_h + y * dst_stride, st + y * src_pitch, w);
+    return OV2_OK;
+}
+
 extern "C" {
 
 int ov2_version(void) { return 100; }

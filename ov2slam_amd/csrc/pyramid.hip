@@ -509,8 +509,8 @@ static int pyr_download_impl(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, u
     const uint8_t *item = p->d.base + (long long)b * p->d.item_stride;
     if (img_h) {
         const uint8_t *src = item + L.img_roi - (long long)pad * L.img_pitch - pad;
-        OV2_HIP_CHECK(hipMemcpy2DAsync(img_h, (size_t)ow, src, (size_t)L.img_pitch, (size_t)ow, (size_t)oh,
-                                       hipMemcpyDeviceToHost, ctx->stream));
+        const int rcd = ctx->download_image(img_h, (size_t)ow, src, (size_t)L.img_pitch, (size_t)ow, (size_t)oh);
+        if (rcd != OV2_OK) return rcd;
     }
     if (deriv_h) {
         // evaluate the derivative of this level on demand; border = BORDER_CONSTANT(0) like the reference's Mats
@@ -520,8 +520,9 @@ static int pyr_download_impl(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, u
         hipLaunchKernelGGL(k_scharr_level, dim3((L.w + 255) / 256, L.h), dim3(256), 0, ctx->stream, p->d, level, b, (uint32_t *)ctx->d_scratch);
         OV2_HIP_CHECK(hipGetLastError());
         if (pad) memset(deriv_h, 0, (size_t)ow * oh * 4);
-        OV2_HIP_CHECK(hipMemcpy2DAsync((uint8_t *)deriv_h + ((size_t)pad * ow + pad) * 4, (size_t)ow * 4, ctx->d_scratch, (size_t)L.w * 4,
-                                       (size_t)L.w * 4, (size_t)L.h, hipMemcpyDeviceToHost, ctx->stream));
+        const int rcd = ctx->download_image((uint8_t *)deriv_h + ((size_t)pad * ow + pad) * 4, (size_t)ow * 4, ctx->d_scratch, (size_t)L.w * 4,
+                                            (size_t)L.w * 4, (size_t)L.h);
+        if (rcd != OV2_OK) return rcd;
     }
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OV2_OK;
