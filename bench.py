@@ -529,6 +529,7 @@ def main():
     # ---- keyframe detection for the whole batch: every sequence's detector on level 0 of its pyramid, one call -------------
     det_batch = None
     if not args.no_extras and world == 1:
+      try:
         ncells = (W // CELL) * (H // CELL)
         cap = 2 * ncells
         det_out = torch.zeros((S, cap, 2), dtype=torch.float32, device=dev)
@@ -559,6 +560,9 @@ def main():
                               "no current keypoints / topping up %d tracked keypoints per sequence; the last figure adds a fifth of the "
                               "top-up call to the tracking step (keyframe every 5th frame)" % n_half}
         del det_out
+      except Exception:
+        import traceback
+        det_batch = {"error": traceback.format_exc()[-1000:]}
     del frames_d, kps_d, pri_d, pri_work, status_d
     for p in pyrs:
         p.close()
@@ -566,9 +570,15 @@ def main():
 
     c5 = None
     if not args.no_extras and args.workload == "euroc":
-        ctx5 = ov2slam_amd.Context(dev.index)
-        c5 = run_config5(ctx5, rank, world, args.config5_scale)
-        ctx5.close()
+        try:
+            ctx5 = ov2slam_amd.Context(dev.index)
+            c5 = run_config5(ctx5, rank, world, args.config5_scale)
+            ctx5.close()
+        except Exception:
+            import traceback
+            c5 = {"error": traceback.format_exc()[-1000:]} if world == 1 else None      # (with several ranks a failure must stay loud: collectives)
+            if world > 1:
+                raise
 
     if rank == 0:
         frames = args.steps * S * world
@@ -597,7 +607,8 @@ def main():
             out["config5"] = c5
         if det_batch is not None:
             out["detect_batch"] = det_batch
-        if world == 1 and not args.no_extras:
+        # The sections below are side measurements: a failure in one of them must not cost the headline line
+        def extras():
             ss = single_sequence(dev.index, views, kps, pri)
             out["single_sequence"] = ss
             out["single_sequence_fps"] = ss["pageable"]["fps_incl_pcie"]
@@ -665,6 +676,12 @@ def main():
                     out["combined_speedup_vs_cpu"] = cpu_s / gpu_single
                     out["combined_speedup_vs_cpu_batch_amortised"] = cpu_s / gpu_batch
                     out["tracking_speedup_vs_cpu_single_sequence"] = ss["pageable"]["fps_incl_pcie"] / cb["value"]
+        if world == 1 and not args.no_extras:
+            try:
+                extras()
+            except Exception:
+                import traceback
+                out["extras_error"] = traceback.format_exc()[-1500:]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
