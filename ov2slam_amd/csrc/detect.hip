@@ -45,7 +45,7 @@ __device__ __forceinline__ int d_reflect101(int p, int len)
 // An exclusion mask only ever removes candidates (masked responses become 0), so when p1 (p2) is positive and its mask bit is
 // still set when the sweep reaches the cell, it IS the masked arg-max -- the sweep then costs two LDS bit tests per cell instead
 // of a load batch and two arg-max passes, and falls back to the full scan otherwise.
-struct CellCand { int p1; float v1; int p2; float v2; };      // p = ly * cs + lx, -1: none
+struct CellCand { int p1; float v1; int p2; float v2; };      // p = lx | ly << 16 (cell-local pixel), -1: none
 
 // Batched launches (one image per batch item of a pyramid, ov2_detect_*_batch_d): per-item strides and parameters; everything
 // zero / NULL for a single image.  The cell kernels run ncells work-groups per item, the selection one work-group per item,
@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         if ((mask_mode != OV2_MASK_AS_EXECUTED || (lx & 3) >= 2) && v > bv) { bv = v; bi = p; }
     }
     block_argmax_f(bv, bi, s_v, s_i);
-    if (threadIdx.x == 0) { CellCand cd; cd.p1 = bv > 0.f ? bi : -1; cd.v1 = bv; cd.p2 = -1; cd.v2 = 0.f; cand_out[cell] = cd; }
+    if (threadIdx.x == 0) {
+        CellCand cd;
+        const int by = bi / cs, bx = bi - by * cs;
+        cd.p1 = bv > 0.f ? (bx | (by << 16)) : -1; cd.v1 = bv; cd.p2 = -1; cd.v2 = 0.f;
+        cand_out[cell] = cd;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -333,7 +338,13 @@ __global__ __launch_bounds__(64) void k_mineig_cells(const uint8_t *__restrict__
         }
     }
     wave_argmax_f(bv2, bi2);
-    if (lane == 0) { CellCand cd; cd.p1 = bi; cd.v1 = bv; cd.p2 = bi2 == 0x7FFFFFFF ? -1 : bi2; cd.v2 = bv2; cand_out[cell] = cd; }
+    if (lane == 0) {
+        CellCand cd;
+        cd.p1 = p1x | (p1y << 16); cd.v1 = bv;
+        const int p2y = bi2 / cs, p2x = bi2 - p2y * cs;
+        cd.p2 = bi2 == 0x7FFFFFFF ? -1 : (p2x | (p2y << 16)); cd.v2 = bv2;
+        cand_out[cell] = cd;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -351,6 +362,7 @@ struct SelectParams {
 struct SelectOut {
     int n;               // points written to out_xy
     int nboccup, nbempty, nbkps;
+    int nslow, pad_;             // cells of the sweep that needed the full masked scan (a candidate was hit by a neighbour's disc)
     unsigned long long dbg[4];   // wall_clock64 ticks (100 MHz): init, prologue, sweep, compaction
 };
 
@@ -423,6 +435,8 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     unsigned long long tk0 = wall_clock64();
     for (int i = tid; i < 4 * ncells; i += nthreads) s_cand[i] = ((const int *)cand)[i];
     for (int i = tid; i < P.nhcells; i += nthreads) progress[i] = 0;
+    __shared__ int s_nslow;
+    if (tid == 0) s_nslow = 0;
     for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
     for (int i = tid; i < ncells; i += nthreads) { prim[i] = -1; sec[i] = -1; }
@@ -443,27 +457,41 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
 
     const unsigned long long tk2 = wall_clock64();
     const int npx = P.cs * P.cs;
+    // cv::circle of an accepted point on the sweep's fast path: 2 radius + 1 <= 33 scan lines, one per lane, the half-width of a
+    // lane's line in a register (the generic mask_draw_circle reads it from LDS: one more round trip on the chain)
+    const int my_k = lane - P.radius;
+    const int my_hw = lane <= 2 * P.radius ? hw[my_k < 0 ? -my_k : my_k] : -1;
+    auto fast_draw = [&](int cx, int cy) {
+        const int y = cy + my_k;
+        if (my_hw < 0 || y < 0 || y >= P.h) return;
+        int xa = cx - my_hw, xb = cx + my_hw;
+        if (xa >= P.w || xb < 0) return;
+        xa = xa < 0 ? 0 : xa; xb = xb > P.w - 1 ? P.w - 1 : xb;
+        mask_clear_span(mask, P.mask_words_per_row, y, xa, xb);
+    };
     // The sweep.  Wavefront w walks along cell rows w, w + 16, ...; cell (r, c) may start when cells (r - 1, <= c + 1) are done
     // (the discs of an accepted point reach the 8 neighbouring cells only) -- a per-row progress counter in LDS, no
     // work-group barrier: a cell that needs the full scan delays its dependants only.  Bit-identical to raster order.
     for (int r = wave; r < P.nhcells; r += nwaves) {
         for (int c = 0; c < P.nwcells; c++) {
+            // what does not depend on the neighbours is read BEFORE the wait: the cell's candidates (wave-uniform) and its occupancy
+            const int cell = r * P.nwcells + c;
+            const int q_p1 = s_cand[4 * cell], q_v1 = s_cand[4 * cell + 1], q_p2 = s_cand[4 * cell + 2], q_v2 = s_cand[4 * cell + 3];
+            const int occd = occ[r * (P.nwcells + 1) + c];
             if (r > 0) {
                 const int need = min(c + 2, P.nwcells);
                 while (__hip_atomic_load(&progress[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             do {
-            const int cell = r * P.nwcells + c;
-            if (occ[r * (P.nwcells + 1) + c]) break;
+            if (occd) break;
             const int x0 = c * P.cs, y0 = r * P.cs;
             if (!(x0 + P.cs < P.w - 1 && y0 + P.cs < P.h - 1)) break;    // :350 / :510
-            // the cell's candidates (wave-uniform)
-            const int c_p1 = __builtin_amdgcn_readfirstlane(s_cand[4 * cell]), c_p2 = __builtin_amdgcn_readfirstlane(s_cand[4 * cell + 2]);
-            const float c_v1 = __int_as_float(__builtin_amdgcn_readfirstlane(s_cand[4 * cell + 1]));
-            const float c_v2 = __int_as_float(__builtin_amdgcn_readfirstlane(s_cand[4 * cell + 3]));
-            const int p1y = c_p1 >= 0 ? c_p1 / P.cs : 0, p1x = c_p1 >= 0 ? c_p1 - p1y * P.cs : 0;
-            const int p2y = c_p2 >= 0 ? c_p2 / P.cs : 0, p2x = c_p2 >= 0 ? c_p2 - p2y * P.cs : 0;
+            const int c_p1 = __builtin_amdgcn_readfirstlane(q_p1), c_p2 = __builtin_amdgcn_readfirstlane(q_p2);
+            const float c_v1 = __int_as_float(__builtin_amdgcn_readfirstlane(q_v1));
+            const float c_v2 = __int_as_float(__builtin_amdgcn_readfirstlane(q_v2));
+            const int p1x = c_p1 >= 0 ? (c_p1 & 0xFFFF) : 0, p1y = c_p1 >= 0 ? (c_p1 >> 16) : 0;
+            const int p2x = c_p2 >= 0 ? (c_p2 & 0xFFFF) : 0, p2y = c_p2 >= 0 ? (c_p2 >> 16) : 0;
             // Full scan (a candidate was masked): lane ly owns row ly of the cell (cs <= 64): its slice of the exclusion
             // mask is ONE 64-bit string (bit j <-> pixel x0 + j), the response map is column-major so that the loads of a
             // column are coalesced.  Raster-order tie-breaking: strict `>` along the row, then the smaller pixel index in
@@ -499,9 +527,11 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 float bv = 0.f; int bi = 0x7FFFFFFF;
                 // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
                 const int mcol = P.mask_mode == OV2_MASK_AS_EXECUTED ? (p1x >> 2) : p1x;
-                if (mask_test(mask, P.mask_words_per_row, x0 + mcol, y0 + p1y)) { bv = c_v1; bi = c_p1; }
+                int mx_ = p1x, my_ = p1y;
+                if (mask_test(mask, P.mask_words_per_row, x0 + mcol, y0 + p1y)) bv = c_v1;
                 else {
                     // best response among the mask-surviving FAST corners, raster order on ties
+                    if (lane == 0) atomicAdd(&s_nslow, 1);
                     const unsigned long long mb = row_mask(x0);
                     if (single) { SEL_LOAD_CHUNK(0) }
 #pragma unroll
@@ -516,16 +546,17 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                         }
                     }
                     wave_argmax_f(bv, bi);
+                    my_ = bi / P.cs; mx_ = bi - my_ * P.cs;
                 }
                 if (bv >= 20.f) {                                         // :521
-                    const int my = bi / P.cs, mx = bi - my * P.cs;
-                    const int px = x0 + mx, py = y0 + my;
+                    const int px = x0 + mx_, py = y0 + my_;
                     if (lane == 0) prim[cell] = px | (py << 16);
-                    mask_draw_circle(mask, P, hw, px, py, lane, 64);      // :527
+                    fast_draw(px, py);                                    // :527
                 }
             } else {
                 // minMaxLoc of response * mask: first maximum, row-major.  Pixel 0 of the row initialises (lanes >= cs: no index)
                 auto scan = [&](float &bv, int &bi) {
+                    if (lane == 0 && !have) atomicAdd(&s_nslow, 1);
                     const unsigned long long mb = row_mask(x0);
                     bv = -FLT_MAX; bi = 0x7FFFFFFF;
                     if (single && !have) { SEL_LOAD_CHUNK(0) have = true; }
@@ -544,27 +575,33 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                     wave_argmax_f(bv, bi);
                 };
                 float bv; int bi;
+                // both candidates are tested at once (p2 lies outside the disc of p1 by construction, so its test does not wait for
+                // that disc): in the common case the cell costs two LDS bit tests and two disc draws, no intermediate fence
+                const bool t1 = mask_test(mask, P.mask_words_per_row, x0 + p1x, y0 + p1y) != 0;
+                const bool t2 = mask_test(mask, P.mask_words_per_row, x0 + p2x, y0 + p2y) != 0;
                 // pass 0
-                const bool f0 = c_v1 > 0.f && mask_test(mask, P.mask_words_per_row, x0 + p1x, y0 + p1y);
-                if (f0) { bv = c_v1; bi = c_p1; } else scan(bv, bi);
-                int my_ = bi / P.cs, mx_ = bi - my_ * P.cs;
+                const bool f0 = c_v1 > 0.f && t1;
+                int mx_ = p1x, my_ = p1y;
+                if (f0) bv = c_v1; else { scan(bv, bi); my_ = bi / P.cs; mx_ = bi - my_ * P.cs; }
                 int mx = x0 + mx_, my = y0 + my_;
                 if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) break;   // `continue` at :363-368
                 if (!((double)bv >= P.quality)) break;                    // nothing accepted: the second minMaxLoc sees the same mask and value
                 if (lane == 0) prim[cell] = mx | (my << 16);
-                mask_draw_circle(mask, P, hw, mx, my, lane, 64);
-                // make the disc visible to this wave's second pass
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                fast_draw(mx, my);
                 // pass 1: the candidate outside the disc just drawn, if the first pass took its candidate
-                const bool f1 = f0 && c_p2 >= 0 && c_v2 > 0.f && mask_test(mask, P.mask_words_per_row, x0 + p2x, y0 + p2y);
-                if (f1) { bv = c_v2; bi = c_p2; } else scan(bv, bi);
-                my_ = bi / P.cs; mx_ = bi - my_ * P.cs;
+                const bool f1 = f0 && c_p2 >= 0 && c_v2 > 0.f && t2;
+                if (f1) { bv = c_v2; mx_ = p2x; my_ = p2y; }
+                else {
+                    // make the disc visible to this wave's full scan
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    scan(bv, bi); my_ = bi / P.cs; mx_ = bi - my_ * P.cs;
+                }
                 mx = x0 + mx_; my = y0 + my_;
                 if (mx < P.roi_x || my < P.roi_y || mx >= P.roi_x + P.roi_w || my >= P.roi_y + P.roi_h) break;   // :379-384
                 if ((double)bv >= P.quality) {
                     if (lane == 0) sec[cell] = mx | (my << 16);
-                    mask_draw_circle(mask, P, hw, mx, my, lane, 64);
+                    fast_draw(mx, my);
                 }
             }
 #undef SEL_LOAD_CHUNK
@@ -606,7 +643,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
             n = nbprim + (k < nbsec ? k : nbsec);
         }
       if (lane == 0) {
-        out->n = n; out->nboccup = nboccup; out->nbempty = nbempty; out->nbkps = nbprim;
+        out->n = n; out->nboccup = nboccup; out->nbempty = nbempty; out->nbkps = nbprim; out->nslow = s_nslow; out->pad_ = 0;
         out->dbg[0] = tk1 - tk0; out->dbg[1] = tk2 - tk1; out->dbg[2] = tk3 - tk2; out->dbg[3] = wall_clock64() - tk3;
       }
     }
@@ -930,7 +967,8 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(so_h, hs + 16 * (size_t)ncells, sizeof(SelectOut));
     if (getenv("OV2_DET_DEBUG"))
-        fprintf(stderr, "[ov2 det] select ticks (100MHz): init %llu prologue %llu sweep %llu compaction %llu\n", so_h->dbg[0], so_h->dbg[1], so_h->dbg[2], so_h->dbg[3]);
+        fprintf(stderr, "[ov2 det] select ticks (100MHz): init %llu prologue %llu sweep %llu compaction %llu; cells on the full-scan path: %d\n",
+                so_h->dbg[0], so_h->dbg[1], so_h->dbg[2], so_h->dbg[3], so_h->nslow);
     const int n = so_h->n;
     if (n > 0) memcpy(out_xy_h, hs, 8 * (size_t)n);
     *out_n = n;
