@@ -41,6 +41,11 @@ typedef struct ov2_ctx ov2_ctx;
 typedef struct ov2_pyr ov2_pyr;
 
 /* ---- context ------------------------------------------------------- */
+/* ABI version of THIS header: bumped whenever a struct passed by pointer grows or an entry point changes its signature
+ * (round 2 added ov2_ba_options::max_solver_time_s).  ov2_version() returns the value the library was built with; a caller
+ * must refuse to run when the two differ (the C++ adapters' ov2::Context and ov2slam_amd/_lib.py do): a shorter options
+ * struct from an older header would otherwise be read past its end.                                                    */
+#define OV2_ABI_VERSION 300
 int  ov2_version(void);
 /* last error message of the calling thread ("" if none); never NULL */
 const char *ov2_last_error(void);
@@ -176,7 +181,10 @@ typedef struct {
     int max_iter; float eps;     /* klt_convg_crit_: nmax_iter (30), fmax_px_precision (0.01)           */
     float err_th, fb_dist;       /* nklt_err (30), fmax_fbklt_dist (0.5)                                */
     int use_clahe; double clahe_clip; int tiles_x, tiles_y;   /* use_clahe, fclahe_val, (w/50, h/50)    */
-    int n_max;                   /* keypoint capacity (nbmaxkps)                                        */
+    int n_max;                   /* keypoints per fused launch (>= nbmaxkps; the adapters pass 2 x nbmaxkps).  NOT a
+                                    limit on n: a frame can carry more than nbmaxkps keypoints (pruning happens at the
+                                    next keyframe, src/map_manager.cpp:74); keypoints beyond n_max run through further
+                                    launches of the same kernel, n_max at a time, with identical results              */
     int use_graph;               /* 1: replay a captured hipGraph per frame (falls back to plain enqueue
                                     when the context's stream cannot be captured)                       */
 } ov2_tracker_config;
@@ -197,7 +205,7 @@ int  ov2_tracker_preprocess(ov2_tracker *t, const uint8_t *img_h, int stride);
  * status_h[i]: bit 0 = tracked, bit 1 = lost on the prior pass and re-tracked on the full pyramid;
  * *p3p_req (may be NULL): 1 when fewer than a third of the prior tracks were good (bp3preq_, :225-230) -- the lost
  * prior tracks are then re-run from the keypoints themselves in a second launch, exactly like the reference.
- * Blocking (one synchronisation).  n == 0 returns OV2_OK.                                                    */
+ * Blocking (one synchronisation; one more per n_max keypoints beyond the first n_max).  n == 0 returns OV2_OK.     */
 int  ov2_tracker_klt(ov2_tracker *t, const float *kps_xy_h, const float *prior_xy_h, const uint8_t *has_prior_h, int n,
                      int klt_use_prior, float *out_xy_h, uint8_t *status_h, int *p3p_req);
 /* preprocess + klt in one enqueue (one graph launch when use_graph): the per-frame call of the drop-in.
@@ -472,7 +480,7 @@ int ov2_stereo_epipolar_check(ov2_ctx *ctx, int rect, const double Frl[9], int m
  *   rect != 0   getLineMinSAD on pyramid level nklt_pyr_lvl (window 7, searching left) gives the x prior of every keypoint
  *               without a 3-D prior when it lies in [0, kp.x] (:421-439)
  *   tracking    keypoints with has_prior3d_h[i] != 0 are tracked from priors3d_h[i] on 1 level first; the ones that fail join
- *               the second call WITH THE SAME PRIOR (:533-538); everything else runs on nklt_pyr_lvl levels (:544-565)
+ *               the second call with the first call's forward result as prior (:533-538: v3dpriors was updated in place); everything else runs on nklt_pyr_lvl levels (:544-565)
  *   gate        ov2_stereo_epipolar_check on the tracked right keypoints (model / K / D of the RIGHT camera, kps_unpx_h = the
  *               left keypoints' undistorted pixels)
  * Outputs: stereo_ok_h[i] (what decides updateKeypointStereo, :584) and right_px_h[i] (rect: y replaced by the left keypoint's,

@@ -17,7 +17,11 @@
  *     variant (exact integer sums, one rounding to float).  The default build's
  *     float/SIMD accumulation order is compiler/ISA dependent; the int64 variant
  *     is order independent, which is what makes a parallel GPU reduction
- *     bit-reproducible.
+ *     bit-reproducible.  Stock OpenCV builds use `float` accumulators instead; their
+ *     summation orders (scalar raster order, the 3.4 SSE2 intrinsics, the 4.x
+ *     universal-intrinsics code) are restated as orc_set_lk_acc_mode(ORC_LK_ACC_FLOAT_*)
+ *     so that the distance between the canonical variant and what a real build
+ *     executes can be MEASURED (tests/test_oracle_frontend.py, bench.py `parity`).
  *   - all float expressions are evaluated without FMA contraction
  *     (-ffp-contract=off) in source order.
  */
@@ -242,6 +246,12 @@ int orc_pyr_copy_level_padded(const orc_pyr *p, int level, uint8_t *img_out, int
 }
 
 /* ---- calcOpticalFlowPyrLK ------------------------------------------- */
+/* Accumulator variant of LKTrackerInvoker (lkpyramid.cpp: `typedef float acctype; typedef float itemtype;` in stock
+ * builds, `int64` / `int` behind the same typedefs): process-wide switch, read once per orc_lk_track call.            */
+static int g_lk_acc_mode = ORC_LK_ACC_INT64;
+void orc_set_lk_acc_mode(int mode) { if (mode >= ORC_LK_ACC_INT64 && mode <= ORC_LK_ACC_FLOAT_UI4) g_lk_acc_mode = mode; }
+int orc_get_lk_acc_mode(void) { return g_lk_acc_mode; }
+
 typedef struct {
     const orc_pyr *prev, *next;
     const float *prev_xy; float *next_xy;
@@ -250,6 +260,7 @@ typedef struct {
     int *iters_out;
     int level;
     int begin, end;
+    int acc_mode;
 } lk_job;
 
 #define LK_MAX_WIN 31
@@ -299,6 +310,12 @@ static void lk_level_range(const lk_job *jb)
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
         int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+        /* float-accumulator variants (stock OpenCV).  The SIMD loops cover the first 4*(win/4) columns of a window row
+         * four at a time: lane k of qA** sums the pixels x = k (mod 4) of those columns over all rows; the remaining
+         * columns go to the scalar float accumulators fA**; the lanes are folded in once after the last row.          */
+        const int accm = jb->acc_mode;
+        const int simdA = accm >= ORC_LK_ACC_FLOAT_SSE34 ? 4 * (win / 4) : 0;
+        float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f, qA11[4] = {0.f, 0.f, 0.f, 0.f}, qA12[4] = {0.f, 0.f, 0.f, 0.f}, qA22[4] = {0.f, 0.f, 0.f, 0.f};
         for (int y = 0; y < win; y++) {
             const uint8_t *src = Ibase + (ptrdiff_t)(y + ipy) * stepI + ipx;
             const int16_t *dsrc = Dbase + (ptrdiff_t)(y + ipy) * dstep + 2 * ipx;
@@ -309,12 +326,36 @@ static void lk_level_range(const lk_job *jb)
                 Iwin[y * win + x] = (int16_t)ival;
                 dIx[y * win + x] = (int16_t)ixval;
                 dIy[y * win + x] = (int16_t)iyval;
-                iA11 += (int)(ixval * ixval);
-                iA12 += (int)(ixval * iyval);
-                iA22 += (int)(iyval * iyval);
+                if (accm == ORC_LK_ACC_INT64) {
+                    iA11 += (int)(ixval * ixval);
+                    iA12 += (int)(ixval * iyval);
+                    iA22 += (int)(iyval * iyval);
+                } else if (x < simdA) {                       /* fx = cvt(t), qA = qA + fx * fx  (no FMA in SSE2 / baseline builds) */
+                    const float fx = (float)ixval, fy = (float)iyval;
+                    qA22[x & 3] = qA22[x & 3] + fy * fy;
+                    qA12[x & 3] = qA12[x & 3] + fx * fy;
+                    qA11[x & 3] = qA11[x & 3] + fx * fx;
+                } else {                                      /* iA11 += (itemtype)(ixval*ixval) */
+                    fA11 += (float)(ixval * ixval);
+                    fA12 += (float)(ixval * iyval);
+                    fA22 += (float)(iyval * iyval);
+                }
             }
         }
-        float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+        float A11, A12, A22;
+        if (accm == ORC_LK_ACC_INT64) { A11 = (float)iA11 * FLT_SCALE; A12 = (float)iA12 * FLT_SCALE; A22 = (float)iA22 * FLT_SCALE; }
+        else {
+            if (accm == ORC_LK_ACC_FLOAT_SSE34) {             /* iA11 += A11buf[0] + A11buf[1] + A11buf[2] + A11buf[3] */
+                fA11 += ((qA11[0] + qA11[1]) + qA11[2]) + qA11[3];
+                fA12 += ((qA12[0] + qA12[1]) + qA12[2]) + qA12[3];
+                fA22 += ((qA22[0] + qA22[1]) + qA22[2]) + qA22[3];
+            } else if (accm == ORC_LK_ACC_FLOAT_UI4) {        /* iA11 += v_reduce_sum(qA11): (a0 + a2) + (a1 + a3) */
+                fA11 += (qA11[0] + qA11[2]) + (qA11[1] + qA11[3]);
+                fA12 += (qA12[0] + qA12[2]) + (qA12[1] + qA12[3]);
+                fA22 += (qA22[0] + qA22[2]) + (qA22[1] + qA22[3]);
+            }
+            A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE;
+        }
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
         if (jb->err && (jb->flags & ORC_LK_GET_MIN_EIGENVALS)) jb->err[i] = minEig;
@@ -339,16 +380,56 @@ static void lk_level_range(const lk_job *jb)
             iw10 = cv_round_f((1.f - a) * b * (float)(1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t ib1 = 0, ib2 = 0;
+            /* float variants: the SIMD loop takes the first 8*(win/8) columns of a row eight at a time into qb0 / qb1 =
+             * (x, y, x, y) lanes.  3.4 SSE2: every product It*Ix is converted to float on its own (mullo / mulhi ->
+             * cvtepi32_ps: rounds above 2^24) -- pixels {0,4} -> qb0[0..1], {1,5} -> qb0[2..3], {2,6} -> qb1[0..1],
+             * {3,7} -> qb1[2..3]; 4.x universal intrinsics: v_dotprod adds the products of pixels p and p+4 exactly in
+             * int32 before v_cvt_f32.  Remaining columns: ib += (itemtype)(diff * dI) in float.                         */
+            const int simdB = accm >= ORC_LK_ACC_FLOAT_SSE34 ? 8 * (win / 8) : 0;
+            float fb1 = 0.f, fb2 = 0.f, qb0[4] = {0.f, 0.f, 0.f, 0.f}, qb1[4] = {0.f, 0.f, 0.f, 0.f};
             for (int y = 0; y < win; y++) {
                 const uint8_t *Jp = Jbase + (ptrdiff_t)(y + iny) * stepJ + inx;
+                int dgrp[8];
                 for (int x = 0; x < win; x++) {
                     int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5)
                                - Iwin[y * win + x];
-                    ib1 += (int)(diff * dIx[y * win + x]);
-                    ib2 += (int)(diff * dIy[y * win + x]);
+                    if (accm == ORC_LK_ACC_INT64) {
+                        ib1 += (int)(diff * dIx[y * win + x]);
+                        ib2 += (int)(diff * dIy[y * win + x]);
+                    } else if (x >= simdB) {
+                        fb1 += (float)(diff * dIx[y * win + x]);
+                        fb2 += (float)(diff * dIy[y * win + x]);
+                    } else {
+                        dgrp[x & 7] = diff;
+                        if ((x & 7) == 7) {
+                            const int16_t *gx = &dIx[y * win + x - 7], *gy = &dIy[y * win + x - 7];
+                            if (accm == ORC_LK_ACC_FLOAT_SSE34) {
+                                for (int h = 0; h < 2; h++) {          /* v00 * diff0 (pixels 0..3), then v01 * diff1 (4..7) */
+                                    const int p = 4 * h;
+                                    qb0[0] = qb0[0] + (float)(dgrp[p] * gx[p]);         qb0[1] = qb0[1] + (float)(dgrp[p] * gy[p]);
+                                    qb0[2] = qb0[2] + (float)(dgrp[p + 1] * gx[p + 1]); qb0[3] = qb0[3] + (float)(dgrp[p + 1] * gy[p + 1]);
+                                    qb1[0] = qb1[0] + (float)(dgrp[p + 2] * gx[p + 2]); qb1[1] = qb1[1] + (float)(dgrp[p + 2] * gy[p + 2]);
+                                    qb1[2] = qb1[2] + (float)(dgrp[p + 3] * gx[p + 3]); qb1[3] = qb1[3] + (float)(dgrp[p + 3] * gy[p + 3]);
+                                }
+                            } else {
+                                qb0[0] = qb0[0] + (float)(dgrp[0] * gx[0] + dgrp[4] * gx[4]); qb0[1] = qb0[1] + (float)(dgrp[0] * gy[0] + dgrp[4] * gy[4]);
+                                qb0[2] = qb0[2] + (float)(dgrp[1] * gx[1] + dgrp[5] * gx[5]); qb0[3] = qb0[3] + (float)(dgrp[1] * gy[1] + dgrp[5] * gy[5]);
+                                qb1[0] = qb1[0] + (float)(dgrp[2] * gx[2] + dgrp[6] * gx[6]); qb1[1] = qb1[1] + (float)(dgrp[2] * gy[2] + dgrp[6] * gy[6]);
+                                qb1[2] = qb1[2] + (float)(dgrp[3] * gx[3] + dgrp[7] * gx[7]); qb1[3] = qb1[3] + (float)(dgrp[3] * gy[3] + dgrp[7] * gy[7]);
+                            }
+                        }
+                    }
                 }
             }
-            float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            float b1, b2;
+            if (accm == ORC_LK_ACC_INT64) { b1 = (float)ib1 * FLT_SCALE; b2 = (float)ib2 * FLT_SCALE; }
+            else {
+                if (simdB) {       /* 3.4: bbuf = qb0 + qb1; ib1 += bbuf[0] + bbuf[2].  4.x: the same sums after interleave / recombine / v_reduce_sum with zeros */
+                    const float s0 = qb0[0] + qb1[0], s1 = qb0[1] + qb1[1], s2 = qb0[2] + qb1[2], s3 = qb0[3] + qb1[3];
+                    fb1 += s0 + s2; fb2 += s1 + s3;
+                }
+                b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
+            }
             float dx = (A12 * b2 - A22 * b1) * D;
             float dy = (A12 * b1 - A11 * b2) * D;
             nextx += dx; nexty += dy;
@@ -402,7 +483,7 @@ int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
     jb.status = status; jb.err = err; jb.win = win; jb.max_level = max_level;
     jb.max_count = max_count; jb.epsilon = epsilon; jb.flags = flags;
     jb.min_eig_threshold = min_eig_threshold; jb.iters_out = iters_out;
-    jb.level = max_level; jb.begin = 0; jb.end = n;
+    jb.level = max_level; jb.begin = 0; jb.end = n; jb.acc_mode = g_lk_acc_mode;
     if (nthreads <= 1) lk_thread(&jb);
     else {
         /* points over the persistent pool (cv::parallel_for_ in LKTrackerInvoker); the pool is grown on demand */

@@ -155,6 +155,50 @@ def fb_klt(prev, cur, win, nbpyrlvl, ferr, fbdist, kps, priors, max_iter=30, eps
     return pr, status.astype(bool), (it.value, vis.value)
 
 
+LK_ACC_INT64, LK_ACC_FLOAT_SCALAR, LK_ACC_FLOAT_SSE34, LK_ACC_FLOAT_UI4 = 0, 1, 2, 3
+LK_ACC_NAMES = {0: "int64 (canonical, what the HIP kernels implement)", 1: "float, scalar raster order (no SIMD build)",
+                2: "float, OpenCV 3.4 SSE2 intrinsics order", 3: "float, OpenCV 4.x universal-intrinsics order"}
+
+
+class lk_acc_mode:
+    """with lk_acc_mode(LK_ACC_FLOAT_UI4): ...  -- accumulator variant of calcOpticalFlowPyrLK (frontend.c)."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        f = lib().orc_get_lk_acc_mode
+        f.restype = C.c_int
+        self.prev = f()
+        lib().orc_set_lk_acc_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_lk_acc_mode(self.prev)
+        return False
+
+
+def lk_acc_mode_report(prev, cur, kps, priors, win=9, nbpyrlvl=3, ferr=30., fbdist=0.5, max_iter=30, eps=0.01):
+    """fbKltTracking with the canonical int64 accumulators against the three float-accumulator orders of stock OpenCV builds on
+    the same inputs: per float mode the number of status flips and the largest position difference among keypoints tracked by
+    both.  This is the measured distance between what the HIP kernels compute bit-exactly and what a real OpenCV build would."""
+    ref_xy, ref_st, _ = fb_klt(prev, cur, win, nbpyrlvl, ferr, fbdist, kps, priors, max_iter, eps)
+    out = {"points": int(len(ref_st)), "tracked_int64": int(ref_st.sum()), "modes": {}}
+    for mode in (LK_ACC_FLOAT_SCALAR, LK_ACC_FLOAT_SSE34, LK_ACC_FLOAT_UI4):
+        with lk_acc_mode(mode):
+            xy, st, _ = fb_klt(prev, cur, win, nbpyrlvl, ferr, fbdist, kps, priors, max_iter, eps)
+        both = ref_st & st
+        d = np.abs(xy[both].astype(np.float64) - ref_xy[both].astype(np.float64)).max(axis=1) if both.any() else np.zeros(0)
+        out["modes"][LK_ACC_NAMES[mode]] = {
+            "status_flips": int((ref_st != st).sum()),
+            "bit_identical_positions": int((xy[both].view(np.uint32) == ref_xy[both].view(np.uint32)).all(axis=1).sum()),
+            "max_abs_dpx": float(d.max()) if len(d) else 0.0,
+            "p99_abs_dpx": float(np.quantile(d, 0.99)) if len(d) else 0.0,
+            "above_0.01px": int((d > 0.01).sum()),
+        }
+    return out
+
+
 # ---------------------------------------------------------------- detection
 def klt_tracking(prev, cur, kps, priors, has_prior, win=9, nklt_pyr_lvl=3, ferr=30., fbdist=0.5, klt_use_prior=True,
                  max_iter=30, eps=0.01):
@@ -459,6 +503,56 @@ def stereo_epipolar_check(rect, Frl, model, K, D, lunpx, rkps):
     f.restype = None
     f(int(bool(rect)), _p(Frl), int(model), _p(K), _p(D) if len(D) else None, int(len(D)), _p(lunpx), _p(rk), n, _p(runpx), _p(err), _p(ok))
     return rk, runpx, err, ok.astype(bool)
+
+
+def stereo_matching(leftpyr, rightpyr, kps_px, kps_unpx, model, K, D, rect, Frl=None, win=9, nklt_pyr_lvl=3, ferr=30., fbdist=0.5,
+                    priors3d=None, max_iter=30, eps=0.01):
+    """Data path of MapManager::stereoMatching (/root/reference/src/map_manager.cpp:367-611) restated list by list, with the
+    reference's own push_back order (test infrastructure; the map look-ups that produce `priors3d` stay outside):
+      :421-439  keypoints without a 3-D prior: prior = keypoint, x replaced by getLineMinSAD on level nklt_pyr_lvl when
+                0 <= xprior <= kp.x (rectified pairs only);
+      :497-541  fbKltTracking(left, right, nbpyrlvl 1) on the 3-D-prior list; a failure is appended to the 2-D list with
+                v3dpriors.at(i) -- the vector fbKltTracking has just overwritten with its forward result (feature_tracker.cpp:66);
+      :544-565  fbKltTracking on the 2-D list with the full pyramid;
+      :568-590  epipolar gate on the good tracks.
+    Returns (stereo_ok (n,) bool, right_px (n,2) float32)."""
+    kps_px = np.ascontiguousarray(kps_px, np.float32).reshape(-1, 2)
+    kps_unpx = np.ascontiguousarray(kps_unpx, np.float32).reshape(-1, 2)
+    n = len(kps_px)
+    priors3d = priors3d or {}
+    v3dkpids, v3dkps, v3dpriors, vkpids, vkps, vpriors = [], [], [], [], [], []
+    up = np.float32(2.0 ** nklt_pyr_lvl); down = np.float32(1.0) / up
+    for i in range(n):                                                     # :392-489 (kps in frame order)
+        if i in priors3d:
+            v3dkpids.append(i); v3dkps.append(kps_px[i]); v3dpriors.append(np.asarray(priors3d[i], np.float32))
+            continue
+        pr = kps_px[i].copy()
+        if rect:
+            xp, _ = line_min_sad(leftpyr.level(nklt_pyr_lvl)[0], rightpyr.level(nklt_pyr_lvl)[0], (kps_px[i] * down)[None], 7, True)
+            x = np.float32(xp[0]) * up
+            if x >= 0 and x <= kps_px[i, 0]:
+                pr[0] = x
+        vkpids.append(i); vkps.append(kps_px[i]); vpriors.append(pr)
+    goodids, goodr = [], []
+    if v3dpriors:
+        out, st, _ = fb_klt(leftpyr, rightpyr, win, 1, ferr, fbdist, np.array(v3dkps, np.float32), np.array(v3dpriors, np.float32), max_iter, eps)
+        v3dpriors = list(out)                                              # updated in place by calcOpticalFlowPyrLK
+        for j in range(len(v3dkpids)):
+            if st[j]:
+                goodr.append(v3dpriors[j]); goodids.append(v3dkpids[j])
+            else:
+                vkpids.append(v3dkpids[j]); vkps.append(v3dkps[j]); vpriors.append(v3dpriors[j])
+    if vkps:
+        out, st, _ = fb_klt(leftpyr, rightpyr, win, nklt_pyr_lvl, ferr, fbdist, np.array(vkps, np.float32), np.array(vpriors, np.float32), max_iter, eps)
+        for j in range(len(vkpids)):
+            if st[j]:
+                goodr.append(out[j]); goodids.append(vkpids[j])
+    ok = np.zeros(n, bool); right = np.zeros((n, 2), np.float32)
+    if goodids:
+        gi = np.array(goodids, np.int64)
+        rk, _, _, eok = stereo_epipolar_check(rect, Frl if Frl is not None else np.zeros(9), model, K, D, kps_unpx[gi], np.array(goodr, np.float32))
+        ok[gi] = eok; right[gi] = rk
+    return ok, right
 
 
 # ---- Optimizer::structureOnlyBA (struct_ba.c) -------------------------------------------------------

@@ -93,6 +93,16 @@ int orc_clahe(const uint8_t *src, int w, int h, int stride, double clip_limit, i
  * NULL) receives, per point, the total number of Gauss-Newton iterations that
  * were executed over all levels (used for the algorithmic-bytes figure).
  * nthreads > 1 splits the points over pthreads (mirrors cv::parallel_for_).  */
+/* LK accumulator variant (frontend.c): INT64 = the canonical, order-independent variant the HIP kernels implement;
+ * FLOAT_* = float accumulators in the summation orders of stock OpenCV builds (restated from the public lkpyramid.cpp, parity
+ * unpinned): scalar raster order (no SIMD), the 3.4 SSE2 intrinsics, the 4.x universal intrinsics (SSE / AVX2 baselines, no FMA). */
+#define ORC_LK_ACC_INT64        0
+#define ORC_LK_ACC_FLOAT_SCALAR 1
+#define ORC_LK_ACC_FLOAT_SSE34  2
+#define ORC_LK_ACC_FLOAT_UI4    3
+void orc_set_lk_acc_mode(int mode);
+int orc_get_lk_acc_mode(void);
+
 int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
                  const float *prev_xy, float *next_xy, int n,
                  uint8_t *status, float *err,

@@ -166,6 +166,8 @@ SIGNATURES = {
     "ov2_ba_destroy": (None, [_vp]),
 }
 
+OV2_ABI_VERSION = 300          # include/ov2slam_hip.h
+
 _lib = None
 
 
@@ -183,6 +185,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.ov2_version() != OV2_ABI_VERSION:    # struct layouts below are those of include/ov2slam_hip.h at this version
+        raise ImportError("%s reports ABI version %d, these bindings were written for %d: rebuild the library"
+                          % (LIB_PATH, lib.ov2_version(), OV2_ABI_VERSION))
     _lib = lib
     return lib
 

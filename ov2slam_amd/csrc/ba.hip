@@ -2102,6 +2102,7 @@ struct ov2_ba_dev {
 };
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static void ba_destroy(ov2_ba_dev *dev);
 
 // transient: the problem lives for one ov2_ba_solve call -- small pools then come out of the context's device scratch instead of
 // a hipMalloc / hipFree pair (~100 us, more than a whole ceresPnP solve)
@@ -2188,6 +2189,11 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) ? 1 : 0;
         if (const char *e = getenv("OV2_BA_BIG")) D.big = e[0] == '1' ? 1 : D.big;       // force the path on small problems (tests)
         if (n_po > 0) D.big = 0;                                                          // pose-only blocks: single-pose problems
+        if (!D.big && (lin_lds > 159 * 1024 || chol_lds > 150 * 1024)) {                  // before any device allocation or upload
+            delete dev;
+            ov2_set_error("too many optimised keyframes (%d) for a problem with pose-only blocks: they have no large-problem path (limit ~90)", n_opt);
+            return OV2_EUNSUPPORTED;
+        }
     }
     // big path: the slots of the sparse W (one per landmark and optimised keyframe seeing or anchoring it) and their per-keyframe lists
     std::vector<int> cw_ptr(p->n_lm + 1, 0), cw_col, cw_lm, res_cw, lm_cwa, kfl_ptr(n_opt + 1, 0), kfl_idx;
@@ -2297,7 +2303,10 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     }
 #undef UP
     // the staging vectors die at return: make sure the copies are done
-    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    {
+        const hipError_t es = hipStreamSynchronize(s);
+        if (es != hipSuccess) { ov2_set_error("hipStreamSynchronize: %s", hipGetErrorString(es)); ba_destroy(dev); return OV2_EHIP; }
+    }
     *out = dev;
     return OV2_OK;
 }
@@ -2326,6 +2335,15 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     for (int k = 0; k < p->n_kf; k++) pose_col[k] = (p->kf_const && p->kf_const[k]) ? -1 : 6 * n_opt++;
     const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
     OV2_REQUIRE(nfp <= 2048, OV2_EUNSUPPORTED, "more than 341 optimised keyframes: dense reduced system too large");
+    {   // size limits BEFORE anything is allocated or uploaded (W and W' alone are 2 x 24 n_pts nfp bytes): the 3-D point form
+        // has no large-problem path, its lineariser and Cholesky hold the reduced system in LDS
+        const size_t lin_lds = 8 * (12 * (size_t)nfp + (size_t)n_opt * 27) + 64;
+        const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
+        if (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) {
+            ov2_set_error("too many optimised keyframes (%d) for the LDS-resident solver (limit ~90; 3-D point landmarks and pose-only blocks have no large-problem path)", n_opt);
+            return OV2_EUNSUPPORTED;
+        }
+    }
     std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
     std::vector<uint8_t> res_type(n_act);
     std::vector<double> res_uv(2 * (size_t)n_act), res_sigma(n_act);
@@ -2393,7 +2411,10 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     UPX(D.res_uv, res_uv.data(), 16 * (size_t)n_act);
     UPX(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
 #undef UPX
-    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    {
+        const hipError_t es = hipStreamSynchronize(s);
+        if (es != hipSuccess) { ov2_set_error("hipStreamSynchronize: %s", hipGetErrorString(es)); ba_destroy(dev); return OV2_EHIP; }
+    }
     *out = dev;
     return OV2_OK;
 }

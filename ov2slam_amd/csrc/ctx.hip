@@ -75,7 +75,7 @@ int ov2_ctx::download_image(uint8_t *dst_h, size_t dst_stride, const void *src_d
 
 extern "C" {
 
-int ov2_version(void) { return 100; }
+int ov2_version(void) { return OV2_ABI_VERSION; }
 
 const char *ov2_last_error(void) { return g_err; }
 

@@ -478,8 +478,9 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
     const bool has_prior = (flags[i] & 1) != 0;
     // sad_x != NULL: MapManager::stereoMatching (src/map_manager.cpp:367-611) -- same two-call structure, but (i) a keypoint
     // without a 3-D prior starts from its own position with x replaced by the getLineMinSAD prior of the coarsest level when
-    // that lies left of it (:433-437), (ii) a 3-D prior track that fails is retried from the SAME prior (:533-538), not from
-    // the first call's forward result
+    // that lies left of it (:433-437); (ii) as in kltTracking, a 3-D prior track that fails is retried on the full pyramid
+    // from the first call's FORWARD RESULT: `vpriors.push_back(v3dpriors.at(i))` (:533-538) runs after fbKltTracking has
+    // overwritten v3dpriors in place (calcOpticalFlowPyrLK writes nextPts into it, feature_tracker.cpp:66)
     const bool stereo = sad_x != nullptr;
     if (stereo && !has_prior) {
         pr = kp;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
         ok = fb_track_point<WIN>(P.base, C.base, P, C, prm, max_level, kp, pr, r, fx, fy, st);
         iters += st.iters;
         if (ok || !has_prior || attempt == 1) break;
-        if (!stereo) pr = make_float2(fx, fy);                            // :213-217
+        pr = make_float2(fx, fy);                                         // visual_front_end.cpp:213-217, map_manager.cpp:533-538
         max_level = lvl_full; retried = 1;
     }
     if (r == 0) {

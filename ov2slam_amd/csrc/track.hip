@@ -82,21 +82,44 @@ static void stage_points(ov2_tracker *t, const float *kps, const float *pri, con
     else memset(f, 0, (size_t)n);
 }
 
-// after the synchronisation: copy results out and apply the cross-keypoint rule of visual_front_end.cpp:225-230
-static int finish_klt(ov2_tracker *t, const float *kps, int n, float *out_xy, uint8_t *status, int *p3p_req)
+// after a synchronisation: copy the m results of the staged chunk out
+static void collect_chunk(ov2_tracker *t, int m, float *out_xy, uint8_t *status)
 {
-    const uint8_t *f = t->hblk + t->o_flg, *st = t->hblk + t->o_st;
-    memcpy(out_xy, t->hblk + t->o_out, 8 * (size_t)n);
-    memcpy(status, st, (size_t)n);
+    memcpy(out_xy, t->hblk + t->o_out, 8 * (size_t)m);
+    memcpy(status, t->hblk + t->o_st, (size_t)m);
+}
+
+// A frame may carry more keypoints than the tracker's capacity (the reference only prunes at the next keyframe,
+// src/map_manager.cpp:74, while extractKeypoints tops cells up that several tracked keypoints share): keypoints
+// [off, n) are run n_max at a time through the same fused launch (keypoints are independent inside fbKltTracking).
+static int klt_overflow_chunks(ov2_tracker *t, const float *kps, const float *pri, const uint8_t *has_prior, int off, int n,
+                               int use_prior, float *out_xy, uint8_t *status)
+{
+    for (; off < n; off += t->cfg.n_max) {
+        const int m = n - off < t->cfg.n_max ? n - off : t->cfg.n_max;
+        stage_points(t, kps + 2 * (size_t)off, pri + 2 * (size_t)off, has_prior ? has_prior + off : nullptr, m, use_prior);
+        const int rc = enqueue_klt(t, t->pyr[t->cur ^ 1], t->pyr[t->cur]);
+        if (rc != OV2_OK) return rc;
+        OV2_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
+        collect_chunk(t, m, out_xy + 2 * (size_t)off, status + off);
+    }
+    return OV2_OK;
+}
+
+// the cross-keypoint rule of visual_front_end.cpp:225-230 over all n results
+static int apply_p3p_rule(ov2_tracker *t, const float *kps, const uint8_t *has_prior, int use_prior, int n, float *out_xy,
+                          uint8_t *status, int *p3p_req)
+{
     size_t nbkps = 0, nbgood = 0;
-    for (int i = 0; i < n; i++) if (f[i]) { nbkps++; if ((st[i] & 3) == 1) nbgood++; }
+    if (use_prior && has_prior)
+        for (int i = 0; i < n; i++) if (has_prior[i]) { nbkps++; if ((status[i] & 3) == 1) nbgood++; }
     int p3p = 0;
     if (nbkps > 0 && (double)nbgood < 0.33 * (double)nbkps) {
         // "Motion model might be quite wrong": vpriors = vkps for the second call (:229) -- only the lost prior
         // tracks had a prior different from their keypoint, so only they are re-run, from the keypoints themselves
         p3p = 1;
         std::vector<int> idx;
-        for (int i = 0; i < n; i++) if (st[i] & 2) idx.push_back(i);
+        for (int i = 0; i < n; i++) if (status[i] & 2) idx.push_back(i);
         if (!idx.empty()) {
             const int m = (int)idx.size();
             std::vector<float> k2(2 * (size_t)m), p2(2 * (size_t)m);
@@ -213,7 +236,7 @@ int ov2_tracker_preprocess(ov2_tracker *t, const uint8_t *img_h, int stride)
     stage_image(t, img_h, stride);
     if (t->frames > 0) t->cur ^= 1;                                   // prev_pyr_.swap(cur_pyr_)  (:1169)
     const int rc = enqueue_preprocess(t, t->pyr[t->cur]);
-    if (rc != OV2_OK) return rc;
+    if (rc != OV2_OK) { if (t->frames > 0) t->cur ^= 1; return rc; }  // nothing was swapped as far as the caller is concerned
     t->frames++;
     return ov2_pyr_mark_ready(t->ctx, t->pyr[t->cur]);
 }
@@ -225,14 +248,11 @@ int ov2_tracker_klt(ov2_tracker *t, const float *kps_xy_h, const float *prior_xy
     if (p3p_req) *p3p_req = 0;
     if (n <= 0) return OV2_OK;
     OV2_REQUIRE(kps_xy_h && prior_xy_h && out_xy_h && status_h, OV2_EINVAL, "NULL point buffer");
-    OV2_REQUIRE(n <= t->cfg.n_max, OV2_EINVAL, "more keypoints than the tracker's capacity");
     OV2_REQUIRE(t->frames >= 2, OV2_EINVAL, "kltTracking needs two preprocessed frames");
     OV2_HIP_CHECK(hipSetDevice(t->ctx->device));
-    stage_points(t, kps_xy_h, prior_xy_h, has_prior_h, n, klt_use_prior);
-    const int rc = enqueue_klt(t, t->pyr[t->cur ^ 1], t->pyr[t->cur]);
+    const int rc = klt_overflow_chunks(t, kps_xy_h, prior_xy_h, has_prior_h, 0, n, klt_use_prior, out_xy_h, status_h);
     if (rc != OV2_OK) return rc;
-    OV2_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
-    return finish_klt(t, kps_xy_h, n, out_xy_h, status_h, p3p_req);
+    return apply_p3p_rule(t, kps_xy_h, has_prior_h, klt_use_prior, n, out_xy_h, status_h, p3p_req);
 }
 
 int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, const float *kps_xy_h,
@@ -241,7 +261,7 @@ int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, co
 {
     OV2_REQUIRE(t && img_h, OV2_EINVAL, "NULL argument");
     OV2_REQUIRE(stride >= t->cfg.w, OV2_EINVAL, "stride < width");
-    OV2_REQUIRE(n >= 0 && n <= t->cfg.n_max, OV2_EINVAL, "more keypoints than the tracker's capacity");
+    OV2_REQUIRE(n >= 0, OV2_EINVAL, "negative keypoint count");
     OV2_REQUIRE(n == 0 || (kps_xy_h && prior_xy_h && out_xy_h && status_h), OV2_EINVAL, "NULL point buffer");
     if (p3p_req) *p3p_req = 0;
     if (t->frames == 0 || n == 0) {
@@ -254,7 +274,8 @@ int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, co
     OV2_HIP_CHECK(hipSetDevice(t->ctx->device));
     OV2_HIP_CHECK(hipEventSynchronize(t->pyr[t->cur]->ready));         // an asynchronous preprocess may still read the pinned frame
     stage_image(t, img_h, stride);
-    stage_points(t, kps_xy_h, prior_xy_h, has_prior_h, n, klt_use_prior);
+    const int n0 = n < t->cfg.n_max ? n : t->cfg.n_max;                // the rest: klt_overflow_chunks
+    stage_points(t, kps_xy_h, prior_xy_h, has_prior_h, n0, klt_use_prior);
     t->cur ^= 1;                                                       // prev_pyr_.swap(cur_pyr_)  (:1169)
     int rc = OV2_OK;
     bool launched = false;
@@ -278,7 +299,12 @@ int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, co
     rc = ov2_pyr_mark_ready(t->ctx, t->pyr[t->cur]);
     if (rc != OV2_OK) return rc;
     OV2_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
-    return finish_klt(t, kps_xy_h, n, out_xy_h, status_h, p3p_req);
+    collect_chunk(t, n0, out_xy_h, status_h);
+    if (n > n0) {
+        rc = klt_overflow_chunks(t, kps_xy_h, prior_xy_h, has_prior_h, n0, n, klt_use_prior, out_xy_h, status_h);
+        if (rc != OV2_OK) return rc;
+    }
+    return apply_p3p_rule(t, kps_xy_h, has_prior_h, klt_use_prior, n, out_xy_h, status_h, p3p_req);
 }
 
 } // extern "C"

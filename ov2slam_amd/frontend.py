@@ -267,14 +267,22 @@ class VisualFrontEndTracker:
         kps = np.ascontiguousarray(vkps, dtype=np.float32).reshape(-1, 2)
         pri = np.ascontiguousarray(vpriors, dtype=np.float32).reshape(-1, 2)
         n = len(kps)
-        assert len(pri) == n
-        hp = None if vhasprior is None else np.ascontiguousarray(vhasprior, dtype=np.uint8)
+        if len(pri) != n:
+            raise ValueError("vkps and vpriors differ in length")
+        hp = None if vhasprior is None else np.ascontiguousarray(vhasprior, dtype=np.uint8).reshape(-1)
+        if hp is not None and len(hp) != n:
+            raise ValueError("vhasprior has %d entries for %d keypoints" % (len(hp), n))
         return kps, pri, hp, n
+
+    def _img(self, img_raw):
+        img = img_raw if img_raw is self.image_buffer else np.ascontiguousarray(img_raw, dtype=np.uint8)
+        if img.ndim != 2 or img.shape[0] != self.h or img.shape[1] < self.w:       # the C side reads h rows of w bytes
+            raise ValueError("image shape %s does not match the tracker's %dx%d" % (img.shape, self.w, self.h))
+        return img
 
     def preprocessImage(self, img_raw):
         """Asynchronous (returns after the enqueue)."""
-        img = np.ascontiguousarray(img_raw, dtype=np.uint8)
-        assert img.shape[0] == self.h and img.shape[1] >= self.w
+        img = self._img(img_raw)
         L.check(self.lib.ov2_tracker_preprocess(self.h_trk, _ptr(img), img.strides[0]))
 
     def kltTracking(self, vkps, vpriors, vhasprior, klt_use_prior=True):
@@ -287,7 +295,7 @@ class VisualFrontEndTracker:
 
     def trackFrame(self, img_raw, vkps, vpriors, vhasprior, klt_use_prior=True):
         """preprocessImage + kltTracking in one enqueue (graph replay when enabled)."""
-        img = img_raw if img_raw is self.image_buffer else np.ascontiguousarray(img_raw, dtype=np.uint8)
+        img = self._img(img_raw)
         kps, pri, hp, n = self._pts(vkps, vpriors, vhasprior)
         out = np.zeros((n, 2), np.float32); st = np.zeros(n, np.uint8); p3p = C.c_int(0)
         L.check(self.lib.ov2_tracker_track_frame(self.h_trk, _ptr(img), img.strides[0], _ptr(kps), _ptr(pri), _ptr(hp), n,

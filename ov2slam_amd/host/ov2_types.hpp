@@ -48,6 +48,8 @@ struct Image8 {
 class Context {
 public:
     explicit Context(int device = 0) {
+        // header / library mismatch: option structs may differ in size (include/ov2slam_hip.h, OV2_ABI_VERSION)
+        if (ov2_version() != OV2_ABI_VERSION) throw std::runtime_error("libov2slam_hip.so ABI version differs from ov2slam_hip.h");
         if (ov2_ctx_create(device, &ctx_) != OV2_OK) throw std::runtime_error(std::string("ov2_ctx_create: ") + ov2_last_error());
     }
     ~Context() { ov2_ctx_destroy(ctx_); }

@@ -18,7 +18,9 @@ public:
         c.w = img_w; c.h = img_h; c.win = nklt_win_size; c.nklt_pyr_lvl = nklt_pyr_lvl; c.prior_pyr_lvl = 1;
         c.max_iter = nmax_iter; c.eps = fmax_px_precision; c.err_th = nklt_err; c.fb_dist = fmax_fbklt_dist;
         c.use_clahe = use_clahe ? 1 : 0; c.clahe_clip = fclahe_val; c.tiles_x = img_w / 50; c.tiles_y = img_h / 50;   // ov2slam.cpp:85-89
-        c.n_max = nbmaxkps; c.use_graph = use_graph ? 1 : 0;
+        // headroom: a frame can carry more than nbmaxkps_ keypoints between keyframes (extractKeypoints tops up cells that several
+        // tracked keypoints share, map_manager.cpp:74 prunes at the next keyframe only); beyond 2 x the library chunks (same results)
+        c.n_max = 2 * nbmaxkps; c.use_graph = use_graph ? 1 : 0;
         if (ov2_tracker_create(ctx.get(), &c, &t_) != OV2_OK) throw std::runtime_error(std::string("ov2_tracker_create: ") + ov2_last_error());
     }
     ~FrameTracker() { ov2_tracker_destroy(t_); }              // destroy before the Context it was created on
@@ -34,20 +36,25 @@ public:
     // VisualFrontEnd::kltTracking on the keypoints of pcurframe_: vkps[i] = kp.px_, vpriors[i] = projected map point for
     // keypoints with a usable 3-D prior (vhasprior[i] = 1) and kp.px_ otherwise (:160-182).  On return vpriors[i] is the
     // tracked pixel (what the reference passes to updateKeypoint), vkpstatus[i] whether the observation survives (false ->
-    // removeObsFromCurFrameById, :260), bp3preq mirrors bp3preq_ (:225-230).  Errors degrade to "nothing tracked".
+    // removeObsFromCurFrameById, :260), bp3preq mirrors bp3preq_ (:225-230).  The reference has no error channel, so an error
+    // degrades to "nothing tracked" -- and is kept: lastError() / lastErrorMessage() say why (never silent).
     void kltTracking(const std::vector<Point2f> &vkps, std::vector<Point2f> &vpriors, const std::vector<uint8_t> &vhasprior,
                      bool klt_use_prior, std::vector<bool> &vkpstatus, bool &bp3preq)
     {
         const size_t n = vkps.size();
         vkpstatus.assign(n, false);
         bp3preq = false;
+        last_rc_ = OV2_OK; last_msg_.clear();
         if (n == 0) return;
+        if (vpriors.size() != n || (!vhasprior.empty() && vhasprior.size() != n)) {
+            last_rc_ = OV2_EINVAL; last_msg_ = "kltTracking: vkps / vpriors / vhasprior differ in length"; return;
+        }
         std::vector<Point2f> out(n);
         std::vector<uint8_t> st(n, 0);
         int p3p = 0;
         const int rc = ov2_tracker_klt(t_, &vkps[0].x, &vpriors[0].x, vhasprior.empty() ? nullptr : vhasprior.data(), (int)n,
                                        klt_use_prior ? 1 : 0, &out[0].x, st.data(), &p3p);
-        if (rc != OV2_OK) return;
+        if (rc != OV2_OK) { last_rc_ = rc; last_msg_ = ov2_last_error(); return; }
         vpriors.swap(out);
         for (size_t i = 0; i < n; i++) vkpstatus[i] = (st[i] & 1) != 0;
         bp3preq = p3p != 0;
@@ -61,14 +68,18 @@ public:
         const size_t n = vkps.size();
         vkpstatus.assign(n, false);
         bp3preq = false;
+        last_rc_ = OV2_OK; last_msg_.clear();
         if (img_raw.empty()) return false;
+        if (vpriors.size() != n || (!vhasprior.empty() && vhasprior.size() != n)) {
+            last_rc_ = OV2_EINVAL; last_msg_ = "trackFrame: vkps / vpriors / vhasprior differ in length"; return false;
+        }
         std::vector<Point2f> out(n);
         std::vector<uint8_t> st(n, 0);
         int p3p = 0;
         const int rc = ov2_tracker_track_frame(t_, img_raw.data, img_raw.step, n ? &vkps[0].x : nullptr, n ? &vpriors[0].x : nullptr,
                                                vhasprior.empty() ? nullptr : vhasprior.data(), (int)n, klt_use_prior ? 1 : 0,
                                                n ? &out[0].x : nullptr, n ? st.data() : nullptr, &p3p);
-        if (rc != OV2_OK) return false;
+        if (rc != OV2_OK) { last_rc_ = rc; last_msg_ = ov2_last_error(); return false; }
         if (n) vpriors.swap(out);
         for (size_t i = 0; i < n; i++) vkpstatus[i] = (st[i] & 1) != 0;
         bp3preq = p3p != 0;
@@ -79,8 +90,14 @@ public:
     const ov2_pyr *curPyr() const { return ov2_tracker_cur_pyr(t_); }
     const ov2_pyr *prevPyr() const { return ov2_tracker_prev_pyr(t_); }
 
+    // why the last kltTracking / trackFrame tracked nothing (OV2_OK when it did not fail)
+    int lastError() const { return last_rc_; }
+    const std::string &lastErrorMessage() const { return last_msg_; }
+
 private:
     ov2_tracker *t_ = nullptr;
+    int last_rc_ = OV2_OK;
+    std::string last_msg_;
 };
 
 }  // namespace ov2

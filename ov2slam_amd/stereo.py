@@ -52,7 +52,8 @@ def stereo_matching(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *
         p3 = np.array([priors3d[i] for i in idx3d], np.float32)
         out, st = tracker.fbKltTracking(leftpyr, rightpyr, nklt_win_size, 1, nklt_err, fmax_fbklt_dist, kps_px[idx3d], p3)
         good_idx += list(idx3d[st]); good_r += list(out[st])
-        idx2d = np.concatenate([idx2d, idx3d[~st]]); pri2d = np.concatenate([pri2d, p3[~st]])   # failures retried with their prior
+        # failures are retried from the first call's forward result: v3dpriors was updated in place (:533-538, feature_tracker.cpp:66)
+        idx2d = np.concatenate([idx2d, idx3d[~st]]); pri2d = np.concatenate([pri2d, out[~st]])
     if len(idx2d):                                                         # :544-565
         out, st = tracker.fbKltTracking(leftpyr, rightpyr, nklt_win_size, nklt_pyr_lvl, nklt_err, fmax_fbklt_dist, kps_px[idx2d], pri2d)
         good_idx += list(idx2d[st]); good_r += list(out[st])

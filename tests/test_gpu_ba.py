@@ -199,6 +199,18 @@ def test_config4_full_size_matches_oracle(gpu_ctx, oracle):
     assert g["final_cost"] < 0.5 * g["initial_cost"]
 
 
+def test_config4_stereo_full_size_matches_oracle(gpu_ctx, oracle):
+    """The stereo variant of BASELINE.json configs[3] at its stated size -- 290000 left + 290000 right + 10000 right-anchor
+    residual blocks (590000), the problem bench.py times as `config3_stereo` and `localba_two_pass_stereo` -- robust pass
+    against the oracle (~1 s of CPU): same iterations / termination / N4 outputs, poses within 1e-7."""
+    pb = synth.make_ba_problem(50, 10000, 30, stereo=True, seed=42)
+    assert pb["n_res"] == 590000
+    g = optimizer.solve(gpu_ctx, pb)
+    r = oracle.ba_solve(pb)
+    _cmp(g, r, pb)
+    assert g["final_cost"] < 0.5 * g["initial_cost"]
+
+
 def test_long_budget_stops_enqueuing_after_convergence(gpu_ctx, oracle):
     """fullBA-style budget (100 iterations) on a problem that converges in a few: the chunked enqueue must return the same
     result as the oracle (and as a run whose budget equals the iterations actually needed)."""

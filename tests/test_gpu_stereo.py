@@ -64,8 +64,9 @@ def test_epipolar_check_bit_exact(gpu_ctx, oracle):
 
 
 def test_stereo_matching_flow(gpu_ctx, oracle):
-    """MapManager::stereoMatching data path on a synthetic rectified pair: SAD priors -> two fbKlt passes -> gate,
-    against the same flow driven through the oracle."""
+    """MapManager::stereoMatching data path on a synthetic rectified pair: SAD priors -> two fbKlt passes (3-D-prior failures
+    retried from the first call's forward result, map_manager.cpp:533-538) -> gate, against oracle.stereo_matching, which
+    restates the reference's lists push_back by push_back."""
     w, h, disp = 752, 480, 20
     l, r = _pair(w, h, disp, 11)
     pl = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(l)
@@ -74,36 +75,34 @@ def test_stereo_matching_flow(gpu_ctx, oracle):
     cal = ov2slam_amd.CameraCalibration(gpu_ctx, "pinhole", *K, D=None)
     rng = np.random.default_rng(3)
     kps = synth.grid_keypoints(w, h, 35, rng)[:300]
-    pri3d = {i: (kps[i, 0] - disp + rng.normal(0, 1.0), kps[i, 1]) for i in range(0, 60)}
+    pri3d = {i: (kps[i, 0] - disp + rng.normal(0, 1.0), kps[i, 1]) for i in range(0, 80)}
+    for i in range(0, 80, 3):                                     # a third of the 3-D priors far off: lost on 2 levels, retried on 4
+        pri3d[i] = (pri3d[i][0] + rng.uniform(8, 16), pri3d[i][1] - rng.uniform(5, 10))
     ok, right = stereo.stereo_matching(trk, pl, pr, kps, kps, cal, rect=True, priors3d=pri3d)
-    # oracle-driven flow
     O = oracle
     opl, opr = O.Pyramid(l, 9, 3), O.Pyramid(r, 9, 3)
-    idx3 = np.array(sorted(pri3d)); idx2 = np.array([i for i in range(len(kps)) if i not in pri3d])
-    up = np.float32(8.0); down = np.float32(1) / up
-    xp, _ = O.line_min_sad(opl.level(3)[0], opr.level(3)[0], kps[idx2] * down, 7, True)
-    xp = xp * up
-    pri2 = kps[idx2].copy(); use = (xp >= 0) & (xp <= kps[idx2, 0]); pri2[use, 0] = xp[use]
-    p3 = np.array([pri3d[i] for i in idx3], np.float32)
-    o3, s3 = O.fb_klt(opl, opr, 9, 1, 30.0, 0.5, kps[idx3], p3, 30, 0.01)[:2]
-    s3 = s3.astype(bool)
-    idx2 = np.concatenate([idx2, idx3[~s3]]); pri2 = np.concatenate([pri2, p3[~s3]])
-    o2, s2 = O.fb_klt(opl, opr, 9, 3, 30.0, 0.5, kps[idx2], pri2, 30, 0.01)[:2]
-    s2 = s2.astype(bool)
-    gi = np.concatenate([idx3[s3], idx2[s2]]); gr = np.concatenate([o3[s3], o2[s2]])
-    rk, _, _, eok = O.stereo_epipolar_check(True, np.zeros(9), O.CAM_PINHOLE, K, None, kps[gi], gr)
-    rok = np.zeros(len(kps), bool); rright = np.zeros((len(kps), 2), np.float32)
-    rok[gi] = eok; rright[gi] = rk
-    assert np.array_equal(ok, rok) and np.array_equal(right, rright)
+    rok, rright = O.stereo_matching(opl, opr, kps, kps, O.CAM_PINHOLE, K, None, True, priors3d=pri3d)
+    assert np.array_equal(ok, rok) and np.array_equal(right.view(np.uint32), rright.view(np.uint32))
+    # the retry really happened and really started from the forward result: with the ORIGINAL prior the outcome differs
+    p3 = np.array([pri3d[i] for i in sorted(pri3d)], np.float32)
+    o3, s3 = O.fb_klt(opl, opr, 9, 1, 30.0, 0.5, kps[:80], p3, 30, 0.01)[:2]
+    lost = ~s3.astype(bool)
+    assert lost.sum() >= 10
+    o_fw = O.fb_klt(opl, opr, 9, 3, 30.0, 0.5, kps[:80][lost], o3[lost], 30, 0.01)[0]
+    o_same = O.fb_klt(opl, opr, 9, 3, 30.0, 0.5, kps[:80][lost], p3[lost], 30, 0.01)[0]
+    assert not np.array_equal(o_fw.view(np.uint32), o_same.view(np.uint32))
     assert ok.mean() > 0.9
     assert np.abs((kps[ok, 0] - right[ok, 0]) - disp).max() < 0.5
+    # and the one-enqueue form agrees with the oracle directly (not only with the call sequence)
+    ok_f, right_f = stereo.stereo_matching_fused(trk, pl, pr, kps, kps, cal, rect=True, priors3d=pri3d)
+    assert np.array_equal(ok_f, rok) and np.array_equal(right_f.view(np.uint32), rright.view(np.uint32))
 
 
 @pytest.mark.parametrize("rect", [True, False])
 def test_fused_stereo_match_equals_the_call_sequence(gpu_ctx, oracle, rect):
     """ov2_stereo_match (SAD priors + both fbKltTracking calls + retry + gate in one enqueue, one sync) returns what the
     sequence of separate calls returns -- which test_stereo_matching_flow pins to the oracle -- including the retry of failed
-    3-D-prior tracks from the SAME prior and, for a non-rectified pair, the Sampson gate."""
+    3-D-prior tracks from the first call's forward result and, for a non-rectified pair, the Sampson gate."""
     w, h, disp = 752, 480, 20
     l, r = _pair(w, h, disp, 23)
     pl = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(l)

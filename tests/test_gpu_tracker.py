@@ -148,3 +148,34 @@ def test_cross_context_pyramid_handoff(oracle):
         assert np.array_equal(gst, rst) and np.array_equal(_bits(gout), _bits(rout))
         a.sync(); Gp.close(); Gc.close()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_more_keypoints_than_capacity(gpu_ctx, oracle, use_graph):
+    """A frame may carry more keypoints than nbmaxkps_ (pruning happens at the next keyframe only,
+    /root/reference/src/map_manager.cpp:74): the tracker must track them all, not report "nothing tracked".  Capacity 100,
+    273 keypoints -> three launches; identical to the oracle, cross-keypoint p3p rule evaluated over ALL keypoints."""
+    w, h = 752, 480
+    views, flow = _sequence(w, h, 3, seed=13)
+    rng = np.random.default_rng(4)
+    trk = ov2slam_amd.VisualFrontEndTracker(gpu_ctx, w, h, use_clahe=True, fclahe_val=CLIP, nbmaxkps=100, use_graph=use_graph)
+    trk.trackFrame(views[0], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+    kps, pri, hp = _points(w, h, flow, 0, rng, 1.0, bad_frac=0.25)
+    assert len(kps) > 2 * 100
+    gout, gst, gp3p = trk.trackFrame(views[1], kps, pri, hp)
+    rout, rok, rretried, rp3p = _oracle_frame(oracle, views[0], views[1], kps, pri, hp, True, w, h)
+    assert gp3p == rp3p and np.array_equal((gst & 1).astype(bool), rok) and np.array_equal((gst & 2).astype(bool), rretried)
+    assert np.array_equal(_bits(gout), _bits(rout))
+    # split API, and the p3p rule with its counts spread over several chunks
+    kps, pri, hp = _points(w, h, flow, 1, rng, 1.0, frac_prior=0.8, bad_frac=0.85, bad_sigma=40.0)
+    trk.preprocessImage(views[2])
+    gout, gst, gp3p = trk.kltTracking(kps, pri, hp)
+    rout, rok, rretried, rp3p = _oracle_frame(oracle, views[1], views[2], kps, pri, hp, True, w, h)
+    assert rp3p and gp3p
+    assert np.array_equal((gst & 1).astype(bool), rok) and np.array_equal((gst & 2).astype(bool), rretried)
+    assert np.array_equal(_bits(gout), _bits(rout))
+    with pytest.raises(ValueError):
+        trk.trackFrame(views[2][:100], kps, pri, hp)                 # wrong image height is refused on the Python side
+    with pytest.raises(ValueError):
+        trk.kltTracking(kps, pri, hp[:10])
+    trk.close()

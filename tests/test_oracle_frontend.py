@@ -177,3 +177,36 @@ def test_pool_and_rebuild_do_not_change_results(oracle):
     for l in range(fresh.levels):
         fi, fd = fresh.level(l, padded=True)
         assert np.array_equal(fi, a[1][l][0]) and np.array_equal(fd, a[1][l][1])
+
+
+def test_float_accumulator_variants_stay_within_a_hundredth_of_a_pixel(oracle):
+    """The HIP kernels are bit-exact against the oracle's int64-accumulator LK; stock OpenCV builds accumulate in float, in a
+    build-dependent order (scalar / 3.4 SSE2 intrinsics / 4.x universal intrinsics, restated in oracle/frontend.c).  This bounds
+    the distance on the config-2 input (CLAHE'd EuRoC-sized frames) and on a worst case of hard-edged binary blocks: no status
+    flip, sub-0.02-px positions -- and the variants are really different code paths (they do differ in the last bits)."""
+    from ov2slam_amd import synth
+    O = oracle
+    w, h = 752, 480
+    prev, cur, flow = synth.frame_pair(w, h, seed=3, shift=(3.8, -1.7), theta=0.004)
+    prev, cur = O.clahe(prev, 3.0, w // 50, h // 50), O.clahe(cur, 3.0, w // 50, h // 50)
+    rng = np.random.default_rng(3)
+    kps = synth.grid_keypoints(w, h, 35, rng)
+    pri = (flow(kps) + rng.normal(0, 1.5, kps.shape)).astype(np.float32)
+    rep = O.lk_acc_mode_report(O.Pyramid(prev, 9, 3), O.Pyramid(cur, 9, 3), kps, pri)
+    assert rep["tracked_int64"] > 0.9 * rep["points"]
+    for name, m in rep["modes"].items():
+        assert m["status_flips"] == 0, name
+        assert m["max_abs_dpx"] < 2e-3, name
+        assert m["bit_identical_positions"] > 0.8 * rep["tracked_int64"], name
+    # worst case: binary 7x7 blocks (Scharr responses up to +-4080, sums far beyond 2^24)
+    big = np.kron((np.random.default_rng(9).integers(0, 2, (120, 140)) * 255).astype(np.uint8), np.ones((7, 7), np.uint8))
+    prev, cur = big[100:100 + h, 100:100 + w].copy(), big[98:98 + h, 96:96 + w].copy()
+    pri = (kps + np.array([4, 2], np.float32) + rng.normal(0, 1.0, kps.shape)).astype(np.float32)
+    rep = O.lk_acc_mode_report(O.Pyramid(prev, 9, 3), O.Pyramid(cur, 9, 3), kps, pri)
+    assert rep["tracked_int64"] > 0.5 * rep["points"]
+    differing = 0
+    for name, m in rep["modes"].items():
+        assert m["status_flips"] <= 2 and m["max_abs_dpx"] < 0.02, (name, m)
+        differing += rep["tracked_int64"] - m["bit_identical_positions"]
+    assert differing > 0
+    assert O.lib().orc_get_lk_acc_mode() == O.LK_ACC_INT64          # the context manager restored the canonical mode
