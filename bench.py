@@ -348,18 +348,31 @@ def ba_section(ctx):
     pbw = synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7)
     out["window_25kf_3k_stereo"], _ = resident("window", pbw, "realistic local-BA window: 25 KF x 3000 landmarks x 12 obs, stereo "
                                                "(optimizer.cpp:150-188)", reps=5)
-    # the whole localBA protocol of optimizer.cpp:436-627 (robust pass, outlier removal, L2 pass), host buffers in / out
+    # the whole localBA protocol of optimizer.cpp:436-735 (robust pass, outlier removal, L2 pass, second test), host buffers in /
+    # out: ONE ov2_local_ba call (problem resident between the passes, outlier handling on the device; the per-block chi2 arrays,
+    # which the reference's write-back does not use, are not downloaded) -- and the two-call form it replaces, for comparison
     opt = optimizer.Optimizer(ctx)
-    opt.localBA(pbs)
-    t0 = time.perf_counter()
-    r = opt.localBA(pbs)
-    wall = time.perf_counter() - t0
-    it1 = r["pass1"]["iterations"]; it2 = r["pass2"]["iterations"] if r["l2_done"] else 0
-    ms = r["pass1"]["solve_ms"] + (r["pass2"]["solve_ms"] if r["l2_done"] else 0.0)
-    out["localba_two_pass_stereo"] = {"wall_ms_incl_h2d_d2h": wall * 1e3, "device_ms": ms, "iterations_robust": it1, "iterations_l2": it2,
-                                      "iters_per_s_device": (it1 + it2) / (ms * 1e-3), "outliers_removed": int(r["bad_obs"].sum()),
-                                      "workload": "Optimizer.localBA on the stereo config[3] problem: robust pass (<=5 it) + outlier "
-                                                  "removal + L2 pass (<=10 it), two ov2_ba_solve calls"}
+
+    def wall_of(fn, reps=3):
+        fn()
+        best, res = 1e9, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = fn()
+            best = min(best, time.perf_counter() - t0)
+        return best, res
+    for key, pbx, what in (("localba_two_pass_stereo", pbs, "the stereo config[3] problem (590000 residual blocks)"),
+                           ("localba_two_pass_window", pbw, "the 25 KF x 3000 landmark x 12 obs stereo window")):
+        wall, r = wall_of(lambda: opt.localBA(pbx, want_chi2=False))
+        wall2, r2 = wall_of(lambda: opt.localBA_two_calls(pbx), reps=2)
+        it1, it2 = r["iterations"]
+        ms = r["solve_ms"][0] + r["solve_ms"][1]
+        out[key] = {"wall_ms_incl_h2d_d2h": wall * 1e3, "device_ms": ms, "iterations_robust": it1, "iterations_l2": it2,
+                    "iters_per_s_device": (it1 + it2) / (ms * 1e-3), "iters_per_s_wall": (it1 + it2) / wall,
+                    "outliers_removed": int(r["bad_obs"].sum()),
+                    "two_ov2_ba_solve_calls_wall_ms": wall2 * 1e3, "same_outlier_set_as_two_calls": bool(np.array_equal(r["bad_obs"], r2["bad_obs"])),
+                    "workload": "Optimizer.localBA on " + what + ": robust pass (<=5 it) + outlier removal + L2 pass (<=10 it) + second "
+                                "test in ONE ov2_local_ba call, host arrays in, poses / inverse depths / outlier flags out"}
     return out, pb, gpu_poses
 
 

@@ -358,6 +358,38 @@ int  ov2_ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out);
 int  ov2_ba_solve_resident(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba_result *r);
 void ov2_ba_destroy(ov2_ba_dev *dev);
 
+/* Optimizer::localBA's whole solve stage (src/optimizer.cpp:436-735) in ONE call with the problem resident in HBM between the
+ * two ceres::Solve calls: one sort + upload of the residual blocks, pass 1 (Huber unless !use_robust_cost), the outlier test
+ * on the values cached by the last Evaluate (chi2err_ > robust_mono_th or depth <= 0, :492-594) and the removal
+ * of the outlier blocks ON THE DEVICE, pass 2 (only if apply_l2_after_robust && use_robust_cost && !stop_requested && outliers
+ * were found, :603-604; loss reset to L2 only when a left AND a right-camera block remain, :606-608 -- mono runs keep Huber),
+ * the second outlier test on the blocks still in the problem (:637-735), one download.  Two ov2_ba_solve calls return the same
+ * (tests/test_gpu_ba.py) but sort, upload and download the residual blocks twice: 11.5 -> see bench `localba_two_pass_stereo`.
+ * pass1 / pass2 carry the iteration caps and tolerances (their huber_delta is ignored: the protocol sets it).  Inverse-depth
+ * problems without OV2_RES_PNP blocks; same size limits as ov2_ba_solve.                                                */
+typedef struct {
+    double robust_mono_th;       /* 5.9915 (slam_params.hpp robust_mono_th_)                              */
+    int use_robust_cost;         /* localBA's buse_robust_cost argument                                   */
+    int apply_l2_after_robust;   /* apply_l2_after_robust_                                                */
+    int stop_requested;          /* stopLocalBA(), polled once before pass 2 (:604)                       */
+    ov2_ba_options pass1, pass2; /* max_iter 5 / 10, function_tolerance 1e-3 (:461-462, :611)             */
+} ov2_local_ba_options;
+typedef struct {
+    double *poses_out;           /* 7*n_kf                                                                */
+    double *invdepth_out;        /* n_lm                                                                  */
+    uint8_t *bad_obs;            /* n_res: 1 = outlier after the whole protocol (remove the observation)  */
+    uint8_t *bad_after_pass1;    /* n_res or NULL: verdicts of the first test only                        */
+    double *chi2_last_eval;      /* n_res or NULL (not downloaded)                                        */
+    uint8_t *depthpos_last_eval; /* n_res or NULL                                                         */
+    int l2_done;                 /* pass 2 ran                                                            */
+    int n_bad_pass1, n_bad_total;
+    int iterations[2], num_successful_steps[2], termination[2];
+    double initial_cost[2], final_cost[2];
+    double solve_ms[2];          /* device time of each pass                                              */
+} ov2_local_ba_result;
+void ov2_local_ba_default_options(ov2_local_ba_options *o);
+int  ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r);
+
 /* ------------------------------------------------------------------ */
 /* Optimizer::structureOnlyBA                                           */
 /* ------------------------------------------------------------------ */

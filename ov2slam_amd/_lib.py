@@ -59,6 +59,23 @@ class BAResult(C.Structure):
     ]
 
 
+class LocalBAOptions(C.Structure):
+    _fields_ = [
+        ("robust_mono_th", C.c_double), ("use_robust_cost", C.c_int), ("apply_l2_after_robust", C.c_int),
+        ("stop_requested", C.c_int), ("pass1", BAOptions), ("pass2", BAOptions),
+    ]
+
+
+class LocalBAResult(C.Structure):
+    _fields_ = [
+        ("poses_out", C.POINTER(C.c_double)), ("invdepth_out", C.POINTER(C.c_double)), ("bad_obs", C.POINTER(C.c_uint8)),
+        ("bad_after_pass1", C.POINTER(C.c_uint8)), ("chi2_last_eval", C.POINTER(C.c_double)),
+        ("depthpos_last_eval", C.POINTER(C.c_uint8)), ("l2_done", C.c_int), ("n_bad_pass1", C.c_int), ("n_bad_total", C.c_int),
+        ("iterations", C.c_int * 2), ("num_successful_steps", C.c_int * 2), ("termination", C.c_int * 2), ("initial_cost", C.c_double * 2),
+        ("final_cost", C.c_double * 2), ("solve_ms", C.c_double * 2),
+    ]
+
+
 class SBAProblem(C.Structure):
     _fields_ = [
         ("n_kf", C.c_int), ("poses", C.POINTER(C.c_double)), ("n_pts", C.c_int), ("xyz", C.POINTER(C.c_double)),
@@ -164,6 +181,8 @@ SIGNATURES = {
     "ov2_ba_create": (_i, [_vp, C.POINTER(BAProblem), _pp]),
     "ov2_ba_solve_resident": (_i, [_vp, _vp, C.POINTER(BAOptions), C.POINTER(BAResult)]),
     "ov2_ba_destroy": (None, [_vp]),
+    "ov2_local_ba_default_options": (None, [C.POINTER(LocalBAOptions)]),
+    "ov2_local_ba": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(LocalBAOptions), C.POINTER(LocalBAResult)]),
 }
 
 OV2_ABI_VERSION = 300          # include/ov2slam_hip.h

@@ -115,8 +115,19 @@ struct BADev {                    // device pointers + sizes (passed by value to
     double *yl;                   // n_lm
     double *chi2;                 // n_res (caller order)
     uint8_t *dpos;                // n_res
+    // resident two-pass localBA (ov2_local_ba): residual blocks are deactivated ON THE DEVICE between the passes
+    uint8_t *res_off;             // n_act (landmark-sorted order): 1 = removed from the problem (optimizer.cpp:500-592)   [ldim 1]
+    uint8_t *lm_live;             // n_lm : the landmark still has a residual block (a block-less landmark is not part of
+                                  //        the program, program.cc RemoveFixedBlocks); NULL = derive it from lm_ptr
+    uint8_t *bad_obs;             // n_res (caller order): outlier verdicts of k_ba_mark_outliers
+    int *lba_cnt;                 // 8 counters of k_ba_mark_outliers
     BACtl *ctl;
 };
+
+__device__ __forceinline__ bool d_lm_has(const BADev &D, int lm)
+{
+    return D.lm_live ? D.lm_live[lm] != 0 : D.lm_ptr[lm] != D.lm_ptr[lm + 1];
+}
 
 struct BAOpt {
     int max_iter;
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     // dependent global round trips order -> header -> residual records -> poses): the header of landmark idx+2 and the
     // residual records of the first 64 blocks of landmark idx+1 are requested before landmark idx is processed.
     struct LmHdr { int lm, beg, end, a, ca; double lam, au, av; };
-    struct ResRec { int type, kf, orig; double u, v, sigma; };
+    struct ResRec { int type, kf, orig, off; double u, v, sigma; };
     auto load_hdr = [&](int idx) {
         LmHdr h;
         h.lm = lm_order[min(idx, i1 - 1)];
@@ -554,7 +565,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     auto load_rec = [&](const LmHdr &h) {
         ResRec r;
         const int k = max(0, min(h.beg + lane, h.end - 1));       // (a landmark without residual blocks: nothing is consumed)
-        r.type = D.res_type[k]; r.kf = D.res_kf[k]; r.orig = D.res_orig[k];
+        r.type = D.res_type[k]; r.kf = D.res_kf[k]; r.orig = D.res_orig[k]; r.off = D.res_off ? D.res_off[k] : 0;
         r.u = D.res_uv[2 * k]; r.v = D.res_uv[2 * k + 1]; r.sigma = D.res_sigma[k];
         return r;
     };
@@ -577,8 +588,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         for (int k = 0; k < 21; k++) Haa[k] = 0;
         for (int base = beg; base < end; base += 64) {
             const int k = base + lane;
-            if (k < end) {
-                const bool first = base == beg;                               // (wave-uniform) records of the first batch were prefetched
+            const bool first = base == beg;                                   // (wave-uniform) records of the first batch were prefetched
+            if (k < end && !(first ? r_cur.off : (D.res_off ? (int)D.res_off[k] : 0))) {   // removed blocks keep their cached chi2 (N4)
                 const int type = first ? r_cur.type : D.res_type[k];
                 const int o = type == OV2_RES_RIGHT_ANCH ? a : (first ? r_cur.kf : D.res_kf[k]);
                 const int co = type == OV2_RES_RIGHT_ANCH ? -1 : D.pose_col[o];
@@ -760,6 +771,7 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
         const double lam = D.c_lam[lm];
         const double auv[2] = {D.lm_auv[2 * lm], D.lm_auv[2 * lm + 1]};
         for (int k = beg + lane; k < end; k += 64) {
+            if (D.res_off && D.res_off[k]) continue;
             const int type = D.res_type[k];
             const int o = type == OV2_RES_RIGHT_ANCH ? a : D.res_kf[k];
             const double uv[2] = {D.res_uv[2 * k], D.res_uv[2 * k + 1]};
@@ -818,7 +830,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         if (D.ldim == 1) {
 #pragma unroll 4
             for (int l = tid; l < D.n_lm; l += nt)
-                if (D.lm_ptr[l] != D.lm_ptr[l + 1]) gm = fmax(gm, fabs(D.etb[l]));
+                if (d_lm_has(D, l)) gm = fmax(gm, fabs(D.etb[l]));
         } else {
             for (int l = tid; l < 3 * D.n_lm; l += nt)
                 if (D.lm_ptr[l / 3] != D.lm_ptr[l / 3 + 1]) gm = fmax(gm, fabs(D.etb[l]));      // Plus(x, -g) - x = -g for a Euclidean block
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         double *__restrict__ diag_l = D.diag_l, *__restrict__ cl = D.cl, *__restrict__ ce = D.ce;
 #pragma unroll 4
         for (int l = tid; l < D.n_lm; l += nt) {
-            const bool has = lm_ptr[l] != lm_ptr[l + 1];
+            const bool has = D.lm_live ? D.lm_live[l] != 0 : lm_ptr[l] != lm_ptr[l + 1];
             const double s = scale_l[l], e = ete[l], b = etb[l];
             const double dg = reuse ? diag_l[l] : fmin(fmax(s * s * e, O.min_diag), O.max_diag);
             const double etep = s * s * e + dg / radius;                  // scaled E^T E + D_e^2
@@ -1712,7 +1724,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
     const int lane = threadIdx.x & 63;
     double a1 = 0, a2 = 0, a3 = 0;
     for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
-        if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) { if (lane == 0) D.yl[lm] = 0; continue; }
+        if (!d_lm_has(D, lm)) { if (lane == 0) D.yl[lm] = 0; continue; }
         double t = 0;
         if (D.big) {
             // sparse W: the landmark's slots
@@ -1817,7 +1829,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
 #pragma unroll 4
     for (int l = tid; l < D.n_lm * D.ldim; l += nt) {
         const int lm = D.ldim == 1 ? l : l / 3;
-        if (D.lm_ptr[lm] == D.lm_ptr[lm + 1]) continue;
+        if (!d_lm_has(D, lm)) continue;
         const double d = D.x_lam[l] - D.c_lam[l];
         sn += d * d; xn += D.c_lam[l] * D.c_lam[l];
     }
@@ -2091,6 +2103,54 @@ __global__ __launch_bounds__(256) void k_ba_init(BADev D)
 }
 
 // ---------------------------------------------------------------------------------- host
+// ---------------------------------------------------------------------------------- resident two-pass localBA
+// Optimizer::localBA between its two ceres::Solve calls (src/optimizer.cpp:492-594) and after the second (:637-735), on the
+// device: a residual block still in the problem is an outlier when its cached chi2err_ (the value of the LAST Evaluate, N4)
+// exceeds the threshold or its depth was not positive; with `deactivate` it is removed from the problem.
+// cnt[0] = outliers found by this call, cnt[1] / cnt[2] = a left / right-camera block remains in the problem (:606-608).
+__global__ __launch_bounds__(256) void k_ba_mark_outliers(BADev D, double th, int deactivate, uint8_t *__restrict__ snapshot)
+{
+    int nbad = 0, left = 0, right = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.n_act; k += gridDim.x * blockDim.x) {
+        if (D.res_off[k]) continue;
+        const int orig = D.res_orig[k];
+        const bool bad = D.chi2[orig] > th || D.dpos[orig] == 0;
+        if (bad) {
+            D.bad_obs[orig] = 1;
+            if (snapshot) snapshot[orig] = 1;
+            if (deactivate) D.res_off[k] = 1;
+            nbad++;
+        } else {
+            const int type = D.res_type[k];
+            left |= type == OV2_RES_LEFT; right |= type == OV2_RES_RIGHT;
+        }
+    }
+    __shared__ int s_cnt[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (nbad) atomicAdd(&s_cnt[0], nbad);
+    if (left) atomicOr(&s_cnt[1], 1);
+    if (right) atomicOr(&s_cnt[2], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_cnt[0]) atomicAdd(&D.lba_cnt[0], s_cnt[0]);
+        if (s_cnt[1]) atomicOr(&D.lba_cnt[1], 1);
+        if (s_cnt[2]) atomicOr(&D.lba_cnt[2], 1);
+    }
+}
+
+// a landmark whose residual blocks were all removed leaves the program (its inverse depth keeps its value)
+__global__ __launch_bounds__(256) void k_ba_lm_live(BADev D)
+{
+    const int lane = threadIdx.x & 63;
+    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
+        int live = 0;
+        for (int k = D.lm_ptr[lm] + lane; k < D.lm_ptr[lm + 1]; k += 64) live |= !D.res_off[k];
+        live = __builtin_amdgcn_ballot_w64(live != 0) != 0;
+        if (lane == 0) D.lm_live[lm] = (uint8_t)live;
+    }
+}
+
 struct ov2_ba_dev {
     BADev D;
     void *pool = nullptr; size_t pool_bytes = 0;
@@ -2242,6 +2302,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
+    const size_t o_res_off = take(na), o_lm_live = take(nl), o_bad_obs = take(nr), o_lba_cnt = take(64);
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
@@ -2266,6 +2327,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
     dev->lm_order = (int *)(b + o_lm_order);
+    D.res_off = b + o_res_off; D.lm_live = b + o_lm_live; D.bad_obs = b + o_bad_obs; D.lba_cnt = (int *)(b + o_lba_cnt);
     D.po_kf = (int *)(b + o_po_kf); D.po_orig = (int *)(b + o_po_orig); D.po_xyz = (double *)(b + o_po_xyz); D.po_uv = (double *)(b + o_po_uv); D.po_sigma = (double *)(b + o_po_sigma);
     for (int i = 0; i < 4; i++) { D.calib_l[i] = p->calib_l[i]; D.calib_r[i] = p->calib_r[i]; }
     {   // Trl: normalised quaternion -> R (host)
@@ -2285,6 +2347,15 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     for (int l = 0; l < p->n_lm; l++) lm_order[l] = l;
     std::stable_sort(lm_order.begin(), lm_order.end(), [&](int x, int y) { return p->lm_anchor_kf[x] < p->lm_anchor_kf[y]; });
     UP(dev->lm_order, lm_order.data(), 4 * (size_t)p->n_lm);
+    std::vector<uint8_t> lm_live(std::max(1, p->n_lm));
+    for (int l = 0; l < p->n_lm; l++) lm_live[l] = cnt[l] != cnt[l + 1];
+    UP(D.lm_live, lm_live.data(), (size_t)p->n_lm);
+    {
+        hipError_t em = hipMemsetAsync(D.res_off, 0, na, s);
+        if (em == hipSuccess) em = hipMemsetAsync(D.bad_obs, 0, nr, s);
+        if (em == hipSuccess) em = hipMemsetAsync(D.lba_cnt, 0, 64, s);
+        if (em != hipSuccess) { ov2_set_error("hipMemsetAsync: %s", hipGetErrorString(em)); ba_destroy(dev); return OV2_EHIP; }
+    }
     UP(D.pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
     UP(D.lm_ptr, cnt.data(), 4 * ((size_t)p->n_lm + 1));
     UP(D.lm_anchor, p->lm_anchor_kf, 4 * (size_t)p->n_lm);
@@ -2427,8 +2498,10 @@ static void ba_destroy(ov2_ba_dev *dev)
     delete dev;
 }
 
+// keep_state: continue from the parameters and the cached chi2 / depth flags that are on the device (second pass of
+// ov2_local_ba) instead of resetting to the problem's initial values
 static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba_result *r,
-                  const double *chi2_init, const uint8_t *dpos_init)
+                  const double *chi2_init, const uint8_t *dpos_init, bool keep_state = false)
 {
     OV2_REQUIRE(o && r, OV2_EINVAL, "NULL options/result");
     OV2_REQUIRE(o->max_iter >= 0 && o->initial_radius > 0 && o->min_lm_diagonal > 0 && o->min_lm_diagonal <= o->max_lm_diagonal,
@@ -2487,13 +2560,15 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     OV2_HIP_CHECK(hipEventCreateWithFlags(&ev.chunk[1], hipEventDisableTiming));
     hipEvent_t e0 = ev.e0, e1 = ev.e1;
     // state reset: x = initial parameters, everything else zero, scales one
-    OV2_HIP_CHECK(hipMemcpyAsync(D.x_pose, dev->h_poses0.data(), 56 * (size_t)D.n_kf, hipMemcpyHostToDevice, s));
     const size_t NL = (size_t)D.n_lm * D.ldim;               // per-landmark state entries (1 inverse depth or 3 coordinates each)
+    if (!keep_state) {
+    OV2_HIP_CHECK(hipMemcpyAsync(D.x_pose, dev->h_poses0.data(), 56 * (size_t)D.n_kf, hipMemcpyHostToDevice, s));
     if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.x_lam, dev->h_lam0.data(), 8 * NL, hipMemcpyHostToDevice, s));
     if (chi2_init) OV2_HIP_CHECK(hipMemcpyAsync(D.chi2, chi2_init, 8 * (size_t)dev->n_res, hipMemcpyHostToDevice, s));
     else OV2_HIP_CHECK(hipMemsetAsync(D.chi2, 0xFF, 8 * (size_t)std::max(1, dev->n_res), s));     // NaN pattern
     if (dpos_init) OV2_HIP_CHECK(hipMemcpyAsync(D.dpos, dpos_init, (size_t)dev->n_res, hipMemcpyHostToDevice, s));
     else OV2_HIP_CHECK(hipMemsetAsync(D.dpos, 0, (size_t)std::max(1, dev->n_res), s));
+    }
     OV2_HIP_CHECK(hipEventRecord(e0, s));
     BACtl h_ctl;
     memset(&h_ctl, 0, sizeof(h_ctl));
@@ -2681,6 +2756,78 @@ int ov2_ba_solve_resident(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o
 }
 
 void ov2_ba_destroy(ov2_ba_dev *dev) { ba_destroy(dev); }
+
+void ov2_local_ba_default_options(ov2_local_ba_options *o)
+{
+    if (!o) return;
+    o->robust_mono_th = 5.9915; o->use_robust_cost = 1; o->apply_l2_after_robust = 1; o->stop_requested = 0;
+    ov2_ba_default_options(&o->pass1);                       // 5 iterations, function_tolerance 1e-3 (optimizer.cpp:461-462)
+    ov2_ba_default_options(&o->pass2);
+    o->pass2.max_iter = 10;                                  // :611
+}
+
+// Optimizer::localBA's solve stage (src/optimizer.cpp:436-735) with the problem RESIDENT between the two passes: one
+// counting sort + one upload, the outlier tests and the removal of residual blocks on the device, one download.
+int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r)
+{
+    OV2_REQUIRE(ctx && p && o && r, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(o->robust_mono_th > 0, OV2_EINVAL, "robust_mono_th must be positive");
+    r->l2_done = 0; r->n_bad_pass1 = 0; r->n_bad_total = 0;
+    for (int i = 0; i < 2; i++) { r->iterations[i] = 0; r->num_successful_steps[i] = 0; r->termination[i] = OV2_TERM_NO_CONVERGENCE; r->initial_cost[i] = r->final_cost[i] = 0; r->solve_ms[i] = 0; }
+    ov2_ba_dev *dev = nullptr;
+    int rc = ba_create(ctx, p, &dev, /*transient*/ false);
+    if (rc != OV2_OK) return rc;
+    struct Guard { ov2_ba_dev *d; ~Guard() { ba_destroy(d); } } guard{dev};
+    if (dev->D.n_po > 0) { ov2_set_error("ov2_local_ba: problems with OV2_RES_PNP blocks go through ov2_ba_solve"); return OV2_EUNSUPPORTED; }
+    BADev &D = dev->D;
+    hipStream_t s = ctx->stream;
+    const double huber = o->use_robust_cost ? sqrt(o->robust_mono_th) : -1.0;
+    // pass 1 (:436-485)
+    ov2_ba_options o1 = o->pass1;
+    o1.huber_delta = huber;
+    ov2_ba_result br;
+    memset(&br, 0, sizeof(br));
+    rc = ba_run(ctx, dev, &o1, &br, nullptr, nullptr);
+    if (rc != OV2_OK) return rc;
+    r->iterations[0] = br.iterations; r->num_successful_steps[0] = br.num_successful_steps; r->termination[0] = br.termination; r->initial_cost[0] = br.initial_cost;
+    r->final_cost[0] = br.final_cost; r->solve_ms[0] = br.solve_ms;
+    // outlier test on the values cached by the last Evaluate of pass 1 (:492-594)
+    rc = ctx->reserve_host(64);
+    if (rc != OV2_OK) return rc;
+    int *cnt_h = (int *)ctx->h_scratch;
+    const int mk_blocks = std::max(1, std::min(1024, (D.n_act + 255) / 256));
+    hipLaunchKernelGGL(k_ba_mark_outliers, dim3(mk_blocks), dim3(256), 0, s, D, o->robust_mono_th, o->apply_l2_after_robust ? 1 : 0, (uint8_t *)nullptr);
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipMemcpyAsync(cnt_h, D.lba_cnt, 16, hipMemcpyDeviceToHost, s));
+    if (r->bad_after_pass1 && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->bad_after_pass1, D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    const int nbbad = cnt_h[0], left_remaining = cnt_h[1], right_remaining = cnt_h[2];
+    r->n_bad_pass1 = nbbad; r->n_bad_total = nbbad;
+    if (o->apply_l2_after_robust && o->use_robust_cost && !o->stop_requested && nbbad > 0) {          // :603-604
+        // the loss is reset to L2 only when both residual lists are still non-empty (:606-608: mono runs keep Huber!)
+        ov2_ba_options o2 = o->pass2;
+        o2.huber_delta = (left_remaining && right_remaining) ? -1.0 : huber;
+        hipLaunchKernelGGL(k_ba_lm_live, dim3(std::max(1, std::min(512, (D.n_lm + 3) / 4))), dim3(256), 0, s, D);
+        OV2_HIP_CHECK(hipMemsetAsync(D.lba_cnt, 0, 16, s));
+        rc = ba_run(ctx, dev, &o2, &br, nullptr, nullptr, /*keep_state*/ true);
+        if (rc != OV2_OK) return rc;
+        r->l2_done = 1;
+        r->iterations[1] = br.iterations; r->num_successful_steps[1] = br.num_successful_steps; r->termination[1] = br.termination; r->initial_cost[1] = br.initial_cost;
+        r->final_cost[1] = br.final_cost; r->solve_ms[1] = br.solve_ms;
+        // second outlier test on the residual blocks that are still in the problem (:637-735)
+        hipLaunchKernelGGL(k_ba_mark_outliers, dim3(mk_blocks), dim3(256), 0, s, D, o->robust_mono_th, 0, (uint8_t *)nullptr);
+        OV2_HIP_CHECK(hipGetLastError());
+        OV2_HIP_CHECK(hipMemcpyAsync(cnt_h, D.lba_cnt, 16, hipMemcpyDeviceToHost, s));
+    }
+    if (r->poses_out) OV2_HIP_CHECK(hipMemcpyAsync(r->poses_out, D.x_pose, 56 * (size_t)D.n_kf, hipMemcpyDeviceToHost, s));
+    if (r->invdepth_out && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->invdepth_out, D.x_lam, 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost, s));
+    if (r->bad_obs && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->bad_obs, D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+    if (r->chi2_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->chi2_last_eval, D.chi2, 8 * (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+    if (r->depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    if (r->l2_done) r->n_bad_total = nbbad + cnt_h[0];
+    return OV2_OK;
+}
 
 int ov2_xyz_ba_solve(ov2_ctx *ctx, const ov2_xyzba_problem *p, const ov2_ba_options *o, ov2_xyzba_result *r)
 {

@@ -98,40 +98,26 @@ public:
     void signalStopLocalBA() { bstop_localba_ = true; }     // optimizer.hpp:48
     bool stopLocalBA() const { return bstop_localba_; }     // optimizer.hpp:49
 
-    LocalBAResult solveLocalBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost) const
+    // Optimizer::localBA's solve stage (src/optimizer.cpp:436-735) as ONE library call: the problem stays in HBM between the
+    // robust and the L2 pass, outlier tests and block removal run on the device (ov2_local_ba).  want_chi2: also download the
+    // per-block chi2err_ / isdepthpositive_ values (the reference's write-back only needs bad_obs).
+    LocalBAResult solveLocalBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost, bool want_chi2 = false) const
     {
         LocalBAResult R;
         const size_t n_res = fp.res_type.size();
         R.poses.resize(fp.poses.size()); R.invdepth.resize(fp.invdepth.size());
-        R.chi2.assign(n_res, 0.0); R.depthpos.assign(n_res, 1); R.bad_obs.assign(n_res, 0);
-        ov2_ba_options opt; ov2_ba_default_options(&opt);
-        opt.max_iter = 5; opt.function_tolerance = 1e-3;
-        opt.huber_delta = buse_robust_cost ? std::sqrt(robust_mono_th_) : -1.0;
-        ov2_ba_result res{};
-        res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data();
+        R.bad_obs.assign(n_res, 0);
+        if (want_chi2) { R.chi2.assign(n_res, 0.0); R.depthpos.assign(n_res, 1); }
+        ov2_local_ba_options opt; ov2_local_ba_default_options(&opt);
+        opt.robust_mono_th = robust_mono_th_; opt.use_robust_cost = buse_robust_cost ? 1 : 0;
+        opt.apply_l2_after_robust = apply_l2_after_robust_ ? 1 : 0; opt.stop_requested = stopLocalBA() ? 1 : 0;
+        ov2_local_ba_result res{};
+        res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.bad_obs = R.bad_obs.data();
+        if (want_chi2) { res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data(); }
         ov2_ba_problem p = fp.view(nullptr);
-        if ((R.error_code = ov2_ba_solve(ctx.get(), &p, &opt, &res)) != OV2_OK) { R.error = ov2_last_error(); return R; }        // BA skipped: caller logs R.error
-        R.ok = true; R.iterations[0] = res.iterations; R.solve_ms[0] = res.solve_ms;
-        std::vector<uint8_t> active(n_res, 1);
-        size_t nbbad = 0; bool left_rem = false, right_rem = false;
-        for (size_t i = 0; i < n_res; i++) {
-            const bool bad = R.chi2[i] > robust_mono_th_ || !R.depthpos[i];
-            R.bad_obs[i] = bad; nbbad += bad;
-            if (bad && apply_l2_after_robust_) active[i] = 0;
-            if (!bad && fp.res_type[i] == OV2_RES_LEFT) left_rem = true;
-            if (!bad && fp.res_type[i] == OV2_RES_RIGHT) right_rem = true;
-        }
-        if (apply_l2_after_robust_ && buse_robust_cost && !stopLocalBA() && nbbad > 0) {
-            if (left_rem && right_rem) opt.huber_delta = -1.0;                   // :606-608
-            opt.max_iter = 10;
-            fp.poses = R.poses; fp.invdepth = R.invdepth;                        // warm start from pass 1
-            p = fp.view(active.data());
-            if (ov2_ba_solve(ctx.get(), &p, &opt, &res) == OV2_OK) {
-                R.l2_done = true; R.iterations[1] = res.iterations; R.solve_ms[1] = res.solve_ms;
-                for (size_t i = 0; i < n_res; i++)
-                    if (active[i] && (R.chi2[i] > robust_mono_th_ || !R.depthpos[i])) R.bad_obs[i] = 1;
-            }
-        }
+        if ((R.error_code = ov2_local_ba(ctx.get(), &p, &opt, &res)) != OV2_OK) { R.error = ov2_last_error(); return R; }       // BA skipped: caller logs R.error
+        R.ok = true; R.l2_done = res.l2_done != 0;
+        for (int i = 0; i < 2; i++) { R.iterations[i] = res.iterations[i]; R.solve_ms[i] = res.solve_ms[i]; }
         return R;
     }
 

@@ -219,7 +219,43 @@ class Optimizer:
             return solve_xyz(self.ctx, prob, opts, res_active, chi2_init, depthpos_init)
         return solve(self.ctx, prob, opts, res_active, chi2_init, depthpos_init)
 
-    def localBA(self, prob, buse_robust_cost=True):
+    def localBA(self, prob, buse_robust_cost=True, want_chi2=True):
+        """Optimizer::localBA's solve stage.  Inverse-depth problems on the GPU go through ov2_local_ba: ONE call, the
+        problem resident in HBM between the two passes, outlier tests and block removal on the device (want_chi2=False
+        skips the download of the per-block chi2 / depth arrays, which the reference's write-back does not need).
+        Everything else -- 3-D point problems, an injected solver (the oracle in the tests) -- runs the same protocol
+        as two solver calls: localBA_two_calls."""
+        if self._solver is None and not is_xyz_problem(prob) and (prob.get("res_xyz") is None):
+            return self._local_ba_resident(prob, buse_robust_cost, want_chi2)
+        return self.localBA_two_calls(prob, buse_robust_cost)
+
+    def _local_ba_resident(self, prob, buse_robust_cost, want_chi2):
+        lib = self.ctx.lib
+        P, keep = pack_problem(prob)
+        O = L.LocalBAOptions()
+        lib.ov2_local_ba_default_options(C.byref(O))
+        O.robust_mono_th = self.robust_mono_th; O.use_robust_cost = int(bool(buse_robust_cost))
+        O.apply_l2_after_robust = int(self.apply_l2_after_robust); O.stop_requested = int(self.stopLocalBA())
+        n_res = P.n_res
+        poses = np.zeros((P.n_kf, 7)); lam = np.zeros(max(1, P.n_lm))
+        bad = np.zeros(max(1, n_res), np.uint8); bad1 = np.zeros(max(1, n_res), np.uint8)
+        R = L.LocalBAResult()
+        R.poses_out = _dp(poses); R.invdepth_out = _dp(lam); R.bad_obs = _u8p(bad); R.bad_after_pass1 = _u8p(bad1)
+        chi2 = dpos = None
+        if want_chi2:
+            chi2 = np.full(max(1, n_res), np.nan); dpos = np.zeros(max(1, n_res), np.uint8)
+            R.chi2_last_eval = _dp(chi2); R.depthpos_last_eval = _u8p(dpos)
+        L.check(lib.ov2_local_ba(self.ctx.h, C.byref(P), C.byref(O), C.byref(R)))
+        out = dict(poses=poses, invdepth=lam[:P.n_lm], bad_obs=bad[:n_res].astype(bool), bad_after_pass1=bad1[:n_res].astype(bool),
+                   l2_done=bool(R.l2_done), iterations=(R.iterations[0], R.iterations[1]),
+                   num_successful_steps=(R.num_successful_steps[0], R.num_successful_steps[1]), termination=(R.termination[0], R.termination[1]),
+                   initial_cost=(R.initial_cost[0], R.initial_cost[1]), final_cost=(R.final_cost[0], R.final_cost[1]),
+                   solve_ms=(R.solve_ms[0], R.solve_ms[1]))
+        if want_chi2:
+            out.update(chi2=chi2[:n_res], depthpos=dpos[:n_res])
+        return out
+
+    def localBA_two_calls(self, prob, buse_robust_cost=True):
         """Inverse-depth problems (make_ba_problem layout) or, with buse_inv_depth: 0, 3-D point problems
         (make_xyz_ba_problem layout): the protocol is the same, the landmark state is `invdepth` resp. `xyz`."""
         lmk = "xyz" if is_xyz_problem(prob) else "invdepth"

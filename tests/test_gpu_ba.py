@@ -44,20 +44,43 @@ def test_single_solve_matches_oracle(gpu_ctx, oracle, n_kf, n_lm, obs, stereo, s
 
 
 def test_localba_protocol_matches_oracle(gpu_ctx, oracle):
-    """Optimizer.localBA (robust pass -> outlier removal -> L2 pass) on GPU vs the same protocol on the oracle."""
+    """Optimizer.localBA -- ONE ov2_local_ba call: robust pass -> outlier test + block removal on the device -> L2 pass -> second
+    test, the problem resident in HBM throughout -- against the same protocol run as two solver calls on the oracle, and against
+    the two-call form on the GPU (two ov2_ba_solve calls, host-side removal)."""
     def oracle_solver(prob, res_active, chi2_init, depthpos_init, **kw):
         return oracle.ba_solve(prob, oracle.ba_default_options(**kw), res_active, chi2_init, depthpos_init)
     for stereo in (True, False):
         pb = synth.make_ba_problem(15, 800, 8, stereo=stereo, seed=7)
         g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
+        g2 = ov2slam_amd.Optimizer(gpu_ctx).localBA_two_calls(pb)
         r = ov2slam_amd.Optimizer(None, solver=oracle_solver).localBA(pb)
-        assert g["l2_done"] and r["l2_done"]
+        assert g["l2_done"] and r["l2_done"] and g2["l2_done"]
         assert np.array_equal(g["bad_after_pass1"], r["bad_after_pass1"])
-        assert np.array_equal(g["bad_obs"], r["bad_obs"])
-        _cmp(g["pass1"], r["pass1"], pb)
-        _cmp(g["pass2"], r["pass2"], pb)
+        assert np.array_equal(g["bad_obs"], r["bad_obs"]) and np.array_equal(g2["bad_obs"], r["bad_obs"])
+        _cmp(g2["pass1"], r["pass1"], pb)
+        _cmp(g2["pass2"], r["pass2"], pb)
+        assert g["iterations"] == (r["pass1"]["iterations"], r["pass2"]["iterations"])
+        assert g["termination"] == (r["pass1"]["termination"], r["pass2"]["termination"])
+        # the final state: pass 2's result; chi2 / depth: pass-2 values for the blocks still in the problem, the values cached by
+        # pass 1 for the removed ones (N4)
+        _cmp(dict(g, iterations=g["iterations"][1], termination=g["termination"][1], final_cost=g["final_cost"][1],
+                  initial_cost=g["initial_cost"][1], num_successful_steps=g["num_successful_steps"][1]), r["pass2"], pb)
+        assert np.allclose(g["poses"], r["poses"], rtol=0, atol=1e-7 * max(1.0, np.abs(r["poses"]).max()))
         # injected gross outliers are (almost) all caught
         assert g["bad_obs"][pb["is_outlier"]].mean() > 0.9
+    # the protocol's switches: no robust cost -> one pass; apply_l2_after_robust off -> verdicts of the first test only; stop flag
+    pb = synth.make_ba_problem(12, 400, 8, stereo=True, seed=3)
+    for kw, robust, stop in ((dict(), False, False), (dict(apply_l2_after_robust=False), True, False), (dict(), True, True)):
+        og, orr = ov2slam_amd.Optimizer(gpu_ctx, **kw), ov2slam_amd.Optimizer(None, solver=oracle_solver, **kw)
+        if stop:
+            og.signalStopLocalBA(); orr.signalStopLocalBA()
+        g, r = og.localBA(pb, robust), orr.localBA(pb, robust)
+        assert not g["l2_done"] and not r["l2_done"]
+        assert np.array_equal(g["bad_obs"], r["bad_obs"]) and g["iterations"][0] == r["pass1"]["iterations"]
+        assert np.allclose(g["poses"], r["poses"], rtol=0, atol=1e-7 * max(1.0, np.abs(r["poses"]).max()))
+    # a mono problem keeps Huber in the second pass (:606-608): exercised by stereo=False above; want_chi2=False skips the arrays
+    g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb, want_chi2=False)
+    assert "chi2" not in g and g["l2_done"]
 
 
 def test_resident_problem_is_repeatable(gpu_ctx, oracle):

@@ -106,6 +106,6 @@ def test_cpp_adapters_run_and_match(gpu_ctx, oracle, tmp_path):
     # ---- Optimizer::localBA: same protocol, same library ----
     g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
     assert c_flags[0] == 1 and bool(c_flags[1]) == bool(g["l2_done"])
-    assert c_flags[2] == g["pass1"]["iterations"] and (not g["l2_done"] or c_flags[3] == g["pass2"]["iterations"])
+    assert c_flags[2] == g["iterations"][0] and (not g["l2_done"] or c_flags[3] == g["iterations"][1])
     assert np.array_equal(c_badobs.astype(bool), np.asarray(g["bad_obs"]).astype(bool))
     assert np.allclose(c_poses.reshape(-1, 7), g["poses"], rtol=0, atol=1e-9) and np.allclose(c_lam, g["invdepth"], rtol=1e-9, atol=1e-12)

@@ -167,7 +167,7 @@ def test_more_keypoints_than_capacity(gpu_ctx, oracle, use_graph):
     assert gp3p == rp3p and np.array_equal((gst & 1).astype(bool), rok) and np.array_equal((gst & 2).astype(bool), rretried)
     assert np.array_equal(_bits(gout), _bits(rout))
     # split API, and the p3p rule with its counts spread over several chunks
-    kps, pri, hp = _points(w, h, flow, 1, rng, 1.0, frac_prior=0.8, bad_frac=0.85, bad_sigma=40.0)
+    kps, pri, hp = _points(w, h, flow, 1, rng, 1.0, frac_prior=0.8, bad_frac=0.95, bad_sigma=60.0)
     trk.preprocessImage(views[2])
     gout, gst, gp3p = trk.kltTracking(kps, pri, hp)
     rout, rok, rretried, rp3p = _oracle_frame(oracle, views[1], views[2], kps, pri, hp, True, w, h)
