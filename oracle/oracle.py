@@ -522,14 +522,16 @@ def stereo_matching(leftpyr, rightpyr, kps_px, kps_unpx, model, K, D, rect, Frl=
     priors3d = priors3d or {}
     v3dkpids, v3dkps, v3dpriors, vkpids, vkps, vpriors = [], [], [], [], [], []
     up = np.float32(2.0 ** nklt_pyr_lvl); down = np.float32(1.0) / up
+    xp_all = None
+    if rect and n:                                                         # getLineMinSAD is per keypoint (:431): one batched call here
+        xp_all, _ = line_min_sad(leftpyr.level(nklt_pyr_lvl)[0], rightpyr.level(nklt_pyr_lvl)[0], kps_px * down, 7, True)
     for i in range(n):                                                     # :392-489 (kps in frame order)
         if i in priors3d:
             v3dkpids.append(i); v3dkps.append(kps_px[i]); v3dpriors.append(np.asarray(priors3d[i], np.float32))
             continue
         pr = kps_px[i].copy()
         if rect:
-            xp, _ = line_min_sad(leftpyr.level(nklt_pyr_lvl)[0], rightpyr.level(nklt_pyr_lvl)[0], (kps_px[i] * down)[None], 7, True)
-            x = np.float32(xp[0]) * up
+            x = np.float32(xp_all[i]) * up
             if x >= 0 and x <= kps_px[i, 0]:
                 pr[0] = x
         vkpids.append(i); vkps.append(kps_px[i]); vpriors.append(pr)

@@ -78,15 +78,18 @@ class SyntheticSequence:
     seeded texture under a smooth similarity motion (a short cycle of distinct views, replayed back and forth, so that a
     sequence costs 0.2 s to generate instead of 30 ms per frame), with the ground-truth flow between consecutive frames."""
 
-    def __init__(self, name, n_frames, seed, w=752, h=480, n_views=7, tex=None):
+    def __init__(self, name, n_frames, seed, w=752, h=480, n_views=7, tex=None, stereo=False, disparity=20.0):
         from . import synth
         self.name, self.n_frames, self.w, self.h = name, int(n_frames), w, h
         rng = np.random.default_rng(seed)
         tex = synth.base_texture(1400, 1234) if tex is None else tex
         ox, oy, th = float(rng.uniform(100, 400)), float(rng.uniform(100, 400)), 0.0
-        self.views, self.offs = [], []
+        self.views, self.offs, self.right_views = [], [], []
+        self.disparity = float(disparity)
         for _ in range(n_views):
             self.views.append(synth.warp(tex, w, h, ox, oy, th)); self.offs.append((ox, oy, th))
+            if stereo:      # rectified right camera: right(x, y) = left(x + d, y) -- a fronto-parallel scene at constant disparity d
+                self.right_views.append(synth.warp(tex, w, h, ox + disparity * np.cos(th), oy + disparity * np.sin(th), th))
             ox += rng.uniform(-5, 5); oy += rng.uniform(-4, 4); th += rng.uniform(-0.006, 0.006)
         self.seed = seed
 
@@ -97,6 +100,9 @@ class SyntheticSequence:
 
     def frame(self, f):
         return self.views[self.view_index(f)]
+
+    def right_frame(self, f):
+        return self.right_views[self.view_index(f)]
 
     def flow(self, pts, fa, fb):
         """ground-truth position in frame fb of pixels `pts` of frame fa"""
@@ -112,44 +118,14 @@ class SyntheticSequence:
         return np.stack([c * dx - s * dy + cx, s * dx + c * dy + cy], 1)
 
 
-def run_sequence(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use_graph=True):
-    """One sequence through the GPU hot path the way the reference's front-end drives it: per frame preprocessImage +
-    kltTracking (ov2_tracker_track_frame); every `kf_every`-th frame is a keyframe: the min-eigenvalue grid detector tops
-    the keypoint set up (MapManager::extractKeypoints, map_manager.cpp:286-341).  Keypoints that were tracked before carry
-    a prior (true flow + noise, standing in for the motion model's projection of their map point).
-    Returns dict(frames, seconds, tracked, attempted, err_sq_sum, err_n, detect_calls)."""
-    import time
-    from . import frontend
-    rng = np.random.default_rng(seq.seed + 17)
-    w, h = seq.w, seq.h
-    trk = frontend.VisualFrontEndTracker(ctx, w, h, nbmaxkps=max(512, 2 * nbmaxkps), use_graph=use_graph)
-    fx = frontend.FeatureExtractor(ctx, dmaxquality=0.001)
-    roi = (5, 5, w - 10, h - 10)
-    empty = np.zeros((0, 2), np.float32)
-    t0 = time.perf_counter()
-    trk.trackFrame(seq.frame(0), empty, empty, None)
-    # frame 0 is a keyframe (visual_front_end.cpp:87-95); the detector reads the CLAHE'd frame = level 0 of cur_pyr_ (no upload)
-    kps = fx.detectSingleScalePyr(trk.cur_pyr, cell, empty, roi)[:nbmaxkps]
-    age = np.zeros(len(kps), np.int32)
-    st = dict(frames=1, tracked=0, attempted=0, err_sq_sum=0.0, err_n=0, detect_calls=1)
-    for f in range(1, seq.n_frames):
-        gt = seq.flow(kps, f - 1, f)
-        has_prior = (age > 0).astype(np.uint8)                                   # tracked at least once: "3-D" keypoint
-        pri = np.where(has_prior[:, None] > 0, gt + rng.normal(0, prior_sigma, gt.shape), kps).astype(np.float32)
-        out, sb, _ = trk.trackFrame(seq.frame(f), kps, pri, has_prior)
-        ok = (sb & 1).astype(bool)
-        st["frames"] += 1; st["attempted"] += len(kps); st["tracked"] += int(ok.sum())
-        if ok.any():
-            d = out[ok].astype(np.float64) - gt[ok]
-            st["err_sq_sum"] += float((d ** 2).sum()); st["err_n"] += int(ok.sum())
-        kps, age = out[ok], age[ok] + 1
-        inside = (kps[:, 0] > 8) & (kps[:, 0] < w - 9) & (kps[:, 1] > 8) & (kps[:, 1] < h - 9)
-        kps, age = kps[inside], age[inside]
-        if f % kf_every == 0 and len(kps) < nbmaxkps:
-            new = fx.detectSingleScalePyr(trk.cur_pyr, cell, kps, roi)[:nbmaxkps - len(kps)]
-            st["detect_calls"] += 1
-            kps = np.concatenate([kps, new]); age = np.concatenate([age, np.zeros(len(new), np.int32)])
-    ctx.sync()
-    st["seconds"] = time.perf_counter() - t0
-    trk.close()
-    return st
+def run_sequence(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use_graph=True, ba_problems=None):
+    """One sequence through the GPU hot path the way the reference schedules it (ov2slam_amd.stream.run_stream): the SLAM
+    thread on `ctx` (per frame preprocessImage + kltTracking + computeKeypoint, at every `kf_every`-th frame the min-eigenvalue
+    grid detector tops the keypoint set up, MapManager::extractKeypoints, map_manager.cpp:286-341), and -- when the sequence
+    carries right images / `ba_problems` is given -- the mapper thread's right-image pyramid + stereo matching and the
+    estimator thread's two-pass localBA per keyframe on contexts of their own, concurrently.  Keypoints that were tracked
+    before carry a prior (true flow + noise, standing in for the motion model's projection of their map point).
+    Returns the counters of run_stream (frames, seconds, tracked, attempted, err_sq_sum, err_n, detect_calls, stereo_*, ba_*)."""
+    from . import stream
+    return stream.run_stream(ctx, seq, kf_every=kf_every, cell=cell, nbmaxkps=nbmaxkps, prior_sigma=prior_sigma, use_graph=use_graph,
+                             do_stereo=bool(seq.right_views), ba_problems=ba_problems)

@@ -33,6 +33,7 @@
 #include <vector>
 #include <mutex>
 #include <chrono>
+#include <thread>
 
 #ifndef BA_KO
 #define BA_KO 0      // knock-out timing of the lineariser: 1 no global Hao atomics, 2 no LDS atomics, 4 no wave sums
@@ -2173,27 +2174,56 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     OV2_REQUIRE(p->poses && p->kf_const, OV2_EINVAL, "NULL pose arrays");
     OV2_REQUIRE(p->n_lm == 0 || (p->invdepth && p->lm_anchor_kf && p->lm_anchor_uv), OV2_EINVAL, "NULL landmark arrays");
     OV2_REQUIRE(p->n_res == 0 || (p->res_type && p->res_kf && p->res_lm && p->res_uv && p->res_sigma), OV2_EINVAL, "NULL residual arrays");
-    // validate + landmark-sorted order of the active residual blocks; pose-only blocks (OV2_RES_PNP) go to their own list
-    std::vector<int> cnt(p->n_lm + 1, 0);
-    int n_act = 0, n_po = 0;
-    for (int i = 0; i < p->n_res; i++) {
-        if (p->res_active && !p->res_active[i]) continue;
-        OV2_REQUIRE(p->res_type[i] <= OV2_RES_PNP, OV2_EINVAL, "unknown residual type");
-        OV2_REQUIRE(p->res_sigma[i] > 0, OV2_EINVAL, "res_sigma must be positive");
-        if (p->res_type[i] == OV2_RES_PNP) {
-            OV2_REQUIRE(p->res_xyz != nullptr, OV2_EINVAL, "OV2_RES_PNP blocks need res_xyz");
-            OV2_REQUIRE(p->res_kf[i] >= 0 && p->res_kf[i] < p->n_kf, OV2_EINVAL, "res_kf out of range");
-            n_po++;
-            continue;
+    // validate + landmark-sorted order of the active residual blocks (a STABLE counting sort: blocks of a landmark keep the
+    // caller's order); pose-only blocks (OV2_RES_PNP) go to their own list.  Large problems (a 590 k-block localBA: 3.8 ms of the
+    // call were this sort and the staging fill) split the residual range over a few host threads: per-thread counts, offsets
+    // = landmark prefix + the counts of the lower-numbered threads, so the result is identical to the serial sort.
+    const int NT = p->n_res >= (1 << 17) ? std::min(8, p->n_res >> 16) : 1;
+    std::vector<std::vector<int>> cntT((size_t)NT, std::vector<int>((size_t)p->n_lm + 1, 0));
+    std::vector<int> nactT((size_t)NT, 0), npoT((size_t)NT, 0);
+    std::vector<const char *> errT((size_t)NT, nullptr);
+    auto range_of = [&](int t, int &b, int &e) { b = (int)((long long)p->n_res * t / NT); e = (int)((long long)p->n_res * (t + 1) / NT); };
+    auto run_threads = [&](auto &&fn) {
+        if (NT == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < NT; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    run_threads([&](int t) {
+        int b, e; range_of(t, b, e);
+        std::vector<int> &cn = cntT[(size_t)t];
+        int na_t = 0, np_t = 0;
+        const char *err = nullptr;
+        for (int i = b; i < e && !err; i++) {
+            if (p->res_active && !p->res_active[i]) continue;
+            if (p->res_type[i] > OV2_RES_PNP) { err = "unknown residual type"; break; }
+            if (!(p->res_sigma[i] > 0)) { err = "res_sigma must be positive"; break; }
+            if (p->res_type[i] == OV2_RES_PNP) {
+                if (!p->res_xyz) { err = "OV2_RES_PNP blocks need res_xyz"; break; }
+                if (p->res_kf[i] < 0 || p->res_kf[i] >= p->n_kf) { err = "res_kf out of range"; break; }
+                np_t++;
+                continue;
+            }
+            const int lm = p->res_lm[i];
+            if (lm < 0 || lm >= p->n_lm) { err = "res_lm out of range"; break; }
+            if (p->res_type[i] != OV2_RES_RIGHT_ANCH && (p->res_kf[i] < 0 || p->res_kf[i] >= p->n_kf)) { err = "res_kf out of range"; break; }
+            cn[lm]++; na_t++;
         }
-        const int lm = p->res_lm[i];
-        OV2_REQUIRE(lm >= 0 && lm < p->n_lm, OV2_EINVAL, "res_lm out of range");
-        if (p->res_type[i] != OV2_RES_RIGHT_ANCH) OV2_REQUIRE(p->res_kf[i] >= 0 && p->res_kf[i] < p->n_kf, OV2_EINVAL, "res_kf out of range");
-        cnt[lm + 1]++; n_act++;
-    }
-    for (int l = 0; l < p->n_lm; l++) {
-        OV2_REQUIRE(p->lm_anchor_kf[l] >= 0 && p->lm_anchor_kf[l] < p->n_kf, OV2_EINVAL, "lm_anchor_kf out of range");
-        cnt[l + 1] += cnt[l];
+        nactT[(size_t)t] = na_t; npoT[(size_t)t] = np_t; errT[(size_t)t] = err;
+    });
+    for (int t = 0; t < NT; t++) OV2_REQUIRE(errT[(size_t)t] == nullptr, OV2_EINVAL, errT[(size_t)t]);
+    std::vector<int> cnt(p->n_lm + 1, 0);                              // cnt[l] = first sorted index of landmark l (CSR)
+    int n_act = 0, n_po = 0;
+    for (int t = 0; t < NT; t++) { n_act += nactT[(size_t)t]; n_po += npoT[(size_t)t]; }
+    {
+        int run = 0;
+        for (int l = 0; l < p->n_lm; l++) {
+            OV2_REQUIRE(p->lm_anchor_kf[l] >= 0 && p->lm_anchor_kf[l] < p->n_kf, OV2_EINVAL, "lm_anchor_kf out of range");
+            cnt[l] = run;
+            for (int t = 0; t < NT; t++) { const int c = cntT[(size_t)t][l]; cntT[(size_t)t][l] = run; run += c; }   // cntT becomes the thread's fill cursor
+        }
+        cnt[p->n_lm] = run;
     }
     std::vector<int> pose_col(p->n_kf);
     int n_opt = 0;
@@ -2203,7 +2233,6 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     // the per-residual upload arrays are filled straight into the context's PINNED host scratch: the H2D copies below are then
     // real asynchronous DMA (from pageable std::vectors every copy went through the runtime's staging buffer, ~2.5 ms for the
     // 20 MB of a 590 k-block problem) and no 20 MB of vectors is allocated and zeroed per call
-    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
     int *res_kf, *res_orig, *po_kf, *po_orig;
     uint8_t *res_type;
     double *res_uv, *res_sigma, *po_xyz, *po_uv, *po_sigma;
@@ -2219,20 +2248,26 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         res_kf = (int *)(hs + h1); res_orig = (int *)(hs + h2); res_type = hs + h3; res_uv = (double *)(hs + h4); res_sigma = (double *)(hs + h5);
         po_kf = (int *)(hs + h6); po_orig = (int *)(hs + h7); po_xyz = (double *)(hs + h8); po_uv = (double *)(hs + h9); po_sigma = (double *)(hs + h10);
     }
-    int kp = 0;
-    for (int i = 0; i < p->n_res; i++) {
-        if (p->res_active && !p->res_active[i]) continue;
-        if (p->res_type[i] == OV2_RES_PNP) {
-            po_kf[kp] = p->res_kf[i]; po_orig[kp] = i; po_sigma[kp] = p->res_sigma[i];
-            po_uv[2 * kp] = p->res_uv[2 * i]; po_uv[2 * kp + 1] = p->res_uv[2 * i + 1];
-            for (int c = 0; c < 3; c++) po_xyz[3 * kp + c] = p->res_xyz[3 * i + c];
-            kp++;
-            continue;
+    std::vector<int> poStart((size_t)NT + 1, 0);
+    for (int t = 0; t < NT; t++) poStart[(size_t)t + 1] = poStart[(size_t)t] + npoT[(size_t)t];
+    run_threads([&](int t) {
+        int b, e; range_of(t, b, e);
+        std::vector<int> &fill = cntT[(size_t)t];
+        int kp = poStart[(size_t)t];
+        for (int i = b; i < e; i++) {
+            if (p->res_active && !p->res_active[i]) continue;
+            if (p->res_type[i] == OV2_RES_PNP) {
+                po_kf[kp] = p->res_kf[i]; po_orig[kp] = i; po_sigma[kp] = p->res_sigma[i];
+                po_uv[2 * kp] = p->res_uv[2 * i]; po_uv[2 * kp + 1] = p->res_uv[2 * i + 1];
+                for (int c = 0; c < 3; c++) po_xyz[3 * kp + c] = p->res_xyz[3 * i + c];
+                kp++;
+                continue;
+            }
+            const int k = fill[p->res_lm[i]]++;
+            res_type[k] = p->res_type[i]; res_kf[k] = p->res_type[i] == OV2_RES_RIGHT_ANCH ? p->lm_anchor_kf[p->res_lm[i]] : p->res_kf[i];
+            res_orig[k] = i; res_uv[2 * k] = p->res_uv[2 * i]; res_uv[2 * k + 1] = p->res_uv[2 * i + 1]; res_sigma[k] = p->res_sigma[i];
         }
-        const int k = fill[p->res_lm[i]]++;
-        res_type[k] = p->res_type[i]; res_kf[k] = p->res_type[i] == OV2_RES_RIGHT_ANCH ? p->lm_anchor_kf[p->res_lm[i]] : p->res_kf[i];
-        res_orig[k] = i; res_uv[2 * k] = p->res_uv[2 * i]; res_uv[2 * k + 1] = p->res_uv[2 * i + 1]; res_sigma[k] = p->res_sigma[i];
-    }
+    });
 
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     ov2_ba_dev *dev = new (std::nothrow) ov2_ba_dev();
@@ -2775,7 +2810,7 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
     r->l2_done = 0; r->n_bad_pass1 = 0; r->n_bad_total = 0;
     for (int i = 0; i < 2; i++) { r->iterations[i] = 0; r->num_successful_steps[i] = 0; r->termination[i] = OV2_TERM_NO_CONVERGENCE; r->initial_cost[i] = r->final_cost[i] = 0; r->solve_ms[i] = 0; }
     ov2_ba_dev *dev = nullptr;
-    int rc = ba_create(ctx, p, &dev, /*transient*/ false);
+    int rc = ba_create(ctx, p, &dev, /*transient*/ true);       // the pool lives in the context's scratch through both passes
     if (rc != OV2_OK) return rc;
     struct Guard { ov2_ba_dev *d; ~Guard() { ba_destroy(d); } } guard{dev};
     if (dev->D.n_po > 0) { ov2_set_error("ov2_local_ba: problems with OV2_RES_PNP blocks go through ov2_ba_solve"); return OV2_EUNSUPPORTED; }

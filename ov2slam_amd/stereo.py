@@ -65,17 +65,18 @@ def stereo_matching(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *
     return ok, right
 
 
-def stereo_matching_fused(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *, rect, Frl=None, nklt_win_size=9,
-                          nklt_pyr_lvl=3, nklt_err=30.0, fmax_fbklt_dist=0.5, priors3d=None):
-    """ov2_stereo_match: the same flow as stereo_matching() in ONE enqueue and ONE synchronisation (SAD priors, both
-    fbKltTracking calls with the retry of failed 3-D-prior tracks, epipolar gate).  Same arguments, same return."""
+def stereo_match_arrays(tracker, leftpyr, rightpyr, kps_px, kps_unpx, priors3d_xy, has_prior3d, right_calib, *, rect, Frl=None,
+                        nklt_win_size=9, nklt_pyr_lvl=3, nklt_err=30.0, fmax_fbklt_dist=0.5):
+    """ov2_stereo_match on flat arrays: priors3d_xy (n,2) float32 (ignored where has_prior3d[i] == 0), has_prior3d (n,) uint8.
+    Returns (stereo_ok (n,) bool, right_px (n,2) float32)."""
     ctx = tracker.ctx
     kps_px = np.ascontiguousarray(kps_px, dtype=np.float32).reshape(-1, 2)
     kps_unpx = np.ascontiguousarray(kps_unpx, dtype=np.float32).reshape(-1, 2)
+    p3 = np.ascontiguousarray(priors3d_xy, dtype=np.float32).reshape(-1, 2)
+    hp = np.ascontiguousarray(has_prior3d, dtype=np.uint8).reshape(-1)
     n = len(kps_px)
-    hp = np.zeros(n, np.uint8); p3 = kps_px.copy()
-    for i, xy in (priors3d or {}).items():
-        hp[i] = 1; p3[i] = xy
+    if len(kps_unpx) != n or len(p3) != n or len(hp) != n:
+        raise ValueError("stereo_match_arrays: arrays differ in length")
     right = np.zeros((n, 2), np.float32); ok = np.zeros(n, np.uint8)
     F = None if Frl is None else np.ascontiguousarray(Frl, dtype=np.float64).reshape(9)
     D = right_calib.D
@@ -86,3 +87,16 @@ def stereo_matching_fused(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_ca
                                      _ptr(p3), _ptr(hp), n, _ptr(right), _ptr(ok)))
     return ok.astype(bool), right
 
+
+def stereo_matching_fused(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *, rect, Frl=None, nklt_win_size=9,
+                          nklt_pyr_lvl=3, nklt_err=30.0, fmax_fbklt_dist=0.5, priors3d=None):
+    """ov2_stereo_match: the same flow as stereo_matching() in ONE enqueue and ONE synchronisation (SAD priors, both
+    fbKltTracking calls with the retry of failed 3-D-prior tracks, epipolar gate).  Same arguments, same return."""
+    kps_px = np.ascontiguousarray(kps_px, dtype=np.float32).reshape(-1, 2)
+    n = len(kps_px)
+    hp = np.zeros(n, np.uint8); p3 = kps_px.copy()
+    for i, xy in (priors3d or {}).items():
+        hp[i] = 1; p3[i] = xy
+    return stereo_match_arrays(tracker, leftpyr, rightpyr, kps_px, kps_unpx, p3, hp, right_calib, rect=rect, Frl=Frl,
+                               nklt_win_size=nklt_win_size, nklt_pyr_lvl=nklt_pyr_lvl, nklt_err=nklt_err,
+                               fmax_fbklt_dist=fmax_fbklt_dist)

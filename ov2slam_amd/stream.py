@@ -1,0 +1,186 @@
+"""One camera, three contexts: the keyframe cycle of BASELINE.json configs[1] (EuRoC stereo, 'accurate') the way the
+reference schedules it -- the front-end on the SLAM thread, stereo matching on the mapper thread, localBA on the estimator
+thread, concurrently (/root/reference/src/ov2slam.cpp:116-237, src/mapper.cpp:62-95, src/estimator.cpp:33-98):
+
+    SLAM thread      (context A)  per frame   preprocessImage + kltTracking       ov2_tracker_track_frame
+                                              Frame::computeKeypoint              ov2_compute_keypoints (tracked keypoints)
+                                  keyframe    MapManager::extractKeypoints        ov2_detect_singlescale_d on cur_pyr_
+                                              computeKeypoint of the new points   ov2_compute_keypoints
+                                              Mapper::addNewKf                    (queue, FIFO: mapper.cpp:784-809)
+    mapper thread    (context B)  keyframe    clahe->apply + buildOpticalFlowPyramid of the RIGHT image, stereoMatching
+                                              (mapper.cpp:74-83)                  ov2_pyr_build_clahe_h + ov2_stereo_match on the
+                                                                                  front-end's left pyramid (cross-context event)
+                                              Estimator::addNewKf
+    estimator thread (context C)  keyframe    Optimizer::localBA                  ov2_local_ba (two passes, problem resident);
+                                              only the LAST queued keyframe is processed (estimator.cpp:185-205)
+
+What stays on the CPU in the reference and is NOT part of this path (pose estimation, triangulation, the map walk that builds the
+BA problem) is stood in for by the synthetic ground truth: priors come from the true flow, the BA problems are pre-generated
+windows.  Python threads: every library call releases the GIL (ctypes), so the three contexts really overlap on the GPU."""
+import queue
+import threading
+import time
+
+import numpy as np
+
+from . import frontend, stereo, optimizer
+
+K_EUROC = (458.654, 457.296, 367.215, 248.375)
+D_EUROC = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+
+
+def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use_graph=True, do_stereo=True, ba_problems=None,
+               distortion=D_EUROC, ba_policy="newest"):
+    """seq: batch.SyntheticSequence (stereo=True for do_stereo).  ba_problems: list of flat local-BA problems (cycled, one
+    localBA per keyframe) or None.  ba_policy: "newest" = the reference's estimator (only the last queued keyframe is optimised
+    when several wait, estimator.cpp:195-205), "all" = every keyframe gets its localBA (equal work for CPU / GPU comparisons).
+    ctx = context A; contexts B and C are created on the same device.
+    Returns a dict of counters and times (seconds)."""
+    from . import Context
+    rng = np.random.default_rng(seq.seed + 17)
+    w, h = seq.w, seq.h
+    dev = ctx.device
+    ctxB = Context(dev) if do_stereo else None
+    ctxC = Context(dev) if ba_problems else None
+    trk = frontend.VisualFrontEndTracker(ctx, w, h, nbmaxkps=2 * nbmaxkps, use_graph=use_graph)
+    fx = frontend.FeatureExtractor(ctx, dmaxquality=0.001)
+    calL = frontend.CameraCalibration(ctx, "pinhole", *K_EUROC, D=distortion)
+    roi = (5, 5, w - 10, h - 10)
+    empty = np.zeros((0, 2), np.float32)
+    st = dict(frames=0, tracked=0, attempted=0, err_sq_sum=0.0, err_n=0, detect_calls=0, keyframes=0, stereo_kfs=0, stereo_ok=0,
+              stereo_kps=0, mapper_busy_s=0.0, ba_solves=0, ba_skipped_kfs=0, ba_iterations=0, ba_busy_s=0.0, ba_device_ms=0.0,
+              slam_wait_for_mapper_s=0.0)
+    errors = []
+    # ---- mapper thread -----------------------------------------------------------------------------------------------
+    map_q = queue.Queue()
+    ba_q = queue.Queue()
+    kf_consumed = {}                                   # keyframe frame index -> Event: the mapper is done with the left pyramid
+
+    def mapper():
+        try:
+            ftrk = frontend.FeatureTracker(ctxB, 30, 0.01)
+            calR = frontend.CameraCalibration(ctxB, "pinhole", *K_EUROC, D=distortion)
+            pyrR = frontend.Pyramid(ctxB, w, h, 9, 3)
+            while True:
+                item = map_q.get()
+                if item is None:
+                    break
+                f, left_pyr, right_img, kps, unpx, p3, hp = item
+                t0 = time.perf_counter()
+                pyrR.build_clahe(right_img, 3.0, w // 50, h // 50)                                   # asynchronous
+                ok, right = stereo.stereo_match_arrays(ftrk, left_pyr, pyrR, kps, unpx, p3, hp, calR, rect=True)
+                st["mapper_busy_s"] += time.perf_counter() - t0
+                kf_consumed[f].set()
+                st["stereo_kfs"] += 1; st["stereo_ok"] += int(ok.sum()); st["stereo_kps"] += len(kps)
+                if ba_problems:
+                    ba_q.put(f)
+            pyrR.close()
+        except Exception as e:                          # surfaced by the caller
+            errors.append(e)
+            for ev in kf_consumed.values():
+                ev.set()
+        finally:
+            ba_q.put(None)
+
+    def estimator():
+        try:
+            opt = optimizer.Optimizer(ctxC)
+            n = 0
+            while True:
+                item = ba_q.get()
+                if item is None:
+                    break
+                # In SLAM mode only the last received keyframe is processed (estimator.cpp:195-205)
+                while ba_policy == "newest":
+                    try:
+                        nxt = ba_q.get_nowait()
+                    except queue.Empty:
+                        break
+                    if nxt is None:
+                        ba_q.put(None)
+                        break
+                    st["ba_skipped_kfs"] += 1
+                    item = nxt
+                pb = ba_problems[n % len(ba_problems)]; n += 1
+                t0 = time.perf_counter()
+                r = opt.localBA(pb, want_chi2=False)
+                st["ba_busy_s"] += time.perf_counter() - t0
+                st["ba_solves"] += 1; st["ba_iterations"] += r["iterations"][0] + r["iterations"][1]
+                st["ba_device_ms"] += r["solve_ms"][0] + r["solve_ms"][1]
+        except Exception as e:
+            errors.append(e)
+
+    th_map = threading.Thread(target=mapper, daemon=True) if do_stereo else None
+    th_ba = threading.Thread(target=estimator, daemon=True) if ba_problems else None
+    if th_map:
+        th_map.start()
+    if th_ba:
+        th_ba.start()
+        if not th_map:
+            pass
+
+    def keyframe(f, kps, age):
+        """createKeyframe: detection tops the keypoint set up; the keyframe goes to the mapper."""
+        new = fx.detectSingleScalePyr(trk.cur_pyr, cell, kps, roi)[:max(0, nbmaxkps - len(kps))]
+        st["detect_calls"] += 1; st["keyframes"] += 1
+        if len(new):
+            kps = np.concatenate([kps, new]); age = np.concatenate([age, np.zeros(len(new), np.int32)])
+        if do_stereo:
+            unpx, _ = calL.computeKeypoints(kps, want_bv=True)
+            hp = (age > 0).astype(np.uint8)                                  # keypoints with a map point: right-image prior (:402-413)
+            p3 = kps.copy()
+            p3[:, 0] -= np.float32(seq.disparity)
+            p3 += rng.normal(0, 1.0, p3.shape).astype(np.float32)
+            kf_consumed[f] = threading.Event()
+            map_q.put((f, trk.cur_pyr, seq.right_frame(f), kps.copy(), unpx, p3, hp))
+        elif ba_problems:
+            ba_q.put(f)
+        return kps, age
+
+    t0 = time.perf_counter()
+    trk.trackFrame(seq.frame(0), empty, empty, None)
+    st["frames"] = 1
+    kps, age = keyframe(0, empty, np.zeros(0, np.int32))                     # frame 0 is a keyframe (visual_front_end.cpp:87-95)
+    last_kf = 0
+    for f in range(1, seq.n_frames):
+        if errors:
+            break
+        gt = seq.flow(kps, f - 1, f)
+        has_prior = (age > 0).astype(np.uint8)
+        pri = np.where(has_prior[:, None] > 0, gt + rng.normal(0, prior_sigma, gt.shape), kps).astype(np.float32)
+        if do_stereo and f == last_kf + 2:
+            # this frame's preprocessImage overwrites the pyramid the keyframe of two frames ago shares with the mapper
+            # (the reference's cv::Mat buffers are re-used the same way): wait until stereo matching has consumed it
+            ev = kf_consumed.get(last_kf)
+            if ev is not None and not ev.is_set():
+                tw = time.perf_counter(); ev.wait(); st["slam_wait_for_mapper_s"] += time.perf_counter() - tw
+        out, sb, _ = trk.trackFrame(seq.frame(f), kps, pri, has_prior)
+        ok = (sb & 1).astype(bool)
+        st["frames"] += 1; st["attempted"] += len(kps); st["tracked"] += int(ok.sum())
+        if ok.any():
+            d = out[ok].astype(np.float64) - gt[ok]
+            st["err_sq_sum"] += float((d ** 2).sum()); st["err_n"] += int(ok.sum())
+        kps, age = out[ok], age[ok] + 1
+        calL.computeKeypoints(kps, want_bv=True)                             # Frame::updateKeypoint -> computeKeypoint (frame.cpp:246-254)
+        inside = (kps[:, 0] > 8) & (kps[:, 0] < w - 9) & (kps[:, 1] > 8) & (kps[:, 1] < h - 9)
+        kps, age = kps[inside], age[inside]
+        if f % kf_every == 0:
+            kps, age = keyframe(f, kps, age)
+            last_kf = f
+    ctx.sync()
+    st["slam_thread_seconds"] = time.perf_counter() - t0
+    if th_map:
+        map_q.put(None); th_map.join()
+    elif th_ba:
+        ba_q.put(None)
+    if th_ba:
+        th_ba.join()
+    st["seconds"] = time.perf_counter() - t0                                  # until the mapper and the estimator have drained
+    trk.close()
+    if ctxB:
+        ctxB.close()
+    if ctxC:
+        ctxC.close()
+    if errors:
+        raise errors[0]
+    return st
