@@ -67,6 +67,22 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c) { return __bu
 // a.lo * b.lo + a.hi * b.hi without an accumulator: the VOP3P encoding with the inline constant 0 (the compiler
 // only selects the two-address v_dot2c form, which costs a v_mov to clear the destination first)
 __device__ __forceinline__ int dot2z(uint32_t a, uint32_t b) { int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a.lo * b.lo + a.hi * b.hi + 256: the rounding constant of the bilinear sums rides in src2 (a scalar register: 256 is no inline
+// constant), so (S + 256) >> 9 needs no separate add
+__device__ __forceinline__ int dot2r(uint32_t a, uint32_t b)
+{
+    int r;
+    const int c256 = __builtin_amdgcn_readfirstlane(256);
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c256));
+    return r;
+}
+// (S0 >> 9, S1 >> 9) as two u16 for sums 0 <= S < 2^24 that already hold their rounding constant: bytes 1-2 of each
+// (S >> 8, 16 bits) by one byte permute, then one packed shift
+__device__ __forceinline__ uint32_t shr9_pair(int s0, int s1)
+{
+    const uint32_t hi8 = __builtin_amdgcn_perm((uint32_t)s1, (uint32_t)s0, 0x06050201u);
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, hi8) >> (unsigned short)1));
+}
 __device__ __forceinline__ uint32_t pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }   // (lo & 0xFFFF) | (hi << 16)
 // ((S0 + 256) >> 9, (S1 + 256) >> 9) as two u16 for bilinear sums S (-256 <= S < 2^23): (S + 256) >> 9 == ((S >> 8) + 1) >> 1,
 // so one byte permute (S >> 8 of both), one packed add and one packed shift replace two 32-bit shifts, a pack and
@@ -99,6 +115,19 @@ __device__ __forceinline__ double l3_sum3_exact(int p, int sub)
     const int slo = l3_sum3(p & 0xFFFF, sub);
     const int shi = l3_sum3(p >> 16, sub);
     return (double)shi * 65536.0 + (double)slo;
+}
+
+// (float)(exact sum of three int32 partials, |p| < 2^30 each) over the group, in all three lanes: lanes 0 + 1 add up in int32
+// (|.| < 2^31), lane 2 joins in fp64 (exact) and rounds ONCE to fp32 -- the rounding of the oracle's (float)int64 -- and the
+// float travels back through two DPP moves.  10 instructions instead of the 20 of the 16-bit-halves form above.
+__device__ __forceinline__ float l3_sum3_f32(int p, int sub)
+{
+    const int t = p + l3_dpp<0x111>(p);            // lane 1: p0 + p1
+    const int q = l3_dpp<0x111>(t);                // lane 2: p0 + p1
+    const float f = (float)((double)q + (double)p);                 // valid in lane 2
+    const int fi = __builtin_bit_cast(int, f);
+    const int f1 = l3_dpp<0x101>(fi), f2 = l3_dpp<0x102>(fi);      // lane 1 <- lane 2, lane 0 <- lane 2
+    return __builtin_bit_cast(float, sub == 2 ? fi : (sub == 1 ? f1 : f2));
 }
 
 __device__ __forceinline__ int l3_round(float v) { return __float2int_rn(v); }
@@ -197,7 +226,9 @@ __device__ __forceinline__ void l3_fetch_J(uint32_t *slot, const uint8_t *jroi, 
 }
 
 // the three window rows of a lane as 16-bit pairs: slots 0..3 = pixels (0,1)(2,3)(4,5)(6,7), slot 4 = (8, -)
-struct L3Tmpl { uint32_t I[L3_RPL][5], X[L3_RPL][5], Y[L3_RPL][5]; };
+// (the interpolated template values I are not kept: sum (J - I) dI = sum J dI - sum I dI, and the second sum is a per-lane
+// constant of the visit -- 15 VGPRs and 15 packed subtractions per Gauss-Newton trip less)
+struct L3Tmpl { uint32_t X[L3_RPL][5], Y[L3_RPL][5]; int cIX, cIY; };
 
 struct L3State {
     float nx, ny;      // nextPts[i] as OpenCV carries it between levels
@@ -320,6 +351,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
     // Scharr (calcSharrDeriv + copyMakeBorder(BORDER_CONSTANT 0)) is evaluated on the fly at the 4 x 10 integer
     // positions the bilinear footprints of these rows touch, two columns per packed instruction.
     L3Tmpl T;
+    T.cIX = 0; T.cIY = 0;
     int s11 = 0, s12 = 0, s22 = 0;
     {
         const int r0 = 3 * sub;
@@ -366,7 +398,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 const int k = x + 1;                                // pixel pair (p[x+1], p[x+2]) of image rows j+1 (top), j+2 (bottom)
                 const uint32_t pt = (k & 1) ? odd_pair(et[(k >> 1) + 1], et[k >> 1]) : et[k >> 1];
                 const uint32_t pb = (k & 1) ? odd_pair(eb[(k >> 1) + 1], eb[k >> 1]) : eb[k >> 1];
-                iv[x] = dot2(pt, W01, dot2z(pb, W23));             // rounded and packed by round9_pair below
+                iv[x] = dot2(pt, W01, dot2r(pb, W23));             // + 256: shifted and packed by shr9_pair below
                 const uint32_t xt = (x & 1) ? odd_pair(dxt[(x >> 1) + 1], dxt[x >> 1]) : dxt[x >> 1];   // (d[x], d[x+1]) of rows j, j+1
                 const uint32_t xb = (x & 1) ? odd_pair(dxb[(x >> 1) + 1], dxb[x >> 1]) : dxb[x >> 1];
                 const uint32_t yt = (x & 1) ? odd_pair(dyt[(x >> 1) + 1], dyt[x >> 1]) : dyt[x >> 1];
@@ -374,20 +406,22 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 xv[x] = dot2(xt, W01, dot2(xb, W23, 1 << 13)) >> 14;
                 yv[x] = dot2(yt, W01, dot2(yb, W23, 1 << 13)) >> 14;
             }
-            iv[WIN] = 0; xv[WIN] = 0; yv[WIN] = 0;
+            iv[WIN] = 256; xv[WIN] = 0; yv[WIN] = 0;                    // (the pad pixel's derivatives are 0: its I never counts)
 #pragma unroll
             for (int t = 0; t < 5; t++) {
-                T.I[j][t] = round9_pair(iv[2 * t], iv[2 * t + 1]);
+                const uint32_t Ipair = shr9_pair(iv[2 * t], iv[2 * t + 1]);
                 T.X[j][t] = pack_lo16(xv[2 * t], xv[2 * t + 1]);
                 T.Y[j][t] = pack_lo16(yv[2 * t], yv[2 * t + 1]);
                 s11 = dot2(T.X[j][t], T.X[j][t], s11);
                 s12 = dot2(T.X[j][t], T.Y[j][t], s12);
                 s22 = dot2(T.Y[j][t], T.Y[j][t], s22);
+                T.cIX = dot2(Ipair, T.X[j][t], T.cIX);              // |I dI| <= 8160 * 4080, 27 pixels: < 2^30
+                T.cIY = dot2(Ipair, T.Y[j][t], T.cIY);
             }
         };
         uint32_t E0[6], E1[6], E2[6], E3[6], DXa[5], DYa[5], DXb[5], DYb[5];
         if (OV2_LK3_KO & 4) {
-            for (int j = 0; j < L3_RPL; j++) for (int t = 0; t < 5; t++) { T.I[j][t] = slot[4 * r0 + j * 5 + t]; T.X[j][t] = T.I[j][t] >> 1; T.Y[j][t] = T.I[j][t] >> 2; }
+            for (int j = 0; j < L3_RPL; j++) for (int t = 0; t < 5; t++) { T.X[j][t] = slot[4 * r0 + j * 5 + t] >> 1; T.Y[j][t] = T.X[j][t] >> 1; }
             s11 = s22 = 1 << 28; s12 = 0;
         } else {
         load_row(0, E0); load_row(1, E1); load_row(2, E2);
@@ -404,9 +438,9 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         }
     }
     // per-lane partials: 27 * 4080^2 = 4.5e8 < 2^31
-    const float A11 = (float)l3_sum3_exact(s11, sub) * FLT_SCALE;
-    const float A12 = (float)l3_sum3_exact(s12, sub) * FLT_SCALE;
-    const float A22 = (float)l3_sum3_exact(s22, sub) * FLT_SCALE;
+    const float A11 = l3_sum3_f32(s11, sub) * FLT_SCALE;
+    const float A12 = l3_sum3_f32(s12, sub) * FLT_SCALE;
+    const float A22 = l3_sum3_f32(s22, sub) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
     if (prm.flags & OV2_LK_GET_MIN_EIGENVALS) st.err = minEig;
@@ -457,23 +491,24 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                     P[m][1] = odd_pair(P[m][2], P[m][0]); P[m][3] = odd_pair(P[m][4], P[m][2]);
                     P[m][5] = odd_pair(P[m][6], P[m][4]); P[m][7] = odd_pair(P[m][8], P[m][6]);
                 }
-                int sb1 = 0, sb2 = 0;
+                // sum (J - I) dI = sum J dI - sum I dI: the accumulators start at minus the template's constants; every partial
+                // sum is  sum_done (J - I) dI - sum_rest I dI,  |.| <= 27 * 8160 * 4080 = 9e8 < 2^30
+                int sb1 = -T.cIX, sb2 = -T.cIY;
 #pragma unroll
                 for (int j = 0; j < L3_RPL; j++) {
                     int v[WIN + 1];
 #pragma unroll
-                    for (int x = 0; x < WIN; x++) v[x] = dot2(P[j][x], W01, dot2z(P[j + 1][x], W23));
+                    for (int x = 0; x < WIN; x++) v[x] = dot2(P[j][x], W01, dot2r(P[j + 1][x], W23));
                     v[WIN] = 0;
 #pragma unroll
                     for (int t = 0; t < 5; t++) {
-                        const uint32_t diff = pk_sub(round9_pair(v[2 * t], v[2 * t + 1]), T.I[j][t]);
-                        sb1 = dot2(diff, T.X[j][t], sb1);
-                        sb2 = dot2(diff, T.Y[j][t], sb2);
+                        const uint32_t Jpair = shr9_pair(v[2 * t], v[2 * t + 1]);
+                        sb1 = dot2(Jpair, T.X[j][t], sb1);
+                        sb2 = dot2(Jpair, T.Y[j][t], sb2);
                     }
                 }
-                // |diff * dI| <= 8160*4080 -> per-lane partial < 27 * 3.33e7 = 9e8 < 2^31
-                const float b1 = (float)l3_sum3_exact(sb1, sub) * FLT_SCALE;
-                const float b2 = (float)l3_sum3_exact(sb2, sub) * FLT_SCALE;
+                const float b1 = l3_sum3_f32(sb1, sub) * FLT_SCALE;
+                const float b2 = l3_sum3_f32(sb2, sub) * FLT_SCALE;
                 const float dx = (A12 * b2 - A22 * b1) * D;
                 const float dy = (A12 * b1 - A11 * b2) * D;
                 nextx += dx; nexty += dy;

@@ -207,6 +207,18 @@ int ov2_tracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, ov2_tracker 
         else (void)hipGetLastError();
     }
     t->graph_ok = cfg->use_graph != 0;
+    if (t->graph_ok) {
+        // Both per-parity graphs are captured HERE, before the caller's other threads exist (the reference constructs everything in
+        // SlamManager's constructor, ov2slam.cpp:91-113, before its threads start).  Capturing lazily inside the first two
+        // track_frame calls raced with the mapper thread: while this stream was in capture, hipStreamWaitEvent on another context
+        // for a pyramid event last recorded on this stream failed with "dependency created on uncaptured work in another stream".
+        OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));                    // the memsets above
+        for (int parity = 0; parity < 2 && t->graph_ok; parity++) {
+            const int rcg = capture_graph(t, parity);
+            if (rcg == OV2_EUNSUPPORTED) t->graph_ok = false;                    // stream cannot be captured: plain enqueue per frame
+            else if (rcg != OV2_OK) { tracker_free(t); return rcg; }
+        }
+    }
     *out = t;
     return OV2_OK;
 }

@@ -30,11 +30,12 @@ D_EUROC = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
 
 
 def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use_graph=True, do_stereo=True, ba_problems=None,
-               distortion=D_EUROC, ba_policy="newest"):
+               distortion=None, ba_policy="newest"):
     """seq: batch.SyntheticSequence (stereo=True for do_stereo).  ba_problems: list of flat local-BA problems (cycled, one
     localBA per keyframe) or None.  ba_policy: "newest" = the reference's estimator (only the last queued keyframe is optimised
     when several wait, estimator.cpp:195-205), "all" = every keyframe gets its localBA (equal work for CPU / GPU comparisons).
-    ctx = context A; contexts B and C are created on the same device.
+    distortion: coefficients of both cameras for computeKeypoint / the epipolar gate (None: the synthetic views are ideal pinhole
+    images; D_EUROC costs the same kernels a few more instructions).  ctx = context A; contexts B and C are created on the same device.
     Returns a dict of counters and times (seconds)."""
     from . import Context
     rng = np.random.default_rng(seq.seed + 17)
@@ -125,12 +126,13 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
         st["detect_calls"] += 1; st["keyframes"] += 1
         if len(new):
             kps = np.concatenate([kps, new]); age = np.concatenate([age, np.zeros(len(new), np.int32)])
+        noise = rng.normal(0, 1.0, kps.shape).astype(np.float32)            # (drawn in every mode: same random stream with and without stereo)
         if do_stereo:
             unpx, _ = calL.computeKeypoints(kps, want_bv=True)
             hp = (age > 0).astype(np.uint8)                                  # keypoints with a map point: right-image prior (:402-413)
             p3 = kps.copy()
             p3[:, 0] -= np.float32(seq.disparity)
-            p3 += rng.normal(0, 1.0, p3.shape).astype(np.float32)
+            p3 += noise
             kf_consumed[f] = threading.Event()
             map_q.put((f, trk.cur_pyr, seq.right_frame(f), kps.copy(), unpx, p3, hp))
         elif ba_problems:
