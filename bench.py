@@ -75,9 +75,12 @@ def make_inputs(seqs, seed):
         c, s = np.cos(-t1), np.sin(-t1)
         return np.stack([c * dx - s * dy + cx, s * dx + c * dy + cy], 1)
 
-    kps = np.zeros((NF, seqs, NKPS, 2), np.float32)
+    # transition t of the ping-pong walk over the views (0 -> 1 -> ... -> NF -> NF-1 -> ... -> 0 -> ...): 2*NF transitions per cycle,
+    # every frame's `prev` pyramid is the previous step's `cur` -- no view is ever pre-processed twice in a row
+    kps = np.zeros((2 * NF, seqs, NKPS, 2), np.float32)
     pri = np.zeros_like(kps)
-    for f in range(NF):
+    for f in range(2 * NF):
+        va, vb = walk_view(f), walk_view(f + 1)
         for s in range(seqs):
             k = synth.grid_keypoints(W, H, CELL, rng)[:NKPS]
             if len(k) < NKPS:
@@ -85,8 +88,14 @@ def make_inputs(seqs, seed):
                 k = np.concatenate([k, extra.astype(np.float32)])
             rng.shuffle(k)
             kps[f, s] = k
-            pri[f, s] = flow(k.astype(np.float64), f, f + 1) + rng.normal(0, 1.5, k.shape)
+            pri[f, s] = flow(k.astype(np.float64), va, vb) + rng.normal(0, 1.5, k.shape)
     return views, kps, pri
+
+
+def walk_view(i):
+    """view shown at step i of the ping-pong walk over the NF + 1 views"""
+    k = i % (2 * NF)
+    return k if k <= NF else 2 * NF - k
 
 
 def lk_algorithmic_bytes(iters, visits, npts):
@@ -599,10 +608,11 @@ def main():
     vp = lambda t: C.c_void_p(t.data_ptr())
     # pre-marshalled arguments: nothing but ctypes calls inside the timed loop
     a_img = [vp(frames_d[f]) for f in range(NF + 1)]
-    a_k = [vp(kps_d[f]) for f in range(NF)]
-    a_kB = [vp(kps_d[f][:, N_PASS_A:]) for f in range(NF)]
-    a_p = [vp(pri_work[f]) for f in range(NF)]
-    a_pB = [vp(pri_work[f][:, N_PASS_A:]) for f in range(NF)]
+    NT = 2 * NF                                                  # transitions of the ping-pong walk over the views
+    a_k = [vp(kps_d[f]) for f in range(NT)]
+    a_kB = [vp(kps_d[f][:, N_PASS_A:]) for f in range(NT)]
+    a_p = [vp(pri_work[f]) for f in range(NT)]
+    a_pB = [vp(pri_work[f][:, N_PASS_A:]) for f in range(NT)]
     a_st, a_stB, a_stats, a_nA, a_nB = vp(status_d), vp(status_d[:, N_PASS_A:]), vp(stats_d), vp(nA_d), vp(nB_d)
     hp = [p.h_pyr for p in pyrs]
     fb, build_clahe = lib.ov2_fb_klt_d, lib.ov2_pyr_build_clahe_d
@@ -613,12 +623,14 @@ def main():
         L.check(build_clahe(ctx.h, pyr, img, PITCH, PITCH * H, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1]))
 
     def step(i, timed):
-        f = i % NF
+        # One camera frame per sequence: EXACTLY one preprocessImage and the two fbKltTracking calls.  The views are walked
+        # back and forth (0, 1, .., NF, NF-1, .., 0, ..), so `prev` is always the previous step's `cur` pyramid (rounds 1-2
+        # restarted the cycle every NF steps with an extra preprocessImage of view 0 and a 60 MB restore of all priors:
+        # ~0.45 ms per step of bench bookkeeping inside the timed region).
+        f = i % NT
         prevp, curp = hp[i % 2], hp[(i + 1) % 2]
-        if f == 0:
-            pri_work.copy_(pri_d)                                   # priors are in/out: restore once per cycle
-            preprocess(prevp, a_img[0])
-        preprocess(curp, a_img[f + 1])                              # preprocessImage
+        pri_work[f].copy_(pri_d[f])                                 # priors are in/out: restore this transition's (10 MB)
+        preprocess(curp, a_img[walk_view(i + 1)])                   # preprocessImage
         if timed:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record(stream)
@@ -632,6 +644,7 @@ def main():
             e2.record(stream)
             lk_events.append((e0, e1, e2))
 
+    preprocess(hp[0], a_img[walk_view(0)])                          # the frame before the first step
     for i in range(args.warmup):
         step(i, False)
     torch.cuda.synchronize()

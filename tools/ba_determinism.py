@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Run-to-run reproducibility of the device LM solver.  H = F^T F, F^T b and W are accumulated with fp64 atomics in arrival
+order (ba.hip), so repeated solves of the same problem differ in the last bits; near chi2 = 5.9915 or a tolerance boundary an
+outlier verdict or the iteration count could in principle flip.  This measures it: N solves of config 4 (mono and stereo) and
+of the whole two-pass localBA, and for each: distinct (iterations, termination) tuples, distinct outlier sets, max pose spread."""
+import hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import ov2slam_amd
+from ov2slam_amd import synth, optimizer
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+ctx = ov2slam_amd.Context(0)
+out = {}
+for name, stereo in (("config4_mono", False), ("config4_stereo", True)):
+    pb = synth.make_ba_problem(50, 10000, 30, stereo=stereo, seed=42)
+    rp = optimizer.ResidentProblem(ctx, pb)
+    its, sets, ref, spread, cost = set(), set(), None, 0.0, set()
+    for i in range(N):
+        r = rp.solve()
+        its.add((r["iterations"], r["termination"]))
+        bad = (r["chi2"] > 5.9915) | (r["depthpos"] == 0)
+        sets.add(hashlib.sha1(np.packbits(bad).tobytes()).hexdigest())
+        cost.add(float(r["final_cost"]))
+        if ref is None:
+            ref = r["poses"].copy()
+        spread = max(spread, float(np.abs(r["poses"] - ref).max()))
+    # how close is the closest residual to the outlier threshold? (a flip needs a chi2 within the run-to-run noise of it)
+    margin = float(np.min(np.abs(r["chi2"] - 5.9915)))
+    out[name] = {"solves": N, "distinct_iteration_termination": len(its), "distinct_outlier_sets": len(sets), "distinct_final_costs": len(cost),
+                 "max_pose_spread_abs": spread, "closest_chi2_to_threshold": margin}
+    rp.close()
+pb = synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7)
+opt = optimizer.Optimizer(ctx)
+its, sets, ref, spread = set(), set(), None, 0.0
+M = max(50, N // 4)
+for i in range(M):
+    r = opt.localBA(pb, want_chi2=False)
+    its.add((r["iterations"], r["termination"], r["l2_done"]))
+    sets.add(hashlib.sha1(np.packbits(r["bad_obs"]).tobytes()).hexdigest())
+    if ref is None:
+        ref = r["poses"].copy()
+    spread = max(spread, float(np.abs(r["poses"] - ref).max()))
+out["localba_two_pass_window"] = {"solves": M, "distinct_iteration_termination": len(its), "distinct_outlier_sets": len(sets), "max_pose_spread_abs": spread}
+print(json.dumps(out, indent=1))
