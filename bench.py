@@ -343,6 +343,10 @@ def config2_stream(dev_index, n_frames=400, kf_every=5, with_cpu=True, cpu_frame
            "frames_per_s_every_keyframe_optimised": st_all["frames"] / st_all["seconds"],
            "ba_solves_every_keyframe_optimised": st_all["ba_solves"],
            "frames_per_s_front_end_alone": trk_only["frames"] / trk_only["seconds"],
+           "slam_thread_ms_per_frame": {"total": st["slam_thread_seconds"] / st["frames"] * 1e3,
+                                        "inside_library_calls": st["slam_library_s"] / st["frames"] * 1e3,
+                                        "note": "the rest is this Python driver (synthetic flow / priors / bookkeeping standing in for "
+                                                "the reference's CPU-side pose estimation and map updates)"},
            "keyframes": st["keyframes"], "mapper_ms_per_keyframe": st["mapper_busy_s"] / max(1, st["stereo_kfs"]) * 1e3,
            "slam_thread_waited_for_mapper_ms_total": st["slam_wait_for_mapper_s"] * 1e3,
            "stereo_ok_fraction": st["stereo_ok"] / max(1, st["stereo_kps"]),

@@ -347,8 +347,8 @@ void ov2_ba_default_options(ov2_ba_options *o);
  * r->chi2_last_eval / r->depthpos_last_eval that belong to inactive residual blocks are IN/OUT:
  * they keep the caller's values, like the cached chi2err_ of a removed residual block (N4).
  * Size: up to ~90 optimised keyframes the reduced system is solved in one work-group's LDS; beyond that (a loop-closure
- * fullBA) a sparse-W / HBM-Cholesky path takes over by itself, same results, up to 341 optimised keyframes; past that -- or
- * past ~90 when the problem also holds OV2_RES_PNP blocks -- OV2_EUNSUPPORTED with a message, nothing enqueued.      */
+ * fullBA) a sparse-W / HBM-Cholesky path takes over by itself, same results, up to 1024 optimised keyframes (the dense reduced
+ * system: 3 x 302 MB at the cap), with or without OV2_RES_PNP blocks; past that OV2_EUNSUPPORTED with a message, nothing enqueued. */
 int  ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
 
 /* Same solve on a problem that is already resident in HBM (upload once, solve many times from the
@@ -439,7 +439,7 @@ int ov2_structure_ba(ov2_ctx *ctx, const ov2_sba_problem *p, const ov2_ba_option
  * SetParameterBlockConstant keyframes (:397-407).  Same options, termination codes and N4 outputs as ov2_ba_solve; the
  * Schur complement eliminates 3x3 point blocks.  No shipped parameter file selects this branch; the inverse-depth form
  * (ov2_ba_solve) is what every preset runs.  Limit: ~90 optimised keyframes (OV2_EUNSUPPORTED beyond; the
- * large-problem path of ov2_ba_solve -- up to 341 optimised keyframes -- covers the inverse-depth form only).      */
+ * large-problem path of ov2_ba_solve -- up to 1024 optimised keyframes -- covers the inverse-depth form only).      */
 typedef struct {
     int n_kf;
     const double *poses;         /* 7*n_kf  [tx ty tz qx qy qz qw] of Twc, initial values      */

@@ -41,6 +41,7 @@
 #pragma clang fp contract(fast)   // BA parity is 1e-4 relative in fp64: FMA contraction is fine here
 
 #define BA_TILE 32
+#define BA_MAX_NFP 6144     // 1024 optimised keyframes: H, G, S are dense nfp x nfp doubles (302 MB each at the cap)
 
 struct BACtl {
     // accumulators
@@ -69,6 +70,8 @@ struct BADev {                    // device pointers + sizes (passed by value to
     // global atomics, the Schur complement is accumulated row block by row block in LDS from per-keyframe slot lists
     // (k_ba_schur_sparse) and the reduced system is factored by a multi-kernel blocked Cholesky on HBM (k_chol_*).
     int big, n_cw;
+    int lin_direct;               // big path with more optimised keyframes than the work-group's LDS can pre-aggregate (n_opt x 27 doubles:
+                                  // ~570): observer diagonal blocks and F^T b go to H / bf with global atomics as well
     double *cww;                  // 6*n_cw   slot values (zeroed by k_ba_zero_lin, filled by the lineariser)          [big]
     int *cw_ptr;                  // n_lm+1   slots of a landmark                                                      [big]
     int *cw_col;                  // n_cw     pose column of the slot
@@ -512,12 +515,14 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int n_opt = D.nf / 6, n_hao = BIG ? 0 : n_opt * 36;      // BIG: no per-wavefront anchor-observer cache, no dense W row
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool direct = BIG && D.lin_direct;                        // no LDS pre-aggregation of the observer blocks at all
+    const int n_agg = direct ? 0 : n_opt;
     double *wrow = (double *)smem_raw + wave * (BIG ? 0 : D.nfp);
     double *Hoo = (double *)smem_raw + 4 * (BIG ? 0 : D.nfp);
-    double *bo = Hoo + n_opt * 21;
-    double *Hao = bo + n_opt * 6 + wave * n_hao;
-    double *red = bo + n_opt * 6 + 4 * n_hao + wave * LIN_RED;
-    for (int e = threadIdx.x; e < n_opt * 27 + 4 * n_hao; e += blockDim.x) Hoo[e] = 0;
+    double *bo = Hoo + n_agg * 21;
+    double *Hao = bo + n_agg * 6 + wave * n_hao;
+    double *red = bo + n_agg * 6 + 4 * n_hao + wave * LIN_RED;
+    for (int e = threadIdx.x; e < n_agg * 27 + 4 * n_hao; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
 
     const int total_waves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
@@ -627,8 +632,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                         int t = 0;
                         for (int c = 0; c < 6; c++) {
                             atomicAdd(&slot[c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);
+                            if (direct) {
+                                atomicAdd(&D.bf[co + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+                                for (int d = c; d < 6; d++) atomicAdd(&D.H[(long long)(co + c) * D.nfp + co + d], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                            } else {
                             atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
                             for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                            }
                             if (cae >= 0)
                                 for (int d = 0; d < 6; d++) h_add_upper(D.H, D.nfp, cae + d, co + c, Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c]);
                         }
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     flush_anchor(cur_ca);
     __syncthreads();
     // block-shared observer blocks
-    for (int e = threadIdx.x; e < n_opt * 21; e += blockDim.x) {
+    for (int e = threadIdx.x; e < n_agg * 21; e += blockDim.x) {
         const double v = Hoo[e];
         if (v != 0.0) {
             const int ob = e / 21;
@@ -703,7 +713,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
             atomicAdd(&D.H[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
         }
     }
-    for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
+    for (int e = threadIdx.x; e < n_agg * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
     if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
@@ -717,7 +727,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize_po(BADev D)
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->need_lin) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int n_opt = D.nf / 6;
+    const bool direct = D.big && D.lin_direct;
+    const int n_opt = direct ? 0 : D.nf / 6;                          // (direct: nothing is pre-aggregated in LDS)
     double *Hoo = (double *)smem_raw, *bo = Hoo + n_opt * 21;
     for (int e = threadIdx.x; e < n_opt * 27; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
@@ -739,6 +750,11 @@ __global__ __launch_bounds__(256) void k_ba_linearize_po(BADev D)
         const int ob = co / 6;
         int t = 0;
         for (int c = 0; c < 6; c++) {
+            if (direct) {
+                atomicAdd(&D.bf[co + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
+                for (int d = c; d < 6; d++) atomicAdd(&D.H[(long long)(co + c) * D.nfp + co + d], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
+                continue;
+            }
             atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
             for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
         }
@@ -1504,23 +1520,28 @@ __global__ __launch_bounds__(256) void k_ba_zero_lin(BADev D)
 // First version: one wavefront per landmark, lane per entry, 36 E^2 GLOBAL atomics per landmark -- 44 ms per iteration on the
 // 50 KF x 10 k x 30 stereo problem, 50 ms at 300 KF (profiles/r2_ba_big_*).
 #define SS_WAVES 8
-__global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int nsplit)
+// Beyond 341 keyframes the row block no longer fits the LDS: blockIdx.y walks over column chunks of `ncol` columns (a multiple of
+// 6: pose blocks never straddle a chunk); a work-group accumulates the part [col0, col0 + ncol) of its row block only, and the
+// chunk that holds no column >= cmin exits at once.
+__global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int nsplit, int ncol)
 {
     const BACtl *ctl = D.ctl;
     if (ctl->done) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int nfp = D.nfp, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *R = (double *)smem_raw;                                       // 6 x nfp
-    double *wsc = R + 6 * nfp + wave * (64 * 6);                          // this wavefront's staged slot blocks
-    int *csc = (int *)(R + 6 * nfp + SS_WAVES * 64 * 6) + wave * 64;      // ... and their columns
+    const int col0 = blockIdx.y * ncol, ncw = min(ncol, nfp - col0);      // this work-group's columns
+    double *R = (double *)smem_raw;                                       // 6 x ncol
+    double *wsc = R + 6 * ncol + wave * (64 * 6);                         // this wavefront's staged slot blocks
+    int *csc = (int *)(R + 6 * ncol + SS_WAVES * 64 * 6) + wave * 64;     // ... and their columns
     __shared__ double vacc[6];
-    for (int e = threadIdx.x; e < 6 * nfp; e += blockDim.x) R[e] = 0;
+    const int ob = blockIdx.x / nsplit, sp = blockIdx.x - ob * nsplit, ci = 6 * ob;
+    const int cmin = (ci / BA_TILE) * BA_TILE - 5;                        // blocks entirely left of the row's first tile are never read
+    if (col0 + ncw + 5 <= cmin) return;                                   // (uniform) nothing of this chunk is ever read
+    for (int e = threadIdx.x; e < 6 * ncol; e += blockDim.x) R[e] = 0;
     if (threadIdx.x < 6) vacc[threadIdx.x] = 0;
     __syncthreads();
-    const int ob = blockIdx.x / nsplit, sp = blockIdx.x - ob * nsplit, ci = 6 * ob;
     const int b0 = D.kfl_ptr[ob], b1 = D.kfl_ptr[ob + 1];
     const int len = (b1 - b0 + nsplit - 1) / nsplit, e0 = b0 + sp * len, e1 = min(b1, e0 + len);
-    const int cmin = (ci / BA_TILE) * BA_TILE - 5;                        // blocks entirely left of the row's first tile are never read
     double dv = 0;
     for (int e = e0 + wave; e < e1; e += SS_WAVES) {
         const int slot = D.kfl_idx[e], lm = D.cw_lm[slot];
@@ -1528,7 +1549,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int 
         const int j0 = D.cw_ptr[lm], j1 = D.cw_ptr[lm + 1];
         double wi[6];
         for (int q = 0; q < 6; q++) wi[q] = D.cww[(long long)6 * slot + q];
-        if (lane < 6) dv += ce * D.cww[(long long)6 * slot + lane];
+        if (lane < 6 && blockIdx.y == 0) dv += ce * D.cww[(long long)6 * slot + lane];
         for (int jb = j0; jb < j1; jb += 64) {
             const int j = jb + lane, nj = min(64, j1 - jb);
             wave_lds_sync();
@@ -1539,20 +1560,20 @@ __global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int 
             wave_lds_sync();
             for (int t = lane; t < nj * 6; t += 64) {
                 const int jj = t / 6, b = t - jj * 6, cj = csc[jj];
-                if (cj < cmin) continue;
+                if (cj < cmin || cj < col0 || cj >= col0 + ncw) continue;
                 const double wjb = c * wsc[t];
-                double *dst = R + cj + b;
+                double *dst = R + (cj - col0) + b;
 #pragma unroll
-                for (int a = 0; a < 6; a++) atomicAdd(&dst[a * nfp], wi[a] * wjb);
+                for (int a = 0; a < 6; a++) atomicAdd(&dst[a * ncol], wi[a] * wjb);
             }
         }
     }
     if (lane < 6 && dv != 0.0) atomicAdd(&vacc[lane], dv);
     __syncthreads();
-    for (int e = threadIdx.x; e < 6 * nfp; e += blockDim.x) {
+    for (int e = threadIdx.x; e < 6 * ncol; e += blockDim.x) {
         const double v = R[e];
         if (v == 0.0) continue;
-        const int a = e / nfp, col = e - a * nfp;
+        const int a = e / ncol, col = col0 + (e - a * ncol);
         double *g = &D.G[(long long)(ci + a) * nfp + col];
         if (nsplit == 1) *g = v; else atomicAdd(g, v);
     }
@@ -2229,7 +2250,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     int n_opt = 0;
     for (int k = 0; k < p->n_kf; k++) pose_col[k] = p->kf_const[k] ? -1 : 6 * n_opt++;
     const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
-    OV2_REQUIRE(nfp <= 2048, OV2_EUNSUPPORTED, "more than 341 optimised keyframes: dense reduced system too large");
+    OV2_REQUIRE(nfp <= BA_MAX_NFP, OV2_EUNSUPPORTED, "more than 1024 optimised keyframes: dense reduced system too large");
     // the per-residual upload arrays are filled straight into the context's PINNED host scratch: the H2D copies below are then
     // real asynchronous DMA (from pageable std::vectors every copy went through the runtime's staging buffer, ~2.5 ms for the
     // 20 MB of a 590 k-block problem) and no 20 MB of vectors is allocated and zeroed per call
@@ -2283,12 +2304,9 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
         D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) ? 1 : 0;
         if (const char *e = getenv("OV2_BA_BIG")) D.big = e[0] == '1' ? 1 : D.big;       // force the path on small problems (tests)
-        if (n_po > 0) D.big = 0;                                                          // pose-only blocks: single-pose problems
-        if (!D.big && (lin_lds > 159 * 1024 || chol_lds > 150 * 1024)) {                  // before any device allocation or upload
-            delete dev;
-            ov2_set_error("too many optimised keyframes (%d) for a problem with pose-only blocks: they have no large-problem path (limit ~90)", n_opt);
-            return OV2_EUNSUPPORTED;
-        }
+        // beyond ~570 optimised keyframes the big-path linearisers cannot pre-aggregate the observer blocks in LDS either
+        D.lin_direct = (D.big && 8 * ((size_t)n_opt * 27 + 4 * (size_t)LIN_RED) + 64 > 159 * 1024) ? 1 : 0;
+        if (const char *e = getenv("OV2_BA_LIN_DIRECT")) D.lin_direct = (D.big && e[0] == '1') ? 1 : D.lin_direct;   // tests: force it on small problems
     }
     // big path: the slots of the sparse W (one per landmark and optimised keyframe seeing or anchoring it) and their per-keyframe lists
     std::vector<int> cw_ptr(p->n_lm + 1, 0), cw_col, cw_lm, res_cw, lm_cwa, kfl_ptr(n_opt + 1, 0), kfl_idx;
@@ -2552,7 +2570,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
 
     // size limits first: nothing is created or enqueued for a problem this path cannot solve
     const int n_opt = D.nf / 6;
-    const size_t lin_lds = D.big ? 8 * ((size_t)(D.nf / 6) * 27 + 4 * (size_t)LIN_RED) + 64
+    const size_t lin_lds = D.big ? 8 * ((D.lin_direct ? 0 : (size_t)(D.nf / 6) * 27) + 4 * (size_t)LIN_RED) + 64
                          : D.ldim == 3 ? 8 * (12 * (size_t)D.nfp + (size_t)n_opt * 27) + 64
                                        : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = D.big ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64       // k_chol_solve: scratch block + the solution vector
@@ -2637,7 +2655,11 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
     // k_ba_schur_sparse: ~512 work-groups; row block + per-wavefront staging (64 slot blocks + columns)
     const int ss_split = std::max(1, (512 + std::max(1, n_opt) - 1) / std::max(1, n_opt));
-    const size_t ss_lds = 8 * (6 * (size_t)D.nfp + (size_t)SS_WAVES * 64 * 6) + 4 * (size_t)SS_WAVES * 64 + 64;
+    // column chunk of the row block kept in LDS: all of it up to 2040 columns (340 pose blocks), else that many per chunk
+    int ss_ncol = D.nfp <= 2048 ? D.nfp : 2040;
+    if (const char *e = getenv("OV2_BA_SCHUR_CHUNK")) { const int v = atoi(e); if (v >= 6) ss_ncol = std::min(ss_ncol, v / 6 * 6); }   // tests
+    const int ss_chunks = (D.nfp + ss_ncol - 1) / ss_ncol;
+    const size_t ss_lds = 8 * (6 * (size_t)ss_ncol + (size_t)SS_WAVES * 64 * 6) + 4 * (size_t)SS_WAVES * 64 + 64;
 
     auto linearize = [&]() {
         if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks), dim3(256), lin_lds, s, D);
@@ -2646,7 +2668,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         }
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
-        if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (size_t)n_opt * 27 * 8 + 16, s, D);
+        if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (D.big && D.lin_direct ? 0 : (size_t)n_opt * 27 * 8) + 16, s, D);
         hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
     linearize();
@@ -2688,7 +2710,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
         OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
-        if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split);
+        if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split, ss_chunks), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split, ss_ncol);
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
         if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
         if (D.big) {

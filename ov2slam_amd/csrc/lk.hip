@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
 // status bit 0 = tracked, bit 1 = the prior-pass failed and the result comes from the full-pyramid retry.  The one
 // cross-keypoint decision of the reference (:225-230: fewer than a third of the prior tracks good -> retry from the
 // keypoints themselves) is taken by the host from the bit-1 count (ov2_tracker_klt, track.hip).
-// One wavefront per work-group (4 keypoints): a single frame has ~300 keypoints, so every wavefront gets a CU of its own.
+// One wavefront per work-group (1 or 4 keypoints, see the launcher): a single frame has ~300 keypoints on 1024 SIMDs.
 template <int WIN>
 __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams prm, int lvl_prior, int lvl_full,
                                                   const int *__restrict__ n_dev, const float2 *__restrict__ kps,
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
 {
     const int n = n_dev ? *n_dev : prm.n_max;
     const int r = threadIdx.x & 15;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    // blockDim.x = 64: four keypoints per wavefront; blockDim.x = 16: one (A/B switch of the launcher)
+    const int i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     if (i >= n) return;
     const float2 kp = kps[i];
     float2 pr = priors[i];
@@ -620,7 +621,12 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
                                err_th, fb_dist, 1, n_max);
     const int lf = prm.max_level;                                  // clamped to the pyramid like feature_tracker.cpp:50-52
     const int lp = lvl_prior > P.n_levels - 1 ? P.n_levels - 1 : (lvl_prior < 0 ? 0 : lvl_prior);
-    dim3 grid((n_max + 3) / 4), block(64);
+    // keypoints per wavefront: 4.  One per wavefront (OV2_TRACK_KPW=1, 16 active lanes) was measured for the single-frame case:
+    // no gain (0.107 vs 0.104 ms per frame, gpurun_out/r3i) -- the frame's latency is every keypoint's own dependent chain of
+    // level visits, not the wait for the slowest of four
+    int kpw = 4;
+    if (const char *e = getenv("OV2_TRACK_KPW")) kpw = e[0] == '1' ? 1 : 4;
+    dim3 grid((n_max + kpw - 1) / kpw), block(16 * kpw);
 #define OV2_TK(W) hipLaunchKernelGGL(k_track_klt<W>, grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
                                      (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up)
     switch (win) {

@@ -50,7 +50,7 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
     empty = np.zeros((0, 2), np.float32)
     st = dict(frames=0, tracked=0, attempted=0, err_sq_sum=0.0, err_n=0, detect_calls=0, keyframes=0, stereo_kfs=0, stereo_ok=0,
               stereo_kps=0, mapper_busy_s=0.0, ba_solves=0, ba_skipped_kfs=0, ba_iterations=0, ba_busy_s=0.0, ba_device_ms=0.0,
-              slam_wait_for_mapper_s=0.0)
+              slam_wait_for_mapper_s=0.0, slam_library_s=0.0)
     errors = []
     # ---- mapper thread -----------------------------------------------------------------------------------------------
     map_q = queue.Queue()
@@ -122,7 +122,9 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
 
     def keyframe(f, kps, age):
         """createKeyframe: detection tops the keypoint set up; the keyframe goes to the mapper."""
+        tl = time.perf_counter()
         new = fx.detectSingleScalePyr(trk.cur_pyr, cell, kps, roi)[:max(0, nbmaxkps - len(kps))]
+        st["slam_library_s"] += time.perf_counter() - tl
         st["detect_calls"] += 1; st["keyframes"] += 1
         if len(new):
             kps = np.concatenate([kps, new]); age = np.concatenate([age, np.zeros(len(new), np.int32)])
@@ -156,14 +158,18 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
             ev = kf_consumed.get(last_kf)
             if ev is not None and not ev.is_set():
                 tw = time.perf_counter(); ev.wait(); st["slam_wait_for_mapper_s"] += time.perf_counter() - tw
+        tl = time.perf_counter()
         out, sb, _ = trk.trackFrame(seq.frame(f), kps, pri, has_prior)
+        st["slam_library_s"] += time.perf_counter() - tl
         ok = (sb & 1).astype(bool)
         st["frames"] += 1; st["attempted"] += len(kps); st["tracked"] += int(ok.sum())
         if ok.any():
             d = out[ok].astype(np.float64) - gt[ok]
             st["err_sq_sum"] += float((d ** 2).sum()); st["err_n"] += int(ok.sum())
         kps, age = out[ok], age[ok] + 1
+        tl = time.perf_counter()
         calL.computeKeypoints(kps, want_bv=True)                             # Frame::updateKeypoint -> computeKeypoint (frame.cpp:246-254)
+        st["slam_library_s"] += time.perf_counter() - tl
         inside = (kps[:, 0] > 8) & (kps[:, 0] < w - 9) & (kps[:, 1] > 8) & (kps[:, 1] < h - 9)
         kps, age = kps[inside], age[inside]
         if f % kf_every == 0:

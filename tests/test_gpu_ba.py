@@ -270,6 +270,58 @@ def test_large_problem_path_matches_oracle(gpu_ctx, oracle, monkeypatch):
     assert np.array_equal(g["bad_obs"], s["bad_obs"]) and np.allclose(g["poses"], s["poses"], atol=1e-9)
 
 
+def _mixed_with_pnp(pb, pn, kf):
+    """the landmark problem `pb` plus the pose-only blocks of `pn` attached to keyframe `kf`"""
+    from tests.test_oracle_ba import np_T
+    n0, n1 = pb["n_res"], pn["n_res"]
+    T = np_T(pb["poses_gt"][kf]) @ np.linalg.inv(np_T(pn["poses_gt"][0]))
+    X = (T[:3, :3] @ pn["res_xyz"].T).T + T[:3, 3]
+    mix = dict(pb)
+    mix["n_res"] = n0 + n1
+    mix["res_type"] = np.concatenate([pb["res_type"], pn["res_type"]])
+    mix["res_kf"] = np.concatenate([pb["res_kf"], np.full(n1, kf, np.int32)])
+    mix["res_lm"] = np.concatenate([pb["res_lm"], pn["res_lm"]])
+    mix["res_uv"] = np.concatenate([pb["res_uv"], pn["res_uv"]])
+    mix["res_sigma"] = np.concatenate([pb["res_sigma"], pn["res_sigma"]])
+    mix["res_xyz"] = np.concatenate([np.zeros((n0, 3)), X])
+    return mix
+
+
+def test_large_problem_path_variants(gpu_ctx, oracle, monkeypatch):
+    """Round 3 extensions of the large-problem path, each forced onto small problems so that the oracle stays cheap:
+    pose-only (OV2_RES_PNP) blocks on the sparse-W path, the lineariser without LDS pre-aggregation of the observer blocks (what
+    runs beyond ~570 optimised keyframes) and the column-chunked sparse Schur complement (beyond 341 keyframes)."""
+    monkeypatch.setenv("OV2_BA_BIG", "1")
+    mix = _mixed_with_pnp(synth.make_ba_problem(8, 200, 5, stereo=True, seed=12), synth.make_pnp_problem(60, seed=4), 3)
+    _cmp(optimizer.solve(gpu_ctx, mix), oracle.ba_solve(mix), mix)
+    cases = ((12, 400, 8, True, 3), (40, 1200, 20, False, 5))
+    for env in (dict(OV2_BA_LIN_DIRECT="1"), dict(OV2_BA_SCHUR_CHUNK="36"), dict(OV2_BA_LIN_DIRECT="1", OV2_BA_SCHUR_CHUNK="96")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for n_kf, n_lm, obs, stereo, seed in cases:
+            pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
+            for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
+                g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+                r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
+                _cmp(g, r, pb)
+        _cmp(optimizer.solve(gpu_ctx, mix), oracle.ba_solve(mix), mix)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_more_than_341_keyframes_match_oracle(gpu_ctx, oracle):
+    """A loop-closure / offline fullBA over 360 keyframes (359 optimised: reduced system 2154 x 2154, beyond the 2048 columns one
+    LDS row block holds -- rounds 1-2 returned OV2_EUNSUPPORTED here): three LM iterations against the oracle (~4 s of CPU).
+    Problems with pose-only blocks take the same path (no longer capped at ~90 keyframes)."""
+    pb = synth.make_ba_problem(360, 3000, 8, stereo=True, seed=1)
+    g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, max_iter=3))
+    r = oracle.ba_solve(pb, oracle.ba_default_options(max_iter=3))
+    _cmp(g, r, pb)
+    assert g["final_cost"] < 0.5 * g["initial_cost"]
+    mix = _mixed_with_pnp(synth.make_ba_problem(120, 900, 6, stereo=False, seed=2), synth.make_pnp_problem(80, seed=5), 60)
+    _cmp(optimizer.solve(gpu_ctx, mix, optimizer.default_options(gpu_ctx.lib, max_iter=4)), oracle.ba_solve(mix, oracle.ba_default_options(max_iter=4)), mix)
+
+
 def test_too_many_keyframes_is_reported_for_point_landmarks(gpu_ctx):
     """The 3-D-point parameterisation has no large-problem path: beyond ~95 optimised keyframes ov2_xyz_ba_solve returns
     OV2_EUNSUPPORTED with a message, never a silent skip."""

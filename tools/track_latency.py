@@ -33,6 +33,9 @@ def run(label, use_graph, pinned, split=False, zc="1"):
     out[label] = {"median_ms": float(np.median(ts)), "mean_ms": float(ts.mean()), "p90_ms": float(np.percentile(ts, 90)),
                   "tracked": float((st & 1).mean()), "retried": int((st & 2).astype(bool).sum()), "graph": trk.uses_graph}
     trk.close(); ctx.close()
+os.environ["OV2_TRACK_KPW"] = "1"          # one keypoint per wavefront instead of four (A/B: no gain, lk.hip launcher comment)
+run("track_frame_graph_pinned_kpw1", True, True)
+del os.environ["OV2_TRACK_KPW"]
 run("track_frame_graph_pinned", True, True)
 run("track_frame_graph_pinned_blitcopies", True, True, zc="0")
 run("track_frame_graph_pageable", True, False)
