@@ -1537,6 +1537,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int 
     const int ob = blockIdx.x / nsplit, sp = blockIdx.x - ob * nsplit, ci = 6 * ob;
     const int cmin = (ci / BA_TILE) * BA_TILE - 5;                        // blocks entirely left of the row's first tile are never read
     if (col0 + ncw + 5 <= cmin) return;                                   // (uniform) nothing of this chunk is ever read
+    const bool own_v = ci >= col0 && ci < col0 + ncw;                     // W^T (c E^T b): added once, by the chunk of the diagonal block
     for (int e = threadIdx.x; e < 6 * ncol; e += blockDim.x) R[e] = 0;
     if (threadIdx.x < 6) vacc[threadIdx.x] = 0;
     __syncthreads();
@@ -1549,7 +1550,7 @@ __global__ __launch_bounds__(64 * SS_WAVES) void k_ba_schur_sparse(BADev D, int 
         const int j0 = D.cw_ptr[lm], j1 = D.cw_ptr[lm + 1];
         double wi[6];
         for (int q = 0; q < 6; q++) wi[q] = D.cww[(long long)6 * slot + q];
-        if (lane < 6 && blockIdx.y == 0) dv += ce * D.cww[(long long)6 * slot + lane];
+        if (lane < 6 && own_v) dv += ce * D.cww[(long long)6 * slot + lane];
         for (int jb = j0; jb < j1; jb += 64) {
             const int j = jb + lane, nj = min(64, j1 - jb);
             wave_lds_sync();
