@@ -591,6 +591,30 @@ static int ba_schur_solve(const ba_ws *w, const double *Df, const double *Dl, do
         const double inv = 1.0 / ete;
         ete_inv[lm] = inv; etb[lm] = g;
         /* S -= w^T inv w ; rhs -= w^T inv g */
+#ifdef ORC_FAST
+        /* speed baseline only (Makefile `fast`): the block rows are gathered contiguously and only the blocks on or below the
+         * diagonal -- all chol_lower reads -- are updated: half the flops, unit-stride inner loops the compiler vectorises */
+        {
+            double wc6[6 * 64], wv[6 * 64];
+            int ord[64];
+            const int ntc = nt > 64 ? 64 : nt;
+            for (int x = 0; x < ntc; x++) ord[x] = touched[x];
+            for (int x = 1; x < ntc; x++) { int v = ord[x], y = x; while (y > 0 && ord[y - 1] > v) { ord[y] = ord[y - 1]; y--; } ord[y] = v; }
+            for (int x = 0; x < ntc; x++)
+                for (int c = 0; c < 6; c++) { wv[6 * x + c] = wrow[ord[x] + c]; wc6[6 * x + c] = wv[6 * x + c] * inv; rhs[ord[x] + c] -= wc6[6 * x + c] * g; }
+            for (int x = 0; x < ntc; x++)
+                for (int c = 0; c < 6; c++) {
+                    const double wc = wc6[6 * x + c];
+                    double *Srow = S + (size_t)(ord[x] + c) * nf;
+                    for (int y = 0; y <= x; y++) {
+                        double *dst = Srow + ord[y];
+                        const double *wy = wv + 6 * y;
+                        for (int d = 0; d < 6; d++) dst[d] -= wc * wy[d];
+                    }
+                }
+            if (nt > 64) return -1;
+        }
+#else
         for (int x = 0; x < nt; x++)
             for (int c = 0; c < 6; c++) {
                 const double wc = wrow[touched[x] + c] * inv;
@@ -599,6 +623,7 @@ static int ba_schur_solve(const ba_ws *w, const double *Df, const double *Dl, do
                     for (int d = 0; d < 6; d++)
                         S[(size_t)(touched[x] + c) * nf + touched[y] + d] -= wc * wrow[touched[y] + d];
             }
+#endif
         for (int x = 0; x < nt; x++) flag[touched[x] / 6] = 0;
     }
     /* rows without an e-block (SchurEliminator::NoEBlockRowsUpdate): pose-only residual blocks */

@@ -58,6 +58,22 @@ def use_native():
     return "-O3 -march=native -ffp-contract=off"
 
 
+def use_fast():
+    """Switch this module to oracle/_fast/liboracle.so (`make fast`): the relaxed-floating-point, vectorisation-friendly build of
+    the same restatement.  A SPEED baseline (bench.py `cpu_baseline_simd`), never the checker: results agree with the strict
+    build to rounding only.  Returns the flags, or None when the build failed."""
+    global _lib
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nl = C.CDLL(os.path.join(_HERE, "_fast", "liboracle.so"))
+    except Exception:
+        return None
+    nl.orc_fb_klt.restype = C.c_int
+    nl.orc_lk_track.restype = C.c_int
+    _lib = nl
+    return "-O3 -march=native -ffast-math -ffp-contract=fast -funroll-loops -DORC_FAST (upper-triangle block Schur update)"
+
+
 def set_num_threads(n):
     """Threads of the persistent pool behind CLAHE / pyrDown / Scharr / LK (cv::setNumThreads)."""
     lib().orc_set_num_threads(int(n))
