@@ -485,7 +485,8 @@ def parity_check(dev_index, views, kps, pri):
     trk.close(); ctx.close()
     # the oracle (and therefore the HIP path) accumulates the LK sums in int64; stock OpenCV builds accumulate in float: the measured
     # distance on this frame pair (the 44 856-track campaign is profiles/r3_lk_acc_modes.json, tools/lk_acc_campaign.py)
-    acc = O.lk_acc_mode_report(O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS), prevp, kps[0, 0],
+    acc = O.lk_acc_mode_report(O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS),
+                               O.Pyramid(O.clahe(views[1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS), kps[0, 0],
                                np.where(hp[:, None] > 0, pri[0, 0], kps[0, 0]).astype(np.float32))
     worst = {"status_flips": max(m["status_flips"] for m in acc["modes"].values()),
              "max_abs_dpx": max(m["max_abs_dpx"] for m in acc["modes"].values()), "points": acc["points"]}
