@@ -213,6 +213,13 @@ int  ov2_tracker_klt(ov2_tracker *t, const float *kps_xy_h, const float *prior_x
 int  ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, const float *kps_xy_h,
                              const float *prior_xy_h, const uint8_t *has_prior_h, int n, int klt_use_prior,
                              float *out_xy_h, uint8_t *status_h, int *p3p_req);
+/* Optional: Frame::computeKeypoint (src/frame.cpp:246-254: undistortImagePoint + bearing vector, what the reference runs for
+ * every keypoint it has just tracked, updateKeypoint) for every output position INSIDE the per-frame enqueue -- no second call,
+ * no second synchronisation.  Same arguments as ov2_compute_keypoints.  Re-captures the tracker's graphs: call it right after
+ * ov2_tracker_create.  ov2_tracker_last_keypoints then returns unpx (2 floats) / bv (3 doubles) per keypoint of the LAST
+ * ov2_tracker_klt / _track_frame call (entries of untracked keypoints are computed from their last forward position).   */
+int  ov2_tracker_set_calibration(ov2_tracker *t, int model, const double K[4], const double *D, int nD, const double iK[9]);
+int  ov2_tracker_last_keypoints(const ov2_tracker *t, int n, float *unpx_xy_h, double *bv_xyz_h);
 /* the tracker's pyramids (valid until the next preprocess), e.g. for createKeyframe / stereo matching / detection */
 const ov2_pyr *ov2_tracker_cur_pyr(const ov2_tracker *t);
 const ov2_pyr *ov2_tracker_prev_pyr(const ov2_tracker *t);

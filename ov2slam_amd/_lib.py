@@ -160,6 +160,8 @@ SIGNATURES = {
     "ov2_tracker_preprocess": (_i, [_vp, _vp, _i]),
     "ov2_tracker_klt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "ov2_tracker_track_frame": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "ov2_tracker_set_calibration": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "ov2_tracker_last_keypoints": (_i, [_vp, _i, _vp, _vp]),
     "ov2_tracker_cur_pyr": (_vp, [_vp]),
     "ov2_tracker_prev_pyr": (_vp, [_vp]),
     "ov2_tracker_frames": (_i, [_vp]),

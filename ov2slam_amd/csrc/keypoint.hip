@@ -14,9 +14,10 @@
 #pragma clang fp contract(off)
 
 __global__ __launch_bounds__(256) void k_compute_keypoints(KpCalib c, const float2 *__restrict__ px, int n,
-                                                           float2 *__restrict__ unpx, double *__restrict__ bv)
+                                                           float2 *__restrict__ unpx, double *__restrict__ bv, const int *__restrict__ n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);                        // the tracker's graph is launched over its capacity: the count lives on the device
     if (i >= n) return;
     const float2 p = px[i];
     const float2 u = kp_undistort_image_point(c, p);
@@ -47,6 +48,14 @@ int ov2_kp_calib(int model, const double K[4], const double *D, int nD, const do
     return OV2_OK;
 }
 
+// launcher for track.hip: Frame::computeKeypoint of the tracker's output positions inside its per-frame enqueue
+int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d)
+{
+    hipLaunchKernelGGL(k_compute_keypoints, dim3((n_max + 255) / 256), dim3(256), 0, s, c, (const float2 *)px_d, n_max, (float2 *)unpx_d, bv_d, n_dev);
+    OV2_HIP_CHECK(hipGetLastError());
+    return OV2_OK;
+}
+
 extern "C" {
 
 int ov2_compute_keypoints_d(ov2_ctx *ctx, int model, const double K[4], const double *D, int nD, const double iK[9],
@@ -60,7 +69,7 @@ int ov2_compute_keypoints_d(ov2_ctx *ctx, int model, const double K[4], const do
     if (rc != OV2_OK) return rc;
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_compute_keypoints, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, c, (const float2 *)px_xy_d, n,
-                       (float2 *)unpx_xy_d, bv_xyz_d);
+                       (float2 *)unpx_xy_d, bv_xyz_d, (const int *)nullptr);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
@@ -83,7 +92,7 @@ int ov2_compute_keypoints(ov2_ctx *ctx, int model, const double K[4], const doub
     memcpy(hs + o_px, px_xy_h, 8 * (size_t)n);
     OV2_HIP_CHECK(hipMemcpyAsync(ds + o_px, hs + o_px, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_compute_keypoints, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, c, (const float2 *)(ds + o_px), n,
-                       (float2 *)(ds + o_un), bv_xyz_h ? (double *)(ds + o_bv) : nullptr);
+                       (float2 *)(ds + o_un), bv_xyz_h ? (double *)(ds + o_bv) : nullptr, (const int *)nullptr);
     OV2_HIP_CHECK(hipGetLastError());
     OV2_HIP_CHECK(hipMemcpyAsync(hs + o_un, ds + o_un, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     if (bv_xyz_h) OV2_HIP_CHECK(hipMemcpyAsync(hs + o_bv, ds + o_bv, 24 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -8,7 +8,11 @@
 //   reference and the retry of lost prior tracks in one launch, lk.hip) -> D2H result block (one copy) -> ONE sync.
 // With use_graph the whole sequence is captured once per pyramid parity and replayed with hipGraphLaunch.
 #include "common.hpp"
+#include "keypoint_dev.hpp"
 #include <new>
+#include <vector>
+
+int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d);
 
 struct ov2_tracker {
     ov2_ctx *ctx = nullptr;
@@ -23,7 +27,12 @@ struct ov2_tracker {
     uint8_t *kblk = nullptr;       // what the LK kernel dereferences: dblk, or the device alias of the pinned block (zero_copy)
     bool zero_copy = false;        // the kernel reads the 9 KB keypoint block from / writes its results to pinned host memory
                                    // itself: two blit kernels (5.5 us each + their launch gaps) cost more than the PCIe round trip
-    size_t o_n, o_kps, o_pri, o_flg, in_bytes, o_out, o_st, o_it, blk_bytes;
+    size_t o_n, o_kps, o_pri, o_flg, in_bytes, o_out, o_st, o_it, o_unpx, o_bv, blk_bytes;
+    // optional Frame::computeKeypoint (undistorted pixel + bearing, src/frame.cpp:246-254) of every output position in the same enqueue
+    bool has_calib = false;
+    KpCalib calib;
+    std::vector<float> last_unpx;      // 2 per keypoint of the last klt / track_frame call
+    std::vector<double> last_bv;       // 3 per keypoint
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     bool graph_ok = false;
 };
@@ -59,6 +68,11 @@ static int enqueue_klt(ov2_tracker *t, const ov2_pyr *prev, const ov2_pyr *cur)
                                   (const float *)(k + t->o_pri), k + t->o_flg, (float *)(k + t->o_out),
                                   k + t->o_st, (int *)(k + t->o_it));
     if (rc != OV2_OK) return rc;
+    if (t->has_calib) {
+        rc = ov2_launch_compute_keypoints(ctx->stream, t->calib, (const float *)(k + t->o_out), c.n_max, (const int *)(k + t->o_n),
+                                          (float *)(k + t->o_unpx), (double *)(k + t->o_bv));
+        if (rc != OV2_OK) return rc;
+    }
     if (!t->zero_copy)
         OV2_HIP_CHECK(hipMemcpyAsync(t->hblk + t->o_out, t->dblk + t->o_out, t->blk_bytes - t->o_out, hipMemcpyDeviceToHost, ctx->stream));
     return OV2_OK;
@@ -83,10 +97,15 @@ static void stage_points(ov2_tracker *t, const float *kps, const float *pri, con
 }
 
 // after a synchronisation: copy the m results of the staged chunk out
-static void collect_chunk(ov2_tracker *t, int m, float *out_xy, uint8_t *status)
+static void collect_chunk(ov2_tracker *t, int m, float *out_xy, uint8_t *status, int off = 0)
 {
     memcpy(out_xy, t->hblk + t->o_out, 8 * (size_t)m);
     memcpy(status, t->hblk + t->o_st, (size_t)m);
+    if (t->has_calib) {
+        if (t->last_unpx.size() < 2 * (size_t)(off + m)) { t->last_unpx.resize(2 * (size_t)(off + m)); t->last_bv.resize(3 * (size_t)(off + m)); }
+        memcpy(t->last_unpx.data() + 2 * (size_t)off, t->hblk + t->o_unpx, 8 * (size_t)m);
+        memcpy(t->last_bv.data() + 3 * (size_t)off, t->hblk + t->o_bv, 24 * (size_t)m);
+    }
 }
 
 // A frame may carry more keypoints than the tracker's capacity (the reference only prunes at the next keyframe,
@@ -101,7 +120,7 @@ static int klt_overflow_chunks(ov2_tracker *t, const float *kps, const float *pr
         const int rc = enqueue_klt(t, t->pyr[t->cur ^ 1], t->pyr[t->cur]);
         if (rc != OV2_OK) return rc;
         OV2_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
-        collect_chunk(t, m, out_xy + 2 * (size_t)off, status + off);
+        collect_chunk(t, m, out_xy + 2 * (size_t)off, status + off, off);
     }
     return OV2_OK;
 }
@@ -132,6 +151,18 @@ static int apply_p3p_rule(ov2_tracker *t, const float *kps, const uint8_t *has_p
             for (int j = 0; j < m; j++) {
                 out_xy[2 * idx[j]] = p2[2 * j]; out_xy[2 * idx[j] + 1] = p2[2 * j + 1];
                 status[idx[j]] = (uint8_t)(2 | (s2[j] ? 1 : 0));
+            }
+            if (t->has_calib) {                                        // their undistorted pixels / bearings follow the new positions
+                std::vector<float> u2(2 * (size_t)m);
+                std::vector<double> b2(3 * (size_t)m);
+                const KpCalib &kc = t->calib;
+                const double Kk[4] = {kc.fx, kc.fy, kc.cx, kc.cy};
+                const int rck = ov2_compute_keypoints(t->ctx, kc.model, Kk, kc.nD ? kc.k : nullptr, kc.nD, kc.iK, p2.data(), m, u2.data(), b2.data());
+                if (rck != OV2_OK) return rck;
+                for (int j = 0; j < m; j++) {
+                    memcpy(&t->last_unpx[2 * (size_t)idx[j]], &u2[2 * (size_t)j], 8);
+                    memcpy(&t->last_bv[3 * (size_t)idx[j]], &b2[3 * (size_t)j], 24);
+                }
             }
         }
     }
@@ -187,7 +218,8 @@ int ov2_tracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, ov2_tracker 
     t->img_bytes = t->img_pitch * (size_t)cfg->h;
     const size_t nm = (size_t)cfg->n_max;
     t->o_n = 0; t->o_kps = 16; t->o_pri = t->o_kps + 8 * nm; t->o_flg = t->o_pri + 8 * nm; t->in_bytes = up16(t->o_flg + nm);
-    t->o_out = t->in_bytes; t->o_st = t->o_out + 8 * nm; t->o_it = up16(t->o_st + nm); t->blk_bytes = t->o_it + 4 * nm;
+    t->o_out = t->in_bytes; t->o_st = t->o_out + 8 * nm; t->o_it = up16(t->o_st + nm);
+    t->o_unpx = up16(t->o_it + 4 * nm); t->o_bv = up16(t->o_unpx + 8 * nm); t->blk_bytes = t->o_bv + 24 * nm;
     const size_t lut_bytes = cfg->use_clahe ? (size_t)cfg->tiles_x * cfg->tiles_y * 256 : 256;
     hipError_t e = hipHostMalloc((void **)&t->himg, t->img_bytes + 256, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&t->hblk, t->blk_bytes, hipHostMallocMapped);
@@ -224,6 +256,35 @@ int ov2_tracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, ov2_tracker 
 }
 
 void ov2_tracker_destroy(ov2_tracker *t) { tracker_free(t); }
+
+int ov2_tracker_set_calibration(ov2_tracker *t, int model, const double K[4], const double *D, int nD, const double iK[9])
+{
+    OV2_REQUIRE(t, OV2_EINVAL, "NULL tracker");
+    KpCalib c;
+    const int rc = ov2_kp_calib(model, K, D, nD, iK, c);
+    if (rc != OV2_OK) return rc;
+    OV2_HIP_CHECK(hipSetDevice(t->ctx->device));
+    OV2_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
+    t->calib = c; t->has_calib = true;
+    // the per-frame enqueue gained a kernel: the captured graphs are stale (call this right after ov2_tracker_create, before the
+    // caller's other threads run: see the note on graph capture there)
+    for (int i = 0; i < 2; i++) if (t->gexec[i]) { (void)hipGraphExecDestroy(t->gexec[i]); t->gexec[i] = nullptr; }
+    for (int parity = 0; parity < 2 && t->graph_ok; parity++) {
+        const int rcg = capture_graph(t, parity);
+        if (rcg == OV2_EUNSUPPORTED) t->graph_ok = false;
+        else if (rcg != OV2_OK) return rcg;
+    }
+    return OV2_OK;
+}
+
+int ov2_tracker_last_keypoints(const ov2_tracker *t, int n, float *unpx_xy_h, double *bv_xyz_h)
+{
+    OV2_REQUIRE(t && t->has_calib, OV2_EINVAL, "no calibration set on this tracker");
+    OV2_REQUIRE(n >= 0 && 2 * (size_t)n <= t->last_unpx.size(), OV2_EINVAL, "more keypoints than the last tracking call returned");
+    if (unpx_xy_h) memcpy(unpx_xy_h, t->last_unpx.data(), 8 * (size_t)n);
+    if (bv_xyz_h) memcpy(bv_xyz_h, t->last_bv.data(), 24 * (size_t)n);
+    return OV2_OK;
+}
 
 uint8_t *ov2_tracker_image_buffer(ov2_tracker *t, int *stride)
 {

@@ -302,6 +302,19 @@ class VisualFrontEndTracker:
                                                  int(bool(klt_use_prior)), _ptr(out), _ptr(st), C.byref(p3p)))
         return out, st, bool(p3p.value)
 
+    def setCalibration(self, calib):
+        """calib: CameraCalibration.  From now on every kltTracking / trackFrame also computes Frame::computeKeypoint (undistorted
+        pixel + bearing vector) of its output positions in the same enqueue: lastKeypoints().  Call right after construction."""
+        L.check(self.lib.ov2_tracker_set_calibration(self.h_trk, calib.model, _ptr(calib.K), _ptr(calib.D) if calib.D is not None else None,
+                                                     0 if calib.D is None else len(calib.D), _ptr(calib.iK)))
+
+    def lastKeypoints(self, n, want_bv=True):
+        """(unpx (n,2) float32, bv (n,3) float64 or None) of the n keypoints of the last kltTracking / trackFrame call."""
+        unpx = np.empty((n, 2), np.float32)
+        bv = np.empty((n, 3), np.float64) if want_bv else None
+        L.check(self.lib.ov2_tracker_last_keypoints(self.h_trk, int(n), _ptr(unpx), _ptr(bv) if want_bv else None))
+        return unpx, bv
+
     @property
     def cur_pyr(self):
         return _PyrView(self.ctx, C.c_void_p(self.lib.ov2_tracker_cur_pyr(self.h_trk)), self.w, self.h, self.win)

@@ -86,6 +86,19 @@ public:
         return true;
     }
 
+    // Frame::computeKeypoint (undistorted pixel + bearing, src/frame.cpp:246-254) for every tracked position inside the per-frame
+    // enqueue: call once after construction with the LEFT camera's model (CameraCalibration: K_, Dcv_, iK_), then read the results
+    // of the last kltTracking / trackFrame with lastKeypoints (row-major: unpx 2 floats, bv 3 doubles per keypoint)
+    bool setCalibration(int model, const double K[4], const double *D, int nD, const double iK[9])
+    {
+        return ov2_tracker_set_calibration(t_, model, K, D, nD, iK) == OV2_OK;
+    }
+    bool lastKeypoints(size_t n, std::vector<Point2f> &vunpx, std::vector<double> &vbv) const
+    {
+        vunpx.resize(n); vbv.resize(3 * n);
+        return n == 0 || ov2_tracker_last_keypoints(t_, (int)n, &vunpx[0].x, vbv.data()) == OV2_OK;
+    }
+
     // cur_pyr_ / prev_pyr_ for createKeyframe, stereo matching and the device-resident detectors (valid until the next frame)
     const ov2_pyr *curPyr() const { return ov2_tracker_cur_pyr(t_); }
     const ov2_pyr *prevPyr() const { return ov2_tracker_prev_pyr(t_); }

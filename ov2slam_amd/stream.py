@@ -3,7 +3,7 @@ reference schedules it -- the front-end on the SLAM thread, stereo matching on t
 thread, concurrently (/root/reference/src/ov2slam.cpp:116-237, src/mapper.cpp:62-95, src/estimator.cpp:33-98):
 
     SLAM thread      (context A)  per frame   preprocessImage + kltTracking       ov2_tracker_track_frame
-                                              Frame::computeKeypoint              ov2_compute_keypoints (tracked keypoints)
+                                              + Frame::computeKeypoint            (same enqueue: ov2_tracker_set_calibration)
                                   keyframe    MapManager::extractKeypoints        ov2_detect_singlescale_d on cur_pyr_
                                               computeKeypoint of the new points   ov2_compute_keypoints
                                               Mapper::addNewKf                    (queue, FIFO: mapper.cpp:784-809)
@@ -46,6 +46,7 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
     trk = frontend.VisualFrontEndTracker(ctx, w, h, nbmaxkps=2 * nbmaxkps, use_graph=use_graph)
     fx = frontend.FeatureExtractor(ctx, dmaxquality=0.001)
     calL = frontend.CameraCalibration(ctx, "pinhole", *K_EUROC, D=distortion)
+    trk.setCalibration(calL)                         # Frame::computeKeypoint of the tracked positions rides in the per-frame enqueue
     roi = (5, 5, w - 10, h - 10)
     empty = np.zeros((0, 2), np.float32)
     st = dict(frames=0, tracked=0, attempted=0, err_sq_sum=0.0, err_n=0, detect_calls=0, keyframes=0, stereo_kfs=0, stereo_ok=0,
@@ -166,10 +167,10 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
         if ok.any():
             d = out[ok].astype(np.float64) - gt[ok]
             st["err_sq_sum"] += float((d ** 2).sum()); st["err_n"] += int(ok.sum())
-        kps, age = out[ok], age[ok] + 1
         tl = time.perf_counter()
-        calL.computeKeypoints(kps, want_bv=True)                             # Frame::updateKeypoint -> computeKeypoint (frame.cpp:246-254)
-        st["slam_library_s"] += time.perf_counter() - tl
+        unpx_all, bv_all = trk.lastKeypoints(len(out))                       # Frame::updateKeypoint -> computeKeypoint (frame.cpp:246-254):
+        st["slam_library_s"] += time.perf_counter() - tl                     # computed by the same enqueue, this is a host copy
+        kps, age = out[ok], age[ok] + 1
         inside = (kps[:, 0] > 8) & (kps[:, 0] < w - 9) & (kps[:, 1] > 8) & (kps[:, 1] < h - 9)
         kps, age = kps[inside], age[inside]
         if f % kf_every == 0:

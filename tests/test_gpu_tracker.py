@@ -179,3 +179,32 @@ def test_more_keypoints_than_capacity(gpu_ctx, oracle, use_graph):
     with pytest.raises(ValueError):
         trk.kltTracking(kps, pri, hp[:10])
     trk.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_tracker_computes_keypoints_in_the_same_enqueue(gpu_ctx, oracle, use_graph):
+    """ov2_tracker_set_calibration: Frame::computeKeypoint (undistorted pixel + bearing, /root/reference/src/frame.cpp:246-254) of
+    every output position inside the per-frame enqueue == ov2_compute_keypoints == the oracle, bit for bit (pinhole model); also
+    beyond the launch capacity (chunks) and after the p3p re-run."""
+    K = (458.654, 457.296, 367.215, 248.375); D = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+    w, h = 752, 480
+    views, flow = _sequence(w, h, 3, seed=21)
+    rng = np.random.default_rng(6)
+    for cap in (512, 100):
+        trk = ov2slam_amd.VisualFrontEndTracker(gpu_ctx, w, h, use_clahe=True, fclahe_val=CLIP, nbmaxkps=cap, use_graph=use_graph)
+        cal = ov2slam_amd.CameraCalibration(gpu_ctx, "pinhole", *K, D=D)
+        trk.setCalibration(cal)
+        trk.trackFrame(views[0], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+        kps, pri, hp = _points(w, h, flow, 0, rng, 1.0, bad_frac=0.25)
+        out, st, _ = trk.trackFrame(views[1], kps, pri, hp)
+        unpx, bv = trk.lastKeypoints(len(out))
+        runpx, rbv = oracle.compute_keypoints(oracle.CAM_PINHOLE, K, D, cal.iK, out)
+        assert np.array_equal(_bits(unpx), _bits(runpx)) and np.array_equal(bv.view(np.uint64), rbv.view(np.uint64))
+        # the p3p rule re-runs lost prior tracks from their keypoints: their keypoints follow the new positions
+        kps, pri, hp = _points(w, h, flow, 1, rng, 1.0, frac_prior=0.8, bad_frac=0.95, bad_sigma=60.0)
+        out, st, p3p = trk.trackFrame(views[2], kps, pri, hp)
+        assert p3p
+        unpx, bv = trk.lastKeypoints(len(out))
+        runpx, rbv = oracle.compute_keypoints(oracle.CAM_PINHOLE, K, D, cal.iK, out)
+        assert np.array_equal(_bits(unpx), _bits(runpx)) and np.array_equal(bv.view(np.uint64), rbv.view(np.uint64))
+        trk.close()
