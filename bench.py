@@ -792,6 +792,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          # what actually limits the kernel (SQ counters of the committed PMC pass): the fraction of SIMD issue slots in use
                          "limiter": limiter_kind, "valu_issue_frac": valu_frac,
+                         # what THIS data layout allows: the kernel gathers 16-byte row segments (12.5 % of every 128-byte line), the
+                         # same pattern without arithmetic tops out at 5.2 TB/s of line traffic (profiles/lk_traffic.json) and the
+                         # kernel's lines are 1.66x its algorithmic bytes: 5.2 / 1.66 / 8 -- 0.60 needs a tiled layout
+                         "layout_ceiling_frac": 0.39 if traffic is None else min(1.0, 5.2e12 / (traffic / (bytes_total / max(1, n_launch))) / (HBM_PEAK_GBS * 1e9)),
                          "avg_launch_ms": avg_launch_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": bytes_total / max(1, n_launch),
                          "gn_iterations": iters, "patch_builds": visits},
