@@ -352,6 +352,29 @@ def config2_stream(dev_index, n_frames=400, kf_every=5, with_cpu=True, cpu_frame
     st_all = stream.run_stream(ctx, seq, kf_every=kf_every, ba_problems=windows, ba_policy="all")
     trk_only = stream.run_stream(ctx, batch.SyntheticSequence("MH_01", n_frames, seed=1000, tex=tex), kf_every=kf_every, do_stereo=False)
     ctx.close()
+    # the same cycle with a native host: tools/stream_driver.cpp (three std::threads, nothing but the C ABI)
+    native = None
+    try:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            exe = stream.build_native_driver(td)
+            case = os.path.join(td, "case.bin")
+            stream.write_case(case, seq, windows, kf_every=kf_every)
+            stream.run_native(exe, case, "newest")
+            n1, n2 = stream.run_native(exe, case, "newest"), stream.run_native(exe, case, "all")
+        native = {"frames_per_s": n1["frames"] / n1["seconds"], "frames_per_s_slam_thread": n1["frames"] / n1["slam_thread_seconds"],
+                  "frames_per_s_every_keyframe_optimised": n2["frames"] / n2["seconds"],
+                  "slam_thread_ms_per_frame": {"total": n1["slam_thread_seconds"] / n1["frames"] * 1e3, "inside_library_calls": n1["slam_library_s"] / n1["frames"] * 1e3},
+                  "mapper_ms_per_keyframe": n1["mapper_busy_s"] / max(1, n1["stereo_kfs"]) * 1e3,
+                  "ba_solves": n1["ba_solves"], "ba_keyframes_skipped_while_busy": n1["ba_skipped_kfs"],
+                  "ba_wall_ms_per_solve": n1["ba_busy_s"] / max(1, n1["ba_solves"]) * 1e3,
+                  "ba_iters_per_s_wall": n1["ba_iterations"] / max(1e-9, n1["ba_busy_s"]),
+                  "tracked_fraction": n1["tracked"] / max(1, n1["attempted"]), "track_rmse_px": (n1["err_sq_sum"] / max(1, n1["err_n"])) ** 0.5,
+                  "stereo_ok_fraction": n1["stereo_ok"] / max(1, n1["stereo_kps"]),
+                  "host": "tools/stream_driver.cpp: g++ -O2, three std::threads on three contexts, the C ABI only (own random stream: same statistics, "
+                          "not the same noise as the Python driver)"}
+    except Exception as e:
+        native = {"error": repr(e)[-400:]}
     out = {"workload": "one synthetic EuRoC-sized stereo stream, %d frames, keyframe every %d: SLAM thread (track_frame + computeKeypoint "
                        "per frame, detectSingleScale + computeKeypoint per keyframe) / mapper thread (right CLAHE + pyramid + "
                        "ov2_stereo_match per keyframe) / estimator thread (ov2_local_ba on a 25 KF x 3000 landmark x 12 obs stereo "
@@ -373,6 +396,12 @@ def config2_stream(dev_index, n_frames=400, kf_every=5, with_cpu=True, cpu_frame
            "ba_iters_per_s_wall": st["ba_iterations"] / max(1e-9, st["ba_busy_s"]),
            "tracked_fraction": st["tracked"] / max(1, st["attempted"]),
            "track_rmse_px": (st["err_sq_sum"] / max(1, st["err_n"])) ** 0.5}
+    out["python_driver_frames_per_s"] = out["frames_per_s"]
+    out["native_host"] = native
+    if native and "frames_per_s" in native:
+        # the figures of record are the native host's: the reference's host side is C++ too
+        out["frames_per_s"] = native["frames_per_s"]
+        out["frames_per_s_every_keyframe_optimised"] = native["frames_per_s_every_keyframe_optimised"]
     if with_cpu:
         out["cpu_same_schedule"] = cpu_stream(batch.SyntheticSequence("MH_01", cpu_frames, seed=1000, tex=tex, stereo=True), windows, kf_every)
         c = out["cpu_same_schedule"]

@@ -193,3 +193,49 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
     if errors:
         raise errors[0]
     return st
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the same keyframe cycle driven by a native host program (tools/stream_driver.cpp): what a C++ front-end achieves when the
+# per-frame bookkeeping is not numpy
+# ---------------------------------------------------------------------------------------------------------------------
+def write_case(path, seq, ba_problems, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5):
+    """Case file of tools/stream_driver.cpp (little-endian, see read_case there)."""
+    import struct
+    ba_problems = ba_problems or []
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i", seq.w, seq.h, len(seq.views), seq.n_frames, kf_every, cell, nbmaxkps, len(ba_problems)))
+        f.write(struct.pack("<2d", seq.disparity, prior_sigma))
+        f.write(np.asarray(seq.offs, np.float64).tobytes())
+        for v in seq.views:
+            f.write(np.ascontiguousarray(v, np.uint8).tobytes())
+        for v in seq.right_views:
+            f.write(np.ascontiguousarray(v, np.uint8).tobytes())
+        for pb in ba_problems:
+            f.write(struct.pack("<3i", int(pb["n_kf"]), int(pb["n_lm"]), int(pb["n_res"])))
+            for name, dt in (("poses", np.float64), ("kf_const", np.uint8), ("invdepth", np.float64), ("lm_anchor_kf", np.int32),
+                             ("lm_anchor_uv", np.float64), ("res_type", np.uint8), ("res_kf", np.int32), ("res_lm", np.int32),
+                             ("res_uv", np.float64), ("res_sigma", np.float64), ("calib_l", np.float64), ("calib_r", np.float64),
+                             ("T_rl", np.float64)):
+                f.write(np.ascontiguousarray(pb[name], dt).tobytes())
+
+
+def build_native_driver(out_dir):
+    """g++ tools/stream_driver.cpp against the in-tree library; returns the executable's path (raises on failure)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(out_dir, "stream_driver")
+    libdir = os.path.join(root, "ov2slam_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(root, "tools", "stream_driver.cpp"), "-I", root,
+                           "-L", libdir, "-lov2slam_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def run_native(exe, case_path, ba_policy="newest"):
+    import json
+    import subprocess
+    r = subprocess.run([exe, case_path, ba_policy], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("stream_driver failed (%d): %s" % (r.returncode, r.stderr[-500:]))
+    return json.loads(r.stdout.strip().splitlines()[-1])

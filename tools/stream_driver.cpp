@@ -1,0 +1,262 @@
+// stream_driver.cpp -- the keyframe cycle of ov2slam_amd/stream.py as a native host program: one camera, three
+// std::threads on three contexts of one GPU, nothing but the C ABI of include/ov2slam_hip.h.
+//
+// The reference's host side is C++ (src/ov2slam.cpp:116-237 SLAM thread, src/mapper.cpp:62-95 mapper thread,
+// src/estimator.cpp:33-98 estimator thread); the Python driver of bench.py spends more time in numpy bookkeeping than in
+// the library (0.24 ms per frame, 0.16 of it library calls).  This program runs the same schedule with the bookkeeping a C++
+// front-end would have: per frame ov2_tracker_track_frame (preprocessImage + kltTracking + computeKeypoint), per keyframe
+// ov2_detect_singlescale_d + ov2_compute_keypoints, the mapper's ov2_pyr_build_clahe_h + ov2_stereo_match (FIFO), the
+// estimator's ov2_local_ba (newest keyframe only, estimator.cpp:195-205, or every keyframe with policy "all").
+// What the reference computes on the CPU around these calls (pose estimation, triangulation, the map walk that builds the BA
+// problem) is stood in for by synthetic ground truth: priors come from the true flow, BA windows are pre-generated.
+//
+//   stream_driver <case file> [policy: newest|all]         -> one JSON line on stdout
+// Case file (written by bench.py: little-endian, see read_case): image size, views, flow offsets, BA problems.
+// Build: g++ -O2 -std=c++17 -pthread tools/stream_driver.cpp -I. -Lov2slam_amd -lov2slam_hip -Wl,-rpath,<dir>
+#include "include/ov2slam_hip.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+static void die(const char *what, int rc) { fprintf(stderr, "stream_driver: %s failed (%d): %s\n", what, rc, ov2_last_error()); exit(3); }
+#define CK(call) do { const int rc_ = (call); if (rc_ != OV2_OK) die(#call, rc_); } while (0)
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct BAProb {
+    int n_kf, n_lm, n_res;
+    std::vector<double> poses, invdepth, lm_auv, res_uv, res_sigma;
+    std::vector<uint8_t> kf_const, res_type;
+    std::vector<int> lm_anchor, res_kf, res_lm;
+    double calib_l[4], calib_r[4], T_rl[7];
+};
+struct Case {
+    int w, h, n_views, n_frames, kf_every, cell, nbmaxkps;
+    double disparity, prior_sigma;
+    std::vector<std::vector<uint8_t>> left, right;
+    std::vector<double> offs;                      // n_views x (ox, oy, theta)
+    std::vector<BAProb> ba;
+};
+
+template <class T> static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "stream_driver: short case file\n"); exit(2); } }
+static Case read_case(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    Case c;
+    int hdr[8]; rd(f, hdr, 8);
+    c.w = hdr[0]; c.h = hdr[1]; c.n_views = hdr[2]; c.n_frames = hdr[3]; c.kf_every = hdr[4]; c.cell = hdr[5]; c.nbmaxkps = hdr[6];
+    const int n_ba = hdr[7];
+    double dd[2]; rd(f, dd, 2); c.disparity = dd[0]; c.prior_sigma = dd[1];
+    c.offs.resize(3 * (size_t)c.n_views); rd(f, c.offs.data(), c.offs.size());
+    for (int side = 0; side < 2; side++)
+        for (int v = 0; v < c.n_views; v++) {
+            std::vector<uint8_t> img((size_t)c.w * c.h); rd(f, img.data(), img.size());
+            (side ? c.right : c.left).push_back(std::move(img));
+        }
+    for (int b = 0; b < n_ba; b++) {
+        BAProb p; int s[3]; rd(f, s, 3); p.n_kf = s[0]; p.n_lm = s[1]; p.n_res = s[2];
+        p.poses.resize(7 * (size_t)p.n_kf); rd(f, p.poses.data(), p.poses.size());
+        p.kf_const.resize(p.n_kf); rd(f, p.kf_const.data(), p.kf_const.size());
+        p.invdepth.resize(p.n_lm); rd(f, p.invdepth.data(), p.invdepth.size());
+        p.lm_anchor.resize(p.n_lm); rd(f, p.lm_anchor.data(), p.lm_anchor.size());
+        p.lm_auv.resize(2 * (size_t)p.n_lm); rd(f, p.lm_auv.data(), p.lm_auv.size());
+        p.res_type.resize(p.n_res); rd(f, p.res_type.data(), p.res_type.size());
+        p.res_kf.resize(p.n_res); rd(f, p.res_kf.data(), p.res_kf.size());
+        p.res_lm.resize(p.n_res); rd(f, p.res_lm.data(), p.res_lm.size());
+        p.res_uv.resize(2 * (size_t)p.n_res); rd(f, p.res_uv.data(), p.res_uv.size());
+        p.res_sigma.resize(p.n_res); rd(f, p.res_sigma.data(), p.res_sigma.size());
+        rd(f, p.calib_l, 4); rd(f, p.calib_r, 4); rd(f, p.T_rl, 7);
+        c.ba.push_back(std::move(p));
+    }
+    fclose(f);
+    return c;
+}
+
+static int view_index(const Case &c, int f) { const int n = c.n_views, k = f % (2 * n - 2); return k < n ? k : 2 * n - 2 - k; }
+// ground-truth position in frame fb of pixel (x, y) of frame fa (batch.SyntheticSequence.flow)
+static void flow(const Case &c, int fa, int fb, float x, float y, double &ox, double &oy)
+{
+    const double cx = (c.w - 1) / 2.0, cy = (c.h - 1) / 2.0;
+    const double *a = &c.offs[3 * (size_t)view_index(c, fa)], *b = &c.offs[3 * (size_t)view_index(c, fb)];
+    double dx = x - cx, dy = y - cy;
+    double co = cos(a[2]), si = sin(a[2]);
+    const double tx = co * dx - si * dy + cx + a[0], ty = si * dx + co * dy + cy + a[1];
+    dx = tx - cx - b[0]; dy = ty - cy - b[1];
+    co = cos(-b[2]); si = sin(-b[2]);
+    ox = co * dx - si * dy + cx; oy = si * dx + co * dy + cy;
+}
+
+struct KfJob { int f; const ov2_pyr *left; const uint8_t *right_img; std::vector<float> kps, unpx, p3; std::vector<uint8_t> hp; };
+template <class T> struct Queue {
+    std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false;
+    void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(v)); } cv.notify_one(); }
+    void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+    bool pop(T &v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); return true; }
+    bool try_pop(T &v) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); return true; }
+};
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: stream_driver <case> [newest|all]\n"); return 2; }
+    if (ov2_version() != OV2_ABI_VERSION) { fprintf(stderr, "stream_driver: header / library ABI mismatch\n"); return 2; }
+    const Case C = read_case(argv[1]);
+    const bool ba_all = argc > 2 && !strcmp(argv[2], "all");
+    const int w = C.w, h = C.h;
+    const double K[4] = {458.654, 457.296, 367.215, 248.375};
+    const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[1], -K[3] / K[1], 0, 0, 1};
+    ov2_ctx *ctxA, *ctxB, *ctxC;
+    CK(ov2_ctx_create(0, &ctxA)); CK(ov2_ctx_create(0, &ctxB)); CK(ov2_ctx_create(0, &ctxC));
+    ov2_tracker_config tc{};
+    tc.w = w; tc.h = h; tc.win = 9; tc.nklt_pyr_lvl = 3; tc.prior_pyr_lvl = 1; tc.max_iter = 30; tc.eps = 0.01f; tc.err_th = 30.f; tc.fb_dist = 0.5f;
+    tc.use_clahe = 1; tc.clahe_clip = 3.0; tc.tiles_x = w / 50; tc.tiles_y = h / 50; tc.n_max = 2 * C.nbmaxkps; tc.use_graph = 1;
+    ov2_tracker *trk;
+    CK(ov2_tracker_create(ctxA, &tc, &trk));
+    CK(ov2_tracker_set_calibration(trk, OV2_CAM_PINHOLE, K, nullptr, 0, iK));
+    ov2_pyr *pyrR;
+    CK(ov2_pyr_create(ctxB, w, h, 9, 3, 1, &pyrR));
+
+    // ---- counters -------------------------------------------------------------------------------------------------
+    long frames = 0, tracked = 0, attempted = 0, err_n = 0, keyframes = 0, stereo_kfs = 0, stereo_ok = 0, stereo_kps = 0;
+    long ba_solves = 0, ba_skipped = 0, ba_iterations = 0;
+    double err_sq = 0, mapper_busy = 0, ba_busy = 0, ba_device_ms = 0, slam_wait = 0, slam_lib = 0;
+
+    Queue<std::unique_ptr<KfJob>> map_q;
+    Queue<int> ba_q;
+    std::mutex done_m; std::condition_variable done_cv; int mapper_done_kf = -1;       // last keyframe frame index the mapper has consumed
+
+    std::thread mapper([&] {
+        std::unique_ptr<KfJob> j;
+        while (map_q.pop(j)) {
+            const double t0 = now();
+            const int n = (int)j->hp.size();
+            CK(ov2_pyr_build_clahe_h(ctxB, pyrR, j->right_img, w, 3.0, w / 50, h / 50));                      // asynchronous
+            std::vector<float> right(2 * (size_t)n); std::vector<uint8_t> ok(n);
+            CK(ov2_stereo_match(ctxB, j->left, pyrR, 9, 3, 30, 0.01f, 30.f, 0.5f, 1, nullptr, OV2_CAM_PINHOLE, K, nullptr, 0, j->kps.data(),
+                                j->unpx.data(), j->p3.data(), j->hp.data(), n, right.data(), ok.data()));
+            mapper_busy += now() - t0;
+            { std::lock_guard<std::mutex> l(done_m); mapper_done_kf = j->f; }
+            done_cv.notify_all();
+            stereo_kfs++; stereo_kps += n;
+            for (int i = 0; i < n; i++) stereo_ok += ok[i];
+            if (!C.ba.empty()) ba_q.push(j->f);
+        }
+        ba_q.close();
+    });
+    std::thread estimator([&] {
+        int f, nsolve = 0;
+        while (ba_q.pop(f)) {
+            if (!ba_all) { int g; while (ba_q.try_pop(g)) { ba_skipped++; f = g; } }      // only the last received keyframe (estimator.cpp:195-205)
+            const BAProb &p = C.ba[nsolve++ % C.ba.size()];
+            ov2_ba_problem P{};
+            P.n_kf = p.n_kf; P.poses = p.poses.data(); P.kf_const = p.kf_const.data(); P.n_lm = p.n_lm; P.invdepth = p.invdepth.data();
+            P.lm_anchor_kf = p.lm_anchor.data(); P.lm_anchor_uv = p.lm_auv.data(); P.n_res = p.n_res; P.res_type = p.res_type.data();
+            P.res_kf = p.res_kf.data(); P.res_lm = p.res_lm.data(); P.res_uv = p.res_uv.data(); P.res_sigma = p.res_sigma.data();
+            memcpy(P.calib_l, p.calib_l, 32); memcpy(P.calib_r, p.calib_r, 32); memcpy(P.T_rl, p.T_rl, 56);
+            ov2_local_ba_options O; ov2_local_ba_default_options(&O);
+            std::vector<double> poses(7 * (size_t)p.n_kf), lam(p.n_lm);
+            std::vector<uint8_t> bad(p.n_res);
+            ov2_local_ba_result R{};
+            R.poses_out = poses.data(); R.invdepth_out = lam.data(); R.bad_obs = bad.data();
+            const double t0 = now();
+            CK(ov2_local_ba(ctxC, &P, &O, &R));
+            ba_busy += now() - t0;
+            ba_solves++; ba_iterations += R.iterations[0] + R.iterations[1]; ba_device_ms += R.solve_ms[0] + R.solve_ms[1];
+        }
+    });
+
+    // ---- SLAM thread ----------------------------------------------------------------------------------------------
+    std::mt19937 rng(12345);
+    std::normal_distribution<float> gauss(0.f, 1.f);
+    std::vector<float> kps, pri, out, unpx; std::vector<double> bv; std::vector<uint8_t> hp, st; std::vector<int> age;
+    const int roi[4] = {5, 5, w - 10, h - 10};
+    double quality = 0.001;
+    auto keyframe = [&](int f) {
+        const int ncur = (int)age.size(), cap = 2 * (w / C.cell) * (h / C.cell);
+        std::vector<float> nw(2 * (size_t)cap); int nn = 0;
+        double tl = now();
+        CK(ov2_detect_singlescale_d(ctxA, ov2_tracker_cur_pyr(trk), 0, C.cell, kps.data(), ncur, roi, &quality, 1, nw.data(), &nn));
+        slam_lib += now() - tl;
+        keyframes++;
+        nn = std::max(0, std::min(nn, C.nbmaxkps - ncur));
+        kps.insert(kps.end(), nw.begin(), nw.begin() + 2 * (size_t)nn);
+        age.insert(age.end(), nn, 0);
+        const int n = (int)age.size();
+        auto j = std::make_unique<KfJob>();
+        j->f = f; j->left = ov2_tracker_cur_pyr(trk); j->right_img = C.right[view_index(C, f)].data();
+        j->kps = kps; j->unpx.resize(2 * (size_t)n); j->p3.resize(2 * (size_t)n); j->hp.resize(n);
+        tl = now();
+        if (n) CK(ov2_compute_keypoints(ctxA, OV2_CAM_PINHOLE, K, nullptr, 0, iK, kps.data(), n, j->unpx.data(), nullptr));   // createKeyframe: new keypoints
+        slam_lib += now() - tl;
+        for (int i = 0; i < n; i++) {
+            j->hp[i] = age[i] > 0;
+            j->p3[2 * i] = kps[2 * i] - (float)C.disparity + gauss(rng); j->p3[2 * i + 1] = kps[2 * i + 1] + gauss(rng);
+        }
+        map_q.push(std::move(j));
+    };
+    const double t0 = now();
+    CK(ov2_tracker_track_frame(trk, C.left[0].data(), w, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr));
+    frames = 1;
+    keyframe(0);
+    int last_kf = 0;
+    for (int f = 1; f < C.n_frames; f++) {
+        const int n = (int)age.size();
+        pri.resize(2 * (size_t)n); hp.resize(n); out.resize(2 * (size_t)n); st.resize(n);
+        std::vector<double> gt(2 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            flow(C, f - 1, f, kps[2 * i], kps[2 * i + 1], gt[2 * i], gt[2 * i + 1]);
+            hp[i] = age[i] > 0;
+            pri[2 * i] = hp[i] ? (float)(gt[2 * i] + C.prior_sigma * gauss(rng)) : kps[2 * i];
+            pri[2 * i + 1] = hp[i] ? (float)(gt[2 * i + 1] + C.prior_sigma * gauss(rng)) : kps[2 * i + 1];
+        }
+        if (f == last_kf + 2) {                 // this frame overwrites the pyramid the keyframe of two frames ago shares with the mapper
+            const double tw = now();
+            std::unique_lock<std::mutex> l(done_m);
+            done_cv.wait(l, [&] { return mapper_done_kf >= last_kf; });
+            slam_wait += now() - tw;
+        }
+        int p3p = 0;
+        double tl = now();
+        CK(ov2_tracker_track_frame(trk, C.left[view_index(C, f)].data(), w, kps.data(), pri.data(), hp.data(), n, 1, out.data(), st.data(), &p3p));
+        unpx.resize(2 * (size_t)n); bv.resize(3 * (size_t)n);
+        if (n) CK(ov2_tracker_last_keypoints(trk, n, unpx.data(), bv.data()));      // Frame::computeKeypoint of the tracked positions (same enqueue)
+        slam_lib += now() - tl;
+        frames++; attempted += n;
+        std::vector<float> nk; std::vector<int> na;
+        for (int i = 0; i < n; i++) {
+            if (!(st[i] & 1)) continue;
+            tracked++;
+            const double ex = out[2 * i] - gt[2 * i], ey = out[2 * i + 1] - gt[2 * i + 1];
+            err_sq += ex * ex + ey * ey; err_n++;
+            const float x = out[2 * i], y = out[2 * i + 1];
+            if (x > 8 && x < w - 9 && y > 8 && y < h - 9) { nk.push_back(x); nk.push_back(y); na.push_back(age[i] + 1); }
+        }
+        kps.swap(nk); age.swap(na);
+        if (f % C.kf_every == 0) { keyframe(f); last_kf = f; }
+    }
+    CK(ov2_ctx_sync(ctxA));
+    const double slam_s = now() - t0;
+    map_q.close();
+    mapper.join(); estimator.join();
+    const double total_s = now() - t0;
+    printf("{\"frames\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, \"slam_library_s\": %.6f, \"tracked\": %ld, \"attempted\": %ld, "
+           "\"err_sq_sum\": %.6f, \"err_n\": %ld, \"keyframes\": %ld, \"stereo_kfs\": %ld, \"stereo_ok\": %ld, \"stereo_kps\": %ld, \"mapper_busy_s\": %.6f, "
+           "\"ba_solves\": %ld, \"ba_skipped_kfs\": %ld, \"ba_iterations\": %ld, \"ba_busy_s\": %.6f, \"ba_device_ms\": %.4f, \"slam_wait_for_mapper_s\": %.6f, "
+           "\"ba_policy\": \"%s\"}\n",
+           frames, total_s, slam_s, slam_lib, tracked, attempted, err_sq, err_n, keyframes, stereo_kfs, stereo_ok, stereo_kps, mapper_busy,
+           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest");
+    ov2_tracker_destroy(trk); ov2_pyr_destroy(pyrR);
+    ov2_ctx_destroy(ctxA); ov2_ctx_destroy(ctxB); ov2_ctx_destroy(ctxC);
+    return 0;
+}
