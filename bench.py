@@ -248,7 +248,7 @@ def run_config5(ctx, rank, world, scale, dry=False):
     from ov2slam_amd import batch
     counts, plan = config5_plan(world, scale)
     mine = plan[rank]
-    loc = dict(frames=0.0, seconds=0.0, tracked=0.0, attempted=0.0, ate_sq_sum=0.0, ate_n=0.0, sequences=float(len(mine)),
+    loc = dict(frames=0.0, seconds=0.0, tracked=0.0, attempted=0.0, ate_sq_sum=0.0, ate_n=0.0, sequences=float(len(mine)), host_native=0.0,
                keyframes=0.0, stereo_ok=0.0, stereo_kps=0.0, ba_solves=0.0, ba_iterations=0.0, ba_seconds=0.0, ba_skipped=0.0)
     if dry:
         loc["frames"] = float(sum(counts[s] for s in mine)); loc["seconds"] = 1.0 + 0.25 * rank
@@ -260,13 +260,28 @@ def run_config5(ctx, rank, world, scale, dry=False):
         names = sorted(batch.EUROC_FRAMES)
         seqs = [batch.SyntheticSequence(s, counts[s], seed=1000 + names.index(s), tex=tex, stereo=True) for s in mine]   # generation untimed
         windows = [synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7 + i) for i in range(2)]    # local-BA windows (optimizer.cpp:150-188)
-        for sq in seqs:
-            st = batch.run_sequence(ctx, sq, ba_problems=windows)
+        # host side: the native driver (tools/stream_driver.cpp, what a C++ front-end costs) when g++ is there, else the Python loop
+        import tempfile
+        from ov2slam_amd import stream
+        td = tempfile.TemporaryDirectory()
+        try:
+            exe = stream.build_native_driver(td.name)
+            cases = []
+            for i, sq in enumerate(seqs):
+                cases.append(os.path.join(td.name, "case%d.bin" % i)); stream.write_case(cases[-1], sq, windows)
+            stream.run_native(exe, cases[-1])                                         # warm-up (page cache, clocks)
+            loc["host_native"] = 1.0
+        except Exception:
+            exe = None
+            loc["host_native"] = 0.0
+        for i, sq in enumerate(seqs):
+            st = stream.run_native(exe, cases[i]) if exe else batch.run_sequence(ctx, sq, ba_problems=windows)
             loc["frames"] += st["frames"]; loc["seconds"] += st["seconds"]; loc["tracked"] += st["tracked"]
             loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
             loc["keyframes"] += st["keyframes"]; loc["stereo_ok"] += st["stereo_ok"]; loc["stereo_kps"] += st["stereo_kps"]
             loc["ba_solves"] += st["ba_solves"]; loc["ba_iterations"] += st["ba_iterations"]; loc["ba_seconds"] += st["ba_busy_s"]
             loc["ba_skipped"] += st["ba_skipped_kfs"]
+        td.cleanup()
     stats = batch.gather_stats(loc)
     agg = batch.aggregate(stats)
     return {"workload": "11 synthetic stereo sequences with EuRoC frame counts / %d (%d frames), longest-first over %d rank(s); every "
@@ -280,6 +295,7 @@ def run_config5(ctx, rank, world, scale, dry=False):
             "keyframes": sum(stats["keyframes"]), "stereo_ok_fraction": sum(stats["stereo_ok"]) / max(1.0, sum(stats["stereo_kps"])),
             "ba_solves": sum(stats["ba_solves"]), "ba_keyframes_skipped_while_busy": sum(stats["ba_skipped"]),
             "ba_iters_per_s": agg.get("ba_iters_per_s", 0.0),
+            "host": "tools/stream_driver.cpp (native, one process per sequence)" if min(stats["host_native"]) > 0 else "Python driver (ov2slam_amd/stream.py)",
             "track_rmse_px": agg.get("ate_rmse", 0.0),
             "ate": "not computable on this path: pose estimation (P3P / PnP, motion model) and triangulation stay on the CPU in the "
                    "reference and are outside SURVEY.md section 8; track_rmse_px is the tracking error against the synthetic flow",

@@ -85,18 +85,24 @@ static Case read_case(const char *path)
 }
 
 static int view_index(const Case &c, int f) { const int n = c.n_views, k = f % (2 * n - 2); return k < n ? k : 2 * n - 2 - k; }
-// ground-truth position in frame fb of pixel (x, y) of frame fa (batch.SyntheticSequence.flow)
-static void flow(const Case &c, int fa, int fb, float x, float y, double &ox, double &oy)
-{
-    const double cx = (c.w - 1) / 2.0, cy = (c.h - 1) / 2.0;
-    const double *a = &c.offs[3 * (size_t)view_index(c, fa)], *b = &c.offs[3 * (size_t)view_index(c, fb)];
-    double dx = x - cx, dy = y - cy;
-    double co = cos(a[2]), si = sin(a[2]);
-    const double tx = co * dx - si * dy + cx + a[0], ty = si * dx + co * dy + cy + a[1];
-    dx = tx - cx - b[0]; dy = ty - cy - b[1];
-    co = cos(-b[2]); si = sin(-b[2]);
-    ox = co * dx - si * dy + cx; oy = si * dx + co * dy + cy;
-}
+// ground-truth position in frame fb of pixel (x, y) of frame fa (batch.SyntheticSequence.flow); the trigonometry is per frame pair
+struct Flow {
+    double cx, cy, ca, sa, ax, ay, cb, sb, bx, by;
+    Flow(const Case &c, int fa, int fb)
+    {
+        cx = (c.w - 1) / 2.0; cy = (c.h - 1) / 2.0;
+        const double *a = &c.offs[3 * (size_t)view_index(c, fa)], *b = &c.offs[3 * (size_t)view_index(c, fb)];
+        ca = cos(a[2]); sa = sin(a[2]); ax = a[0]; ay = a[1];
+        cb = cos(-b[2]); sb = sin(-b[2]); bx = b[0]; by = b[1];
+    }
+    void operator()(float x, float y, double &ox, double &oy) const
+    {
+        double dx = x - cx, dy = y - cy;
+        const double tx = ca * dx - sa * dy + cx + ax, ty = sa * dx + ca * dy + cy + ay;
+        dx = tx - cx - bx; dy = ty - cy - by;
+        ox = cb * dx - sb * dy + cx; oy = sb * dx + cb * dy + cy;
+    }
+};
 
 struct KfJob { int f; const ov2_pyr *left; const uint8_t *right_img; std::vector<float> kps, unpx, p3; std::vector<uint8_t> hp; };
 template <class T> struct Queue {
@@ -179,7 +185,7 @@ int main(int argc, char **argv)
     // ---- SLAM thread ----------------------------------------------------------------------------------------------
     std::mt19937 rng(12345);
     std::normal_distribution<float> gauss(0.f, 1.f);
-    std::vector<float> kps, pri, out, unpx; std::vector<double> bv; std::vector<uint8_t> hp, st; std::vector<int> age;
+    std::vector<float> kps, pri, out, unpx, nk; std::vector<double> bv, gt; std::vector<uint8_t> hp, st; std::vector<int> age, na;
     const int roi[4] = {5, 5, w - 10, h - 10};
     double quality = 0.001;
     auto keyframe = [&](int f) {
@@ -212,10 +218,10 @@ int main(int argc, char **argv)
     int last_kf = 0;
     for (int f = 1; f < C.n_frames; f++) {
         const int n = (int)age.size();
-        pri.resize(2 * (size_t)n); hp.resize(n); out.resize(2 * (size_t)n); st.resize(n);
-        std::vector<double> gt(2 * (size_t)n);
+        pri.resize(2 * (size_t)n); hp.resize(n); out.resize(2 * (size_t)n); st.resize(n); gt.resize(2 * (size_t)n);
+        const Flow flow(C, f - 1, f);
         for (int i = 0; i < n; i++) {
-            flow(C, f - 1, f, kps[2 * i], kps[2 * i + 1], gt[2 * i], gt[2 * i + 1]);
+            flow(kps[2 * i], kps[2 * i + 1], gt[2 * i], gt[2 * i + 1]);
             hp[i] = age[i] > 0;
             pri[2 * i] = hp[i] ? (float)(gt[2 * i] + C.prior_sigma * gauss(rng)) : kps[2 * i];
             pri[2 * i + 1] = hp[i] ? (float)(gt[2 * i + 1] + C.prior_sigma * gauss(rng)) : kps[2 * i + 1];
@@ -233,7 +239,7 @@ int main(int argc, char **argv)
         if (n) CK(ov2_tracker_last_keypoints(trk, n, unpx.data(), bv.data()));      // Frame::computeKeypoint of the tracked positions (same enqueue)
         slam_lib += now() - tl;
         frames++; attempted += n;
-        std::vector<float> nk; std::vector<int> na;
+        nk.clear(); na.clear();
         for (int i = 0; i < n; i++) {
             if (!(st[i] & 1)) continue;
             tracked++;
