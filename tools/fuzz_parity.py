@@ -119,7 +119,12 @@ for case in range(N):
     # ---- single-sequence tracker: preprocessImage + kltTracking (visual_front_end.cpp:1143-1177, :132-275) ----
     if w >= 150 and h >= 150 and case % 2 == 0:
         use_clahe = bool(rng.integers(0, 2)); clipv = float(rng.choice([1.0, 3.0, 8.0]))
-        t = ov2slam_amd.VisualFrontEndTracker(ctx, w, h, use_clahe=use_clahe, fclahe_val=clipv, nbmaxkps=512, use_graph=bool(rng.integers(0, 2)))
+        cap = int(rng.choice([512, 512, 64, 150]))                         # small capacities: keypoints beyond it run as further chunks
+        t = ov2slam_amd.VisualFrontEndTracker(ctx, w, h, use_clahe=use_clahe, fclahe_val=clipv, nbmaxkps=cap, use_graph=bool(rng.integers(0, 2)))
+        with_cal = bool(rng.integers(0, 2))
+        if with_cal:                                                       # Frame::computeKeypoint inside the frame's enqueue
+            tcal = ov2slam_amd.CameraCalibration(ctx, "pinhole", 458.654, 457.296, w / 2.0, h / 2.0, D=(-0.2834, 0.0739, 0.00019, 1.76e-05))
+            t.setCalibration(tcal)
         t.trackFrame(prev, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
         nk = int(rng.integers(1, 500))
         tk = np.stack([rng.uniform(-4, w + 4, nk), rng.uniform(-4, h + 4, nk)], 1).astype(np.float32)
@@ -134,7 +139,12 @@ for case in range(N):
         ro, rok, rretry, rp3p = O.klt_tracking(O.Pyramid(a, 9, 3), O.Pyramid(b, 9, 3), tk, tp, hp, klt_use_prior=use_prior)
         check("tracker", gp3p == rp3p and np.array_equal((gs & 1).astype(bool), rok) and np.array_equal((gs & 2).astype(bool), rretry)
               and np.array_equal(np.ascontiguousarray(go, np.float32).view(np.uint32), np.ascontiguousarray(ro, np.float32).view(np.uint32)),
-              dict(info, n=nk, clahe=use_clahe, prior=use_prior))
+              dict(info, n=nk, clahe=use_clahe, prior=use_prior, cap=cap))
+        if with_cal:
+            gu, gb = t.lastKeypoints(nk)
+            ru, rb = O.compute_keypoints(O.CAM_PINHOLE, tcal.K, tcal.D, tcal.iK, go)
+            check("tracker_keypoints", np.array_equal(gu.view(np.uint32), ru.view(np.uint32)) and np.array_equal(gb.view(np.uint64), rb.view(np.uint64)),
+                  dict(info, n=nk, cap=cap))
         t.close()
     # ---- bundle adjustment: random small problems, both landmark forms, both problem-size paths ----
     if case % 4 == 0:
@@ -173,7 +183,25 @@ for case in range(N):
             os.environ["OV2_BA_BIG"] = big
             g = optimizer.solve(ctx, pb, optimizer.default_options(ctx.lib, **kw))
             ba_check("ba_invdepth_big" + big, g, r, "invdepth")
-        os.environ.pop("OV2_BA_BIG", None)
+        # round 3: the lineariser without LDS pre-aggregation and the column-chunked sparse Schur complement, forced onto the small problem
+        os.environ["OV2_BA_LIN_DIRECT"] = "1"; os.environ["OV2_BA_SCHUR_CHUNK"] = str(int(rng.choice([36, 60, 96])))
+        g = optimizer.solve(ctx, pb, optimizer.default_options(ctx.lib, **kw))
+        ba_check("ba_invdepth_big_direct_chunked", g, r, "invdepth")
+        for k_ in ("OV2_BA_BIG", "OV2_BA_LIN_DIRECT", "OV2_BA_SCHUR_CHUNK"):
+            os.environ.pop(k_, None)
+        # round 3: both passes of localBA on the resident problem (ov2_local_ba) vs the two-call protocol on the oracle
+        def osolver(prob, res_active, chi2_init, depthpos_init, **kk):
+            return O.ba_solve(prob, O.ba_default_options(**kk), res_active, chi2_init, depthpos_init)
+        gl = optimizer.Optimizer(ctx).localBA(pb); rl = optimizer.Optimizer(None, solver=osolver).localBA(pb)
+        rits = (rl["pass1"]["iterations"], rl["pass2"]["iterations"] if rl["l2_done"] else 0)
+        okl = (gl["l2_done"] == rl["l2_done"] and tuple(gl["iterations"]) == rits and np.array_equal(gl["bad_obs"], rl["bad_obs"])
+               and np.abs(gl["poses"] - rl["poses"]).max() <= 1e-6 * max(1.0, np.abs(rl["poses"]).max()))
+        if not okl:
+            # an outlier verdict within rounding of the chi2 threshold may flip on barely constrained draws: listed, not failed, when the poses agree
+            if np.abs(gl["poses"] - rl["poses"]).max() <= 1e-4 * max(1.0, np.abs(rl["poses"]).max()) and int((gl["bad_obs"] != rl["bad_obs"]).sum()) <= 2:
+                loose.append(("local_ba", dict(binfo, its=(tuple(gl["iterations"]), rits)))); print("LOOSE local_ba", loose[-1][1], flush=True)
+            else:
+                check("local_ba", False, dict(binfo, its=(tuple(gl["iterations"]), rits), nbad=(int(gl["bad_obs"].sum()), int(rl["bad_obs"].sum()))))
         pb = synth.make_xyz_ba_problem(n_kf, n_lm, min(obs, n_kf), stereo=stereo, seed=bseed)
         g = optimizer.solve_xyz(ctx, pb, optimizer.default_options(ctx.lib, **kw)); r = O.xyz_ba_solve(pb, O.ba_default_options(**kw))
         ba_check("ba_xyz", g, r, "xyz")
