@@ -2833,8 +2833,14 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
     r->l2_done = 0; r->n_bad_pass1 = 0; r->n_bad_total = 0;
     for (int i = 0; i < 2; i++) { r->iterations[i] = 0; r->num_successful_steps[i] = 0; r->termination[i] = OV2_TERM_NO_CONVERGENCE; r->initial_cost[i] = r->final_cost[i] = 0; r->solve_ms[i] = 0; }
     ov2_ba_dev *dev = nullptr;
+    const bool dbg = getenv("OV2_BA_DEBUG") != nullptr;
+    const auto tw0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg) fprintf(stderr, "[ov2 local_ba] %-28s %8.3f ms since entry\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
+    };
     int rc = ba_create(ctx, p, &dev, /*transient*/ true);       // the pool lives in the context's scratch through both passes
     if (rc != OV2_OK) return rc;
+    lap("sort + upload (ba_create)");
     struct Guard { ov2_ba_dev *d; ~Guard() { ba_destroy(d); } } guard{dev};
     if (dev->D.n_po > 0) { ov2_set_error("ov2_local_ba: problems with OV2_RES_PNP blocks go through ov2_ba_solve"); return OV2_EUNSUPPORTED; }
     BADev &D = dev->D;
@@ -2849,6 +2855,7 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
     if (rc != OV2_OK) return rc;
     r->iterations[0] = br.iterations; r->num_successful_steps[0] = br.num_successful_steps; r->termination[0] = br.termination; r->initial_cost[0] = br.initial_cost;
     r->final_cost[0] = br.final_cost; r->solve_ms[0] = br.solve_ms;
+    lap("pass 1");
     // outlier test on the values cached by the last Evaluate of pass 1 (:492-594)
     rc = ctx->reserve_host(64);
     if (rc != OV2_OK) return rc;
@@ -2859,6 +2866,7 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
     OV2_HIP_CHECK(hipMemcpyAsync(cnt_h, D.lba_cnt, 16, hipMemcpyDeviceToHost, s));
     if (r->bad_after_pass1 && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->bad_after_pass1, D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
     OV2_HIP_CHECK(hipStreamSynchronize(s));
+    lap("outlier test 1");
     const int nbbad = cnt_h[0], left_remaining = cnt_h[1], right_remaining = cnt_h[2];
     r->n_bad_pass1 = nbbad; r->n_bad_total = nbbad;
     if (o->apply_l2_after_robust && o->use_robust_cost && !o->stop_requested && nbbad > 0) {          // :603-604
@@ -2872,6 +2880,7 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
         r->l2_done = 1;
         r->iterations[1] = br.iterations; r->num_successful_steps[1] = br.num_successful_steps; r->termination[1] = br.termination; r->initial_cost[1] = br.initial_cost;
         r->final_cost[1] = br.final_cost; r->solve_ms[1] = br.solve_ms;
+        lap("pass 2");
         // second outlier test on the residual blocks that are still in the problem (:637-735)
         hipLaunchKernelGGL(k_ba_mark_outliers, dim3(mk_blocks), dim3(256), 0, s, D, o->robust_mono_th, 0, (uint8_t *)nullptr);
         OV2_HIP_CHECK(hipGetLastError());
@@ -2884,6 +2893,7 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
     if (r->depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
     OV2_HIP_CHECK(hipStreamSynchronize(s));
     if (r->l2_done) r->n_bad_total = nbbad + cnt_h[0];
+    lap("outlier test 2 + download");
     return OV2_OK;
 }
 
