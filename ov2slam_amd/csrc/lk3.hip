@@ -76,6 +76,16 @@ __device__ __forceinline__ int dot2r(uint32_t a, uint32_t b)
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c256));
     return r;
 }
+// a.lo * b.lo + a.hi * b.hi + 2^15 (scalar-register accumulator like dot2r): the derivative taps, whose inputs carry a factor 4
+__device__ __forceinline__ int dot2h(uint32_t a, uint32_t b)
+{
+    int r;
+    const int c = __builtin_amdgcn_readfirstlane(1 << 15);
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+// (S0 >> 16, S1 >> 16) of two signed sums as an i16 pair: their high halves, one byte permute
+__device__ __forceinline__ uint32_t hi16_pair(int s0, int s1) { return __builtin_amdgcn_perm((uint32_t)s1, (uint32_t)s0, 0x07060302u); }
 // (S0 >> 9, S1 >> 9) as two u16 for sums 0 <= S < 2^24 that already hold their rounding constant: bytes 1-2 of each
 // (S >> 8, 16 bits) by one byte permute, then one packed shift
 __device__ __forceinline__ uint32_t shr9_pair(int s0, int s1)
@@ -370,14 +380,17 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         auto deriv_row = [&](int d, const uint32_t (&ea)[6], const uint32_t (&eb)[6], const uint32_t (&ec)[6], uint32_t (&dx)[5], uint32_t (&dy)[5]) {
             uint32_t T0[6], T1[6];
 #pragma unroll
+            // The derivatives are produced with a factor 4 (Scharr weights 12 / 40 instead of 3 / 10: |4 d| <= 16320 still fits 16
+            // bits), so that the bilinear tap sum 4 S = sum w (4 d) descales with the high half of (4 S + 2^15):
+            // (S + 2^13) >> 14 == (4 S + 2^15) >> 16 -- one byte permute per pixel pair instead of two shifts and a pack
             for (int i = 0; i < 6; i++) {
-                T0[i] = pk_add(pk_mul(pk_add(ea[i], ec[i]), 3), pk_mul(eb[i], 10));
+                T0[i] = pk_add(pk_mul(pk_add(ea[i], ec[i]), 12), pk_mul(eb[i], 40));
                 T1[i] = pk_sub(ec[i], ea[i]);
             }
 #pragma unroll
             for (int i = 0; i < 5; i++) {
                 dx[i] = pk_sub(T0[i + 1], T0[i]);
-                dy[i] = pk_add(pk_mul(pk_add(T1[i], T1[i + 1]), 3), pk_mul(odd_pair(T1[i + 1], T1[i]), 10));
+                dy[i] = pk_add(pk_mul(pk_add(T1[i], T1[i + 1]), 12), pk_mul(odd_pair(T1[i + 1], T1[i]), 40));
             }
             if (any_border) {
                 const int Yd = ipy + r0 + d;
@@ -403,15 +416,15 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 const uint32_t xb = (x & 1) ? odd_pair(dxb[(x >> 1) + 1], dxb[x >> 1]) : dxb[x >> 1];
                 const uint32_t yt = (x & 1) ? odd_pair(dyt[(x >> 1) + 1], dyt[x >> 1]) : dyt[x >> 1];
                 const uint32_t yb = (x & 1) ? odd_pair(dyb[(x >> 1) + 1], dyb[x >> 1]) : dyb[x >> 1];
-                xv[x] = dot2(xt, W01, dot2(xb, W23, 1 << 13)) >> 14;
-                yv[x] = dot2(yt, W01, dot2(yb, W23, 1 << 13)) >> 14;
+                xv[x] = dot2(xt, W01, dot2h(xb, W23));              // 4 S + 2^15: descaled by hi16_pair below
+                yv[x] = dot2(yt, W01, dot2h(yb, W23));
             }
             iv[WIN] = 256; xv[WIN] = 0; yv[WIN] = 0;                    // (the pad pixel's derivatives are 0: its I never counts)
 #pragma unroll
             for (int t = 0; t < 5; t++) {
                 const uint32_t Ipair = shr9_pair(iv[2 * t], iv[2 * t + 1]);
-                T.X[j][t] = pack_lo16(xv[2 * t], xv[2 * t + 1]);
-                T.Y[j][t] = pack_lo16(yv[2 * t], yv[2 * t + 1]);
+                T.X[j][t] = hi16_pair(xv[2 * t], xv[2 * t + 1]);
+                T.Y[j][t] = hi16_pair(yv[2 * t], yv[2 * t + 1]);
                 s11 = dot2(T.X[j][t], T.X[j][t], s11);
                 s12 = dot2(T.X[j][t], T.Y[j][t], s12);
                 s22 = dot2(T.Y[j][t], T.Y[j][t], s22);
