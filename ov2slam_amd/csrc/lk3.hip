@@ -76,6 +76,10 @@ __device__ __forceinline__ int dot2r(uint32_t a, uint32_t b)
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c256));
     return r;
 }
+#ifndef L3_DOT2H_ASM
+#define L3_DOT2H_ASM 0
+#endif
+#define DOT2H(a, b) (L3_DOT2H_ASM ? dot2h((a), (b)) : dot2((a), (b), 1 << 15))
 // a.lo * b.lo + a.hi * b.hi + 2^15 (scalar-register accumulator like dot2r): the derivative taps, whose inputs carry a factor 4
 __device__ __forceinline__ int dot2h(uint32_t a, uint32_t b)
 {
@@ -405,26 +409,28 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         };
         auto window_row = [&](int j, const uint32_t (&et)[6], const uint32_t (&eb)[6], const uint32_t (&dxt)[5], const uint32_t (&dyt)[5],
                               const uint32_t (&dxb)[5], const uint32_t (&dyb)[5]) {
-            int iv[WIN + 1], xv[WIN + 1], yv[WIN + 1];
-#pragma unroll
-            for (int x = 0; x < WIN; x++) {
+            // two window pixels at a time, packed at once (short live ranges: the first form kept three 10-entry sum arrays alive
+            // and spilled once the derivative sums stayed 32 bits wide until the pack)
+            auto taps = [&](int x, int &iv, int &xv, int &yv) {
                 const int k = x + 1;                                // pixel pair (p[x+1], p[x+2]) of image rows j+1 (top), j+2 (bottom)
                 const uint32_t pt = (k & 1) ? odd_pair(et[(k >> 1) + 1], et[k >> 1]) : et[k >> 1];
                 const uint32_t pb = (k & 1) ? odd_pair(eb[(k >> 1) + 1], eb[k >> 1]) : eb[k >> 1];
-                iv[x] = dot2(pt, W01, dot2r(pb, W23));             // + 256: shifted and packed by shr9_pair below
+                iv = dot2(pt, W01, dot2r(pb, W23));                 // + 256: shifted and packed by shr9_pair
                 const uint32_t xt = (x & 1) ? odd_pair(dxt[(x >> 1) + 1], dxt[x >> 1]) : dxt[x >> 1];   // (d[x], d[x+1]) of rows j, j+1
                 const uint32_t xb = (x & 1) ? odd_pair(dxb[(x >> 1) + 1], dxb[x >> 1]) : dxb[x >> 1];
                 const uint32_t yt = (x & 1) ? odd_pair(dyt[(x >> 1) + 1], dyt[x >> 1]) : dyt[x >> 1];
                 const uint32_t yb = (x & 1) ? odd_pair(dyb[(x >> 1) + 1], dyb[x >> 1]) : dyb[x >> 1];
-                xv[x] = dot2(xt, W01, dot2h(xb, W23));              // 4 S + 2^15: descaled by hi16_pair below
-                yv[x] = dot2(yt, W01, dot2h(yb, W23));
-            }
-            iv[WIN] = 256; xv[WIN] = 0; yv[WIN] = 0;                    // (the pad pixel's derivatives are 0: its I never counts)
+                xv = dot2(xt, W01, DOT2H(xb, W23));                 // 4 S + 2^15: descaled by hi16_pair
+                yv = dot2(yt, W01, DOT2H(yb, W23));
+            };
 #pragma unroll
             for (int t = 0; t < 5; t++) {
-                const uint32_t Ipair = shr9_pair(iv[2 * t], iv[2 * t + 1]);
-                T.X[j][t] = hi16_pair(xv[2 * t], xv[2 * t + 1]);
-                T.Y[j][t] = hi16_pair(yv[2 * t], yv[2 * t + 1]);
+                int i0, x0, y0, i1 = 256, x1 = 0, y1 = 0;           // (the pad pixel's derivatives are 0: its I never counts)
+                taps(2 * t, i0, x0, y0);
+                if (2 * t + 1 < WIN) taps(2 * t + 1, i1, x1, y1);
+                const uint32_t Ipair = shr9_pair(i0, i1);
+                T.X[j][t] = hi16_pair(x0, x1);
+                T.Y[j][t] = hi16_pair(y0, y1);
                 s11 = dot2(T.X[j][t], T.X[j][t], s11);
                 s12 = dot2(T.X[j][t], T.Y[j][t], s12);
                 s22 = dot2(T.Y[j][t], T.Y[j][t], s22);
