@@ -2200,7 +2200,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     // caller's order); pose-only blocks (OV2_RES_PNP) go to their own list.  Large problems (a 590 k-block localBA: 3.8 ms of the
     // call were this sort and the staging fill) split the residual range over a few host threads: per-thread counts, offsets
     // = landmark prefix + the counts of the lower-numbered threads, so the result is identical to the serial sort.
-    const int NT = p->n_res >= (1 << 17) ? std::min(8, p->n_res >> 16) : 1;
+    const int NT = p->n_res >= (1 << 16) ? std::min(8, p->n_res >> 15) : 1;   // (a 25-KF window of 69 k blocks: 2 threads)
     std::vector<std::vector<int>> cntT((size_t)NT, std::vector<int>((size_t)p->n_lm + 1, 0));
     std::vector<int> nactT((size_t)NT, 0), npoT((size_t)NT, 0);
     std::vector<const char *> errT((size_t)NT, nullptr);
@@ -2258,16 +2258,26 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     int *res_kf, *res_orig, *po_kf, *po_orig;
     uint8_t *res_type;
     double *res_uv, *res_sigma, *po_xyz, *po_uv, *po_sigma;
+    // Round 3: the staging buffer MIRRORS the first eleven arrays of the device pool (same offsets), so that everything a solve
+    // needs from the host goes up in ONE copy instead of eleven (each ~15 us of launch overhead: a third of ba_create on a
+    // 69 k-block window)
+    const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
+    const size_t o_pose_col = take(4 * (size_t)p->n_kf), o_lm_ptr = take(4 * (nl + 1)), o_lm_anchor = take(4 * nl), o_lm_auv = take(16 * nl);
+    const size_t o_res_type = take(na), o_res_kf = take(4 * na), o_res_orig = take(4 * na), o_res_uv = take(16 * na), o_res_sigma = take(8 * na);
+    const size_t o_lm_order = take(4 * nl), o_lm_live = take(nl);
+    const size_t up_bytes = off;                                       // [0, up_bytes) of the pool = the staging buffer
+    uint8_t *hs = nullptr;
     {
-        const size_t na_h = (size_t)std::max(1, n_act), np_h = (size_t)std::max(1, n_po);
-        size_t hoff = 0;
+        const size_t np_h = (size_t)std::max(1, n_po);
+        size_t hoff = up_bytes;
         auto htake = [&](size_t bytes) { const size_t o = hoff; hoff += (bytes + 255) & ~(size_t)255; return o; };
-        const size_t h1 = htake(4 * na_h), h2 = htake(4 * na_h), h3 = htake(na_h), h4 = htake(16 * na_h), h5 = htake(8 * na_h);
         const size_t h6 = htake(4 * np_h), h7 = htake(4 * np_h), h8 = htake(24 * np_h), h9 = htake(16 * np_h), h10 = htake(8 * np_h);
         const int rch = ctx->reserve_host(hoff);
         if (rch != OV2_OK) return rch;
-        uint8_t *hs = (uint8_t *)ctx->h_scratch;
-        res_kf = (int *)(hs + h1); res_orig = (int *)(hs + h2); res_type = hs + h3; res_uv = (double *)(hs + h4); res_sigma = (double *)(hs + h5);
+        hs = (uint8_t *)ctx->h_scratch;
+        res_kf = (int *)(hs + o_res_kf); res_orig = (int *)(hs + o_res_orig); res_type = hs + o_res_type; res_uv = (double *)(hs + o_res_uv); res_sigma = (double *)(hs + o_res_sigma);
         po_kf = (int *)(hs + h6); po_orig = (int *)(hs + h7); po_xyz = (double *)(hs + h8); po_uv = (double *)(hs + h9); po_sigma = (double *)(hs + h10);
     }
     std::vector<int> poStart((size_t)NT + 1, 0);
@@ -2341,12 +2351,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         for (size_t j = 0; j < cw_col.size(); j++) kfl_idx[kfill[cw_col[j] / 6]++] = (int)j;
     }
     D.n_cw = (int)cw_col.size();
-    const size_t nl = (size_t)std::max(1, p->n_lm), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
     const size_t ncw = (size_t)std::max(1, D.n_cw);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
-    const size_t o_pose_col = take(4 * (size_t)p->n_kf), o_lm_ptr = take(4 * (nl + 1)), o_lm_anchor = take(4 * nl), o_lm_auv = take(16 * nl);
-    const size_t o_res_type = take(na), o_res_kf = take(4 * na), o_res_orig = take(4 * na), o_res_uv = take(16 * na), o_res_sigma = take(8 * na);
     const size_t o_x_pose = take(56 * (size_t)p->n_kf), o_c_pose = take(56 * (size_t)p->n_kf), o_x_RT = take(96 * (size_t)p->n_kf), o_c_RT = take(96 * (size_t)p->n_kf);
     const size_t o_x_lam = take(8 * nl), o_c_lam = take(8 * nl), o_scale_f = take(8 * (size_t)nfp), o_diag_f = take(8 * (size_t)nfp);
     const size_t o_scale_l = take(8 * nl), o_diag_l = take(8 * nl), o_ete = take(8 * nl), o_etb = take(8 * nl), o_cl = take(8 * nl), o_ce = take(8 * nl);
@@ -2355,8 +2360,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t o_res_cw = take(4 * na), o_lm_cwa = take(4 * nl), o_kfl_ptr = take(4 * ((size_t)n_opt + 1)), o_kfl_idx = take(4 * ncw);
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
-    const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl)), o_lm_order = take(4 * nl);
-    const size_t o_res_off = take(na), o_lm_live = take(nl), o_bad_obs = take(nr), o_lba_cnt = take(64);
+    const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl));
+    const size_t o_res_off = take(na), o_bad_obs = take(nr), o_lba_cnt = take(64);
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
@@ -2397,28 +2402,23 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     hipStream_t s = ctx->stream;
 #define UP(dst, src, bytes) do { if ((bytes) > 0) { hipError_t _e = hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, s); \
         if (_e != hipSuccess) { if (dev->pool_owned) (void)hipFree(dev->pool); delete dev; ov2_set_error("H2D: %s", hipGetErrorString(_e)); return OV2_EHIP; } } } while (0)
-    std::vector<int> lm_order(p->n_lm);
-    for (int l = 0; l < p->n_lm; l++) lm_order[l] = l;
-    std::stable_sort(lm_order.begin(), lm_order.end(), [&](int x, int y) { return p->lm_anchor_kf[x] < p->lm_anchor_kf[y]; });
-    UP(dev->lm_order, lm_order.data(), 4 * (size_t)p->n_lm);
-    std::vector<uint8_t> lm_live(std::max(1, p->n_lm));
-    for (int l = 0; l < p->n_lm; l++) lm_live[l] = cnt[l] != cnt[l + 1];
-    UP(D.lm_live, lm_live.data(), (size_t)p->n_lm);
+    {   // the small arrays join the residual arrays in the staging mirror; landmarks are processed anchor by anchor (lm_order)
+        int *lm_order = (int *)(hs + o_lm_order);
+        for (int l = 0; l < p->n_lm; l++) lm_order[l] = l;
+        std::stable_sort(lm_order, lm_order + p->n_lm, [&](int x, int y) { return p->lm_anchor_kf[x] < p->lm_anchor_kf[y]; });
+        uint8_t *lm_live = hs + o_lm_live;
+        for (int l = 0; l < p->n_lm; l++) lm_live[l] = cnt[l] != cnt[l + 1];
+        memcpy(hs + o_pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
+        memcpy(hs + o_lm_ptr, cnt.data(), 4 * ((size_t)p->n_lm + 1));
+        if (p->n_lm > 0) { memcpy(hs + o_lm_anchor, p->lm_anchor_kf, 4 * (size_t)p->n_lm); memcpy(hs + o_lm_auv, p->lm_anchor_uv, 16 * (size_t)p->n_lm); }
+    }
+    UP(b, hs, up_bytes);                                               // ONE copy: pose_col .. lm_live
     {
         hipError_t em = hipMemsetAsync(D.res_off, 0, na, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.bad_obs, 0, nr, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.lba_cnt, 0, 64, s);
         if (em != hipSuccess) { ov2_set_error("hipMemsetAsync: %s", hipGetErrorString(em)); ba_destroy(dev); return OV2_EHIP; }
     }
-    UP(D.pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
-    UP(D.lm_ptr, cnt.data(), 4 * ((size_t)p->n_lm + 1));
-    UP(D.lm_anchor, p->lm_anchor_kf, 4 * (size_t)p->n_lm);
-    UP(D.lm_auv, p->lm_anchor_uv, 16 * (size_t)p->n_lm);
-    UP(D.res_type, res_type, (size_t)n_act);
-    UP(D.res_kf, res_kf, 4 * (size_t)n_act);
-    UP(D.res_orig, res_orig, 4 * (size_t)n_act);
-    UP(D.res_uv, res_uv, 16 * (size_t)n_act);
-    UP(D.res_sigma, res_sigma, 8 * (size_t)n_act);
     UP(D.po_kf, po_kf, 4 * (size_t)n_po); UP(D.po_orig, po_orig, 4 * (size_t)n_po);
     UP(D.po_xyz, po_xyz, 24 * (size_t)n_po); UP(D.po_uv, po_uv, 16 * (size_t)n_po); UP(D.po_sigma, po_sigma, 8 * (size_t)n_po);
     if (D.big) {
