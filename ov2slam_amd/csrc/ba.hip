@@ -1330,6 +1330,183 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 #undef CH_TICK
 }
 
+// ---------------------------------------------------------------------------------- reduced system, several work-groups
+// Round 3.  k_ba_cholesky keeps 255 of 256 CUs idle through half of an LM iteration: ten 32-column panels x (pivot chain +
+// panel solve + trailing update of everything to the right + barriers) on ONE compute unit.  Here work-group j OWNS block column
+// j (rows >= 32 j of S and, as one more row, the right-hand side) and keeps it in LDS for the whole factorisation:
+//   for k < j : wait until panel k is published, then  C_j -= P_k[rows] P_k[rows of block j]^T   (row per thread, fp64 FMA)
+//   factor the diagonal block (one wavefront, register rows: the body of k_chol_diag), solve the rows below and the
+//   right-hand-side row against it (row per thread), publish the finished column (S, z) and raise flag j
+//   backward substitution, column oriented: wait for y_k (k > j), fold L[block k rows, my columns]^T y_k into my right-hand side,
+//   solve L_jj^T y_j = .  and publish y_j.
+// The update with panel k overlaps the factorisation of panel k+1 by construction (look-ahead), so the critical path per panel is
+// pivot chain + panel solve + one publish / acquire hand-over + ONE column update instead of the whole trailing matrix.
+// Work-groups synchronise through generation-stamped flags in global memory (agent-scope release / acquire; in-order dispatch
+// guarantees the producers of a flag are resident before its consumers).  With xcd_stride = 8 only every eighth work-group id
+// works, which puts all of them on one XCD (ids are dealt round-robin over the XCDs): the panels then travel through one L2.
+#define MW_MAX_N 384
+__device__ __forceinline__ void mw_wait(const int *flag, int gen)
+{
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(1);
+    // (thread 0's acquire invalidated this CU's vector L1 -- the one every wavefront of the work-group reads through -- and the
+    // barrier orders the other threads' loads behind it: one cache invalidate per hand-over instead of one per wavefront)
+    __syncthreads();
+}
+__device__ __forceinline__ void mw_publish(int *flag, int gen)
+{
+    // every thread's stores of the column have reached L2 (write-through L1) when its work-group-scope release completes; the
+    // barrier makes them happen-before thread 0's agent-scope release, which is cumulative: ONE L2 write-back per hand-over
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(512) void k_ba_cholesky_mw(BADev D, int gen, int xcd_stride)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done) return;
+    if (blockIdx.x % xcd_stride) return;
+    const int j = blockIdx.x / xcd_stride;
+    const int n = D.nf, ld = D.nfp, nblk = (n + CH_NB - 1) / CH_NB;
+    if (j >= nblk) return;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int c0 = CH_NB * j, nb = min(CH_NB, n - c0), m = n - c0;      // my rows: c0 .. n-1 (thread t < m), then the right-hand side (t == m)
+    double *C = (double *)smem_raw;                                     // (m + 1) x CH_LDP
+    double *Pj = C + (size_t)(m + 1) * CH_LDP;                          // CH_NB x CH_LDP : rows of the incoming panel that face my diagonal block
+    double *L11 = Pj + CH_NB * CH_LDP;                                  // CH_NB x CH_LDP : my diagonal block (identity padded), reciprocal pivots in column 32
+    double *ybuf = L11 + CH_NB * CH_LDP;                                // CH_NB
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, t = tid, lane = tid & 63, wave = tid >> 6;
+    int *flags = (int *)D.Linv, *yflags = flags + 64;                   // (zeroed by ba_create; stamped with the launch's generation)
+    double *Z = D.Linv + 64;                                            // forward solution, block by block
+    double *S = D.S, *Y = D.yf;
+    if (tid == 0) s_fail = 0;
+    // ---- my block column -> LDS ----
+    if (t < m) {
+        const double *src = S + (long long)(c0 + t) * ld + c0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = (c < nb && (t >= CH_NB || c <= t)) ? src[c] : 0.0;
+    } else if (t == m) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = c < nb ? D.scale_f[c0 + c] * (D.bf[c0 + c] - D.v[c0 + c]) : 0.0;
+    }
+    __syncthreads();
+    // ---- updates with the panels to my left ----
+    for (int k = 0; k < j; k++) {
+        mw_wait(&flags[k], gen);
+        double row[CH_NB];
+        const double *src = t < m ? S + (long long)(c0 + t) * ld + CH_NB * k : Z + CH_NB * k;
+#pragma unroll
+        for (int q = 0; q < CH_NB; q++) row[q] = t <= m ? src[q] : 0.0;
+        if (t < CH_NB) {
+#pragma unroll
+            for (int q = 0; q < CH_NB; q++) Pj[t * CH_LDP + q] = t < nb ? row[q] : 0.0;
+        }
+        __syncthreads();
+        if (t <= m) {
+#pragma unroll 4
+            for (int c = 0; c < CH_NB; c++) {
+                double acc = C[t * CH_LDP + c];
+                const double *pr = Pj + c * CH_LDP;
+#pragma unroll
+                for (int q = 0; q < CH_NB; q++) acc -= row[q] * pr[q];
+                C[t * CH_LDP + c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- my diagonal block: one wavefront, lane = row, left-looking (k_chol_diag) ----
+    for (int e = tid; e < CH_NB * CH_NB; e += blockDim.x) {
+        const int i = e >> 5, c = e & 31;
+        L11[i * CH_LDP + c] = (i < nb && c <= i) ? C[i * CH_LDP + c] : (i == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double a[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) a[c] = lane < CH_NB ? L11[lane * CH_LDP + c] : 0.0;
+        bool fail = false;
+        double pnext = a[0];
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            double sacc = pnext;
+            if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];
+            const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
+            if (c + 1 < CH_NB) {
+                pnext = a[c + 1];
+#pragma unroll
+                for (int k = 0; k < c; k++) pnext -= a[k] * L11[(c + 1) * CH_LDP + k];
+            }
+            if (!(d > 0.0) || !isfinite(d)) fail = true;
+            double r = __builtin_amdgcn_rsq(d);
+            r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
+            r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
+            double dj = d * r;
+            dj = fma(0.5 * r, fma(-dj, dj, d), dj);
+            const double l = lane == c ? dj : sacc * r;
+            a[c] = lane >= c ? l : 0.0;
+            if (lane >= c && lane < CH_NB) L11[lane * CH_LDP + c] = a[c];
+            if (lane == c) L11[c * CH_LDP + CH_NB] = fma(r, fma(-dj, r, 1.0), r);      // reciprocal pivot
+            wave_lds_sync();
+        }
+        if (__builtin_amdgcn_ballot_w64(fail) != 0 && lane == 0) s_fail = 1;
+    }
+    __syncthreads();
+    // ---- rows below the diagonal block and the right-hand-side row: X L11^T = A21, one row per thread ----
+    if (t < nb) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = c <= t ? L11[t * CH_LDP + c] : 0.0;
+    } else if (t <= m) {
+        double x[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) x[c] = C[t * CH_LDP + c];
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            double acc = x[c];
+#pragma unroll
+            for (int k = 0; k < c; k++) acc -= x[k] * L11[c * CH_LDP + k];
+            x[c] = acc * L11[c * CH_LDP + CH_NB];
+        }
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = x[c];
+    }
+    // ---- publish my column: L into S (the later columns' updates read it), z into Z ----
+    if (t < m) {
+        double *dst = S + (long long)(c0 + t) * ld + c0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) if (c < nb && (t >= CH_NB || c <= t)) dst[c] = C[t * CH_LDP + c];
+    } else if (t == m) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) if (c < nb) Z[c0 + c] = C[t * CH_LDP + c];
+    }
+    mw_publish(&flags[j], gen);
+    // ---- backward substitution  L^T y = z, column oriented ----
+    double racc = 0.0;
+    for (int k = nblk - 1; k > j; k--) {
+        mw_wait(&yflags[k], gen);
+        const int kb = min(CH_NB, n - CH_NB * k);
+        if (t < nb) {
+            const double *Lk = C + (size_t)(CH_NB * (k - j)) * CH_LDP + t;            // L[32 k + r][c0 + t]
+            for (int r = 0; r < kb; r++) racc += Lk[r * CH_LDP] * Y[CH_NB * k + r];
+        }
+    }
+    if (t < CH_NB) ybuf[t] = t < nb ? C[m * CH_LDP + t] - racc : 0.0;
+    __syncthreads();
+    if (wave == 0) {
+        // y[c] for c = nb-1 .. 0:  y[c] = (rhs[c] - sum_{r > c} L[r][c] y[r]) / L[c][c];  lane c carries rhs[c]
+        double rhs = lane < CH_NB ? ybuf[lane] : 0.0;
+        for (int c = nb - 1; c >= 0; c--) {
+            const double yc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rhs), c), __builtin_amdgcn_readlane(__double2loint(rhs), c)) * L11[c * CH_LDP + CH_NB];
+            if (lane == c) rhs = yc;
+            else if (lane < c) rhs -= L11[c * CH_LDP + lane] * yc;
+        }
+        if (lane < nb) Y[c0 + lane] = rhs;
+    }
+    mw_publish(&yflags[j], gen);
+    if (tid == 0 && s_fail) ctl->lin_fail = 1;
+}
+
 // ================================================================================== pose-only problems in ONE kernel
 // MultiViewGeometry::ceresPnP (src/multi_view_geometry.cpp:492-586): one free pose, a few hundred fixed world points.  The
 // multi-kernel loop above costs ~10 launches of ~6 us per LM iteration whatever the problem size -- 0.45 ms per solve, four times
@@ -2182,6 +2359,7 @@ struct ov2_ba_dev {
     int *lm_order = nullptr;            // landmarks sorted by anchor keyframe (device)
     std::vector<double> h_poses0, h_lam0;
     int device = 0;
+    int chol_gen = 0;                   // launch stamp of k_ba_cholesky_mw's flags (Linv[0..127] as ints, zeroed at creation)
 };
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2417,6 +2595,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         hipError_t em = hipMemsetAsync(D.res_off, 0, na, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.bad_obs, 0, nr, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.lba_cnt, 0, 64, s);
+        if (em == hipSuccess) em = hipMemsetAsync(D.Linv, 0, 512, s);          // k_ba_cholesky_mw's flags
         if (em != hipSuccess) { ov2_set_error("hipMemsetAsync: %s", hipGetErrorString(em)); ba_destroy(dev); return OV2_EHIP; }
     }
     UP(D.po_kf, po_kf, 4 * (size_t)n_po); UP(D.po_orig, po_orig, 4 * (size_t)n_po);
@@ -2536,6 +2715,7 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     UPX(D.res_uv, res_uv.data(), 16 * (size_t)n_act);
     UPX(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
 #undef UPX
+    (void)hipMemsetAsync(D.Linv, 0, 512, s);                                   // k_ba_cholesky_mw's flags
     {
         const hipError_t es = hipStreamSynchronize(s);
         if (es != hipSuccess) { ov2_set_error("hipStreamSynchronize: %s", hipGetErrorString(es)); ba_destroy(dev); return OV2_EHIP; }
@@ -2601,6 +2781,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_schur_sparse);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize_xyz);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky_mw);
         });
         OV2_HIP_CHECK(attr_err);
     }
@@ -2662,6 +2843,19 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int ss_chunks = (D.nfp + ss_ncol - 1) / ss_ncol;
     const size_t ss_lds = 8 * (6 * (size_t)ss_ncol + (size_t)SS_WAVES * 64 * 6) + 4 * (size_t)SS_WAVES * 64 + 64;
 
+    // reduced system: the several-work-group Cholesky (block column per work-group, look-ahead by construction) from two block
+    // columns up to MW_MAX_N unknowns when OV2_BA_CHOL_MW=1 (default: the one-work-group kernel); OV2_BA_CHOL_XCD=1 keeps the
+    // work-groups on one XCD (every eighth id) instead of spreading them over all
+    const int mw_nblk = (D.nf + CH_NB - 1) / CH_NB;
+    const char *env_mw = getenv("OV2_BA_CHOL_MW"), *env_xcd = getenv("OV2_BA_CHOL_XCD");
+    // MEASURED (MI355X, gpurun_out/r3q): config 4 550 us per LM iteration with the work-groups on all XCDs, 629 on one XCD, against
+    // 532 with the one-work-group kernel -- every hand-over costs an L2 write-back + invalidate and a global round trip for the
+    // panel rows, and the row-per-thread column update reads the 32 x 32 block through 1024 LDS broadcasts per thread: the
+    // critical path per panel (factor 5 + solve 3 + hand-over ~4 + rows ~2 + update ~7 us) is no shorter than the old kernel's
+    // 27 us.  An MFMA column update would bring it to ~495 us (-7 %).  Kept as an opt-in (OV2_BA_CHOL_MW=1), parity-tested.
+    const bool chol_mw = !D.big && D.nf > CH_NB && D.nf <= MW_MAX_N && (env_mw && env_mw[0] == '1');
+    const int mw_stride = (env_xcd && env_xcd[0] == '1') ? 8 : 1;              // (all XCDs is the faster placement)
+    const size_t mw_lds = 8 * ((size_t)(D.nf + 1) * CH_LDP + 2 * (size_t)CH_NB * CH_LDP + CH_NB) + 64;
     auto linearize = [&]() {
         if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks), dim3(256), lin_lds, s, D);
         else if (D.n_lm > 0 && D.big) {
@@ -2726,6 +2920,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
                 }
             }
             if (budget > 0) hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
+        } else if (chol_mw) {
+            hipLaunchKernelGGL(k_ba_cholesky_mw, dim3(mw_nblk * mw_stride), dim3(512), mw_lds, s, D, ++dev->chol_gen, mw_stride);
         } else
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
