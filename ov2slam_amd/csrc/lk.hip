@@ -608,6 +608,11 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
     return prm;
 }
 
+// lkw.hip: a whole wavefront per keypoint (window 9): the single-frame kernel of record
+int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const void *prm_lk, int lp, int lf, int n_max, const int *n_dev,
+                           const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
+                           const float *sad_x, float sad_up);
+
 // launcher of the fused kltTracking kernel (used by track.hip); all pointers are device memory, *n_dev <= n_max
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
@@ -621,6 +626,13 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
                                err_th, fb_dist, 1, n_max);
     const int lf = prm.max_level;                                  // clamped to the pyramid like feature_tracker.cpp:50-52
     const int lp = lvl_prior > P.n_levels - 1 ? P.n_levels - 1 : (lvl_prior < 0 ? 0 : lvl_prior);
+    // window 9 (the reference's): the wavefront-per-keypoint kernel (lkw.hip) -- the 81 window pixels over all 64 lanes, the next
+    // level's search block requested while the current level iterates; OV2_TRACK_IMPL=row keeps the row-per-lane kernel (A/B)
+    {
+        const char *e = getenv("OV2_TRACK_IMPL");
+        if (win == 9 && !(e && !strcmp(e, "row")))
+            return ov2_launch_track_klt_w(s, P, C, &prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up);
+    }
     // keypoints per wavefront: 4.  One per wavefront (OV2_TRACK_KPW=1, 16 active lanes) was measured for the single-frame case:
     // no gain (0.107 vs 0.104 ms per frame, gpurun_out/r3i) -- the frame's latency is every keypoint's own dependent chain of
     // level visits, not the wait for the slowest of four
