@@ -10,6 +10,7 @@
 #include "xcd_map.hpp"
 #include <math.h>
 #include <mutex>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -31,6 +32,10 @@ struct ClaheParams {
     int til_ntx;         //       tiles per row of it (common.hpp: ov2_til_offset)
     int ysplit;          // apply kernel: work-groups per row of interpolation cells (1 in batch mode; a single image is cut
                          // into ~60 short row bands so that it does not run on 10 CUs only -- latency)
+    // strip kernel (k_clahe_apply_pyr): column strips per image, level 1 of the pyramid next to the level-0 destination
+    int nstrips;
+    long long l1_delta;  // byte offset of level 1's ROI pixel (0, 0) from the dst ROI pointer
+    int l1_pitch, l1_w, l1_h;
 };
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
@@ -404,10 +409,218 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
     }
 }
 
+// ---- strip kernel: CLAHE apply + pyramid level 1 + both REFLECT_101 borders in one walk (batch mode) -------------------
+// One WAVEFRONT per (column strip, image), walking the image top to bottom.  A lane owns one dword column (4 pixels) like
+// k_clahe_apply; the strip's first / last lane is a halo column (computed, not stored) so that every core lane finds its
+// horizontal neighbours in the lanes next to it (v_mov_dpp wave_shr / wave_shl) -- 752 pixels = 188 dwords = 63 + 62 + 63
+// core columns + 4 halo columns = 3 x 64 lanes.  What the separate kernels re-read from HBM stays in registers here:
+//   * level 0 is stored once (plus its mirror rows / border dwords, built from the lane's and its neighbour's dword);
+//   * pyrDown: the 5-tap horizontal sums of a row (v_dot4_u32_u8 on the lane's dword and its neighbours') roll through a
+//     five-row register window, every second row emits two level-1 pixels per lane (same integer arithmetic as k_pyr_level);
+//   * the four-LUT table of the strip's cell columns is staged once per row of cells, not once per work-group of 192 threads.
+// No work-group barrier, no LDS traffic besides the LUT look-ups.  Geometry: w % 4 == 0, dword-aligned rows, h >= 4.
+__device__ __forceinline__ uint32_t c_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }   // lane i <- lane i-1
+__device__ __forceinline__ uint32_t c_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }   // lane i <- lane i+1
+
+#define CS_UNROLL 6
+#define CS_MAX_STRIPS 8
+__global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
+                                                                          uint8_t *__restrict__ dst)
+{
+    extern __shared__ __align__(16) unsigned char clahe_smem[];
+    uint32_t *lut4 = (uint32_t *)clahe_smem;                            // (tiles_x + 1 cell columns) x 256 packed LUT quadruples
+    // one work-group per image, one wavefront per column strip: the strips share the LUT table (two barriers per row of cells),
+    // everything else is wave-private
+    const int b = blockIdx.x, s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, ndw = P.w >> 2;
+    // core columns of strip s: 63 (first), 62 (middle), <= 63 (last); lane 0 of every strip but the first is the left halo
+    const int core0 = s == 0 ? 0 : 63 + 62 * (s - 1);
+    const int core1 = s == P.nstrips - 1 ? ndw : 63 + 62 * s;
+    const int d_first = s == 0 ? 0 : core0 - 1;
+    const int d_raw = d_first + lane;
+    const int d = min(d_raw, ndw - 1);                                  // lanes beyond the strip recompute the last column
+    const bool core = d_raw >= core0 && d_raw < core1;
+    const int xb = 4 * d;
+    const int cmin = 0, ncell = P.tiles_x + 1;
+    float xa[4], xa1[4];
+    const uint32_t *lutc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float txf = (float)(xb + k) * P.inv_tw - 0.5f;
+        const int fx = (int)floorf(txf);
+        xa[k] = txf - (float)fx; xa1[k] = 1.0f - xa[k];
+        lutc[k] = lut4 + ((fx + 1 - cmin) << 8);
+    }
+    const c_f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
+    const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;
+    uint8_t *dimg = dst + (long long)b * P.dst_item_stride;
+    uint8_t *l1 = dimg + P.l1_delta;
+    const int win = P.border;
+    // Border columns this lane writes besides its own: level 0 in dwords, level 1 in pixel pairs -- pixel -k is pixel k, pixel
+    // w - 1 + k is pixel w - 1 - k.  The kernel is bound by the SCALAR unit if one lets it (a wavefront walking 480 rows does
+    // all its row bookkeeping on the SALU, which issues once per four cycles like the VALU): so no store is predicated -- halo
+    // lanes store their (identical) copy of the neighbouring strip's dword, lanes without a border column / level-1 pair aim
+    // at the row's alignment slack right of the border (never consumed) -- row pointers advance by one scalar add, and the
+    // switch to the next row of cells is one scalar compare against a precomputed row number.
+    const int nb0 = (win + 3) >> 2, nb1 = (win + 1) >> 1;
+    const bool bl0 = core && d < nb0, br0 = core && d >= ndw - nb0;
+    const bool bl1 = core && d >= 1 && d <= nb1, br1 = core && d >= ndw - nb1;
+    const bool edge_strip = s == 0 || core1 > ndw - max(nb0, nb1);      // (uniform) only these strips hold border lanes
+    const bool first_col = d_raw == 0, last_col = d_raw == ndw - 1;
+    const uint32_t pad0 = 4u * nb0, pad1 = 2u * nb1;
+    const uint32_t slack0 = pad0 + (uint32_t)P.w + 4u * nb0, slack1 = pad1 + (uint32_t)P.l1_w + 2u * nb1;
+    const uint32_t o0 = pad0 + 4u * d;
+    const uint32_t o0b = bl0 ? pad0 - 4u * (d + 1) : (br0 ? pad0 + (uint32_t)P.w + 4u * (ndw - 1 - d) : slack0);
+    const uint32_t o1 = core ? pad1 + 2u * d : slack1;
+    const uint32_t o1b = bl1 ? pad1 - 2u * d : (br1 ? pad1 + (uint32_t)P.l1_w + 2u * (ndw - 1 - d) : slack1);
+    uint8_t *d0m = dimg - pad0, *d1m = l1 - pad1;
+
+    auto cell_row = [&](int y) { return (int)floorf((float)y * P.inv_th - 0.5f) + 1; };
+    int cy = -1, y_switch = 0;                                          // rows [.., y_switch) belong to the row of cells cy
+    auto stage = [&](int y) {
+        cy = cell_row(y);
+        int yn = max(y + 1, (int)(((float)cy + 0.5f) * (float)P.th) - 2);
+        while (yn < P.h && cell_row(yn) == cy) yn++;
+        y_switch = yn;
+        const int ty1 = max(cy - 1, 0), ty2 = min(cy, P.tiles_y - 1);
+        __syncthreads();                                                // the previous table's look-ups are done
+        for (int e = threadIdx.x; e < ncell * 64; e += blockDim.x) {
+            const int cx = cmin + (e >> 6), v4 = (e & 63) * 4;
+            const int tx1 = max(cx - 1, 0), tx2 = min(cx, P.tiles_x - 1);
+            const uint32_t a = *(const uint32_t *)(L + (ty1 * P.tiles_x + tx1) * 256 + v4), bb = *(const uint32_t *)(L + (ty1 * P.tiles_x + tx2) * 256 + v4);
+            const uint32_t c = *(const uint32_t *)(L + (ty2 * P.tiles_x + tx1) * 256 + v4), dd = *(const uint32_t *)(L + (ty2 * P.tiles_x + tx2) * 256 + v4);
+            const uint32_t ab01 = __builtin_amdgcn_perm(bb, a, 0x05010400u), ab23 = __builtin_amdgcn_perm(bb, a, 0x07030602u);
+            const uint32_t cd01 = __builtin_amdgcn_perm(dd, c, 0x05010400u), cd23 = __builtin_amdgcn_perm(dd, c, 0x07030602u);
+            c_u32x4 o;
+            o.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u); o.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
+            o.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u); o.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
+            *(c_u32x4 *)(lut4 + ((e >> 6) << 8) + v4) = o;
+        }
+        __syncthreads();
+    };
+    // a level-0 row: every lane's dword and, in the edge strips, the border dword
+    auto put0 = [&](uint8_t *row, uint32_t v, uint32_t bv) {
+        *(uint32_t *)(row + o0) = v;
+        if (edge_strip) *(uint32_t *)(row + o0b) = bv;
+    };
+    auto put1 = [&](uint8_t *row, uint32_t v, uint32_t bv) {               // a level-1 row: pixel pairs
+        *(uint16_t *)(row + o1) = (uint16_t)v;
+        if (edge_strip) *(uint16_t *)(row + o1b) = (uint16_t)bv;
+    };
+    typedef unsigned short cu16x2 __attribute__((ext_vector_type(2)));
+    uint8_t *r1 = d1m;                                                  // level-1 row of the next emit
+    // level-1 row Y from the horizontal sums of level-0 rows 2Y-2 .. 2Y+2 (packed pairs, <= 16 * 255 each); rows are emitted in order.
+    // The REFLECT_101 border mirrors rows 1 .. win above the image and rows h1-1-win .. h1-2 below it: the same stores once more
+    auto emit = [&](int Y, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4, auto mirror_c) {
+        constexpr bool MIRROR = decltype(mirror_c)::value;
+        const cu16x2 s0 = __builtin_bit_cast(cu16x2, c0), s1 = __builtin_bit_cast(cu16x2, c1), s2 = __builtin_bit_cast(cu16x2, c2),
+                     s3 = __builtin_bit_cast(cu16x2, c3), s4 = __builtin_bit_cast(cu16x2, c4);
+        const cu16x2 v = (s2 * (unsigned short)6 + (s1 + s3) * (unsigned short)4 + s0 + s4 + (unsigned short)128) >> (unsigned short)8;
+        const uint32_t o = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, v), 0x0c0c0200u);       // (v0, v1) as two bytes
+        uint32_t bv = 0;
+        if (edge_strip) bv = __builtin_amdgcn_perm(c_wave_shr1(o), o, 0x0c0c0500u);    // border pair: (own first pixel, left neighbour's second)
+        put1(r1, o, bv);
+        r1 += P.l1_pitch;
+        if (MIRROR) {
+            if (Y >= 1 && Y <= win) put1(d1m - (long long)Y * P.l1_pitch, o, bv);
+            if (Y >= P.l1_h - 1 - win && Y <= P.l1_h - 2) put1(d1m + (long long)(2 * (P.l1_h - 1) - Y) * P.l1_pitch, o, bv);
+        }
+    };
+
+    uint32_t hA = 0, hB = 0, hC = 0, hD = 0, hE = 0;                      // horizontal sums of rows y-4 .. y
+    const uint8_t *srow = src + (long long)b * P.src_item_stride;        // (uniform) source row of the next prefetch
+    const uint32_t xo = (uint32_t)xb;
+    uint8_t *r0 = d0m;                                                  // level-0 row of the next store
+    uint32_t inr[CS_UNROLL], nxt[CS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < CS_UNROLL; u++) inr[u] = *(const uint32_t *)(srow + (long long)min(u, P.h - 1) * P.stride + xo);
+    srow += (long long)CS_UNROLL * P.stride;
+    // one row: CLAHE blend of the lane's four pixels, level-0 stores, horizontal pyrDown sums into the rolling window.
+    // MIRROR: the row may be one the REFLECT_101 border mirrors (-y for 1 <= y <= win, 2 (h-1) - y for h-1-win <= y <= h-2)
+    auto do_row = [&](int y, uint32_t in, auto mirror_c) {
+        constexpr bool MIRROR = decltype(mirror_c)::value;
+        const float tyf = (float)y * P.inv_th - 0.5f;
+        const float ya = tyf - (float)(cy - 1), ya1 = 1.0f - ya;
+        const c_f32x2 YA = {ya, ya}, YB = {ya1, ya1};
+        const uint32_t q0 = lutc[0][in & 0xFF], q1 = lutc[1][(in >> 8) & 0xFF], q2 = lutc[2][(in >> 16) & 0xFF], q3 = lutc[3][in >> 24];
+        const c_f32x2 A11 = {c_ub(q0, 0), c_ub(q1, 0)}, A12 = {c_ub(q0, 1), c_ub(q1, 1)}, A21 = {c_ub(q0, 2), c_ub(q1, 2)}, A22 = {c_ub(q0, 3), c_ub(q1, 3)};
+        const c_f32x2 B11 = {c_ub(q2, 0), c_ub(q3, 0)}, B12 = {c_ub(q2, 1), c_ub(q3, 1)}, B21 = {c_ub(q2, 2), c_ub(q3, 2)}, B22 = {c_ub(q2, 3), c_ub(q3, 3)};
+        const c_f32x2 r01 = (A11 * XB01 + A12 * XA01) * YB + (A21 * XB01 + A22 * XA01) * YA;
+        const c_f32x2 r23 = (B11 * XB23 + B12 * XA23) * YB + (B21 * XB23 + B22 * XA23) * YA;
+        uint32_t out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.x), 0, 0u);
+        out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.y), 1, out);
+        out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.x), 2, out);
+        out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.y), 3, out);
+        // neighbours: pixels xb-2, xb-1 (left lane's bytes 2, 3) and xb+4 (right lane's byte 0); REFLECT_101 at the image edge
+        uint32_t lf = c_wave_shr1(out), rt = c_wave_shl1(out);
+        if (first_col) lf = __builtin_amdgcn_perm(out, out, 0x01020000u);      // (.., .., p2, p1)
+        if (last_col) rt = out >> 16;                                          // p(w) = p(w-2)
+        uint32_t bv = 0;                                                        // border dword of the edge lanes:
+        if (edge_strip)                                                         // (p[4d+4], p[4d+3], p[4d+2], p[4d+1]) left, (p[xb+2], p[xb+1], p[xb], p[xb-1]) right
+            bv = bl0 ? __builtin_amdgcn_perm(out, rt, 0x05060700u) : __builtin_amdgcn_perm(out, lf, 0x03040506u);
+        put0(r0, out, bv);
+        r0 += P.dst_stride;
+        if (MIRROR) {
+            if (y >= 1 && y <= win) put0(d0m - (long long)y * P.dst_stride, out, bv);
+            if (y >= P.h - 1 - win && y <= P.h - 2) put0(d0m + (long long)(2 * (P.h - 1) - y) * P.dst_stride, out, bv);
+        }
+        // pyrDown, horizontal: sums centred on pixels xb and xb + 2
+        const uint32_t l0 = __builtin_amdgcn_alignbyte(out, lf, 2);
+        const uint32_t h0 = __builtin_amdgcn_udot4(l0, 0x04060401u, __builtin_amdgcn_udot4(out, 0x00010000u, 0u, false), false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(out, 0x04060401u, __builtin_amdgcn_udot4(rt, 0x00000001u, 0u, false), false);
+        hA = hB; hB = hC; hC = hD; hD = hE; hE = h0 | (h1 << 16);
+    };
+    // Rows go in groups of six (the prefetch distance).  Almost every group is FAST: no row of it is mirrored by a border, the
+    // table of its row of cells is already staged, all six rows exist -- straight-line code, so that the look-ups and loads of
+    // one row overlap the arithmetic of another.  The few others (top / bottom of the image, a switch of tables inside the
+    // group) take the rolled loop below with every test per row.
+    for (int yb = 0; yb < P.h; yb += CS_UNROLL) {
+        if (yb + 2 * CS_UNROLL <= P.h) {
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = *(const uint32_t *)(srow + xo); srow += P.stride; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; u++)
+                nxt[u] = *(const uint32_t *)(src + (long long)b * P.src_item_stride + (long long)min(yb + CS_UNROLL + u, P.h - 1) * P.stride + xo);
+        }
+        if (yb == y_switch) stage(yb);
+        // (level-0 rows yb .. yb+5 and the level-1 rows (yb-2)/2 .. (yb+2)/2 they complete are not mirrored by a border)
+        const bool fast = yb > 2 * win + 2 && yb + CS_UNROLL - 1 < P.h - 1 - win && yb + CS_UNROLL - 4 < 2 * (P.l1_h - 1 - win) &&
+                          y_switch >= yb + CS_UNROLL && yb + CS_UNROLL <= P.h;
+        if (fast) {
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; u++) {
+                do_row(yb + u, inr[u], std::false_type());
+                if ((u & 1) == 0) emit((yb + u - 2) >> 1, hA, hB, hC, hD, hE, std::false_type());   // yb is even, > 2
+            }
+        } else {
+#pragma nounroll
+            for (int u = 0; u < CS_UNROLL; u++) {
+                const int y = yb + u;
+                if (y >= P.h) break;
+                if (y == y_switch) stage(y);
+                do_row(y, inr[0], std::true_type());
+                if (!(y & 1)) {
+                    if (y == 2) emit(0, hE, hD, hC, hD, hE, std::true_type());        // rows -2, -1 mirror rows 2, 1
+                    else if (y > 2) emit((y - 2) >> 1, hA, hB, hC, hD, hE, std::true_type());
+                }
+#pragma unroll
+                for (int k = 0; k + 1 < CS_UNROLL; k++) inr[k] = inr[k + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CS_UNROLL; u++) inr[u] = nxt[u];
+    }
+    // the last level-1 row: its window hangs over the bottom edge (row h mirrors h-2, row h+1 mirrors h-3)
+    if (P.h & 1) emit((P.h - 1) >> 1, hC, hD, hE, hD, hC, std::true_type());
+    else emit((P.h - 2) >> 1, hB, hC, hD, hE, hD, std::true_type());
+}
+
 int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                      double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                     uint8_t *lut_d, int border, long long til_delta, int til_ntx)
+                     uint8_t *lut_d, int border, long long til_delta, int til_ntx, const PyrDesc *pyr, int *level1_done)
 {
+    if (level1_done) *level1_done = 0;
     // geometry checks first: nothing is enqueued when the call is going to fail
     OV2_REQUIRE(tiles_x + 1 <= CLAHE_MAX_CELLS && (size_t)(tiles_x + 1) * 1024 <= 160 * 1024, OV2_EUNSUPPORTED,
                 "CLAHE: too many tile columns / too wide an image for the LDS tables");
@@ -423,6 +636,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     OV2_HIP_CHECK(attr_err);
     ClaheParams P;
     P.border = border; P.til_delta = til_delta; P.til_ntx = til_ntx;
+    P.nstrips = 0; P.l1_delta = 0; P.l1_pitch = P.l1_w = P.l1_h = 0;
     int ew = w, eh = h;
     if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
     P.w = w; P.h = h; P.stride = stride; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
@@ -439,6 +653,26 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     P.ysplit = (long long)batch * (tiles_y + 1) >= 256 ? 1 : (P.th >= 48 ? 6 : (P.th >= 16 ? 3 : 1));
     P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
     hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+    // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk
+    // (OV2_CLAHE_STRIPS=1 forces it for any batch, =0 disables it -- A/B runs, parity tests of both paths)
+    if (pyr && pyr->n_levels >= 2 && !pyr->tiled && til_delta == 0 && border == pyr->win && src_al && (w & 3) == 0 && w >= 64 && h >= 8 &&
+        (((size_t)dst_d | (size_t)dst_stride | dst_batch_stride) & 3) == 0 && (pyr->lv[1].img_pitch & 1) == 0) {
+        const int ndw = w / 4, nstrips = ndw <= 64 ? 1 : 2 + (ndw - 126 + 61) / 62;
+        const char *e = getenv("OV2_CLAHE_STRIPS");
+        const bool want = e ? e[0] == '1' : (long long)batch * nstrips >= 1024;
+        if (want && nstrips <= CS_MAX_STRIPS && tiles_x + 1 <= 40) {
+            static std::once_flag strip_once;
+            static hipError_t strip_err = hipSuccess;
+            std::call_once(strip_once, [] { strip_err = hipFuncSetAttribute((const void *)k_clahe_apply_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024); });
+            OV2_HIP_CHECK(strip_err);
+            P.nstrips = nstrips;
+            P.l1_delta = pyr->lv[1].img_roi - pyr->lv[0].img_roi; P.l1_pitch = pyr->lv[1].img_pitch; P.l1_w = pyr->lv[1].w; P.l1_h = pyr->lv[1].h;
+            hipLaunchKernelGGL(k_clahe_apply_pyr, dim3(batch), dim3(64 * nstrips), (size_t)(tiles_x + 1) * 1024, ctx->stream, P, src_d, lut_d, dst_d);
+            OV2_HIP_CHECK(hipGetLastError());
+            if (level1_done) *level1_done = 1;
+            return OV2_OK;
+        }
+    }
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 2048 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 511) / 512;
@@ -461,7 +695,7 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
     const int rc = ctx->reserve_device(lut_bytes);
     if (rc != OV2_OK) return rc;
     return ov2_launch_clahe(ctx, src_d, w, h, stride, src_batch_stride, batch, clip_limit, tiles_x, tiles_y, dst_d, dst_stride,
-                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0, 0, 0);
+                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0, 0, 0, nullptr, nullptr);
 }
 
 int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
@@ -477,11 +711,12 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
     // the equalised image is written straight into the pyramid's padded level-0 slot (no intermediate image,
     // no level-0 copy); borders and the coarser levels follow from there
     const PyrLevelDesc &L0 = p->d.lv[0];
+    int l1_done = 0;
     rc = ov2_launch_clahe(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
                           p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win,
-                          p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
+                          p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx, &p->d, &l1_done);
     if (rc != OV2_OK) return rc;
-    rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+    rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0, l1_done);
     if (rc != OV2_OK) return rc;
     return ov2_pyr_mark_ready(ctx, p);
 }
@@ -502,10 +737,11 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     rc = ctx->upload_image(ds, pitch, img_h, (size_t)stride, (size_t)p->w, (size_t)p->h);
     if (rc != OV2_OK) return rc;
     const PyrLevelDesc &L0 = p->d.lv[0];
+    int l1_done = 0;
     rc = ov2_launch_clahe(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
-                          (size_t)p->d.item_stride, ds + img, p->d.win, p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
+                          (size_t)p->d.item_stride, ds + img, p->d.win, p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx, &p->d, &l1_done);
     if (rc != OV2_OK) return rc;
-    rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0);
+    rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0, l1_done);
     if (rc != OV2_OK) return rc;
     return ov2_pyr_mark_ready(ctx, p);
 }
@@ -524,7 +760,7 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
     rc = ctx->upload_image(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h);
     if (rc != OV2_OK) return rc;
-    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, 0, 0);
+    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, 0, 0, nullptr, nullptr);
     if (rc2 != OV2_OK) return rc2;
     rc = ctx->download_image(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h);      // (synchronises)
     if (rc != OV2_OK) return rc;

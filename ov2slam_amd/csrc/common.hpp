@@ -113,11 +113,13 @@ int ov2_pyr_mark_ready(ov2_ctx *ctx, ov2_pyr *p);              // after the last
 int ov2_pyr_wait_ready(ov2_ctx *ctx, const ov2_pyr *p);        // before the first kernel of a consumer
 
 // kernels' host launchers (defined in the .hip files)
-int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride);
+// from_level = 1: levels 0 and 1 (borders included) are already in place (k_clahe_apply_pyr)
+int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride, int from_level = 0);
 // cv::CLAHE::apply on `batch` device images; border > 0: dst is a padded pyramid level, its REFLECT_101 border is written too
 int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                      double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                     uint8_t *lut_d, int border, long long til_delta = 0, int til_ntx = 0);
+                     uint8_t *lut_d, int border, long long til_delta = 0, int til_ntx = 0, const struct PyrDesc *pyr = nullptr,
+                     int *level1_done = nullptr);
 // fused VisualFrontEnd::kltTracking launch (lk.hip), device pointers only
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_scharr_level(PyrDesc P, int level, int 
     out[(long long)y * L.w + x] = ((uint32_t)(uint16_t)(int16_t)dx) | (((uint32_t)(uint16_t)(int16_t)dy) << 16);
 }
 
-int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride)
+int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride, int from_level)
 {
     const PyrDesc &P = p->d;
     auto border = [&](int l) {
@@ -336,7 +336,7 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
         const int n = 2 * P.win * ((PB_LEFT + wend) >> 2) + L.h * (PB_LEFT / 4 + ((wend - (L.w & ~3)) >> 2));
         hipLaunchKernelGGL(k_pyr_border, dim3((n + 255) / 256, 1, P.batch), dim3(256), 0, ctx->stream, P, l);
     };
-    for (int l = 0; l < P.n_levels; l++) {
+    for (int l = from_level; l < P.n_levels; l++) {
         const PyrLevelDesc &L = P.lv[l];
         const int gx = (L.w + PT_W - 1) / PT_W, gy = (L.h + PT_H - 1) / PT_H;
         dim3 grid(gx * gy * P.batch);                       // 1-D: the kernel decodes (image, tile) XCD-aware

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Pre-processing step on the GPU box in isolation: ov2_pyr_build_clahe_d (CLAHE LUT + apply [+ level 1] + pyramid levels) on S
+resident 752x480 frames, HIP-event time per call.  Usage: pre_micro.py [S] [reps]; under rocprofv3 for per-kernel counters."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import ov2slam_amd
+from ov2slam_amd import _lib as L
+import bench
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+views, _, _ = bench.make_inputs(S, 1234)
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream()
+ctx = ov2slam_amd.Context(0, stream=stream.cuda_stream)
+lib = ctx.lib
+W, H = bench.W, bench.H
+fr = torch.from_numpy(views[:2]).to(dev)[:, None].expand(-1, S, H, W).contiguous()
+P = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=S)
+ts = []
+for r in range(reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    L.check(lib.ov2_pyr_build_clahe_d(ctx.h, P.h_pyr, C.c_void_p(fr[r & 1].data_ptr()), W, W * H, C.c_double(3.0), W // 50, H // 50))
+    e1.record(stream); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+print("S=%d  pre-processing per call: min %.1f us  median %.1f us   (%s)" % (S, min(ts[1:]) * 1e3, float(np.median(ts[1:])) * 1e3,
+      "OV2_CLAHE_STRIPS=" + os.environ.get("OV2_CLAHE_STRIPS", "auto")))
