@@ -547,10 +547,13 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
         const c_f32x2 B11 = {c_ub(q2, 0), c_ub(q3, 0)}, B12 = {c_ub(q2, 1), c_ub(q3, 1)}, B21 = {c_ub(q2, 2), c_ub(q3, 2)}, B22 = {c_ub(q2, 3), c_ub(q3, 3)};
         const c_f32x2 r01 = (A11 * XB01 + A12 * XA01) * YB + (A21 * XB01 + A22 * XA01) * YA;
         const c_f32x2 r23 = (B11 * XB23 + B12 * XA23) * YB + (B21 * XB23 + B22 * XA23) * YA;
-        uint32_t out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.x), 0, 0u);
-        out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r01.y), 1, out);
-        out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.x), 2, out);
-        out = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r23.y), 3, out);
+        // cvRound + saturate_cast<uchar>: 0 <= res < 255.5 (a convex combination of bytes), so adding 1.5 * 2^23 rounds to the
+        // nearest even integer in the float's low mantissa byte -- two packed adds and three byte permutes for four pixels
+        const c_f32x2 MAGIC = {12582912.0f, 12582912.0f};
+        const c_f32x2 m01 = r01 + MAGIC, m23 = r23 + MAGIC;
+        const uint32_t u0 = __builtin_bit_cast(uint32_t, (float)m01.x), u1 = __builtin_bit_cast(uint32_t, (float)m01.y);
+        const uint32_t u2 = __builtin_bit_cast(uint32_t, (float)m23.x), u3 = __builtin_bit_cast(uint32_t, (float)m23.y);
+        const uint32_t out = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u3, u2, 0x0c0c0400u), __builtin_amdgcn_perm(u1, u0, 0x0c0c0400u), 0x05040100u);
         // neighbours: pixels xb-2, xb-1 (left lane's bytes 2, 3) and xb+4 (right lane's byte 0); REFLECT_101 at the image edge
         uint32_t lf = c_wave_shr1(out), rt = c_wave_shl1(out);
         if (first_col) lf = __builtin_amdgcn_perm(out, out, 0x01020000u);      // (.., .., p2, p1)
