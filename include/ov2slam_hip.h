@@ -445,8 +445,9 @@ int ov2_structure_ba(ov2_ctx *ctx, const ov2_sba_problem *p, const ov2_ba_option
  * residual block with a VARIABLE keyframe pose (factors src/ceres_parametrization.cpp:107-298); kf_const marks the
  * SetParameterBlockConstant keyframes (:397-407).  Same options, termination codes and N4 outputs as ov2_ba_solve; the
  * Schur complement eliminates 3x3 point blocks.  No shipped parameter file selects this branch; the inverse-depth form
- * (ov2_ba_solve) is what every preset runs.  Limit: ~90 optimised keyframes (OV2_EUNSUPPORTED beyond; the
- * large-problem path of ov2_ba_solve -- up to 1024 optimised keyframes -- covers the inverse-depth form only).      */
+ * (ov2_ba_solve) is what every preset runs.  Limit: ~450 optimised keyframes (OV2_EUNSUPPORTED beyond): W stays dense in
+ * this form (3 rows per wavefront in LDS); beyond ~90 keyframes its reduced system is factored by the same multi-kernel
+ * Cholesky on HBM as ov2_ba_solve's large-problem path (which reaches 1024 keyframes with a sparse W).              */
 typedef struct {
     int n_kf;
     const double *poses;         /* 7*n_kf  [tx ty tz qx qy qz qw] of Twc, initial values      */

@@ -70,6 +70,9 @@ struct BADev {                    // device pointers + sizes (passed by value to
     // global atomics, the Schur complement is accumulated row block by row block in LDS from per-keyframe slot lists
     // (k_ba_schur_sparse) and the reduced system is factored by a multi-kernel blocked Cholesky on HBM (k_chol_*).
     int big, n_cw;
+    int chol_hbm;                 // reduced system factored by the multi-kernel Cholesky on HBM (k_chol_*): always with big, and for 3-D point
+                                  // problems (dense W, k_ba_schur_gemm) whose reduced system outgrows the one-work-group LDS kernel
+    int lin_waves;                // 3-D point lineariser: wavefronts per work-group (each keeps 3 rows of W in LDS: 4 up to ~200 keyframes, 2, 1 up to ~450)
     int lin_direct;               // big path with more optimised keyframes than the work-group's LDS can pre-aggregate (n_opt x 27 doubles:
                                   // ~570): observer diagonal blocks and F^T b go to H / bf with global atomics as well
     double *cww;                  // 6*n_cw   slot values (zeroed by k_ba_zero_lin, filled by the lineariser)          [big]
@@ -2079,13 +2082,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize_xyz(BADev D)
     if (ctl->done || !ctl->need_lin) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int n_opt = D.nf / 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     double *wrow = (double *)smem_raw + wave * 3 * D.nfp;
-    double *Hoo = (double *)smem_raw + 4 * 3 * D.nfp;
+    double *Hoo = (double *)smem_raw + nw * 3 * D.nfp;
     double *bo = Hoo + n_opt * 21;
     for (int e = threadIdx.x; e < n_opt * 27; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
-    const int total_waves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int total_waves = gridDim.x * nw, gw = blockIdx.x * nw + wave;
     const int chunk = (D.n_lm + total_waves - 1) / total_waves;
     const int i0 = gw * chunk, i1 = min(D.n_lm, i0 + chunk);
     double cost = 0;
@@ -2496,6 +2499,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         // beyond ~570 optimised keyframes the big-path linearisers cannot pre-aggregate the observer blocks in LDS either
         D.lin_direct = (D.big && 8 * ((size_t)n_opt * 27 + 4 * (size_t)LIN_RED) + 64 > 159 * 1024) ? 1 : 0;
         if (const char *e = getenv("OV2_BA_LIN_DIRECT")) D.lin_direct = (D.big && e[0] == '1') ? 1 : D.lin_direct;   // tests: force it on small problems
+        D.chol_hbm = D.big; D.lin_waves = 4;
     }
     // big path: the slots of the sparse W (one per landmark and optimised keyframe seeing or anchoring it) and their per-keyframe lists
     std::vector<int> cw_ptr(p->n_lm + 1, 0), cw_col, cw_lm, res_cw, lm_cwa, kfl_ptr(n_opt + 1, 0), kfl_idx;
@@ -2638,16 +2642,21 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     int n_opt = 0;
     for (int k = 0; k < p->n_kf; k++) pose_col[k] = (p->kf_const && p->kf_const[k]) ? -1 : 6 * n_opt++;
     const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
-    OV2_REQUIRE(nfp <= 2048, OV2_EUNSUPPORTED, "more than 341 optimised keyframes: dense reduced system too large");
-    {   // size limits BEFORE anything is allocated or uploaded (W and W' alone are 2 x 24 n_pts nfp bytes): the 3-D point form
-        // has no large-problem path, its lineariser and Cholesky hold the reduced system in LDS
-        const size_t lin_lds = 8 * (12 * (size_t)nfp + (size_t)n_opt * 27) + 64;
-        const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
-        if (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) {
-            ov2_set_error("too many optimised keyframes (%d) for the LDS-resident solver (limit ~90; 3-D point landmarks and pose-only blocks have no large-problem path)", n_opt);
-            return OV2_EUNSUPPORTED;
-        }
+    // Size limits BEFORE anything is allocated or uploaded (W and W' alone are 2 x 24 n_pts nfp bytes).  The 3-D point form keeps
+    // W dense: its lineariser holds 3 rows of it per wavefront in LDS next to the observer blocks (4 wavefronts per work-group up
+    // to ~200 optimised keyframes, then 2, then 1: ~450), and beyond ~90 keyframes the reduced system is factored by the
+    // multi-kernel Cholesky on HBM instead of the one-work-group LDS kernel.
+    int lin_waves = 0;
+    for (int nw = 4; nw >= 1 && !lin_waves; nw >>= 1)
+        if (8 * (3 * (size_t)nw * nfp + (size_t)n_opt * 27) + 64 <= 159 * 1024) lin_waves = nw;
+    if (const char *e = getenv("OV2_BA_XYZ_LIN_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2) lin_waves = lin_waves ? std::min(lin_waves, v) : 0; }   // tests
+    if (!lin_waves || nfp > BA_MAX_NFP) {
+        ov2_set_error("too many optimised keyframes (%d) for the 3-D point form (limit ~450: dense W rows in LDS)", n_opt);
+        return OV2_EUNSUPPORTED;
     }
+    const size_t chol_lds_res = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
+    int chol_hbm = chol_lds_res > 150 * 1024 ? 1 : 0;
+    if (const char *e = getenv("OV2_BA_BIG")) chol_hbm = e[0] == '1' ? 1 : chol_hbm;                 // tests: force the HBM factorisation on small problems
     std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
     std::vector<uint8_t> res_type(n_act);
     std::vector<double> res_uv(2 * (size_t)n_act), res_sigma(n_act);
@@ -2666,6 +2675,7 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     BADev &D = dev->D;
     memset(&D, 0, sizeof(D));
     D.n_kf = p->n_kf; D.n_lm = p->n_pts; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = 0; D.ldim = 3;
+    D.chol_hbm = chol_hbm; D.lin_waves = lin_waves;
     const size_t nl = (size_t)std::max(1, p->n_pts), na = (size_t)std::max(1, n_act), nr = (size_t)std::max(1, p->n_res);
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
@@ -2752,12 +2762,12 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     // size limits first: nothing is created or enqueued for a problem this path cannot solve
     const int n_opt = D.nf / 6;
     const size_t lin_lds = D.big ? 8 * ((D.lin_direct ? 0 : (size_t)(D.nf / 6) * 27) + 4 * (size_t)LIN_RED) + 64
-                         : D.ldim == 3 ? 8 * (12 * (size_t)D.nfp + (size_t)n_opt * 27) + 64
+                         : D.ldim == 3 ? 8 * (3 * (size_t)D.lin_waves * D.nfp + (size_t)n_opt * 27) + 64
                                        : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
-    const size_t chol_lds = D.big ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64       // k_chol_solve: scratch block + the solution vector
+    const size_t chol_lds = D.chol_hbm ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64  // k_chol_solve: scratch block + the solution vector
                                   : 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
-    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser (limit ~90; 3-D point landmarks and pose-only blocks have no large-problem path)");
-    OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky (limit ~90 optimised keyframes)");
+    OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
+    OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky");
     {   // dynamic-LDS limits are per-function, process-wide attributes: raise them once to the hardware maximum (two
         // contexts solving problems of different size on two threads would otherwise race on them)
         static std::once_flag attr_once;
@@ -2853,11 +2863,11 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     // panel rows, and the row-per-thread column update reads the 32 x 32 block through 1024 LDS broadcasts per thread: the
     // critical path per panel (factor 5 + solve 3 + hand-over ~4 + rows ~2 + update ~7 us) is no shorter than the old kernel's
     // 27 us.  An MFMA column update would bring it to ~495 us (-7 %).  Kept as an opt-in (OV2_BA_CHOL_MW=1), parity-tested.
-    const bool chol_mw = !D.big && D.nf > CH_NB && D.nf <= MW_MAX_N && (env_mw && env_mw[0] == '1');
+    const bool chol_mw = !D.chol_hbm && D.nf > CH_NB && D.nf <= MW_MAX_N && (env_mw && env_mw[0] == '1');
     const int mw_stride = (env_xcd && env_xcd[0] == '1') ? 8 : 1;              // (all XCDs is the faster placement)
     const size_t mw_lds = 8 * ((size_t)(D.nf + 1) * CH_LDP + 2 * (size_t)CH_NB * CH_LDP + CH_NB) + 64;
     auto linearize = [&]() {
-        if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks), dim3(256), lin_lds, s, D);
+        if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks * (4 / D.lin_waves)), dim3(64 * D.lin_waves), lin_lds, s, D);
         else if (D.n_lm > 0 && D.big) {
             hipLaunchKernelGGL(k_ba_zero_lin, dim3(1024), dim3(256), 0, s, D);
             hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
@@ -2908,7 +2918,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split, ss_chunks), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split, ss_ncol);
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
         if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
-        if (D.big) {
+        if (D.chol_hbm) {
             int budget = getenv("OV2_BA_CHOL_STAGES") ? atoi(getenv("OV2_BA_CHOL_STAGES")) : 1 << 30;      // debugging: stop the factorisation early
             for (int k0 = 0; k0 < D.nf; k0 += CH_NB) {
                 const int m = D.nf - k0 - std::min(CH_NB, D.nf - k0);

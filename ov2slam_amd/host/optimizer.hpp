@@ -83,7 +83,7 @@ struct FlatXYZProblem : FlatStructureProblem {
 struct LocalBAResult {
     bool ok = false, l2_done = false;
     // why a solve was skipped (ok == false): the library's return code and message, e.g. OV2_EUNSUPPORTED "reduced system too
-    // large ..." when more than 341 keyframes are optimised (~90 for 3-D point landmarks) -- log it, do not drop it
+    // large ..." when more than 1024 keyframes are optimised (~450 for 3-D point landmarks) -- log it, do not drop it
     int error_code = OV2_OK;
     std::string error;
     std::vector<double> poses, invdepth, chi2;

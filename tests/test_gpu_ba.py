@@ -323,9 +323,9 @@ def test_more_than_341_keyframes_match_oracle(gpu_ctx, oracle):
 
 
 def test_too_many_keyframes_is_reported_for_point_landmarks(gpu_ctx):
-    """The 3-D-point parameterisation has no large-problem path: beyond ~95 optimised keyframes ov2_xyz_ba_solve returns
-    OV2_EUNSUPPORTED with a message, never a silent skip."""
-    pb = synth.make_xyz_ba_problem(120, 600, 4, stereo=False, seed=1)
+    """The 3-D-point parameterisation keeps W dense (3 rows per wavefront in LDS): beyond ~450 optimised keyframes
+    ov2_xyz_ba_solve returns OV2_EUNSUPPORTED with a message, never a silent skip (up to there: tests/test_gpu_xyz_ba.py)."""
+    pb = synth.make_xyz_ba_problem(500, 600, 4, stereo=False, seed=1)
     with pytest.raises(ov2slam_amd.Ov2Error) as e:
         optimizer.solve_xyz(gpu_ctx, pb)
     assert e.value.code == -4 and "keyframes" in str(e.value)
