@@ -38,6 +38,9 @@ def check(name, ok, info):
 t0 = time.time()
 for case in range(N):
     w, h = int(rng.integers(64, 900)), int(rng.integers(48, 520))
+    if rng.integers(0, 2): w = 4 * (w // 4)                            # dword-multiple widths: the strip kernel's geometry
+    # batch mode's strip kernel (CLAHE apply + level 1 + borders in one walk) forced on / off per case (read at every launch)
+    os.environ["OV2_CLAHE_STRIPS"] = "1" if rng.integers(0, 2) else "0"
     kind = int(rng.integers(0, 4))
     prev = rand_image(w, h, kind)
     shift = rng.uniform(-6, 6, 2)
