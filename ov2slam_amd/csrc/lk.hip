@@ -19,20 +19,11 @@
 // All levels (coarse -> fine), the forward pass, the status/err/border filter, the
 // backward pass and the forward-backward distance test run in ONE launch.
 #include "common.hpp"
+#include "lk_params.hpp"
 #include <float.h>
 #include <math.h>
 
 #pragma clang fp contract(off)
-
-struct LKParams {
-    int win, max_level, max_iter;
-    double eps2;          // clamp(eps,0,10)^2 (double, like cv::TermCriteria::epsilon)
-    float min_eig_th;     // 1e-4f
-    int flags;
-    float err_th, fb_dist;
-    int do_fb;            // 1: fbKltTracking, 0: single calcOpticalFlowPyrLK
-    int n_max;            // points per batch item (stride)
-};
 
 #define DPP_ROW_SHL1   0x101
 #define DPP_ROW_SHL2   0x102
@@ -608,11 +599,6 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
     return prm;
 }
 
-// lkw.hip: a whole wavefront per keypoint (window 9): the single-frame kernel of record
-int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const void *prm_lk, int lp, int lf, int n_max, const int *n_dev,
-                           const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                           const float *sad_x, float sad_up);
-
 // launcher of the fused kltTracking kernel (used by track.hip); all pointers are device memory, *n_dev <= n_max
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
@@ -631,7 +617,7 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
     {
         const char *e = getenv("OV2_TRACK_IMPL");
         if (win == 9 && !(e && !strcmp(e, "row")))
-            return ov2_launch_track_klt_w(s, P, C, &prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up);
+            return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up);
     }
     // keypoints per wavefront: 4.  One per wavefront (OV2_TRACK_KPW=1, 16 active lanes) was measured for the single-frame case:
     // no gain (0.107 vs 0.104 ms per frame, gpurun_out/r3i) -- the frame's latency is every keypoint's own dependent chain of

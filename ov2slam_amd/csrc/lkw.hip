@@ -16,21 +16,12 @@
 // The search block of the NEXT level is requested while the current level iterates (its position is predicted from the current
 // estimate; the +-3-pixel margin of the block absorbs the rest, and the ordinary re-centring fetch is the fall-back).
 #include "common.hpp"
+#include "lk_params.hpp"
 #include "keypoint_dev.hpp"
 #include <float.h>
 #include <math.h>
 
 #pragma clang fp contract(off)
-
-struct LKParams {                     // (lk.hip)
-    int win, max_level, max_iter;
-    double eps2;
-    float min_eig_th;
-    int flags;
-    float err_th, fb_dist;
-    int do_fb;
-    int n_max;
-};
 
 #define W_WIN 9
 #define W_NPIX (W_WIN * W_WIN)        // 81
@@ -65,7 +56,7 @@ __device__ __forceinline__ double w_sum_exact(int p)
 struct WState { float nx, ny; int status; float err; int iters; };
 
 // stage the 16 x 20-byte search block with origin (jx0, jy0) (rows clamped into the padded buffer: rows beyond it are never consumed)
-__device__ __forceinline__ void w_fetch_J(uint32_t *Jb, const uint8_t *jroi, const PyrLevelDesc &LJ, int jx0, int jy0, int lane, uint32_t (&v)[2])
+__device__ __forceinline__ void w_fetch_J(const uint8_t *jroi, const PyrLevelDesc &LJ, int jx0, int jy0, int lane, uint32_t (&v)[2])
 {
     const int xa = jx0 & ~3;
 #pragma unroll
@@ -79,7 +70,6 @@ __device__ __forceinline__ void w_fetch_J(uint32_t *Jb, const uint8_t *jroi, con
             v[k] = *(const uint32_t *)(jroi + (long long)y * LJ.img_pitch + xa + 4 * dwc);
         }
     }
-    (void)Jb;
 }
 __device__ __forceinline__ void w_store_J(uint32_t *Jb, int lane, const uint32_t (&v)[2])
 {
@@ -142,7 +132,7 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
     const int fx = w_floor(sx) - pre_x0, fy = w_floor(sy) - pre_y0;
     const bool use_pre = had_pre && (unsigned)(fx - 1) <= (unsigned)(2 * W_R - 2) && (unsigned)(fy - 1) <= (unsigned)(2 * W_R - 2);
     if (use_pre) { jx0 = pre_x0; jy0 = pre_y0; jv[0] = pre_v[0]; jv[1] = pre_v[1]; }
-    else w_fetch_J(Jb, jroi, LJ, jx0, jy0, lane, jv);
+    else w_fetch_J(jroi, LJ, jx0, jy0, lane, jv);
     w_sync();                                                     // the previous visit's LDS reads are done
     if (lane < W_IROWS * 4) Ib[lane] = iv;
     w_store_J(Jb, lane, jv);
@@ -206,7 +196,7 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
         const float qx = (nextx + halfWin) * 2.f - halfWin, qy = (nexty + halfWin) * 2.f - halfWin;
         pre_x0 = w_floor(fminf(fmaxf(qx, (float)(-WIN)), (float)(LJnext->w - 1))) - W_R;
         pre_y0 = w_floor(fminf(fmaxf(qy, (float)(-WIN)), (float)(LJnext->h - 1))) - W_R;
-        w_fetch_J(Jb, itemJ + LJnext->img_roi, *LJnext, pre_x0, pre_y0, lane, pre_v);
+        w_fetch_J(itemJ + LJnext->img_roi, *LJnext, pre_x0, pre_y0, lane, pre_v);
         pre_ok = true;
     }
     float pdx = 0.f, pdy = 0.f;
@@ -225,7 +215,7 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
         int ox = inx - jx0, oy = iny - jy0;
         if ((unsigned)ox > (unsigned)(2 * W_R) || (unsigned)oy > (unsigned)(2 * W_R)) {   // drifted: re-centre the block (wave-uniform)
             jx0 = inx - W_R; jy0 = iny - W_R;
-            w_fetch_J(Jb, jroi, LJ, jx0, jy0, lane, jv);
+            w_fetch_J(jroi, LJ, jx0, jy0, lane, jv);
             w_sync();
             w_store_J(Jb, lane, jv);
             w_sync();
@@ -332,12 +322,10 @@ __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKPara
     }
 }
 
-int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const void *prm_lk, int lp, int lf, int n_max, const int *n_dev,
+int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int lp, int lf, int n_max, const int *n_dev,
                            const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
                            const float *sad_x, float sad_up)
 {
-    LKParams prm;
-    memcpy(&prm, prm_lk, sizeof(prm));
     hipLaunchKernelGGL(k_track_klt_w, dim3(n_max), dim3(64), 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, (const float2 *)priors, flags,
                        (float2 *)out_xy, status, iters, sad_x, sad_up);
     OV2_HIP_CHECK(hipGetLastError());
