@@ -38,13 +38,15 @@ struct ClaheParams {
     int l1_pitch, l1_w, l1_h;
 };
 
-// One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
+// One WAVEFRONT (= one work-group) per (tile, image), no barriers: 16 lanes cover one
 // tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
-//   * every wavefront keeps 8 private 256-bin copies -- copy = (row & 3, dword column & 1) -- staggered by
-//     4 banks, so that neighbouring pixels (equal or adjacent gray values) rarely meet on one address;
-//   * bytes of an edge dword that lie outside the tile are counted into a scratch copy instead of being
-//     branched around; all loads of a tile are in flight before the first ds_add (the loop is latency-bound
-//     otherwise);
+//   * ONE 256-bin histogram per wavefront.  Rounds 1-2 kept 8 staggered copies against same-address / same-bank collisions
+//     of neighbouring pixels; measured in round 3 (OV2SLAM_HIP_LIB A/B builds, tools/pre_micro.py): 16, 8, 4, 2 and 1 copies run
+//     within noise of each other (16: slower, occupancy) -- the ds_adds are not what bounds the kernel, its ~350 vector
+//     instructions per tile are.  One copy needs no per-lane base (the address is the bin, the base an instruction offset),
+//     one b128 store per lane to clear and one b128 load to read it back;
+//   * bytes of an edge dword that lie outside the tile are added with weight 0 instead of being branched around; all loads of
+//     a tile are in flight before the first ds_add (the loop is latency-bound otherwise);
 //   * clip / redistribute / scan / LUT run on 4 bins per lane with DPP row scans and readlane, no division
 //     per bin.
 __device__ __forceinline__ void clahe_wave_sync()
@@ -57,26 +59,25 @@ __device__ __forceinline__ void clahe_wave_sync()
 #ifndef CLAHE_KO
 #define CLAHE_KO 0        // knock-out timing experiments. lut: 1 loads hit one line, 2 no ds_add, 4 no clip/scan tail;
 #endif                    // apply: 8 loads hit, 16 no stores, 32 no LUT look-ups, 64 no blend
-#define CH_COPIES 8
-#define CH_STRIDE 260                 // dwords per copy: 256 + 4 (bank stagger, keeps 16-byte alignment)
-#define CH_WAVE_DW (CH_COPIES * CH_STRIDE + 256)      // + scratch copy for out-of-tile bytes
+#define CH_WAVE_DW 256               // one 256-bin histogram per wavefront (see the kernel comment)
 typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
 __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // out-of-row sources read 0
 
 template <bool SRC_ALIGNED>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
-__global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
+__global__ __launch_bounds__(64, 6) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
+    // one wavefront per work-group: the histogram sits at LDS offset 0, so a bin's address is (bin << 2) alone -- no base to add
+    __shared__ __attribute__((aligned(16))) uint32_t hw[CH_WAVE_DW];
+    const int lane = threadIdx.x;
     const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * P.gx_lut;
-    int b, bx;
-    ov2_xcd_map(blockIdx.x, P.gx_lut, P.batch, &b, &bx);    // the work-groups of an image share image lines and its LUTs
-    uint32_t *hw = hist_all[wave];
+    int b, wv;
+    ov2_xcd_map(blockIdx.x, 4 * P.gx_lut, P.batch, &b, &wv);    // the work-groups of an image share image lines and its LUTs
+    const int bx = wv >> 2, wave = wv & 3;
     const uint8_t *img = src + (long long)b * P.src_item_stride;
     const int sub = lane >> 4, l16 = lane & 15;
-    uint32_t *hist = hw + ((sub << 1) | (l16 & 1)) * CH_STRIDE;
+    uint32_t *hist = hw;
     const bool fast_geom = P.tw <= 61 && P.th <= 64;
     // Rows are fetched as ALIGNED dwords whatever the alignment of the image (KITTI: 1241-byte rows): dword l16 of
     // the row segment starts `ph` bytes before the first tile byte, ph = (address of that byte) & 3, per row.
@@ -150,35 +151,30 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
         if (tn < ntiles && tile_fast(tn)) tile_load(tn, nxt, nxt_ph);
         const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
         const int x_begin = tx * P.tw;                              // tile columns in padded coordinates
-        for (int e = lane; e < CH_COPIES * CH_STRIDE / 4; e += 64) ((c_u32x4 *)hw)[e] = (c_u32x4)(0u);
+        ((c_u32x4 *)hw)[lane] = (c_u32x4)(0u);
         clahe_wave_sync();
         if (tile_fast(t)) {
-            // byte k of this lane's dword is tile column 4*l16 + k - ph; bytes outside [0, tw) are counted into the
-            // scratch copy instead of being branched around
+            // byte k of this lane's dword is tile column 4*l16 + k - ph; bytes outside [0, tw) are added with weight 0
             // weight of tile column p (image column x_begin + p): see tile_fast
             const int dbl_lo = 2 * P.w - 2 - (x_begin + P.tw);      // columns in (dbl_lo, w - 2] also stand for a padded column
             auto wgt = [&](int p) { const int c = x_begin + p; return ((unsigned)p < (unsigned)P.tw && c < P.w) ? ((c > dbl_lo && c <= P.w - 2) ? 2u : 1u) : 0u; };
-            const uint32_t hist_o = (uint32_t)(((sub << 1) | (l16 & 1)) * CH_STRIDE), trash_o = CH_COPIES * CH_STRIDE;   // dword offsets in hw
-            auto sel = [&](int p) { return wgt(p) ? hist_o : trash_o; };
             const int p_same = 4 * l16 - (int)(cur_ph & 3);
-            uint32_t h0 = sel(p_same), h1 = sel(p_same + 1), h2 = sel(p_same + 2), h3 = sel(p_same + 3);
             uint32_t w0 = wgt(p_same), w1 = wgt(p_same + 1), w2 = wgt(p_same + 2), w3 = wgt(p_same + 3);
             bool mine = p_same < P.tw;                              // this lane's dword holds at least one tile byte
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (!same_phase) {                                   // wave-uniform: rows of an unaligned image differ in phase
                     const int p0 = 4 * l16 - (int)((cur_ph >> (2 * i)) & 3);
-                    h0 = sel(p0); h1 = sel(p0 + 1); h2 = sel(p0 + 2); h3 = sel(p0 + 3);
                     w0 = wgt(p0); w1 = wgt(p0 + 1); w2 = wgt(p0 + 2); w3 = wgt(p0 + 3);
                     mine = p0 < P.tw;
                 }
                 if (mine && 4 * i + sub < P.th) {
                     const uint32_t v = cur[i];
-                    if (CLAHE_KO & 2) { if (v == 0x12345678u) hw[h0] = 1; continue; }
-                    atomicAdd(&hw[h0 + (v & 0xFF)], w0);
-                    atomicAdd(&hw[h1 + ((v >> 8) & 0xFF)], w1);
-                    atomicAdd(&hw[h2 + ((v >> 16) & 0xFF)], w2);
-                    atomicAdd(&hw[h3 + (v >> 24)], w3);
+                    if (CLAHE_KO & 2) { if (v == 0x12345678u) hw[0] = 1; continue; }
+                    atomicAdd(&hw[v & 0xFF], w0);
+                    atomicAdd(&hw[(v >> 8) & 0xFF], w1);
+                    atomicAdd(&hw[(v >> 16) & 0xFF], w2);
+                    atomicAdd(&hw[v >> 24], w3);
                 }
             }
         } else {
@@ -189,13 +185,12 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
         }
         clahe_wave_sync();
         // lane owns bins 4*lane .. 4*lane+3
-        int hv[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < CH_COPIES; c++) {
-            const c_u32x4 q = *(const c_u32x4 *)(hw + c * CH_STRIDE + 4 * lane);
-            hv[0] += (int)q.x; hv[1] += (int)q.y; hv[2] += (int)q.z; hv[3] += (int)q.w;
+        int hv[4];
+        {
+            const c_u32x4 q = *(const c_u32x4 *)(hw + 4 * lane);
+            hv[0] = (int)q.x; hv[1] = (int)q.y; hv[2] = (int)q.z; hv[3] = (int)q.w;
         }
-        clahe_wave_sync();                                            // the copies may be cleared for the next tile
+        clahe_wave_sync();                                            // the histogram may be cleared for the next tile
         if (P.clip > 0 && !(CLAHE_KO & 4)) {
             int over = 0;
 #pragma unroll
@@ -655,7 +650,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
     P.ysplit = (long long)batch * (tiles_y + 1) >= 256 ? 1 : (P.th >= 48 ? 6 : (P.th >= 16 ? 3 : 1));
     P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
-    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(4 * P.gx_lut * batch), dim3(64), 0, ctx->stream, P, src_d, lut_d);
     // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk
     // (OV2_CLAHE_STRIPS=1 forces it for any batch, =0 disables it -- A/B runs, parity tests of both paths)
     if (pyr && pyr->n_levels >= 2 && !pyr->tiled && til_delta == 0 && border == pyr->win && src_al && (w & 3) == 0 && w >= 64 && h >= 8 &&
