@@ -764,6 +764,51 @@ def main():
     except Exception:
         pass
 
+    # ---- the same K steps with pre-processing and tracking on TWO streams (side measurement, never `value`) ------------------
+    # Offline batch mode knows frame t+1 while frame t is tracked: preprocessImage of the next frame (LDS-atomic bound histogram,
+    # memory-bound strip kernel) runs on its own context / stream beside the VALU-bound LK kernels of the current one.  Three
+    # pyramids rotate; a pyramid's `ready` event orders producer -> consumer (ov2_pyr_wait_ready inside ov2_fb_klt_d), a torch
+    # event per tracking step orders consumer -> the producer that overwrites the buffer two steps later.  The headline `value`
+    # and `roofline` stay the serial ones above: a kernel's launch time measured while it shares the CUs says nothing about it.
+    pipelined = None
+    if not args.no_extras and world == 1:
+      try:
+        s_pre = torch.cuda.Stream(device=dev)
+        ctx_pre = ov2slam_amd.Context(dev.index, stream=s_pre.cuda_stream)
+        pyr3 = pyrs + [ov2slam_amd.Pyramid(ctx, W, H, WIN, LEVELS, batch=S)]
+        h3 = [p.h_pyr for p in pyr3]
+        ev_lk = {}
+        def pre_on(idx, frame_no):                                   # frame `frame_no` -> buffer idx, on the pre-processing stream
+            L.check(build_clahe(ctx_pre.h, h3[idx], a_img[walk_view(frame_no)], PITCH, PITCH * H, CLAHE_CLIP, CLAHE_TILES[0], CLAHE_TILES[1]))
+        def pstep(i):
+            f = i % NT
+            if i - 2 in ev_lk: s_pre.wait_event(ev_lk.pop(i - 2))     # buffer (i+1) % 3 held frame i-2: its last reader was step i-2
+            pre_on((i + 1) % 3, i + 1)
+            pri_work[f].copy_(pri_d[f])
+            prevp, curp = h3[i % 3], h3[(i + 1) % 3]
+            L.check(fb(ctx.h, prevp, curp, WIN, 1, 30, 0.01, 30.0, 0.5, a_k[f], a_p[f], NKPS, a_nA, a_st, a_stats))
+            L.check(fb(ctx.h, prevp, curp, WIN, LEVELS, 30, 0.01, 30.0, 0.5, a_kB[f], a_pB[f], NKPS, a_nB, a_stB, a_stats))
+            e = torch.cuda.Event(); e.record(stream); ev_lk[i] = e
+        torch.cuda.synchronize()
+        pre_on(0, 0)
+        nw = min(args.warmup, 12)
+        for i in range(nw):
+            pstep(i)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for i in range(args.steps):
+            pstep(nw + i)
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp0
+        pipelined = {"ms_per_step": tp / args.steps * 1e3, "frames_per_s": args.steps * S / tp, "streams": 2, "pyramid_buffers": 3,
+                     "tracked_fraction": float(status_d.float().mean().item()),
+                     "note": "same work per step as the headline (one preprocessImage + two fbKltTracking calls over %d sequences), "
+                             "preprocessImage of frame t+1 on a second context beside the tracking of frame t; side measurement" % S}
+        del pyr3, h3
+        ctx_pre.close() if hasattr(ctx_pre, "close") else None
+      except Exception as e:                                          # a side measurement must not cost the headline line
+        pipelined = {"error": repr(e)}
+
     # free the batch buffers before the single-sequence / BA sections
     # ---- keyframe detection for the whole batch: every sequence's detector on level 0 of its pyramid, one call -------------
     det_batch = None
@@ -850,6 +895,8 @@ def main():
             out["config5"] = c5
         if det_batch is not None:
             out["detect_batch"] = det_batch
+        if pipelined is not None:
+            out["pipelined_two_streams"] = pipelined
         # The sections below are side measurements: a failure in one of them must not cost the headline line
         def extras():
             ss = single_sequence(dev.index, views, kps, pri)
