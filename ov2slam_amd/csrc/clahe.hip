@@ -405,15 +405,19 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
 }
 
 // ---- strip kernel: CLAHE apply + pyramid level 1 + both REFLECT_101 borders in one walk (batch mode) -------------------
-// One WAVEFRONT per (column strip, image), walking the image top to bottom.  A lane owns one dword column (4 pixels) like
-// k_clahe_apply; the strip's first / last lane is a halo column (computed, not stored) so that every core lane finds its
-// horizontal neighbours in the lanes next to it (v_mov_dpp wave_shr / wave_shl) -- 752 pixels = 188 dwords = 63 + 62 + 63
-// core columns + 4 halo columns = 3 x 64 lanes.  What the separate kernels re-read from HBM stays in registers here:
+// One work-group per image, one WAVEFRONT per column strip, walking the image top to bottom.  A lane owns one dword column
+// (4 pixels) like k_clahe_apply; the strip's first / last lane is a halo column (it computes the same dword as the neighbouring
+// strip's core lane and stores that identical copy) so that every core lane finds its horizontal neighbours in the lanes next
+// to it (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- 752 pixels = 188 dwords = 63 + 62 + 63 core columns + 4 halo columns =
+// 3 x 64 lanes.  What the separate kernels re-read from HBM stays in registers here:
 //   * level 0 is stored once (plus its mirror rows / border dwords, built from the lane's and its neighbour's dword);
 //   * pyrDown: the 5-tap horizontal sums of a row (v_dot4_u32_u8 on the lane's dword and its neighbours') roll through a
 //     five-row register window, every second row emits two level-1 pixels per lane (same integer arithmetic as k_pyr_level);
-//   * the four-LUT table of the strip's cell columns is staged once per row of cells, not once per work-group of 192 threads.
-// No work-group barrier, no LDS traffic besides the LUT look-ups.  Geometry: w % 4 == 0, dword-aligned rows, h >= 4.
+//   * the packed four-LUT table of all cell columns is staged once per image and row of cells and shared by the strips
+//     (two barriers per row of cells -- the only work-group synchronisation), not once per 192-thread work-group.
+// Geometry: w % 4 == 0, dword-aligned rows and destinations, h >= 8, at most CS_MAX_STRIPS strips, tiles_x + 1 <= 40 (host-checked;
+// anything else takes the separate kernels).  tests/test_gpu_clahe.py: named geometries vs the oracle + a random sweep vs the
+// separate kernels.
 __device__ __forceinline__ uint32_t c_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }   // lane i <- lane i-1
 __device__ __forceinline__ uint32_t c_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }   // lane i <- lane i+1
 
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     const int core1 = s == P.nstrips - 1 ? ndw : 63 + 62 * s;
     const int d_first = s == 0 ? 0 : core0 - 1;
     const int d_raw = d_first + lane;
-    const int d = min(d_raw, ndw - 1);                                  // lanes beyond the strip recompute the last column
+    const int d = min(d_raw, ndw - 1);                                  // lanes beyond the image recompute (and re-store) the last column
     const bool core = d_raw >= core0 && d_raw < core1;
     const int xb = 4 * d;
     const int cmin = 0, ncell = P.tiles_x + 1;
