@@ -267,6 +267,12 @@ typedef struct {
 
 /* LKTrackerInvoker::operator() for one level and a range of points
  * (video/src/lkpyramid.cpp).  W_BITS = 14, FLT_SCALE = 2^-20.             */
+/* diagnostics (tools/lk_trip_hist.py): histogram of Gauss-Newton trips per level visit; off unless switched on */
+static int orc_lk_trip_hist_on = 0;
+static int orc_lk_trip_hist[64];
+void orc_lk_trip_hist_enable(int on) { orc_lk_trip_hist_on = on; if (on) for (int k = 0; k < 64; k++) orc_lk_trip_hist[k] = 0; }
+void orc_lk_trip_hist_get(int *out64) { for (int k = 0; k < 64; k++) out64[k] = orc_lk_trip_hist[k]; }
+
 static void lk_level_range(const lk_job *jb)
 {
     const int win = jb->win, level = jb->level;
@@ -366,7 +372,7 @@ static void lk_level_range(const lk_job *jb)
         D = 1.f / D;
         nextx -= halfWin; nexty -= halfWin;
         float pdx = 0.f, pdy = 0.f;
-        int j;
+        int j, visit_trips = 0;
         for (j = 0; j < jb->max_count; j++) {
             int inx = cv_floor_f(nextx), iny = cv_floor_f(nexty);
             if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
@@ -374,6 +380,7 @@ static void lk_level_range(const lk_job *jb)
                 break;
             }
             if (jb->iters_out) jb->iters_out[i]++;
+            visit_trips++;
             a = nextx - (float)inx; b = nexty - (float)iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
             iw01 = cv_round_f(a * (1.f - b) * (float)(1 << W_BITS));
@@ -440,6 +447,11 @@ static void lk_level_range(const lk_job *jb)
                 break;
             }
             pdx = dx; pdy = dy;
+        }
+        /* (diagnostics, tools/lk_trip_hist.py) Gauss-Newton trips of this level visit: j + 1 when the loop left through a
+         * break after computing a step, j when it ran out of iterations or left the image before computing one */
+        if (orc_lk_trip_hist_on) {
+            __atomic_fetch_add(&orc_lk_trip_hist[visit_trips < 63 ? visit_trips : 63], 1, __ATOMIC_RELAXED);
         }
     }
 }

@@ -101,6 +101,9 @@ int orc_clahe(const uint8_t *src, int w, int h, int stride, double clip_limit, i
 #define ORC_LK_ACC_FLOAT_SSE34  2
 #define ORC_LK_ACC_FLOAT_UI4    3
 void orc_set_lk_acc_mode(int mode);
+/* diagnostics: histogram (64 bins, last = 63 and more) of Gauss-Newton trips per level visit of every orc_lk_track since enable(1) */
+void orc_lk_trip_hist_enable(int on);
+void orc_lk_trip_hist_get(int *out64);
 int orc_get_lk_acc_mode(void);
 
 int orc_lk_track(const orc_pyr *prev, const orc_pyr *next,
