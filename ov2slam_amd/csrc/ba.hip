@@ -829,7 +829,9 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
     __shared__ double s_part[3][16];
     __shared__ double s_gmax;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int fresh = ctl->fresh_lin;
+    // (the linearisers that ran since the last call -- they run when need_lin is set -- produced a linearisation: what the
+    // one-thread kernel k_ba_lin_done used to record between them and this kernel)
+    const int fresh = ctl->fresh_lin | ctl->need_lin;
     if (fresh) {
         // a new linearisation at x is available: jacobi scaling (iteration 0 only), gradient max-norm
         if (O.jacobi && !ctl->scaled) {
@@ -864,6 +866,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
         // the control block is worked on in registers: one load batch, one store batch (every ctl-> access used to be a
         // dependent global round trip of thread 0)
         BACtl cl = *ctl;
+        cl.need_lin = 0; cl.fresh_lin = fresh;
         d_ctl_iter_begin(cl, O, fresh, s_gmax);
         *D.ctl = cl;
     }
@@ -1919,7 +1922,11 @@ __global__ __launch_bounds__(512) void k_chol_solve(BADev D)
 __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
 {
     BACtl *ctl = D.ctl;
-    if (ctl->done || ctl->lin_fail) return;
+    if (ctl->done) return;
+    // G = W^T C W was consumed by k_ba_assemble: clear it for the next iteration's Schur kernels here (many work-groups) instead
+    // of a memset launch per iteration
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)D.nfp * D.nfp; e += (long long)gridDim.x * blockDim.x) D.G[e] = 0;
+    if (ctl->lin_fail) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *sy = (double *)smem_raw;                        // s_j * yf_j
     for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
@@ -2223,7 +2230,11 @@ __global__ __launch_bounds__(256) void k_ba_xyz_prep(BADev D)
 __global__ __launch_bounds__(256) void k_ba_backsub_xyz(BADev D)
 {
     BACtl *ctl = D.ctl;
-    if (ctl->done || ctl->lin_fail) return;
+    if (ctl->done) return;
+    // G = W^T C W was consumed by k_ba_assemble: clear it for the next iteration's Schur kernels here (many work-groups) instead
+    // of a memset launch per iteration
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)D.nfp * D.nfp; e += (long long)gridDim.x * blockDim.x) D.G[e] = 0;
+    if (ctl->lin_fail) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *sy = (double *)smem_raw;                        // s_j * yf_j
     for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
@@ -2285,14 +2296,6 @@ __global__ __launch_bounds__(256) void k_ba_cost_xyz(BADev D)
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
     if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
-}
-
-// marks that k_ba_linearize has produced a linearisation (1 thread; keeps the flag flip race-free)
-__global__ void k_ba_lin_done(BADev D)
-{
-    BACtl *ctl = D.ctl;
-    if (ctl->done || !ctl->need_lin) return;
-    ctl->need_lin = 0; ctl->fresh_lin = 1;
 }
 
 // cached R | t of every pose; scales = 1 (Jacobi scaling, when on, overwrites them at the first k_ba_iter_begin)
@@ -2874,9 +2877,9 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         }
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (D.big && D.lin_direct ? 0 : (size_t)n_opt * 27 * 8) + 16, s, D);
-        hipLaunchKernelGGL(k_ba_lin_done, dim3(1), dim3(1), 0, s, D);
     };
     linearize();
+    OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));    // (every later iteration: cleared by the back-substitution kernel)
     // The LM loop is enqueued in chunks of BA_CHUNK iterations.  After each chunk the control block's `done` flag is
     // copied to pinned memory and an event recorded; before enqueuing chunk c+2 the host looks at the flag of chunk c
     // (one chunk of look-ahead, so the stream never drains).  A solve that converges after 3 iterations of a
@@ -2913,7 +2916,6 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             }
         }
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
-        OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));
         if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
         if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split, ss_chunks), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split, ss_ncol);
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
