@@ -38,13 +38,14 @@ struct ClaheParams {
     int l1_pitch, l1_w, l1_h;
 };
 
-// One WAVEFRONT (= one work-group) per (tile, image), no barriers: 16 lanes cover one
+// One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
 // tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
 //   * ONE 256-bin histogram per wavefront.  Rounds 1-2 kept 8 staggered copies against same-address / same-bank collisions
 //     of neighbouring pixels; measured in round 3 (OV2SLAM_HIP_LIB A/B builds, tools/pre_micro.py): 16, 8, 4, 2 and 1 copies run
-//     within noise of each other (16: slower, occupancy) -- the ds_adds are not what bounds the kernel, its ~350 vector
-//     instructions per tile are.  One copy needs no per-lane base (the address is the bin, the base an instruction offset),
-//     one b128 store per lane to clear and one b128 load to read it back;
+//     within noise of each other (16: slower, occupancy), and so does a build with 27 % fewer vector instructions: the kernel is
+//     bound by the rate of the LDS atomics themselves (one ds_add_u32 per pixel, ~10 cycles per wave64 instruction, 83 % of the
+//     CUs' LDS-unit time).  One copy is the simplest form: the address is the bin, one b128 store per lane to clear, one b128
+//     load to read it back;
 //   * bytes of an edge dword that lie outside the tile are added with weight 0 instead of being branched around; all loads of
 //     a tile are in flight before the first ds_add (the loop is latency-bound otherwise);
 //   * clip / redistribute / scan / LUT run on 4 bins per lane with DPP row scans and readlane, no division
@@ -66,15 +67,17 @@ template <int CTRL>
 __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // out-of-row sources read 0
 
 template <bool SRC_ALIGNED>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
-__global__ __launch_bounds__(64, 6) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
+__global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
 {
-    // one wavefront per work-group: the histogram sits at LDS offset 0, so a bin's address is (bin << 2) alone -- no base to add
-    __shared__ __attribute__((aligned(16))) uint32_t hw[CH_WAVE_DW];
-    const int lane = threadIdx.x;
+    // four wavefronts = four neighbouring tiles per work-group (no barrier between them): tiles that share cache lines run at
+    // the same time on one CU.  (One wavefront per work-group makes a bin's LDS address a single SDWA shift, but the tiles of a
+    // row then run at different times and the kernel fetches 1.44x the bytes from HBM -- same 635 us, LDS-atomic bound either way.)
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
     const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * P.gx_lut;
-    int b, wv;
-    ov2_xcd_map(blockIdx.x, 4 * P.gx_lut, P.batch, &b, &wv);    // the work-groups of an image share image lines and its LUTs
-    const int bx = wv >> 2, wave = wv & 3;
+    int b, bx;
+    ov2_xcd_map(blockIdx.x, P.gx_lut, P.batch, &b, &bx);    // the work-groups of an image share image lines and its LUTs
+    uint32_t *hw = hist_all[wave];
     const uint8_t *img = src + (long long)b * P.src_item_stride;
     const int sub = lane >> 4, l16 = lane & 15;
     uint32_t *hist = hw;
@@ -654,7 +657,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
     P.ysplit = (long long)batch * (tiles_y + 1) >= 256 ? 1 : (P.th >= 48 ? 6 : (P.th >= 16 ? 3 : 1));
     P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
-    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(4 * P.gx_lut * batch), dim3(64), 0, ctx->stream, P, src_d, lut_d);
+    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk
     // (OV2_CLAHE_STRIPS=1 forces it for any batch, =0 disables it -- A/B runs, parity tests of both paths)
     if (pyr && pyr->n_levels >= 2 && !pyr->tiled && til_delta == 0 && border == pyr->win && src_al && (w & 3) == 0 && w >= 64 && h >= 8 &&
