@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_ba_pose_only(BADev D, BAOpt O, BACtl ct
         cost = wave_sum(cost);
         if ((tid & 63) == 0 && cost != 0.0) atomicAdd(&s_cost, cost);
         __syncthreads();
-        if (tid == 0) { cl.cost_acc += s_cost; cl.need_lin = 0; cl.fresh_lin = 1; }       // (k_ba_lin_done)
+        if (tid == 0) { cl.cost_acc += s_cost; cl.need_lin = 0; cl.fresh_lin = 1; }       // (a linearisation at x is now available)
         __syncthreads();
     };
     auto Hd = [&](int i, int j) { const int a = i < j ? i : j, bq = i < j ? j : i; return s_H[a * 6 - a * (a - 1) / 2 + (bq - a)]; };   // upper-packed
