@@ -150,15 +150,16 @@ def test_strip_kernel_equals_separate_kernels_random_geometry(gpu_ctx, monkeypat
     """Randomised geometry sweep: the strip kernel and the separate kernels (both bit-exact against the oracle above on the
     named sizes) must produce identical padded pyramids for any width % 4 == 0, any height, any tile grid."""
     rng = np.random.default_rng(77)
-    for case in range(40):
-        w = 4 * int(rng.integers(16, 280)); h = int(rng.integers(2 * 9 + 6, 260))
+    for case in range(60):
+        win = 9 if case < 30 else int(rng.choice([5, 7, 13, 21]))         # LK window = border width of every level
+        w = 4 * int(rng.integers(16, 280)); h = int(rng.integers(2 * win + 6, 260))
         tx = int(rng.integers(1, max(2, min(30, w // 8)))); ty = int(rng.integers(1, max(2, min(12, h // 8))))
         img = rng.integers(0, 256, (h, w), dtype=np.uint8)
         out = {}
         for force in ("1", "0"):
             monkeypatch.setenv("OV2_CLAHE_STRIPS", force)
-            P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(img, 2.5, tx, ty)
+            P = ov2slam_amd.Pyramid(gpu_ctx, w, h, win, 3).build_clahe(img, 2.5, tx, ty)
             out[force] = [P.download(l, padded=True)[0] for l in range(P.levels)]
             P.close()
         for l, (a, b) in enumerate(zip(out["1"], out["0"])):
-            assert np.array_equal(a, b), (case, w, h, tx, ty, l, np.argwhere(a != b)[:4].tolist())
+            assert np.array_equal(a, b), (case, win, w, h, tx, ty, l, np.argwhere(a != b)[:4].tolist())
