@@ -242,14 +242,14 @@ def config5_plan(world, scale):
     return counts, batch.assign_sequences(counts, world)
 
 
-def run_config5(ctx, rank, world, scale, dry=False):
+def run_config5(ctx, rank, world, scale, dry=False, device=0):
     """This rank's share of the 11 EuRoC-length synthetic sequences through the single-sequence path; all-gather of
     (frames, seconds, tracked, attempted, squared tracking error) over torch.distributed -- the only collective."""
     from ov2slam_amd import batch
     counts, plan = config5_plan(world, scale)
     mine = plan[rank]
     loc = dict(frames=0.0, seconds=0.0, tracked=0.0, attempted=0.0, ate_sq_sum=0.0, ate_n=0.0, sequences=float(len(mine)), host_native=0.0,
-               keyframes=0.0, stereo_ok=0.0, stereo_kps=0.0, ba_solves=0.0, ba_iterations=0.0, ba_seconds=0.0, ba_skipped=0.0)
+               keyframes=0.0, stereo_ok=0.0, stereo_kps=0.0, ba_solves=0.0, ba_iterations=0.0, ba_seconds=0.0, ba_skipped=0.0, device=float(device))
     if dry:
         loc["frames"] = float(sum(counts[s] for s in mine)); loc["seconds"] = 1.0 + 0.25 * rank
         loc["tracked"] = loc["attempted"] = 300.0 * loc["frames"]
@@ -269,13 +269,13 @@ def run_config5(ctx, rank, world, scale, dry=False):
             cases = []
             for i, sq in enumerate(seqs):
                 cases.append(os.path.join(td.name, "case%d.bin" % i)); stream.write_case(cases[-1], sq, windows)
-            stream.run_native(exe, cases[-1])                                         # warm-up (page cache, clocks)
+            stream.run_native(exe, cases[-1], device=device)                          # warm-up (page cache, clocks)
             loc["host_native"] = 1.0
         except Exception:
             exe = None
             loc["host_native"] = 0.0
         for i, sq in enumerate(seqs):
-            st = stream.run_native(exe, cases[i]) if exe else batch.run_sequence(ctx, sq, ba_problems=windows)
+            st = stream.run_native(exe, cases[i], device=device) if exe else batch.run_sequence(ctx, sq, ba_problems=windows)
             loc["frames"] += st["frames"]; loc["seconds"] += st["seconds"]; loc["tracked"] += st["tracked"]
             loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
             loc["keyframes"] += st["keyframes"]; loc["stereo_ok"] += st["stereo_ok"]; loc["stereo_kps"] += st["stereo_kps"]
@@ -291,6 +291,7 @@ def run_config5(ctx, rank, world, scale, dry=False):
                         % (scale, int(sum(counts.values())), world),
             "fps": agg["fps"], "frames": agg["frames"], "seconds_slowest_rank": agg["seconds"],
             "frames_per_rank": stats["frames"], "seconds_per_rank": stats["seconds"], "sequences_per_rank": stats["sequences"],
+            "device_per_rank": [int(d) for d in stats["device"]],
             "tracked_fraction": sum(stats["tracked"]) / max(1.0, sum(stats["attempted"])),
             "keyframes": sum(stats["keyframes"]), "stereo_ok_fraction": sum(stats["stereo_ok"]) / max(1.0, sum(stats["stereo_kps"])),
             "ba_solves": sum(stats["ba_solves"]), "ba_keyframes_skipped_while_busy": sum(stats["ba_skipped"]),
@@ -376,8 +377,8 @@ def config2_stream(dev_index, n_frames=400, kf_every=5, with_cpu=True, cpu_frame
             exe = stream.build_native_driver(td)
             case = os.path.join(td, "case.bin")
             stream.write_case(case, seq, windows, kf_every=kf_every)
-            stream.run_native(exe, case, "newest")
-            n1, n2 = stream.run_native(exe, case, "newest"), stream.run_native(exe, case, "all")
+            stream.run_native(exe, case, "newest", dev_index)
+            n1, n2 = stream.run_native(exe, case, "newest", dev_index), stream.run_native(exe, case, "all", dev_index)
         native = {"frames_per_s": n1["frames"] / n1["seconds"], "frames_per_s_slam_thread": n1["frames"] / n1["slam_thread_seconds"],
                   "frames_per_s_every_keyframe_optimised": n2["frames"] / n2["seconds"],
                   "slam_thread_ms_per_frame": {"total": n1["slam_thread_seconds"] / n1["frames"] * 1e3, "inside_library_calls": n1["slam_library_s"] / n1["frames"] * 1e3},
@@ -644,7 +645,7 @@ def main():
         t = torch.tensor([1.0 + 0.1 * rank], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c5 = run_config5(None, rank, world, args.config5_scale, dry=True)
+        c5 = run_config5(None, rank, world, args.config5_scale, dry=True, device=local_rank if world > 1 else 0)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "dry": True, "backend": args.backend, "elapsed_max_over_ranks": float(t.item()),
@@ -856,7 +857,7 @@ def main():
     if not args.no_extras and args.workload == "euroc":
         try:
             ctx5 = ov2slam_amd.Context(dev.index)
-            c5 = run_config5(ctx5, rank, world, args.config5_scale)
+            c5 = run_config5(ctx5, rank, world, args.config5_scale, device=dev.index)
             ctx5.close()
         except Exception:
             import traceback

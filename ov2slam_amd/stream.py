@@ -232,10 +232,19 @@ def build_native_driver(out_dir):
     return exe
 
 
-def run_native(exe, case_path, ba_policy="newest"):
+def native_argv(exe, case_path, ba_policy="newest", device=0):
+    """Command line of tools/stream_driver.cpp: the rank's GPU travels as argv[3] (one process per GPU, SURVEY 8(e);
+    the reference's own protocol starts one process per sequence, benchmark_scripts/euroc_bench.sh:3-27)."""
+    return [exe, case_path, ba_policy, str(int(device))]
+
+
+def run_native(exe, case_path, ba_policy="newest", device=0):
     import json
     import subprocess
-    r = subprocess.run([exe, case_path, ba_policy], capture_output=True, text=True, timeout=600)
+    r = subprocess.run(native_argv(exe, case_path, ba_policy, device), capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("stream_driver failed (%d): %s" % (r.returncode, r.stderr[-500:]))
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    if int(st.get("device", -1)) != int(device):
+        raise RuntimeError("stream_driver ran on device %s, asked for %d" % (st.get("device"), device))
+    return st

@@ -97,6 +97,20 @@ def test_bench_launcher_dry_gloo():
     assert len(c5["frames_per_rank"]) == 2 and c5["frames"] == sum(c5["frames_per_rank"])
     assert abs(c5["seconds_slowest_rank"] - max(c5["seconds_per_rank"])) < 1e-12
     assert abs(out["elapsed_max_over_ranks"] - 1.1) < 1e-12                # max over ranks of (1.0, 1.1)
+    assert c5["device_per_rank"] == [0, 1]                                  # every rank's config-5 worker on ITS GPU
+
+
+def test_native_driver_receives_the_ranks_device():
+    """The config-5 worker is a separate process (tools/stream_driver.cpp): its three contexts must sit on the rank's GPU.
+    The device index travels as argv[3]; the driver source creates every context on it and echoes it back."""
+    from ov2slam_amd import stream
+    assert stream.native_argv("drv", "case.bin", "newest", 5) == ["drv", "case.bin", "newest", "5"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "tools", "stream_driver.cpp")).read()
+    assert "ov2_ctx_create(0" not in src and src.count("ov2_ctx_create(device") == 3
+    import inspect
+    import bench
+    assert "device=dev.index" in inspect.getsource(bench.main) and "device=device" in inspect.getsource(bench.run_config5)
 
 
 def test_bench_launcher_refuses_missing_gpus():

@@ -115,15 +115,18 @@ template <class T> struct Queue {
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: stream_driver <case> [newest|all]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: stream_driver <case> [newest|all] [device]\n"); return 2; }
     if (ov2_version() != OV2_ABI_VERSION) { fprintf(stderr, "stream_driver: header / library ABI mismatch\n"); return 2; }
     const Case C = read_case(argv[1]);
     const bool ba_all = argc > 2 && !strcmp(argv[2], "all");
+    // one process per GPU: the rank's device index comes from the launcher (argv[3], else OV2_DEVICE, else 0)
+    const char *dev_s = argc > 3 ? argv[3] : getenv("OV2_DEVICE");
+    const int device = dev_s ? atoi(dev_s) : 0;
     const int w = C.w, h = C.h;
     const double K[4] = {458.654, 457.296, 367.215, 248.375};
     const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[1], -K[3] / K[1], 0, 0, 1};
     ov2_ctx *ctxA, *ctxB, *ctxC;
-    CK(ov2_ctx_create(0, &ctxA)); CK(ov2_ctx_create(0, &ctxB)); CK(ov2_ctx_create(0, &ctxC));
+    CK(ov2_ctx_create(device, &ctxA)); CK(ov2_ctx_create(device, &ctxB)); CK(ov2_ctx_create(device, &ctxC));
     ov2_tracker_config tc{};
     tc.w = w; tc.h = h; tc.win = 9; tc.nklt_pyr_lvl = 3; tc.prior_pyr_lvl = 1; tc.max_iter = 30; tc.eps = 0.01f; tc.err_th = 30.f; tc.fb_dist = 0.5f;
     tc.use_clahe = 1; tc.clahe_clip = 3.0; tc.tiles_x = w / 50; tc.tiles_y = h / 50; tc.n_max = 2 * C.nbmaxkps; tc.use_graph = 1;
@@ -259,9 +262,9 @@ int main(int argc, char **argv)
     printf("{\"frames\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, \"slam_library_s\": %.6f, \"tracked\": %ld, \"attempted\": %ld, "
            "\"err_sq_sum\": %.6f, \"err_n\": %ld, \"keyframes\": %ld, \"stereo_kfs\": %ld, \"stereo_ok\": %ld, \"stereo_kps\": %ld, \"mapper_busy_s\": %.6f, "
            "\"ba_solves\": %ld, \"ba_skipped_kfs\": %ld, \"ba_iterations\": %ld, \"ba_busy_s\": %.6f, \"ba_device_ms\": %.4f, \"slam_wait_for_mapper_s\": %.6f, "
-           "\"ba_policy\": \"%s\"}\n",
+           "\"ba_policy\": \"%s\", \"device\": %d}\n",
            frames, total_s, slam_s, slam_lib, tracked, attempted, err_sq, err_n, keyframes, stereo_kfs, stereo_ok, stereo_kps, mapper_busy,
-           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest");
+           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest", device);
     ov2_tracker_destroy(trk); ov2_pyr_destroy(pyrR);
     ov2_ctx_destroy(ctxA); ov2_ctx_destroy(ctxB); ov2_ctx_destroy(ctxC);
     return 0;
