@@ -45,7 +45,7 @@ typedef struct ov2_pyr ov2_pyr;
  * (round 2 added ov2_ba_options::max_solver_time_s).  ov2_version() returns the value the library was built with; a caller
  * must refuse to run when the two differ (the C++ adapters' ov2::Context and ov2slam_amd/_lib.py do): a shorter options
  * struct from an older header would otherwise be read past its end.                                                    */
-#define OV2_ABI_VERSION 300
+#define OV2_ABI_VERSION 400
 int  ov2_version(void);
 /* last error message of the calling thread ("" if none); never NULL */
 const char *ov2_last_error(void);
@@ -65,7 +65,40 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
 #define OV2_OPT_SOBEL_DY_ORDER         1
 #define OV2_SOBEL_DY_OPENCV_ROWFILTER  0
 #define OV2_SOBEL_DY_EXACT_SUM         1
+/* Path selection.  Every kernel choice the library makes by itself can be pinned per context -- the parity tests run every
+ * path on the same inputs this way, A/B measurements use it.  The library reads no environment variable after ov2_ctx_create
+ * (its entry points are called from several threads of a host process that may call setenv concurrently).
+ * OV2_OPT_LK_IMPL           ov2_fb_klt* / ov2_lk_track with the reference's window (9): AUTO picks the 3-lanes-per-keypoint kernel
+ *                           (lk3.hip) from 65536 points per call on, the row-per-lane kernel (lk.hip) below
+ * OV2_OPT_TRACK_IMPL        ov2_tracker_* / ov2_stereo_match, window 9: wavefront per keypoint (lkw.hip, default) or row per lane
+ * OV2_OPT_CLAHE_STRIPS      ov2_pyr_build_clahe_*: the one-walk strip kernel (CLAHE apply + level 1 + borders): -1 auto (batch x
+ *                           strips >= 1024), 0 never, 1 whenever the geometry allows
+ * OV2_OPT_BA_FORCE_LARGE    1: the large-problem BA path (sparse W slots, HBM Cholesky) on a problem of any size
+ * OV2_OPT_BA_LIN_DIRECT     1 (with FORCE_LARGE): the lineariser without LDS aggregation of the observer blocks
+ * OV2_OPT_BA_SCHUR_CHUNK    columns of the sparse Schur row block kept in LDS per chunk (0 = auto)
+ * OV2_OPT_BA_XYZ_LIN_WAVES  wavefronts per work-group of the 3-D-point lineariser: 0 auto, 1, 2
+ * OV2_OPT_BA_POSE_ONLY_FUSED 0: ceresPnP through the multi-kernel LM loop instead of the one-kernel form (default 1)
+ * OV2_OPT_BA_DETERMINISTIC  1: H, F^T b and W are accumulated in a fixed order (bit-identical results run to run, like the
+ *                           reference's num_threads = 1); 0 (default): fp64 atomics in arrival order (spread ~2e-13)
+ * OV2_OPT_DEBUG             1: timing laps of ov2_local_ba / detection on stderr (initial value: environment OV2_DEBUG at
+ *                           ov2_ctx_create, the only environment variable the library ever reads)                          */
+#define OV2_OPT_LK_IMPL            2
+#define OV2_LK_IMPL_AUTO           0
+#define OV2_LK_IMPL_ROW            1
+#define OV2_LK_IMPL_LANE3          2
+#define OV2_OPT_TRACK_IMPL         3
+#define OV2_TRACK_IMPL_WAVE        0
+#define OV2_TRACK_IMPL_ROW         1
+#define OV2_OPT_CLAHE_STRIPS       4
+#define OV2_OPT_BA_FORCE_LARGE     5
+#define OV2_OPT_BA_LIN_DIRECT      6
+#define OV2_OPT_BA_SCHUR_CHUNK     7
+#define OV2_OPT_BA_XYZ_LIN_WAVES   8
+#define OV2_OPT_BA_POSE_ONLY_FUSED 9
+#define OV2_OPT_BA_DETERMINISTIC   10
+#define OV2_OPT_DEBUG              11
 int  ov2_ctx_set_option(ov2_ctx *ctx, int option, int value);
+int  ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value);
 
 /* ---- image pyramid -------------------------------------------------
  * Replaces cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), max_level)
@@ -91,13 +124,6 @@ int  ov2_pyr_build_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride,
 int  ov2_pyr_download(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h);
 /* same but including the `win` border on every side ((w+2win)*(h+2win))        */
 int  ov2_pyr_download_padded(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h);
-/* Experimental, off unless the environment has OV2_PYR_TILED=1 when the pyramid is created: every level is ALSO kept as
- * 16 x 8-pixel tiles of 128 bytes (one cache line each) and the batch LK kernel fetches its 16-row blocks from that copy --
- * 4-6 cache lines per block instead of 12-18.  Measured: 3 % on the LK kernel, +1.5 ms of pre-processing per 4096 images
- * (DESIGN.md 7), hence not the default.  ov2_pyr_tiled: 1 if this pyramid has it; ov2_pyr_download_tiled: the padded level read back from the tiled copy
- * (same layout as ov2_pyr_download_padded's image; test / debug).                                                       */
-int  ov2_pyr_tiled(const ov2_pyr *p);
-int  ov2_pyr_download_tiled(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h);
 /* algorithmic HBM bytes of one build of one image (SURVEY.md 8d "B_pyr")       */
 size_t ov2_pyr_algorithmic_bytes(const ov2_pyr *p);
 
@@ -378,8 +404,15 @@ typedef struct {
     double robust_mono_th;       /* 5.9915 (slam_params.hpp robust_mono_th_)                              */
     int use_robust_cost;         /* localBA's buse_robust_cost argument                                   */
     int apply_l2_after_robust;   /* apply_l2_after_robust_                                                */
-    int stop_requested;          /* stopLocalBA(), polled once before pass 2 (:604)                       */
-    ov2_ba_options pass1, pass2; /* max_iter 5 / 10, function_tolerance 1e-3 (:461-462, :611)             */
+    int stop_requested;          /* a stop that is already known at entry (ORed with *stop_flag)          */
+    const volatile int *stop_flag;/* or NULL.  The LIVE Optimizer::bstop_localba_ (include/optimizer.hpp:48-49): the reference tests
+                                    !stopLocalBA() AFTER its first ceres::Solve (:603-604) and Estimator::addNewKf raises the flag from
+                                    another thread while pass 1 runs, so the library reads *stop_flag once, right before it decides
+                                    on pass 2 (after pass 1 and the first outlier test), never at entry                              */
+    ov2_ba_options pass1, pass2; /* max_iter 5 / 10, function_tolerance 1e-3 (:461-462, :611).  max_solver_time_s: the reference runs
+                                    pass 1 with 0.2 s (0.4 s unless force_realtime, :463-467) and pass 2 with HALF of that (:612); the
+                                    defaults here are 0 = no limit (results independent of machine load): an adapter that wants the
+                                    reference's limits sets pass1.max_solver_time_s = t and pass2.max_solver_time_s = t / 2           */
 } ov2_local_ba_options;
 typedef struct {
     double *poses_out;           /* 7*n_kf                                                                */
@@ -388,7 +421,10 @@ typedef struct {
     uint8_t *bad_after_pass1;    /* n_res or NULL: verdicts of the first test only                        */
     double *chi2_last_eval;      /* n_res or NULL (not downloaded)                                        */
     uint8_t *depthpos_last_eval; /* n_res or NULL                                                         */
-    int l2_done;                 /* pass 2 ran                                                            */
+    int l2_done;                 /* pass 2 ran (and succeeded)                                            */
+    int pass2_error;             /* OV2_OK, or why pass 2 could not run: the call then still returns OV2_OK with the valid result of
+                                    pass 1 + first outlier test in every output (what the reference keeps when its second Solve
+                                    gives up); the message is in ov2_last_error()                                                    */
     int n_bad_pass1, n_bad_total;
     int iterations[2], num_successful_steps[2], termination[2];
     double initial_cost[2], final_cost[2];

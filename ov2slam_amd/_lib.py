@@ -18,6 +18,11 @@ OV2_MASK_AS_EXECUTED, OV2_MASK_INTENDED = 0, 1
 OV2_CAM_PINHOLE, OV2_CAM_FISHEYE = 0, 1
 OV2_OPT_SOBEL_DY_ORDER = 1
 OV2_SOBEL_DY_OPENCV_ROWFILTER, OV2_SOBEL_DY_EXACT_SUM = 0, 1
+# path selection / test forcing (include/ov2slam_hip.h): per context, never through the environment
+OV2_OPT_LK_IMPL, OV2_OPT_TRACK_IMPL, OV2_OPT_CLAHE_STRIPS, OV2_OPT_BA_FORCE_LARGE, OV2_OPT_BA_LIN_DIRECT = 2, 3, 4, 5, 6
+OV2_OPT_BA_SCHUR_CHUNK, OV2_OPT_BA_XYZ_LIN_WAVES, OV2_OPT_BA_POSE_ONLY_FUSED, OV2_OPT_BA_DETERMINISTIC, OV2_OPT_DEBUG = 7, 8, 9, 10, 11
+OV2_LK_IMPL_AUTO, OV2_LK_IMPL_ROW, OV2_LK_IMPL_LANE3 = 0, 1, 2
+OV2_TRACK_IMPL_WAVE, OV2_TRACK_IMPL_ROW = 0, 1
 OV2_RES_LEFT, OV2_RES_RIGHT, OV2_RES_RIGHT_ANCH, OV2_RES_PNP = 0, 1, 2, 3
 
 
@@ -62,7 +67,7 @@ class BAResult(C.Structure):
 class LocalBAOptions(C.Structure):
     _fields_ = [
         ("robust_mono_th", C.c_double), ("use_robust_cost", C.c_int), ("apply_l2_after_robust", C.c_int),
-        ("stop_requested", C.c_int), ("pass1", BAOptions), ("pass2", BAOptions),
+        ("stop_requested", C.c_int), ("stop_flag", C.POINTER(C.c_int)), ("pass1", BAOptions), ("pass2", BAOptions),
     ]
 
 
@@ -70,7 +75,7 @@ class LocalBAResult(C.Structure):
     _fields_ = [
         ("poses_out", C.POINTER(C.c_double)), ("invdepth_out", C.POINTER(C.c_double)), ("bad_obs", C.POINTER(C.c_uint8)),
         ("bad_after_pass1", C.POINTER(C.c_uint8)), ("chi2_last_eval", C.POINTER(C.c_double)),
-        ("depthpos_last_eval", C.POINTER(C.c_uint8)), ("l2_done", C.c_int), ("n_bad_pass1", C.c_int), ("n_bad_total", C.c_int),
+        ("depthpos_last_eval", C.POINTER(C.c_uint8)), ("l2_done", C.c_int), ("pass2_error", C.c_int), ("n_bad_pass1", C.c_int), ("n_bad_total", C.c_int),
         ("iterations", C.c_int * 2), ("num_successful_steps", C.c_int * 2), ("termination", C.c_int * 2), ("initial_cost", C.c_double * 2),
         ("final_cost", C.c_double * 2), ("solve_ms", C.c_double * 2),
     ]
@@ -133,6 +138,7 @@ SIGNATURES = {
     "ov2_ctx_sync": (_i, [_vp]),
     "ov2_ctx_stream": (_vp, [_vp]),
     "ov2_ctx_set_option": (_i, [_vp, _i, _i]),
+    "ov2_ctx_get_option": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "ov2_pyr_create": (_i, [_vp, _i, _i, _i, _i, _i, _pp]),
     "ov2_pyr_destroy": (None, [_vp]),
     "ov2_pyr_levels": (_i, [_vp]),
@@ -143,8 +149,6 @@ SIGNATURES = {
     "ov2_pyr_download": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ov2_pyr_download_padded": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ov2_pyr_algorithmic_bytes": (C.c_size_t, [_vp]),
-    "ov2_pyr_tiled": (_i, [_vp]),
-    "ov2_pyr_download_tiled": (_i, [_vp, _vp, _i, _i, _vp]),
     "ov2_clahe_h": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _i, _vp, _i]),
     "ov2_clahe_d": (_i, [_vp, _vp, _i, _i, _i, C.c_size_t, _i, _d, _i, _i, _vp, _i, C.c_size_t]),
     "ov2_compute_keypoints": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
@@ -187,7 +191,7 @@ SIGNATURES = {
     "ov2_local_ba": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(LocalBAOptions), C.POINTER(LocalBAResult)]),
 }
 
-OV2_ABI_VERSION = 300          # include/ov2slam_hip.h
+OV2_ABI_VERSION = 400          # include/ov2slam_hip.h
 
 _lib = None
 

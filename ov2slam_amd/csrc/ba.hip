@@ -1336,183 +1336,6 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 #undef CH_TICK
 }
 
-// ---------------------------------------------------------------------------------- reduced system, several work-groups
-// Round 3.  k_ba_cholesky keeps 255 of 256 CUs idle through half of an LM iteration: ten 32-column panels x (pivot chain +
-// panel solve + trailing update of everything to the right + barriers) on ONE compute unit.  Here work-group j OWNS block column
-// j (rows >= 32 j of S and, as one more row, the right-hand side) and keeps it in LDS for the whole factorisation:
-//   for k < j : wait until panel k is published, then  C_j -= P_k[rows] P_k[rows of block j]^T   (row per thread, fp64 FMA)
-//   factor the diagonal block (one wavefront, register rows: the body of k_chol_diag), solve the rows below and the
-//   right-hand-side row against it (row per thread), publish the finished column (S, z) and raise flag j
-//   backward substitution, column oriented: wait for y_k (k > j), fold L[block k rows, my columns]^T y_k into my right-hand side,
-//   solve L_jj^T y_j = .  and publish y_j.
-// The update with panel k overlaps the factorisation of panel k+1 by construction (look-ahead), so the critical path per panel is
-// pivot chain + panel solve + one publish / acquire hand-over + ONE column update instead of the whole trailing matrix.
-// Work-groups synchronise through generation-stamped flags in global memory (agent-scope release / acquire; in-order dispatch
-// guarantees the producers of a flag are resident before its consumers).  With xcd_stride = 8 only every eighth work-group id
-// works, which puts all of them on one XCD (ids are dealt round-robin over the XCDs): the panels then travel through one L2.
-#define MW_MAX_N 384
-__device__ __forceinline__ void mw_wait(const int *flag, int gen)
-{
-    if (threadIdx.x == 0)
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(1);
-    // (thread 0's acquire invalidated this CU's vector L1 -- the one every wavefront of the work-group reads through -- and the
-    // barrier orders the other threads' loads behind it: one cache invalidate per hand-over instead of one per wavefront)
-    __syncthreads();
-}
-__device__ __forceinline__ void mw_publish(int *flag, int gen)
-{
-    // every thread's stores of the column have reached L2 (write-through L1) when its work-group-scope release completes; the
-    // barrier makes them happen-before thread 0's agent-scope release, which is cumulative: ONE L2 write-back per hand-over
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(512) void k_ba_cholesky_mw(BADev D, int gen, int xcd_stride)
-{
-    BACtl *ctl = D.ctl;
-    if (ctl->done) return;
-    if (blockIdx.x % xcd_stride) return;
-    const int j = blockIdx.x / xcd_stride;
-    const int n = D.nf, ld = D.nfp, nblk = (n + CH_NB - 1) / CH_NB;
-    if (j >= nblk) return;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int c0 = CH_NB * j, nb = min(CH_NB, n - c0), m = n - c0;      // my rows: c0 .. n-1 (thread t < m), then the right-hand side (t == m)
-    double *C = (double *)smem_raw;                                     // (m + 1) x CH_LDP
-    double *Pj = C + (size_t)(m + 1) * CH_LDP;                          // CH_NB x CH_LDP : rows of the incoming panel that face my diagonal block
-    double *L11 = Pj + CH_NB * CH_LDP;                                  // CH_NB x CH_LDP : my diagonal block (identity padded), reciprocal pivots in column 32
-    double *ybuf = L11 + CH_NB * CH_LDP;                                // CH_NB
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, t = tid, lane = tid & 63, wave = tid >> 6;
-    int *flags = (int *)D.Linv, *yflags = flags + 64;                   // (zeroed by ba_create; stamped with the launch's generation)
-    double *Z = D.Linv + 64;                                            // forward solution, block by block
-    double *S = D.S, *Y = D.yf;
-    if (tid == 0) s_fail = 0;
-    // ---- my block column -> LDS ----
-    if (t < m) {
-        const double *src = S + (long long)(c0 + t) * ld + c0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = (c < nb && (t >= CH_NB || c <= t)) ? src[c] : 0.0;
-    } else if (t == m) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = c < nb ? D.scale_f[c0 + c] * (D.bf[c0 + c] - D.v[c0 + c]) : 0.0;
-    }
-    __syncthreads();
-    // ---- updates with the panels to my left ----
-    for (int k = 0; k < j; k++) {
-        mw_wait(&flags[k], gen);
-        double row[CH_NB];
-        const double *src = t < m ? S + (long long)(c0 + t) * ld + CH_NB * k : Z + CH_NB * k;
-#pragma unroll
-        for (int q = 0; q < CH_NB; q++) row[q] = t <= m ? src[q] : 0.0;
-        if (t < CH_NB) {
-#pragma unroll
-            for (int q = 0; q < CH_NB; q++) Pj[t * CH_LDP + q] = t < nb ? row[q] : 0.0;
-        }
-        __syncthreads();
-        if (t <= m) {
-#pragma unroll 4
-            for (int c = 0; c < CH_NB; c++) {
-                double acc = C[t * CH_LDP + c];
-                const double *pr = Pj + c * CH_LDP;
-#pragma unroll
-                for (int q = 0; q < CH_NB; q++) acc -= row[q] * pr[q];
-                C[t * CH_LDP + c] = acc;
-            }
-        }
-        __syncthreads();
-    }
-    // ---- my diagonal block: one wavefront, lane = row, left-looking (k_chol_diag) ----
-    for (int e = tid; e < CH_NB * CH_NB; e += blockDim.x) {
-        const int i = e >> 5, c = e & 31;
-        L11[i * CH_LDP + c] = (i < nb && c <= i) ? C[i * CH_LDP + c] : (i == c ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        double a[CH_NB];
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) a[c] = lane < CH_NB ? L11[lane * CH_LDP + c] : 0.0;
-        bool fail = false;
-        double pnext = a[0];
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) {
-            double sacc = pnext;
-            if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];
-            const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
-            if (c + 1 < CH_NB) {
-                pnext = a[c + 1];
-#pragma unroll
-                for (int k = 0; k < c; k++) pnext -= a[k] * L11[(c + 1) * CH_LDP + k];
-            }
-            if (!(d > 0.0) || !isfinite(d)) fail = true;
-            double r = __builtin_amdgcn_rsq(d);
-            r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
-            r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
-            double dj = d * r;
-            dj = fma(0.5 * r, fma(-dj, dj, d), dj);
-            const double l = lane == c ? dj : sacc * r;
-            a[c] = lane >= c ? l : 0.0;
-            if (lane >= c && lane < CH_NB) L11[lane * CH_LDP + c] = a[c];
-            if (lane == c) L11[c * CH_LDP + CH_NB] = fma(r, fma(-dj, r, 1.0), r);      // reciprocal pivot
-            wave_lds_sync();
-        }
-        if (__builtin_amdgcn_ballot_w64(fail) != 0 && lane == 0) s_fail = 1;
-    }
-    __syncthreads();
-    // ---- rows below the diagonal block and the right-hand-side row: X L11^T = A21, one row per thread ----
-    if (t < nb) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = c <= t ? L11[t * CH_LDP + c] : 0.0;
-    } else if (t <= m) {
-        double x[CH_NB];
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) x[c] = C[t * CH_LDP + c];
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) {
-            double acc = x[c];
-#pragma unroll
-            for (int k = 0; k < c; k++) acc -= x[k] * L11[c * CH_LDP + k];
-            x[c] = acc * L11[c * CH_LDP + CH_NB];
-        }
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) C[t * CH_LDP + c] = x[c];
-    }
-    // ---- publish my column: L into S (the later columns' updates read it), z into Z ----
-    if (t < m) {
-        double *dst = S + (long long)(c0 + t) * ld + c0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) if (c < nb && (t >= CH_NB || c <= t)) dst[c] = C[t * CH_LDP + c];
-    } else if (t == m) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) if (c < nb) Z[c0 + c] = C[t * CH_LDP + c];
-    }
-    mw_publish(&flags[j], gen);
-    // ---- backward substitution  L^T y = z, column oriented ----
-    double racc = 0.0;
-    for (int k = nblk - 1; k > j; k--) {
-        mw_wait(&yflags[k], gen);
-        const int kb = min(CH_NB, n - CH_NB * k);
-        if (t < nb) {
-            const double *Lk = C + (size_t)(CH_NB * (k - j)) * CH_LDP + t;            // L[32 k + r][c0 + t]
-            for (int r = 0; r < kb; r++) racc += Lk[r * CH_LDP] * Y[CH_NB * k + r];
-        }
-    }
-    if (t < CH_NB) ybuf[t] = t < nb ? C[m * CH_LDP + t] - racc : 0.0;
-    __syncthreads();
-    if (wave == 0) {
-        // y[c] for c = nb-1 .. 0:  y[c] = (rhs[c] - sum_{r > c} L[r][c] y[r]) / L[c][c];  lane c carries rhs[c]
-        double rhs = lane < CH_NB ? ybuf[lane] : 0.0;
-        for (int c = nb - 1; c >= 0; c--) {
-            const double yc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rhs), c), __builtin_amdgcn_readlane(__double2loint(rhs), c)) * L11[c * CH_LDP + CH_NB];
-            if (lane == c) rhs = yc;
-            else if (lane < c) rhs -= L11[c * CH_LDP + lane] * yc;
-        }
-        if (lane < nb) Y[c0 + lane] = rhs;
-    }
-    mw_publish(&yflags[j], gen);
-    if (tid == 0 && s_fail) ctl->lin_fail = 1;
-}
-
 // ================================================================================== pose-only problems in ONE kernel
 // MultiViewGeometry::ceresPnP (src/multi_view_geometry.cpp:492-586): one free pose, a few hundred fixed world points.  The
 // multi-kernel loop above costs ~10 launches of ~6 us per LM iteration whatever the problem size -- 0.45 ms per solve, four times
@@ -2365,7 +2188,6 @@ struct ov2_ba_dev {
     int *lm_order = nullptr;            // landmarks sorted by anchor keyframe (device)
     std::vector<double> h_poses0, h_lam0;
     int device = 0;
-    int chol_gen = 0;                   // launch stamp of k_ba_cholesky_mw's flags (Linv[0..127] as ints, zeroed at creation)
 };
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2498,10 +2320,10 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         const size_t lin_lds = 8 * (4 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
         const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
         D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) ? 1 : 0;
-        if (const char *e = getenv("OV2_BA_BIG")) D.big = e[0] == '1' ? 1 : D.big;       // force the path on small problems (tests)
+        if (ctx->ba_force_large) D.big = 1;                                    // OV2_OPT_BA_FORCE_LARGE: the path on small problems (tests)
         // beyond ~570 optimised keyframes the big-path linearisers cannot pre-aggregate the observer blocks in LDS either
         D.lin_direct = (D.big && 8 * ((size_t)n_opt * 27 + 4 * (size_t)LIN_RED) + 64 > 159 * 1024) ? 1 : 0;
-        if (const char *e = getenv("OV2_BA_LIN_DIRECT")) D.lin_direct = (D.big && e[0] == '1') ? 1 : D.lin_direct;   // tests: force it on small problems
+        if (ctx->ba_lin_direct && D.big) D.lin_direct = 1;                     // OV2_OPT_BA_LIN_DIRECT (tests: force it on small problems)
         D.chol_hbm = D.big; D.lin_waves = 4;
     }
     // big path: the slots of the sparse W (one per landmark and optimised keyframe seeing or anchoring it) and their per-keyframe lists
@@ -2602,7 +2424,6 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         hipError_t em = hipMemsetAsync(D.res_off, 0, na, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.bad_obs, 0, nr, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.lba_cnt, 0, 64, s);
-        if (em == hipSuccess) em = hipMemsetAsync(D.Linv, 0, 512, s);          // k_ba_cholesky_mw's flags
         if (em != hipSuccess) { ov2_set_error("hipMemsetAsync: %s", hipGetErrorString(em)); ba_destroy(dev); return OV2_EHIP; }
     }
     UP(D.po_kf, po_kf, 4 * (size_t)n_po); UP(D.po_orig, po_orig, 4 * (size_t)n_po);
@@ -2652,14 +2473,14 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     int lin_waves = 0;
     for (int nw = 4; nw >= 1 && !lin_waves; nw >>= 1)
         if (8 * (3 * (size_t)nw * nfp + (size_t)n_opt * 27) + 64 <= 159 * 1024) lin_waves = nw;
-    if (const char *e = getenv("OV2_BA_XYZ_LIN_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2) lin_waves = lin_waves ? std::min(lin_waves, v) : 0; }   // tests
+    if (ctx->ba_xyz_lin_waves == 1 || ctx->ba_xyz_lin_waves == 2) lin_waves = lin_waves ? std::min(lin_waves, ctx->ba_xyz_lin_waves) : 0;   // OV2_OPT_BA_XYZ_LIN_WAVES (tests)
     if (!lin_waves || nfp > BA_MAX_NFP) {
         ov2_set_error("too many optimised keyframes (%d) for the 3-D point form (limit ~450: dense W rows in LDS)", n_opt);
         return OV2_EUNSUPPORTED;
     }
     const size_t chol_lds_res = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
     int chol_hbm = chol_lds_res > 150 * 1024 ? 1 : 0;
-    if (const char *e = getenv("OV2_BA_BIG")) chol_hbm = e[0] == '1' ? 1 : chol_hbm;                 // tests: force the HBM factorisation on small problems
+    if (ctx->ba_force_large) chol_hbm = 1;                                      // OV2_OPT_BA_FORCE_LARGE (tests: the HBM factorisation on small problems)
     std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
     std::vector<uint8_t> res_type(n_act);
     std::vector<double> res_uv(2 * (size_t)n_act), res_sigma(n_act);
@@ -2728,7 +2549,6 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
     UPX(D.res_uv, res_uv.data(), 16 * (size_t)n_act);
     UPX(D.res_sigma, res_sigma.data(), 8 * (size_t)n_act);
 #undef UPX
-    (void)hipMemsetAsync(D.Linv, 0, 512, s);                                   // k_ba_cholesky_mw's flags
     {
         const hipError_t es = hipStreamSynchronize(s);
         if (es != hipSuccess) { ov2_set_error("hipStreamSynchronize: %s", hipGetErrorString(es)); ba_destroy(dev); return OV2_EHIP; }
@@ -2794,7 +2614,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_schur_sparse);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize_xyz);
             if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky);
-            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_cholesky_mw);
+            if (attr_err == hipSuccess) attr_err = raise((const void *)k_ba_linearize_po);
         });
         OV2_HIP_CHECK(attr_err);
     }
@@ -2823,10 +2643,9 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     h_ctl.radius = o->initial_radius; h_ctl.decrease_factor = 2.0; h_ctl.x_norm = -1.0;
     h_ctl.need_lin = 1; h_ctl.step_successful = 1;
     h_ctl.termination = OV2_TERM_NO_CONVERGENCE;
-    // one optimised pose, pose-only residual blocks, no landmarks (ceresPnP): the whole loop in one kernel (OV2_BA_POSE_ONLY_FUSED=0
-    // keeps the multi-kernel path for A/B runs)
-    const char *env_po = getenv("OV2_BA_POSE_ONLY_FUSED");
-    const bool fused_po = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && !(env_po && env_po[0] == '0') && !(o->max_solver_time_s > 0.0);
+    // one optimised pose, pose-only residual blocks, no landmarks (ceresPnP): the whole loop in one kernel (OV2_OPT_BA_POSE_ONLY_FUSED
+    // = 0 keeps the multi-kernel path for A/B runs)
+    const bool fused_po = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && ctx->ba_pose_only_fused && !(o->max_solver_time_s > 0.0);
     if (fused_po) {
         hipLaunchKernelGGL(k_ba_pose_only, dim3(1), dim3(256), 0, s, D, O, h_ctl);
         OV2_HIP_CHECK(hipGetLastError());
@@ -2852,28 +2671,16 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int ss_split = std::max(1, (512 + std::max(1, n_opt) - 1) / std::max(1, n_opt));
     // column chunk of the row block kept in LDS: all of it up to 2040 columns (340 pose blocks), else that many per chunk
     int ss_ncol = D.nfp <= 2048 ? D.nfp : 2040;
-    if (const char *e = getenv("OV2_BA_SCHUR_CHUNK")) { const int v = atoi(e); if (v >= 6) ss_ncol = std::min(ss_ncol, v / 6 * 6); }   // tests
+    if (ctx->ba_schur_chunk >= 6) ss_ncol = std::min(ss_ncol, ctx->ba_schur_chunk / 6 * 6);                                     // OV2_OPT_BA_SCHUR_CHUNK (tests)
     const int ss_chunks = (D.nfp + ss_ncol - 1) / ss_ncol;
     const size_t ss_lds = 8 * (6 * (size_t)ss_ncol + (size_t)SS_WAVES * 64 * 6) + 4 * (size_t)SS_WAVES * 64 + 64;
 
-    // reduced system: the several-work-group Cholesky (block column per work-group, look-ahead by construction) from two block
-    // columns up to MW_MAX_N unknowns when OV2_BA_CHOL_MW=1 (default: the one-work-group kernel); OV2_BA_CHOL_XCD=1 keeps the
-    // work-groups on one XCD (every eighth id) instead of spreading them over all
-    const int mw_nblk = (D.nf + CH_NB - 1) / CH_NB;
-    const char *env_mw = getenv("OV2_BA_CHOL_MW"), *env_xcd = getenv("OV2_BA_CHOL_XCD");
-    // MEASURED (MI355X, gpurun_out/r3q): config 4 550 us per LM iteration with the work-groups on all XCDs, 629 on one XCD, against
-    // 532 with the one-work-group kernel -- every hand-over costs an L2 write-back + invalidate and a global round trip for the
-    // panel rows, and the row-per-thread column update reads the 32 x 32 block through 1024 LDS broadcasts per thread: the
-    // critical path per panel (factor 5 + solve 3 + hand-over ~4 + rows ~2 + update ~7 us) is no shorter than the old kernel's
-    // 27 us.  An MFMA column update would bring it to ~495 us (-7 %).  Kept as an opt-in (OV2_BA_CHOL_MW=1), parity-tested.
-    const bool chol_mw = !D.chol_hbm && D.nf > CH_NB && D.nf <= MW_MAX_N && (env_mw && env_mw[0] == '1');
-    const int mw_stride = (env_xcd && env_xcd[0] == '1') ? 8 : 1;              // (all XCDs is the faster placement)
-    const size_t mw_lds = 8 * ((size_t)(D.nf + 1) * CH_LDP + 2 * (size_t)CH_NB * CH_LDP + CH_NB) + 64;
     auto linearize = [&]() {
         if (D.n_lm > 0 && D.ldim == 3) hipLaunchKernelGGL(k_ba_linearize_xyz, dim3(lin_blocks * (4 / D.lin_waves)), dim3(64 * D.lin_waves), lin_lds, s, D);
-        else if (D.n_lm > 0 && D.big) {
-            hipLaunchKernelGGL(k_ba_zero_lin, dim3(1024), dim3(256), 0, s, D);
-            hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        else if (D.big) {
+            // (k_ba_decide leaves H, F^T b and the W slots to this kernel on the large path: also for pose-only problems)
+            if (D.n_lm > 0 || D.n_po > 0) hipLaunchKernelGGL(k_ba_zero_lin, dim3(1024), dim3(256), 0, s, D);
+            if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         }
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (D.big && D.lin_direct ? 0 : (size_t)n_opt * 27 * 8) + 16, s, D);
@@ -2921,19 +2728,16 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
         if (D.nf > 0) hipLaunchKernelGGL(k_ba_assemble, dim3((D.nf + 255) / 256, D.nf), dim3(256), 0, s, D);   // (structure-only problems: no reduced system)
         if (D.chol_hbm) {
-            int budget = getenv("OV2_BA_CHOL_STAGES") ? atoi(getenv("OV2_BA_CHOL_STAGES")) : 1 << 30;      // debugging: stop the factorisation early
             for (int k0 = 0; k0 < D.nf; k0 += CH_NB) {
                 const int m = D.nf - k0 - std::min(CH_NB, D.nf - k0);
-                if (budget-- > 0) hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, D, k0);
+                hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, D, k0);
                 if (m > 0) {
                     const int mb = (m + 31) / 32;
-                    if (budget-- > 0) hipLaunchKernelGGL(k_chol_panel, dim3((m + 63) / 64), dim3(64), 0, s, D, k0);
-                    if (budget-- > 0) hipLaunchKernelGGL(k_chol_trail, dim3(mb * (mb + 1) / 2), dim3(256), 0, s, D, k0);
+                    hipLaunchKernelGGL(k_chol_panel, dim3((m + 63) / 64), dim3(64), 0, s, D, k0);
+                    hipLaunchKernelGGL(k_chol_trail, dim3(mb * (mb + 1) / 2), dim3(256), 0, s, D, k0);
                 }
             }
-            if (budget > 0) hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
-        } else if (chol_mw) {
-            hipLaunchKernelGGL(k_ba_cholesky_mw, dim3(mw_nblk * mw_stride), dim3(512), mw_lds, s, D, ++dev->chol_gen, mw_stride);
+            hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
         } else
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
@@ -2960,24 +2764,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     r->iterations = h_ctl.n_steps; r->num_successful_steps = h_ctl.n_success;
     r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
     r->solve_ms = ms;
-    if (const char *dump = getenv("OV2_BA_DUMP")) {
-        // debugging aid: H, G, S (factor), bf, v, yf, etb, cl of the LAST iteration as raw doubles (nfp, then the arrays)
-        FILE *f = fopen(dump, "wb");
-        if (f) {
-            const size_t nn = (size_t)D.nfp * D.nfp;
-            std::vector<double> buf(std::max(nn, (size_t)std::max(1, D.n_lm)));
-            const double hdr[4] = {(double)D.nfp, (double)D.nf, (double)D.n_lm, (double)D.big};
-            fwrite(hdr, 8, 4, f);
-            const double *arrs[3] = {D.H, D.G, D.S};
-            for (int a = 0; a < 3; a++) { (void)hipMemcpy(buf.data(), arrs[a], 8 * nn, hipMemcpyDeviceToHost); fwrite(buf.data(), 8, nn, f); }
-            const double *vecs[3] = {D.bf, D.v, D.yf};
-            for (int a = 0; a < 3; a++) { (void)hipMemcpy(buf.data(), vecs[a], 8 * (size_t)D.nfp, hipMemcpyDeviceToHost); fwrite(buf.data(), 8, (size_t)D.nfp, f); }
-            const double *lv[3] = {D.etb, D.cl, D.yl};
-            for (int a = 0; a < 3; a++) { (void)hipMemcpy(buf.data(), lv[a], 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost); fwrite(buf.data(), 8, (size_t)D.n_lm, f); }
-            fclose(f);
-        }
-    }
-    if (getenv("OV2_BA_DEBUG"))
+    if (ctx->debug)
         fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): copy-in %llu diag %llu panel %llu trail %llu solve %llu\n",
                 h_ctl.dbg[0], h_ctl.dbg[1], h_ctl.dbg[2], h_ctl.dbg[3], h_ctl.dbg[4]);
     return OV2_OK;
@@ -3026,7 +2813,7 @@ void ov2_ba_destroy(ov2_ba_dev *dev) { ba_destroy(dev); }
 void ov2_local_ba_default_options(ov2_local_ba_options *o)
 {
     if (!o) return;
-    o->robust_mono_th = 5.9915; o->use_robust_cost = 1; o->apply_l2_after_robust = 1; o->stop_requested = 0;
+    o->robust_mono_th = 5.9915; o->use_robust_cost = 1; o->apply_l2_after_robust = 1; o->stop_requested = 0; o->stop_flag = nullptr;
     ov2_ba_default_options(&o->pass1);                       // 5 iterations, function_tolerance 1e-3 (optimizer.cpp:461-462)
     ov2_ba_default_options(&o->pass2);
     o->pass2.max_iter = 10;                                  // :611
@@ -3038,10 +2825,10 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
 {
     OV2_REQUIRE(ctx && p && o && r, OV2_EINVAL, "NULL argument");
     OV2_REQUIRE(o->robust_mono_th > 0, OV2_EINVAL, "robust_mono_th must be positive");
-    r->l2_done = 0; r->n_bad_pass1 = 0; r->n_bad_total = 0;
+    r->l2_done = 0; r->pass2_error = OV2_OK; r->n_bad_pass1 = 0; r->n_bad_total = 0;
     for (int i = 0; i < 2; i++) { r->iterations[i] = 0; r->num_successful_steps[i] = 0; r->termination[i] = OV2_TERM_NO_CONVERGENCE; r->initial_cost[i] = r->final_cost[i] = 0; r->solve_ms[i] = 0; }
     ov2_ba_dev *dev = nullptr;
-    const bool dbg = getenv("OV2_BA_DEBUG") != nullptr;
+    const bool dbg = ctx->debug != 0;
     const auto tw0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (dbg) fprintf(stderr, "[ov2 local_ba] %-28s %8.3f ms since entry\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
@@ -3077,14 +2864,21 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
     lap("outlier test 1");
     const int nbbad = cnt_h[0], left_remaining = cnt_h[1], right_remaining = cnt_h[2];
     r->n_bad_pass1 = nbbad; r->n_bad_total = nbbad;
-    if (o->apply_l2_after_robust && o->use_robust_cost && !o->stop_requested && nbbad > 0) {          // :603-604
+    // stopLocalBA() is evaluated HERE, after the first solve (:603-604): a keyframe that arrived while pass 1 ran skips pass 2
+    const bool stop = o->stop_requested || (o->stop_flag && *o->stop_flag);
+    if (o->apply_l2_after_robust && o->use_robust_cost && !stop && nbbad > 0) {          // :603-604
         // the loss is reset to L2 only when both residual lists are still non-empty (:606-608: mono runs keep Huber!)
         ov2_ba_options o2 = o->pass2;
         o2.huber_delta = (left_remaining && right_remaining) ? -1.0 : huber;
         hipLaunchKernelGGL(k_ba_lm_live, dim3(std::max(1, std::min(512, (D.n_lm + 3) / 4))), dim3(256), 0, s, D);
         OV2_HIP_CHECK(hipMemsetAsync(D.lba_cnt, 0, 16, s));
         rc = ba_run(ctx, dev, &o2, &br, nullptr, nullptr, /*keep_state*/ true);
-        if (rc != OV2_OK) return rc;
+        if (rc != OV2_OK) {
+            // pass 2 could not run: the device still holds an accepted state (pass 1's, or a later accepted LM step) and the
+            // verdicts of the first test -- hand those back instead of dropping a valid solve
+            r->pass2_error = rc;
+            goto download;
+        }
         r->l2_done = 1;
         r->iterations[1] = br.iterations; r->num_successful_steps[1] = br.num_successful_steps; r->termination[1] = br.termination; r->initial_cost[1] = br.initial_cost;
         r->final_cost[1] = br.final_cost; r->solve_ms[1] = br.solve_ms;
@@ -3094,6 +2888,7 @@ int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_optio
         OV2_HIP_CHECK(hipGetLastError());
         OV2_HIP_CHECK(hipMemcpyAsync(cnt_h, D.lba_cnt, 16, hipMemcpyDeviceToHost, s));
     }
+download:
     if (r->poses_out) OV2_HIP_CHECK(hipMemcpyAsync(r->poses_out, D.x_pose, 56 * (size_t)D.n_kf, hipMemcpyDeviceToHost, s));
     if (r->invdepth_out && D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->invdepth_out, D.x_lam, 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost, s));
     if (r->bad_obs && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->bad_obs, D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));

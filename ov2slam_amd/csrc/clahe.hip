@@ -28,8 +28,6 @@ struct ClaheParams {
     int dst_stride;
     int border;          // > 0: dst is a padded pyramid level -- also write its REFLECT_101 border of this many pixels
     int batch, gx_lut;   // images in the launch, work-groups per image of the LUT kernel (1-D XCD-aware launches)
-    long long til_delta; // != 0: dst is level 0 of a pyramid with a tiled LK copy: byte offset of that copy from the dst ROI pointer
-    int til_ntx;         //       tiles per row of it (common.hpp: ov2_til_offset)
     int ysplit;          // apply kernel: work-groups per row of interpolation cells (1 in batch mode; a single image is cut
                          // into ~60 short row bands so that it does not run on 10 CUs only -- latency)
     // strip kernel (k_clahe_apply_pyr): column strips per image, level 1 of the pyramid next to the level-0 destination
@@ -360,13 +358,6 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
                 if ((CLAHE_KO & 16) && out != 0x12345678u) continue;
                 if (full) *(uint32_t *)(drow + xb) = out;
                 else for (int k = 0; k < 4; k++) if (xb + k < P.w) drow[xb + k] = (uint8_t)(out >> (8 * k));
-                if (P.til_delta != 0) {
-                    // the same pixels in the tiled LK copy of level 0 (16 x 8-pixel tiles of 128 B; x, y offset by OV2_TIL_PAD)
-                    const int X = xb + OV2_TIL_PAD, Y = y + OV2_TIL_PAD;
-                    uint8_t *dt = dimg + P.til_delta + ((long long)((Y >> 3) * P.til_ntx + (X >> 4)) << 7) + ((Y & 7) << 4) + (X & 15);
-                    if (xb + 3 < P.w) *(uint32_t *)dt = out;
-                    else for (int k = 0; k < 4; k++) if (xb + k < P.w) dt[k] = (uint8_t)(out >> (8 * k));
-                }
             }
 #pragma unroll
             for (int u = 0; u < CA_UNROLL; u++) inr[u] = nxt[u];
@@ -623,7 +614,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
 
 int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                      double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                     uint8_t *lut_d, int border, long long til_delta, int til_ntx, const PyrDesc *pyr, int *level1_done)
+                     uint8_t *lut_d, int border, const PyrDesc *pyr, int *level1_done)
 {
     if (level1_done) *level1_done = 0;
     // geometry checks first: nothing is enqueued when the call is going to fail
@@ -640,7 +631,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     });
     OV2_HIP_CHECK(attr_err);
     ClaheParams P;
-    P.border = border; P.til_delta = til_delta; P.til_ntx = til_ntx;
+    P.border = border;
     P.nstrips = 0; P.l1_delta = 0; P.l1_pitch = P.l1_w = P.l1_h = 0;
     int ew = w, eh = h;
     if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
@@ -659,12 +650,11 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
     hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk
-    // (OV2_CLAHE_STRIPS=1 forces it for any batch, =0 disables it -- A/B runs, parity tests of both paths)
-    if (pyr && pyr->n_levels >= 2 && !pyr->tiled && til_delta == 0 && border == pyr->win && src_al && (w & 3) == 0 && w >= 64 && h >= 8 &&
+    // (OV2_OPT_CLAHE_STRIPS = 1 forces it for any batch, 0 disables it -- A/B runs, parity tests of both paths)
+    if (pyr && pyr->n_levels >= 2 && border == pyr->win && src_al && (w & 3) == 0 && w >= 64 && h >= 8 &&
         (((size_t)dst_d | (size_t)dst_stride | dst_batch_stride) & 3) == 0 && (pyr->lv[1].img_pitch & 1) == 0) {
         const int ndw = w / 4, nstrips = ndw <= 64 ? 1 : 2 + (ndw - 126 + 61) / 62;
-        const char *e = getenv("OV2_CLAHE_STRIPS");
-        const bool want = e ? e[0] == '1' : (long long)batch * nstrips >= 1024;
+        const bool want = ctx->clahe_strips >= 0 ? ctx->clahe_strips == 1 : (long long)batch * nstrips >= 1024;
         if (want && nstrips <= CS_MAX_STRIPS && tiles_x + 1 <= 40) {
             static std::once_flag strip_once;
             static hipError_t strip_err = hipSuccess;
@@ -700,7 +690,7 @@ int ov2_clahe_d(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, si
     const int rc = ctx->reserve_device(lut_bytes);
     if (rc != OV2_OK) return rc;
     return ov2_launch_clahe(ctx, src_d, w, h, stride, src_batch_stride, batch, clip_limit, tiles_x, tiles_y, dst_d, dst_stride,
-                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0, 0, 0, nullptr, nullptr);
+                            dst_batch_stride, (uint8_t *)ctx->d_scratch, 0, nullptr, nullptr);
 }
 
 int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int stride, size_t img_batch_stride,
@@ -719,7 +709,7 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
     int l1_done = 0;
     rc = ov2_launch_clahe(ctx, img_d, p->w, p->h, stride, img_batch_stride, p->d.batch, clip_limit, tiles_x, tiles_y,
                           p->d.base + L0.img_roi, L0.img_pitch, (size_t)p->d.item_stride, (uint8_t *)ctx->d_scratch, p->d.win,
-                          p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx, &p->d, &l1_done);
+                          &p->d, &l1_done);
     if (rc != OV2_OK) return rc;
     rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0, l1_done);
     if (rc != OV2_OK) return rc;
@@ -744,7 +734,7 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     const PyrLevelDesc &L0 = p->d.lv[0];
     int l1_done = 0;
     rc = ov2_launch_clahe(ctx, ds, p->w, p->h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, p->d.base + L0.img_roi, L0.img_pitch,
-                          (size_t)p->d.item_stride, ds + img, p->d.win, p->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx, &p->d, &l1_done);
+                          (size_t)p->d.item_stride, ds + img, p->d.win, &p->d, &l1_done);
     if (rc != OV2_OK) return rc;
     rc = ov2_launch_pyr_build(ctx, p, nullptr, 0, 0, l1_done);
     if (rc != OV2_OK) return rc;
@@ -765,7 +755,7 @@ int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, do
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
     rc = ctx->upload_image(ds, pitch, src_h, (size_t)stride, (size_t)w, (size_t)h);
     if (rc != OV2_OK) return rc;
-    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, 0, 0, nullptr, nullptr);
+    const int rc2 = ov2_launch_clahe(ctx, ds, w, h, (int)pitch, 0, 1, clip_limit, tiles_x, tiles_y, ds + img, (int)pitch, 0, ds + 2 * img, 0, nullptr, nullptr);
     if (rc2 != OV2_OK) return rc2;
     rc = ctx->download_image(dst_h, (size_t)dst_stride, ds + img, pitch, (size_t)w, (size_t)h);      // (synchronises)
     if (rc != OV2_OK) return rc;

@@ -45,6 +45,18 @@ struct ov2_ctx {
     // 200 us floor under a 16k-work-group launch); a one-block kernel folds the lines into the caller's pair.
     unsigned long long *stat_slots = nullptr;
     int sobel_dy_order = OV2_SOBEL_DY_OPENCV_ROWFILTER;   // ov2_ctx_set_option(OV2_OPT_SOBEL_DY_ORDER)
+    // Path selection / test forcing (ov2_ctx_set_option, OV2_OPT_*).  The library reads NO environment variable after
+    // ov2_ctx_create: the entry points are called from several threads of a host that may setenv() concurrently.
+    int lk_impl = OV2_LK_IMPL_AUTO;            // OV2_OPT_LK_IMPL
+    int track_impl = OV2_TRACK_IMPL_WAVE;      // OV2_OPT_TRACK_IMPL
+    int clahe_strips = -1;                     // OV2_OPT_CLAHE_STRIPS: -1 auto, 0 never, 1 whenever the geometry allows
+    int ba_force_large = 0;                    // OV2_OPT_BA_FORCE_LARGE
+    int ba_lin_direct = 0;                     // OV2_OPT_BA_LIN_DIRECT
+    int ba_schur_chunk = 0;                    // OV2_OPT_BA_SCHUR_CHUNK (columns; 0 = auto)
+    int ba_xyz_lin_waves = 0;                  // OV2_OPT_BA_XYZ_LIN_WAVES (0 = auto, 1, 2)
+    int ba_pose_only_fused = 1;                // OV2_OPT_BA_POSE_ONLY_FUSED
+    int ba_deterministic = 0;                  // OV2_OPT_BA_DETERMINISTIC
+    int debug = 0;                             // OV2_OPT_DEBUG; initial value: environment OV2_DEBUG, read once by ov2_ctx_create
     // pinned staging of host images on their way to the device: its own buffer (h_scratch is rewritten by the next call's small
     // arrays while an asynchronous image upload may still be in flight) and an event that says when it may be refilled
     void *h_img = nullptr;  size_t h_img_bytes = 0;
@@ -73,19 +85,7 @@ struct PyrLevelDesc {
     long long img_roi;    // byte offset (from the item base) of image ROI pixel (0,0)
     long long der_roi;    // byte offset (from the item base) of derivative ROI element (0,0)
     int img_padx, der_padx, pady;
-    // Tiled copy for the batch LK kernel (k_fb_klt3): 16 x 8-pixel tiles of 128 bytes = one cache line each, covering the
-    // image plus 16 columns / rows of padding on the left / top (REFLECT_101 border inside it) and the slack LK's block
-    // fetches can touch on the right / bottom.  A 16-row block of 16-byte row segments then spans 4-6 lines instead of
-    // 12-18 (the kernel is bound by line fills).  til_base < 0: this pyramid has no tiled copy.
-    long long til_base;   // byte offset (from the item base) of tile (0, 0)
-    int til_ntx, til_nty; // tiles per row / tile rows
 };
-#define OV2_TIL_PAD 16        // pixel (x, y) lives at tile column (x + 16) >> 4, tile row (y + 16) >> 3
-__host__ __device__ __forceinline__ long long ov2_til_offset(const PyrLevelDesc &L, int x, int y)
-{
-    const int X = x + OV2_TIL_PAD, Y = y + OV2_TIL_PAD;
-    return L.til_base + ((long long)((Y >> 3) * L.til_ntx + (X >> 4)) << 7) + ((Y & 7) << 4) + (X & 15);
-}
 
 struct PyrDesc {
     uint8_t *base;            // device pointer of batch item 0
@@ -93,7 +93,6 @@ struct PyrDesc {
     int n_levels;
     int win;
     int batch;
-    int tiled;                // 1: every level also has its tiled copy (batch pyramids)
     PyrLevelDesc lv[OV2_MAX_LEVELS];
 };
 
@@ -118,10 +117,10 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
 // cv::CLAHE::apply on `batch` device images; border > 0: dst is a padded pyramid level, its REFLECT_101 border is written too
 int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int stride, size_t src_batch_stride, int batch,
                      double clip_limit, int tiles_x, int tiles_y, uint8_t *dst_d, int dst_stride, size_t dst_batch_stride,
-                     uint8_t *lut_d, int border, long long til_delta = 0, int til_ntx = 0, const struct PyrDesc *pyr = nullptr,
-                     int *level1_done = nullptr);
+                     uint8_t *lut_d, int border, const struct PyrDesc *pyr = nullptr, int *level1_done = nullptr);
 // fused VisualFrontEnd::kltTracking launch (lk.hip), device pointers only
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
                          const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                         const float *sad_x = nullptr, float sad_up = 0.f);      // sad_x: stereo mode (lk.hip: k_track_klt)
+                         const float *sad_x = nullptr, float sad_up = 0.f,       // sad_x: stereo mode (lk.hip: k_track_klt)
+                         int track_impl = OV2_TRACK_IMPL_WAVE);

@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -94,6 +95,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, ov2_ctx *
     ov2_ctx *c = new (std::nothrow) ov2_ctx();
     OV2_REQUIRE(c != nullptr, OV2_ENOMEM, "out of host memory");
     c->device = device;
+    if (const char *e = getenv("OV2_DEBUG")) c->debug = e[0] == '1';     // the one environment read of the library
     if (own) {
         hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { delete c; ov2_set_error("hipStreamCreate: %s", hipGetErrorString(se)); return OV2_EHIP; }
@@ -151,6 +153,47 @@ int ov2_ctx_set_option(ov2_ctx *ctx, int option, int value)
         OV2_REQUIRE(value == OV2_SOBEL_DY_OPENCV_ROWFILTER || value == OV2_SOBEL_DY_EXACT_SUM, OV2_EINVAL, "unknown Sobel dy order");
         ctx->sobel_dy_order = value;
         return OV2_OK;
+    case OV2_OPT_LK_IMPL:
+        OV2_REQUIRE(value >= OV2_LK_IMPL_AUTO && value <= OV2_LK_IMPL_LANE3, OV2_EINVAL, "unknown LK kernel choice");
+        ctx->lk_impl = value; return OV2_OK;
+    case OV2_OPT_TRACK_IMPL:
+        OV2_REQUIRE(value == OV2_TRACK_IMPL_WAVE || value == OV2_TRACK_IMPL_ROW, OV2_EINVAL, "unknown tracker kernel choice");
+        ctx->track_impl = value; return OV2_OK;
+    case OV2_OPT_CLAHE_STRIPS:
+        OV2_REQUIRE(value >= -1 && value <= 1, OV2_EINVAL, "OV2_OPT_CLAHE_STRIPS takes -1, 0 or 1");
+        ctx->clahe_strips = value; return OV2_OK;
+    case OV2_OPT_BA_FORCE_LARGE:     ctx->ba_force_large = value != 0; return OV2_OK;
+    case OV2_OPT_BA_LIN_DIRECT:      ctx->ba_lin_direct = value != 0; return OV2_OK;
+    case OV2_OPT_BA_SCHUR_CHUNK:
+        OV2_REQUIRE(value == 0 || value >= 6, OV2_EINVAL, "OV2_OPT_BA_SCHUR_CHUNK takes 0 or >= 6 columns");
+        ctx->ba_schur_chunk = value; return OV2_OK;
+    case OV2_OPT_BA_XYZ_LIN_WAVES:
+        OV2_REQUIRE(value >= 0 && value <= 2, OV2_EINVAL, "OV2_OPT_BA_XYZ_LIN_WAVES takes 0, 1 or 2");
+        ctx->ba_xyz_lin_waves = value; return OV2_OK;
+    case OV2_OPT_BA_POSE_ONLY_FUSED: ctx->ba_pose_only_fused = value != 0; return OV2_OK;
+    case OV2_OPT_BA_DETERMINISTIC:   ctx->ba_deterministic = value != 0; return OV2_OK;
+    case OV2_OPT_DEBUG:              ctx->debug = value != 0; return OV2_OK;
+    default:
+        ov2_set_error("unknown context option %d", option);
+        return OV2_EINVAL;
+    }
+}
+
+int ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value)
+{
+    OV2_REQUIRE(ctx != nullptr && value != nullptr, OV2_EINVAL, "NULL argument");
+    switch (option) {
+    case OV2_OPT_SOBEL_DY_ORDER:     *value = ctx->sobel_dy_order; return OV2_OK;
+    case OV2_OPT_LK_IMPL:            *value = ctx->lk_impl; return OV2_OK;
+    case OV2_OPT_TRACK_IMPL:         *value = ctx->track_impl; return OV2_OK;
+    case OV2_OPT_CLAHE_STRIPS:       *value = ctx->clahe_strips; return OV2_OK;
+    case OV2_OPT_BA_FORCE_LARGE:     *value = ctx->ba_force_large; return OV2_OK;
+    case OV2_OPT_BA_LIN_DIRECT:      *value = ctx->ba_lin_direct; return OV2_OK;
+    case OV2_OPT_BA_SCHUR_CHUNK:     *value = ctx->ba_schur_chunk; return OV2_OK;
+    case OV2_OPT_BA_XYZ_LIN_WAVES:   *value = ctx->ba_xyz_lin_waves; return OV2_OK;
+    case OV2_OPT_BA_POSE_ONLY_FUSED: *value = ctx->ba_pose_only_fused; return OV2_OK;
+    case OV2_OPT_BA_DETERMINISTIC:   *value = ctx->ba_deterministic; return OV2_OK;
+    case OV2_OPT_DEBUG:              *value = ctx->debug; return OV2_OK;
     default:
         ov2_set_error("unknown context option %d", option);
         return OV2_EINVAL;

@@ -966,7 +966,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     OV2_HIP_CHECK(hipMemcpyAsync(hs, ds + o_out, 16 * (size_t)ncells + sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(so_h, hs + 16 * (size_t)ncells, sizeof(SelectOut));
-    if (getenv("OV2_DET_DEBUG"))
+    if (ctx->debug)
         fprintf(stderr, "[ov2 det] select ticks (100MHz): init %llu prologue %llu sweep %llu compaction %llu; cells on the full-scan path: %d\n",
                 so_h->dbg[0], so_h->dbg[1], so_h->dbg[2], so_h->dbg[3], so_h->nslow);
     const int n = so_h->n;

@@ -524,12 +524,11 @@ int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int ma
 // Kernel choice for the reference's window (9): the 3-lanes-per-keypoint kernel needs >= ~3000 wavefronts of
 // 20 keypoints to fill the 1024 SIMDs (offline batch-of-sequences mode); below that -- the single-sequence
 // drop-in case: a few hundred keypoints -- the row-per-lane kernel has 5x more, 4x shorter wavefronts and
-// the lower latency.  OV2_LK_IMPL=row|lane3 forces one of them (A/B measurements).
-static bool lk_use_row_kernel(long long points)
+// the lower latency.  ov2_ctx_set_option(OV2_OPT_LK_IMPL) pins one of them (parity tests, A/B measurements).
+static bool lk_use_row_kernel(const ov2_ctx *ctx, long long points)
 {
-    const char *e = getenv("OV2_LK_IMPL");                 // read per call: the parity tests flip it between calls
-    if (e && !strcmp(e, "row")) return true;
-    if (e && !strcmp(e, "lane3")) return false;
+    if (ctx->lk_impl == OV2_LK_IMPL_ROW) return true;
+    if (ctx->lk_impl == OV2_LK_IMPL_LANE3) return false;
     return points < 65536;
 }
 
@@ -558,7 +557,7 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
         if (int rc = ctx->reserve_stat_slots()) return rc;
         slots = ctx->stat_slots;
     }
-    if (prm.win == 9 && !lk_use_row_kernel((long long)prm.n_max * P.batch)) {
+    if (prm.win == 9 && !lk_use_row_kernel(ctx, (long long)prm.n_max * P.batch)) {
         ov2_launch_fb_klt3(ctx->stream, P, C, prm.max_level, prm.max_iter, prm.eps2, prm.min_eig_th, prm.flags, prm.err_th,
                            prm.fb_dist, prm.do_fb, prm.n_max, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots);
         if (slots) hipLaunchKernelGGL(k_lk_stats_fold, dim3(1), dim3(LK_STAT_SLOTS), 0, ctx->stream, slots, stats_d);
@@ -603,7 +602,7 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
                          const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                         const float *sad_x, float sad_up)
+                         const float *sad_x, float sad_up, int track_impl)
 {
     const PyrDesc &P = prev->d, &C = cur->d;
     OV2_REQUIRE(P.n_levels == C.n_levels && P.batch == 1 && C.batch == 1 && P.win == C.win && win == P.win, OV2_EINVAL,
@@ -613,17 +612,11 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
     const int lf = prm.max_level;                                  // clamped to the pyramid like feature_tracker.cpp:50-52
     const int lp = lvl_prior > P.n_levels - 1 ? P.n_levels - 1 : (lvl_prior < 0 ? 0 : lvl_prior);
     // window 9 (the reference's): the wavefront-per-keypoint kernel (lkw.hip) -- the 81 window pixels over all 64 lanes, the next
-    // level's search block requested while the current level iterates; OV2_TRACK_IMPL=row keeps the row-per-lane kernel (A/B)
-    {
-        const char *e = getenv("OV2_TRACK_IMPL");
-        if (win == 9 && !(e && !strcmp(e, "row")))
-            return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up);
-    }
-    // keypoints per wavefront: 4.  One per wavefront (OV2_TRACK_KPW=1, 16 active lanes) was measured for the single-frame case:
-    // no gain (0.107 vs 0.104 ms per frame, gpurun_out/r3i) -- the frame's latency is every keypoint's own dependent chain of
-    // level visits, not the wait for the slowest of four
-    int kpw = 4;
-    if (const char *e = getenv("OV2_TRACK_KPW")) kpw = e[0] == '1' ? 1 : 4;
+    // level's search block requested while the current level iterates.  Other windows (and OV2_OPT_TRACK_IMPL = ROW): the
+    // row-per-lane kernel, four keypoints per wavefront
+    if (win == 9 && track_impl == OV2_TRACK_IMPL_WAVE)
+        return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up);
+    constexpr int kpw = 4;
     dim3 grid((n_max + kpw - 1) / kpw), block(16 * kpw);
 #define OV2_TK(W) hipLaunchKernelGGL(k_track_klt<W>, grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
                                      (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up)

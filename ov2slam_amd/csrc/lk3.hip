@@ -48,7 +48,7 @@ struct LK3Params {
 #define L3_NBH_R 3                    // (16 - (WIN+1)) / 2
 #define L3_STRIDE 116                 // dwords per keypoint slot: 48 (I) + 64 (J) + 4 pad; 16-byte multiple so that rows move as b128
 
-struct L3Lv { int w, h, img_pitch, pady; long long img_roi; long long til_base; int til_ntx; };      // the level fields this kernel needs (kept in SGPRs)
+struct L3Lv { int w, h, img_pitch, pady; long long img_roi; };      // the level fields this kernel needs (kept in SGPRs)
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -188,53 +188,12 @@ __device__ __forceinline__ void l3_fetch_J_rows(uint32_t *slot, const uint8_t *j
     }
 }
 
-// ---- tiled LK copy (common.hpp: 16 x 8-pixel tiles of 128 B = one cache line) -------------------------------------------
-// A row segment [xa, xa + 20) (xa 4-aligned) lies in two horizontally adjacent tiles: two aligned 16-byte loads (the same
-// row of both tiles) and a dword select by q = ((xa + 16) & 15) / 4 replace the 16 + 4-byte pair of the row-major path.
-// The three lanes of a keypoint fetch rows sub + 3k: neighbouring rows share a tile, so the wavefront's load instruction
-// touches ~2 lines per keypoint instead of 3, and the block of 16 rows 4-6 lines instead of 16-18.
-__device__ __forceinline__ u32x4 l3_pick5(const u32x4 A, const u32x4 B, int q, uint32_t sh)
-{
-    const bool s2 = (q & 2) != 0, s1 = (q & 1) != 0;
-    const uint32_t t0 = s2 ? A.z : A.x, t1 = s2 ? A.w : A.y, t2 = s2 ? B.x : A.z, t3 = s2 ? B.y : A.w, t4 = s2 ? B.z : B.x, t5 = s2 ? B.w : B.y;
-    const uint32_t u0 = s1 ? t1 : t0, u1 = s1 ? t2 : t1, u2 = s1 ? t3 : t2, u3 = s1 ? t4 : t3, u4 = s1 ? t5 : t4;
-    u32x4 o;
-    o.x = __builtin_amdgcn_alignbyte(u1, u0, sh); o.y = __builtin_amdgcn_alignbyte(u2, u1, sh);
-    o.z = __builtin_amdgcn_alignbyte(u3, u2, sh); o.w = __builtin_amdgcn_alignbyte(u4, u3, sh);
-    return o;
-}
-
-template <bool CLAMP>
-__device__ __forceinline__ void l3_fetch_J_rows_tiled(uint32_t *slot, const uint8_t *til, const L3Lv &LJ, int xa, uint32_t sh, int jy0, int sub)
-{
-    const int X = xa + OV2_TIL_PAD, q = (X & 15) >> 2;
-    const uint8_t *col = til + ((long long)(X >> 4) << 7);
-    uint32_t *dst = slot + 48 + 4 * sub;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        if (k < 5 || sub == 0) {                                    // rows sub + 3k < 16
-            int y = jy0 + sub + 3 * k;
-            if (CLAMP) y = y < -LJ.pady ? -LJ.pady : (y > LJ.h + LJ.pady - 1 ? LJ.h + LJ.pady - 1 : y);   // rows beyond the ring are never consumed
-            const int Y = y + OV2_TIL_PAD;
-            const uint8_t *p = col + ((long long)l3_m24(Y >> 3, LJ.til_ntx) << 7) + ((Y & 7) << 4);
-            const u32x4 A = *(const u32x4 *)p, B = *(const u32x4 *)(p + 128);
-            *(u32x4 *)(dst + 12 * k) = l3_pick5(A, B, q, sh);
-        }
-    }
-}
-
-template <bool TILED>
 __device__ __forceinline__ void l3_fetch_J(uint32_t *slot, const uint8_t *jroi, const L3Lv &LJ, int jx0, int jy0, int sub)
 {
     const int xa = jx0 & ~3;
     const uint32_t sh = (uint32_t)(jx0 - xa);
     const bool outside = jy0 < -LJ.pady || jy0 + L3_JROWS - 1 > LJ.h + LJ.pady - 1;
     if (OV2_LK3_KO & 16) return;
-    if (TILED) {                                                     // jroi = item + til_base
-        if (__builtin_amdgcn_ballot_w64(outside) == 0) l3_fetch_J_rows_tiled<false>(slot, jroi, LJ, xa, sh, jy0, sub);
-        else l3_fetch_J_rows_tiled<true>(slot, jroi, LJ, xa, sh, jy0, sub);
-        return;
-    }
     if (__builtin_amdgcn_ballot_w64(outside) == 0) l3_fetch_J_rows<false>(slot, jroi, LJ, xa, sh, jy0, sub);
     else l3_fetch_J_rows<true>(slot, jroi, LJ, xa, sh, jy0, sub);
 }
@@ -256,7 +215,6 @@ struct L3State {
 struct L3Slot { int ax0, ay0, bx0, by0; };
 
 // One pyramid level for the keypoint owned by this 3-lane group; lane `sub` owns window rows 3 sub .. 3 sub + 2.
-template <bool TILED>
 __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, const L3Lv &LI,
                                          const uint8_t *__restrict__ itemJ, const L3Lv &LJ,
                                          const LK3Params &prm, int level, bool scale_from_input, bool reuse,
@@ -290,28 +248,11 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
 
     // ---- stage both neighbourhoods (all global loads of this level are issued here) ----
     l3_lds_sync();                                                  // previous level's reads are done
-    const uint8_t *iroi = itemI + (TILED ? LI.til_base : LI.img_roi), *jroi = itemJ + (TILED ? LJ.til_base : LJ.img_roi);
+    const uint8_t *iroi = itemI + LI.img_roi, *jroi = itemJ + LJ.img_roi;
     // 12 rows, one 16-byte request each, rows sub + 3k from one base pointer (clamp only near the image border)
     auto fetch_I = [&](uint32_t *dst, int ixa) {
         const bool outside = ipy - 1 < -LI.pady || ipy - 1 + L3_IROWS - 1 > LI.h + LI.pady - 1;
         const bool clamp_rows = __builtin_amdgcn_ballot_w64(outside) != 0;
-        if (TILED) {
-            // 16 bytes from the 4-aligned column ixa: dwords q .. q + 3 of the two tile rows (the right-hand tile only when q != 0)
-            const int X = ixa + OV2_TIL_PAD, q = (X & 15) >> 2;
-            const uint8_t *col = iroi + ((long long)(X >> 4) << 7);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int y = ipy - 1 + sub + 3 * k;
-                if (clamp_rows) y = y < -LI.pady ? -LI.pady : (y > LI.h + LI.pady - 1 ? LI.h + LI.pady - 1 : y);
-                const int Y = y + OV2_TIL_PAD;
-                const uint8_t *p = col + ((long long)l3_m24(Y >> 3, LI.til_ntx) << 7) + ((Y & 7) << 4);
-                const u32x4 A = *(const u32x4 *)p;
-                u32x4 B = {0u, 0u, 0u, 0u};
-                if (q != 0) B = *(const u32x4 *)(p + 128);
-                *(u32x4 *)(dst + 4 * sub + 12 * k) = l3_pick5(A, B, q, 0u);
-            }
-            return;
-        }
         const uint8_t *p0 = iroi + (long long)(ipy - 1 + sub) * LI.img_pitch + ixa;
         const long long step = 3LL * LI.img_pitch;
 #pragma unroll
@@ -339,7 +280,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         const int cx0 = l3_floor(fminf(fmaxf(sx, (float)(-WIN)), (float)(LJ.w - 1)));
         const int cy0 = l3_floor(fminf(fmaxf(sy, (float)(-WIN)), (float)(LJ.h - 1)));
         jx0 = cx0 - L3_NBH_R; jy0 = cy0 - L3_NBH_R; jb = 48;
-        l3_fetch_J<TILED>(slot, jroi, LJ, jx0, jy0, sub);
+        l3_fetch_J(slot, jroi, LJ, jx0, jy0, sub);
     } else {
         // Backward level 0 straight after forward level 0: the two images swap roles and the slot already holds
         // them.  Region B (search block of the forward level, around the tracked position) contains the
@@ -494,7 +435,7 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                 if ((unsigned)ox > (unsigned)(2 * L3_NBH_R) || (unsigned)oy > (jb ? (unsigned)(2 * L3_NBH_R) : (unsigned)(L3_IROWS - L3_WIN - 1))) {
                     jx0 = inx - L3_NBH_R; jy0 = iny - L3_NBH_R; jb = 48;       // drifted: re-centre the block (always into region B)
                     l3_lds_sync();
-                    l3_fetch_J<TILED>(slot, jroi, LJ, jx0, jy0, sub);
+                    l3_fetch_J(slot, jroi, LJ, jx0, jy0, sub);
                     l3_lds_sync();
                     ox = L3_NBH_R; oy = L3_NBH_R;
                 }
@@ -544,7 +485,6 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
     sl.bx0 = jx0; sl.by0 = jy0;
 }
 
-template <bool TILED>
 __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(PyrDesc P, PyrDesc C, LK3Params prm, int nbx,
                                                  const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                  uint8_t *__restrict__ status, float *__restrict__ err_out,
@@ -610,10 +550,8 @@ __global__ __launch_bounds__(64 * L3_WAVES, L3_MIN_WAVES_PER_EU) void k_fb_klt3(
                 LI.pady = bwd ? c.pady : a.pady; LI.img_roi = bwd ? c.img_roi : a.img_roi;
                 LJ.w = bwd ? a.w : c.w; LJ.h = bwd ? a.h : c.h; LJ.img_pitch = bwd ? a.img_pitch : c.img_pitch;
                 LJ.pady = bwd ? a.pady : c.pady; LJ.img_roi = bwd ? a.img_roi : c.img_roi;
-                LI.til_base = bwd ? c.til_base : a.til_base; LI.til_ntx = bwd ? c.til_ntx : a.til_ntx;
-                LJ.til_base = bwd ? a.til_base : c.til_base; LJ.til_ntx = bwd ? a.til_ntx : c.til_ntx;
             }
-            l3_level<TILED>(itemI, LI, itemJ, LJ, prm, level, top, bwd, bwd ? fx : kp.x, bwd ? fy : kp.y, sub, slot, st, sl);
+            l3_level(itemI, LI, itemJ, LJ, prm, level, top, bwd, bwd ? fx : kp.x, bwd ? fy : kp.y, sub, slot, st, sl);
         }
         if (prm.do_fb) {
             if (ok) {
@@ -657,10 +595,6 @@ int ov2_launch_fb_klt3(hipStream_t s, const PyrDesc &P, const PyrDesc &C, int ma
     prm.err_th = err_th; prm.fb_dist = fb_dist; prm.do_fb = do_fb; prm.n_max = n_max;
     const int nbx = (n_max + L3_KPB - 1) / L3_KPB;
     dim3 grid(nbx * P.batch);
-    // both pyramids carry the tiled LK copy (batch pyramids do): fetch from it -- 3x fewer cache-line fills per level visit
-    const char *e = getenv("OV2_LK3_TILED");                // 0: row-major fetch even when the tiled copy exists (A/B runs)
-    const bool tiled = P.tiled && C.tiled && !(e && e[0] == '0');
-    if (tiled) hipLaunchKernelGGL(k_fb_klt3<true>, grid, dim3(64 * L3_WAVES), 0, s, P, C, prm, nbx, kps, priors, status, err, iters, n_per_item, stats);
-    else hipLaunchKernelGGL(k_fb_klt3<false>, grid, dim3(64 * L3_WAVES), 0, s, P, C, prm, nbx, kps, priors, status, err, iters, n_per_item, stats);
+    hipLaunchKernelGGL(k_fb_klt3, grid, dim3(64 * L3_WAVES), 0, s, P, C, prm, nbx, kps, priors, status, err, iters, n_per_item, stats);
     return 0;
 }

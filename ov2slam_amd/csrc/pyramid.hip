@@ -141,9 +141,8 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
                 const int xx = x + 4 * hx;
                 const uint32_t v = tile[4 * ty + 2 + rr][2 * tx + 1 + hx];
                 uint8_t *d = roi + yy * L.img_pitch + xx;
-                uint8_t *dt = P.tiled ? item + ov2_til_offset(L, xx, yy) : nullptr;       // the same dword in the tiled LK copy
-                if (xx + 3 < L.w) { *(uint32_t *)d = v; if (P.tiled) *(uint32_t *)dt = v; }
-                else for (int j = 0; j < 4 && xx + j < L.w; j++) { d[j] = (uint8_t)(v >> (8 * j)); if (P.tiled) dt[j] = (uint8_t)(v >> (8 * j)); }
+                if (xx + 3 < L.w) *(uint32_t *)d = v;
+                else for (int j = 0; j < 4 && xx + j < L.w; j++) d[j] = (uint8_t)(v >> (8 * j));
             }
         }
     }
@@ -184,11 +183,6 @@ __global__ __launch_bounds__(256) void k_pyr_level(PyrDesc P, int level, const u
             if (FUSE_BORDER) otile[2 * ty + oy][tx] = out;
             if ((PYR_KO & 2) && out != 0x12345678u) continue;
             uint8_t *d = nroi + (Y + oy) * N.img_pitch + X;                         // X % 4 == 0, ROI origin 16-byte aligned
-            if (P.tiled) {                                                          // interior of the tiled LK copy (its ring: k_pyr_tile_ring)
-                uint8_t *dt = item + ov2_til_offset(N, X, Y + oy);
-                if (X + 3 < N.w) *(uint32_t *)dt = out;
-                else for (int j = 0; j < 4 && X + j < N.w; j++) dt[j] = (uint8_t)(out >> (8 * j));
-            }
             if (X + 3 < N.w) {
                 *(uint32_t *)d = out;
                 if (FUSE_BORDER) {
@@ -277,37 +271,6 @@ __global__ __launch_bounds__(256) void k_pyr_border(PyrDesc P, int level)
     *(uint32_t *)(roi + yt * L.img_pitch + c0) = v;
 }
 
-// ---- padding ring of the tiled LK copy: thread per DWORD, all levels in one launch (blockIdx.y = level) --------
-// The producers (k_clahe_apply, k_pyr_level) write the image interior of the tiled copy next to their row-major stores;
-// the REFLECT_101 ring around it (win pixels) is copied here from the finished row-major border -- 6 % of the pixels.
-// Dwords: rows [-win, 0) and [h, h + win) over columns [-PB_LEFT, wend); rows [0, h) over [-PB_LEFT, 0) and [w & ~3, wend).
-__global__ __launch_bounds__(256) void k_pyr_tile_ring(PyrDesc P)
-{
-    const int level = blockIdx.y;
-    const PyrLevelDesc L = P.lv[level];
-    const int win = P.win, PB_LEFT = (P.win + 3) & ~3;
-    const int wend = (L.w + win + 3) & ~3;
-    const int ndw_row = (PB_LEFT + wend) >> 2;
-    const int rbeg = L.w & ~3, ndw_r = (wend - rbeg) >> 2, ndw_lr = PB_LEFT / 4 + ndw_r;
-    const int n_tb = 2 * win * ndw_row, n_lr = L.h * ndw_lr;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_tb + n_lr) return;
-    int yt, c0;
-    if (e < n_tb) {
-        const int row = e / ndw_row;
-        c0 = (e - row * ndw_row) * 4 - PB_LEFT;
-        yt = row < win ? row - win : L.h + (row - win);
-    } else {
-        const int f = e - n_tb;
-        yt = f / ndw_lr;
-        const int d = f - yt * ndw_lr;
-        c0 = d < PB_LEFT / 4 ? 4 * d - PB_LEFT : rbeg + 4 * (d - PB_LEFT / 4);
-    }
-    uint8_t *item = P.base + (long long)blockIdx.z * P.item_stride;
-    const uint32_t v = *(const uint32_t *)(item + L.img_roi + (long long)yt * L.img_pitch + c0);
-    *(uint32_t *)(item + ov2_til_offset(L, c0, yt)) = v;
-}
-
 // ---- Scharr derivative of one level of one item, on demand (ov2_pyr_download only) -----------
 __global__ __launch_bounds__(256) void k_scharr_level(PyrDesc P, int level, int b, uint32_t *__restrict__ out)
 {
@@ -354,13 +317,6 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
         }
         if (has_next && !fuse) border(l + 1);        // level l+1 was just produced
     }
-    if (P.tiled) {
-        // every row-major border is complete now: copy the rings into the tiled LK copy (largest level sizes the grid)
-        const PyrLevelDesc &L0 = P.lv[0];
-        const int wend = (L0.w + P.win + 3) & ~3, PB_LEFT = (P.win + 3) & ~3;
-        const int n = 2 * P.win * ((PB_LEFT + wend) >> 2) + L0.h * (PB_LEFT / 4 + ((wend - (L0.w & ~3)) >> 2));
-        hipLaunchKernelGGL(k_pyr_tile_ring, dim3((n + 255) / 256, P.n_levels, P.batch), dim3(256), 0, ctx->stream, P);
-    }
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }
@@ -398,12 +354,6 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
     PyrDesc &D = p->d;
     memset(&D, 0, sizeof(D));
     D.win = win; D.batch = batch;
-    // Tiled LK copy: OFF by default.  Measured (gpurun_out/r2f, 4096 sequences): with it k_fb_klt3 fetches 3x fewer cache lines
-    // per level visit but gets only 2.9 % faster (1.839 -> 1.786 ms per step) -- the kernel is bound by the latency of its
-    // dependent phases at 3 waves per SIMD, not by line fills -- while the scattered dword stores of the second copy cost the
-    // pre-processing kernels +1.5 ms per step.  OV2_PYR_TILED=1 builds it (A/B runs, parity tests of the path).
-    D.tiled = 0;
-    if (const char *e = getenv("OV2_PYR_TILED")) D.tiled = (e[0] == '1' && win == 9) ? 1 : 0;
     long long off = 0;
     int lw = w, lh = h;
     for (int l = 0; l <= max_level; l++) {
@@ -417,14 +367,6 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
         off = round_up(off, 256);
         L.img_roi = off + (long long)L.pady * L.img_pitch + L.img_padx;
         off += img_bytes;
-        L.til_base = -1; L.til_ntx = L.til_nty = 0;
-        if (D.tiled) {
-            // columns -16 .. w + 31 (block fetches read two whole tile columns from a 4-aligned x <= w - 2), rows -16 .. h + 8 + 7
-            L.til_ntx = lw / 16 + 3; L.til_nty = (lh + 24) / 8 + 1;
-            off = round_up(off, 256);
-            L.til_base = off;
-            off += (long long)L.til_ntx * L.til_nty * 128;
-        }
         D.n_levels = l + 1;
         lw = (lw + 1) / 2; lh = (lh + 1) / 2;
         if (lw <= win || lh <= win) break;     // buildOpticalFlowPyramid stops early
@@ -536,30 +478,6 @@ int ov2_pyr_download(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *
 int ov2_pyr_download_padded(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h, int16_t *deriv_h)
 {
     return pyr_download_impl(ctx, p, b, level, img_h, deriv_h, 1);
-}
-
-int ov2_pyr_tiled(const ov2_pyr *p) { return p && p->d.tiled ? 1 : 0; }
-
-// the padded level ((w + 2 win) x (h + 2 win), like ov2_pyr_download_padded) read back from the TILED LK copy: the raw tiles
-// are copied to the host and un-tiled there (test / debug entry; the kernels never need it)
-int ov2_pyr_download_tiled(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img_h)
-{
-    OV2_REQUIRE(ctx && p && img_h, OV2_EINVAL, "NULL argument");
-    OV2_REQUIRE(level >= 0 && level < p->d.n_levels && b >= 0 && b < p->d.batch, OV2_EINVAL, "bad level/batch index");
-    OV2_REQUIRE(p->d.tiled, OV2_EINVAL, "this pyramid has no tiled copy");
-    OV2_HIP_CHECK(hipSetDevice(ctx->device));
-    if (int rcw = ov2_pyr_wait_ready(ctx, p)) return rcw;
-    const PyrLevelDesc &L = p->d.lv[level];
-    const size_t bytes = (size_t)L.til_ntx * L.til_nty * 128;
-    std::vector<uint8_t> raw(bytes);
-    OV2_HIP_CHECK(hipMemcpyAsync(raw.data(), p->d.base + (long long)b * p->d.item_stride + L.til_base, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int pad = p->d.win, ow = L.w + 2 * pad;
-    PyrLevelDesc L0 = L;
-    L0.til_base = 0;
-    for (int y = -pad; y < L.h + pad; y++)
-        for (int x = -pad; x < L.w + pad; x++) img_h[(size_t)(y + pad) * ow + (x + pad)] = raw[(size_t)ov2_til_offset(L0, x, y)];
-    return OV2_OK;
 }
 
 size_t ov2_pyr_algorithmic_bytes(const ov2_pyr *p)

@@ -281,7 +281,7 @@ int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
         sad_d = (const float *)(ds + o_s);
     }
     rc = ov2_launch_track_klt(ctx->stream, left, right, nklt_win_size, 1, lvl, max_iter, eps, nklt_err, fmax_fbklt_dist, n, nullptr,
-                              (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr, sad_d, up);
+                              (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr, sad_d, up, ctx->track_impl);
     if (rc != OV2_OK) return rc;
     hipLaunchKernelGGL(k_epipolar_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_u),
                        (float2 *)(ds + o_o), n, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok);

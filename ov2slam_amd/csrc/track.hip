@@ -48,8 +48,7 @@ static int enqueue_preprocess(ov2_tracker *t, ov2_pyr *dst)
     if (c.use_clahe) {
         const PyrLevelDesc &L0 = dst->d.lv[0];
         int rc = ov2_launch_clahe(ctx, t->dimg, c.w, c.h, (int)t->img_pitch, 0, 1, c.clahe_clip, c.tiles_x, c.tiles_y,
-                                  dst->d.base + L0.img_roi, L0.img_pitch, (size_t)dst->d.item_stride, t->lut, dst->d.win,
-                                  dst->d.tiled ? L0.til_base - L0.img_roi : 0, L0.til_ntx);
+                                  dst->d.base + L0.img_roi, L0.img_pitch, (size_t)dst->d.item_stride, t->lut, dst->d.win);
         if (rc != OV2_OK) return rc;
         return ov2_launch_pyr_build(ctx, dst, nullptr, 0, 0);
     }
@@ -66,7 +65,7 @@ static int enqueue_klt(ov2_tracker *t, const ov2_pyr *prev, const ov2_pyr *cur)
     int rc = ov2_launch_track_klt(ctx->stream, prev, cur, c.win, c.prior_pyr_lvl, c.nklt_pyr_lvl, c.max_iter, c.eps, c.err_th,
                                   c.fb_dist, c.n_max, (const int *)(k + t->o_n), (const float *)(k + t->o_kps),
                                   (const float *)(k + t->o_pri), k + t->o_flg, (float *)(k + t->o_out),
-                                  k + t->o_st, (int *)(k + t->o_it));
+                                  k + t->o_st, (int *)(k + t->o_it), nullptr, 0.f, ctx->track_impl);
     if (rc != OV2_OK) return rc;
     if (t->has_calib) {
         rc = ov2_launch_compute_keypoints(ctx->stream, t->calib, (const float *)(k + t->o_out), c.n_max, (const int *)(k + t->o_n),
@@ -232,8 +231,7 @@ int ov2_tracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, ov2_tracker 
     memset(t->himg, 0, t->img_bytes + 256);
     memset(t->hblk, 0, t->blk_bytes);
     t->kblk = t->dblk;
-    const char *zc = getenv("OV2_TRACK_ZC");                         // A/B switch, read once per tracker
-    if (!zc || strcmp(zc, "0") != 0) {
+    {   // kernels read / write the pinned block through its device alias (no staging copies); the device block is the fallback
         void *alias = nullptr;
         if (hipHostGetDevicePointer(&alias, t->hblk, 0) == hipSuccess && alias) { t->kblk = (uint8_t *)alias; t->zero_copy = true; }
         else (void)hipGetLastError();

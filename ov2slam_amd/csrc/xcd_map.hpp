@@ -11,7 +11,7 @@
 // batch >= 1 (checked exhaustively for small sizes by the test).
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define OV2_XCD_HD __host__ __device__ __forceinline__
 #else
 #define OV2_XCD_HD static inline

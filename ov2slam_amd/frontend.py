@@ -46,6 +46,29 @@ class Context:
         """ov2_ctx_set_option, e.g. (L.OV2_OPT_SOBEL_DY_ORDER, L.OV2_SOBEL_DY_EXACT_SUM)."""
         L.check(self.lib.ov2_ctx_set_option(self.h, int(option), int(value)))
 
+    def get_option(self, option):
+        v = C.c_int(0)
+        L.check(self.lib.ov2_ctx_get_option(self.h, int(option), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """Context manager: pin kernel paths for a block (tests, A/B runs), e.g. ctx.options(lk_impl=L.OV2_LK_IMPL_LANE3);
+        names are the OV2_OPT_* suffixes in lower case.  The previous values come back on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            ids = {k: getattr(L, "OV2_OPT_" + k.upper()) for k in kw}
+            old = {k: self.get_option(ids[k]) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(ids[k], v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(ids[k], v)
+        return _cm()
+
     @property
     def stream(self):
         return self.lib.ov2_ctx_stream(self.h)
@@ -126,17 +149,6 @@ class Pyramid:
         fn = self.lib.ov2_pyr_download_padded if padded else self.lib.ov2_pyr_download
         L.check(fn(self.ctx.h, self.h_pyr, b, level, _ptr(img), _ptr(der)))
         return img, der
-
-    @property
-    def tiled(self):
-        return bool(self.lib.ov2_pyr_tiled(self.h_pyr))
-
-    def download_tiled(self, level, b=0):
-        """the padded level image read back from the tiled LK copy (must equal download(level, padded=True)[0])"""
-        w, h = self.level_size(level)
-        img = np.empty((h + 2 * self.win, w + 2 * self.win), np.uint8)
-        L.check(self.lib.ov2_pyr_download_tiled(self.ctx.h, self.h_pyr, b, level, _ptr(img)))
-        return img
 
     @property
     def algorithmic_bytes(self):

@@ -95,13 +95,18 @@ struct LocalBAResult {
 class Optimizer {
 public:
     Optimizer(double robust_mono_th, bool apply_l2_after_robust) : robust_mono_th_(robust_mono_th), apply_l2_after_robust_(apply_l2_after_robust) {}
-    void signalStopLocalBA() { bstop_localba_ = true; }     // optimizer.hpp:48
-    bool stopLocalBA() const { return bstop_localba_; }     // optimizer.hpp:49
+    void signalStopLocalBA() { bstop_localba_ = 1; }        // optimizer.hpp:48 (called by the estimator thread while localBA runs)
+    bool stopLocalBA() const { return bstop_localba_ != 0; } // optimizer.hpp:49
+    // Ceres' max_solver_time_in_seconds of the first pass: the reference sets 0.2 s, doubled unless force_realtime
+    // (src/optimizer.cpp:463-467), and halves it for the L2 pass (:612).  0 (default) = no limit.
+    void setMaxSolverTime(double pass1_seconds) { max_solver_time_s_ = pass1_seconds; }
 
     // Optimizer::localBA's solve stage (src/optimizer.cpp:436-735) as ONE library call: the problem stays in HBM between the
     // robust and the L2 pass, outlier tests and block removal run on the device (ov2_local_ba).  want_chi2: also download the
     // per-block chi2err_ / isdepthpositive_ values (the reference's write-back only needs bad_obs).
-    LocalBAResult solveLocalBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost, bool want_chi2 = false) const
+    // The stop flag is handed over LIVE (ov2_local_ba_options::stop_flag): the library reads it after pass 1, where the
+    // reference evaluates !stopLocalBA() (:603-604), and it is cleared when the call is over (:896).
+    LocalBAResult solveLocalBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost, bool want_chi2 = false)
     {
         LocalBAResult R;
         const size_t n_res = fp.res_type.size();
@@ -110,13 +115,17 @@ public:
         if (want_chi2) { R.chi2.assign(n_res, 0.0); R.depthpos.assign(n_res, 1); }
         ov2_local_ba_options opt; ov2_local_ba_default_options(&opt);
         opt.robust_mono_th = robust_mono_th_; opt.use_robust_cost = buse_robust_cost ? 1 : 0;
-        opt.apply_l2_after_robust = apply_l2_after_robust_ ? 1 : 0; opt.stop_requested = stopLocalBA() ? 1 : 0;
+        opt.apply_l2_after_robust = apply_l2_after_robust_ ? 1 : 0; opt.stop_requested = 0; opt.stop_flag = &bstop_localba_;
+        opt.pass1.max_solver_time_s = max_solver_time_s_; opt.pass2.max_solver_time_s = 0.5 * max_solver_time_s_;
         ov2_local_ba_result res{};
         res.poses_out = R.poses.data(); res.invdepth_out = R.invdepth.data(); res.bad_obs = R.bad_obs.data();
         if (want_chi2) { res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data(); }
         ov2_ba_problem p = fp.view(nullptr);
-        if ((R.error_code = ov2_local_ba(ctx.get(), &p, &opt, &res)) != OV2_OK) { R.error = ov2_last_error(); return R; }       // BA skipped: caller logs R.error
+        R.error_code = ov2_local_ba(ctx.get(), &p, &opt, &res);
+        bstop_localba_ = 0;                                                                                                      // :896
+        if (R.error_code != OV2_OK) { R.error = ov2_last_error(); return R; }       // BA skipped: caller logs R.error
         R.ok = true; R.l2_done = res.l2_done != 0;
+        if (res.pass2_error != OV2_OK) { R.error_code = res.pass2_error; R.error = ov2_last_error(); }     // pass 1's result is valid and kept
         for (int i = 0; i < 2; i++) { R.iterations[i] = res.iterations[i]; R.solve_ms[i] = res.solve_ms[i]; }
         return R;
     }
@@ -241,7 +250,8 @@ private:
 
     double robust_mono_th_;
     bool apply_l2_after_robust_;
-    bool bstop_localba_ = false;
+    volatile int bstop_localba_ = 0;
+    double max_solver_time_s_ = 0.0;
 };
 
 }  // namespace ov2

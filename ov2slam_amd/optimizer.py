@@ -203,13 +203,19 @@ class Optimizer:
         self.robust_mono_th = float(robust_mono_th)
         self.apply_l2_after_robust = bool(apply_l2_after_robust)
         self._solver = solver
-        self._stop = False
+        # Optimizer::bstop_localba_ (include/optimizer.hpp:64): raised by the estimator thread while a localBA runs; the
+        # library reads this very int between the two passes (ov2_local_ba_options::stop_flag), like the reference's
+        # !stopLocalBA() after its first ceres::Solve (src/optimizer.cpp:603-604)
+        self._stop_flag = C.c_int(0)
+        # Ceres' max_solver_time_in_seconds of pass 1: the reference uses 0.2 s, 0.4 s unless force_realtime (:463-467), and
+        # half of it for the L2 pass (:612).  0 = no limit (default: results independent of machine load)
+        self.max_solver_time_s = 0.0
 
     def signalStopLocalBA(self):          # optimizer.hpp:48
-        self._stop = True
+        self._stop_flag.value = 1
 
     def stopLocalBA(self):                # optimizer.hpp:49
-        return self._stop
+        return bool(self._stop_flag.value)
 
     def _solve(self, prob, res_active, chi2_init, depthpos_init, **opt_kw):
         if self._solver is not None:
@@ -235,7 +241,9 @@ class Optimizer:
         O = L.LocalBAOptions()
         lib.ov2_local_ba_default_options(C.byref(O))
         O.robust_mono_th = self.robust_mono_th; O.use_robust_cost = int(bool(buse_robust_cost))
-        O.apply_l2_after_robust = int(self.apply_l2_after_robust); O.stop_requested = int(self.stopLocalBA())
+        O.apply_l2_after_robust = int(self.apply_l2_after_robust); O.stop_requested = 0
+        O.stop_flag = C.pointer(self._stop_flag)                                  # the LIVE flag, polled after pass 1
+        O.pass1.max_solver_time_s = self.max_solver_time_s; O.pass2.max_solver_time_s = 0.5 * self.max_solver_time_s
         n_res = P.n_res
         poses = np.zeros((P.n_kf, 7)); lam = np.zeros(max(1, P.n_lm))
         bad = np.zeros(max(1, n_res), np.uint8); bad1 = np.zeros(max(1, n_res), np.uint8)
@@ -245,9 +253,12 @@ class Optimizer:
         if want_chi2:
             chi2 = np.full(max(1, n_res), np.nan); dpos = np.zeros(max(1, n_res), np.uint8)
             R.chi2_last_eval = _dp(chi2); R.depthpos_last_eval = _u8p(dpos)
-        L.check(lib.ov2_local_ba(self.ctx.h, C.byref(P), C.byref(O), C.byref(R)))
+        try:
+            L.check(lib.ov2_local_ba(self.ctx.h, C.byref(P), C.byref(O), C.byref(R)))
+        finally:
+            self._stop_flag.value = 0                                             # src/optimizer.cpp:896
         out = dict(poses=poses, invdepth=lam[:P.n_lm], bad_obs=bad[:n_res].astype(bool), bad_after_pass1=bad1[:n_res].astype(bool),
-                   l2_done=bool(R.l2_done), iterations=(R.iterations[0], R.iterations[1]),
+                   l2_done=bool(R.l2_done), pass2_error=int(R.pass2_error), iterations=(R.iterations[0], R.iterations[1]),
                    num_successful_steps=(R.num_successful_steps[0], R.num_successful_steps[1]), termination=(R.termination[0], R.termination[1]),
                    initial_cost=(R.initial_cost[0], R.initial_cost[1]), final_cost=(R.final_cost[0], R.final_cost[1]),
                    solve_ms=(R.solve_ms[0], R.solve_ms[1]))

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libov2slam_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
-    assert lib.ov2_version() == _lib.OV2_ABI_VERSION == 300
+    assert lib.ov2_version() == _lib.OV2_ABI_VERSION == 400
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -59,3 +59,18 @@ def test_library_path_override_and_missing_library_fail_loudly(tmp_path):
     missing = str(tmp_path / "nope.so")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OV2SLAM_HIP_LIB=missing), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "ImportError" in r.stderr and "no CPU fallback" in r.stderr.replace("\n", " "), r.stderr
+
+
+def test_library_reads_the_environment_only_at_context_creation():
+    """The entry points run on several threads of a host process that may call setenv concurrently (a ROS node): kernel-path
+    switches are per-context options (ov2_ctx_set_option), and the only getenv of the product sits in ov2_ctx_create (OV2_DEBUG)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = []
+    for f in sorted(glob.glob(os.path.join(root, "ov2slam_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "ov2slam_amd", "host", "*.hpp"))):
+        for i, line in enumerate(open(f), 1):
+            if re.search(r"\bgetenv\s*\(", line):
+                hits.append((os.path.basename(f), i))
+    assert [h[0] for h in hits] == ["ctx.hip"], hits
+    assert "__CUDACC__" not in open(os.path.join(root, "ov2slam_amd", "csrc", "xcd_map.hpp")).read()

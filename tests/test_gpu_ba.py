@@ -247,25 +247,24 @@ def test_long_budget_stops_enqueuing_after_convergence(gpu_ctx, oracle):
     assert np.allclose(g2["poses"], g["poses"], atol=1e-12)
 
 
-def test_large_problem_path_matches_oracle(gpu_ctx, oracle, monkeypatch):
+def test_large_problem_path_matches_oracle(gpu_ctx, oracle):
     """More optimised keyframes than the LDS-resident reduced system holds (~95): the sparse-W / HBM-Cholesky path (BADev::big)
     takes over -- a loop-closure fullBA is the realistic case.  It must follow the oracle like the small path does; it is also
-    forced onto small problems (OV2_BA_BIG=1) so that both paths are compared on the same inputs."""
+    forced onto small problems (OV2_OPT_BA_FORCE_LARGE) so that both paths are compared on the same inputs."""
     pb = synth.make_ba_problem(120, 1500, 8, stereo=True, seed=1)
     g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, max_iter=6))
     r = oracle.ba_solve(pb, oracle.ba_default_options(max_iter=6))
     _cmp(g, r, pb)
     assert g["final_cost"] < 0.5 * g["initial_cost"]
-    monkeypatch.setenv("OV2_BA_BIG", "1")
-    for n_kf, n_lm, obs, stereo, seed in ((6, 40, 4, False, 1), (12, 400, 8, True, 3), (40, 1200, 20, False, 5)):
-        pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
-        for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
-            g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
-            r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
-            _cmp(g, r, pb)
-    pb = synth.make_ba_problem(15, 800, 8, stereo=True, seed=7)               # the whole localBA protocol on the big path
-    g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
-    monkeypatch.delenv("OV2_BA_BIG")
+    with gpu_ctx.options(ba_force_large=1):
+        for n_kf, n_lm, obs, stereo, seed in ((6, 40, 4, False, 1), (12, 400, 8, True, 3), (40, 1200, 20, False, 5)):
+            pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
+            for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
+                g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+                r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
+                _cmp(g, r, pb)
+        pb = synth.make_ba_problem(15, 800, 8, stereo=True, seed=7)               # the whole localBA protocol on the big path
+        g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
     s = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
     assert np.array_equal(g["bad_obs"], s["bad_obs"]) and np.allclose(g["poses"], s["poses"], atol=1e-9)
 
@@ -287,26 +286,33 @@ def _mixed_with_pnp(pb, pn, kf):
     return mix
 
 
-def test_large_problem_path_variants(gpu_ctx, oracle, monkeypatch):
+def test_large_problem_path_variants(gpu_ctx, oracle):
     """Round 3 extensions of the large-problem path, each forced onto small problems so that the oracle stays cheap:
-    pose-only (OV2_RES_PNP) blocks on the sparse-W path, the lineariser without LDS pre-aggregation of the observer blocks (what
-    runs beyond ~570 optimised keyframes) and the column-chunked sparse Schur complement (beyond 341 keyframes)."""
-    monkeypatch.setenv("OV2_BA_BIG", "1")
+    pose-only (OV2_RES_PNP) blocks on the sparse-W path -- mixed with landmarks AND alone (round 4: the path's accumulators are
+    cleared by k_ba_zero_lin whenever anything is linearised) --, the lineariser without LDS pre-aggregation of the observer blocks
+    (what runs beyond ~570 optimised keyframes) and the column-chunked sparse Schur complement (beyond 341 keyframes)."""
     mix = _mixed_with_pnp(synth.make_ba_problem(8, 200, 5, stereo=True, seed=12), synth.make_pnp_problem(60, seed=4), 3)
-    _cmp(optimizer.solve(gpu_ctx, mix), oracle.ba_solve(mix), mix)
+    pnp = synth.make_pnp_problem(120, seed=9)
     cases = ((12, 400, 8, True, 3), (40, 1200, 20, False, 5))
-    for env in (dict(OV2_BA_LIN_DIRECT="1"), dict(OV2_BA_SCHUR_CHUNK="36"), dict(OV2_BA_LIN_DIRECT="1", OV2_BA_SCHUR_CHUNK="96")):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        for n_kf, n_lm, obs, stereo, seed in cases:
-            pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
-            for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
-                g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
-                r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
-                _cmp(g, r, pb)
+    with gpu_ctx.options(ba_force_large=1):
         _cmp(optimizer.solve(gpu_ctx, mix), oracle.ba_solve(mix), mix)
-        for k in env:
-            monkeypatch.delenv(k)
+        # pose-only blocks ALONE on the large path, through the multi-kernel loop (several re-linearisations of H and F^T b)
+        with gpu_ctx.options(ba_pose_only_fused=0):
+            for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
+                g = optimizer.solve(gpu_ctx, pnp, optimizer.default_options(gpu_ctx.lib, **kw))
+                r = oracle.ba_solve(pnp, oracle.ba_default_options(**kw))
+                assert g["iterations"] == r["iterations"] >= 2 and g["termination"] == r["termination"]
+                assert np.allclose(g["poses"], r["poses"], rtol=0, atol=1e-7 * max(1.0, np.abs(r["poses"]).max()))
+        for opts in (dict(ba_lin_direct=1), dict(ba_schur_chunk=36), dict(ba_lin_direct=1, ba_schur_chunk=96)):
+            with gpu_ctx.options(**opts):
+                for n_kf, n_lm, obs, stereo, seed in cases:
+                    pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
+                    for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
+                        g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
+                        r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
+                        _cmp(g, r, pb)
+                _cmp(optimizer.solve(gpu_ctx, mix), oracle.ba_solve(mix), mix)
+    assert gpu_ctx.get_option(ov2slam_amd._lib.OV2_OPT_BA_FORCE_LARGE) == 0
 
 
 def test_more_than_341_keyframes_match_oracle(gpu_ctx, oracle):
@@ -345,20 +351,3 @@ def test_max_solver_time_stops_between_chunks(gpu_ctx, oracle):
     assert cut["final_cost"] <= cut["initial_cost"] and full["final_cost"] <= cut["final_cost"]
 
 
-def test_multi_workgroup_cholesky_matches_oracle(gpu_ctx, oracle, monkeypatch):
-    """k_ba_cholesky_mw (opt-in, OV2_BA_CHOL_MW=1): one work-group per 32-column block of the reduced system, hand-over through
-    generation-stamped flags, look-ahead by construction.  Same results as the one-work-group kernel; slower on this part (measured:
-    DESIGN.md 4.4), hence off by default -- this keeps it honest."""
-    monkeypatch.setenv("OV2_BA_CHOL_MW", "1")
-    for xcd in ("0", "1"):
-        monkeypatch.setenv("OV2_BA_CHOL_XCD", xcd)
-        for n_kf, n_lm, obs, stereo, seed in ((12, 400, 8, True, 3), (25, 3000, 12, True, 4), (50, 2000, 30, False, 5), (60, 1500, 10, True, 6)):
-            pb = synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed)
-            for kw in (dict(), dict(max_iter=10, huber_delta=-1.0)):
-                g = optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, **kw))
-                r = oracle.ba_solve(pb, oracle.ba_default_options(**kw))
-                _cmp(g, r, pb)
-    g = ov2slam_amd.Optimizer(gpu_ctx).localBA(synth.make_ba_problem(15, 800, 8, stereo=True, seed=7))
-    monkeypatch.delenv("OV2_BA_CHOL_MW")
-    s = ov2slam_amd.Optimizer(gpu_ctx).localBA(synth.make_ba_problem(15, 800, 8, stereo=True, seed=7))
-    assert np.array_equal(g["bad_obs"], s["bad_obs"]) and np.allclose(g["poses"], s["poses"], atol=1e-9)

@@ -55,14 +55,13 @@ for b in range(3):
         assert np.array_equal(a, c), (b, lvl)
         assert np.array_equal(pf.download(lvl, b, padded=True)[0], ref.level(lvl, padded=True)[0]), (b, lvl)
 # the same through the strip kernel (what a large batch selects by itself: apply + level 1 + borders in one walk)
-import os
-os.environ["OV2_CLAHE_STRIPS"] = "1"
+ctx.set_option(L.OV2_OPT_CLAHE_STRIPS, 1)
 pq = ov2slam_amd.Pyramid(ctx, 752, 480, 9, 3, batch=3).build_clahe_from_device(src.data_ptr(), 3.0, 15, 9)
 ctx.sync()
 for b in range(3):
     for lvl in range(pq.levels):
         assert np.array_equal(pq.download(lvl, b, padded=True)[0], pf.download(lvl, b, padded=True)[0]), ("strips", b, lvl)
-del os.environ["OV2_CLAHE_STRIPS"]
+ctx.set_option(L.OV2_OPT_CLAHE_STRIPS, -1)
 # images whose rows are NOT 4-byte aligned (KITTI: 1241-byte rows; 103x57) through the device entry points: this is the
 # only way to reach the unaligned-source kernel instances (the host entry points stage with an aligned pitch)
 for (w, h), tiles in (((1241, 376), (24, 7)), ((103, 57), (3, 2)), ((751, 97), (15, 2))):
@@ -106,47 +105,26 @@ def test_fused_preprocess_from_host_image(gpu_ctx, oracle):
             assert np.array_equal(P.download(lvl, padded=True)[0], ref.level(lvl, padded=True)[0]), (w, h, lvl)
 
 
-@pytest.mark.parametrize("wh", [(752, 480), (1241, 376), (264, 100)])
-def test_tiled_lk_copy_equals_row_major_pyramid(gpu_ctx, wh, monkeypatch):
-    """OV2_PYR_TILED=1 (experimental): a second, tiled copy of every level for the batch LK kernel (16 x 8-pixel
-    tiles of one cache line), written by the producers themselves (CLAHE apply, level kernels, ring kernel).  It must hold
-    exactly the padded row-major image -- through the fused CLAHE path and the plain path, for every batch item."""
-    monkeypatch.setenv("OV2_PYR_TILED", "1")
-    w, h = wh
-    rng = np.random.default_rng(21)
-    imgs = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
-    P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(imgs[0], 3.0, max(1, w // 50), max(1, h // 50))     # fused CLAHE path
-    assert P.tiled
-    for l in range(P.levels):
-        assert np.array_equal(P.download_tiled(l), P.download(l, padded=True)[0]), ("fused", l)
-    P.close()
-    P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3, batch=3).build(imgs)                                            # plain path, batch
-    for b in range(3):
-        for l in range(P.levels):
-            assert np.array_equal(P.download_tiled(l, b=b), P.download(l, b=b, padded=True)[0]), ("plain", b, l)
-    P.close()
-
-
 @pytest.mark.parametrize("wh,tiles", [((752, 480), (15, 9)), ((640, 480), (12, 9)), ((376, 240), (7, 4)), ((264, 100), (5, 2)),
                                        ((512, 97), (10, 1)), ((1000, 64), (20, 1)), ((64, 48), (1, 1)), ((260, 50), (3, 1)), ((508, 33), (47, 2))])
-def test_strip_kernel_equals_oracle_pyramid(gpu_ctx, oracle, wh, tiles, monkeypatch):
-    """k_clahe_apply_pyr (batch mode's CLAHE apply + level 1 + both borders in one walk, forced here with OV2_CLAHE_STRIPS=1):
+def test_strip_kernel_equals_oracle_pyramid(gpu_ctx, oracle, wh, tiles):
+    """k_clahe_apply_pyr (batch mode's CLAHE apply + level 1 + both borders in one walk, forced here with OV2_OPT_CLAHE_STRIPS = 1):
     every level, borders included, equals CLAHE (oracle) followed by the pyramid (oracle) -- one to four column strips,
     odd heights, cell columns narrower than a strip."""
     w, h = wh
     rng = np.random.default_rng(w + h)
     for img in (synth.frame_pair(w, h, seed=w + h)[0], rng.integers(0, 256, (h, w), dtype=np.uint8)):
         ref = oracle.Pyramid(oracle.clahe(img, 3.0, tiles[0], tiles[1]), 9, 3)
-        for force in ("1", "0"):
-            monkeypatch.setenv("OV2_CLAHE_STRIPS", force)
-            P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(img, 3.0, tiles[0], tiles[1])
+        for force in (1, 0):
+            with gpu_ctx.options(clahe_strips=force):
+                P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(img, 3.0, tiles[0], tiles[1])
             assert P.levels == ref.levels
             for lvl in range(P.levels):
                 assert np.array_equal(P.download(lvl, padded=True)[0], ref.level(lvl, padded=True)[0]), (w, h, force, lvl)
             P.close()
 
 
-def test_strip_kernel_equals_separate_kernels_random_geometry(gpu_ctx, monkeypatch):
+def test_strip_kernel_equals_separate_kernels_random_geometry(gpu_ctx):
     """Randomised geometry sweep: the strip kernel and the separate kernels (both bit-exact against the oracle above on the
     named sizes) must produce identical padded pyramids for any width % 4 == 0, any height, any tile grid."""
     rng = np.random.default_rng(77)
@@ -156,10 +134,10 @@ def test_strip_kernel_equals_separate_kernels_random_geometry(gpu_ctx, monkeypat
         tx = int(rng.integers(1, max(2, min(30, w // 8)))); ty = int(rng.integers(1, max(2, min(12, h // 8))))
         img = rng.integers(0, 256, (h, w), dtype=np.uint8)
         out = {}
-        for force in ("1", "0"):
-            monkeypatch.setenv("OV2_CLAHE_STRIPS", force)
-            P = ov2slam_amd.Pyramid(gpu_ctx, w, h, win, 3).build_clahe(img, 2.5, tx, ty)
+        for force in (1, 0):
+            with gpu_ctx.options(clahe_strips=force):
+                P = ov2slam_amd.Pyramid(gpu_ctx, w, h, win, 3).build_clahe(img, 2.5, tx, ty)
             out[force] = [P.download(l, padded=True)[0] for l in range(P.levels)]
             P.close()
-        for l, (a, b) in enumerate(zip(out["1"], out["0"])):
+        for l, (a, b) in enumerate(zip(out[1], out[0])):
             assert np.array_equal(a, b), (case, win, w, h, tx, ty, l, np.argwhere(a != b)[:4].tolist())

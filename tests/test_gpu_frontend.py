@@ -9,17 +9,14 @@ from ov2slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["row", "lane3", "lane3_tiled"], autouse=True)
-def lk_impl(request, monkeypatch):
-    """Every test of this file runs with both LK kernels (lk.hip: row per lane, lk3.hip: 3 lanes per keypoint) and, for the
-    latter, with both fetch paths (row-major pyramid / the tiled LK copy that batch pyramids carry); without the overrides the
-    library picks by launch and batch size and these small cases would only see the first one."""
-    monkeypatch.setenv("OV2_LK_IMPL", "lane3" if request.param.startswith("lane3") else request.param)
-    if request.param == "lane3_tiled":
-        monkeypatch.setenv("OV2_PYR_TILED", "1")
-    else:
-        monkeypatch.delenv("OV2_PYR_TILED", raising=False)
-    return request.param
+@pytest.fixture(params=["row", "lane3"], autouse=True)
+def lk_impl(request, gpu_ctx):
+    """Every test of this file runs with both LK kernels (lk.hip: row per lane, lk3.hip: 3 lanes per keypoint), pinned through
+    ov2_ctx_set_option(OV2_OPT_LK_IMPL); without it the library picks by launch size and these small cases would only see the
+    first one."""
+    from ov2slam_amd import _lib as L
+    with gpu_ctx.options(lk_impl=L.OV2_LK_IMPL_ROW if request.param == "row" else L.OV2_LK_IMPL_LANE3):
+        yield request.param
 
 
 def _pyr_pair(ctx, oracle, img, win=9, lvl=3):
@@ -44,8 +41,6 @@ def test_pyramid_bit_exact(gpu_ctx, oracle, wh):
         ri, rd = R.level(l, padded=True)
         assert np.array_equal(gi, ri), "image level %d" % l
         assert np.array_equal(gd, rd), "derivative level %d" % l
-        if G.tiled:                                        # the tiled LK copy holds the same padded image, ring included
-            assert np.array_equal(G.download_tiled(l), ri), "tiled copy level %d" % l
 
 
 def test_pyramid_batch_matches_single(gpu_ctx, oracle):
@@ -228,7 +223,7 @@ Pc = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=B).build(np.stack(curs))
 ctx.sync()
 vp = lambda t: C.c_void_p(t.data_ptr())
 for impl in ("row", "lane3"):
-    os.environ["OV2_LK_IMPL"] = impl
+    ctx.set_option(L.OV2_OPT_LK_IMPL, L.OV2_LK_IMPL_ROW if impl == "row" else L.OV2_LK_IMPL_LANE3)
     for lvl in (3, 1):
         dk = torch.from_numpy(kps).cuda(); dp = torch.from_numpy(pri).cuda(); dn = torch.from_numpy(n_item).cuda()
         st = torch.full((B, NMAX), 7, dtype=torch.uint8, device="cuda"); stats = torch.zeros(2, dtype=torch.int64, device="cuda")

@@ -59,11 +59,15 @@ def _points(w, h, flow, f, rng, prior_sigma, frac_prior=0.7, bad_frac=0.0, bad_s
 @pytest.mark.parametrize("impl", ["wave", "row"])
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("wh,use_clahe", [((752, 480), True), ((1241, 376), True), ((376, 240), False)])
-def test_track_frame_matches_oracle(gpu_ctx, oracle, wh, use_clahe, use_graph, impl, monkeypatch):
-    # impl: the wavefront-per-keypoint LK kernel (k_track_klt_w, the default for the 9 x 9 window) and the row-per-lane one it
-    # replaced (k_track_klt, still the kernel of every other window size; OV2_TRACK_IMPL is read when the launch is built)
-    if impl == "row": monkeypatch.setenv("OV2_TRACK_IMPL", "row")
-    else: monkeypatch.delenv("OV2_TRACK_IMPL", raising=False)
+def test_track_frame_matches_oracle(gpu_ctx, oracle, wh, use_clahe, use_graph, impl):
+    # impl: the wavefront-per-keypoint LK kernel (k_track_klt_w, the default for the 9 x 9 window) and the row-per-lane one
+    # (k_track_klt, the kernel of every other window size); OV2_OPT_TRACK_IMPL is read when the launch is built / captured
+    from ov2slam_amd import _lib as L
+    with gpu_ctx.options(track_impl=L.OV2_TRACK_IMPL_ROW if impl == "row" else L.OV2_TRACK_IMPL_WAVE):
+        _track_frame_case(gpu_ctx, oracle, wh, use_clahe, use_graph)
+
+
+def _track_frame_case(gpu_ctx, oracle, wh, use_clahe, use_graph):
     w, h = wh
     views, flow = _sequence(w, h, 5, seed=31)
     rng = np.random.default_rng(5)

@@ -70,18 +70,15 @@ def test_xyz_ba_edge_cases(gpu_ctx, oracle):
     assert np.array_equal(g["xyz"][3], pb["xyz"][3]) and np.all(g["chi2"][act == 0] == 7.0)
 
 
-def test_xyz_large_problem_path_matches_oracle(gpu_ctx, oracle, monkeypatch):
+def test_xyz_large_problem_path_matches_oracle(gpu_ctx, oracle):
     """3-D point BA beyond the LDS-resident solver (~90 optimised keyframes): the reduced system goes through the multi-kernel
     Cholesky on HBM, the lineariser keeps fewer wavefronts per work-group so that its dense W rows still fit in LDS (4 -> 2 -> 1).
     Forced on a small problem (every combination), then at 150 and 260 keyframes where the sizes select them."""
     pb = synth.make_xyz_ba_problem(12, 400, 6, stereo=True, seed=2)
     r = oracle.xyz_ba_solve(pb, oracle.ba_default_options())
-    for big, waves in (("1", None), ("0", "1"), ("0", "2"), ("1", "1")):
-        monkeypatch.setenv("OV2_BA_BIG", big)
-        if waves: monkeypatch.setenv("OV2_BA_XYZ_LIN_WAVES", waves)
-        else: monkeypatch.delenv("OV2_BA_XYZ_LIN_WAVES", raising=False)
-        _cmp(optimizer.solve_xyz(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib)), r)
-    monkeypatch.delenv("OV2_BA_BIG"); monkeypatch.delenv("OV2_BA_XYZ_LIN_WAVES", raising=False)
+    for big, waves in ((1, 0), (0, 1), (0, 2), (1, 1)):
+        with gpu_ctx.options(ba_force_large=big, ba_xyz_lin_waves=waves):
+            _cmp(optimizer.solve_xyz(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib)), r)
     for n_kf, n_pts, obs, stereo, iters in ((150, 2000, 8, True, 6), (260, 1500, 8, False, 3), (420, 1200, 8, True, 2)):
         pb = synth.make_xyz_ba_problem(n_kf, n_pts, obs, stereo=stereo, seed=n_kf)
         kw = dict(max_iter=iters)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# BA GPU tests + the in-kernel phase clocks of k_ba_cholesky (OV2_BA_DEBUG=1) + solve time of config 4; run through gpurun.
-python -m pytest tests/test_gpu_ba.py -x -q 2>&1 | tail -1; OV2_BA_DEBUG=1 python /dev/stdin <<PY 2>&1 | tail -2
+# BA GPU tests + the in-kernel phase clocks of k_ba_cholesky (OV2_DEBUG=1) + solve time of config 4; run through gpurun.
+python -m pytest tests/test_gpu_ba.py -x -q 2>&1 | tail -1; OV2_DEBUG=1 python /dev/stdin <<PY 2>&1 | tail -2
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import ov2slam_amd

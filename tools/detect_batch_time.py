@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batched keyframe detector on the GPU box in isolation: ov2_detect_singlescale_batch_d on level 0 of an S-image pyramid
-(bench.py's detect_batch section without the rest of the bench).  Usage: detect_batch_time.py [S]; OV2_SUBPIX_MP=0|1 for A/B."""
+(bench.py's detect_batch section without the rest of the bench).  Usage: detect_batch_time.py [S]."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -28,4 +28,4 @@ for subpix in (True, False):
         qual[:] = 1e-3
         nd = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P, CELL, 0, 0, 0, roi, qual, out.data_ptr(), cap, subpix=subpix)
     ms = (time.perf_counter() - t) / 3 * 1e3
-    print("S=%d subpix=%d: %.2f ms per call, %.1f points per image  (OV2_SUBPIX_MP=%s)" % (S, subpix, ms, nd.mean(), os.environ.get("OV2_SUBPIX_MP", "auto")))
+    print("S=%d subpix=%d: %.2f ms per call, %.1f points per image" % (S, subpix, ms, nd.mean()))

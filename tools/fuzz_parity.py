@@ -40,7 +40,7 @@ for case in range(N):
     w, h = int(rng.integers(64, 900)), int(rng.integers(48, 520))
     if rng.integers(0, 2): w = 4 * (w // 4)                            # dword-multiple widths: the strip kernel's geometry
     # batch mode's strip kernel (CLAHE apply + level 1 + borders in one walk) forced on / off per case (read at every launch)
-    os.environ["OV2_CLAHE_STRIPS"] = "1" if rng.integers(0, 2) else "0"
+    ctx.set_option(L.OV2_OPT_CLAHE_STRIPS, 1 if rng.integers(0, 2) else 0)
     kind = int(rng.integers(0, 4))
     prev = rand_image(w, h, kind)
     shift = rng.uniform(-6, 6, 2)
@@ -69,11 +69,11 @@ for case in range(N):
     pri = (kps - shift + rng.normal(0, rng.choice([0.3, 2.0, 8.0]), kps.shape)).astype(np.float32)
     nl = int(rng.integers(0, Gp.levels))
     for impl in ("row", "lane3"):
-        os.environ["OV2_LK_IMPL"] = impl
+        ctx.set_option(L.OV2_OPT_LK_IMPL, L.OV2_LK_IMPL_ROW if impl == "row" else L.OV2_LK_IMPL_LANE3)
         go, gs, gst = trk.fbKltTracking(Gp, Gc, 9, nl, 30., 0.5, kps, pri, return_stats=True)
         ro, rs, rst = O.fb_klt(Rp, Rc, 9, nl, 30., 0.5, kps, pri)
         check("fbklt_" + impl, np.array_equal(gs, rs) and np.array_equal(go.view(np.uint32), ro.view(np.uint32)) and gst[0] == rst[0], dict(info, n=n, nl=nl))
-    os.environ.pop("OV2_LK_IMPL", None)
+    ctx.set_option(L.OV2_OPT_LK_IMPL, L.OV2_LK_IMPL_AUTO)
     # ---- stereo SAD scan on a random level ----
     sl = int(rng.integers(0, Gp.levels))
     lw, lh = Gp.level_size(sl)
@@ -182,16 +182,16 @@ for case in range(N):
             else: check(name, False, dict(binfo, **ba_diff(g, r, key)))
         pb = synth.make_ba_problem(n_kf, n_lm, min(obs, n_kf), stereo=stereo, seed=bseed)
         r = O.ba_solve(pb, O.ba_default_options(**kw))
-        for big in ("0", "1"):
-            os.environ["OV2_BA_BIG"] = big
+        for big in (0, 1):
+            ctx.set_option(L.OV2_OPT_BA_FORCE_LARGE, big)
             g = optimizer.solve(ctx, pb, optimizer.default_options(ctx.lib, **kw))
-            ba_check("ba_invdepth_big" + big, g, r, "invdepth")
+            ba_check("ba_invdepth_big%d" % big, g, r, "invdepth")
         # round 3: the lineariser without LDS pre-aggregation and the column-chunked sparse Schur complement, forced onto the small problem
-        os.environ["OV2_BA_LIN_DIRECT"] = "1"; os.environ["OV2_BA_SCHUR_CHUNK"] = str(int(rng.choice([36, 60, 96])))
+        ctx.set_option(L.OV2_OPT_BA_LIN_DIRECT, 1); ctx.set_option(L.OV2_OPT_BA_SCHUR_CHUNK, int(rng.choice([36, 60, 96])))
         g = optimizer.solve(ctx, pb, optimizer.default_options(ctx.lib, **kw))
         ba_check("ba_invdepth_big_direct_chunked", g, r, "invdepth")
-        for k_ in ("OV2_BA_BIG", "OV2_BA_LIN_DIRECT", "OV2_BA_SCHUR_CHUNK"):
-            os.environ.pop(k_, None)
+        for k_ in (L.OV2_OPT_BA_FORCE_LARGE, L.OV2_OPT_BA_LIN_DIRECT, L.OV2_OPT_BA_SCHUR_CHUNK):
+            ctx.set_option(k_, 0)
         # round 3: both passes of localBA on the resident problem (ov2_local_ba) vs the two-call protocol on the oracle
         def osolver(prob, res_active, chi2_init, depthpos_init, **kk):
             return O.ba_solve(prob, O.ba_default_options(**kk), res_active, chi2_init, depthpos_init)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Pre-processing step on the GPU box in isolation: ov2_pyr_build_clahe_d (CLAHE LUT + apply [+ level 1] + pyramid levels) on S
-resident 752x480 frames, HIP-event time per call.  Usage: pre_micro.py [S] [reps]; under rocprofv3 for per-kernel counters."""
+resident 752x480 frames, HIP-event time per call.  Usage: pre_micro.py [S] [reps] [strips: -1 auto | 0 | 1]; under rocprofv3 for per-kernel counters."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,11 +11,13 @@ import bench
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+strips = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 views, _, _ = bench.make_inputs(S, 1234)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
 ctx = ov2slam_amd.Context(0, stream=stream.cuda_stream)
 lib = ctx.lib
+ctx.set_option(L.OV2_OPT_CLAHE_STRIPS, strips)
 W, H = bench.W, bench.H
 fr = torch.from_numpy(views[:2]).to(dev)[:, None].expand(-1, S, H, W).contiguous()
 P = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=S)
@@ -27,4 +29,4 @@ for r in range(reps):
     e1.record(stream); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 print("S=%d  pre-processing per call: min %.1f us  median %.1f us   (%s)" % (S, min(ts[1:]) * 1e3, float(np.median(ts[1:])) * 1e3,
-      "OV2_CLAHE_STRIPS=" + os.environ.get("OV2_CLAHE_STRIPS", "auto")))
+      "OV2_OPT_CLAHE_STRIPS=%d" % strips))

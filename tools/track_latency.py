@@ -8,8 +8,7 @@ views, kps, pri = bench.make_inputs(1, 1234)
 W, H, WIN, LEVELS, NA, NF = bench.W, bench.H, bench.WIN, bench.LEVELS, bench.N_PASS_A, bench.NF
 hp = np.zeros(bench.NKPS, np.uint8); hp[:NA] = 1
 out = {}
-def run(label, use_graph, pinned, split=False, zc="1"):
-    os.environ["OV2_TRACK_ZC"] = zc
+def run(label, use_graph, pinned, split=False):
     ctx = ov2slam_amd.Context(0)
     trk = ov2slam_amd.VisualFrontEndTracker(ctx, W, H, use_clahe=True, fclahe_val=bench.CLAHE_CLIP, nbmaxkps=512, use_graph=use_graph)
     trk.trackFrame(views[0], kps[0, 0][:0], kps[0, 0][:0], None)
@@ -33,11 +32,7 @@ def run(label, use_graph, pinned, split=False, zc="1"):
     out[label] = {"median_ms": float(np.median(ts)), "mean_ms": float(ts.mean()), "p90_ms": float(np.percentile(ts, 90)),
                   "tracked": float((st & 1).mean()), "retried": int((st & 2).astype(bool).sum()), "graph": trk.uses_graph}
     trk.close(); ctx.close()
-os.environ["OV2_TRACK_KPW"] = "1"          # one keypoint per wavefront instead of four (A/B: no gain, lk.hip launcher comment)
-run("track_frame_graph_pinned_kpw1", True, True)
-del os.environ["OV2_TRACK_KPW"]
 run("track_frame_graph_pinned", True, True)
-run("track_frame_graph_pinned_blitcopies", True, True, zc="0")
 run("track_frame_graph_pageable", True, False)
 run("track_frame_plain_pinned", False, True)
 run("split_plain_pageable", False, False, split=True)
