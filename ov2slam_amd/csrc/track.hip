@@ -33,6 +33,7 @@ struct ov2_tracker {
     KpCalib calib;
     std::vector<float> last_unpx;      // 2 per keypoint of the last klt / track_frame call
     std::vector<double> last_bv;       // 3 per keypoint
+    int last_n = 0;                    // keypoints of the LAST klt / track_frame call that completed (0 after a call that tracked nothing or failed)
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     bool graph_ok = false;
 };
@@ -278,7 +279,7 @@ int ov2_tracker_set_calibration(ov2_tracker *t, int model, const double K[4], co
 int ov2_tracker_last_keypoints(const ov2_tracker *t, int n, float *unpx_xy_h, double *bv_xyz_h)
 {
     OV2_REQUIRE(t && t->has_calib, OV2_EINVAL, "no calibration set on this tracker");
-    OV2_REQUIRE(n >= 0 && 2 * (size_t)n <= t->last_unpx.size(), OV2_EINVAL, "more keypoints than the last tracking call returned");
+    OV2_REQUIRE(n >= 0 && n <= t->last_n, OV2_EINVAL, "more keypoints than the last tracking call returned");
     if (unpx_xy_h) memcpy(unpx_xy_h, t->last_unpx.data(), 8 * (size_t)n);
     if (bv_xyz_h) memcpy(bv_xyz_h, t->last_bv.data(), 24 * (size_t)n);
     return OV2_OK;
@@ -317,13 +318,16 @@ int ov2_tracker_klt(ov2_tracker *t, const float *kps_xy_h, const float *prior_xy
 {
     OV2_REQUIRE(t, OV2_EINVAL, "NULL tracker");
     if (p3p_req) *p3p_req = 0;
+    t->last_n = 0;                                                     // ov2_tracker_last_keypoints describes THIS call from here on
     if (n <= 0) return OV2_OK;
     OV2_REQUIRE(kps_xy_h && prior_xy_h && out_xy_h && status_h, OV2_EINVAL, "NULL point buffer");
     OV2_REQUIRE(t->frames >= 2, OV2_EINVAL, "kltTracking needs two preprocessed frames");
     OV2_HIP_CHECK(hipSetDevice(t->ctx->device));
-    const int rc = klt_overflow_chunks(t, kps_xy_h, prior_xy_h, has_prior_h, 0, n, klt_use_prior, out_xy_h, status_h);
+    int rc = klt_overflow_chunks(t, kps_xy_h, prior_xy_h, has_prior_h, 0, n, klt_use_prior, out_xy_h, status_h);
     if (rc != OV2_OK) return rc;
-    return apply_p3p_rule(t, kps_xy_h, has_prior_h, klt_use_prior, n, out_xy_h, status_h, p3p_req);
+    rc = apply_p3p_rule(t, kps_xy_h, has_prior_h, klt_use_prior, n, out_xy_h, status_h, p3p_req);
+    if (rc == OV2_OK && t->has_calib) t->last_n = n;
+    return rc;
 }
 
 int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, const float *kps_xy_h,
@@ -335,6 +339,7 @@ int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, co
     OV2_REQUIRE(n >= 0, OV2_EINVAL, "negative keypoint count");
     OV2_REQUIRE(n == 0 || (kps_xy_h && prior_xy_h && out_xy_h && status_h), OV2_EINVAL, "NULL point buffer");
     if (p3p_req) *p3p_req = 0;
+    t->last_n = 0;
     if (t->frames == 0 || n == 0) {
         // first frame (trackMono returns right after preprocessImage) or nothing to track
         const int rc = ov2_tracker_preprocess(t, img_h, stride);
@@ -375,7 +380,9 @@ int ov2_tracker_track_frame(ov2_tracker *t, const uint8_t *img_h, int stride, co
         rc = klt_overflow_chunks(t, kps_xy_h, prior_xy_h, has_prior_h, n0, n, klt_use_prior, out_xy_h, status_h);
         if (rc != OV2_OK) return rc;
     }
-    return apply_p3p_rule(t, kps_xy_h, has_prior_h, klt_use_prior, n, out_xy_h, status_h, p3p_req);
+    rc = apply_p3p_rule(t, kps_xy_h, has_prior_h, klt_use_prior, n, out_xy_h, status_h, p3p_req);
+    if (rc == OV2_OK && t->has_calib) t->last_n = n;
+    return rc;
 }
 
 } // extern "C"

@@ -79,7 +79,7 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
             pyrR.close()
         except Exception as e:                          # surfaced by the caller
             errors.append(e)
-            for ev in kf_consumed.values():
+            for ev in list(kf_consumed.values()):     # snapshot: the SLAM thread may insert while this runs
                 ev.set()
         finally:
             ba_q.put(None)
@@ -153,10 +153,11 @@ def run_stream(ctx, seq, kf_every=5, cell=35, nbmaxkps=308, prior_sigma=1.5, use
         gt = seq.flow(kps, f - 1, f)
         has_prior = (age > 0).astype(np.uint8)
         pri = np.where(has_prior[:, None] > 0, gt + rng.normal(0, prior_sigma, gt.shape), kps).astype(np.float32)
-        if do_stereo and f == last_kf + 2:
-            # this frame's preprocessImage overwrites the pyramid the keyframe of two frames ago shares with the mapper
-            # (the reference's cv::Mat buffers are re-used the same way): wait until stereo matching has consumed it
-            ev = kf_consumed.get(last_kf)
+        if do_stereo and f >= 2:
+            # this frame's preprocessImage overwrites the pyramid of frame f - 2 (two pyramids alternate); if that frame was a
+            # keyframe the mapper may still be reading it (the reference's cv::Mat buffers are re-used the same way): wait until
+            # stereo matching has consumed it -- whatever kf_every is (with kf_every = 1 every frame's pyramid is shared)
+            ev = kf_consumed.get(f - 2)
             if ev is not None and not ev.is_set():
                 tw = time.perf_counter(); ev.wait(); st["slam_wait_for_mapper_s"] += time.perf_counter() - tw
         tl = time.perf_counter()

@@ -269,6 +269,34 @@ def test_large_problem_path_matches_oracle(gpu_ctx, oracle):
     assert np.array_equal(g["bad_obs"], s["bad_obs"]) and np.allclose(g["poses"], s["poses"], atol=1e-9)
 
 
+def test_stop_flag_raised_during_pass_1_skips_the_l2_pass(gpu_ctx):
+    """The reference evaluates !stopLocalBA() AFTER its first ceres::Solve (src/optimizer.cpp:603-604) and Estimator::addNewKf raises
+    the flag from another thread while pass 1 runs.  ov2_local_ba reads the LIVE flag (ov2_local_ba_options::stop_flag) right before
+    it decides on pass 2: a flag raised after the call has started (here: 0.3 ms into a ~5 ms call) must skip the L2 pass, and the
+    adapter clears it when the call is over (:896)."""
+    import threading
+    import time
+    pb = synth.make_ba_problem(50, 10000, 30, stereo=False, seed=11)
+    opt = ov2slam_amd.Optimizer(gpu_ctx)
+    base = opt.localBA(pb, want_chi2=False)
+    assert base["l2_done"] and base["pass2_error"] == 0
+    started = threading.Event()
+
+    def raiser():
+        started.wait()
+        time.sleep(3e-4)
+        opt.signalStopLocalBA()
+    th = threading.Thread(target=raiser)
+    th.start()
+    started.set()
+    g = opt.localBA(pb, want_chi2=False)
+    th.join()
+    assert not g["l2_done"] and g["iterations"][0] == base["iterations"][0]
+    assert np.array_equal(g["bad_obs"], g["bad_after_pass1"])
+    assert not opt.stopLocalBA()                                   # cleared at the end of localBA
+    assert opt.localBA(pb, want_chi2=False)["l2_done"]              # and the next keyframe's localBA is unaffected
+
+
 def _mixed_with_pnp(pb, pn, kf):
     """the landmark problem `pb` plus the pose-only blocks of `pn` attached to keyframe `kf`"""
     from tests.test_oracle_ba import np_T

@@ -216,4 +216,13 @@ def test_tracker_computes_keypoints_in_the_same_enqueue(gpu_ctx, oracle, use_gra
         unpx, bv = trk.lastKeypoints(len(out))
         runpx, rbv = oracle.compute_keypoints(oracle.CAM_PINHOLE, K, D, cal.iK, out)
         assert np.array_equal(_bits(unpx), _bits(runpx)) and np.array_equal(bv.view(np.uint64), rbv.view(np.uint64))
+        # the "LAST call" contract: a frame that tracks fewer keypoints (or none) must not hand out the previous frame's entries
+        n_small = 7
+        out, st, _ = trk.trackFrame(views[0], kps[:n_small], kps[:n_small], None)
+        trk.lastKeypoints(n_small)
+        with pytest.raises(ov2slam_amd.Ov2Error):
+            trk.lastKeypoints(n_small + 1)
+        trk.trackFrame(views[1], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+        with pytest.raises(ov2slam_amd.Ov2Error):
+            trk.lastKeypoints(1)
         trk.close()

@@ -218,7 +218,6 @@ int main(int argc, char **argv)
     CK(ov2_tracker_track_frame(trk, C.left[0].data(), w, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr));
     frames = 1;
     keyframe(0);
-    int last_kf = 0;
     for (int f = 1; f < C.n_frames; f++) {
         const int n = (int)age.size();
         pri.resize(2 * (size_t)n); hp.resize(n); out.resize(2 * (size_t)n); st.resize(n); gt.resize(2 * (size_t)n);
@@ -229,10 +228,11 @@ int main(int argc, char **argv)
             pri[2 * i] = hp[i] ? (float)(gt[2 * i] + C.prior_sigma * gauss(rng)) : kps[2 * i];
             pri[2 * i + 1] = hp[i] ? (float)(gt[2 * i + 1] + C.prior_sigma * gauss(rng)) : kps[2 * i + 1];
         }
-        if (f == last_kf + 2) {                 // this frame overwrites the pyramid the keyframe of two frames ago shares with the mapper
+        if (f >= 2 && (f - 2) % C.kf_every == 0) {   // this frame overwrites the pyramid of frame f - 2 (two pyramids alternate): if that
+            const int kf2 = f - 2;                  // frame was a keyframe the mapper may still be reading it (whatever kf_every is)
             const double tw = now();
             std::unique_lock<std::mutex> l(done_m);
-            done_cv.wait(l, [&] { return mapper_done_kf >= last_kf; });
+            done_cv.wait(l, [&] { return mapper_done_kf >= kf2; });
             slam_wait += now() - tw;
         }
         int p3p = 0;
@@ -252,7 +252,7 @@ int main(int argc, char **argv)
             if (x > 8 && x < w - 9 && y > 8 && y < h - 9) { nk.push_back(x); nk.push_back(y); na.push_back(age[i] + 1); }
         }
         kps.swap(nk); age.swap(na);
-        if (f % C.kf_every == 0) { keyframe(f); last_kf = f; }
+        if (f % C.kf_every == 0) keyframe(f);
     }
     CK(ov2_ctx_sync(ctxA));
     const double slam_s = now() - t0;
