@@ -409,14 +409,22 @@ __global__ __launch_bounds__(512) void k_clahe_apply(ClaheParams P, const uint8_
 //     five-row register window, every second row emits two level-1 pixels per lane (same integer arithmetic as k_pyr_level);
 //   * the packed four-LUT table of all cell columns is staged once per image and row of cells and shared by the strips
 //     (two barriers per row of cells -- the only work-group synchronisation), not once per 192-thread work-group.
-// Geometry: w % 4 == 0, dword-aligned rows and destinations, h >= 8, at most CS_MAX_STRIPS strips, tiles_x + 1 <= 40 (host-checked;
-// anything else takes the separate kernels).  tests/test_gpu_clahe.py: named geometries vs the oracle + a random sweep vs the
+// Width: any (round 4; KITTI's 1241).  With r = w % 4 != 0 the last dword column holds r image pixels; its other bytes ARE border
+// pixels (x >= w mirrors 2 (w - 1) - x), so the last lane patches its dword from its own and its left neighbour's bytes and stores
+// it whole; the mirror axis of the right border then sits mid-dword, which moves every right-border dword's source window by 2 r
+// bytes (one r-dependent byte selector) and adds one border lane.  Level 1 likewise when its width (w + 1) / 2 is odd.  Source rows
+// may be unaligned (hardware handles unaligned dword loads).
+// Geometry: dword-aligned destinations, h >= 8, at most CS_MAX_STRIPS strips, tiles_x + 1 <= 40 (host-checked; anything else takes
+// the separate kernels).  tests/test_gpu_clahe.py: named geometries vs the oracle + a random sweep vs the
 // separate kernels.
 __device__ __forceinline__ uint32_t c_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }   // lane i <- lane i-1
 __device__ __forceinline__ uint32_t c_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }   // lane i <- lane i+1
 
 #define CS_UNROLL 6
 #define CS_MAX_STRIPS 8
+// UNAL: w % 4 != 0 or an odd level-1 width (the generic right edge); false keeps the w % 4 == 0 instance free of its per-lane
+// selectors (they cost three spilled registers at this kernel's 80-VGPR budget)
+template <bool UNAL>
 __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
                                                                           uint8_t *__restrict__ dst)
 {
@@ -425,7 +433,8 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     // one work-group per image, one wavefront per column strip: the strips share the LUT table (two barriers per row of cells),
     // everything else is wave-private
     const int b = blockIdx.x, s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, ndw = P.w >> 2;
+    const int lane = threadIdx.x & 63, ndw = (P.w + 3) >> 2, wr = UNAL ? (P.w & 3) : 0;
+    typedef uint32_t cs_u32_a1 __attribute__((aligned(1)));             // source rows of any alignment (KITTI: 1241-byte rows)
     // core columns of strip s: 63 (first), 62 (middle), <= 63 (last); lane 0 of every strip but the first is the left halo
     const int core0 = s == 0 ? 0 : 63 + 62 * (s - 1);
     const int core1 = s == P.nstrips - 1 ? ndw : 63 + 62 * s;
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     const uint32_t *lutc[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float txf = (float)(xb + k) * P.inv_tw - 0.5f;
+        const float txf = (float)min(xb + k, P.w - 1) * P.inv_tw - 0.5f;     // (bytes beyond the image are patched below: any table)
         const int fx = (int)floorf(txf);
         xa[k] = txf - (float)fx; xa1[k] = 1.0f - xa[k];
         lutc[k] = lut4 + ((fx + 1 - cmin) << 8);
@@ -455,18 +464,33 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     // lanes store their (identical) copy of the neighbouring strip's dword, lanes without a border column / level-1 pair aim
     // at the row's alignment slack right of the border (never consumed) -- row pointers advance by one scalar add, and the
     // switch to the next row of cells is one scalar compare against a precomputed row number.
-    const int nb0 = (win + 3) >> 2, nb1 = (win + 1) >> 1;
-    const bool bl0 = core && d < nb0, br0 = core && d >= ndw - nb0;
-    const bool bl1 = core && d >= 1 && d <= nb1, br1 = core && d >= ndw - nb1;
-    const bool edge_strip = s == 0 || core1 > ndw - max(nb0, nb1);      // (uniform) only these strips hold border lanes
+    const int l1odd = UNAL ? (P.l1_w & 1) : 0;
+    const int nb0 = (win + 3) >> 2, nb1 = (win + 1) >> 1;              // border lanes on the left; on the right one more when the
+    const int nbr0 = nb0 + (wr ? 1 : 0), nbr1 = nb1 + l1odd;            // mirror axis sits inside the last dword / pixel pair
+    const bool bl0 = core && d < nb0, br0 = core && d >= ndw - nbr0;
+    const bool bl1 = core && d >= 1 && d <= nb1, br1 = core && d >= ndw - nbr1;
+    const bool edge_strip = s == 0 || core1 > ndw - max(nbr0, nbr1);    // (uniform) only these strips hold border lanes
     const bool first_col = d_raw == 0, last_col = d_raw == ndw - 1;
+    const bool dup = d_raw > ndw - 1;                                   // lanes beyond the image recompute the last column: their stores go to the slack
     const uint32_t pad0 = 4u * nb0, pad1 = 2u * nb1;
-    const uint32_t slack0 = pad0 + (uint32_t)P.w + 4u * nb0, slack1 = pad1 + (uint32_t)P.l1_w + 2u * nb1;
-    const uint32_t o0 = pad0 + 4u * d;
-    const uint32_t o0b = bl0 ? pad0 - 4u * (d + 1) : (br0 ? pad0 + (uint32_t)P.w + 4u * (ndw - 1 - d) : slack0);
+    // stores of lanes without a border column: the alignment slack right of the border (never consumed, inside the row pitch)
+    const uint32_t slack0 = pad0 + 4u * (uint32_t)((P.w + win + 3) >> 2), slack1 = pad1 + 2u * (uint32_t)((P.l1_w + win + 3) >> 1);
+    const uint32_t o0 = dup ? slack0 : pad0 + 4u * d;
+    // right border dword of this lane: pixels p[top], p[top-1], p[top-2], p[top-3] at x0 = 2 (w - 1) - top, top = xb + 2 (w even)
+    // or xb (w odd): the choice that makes x0 a multiple of 4; both windows lie inside (left neighbour's dword, own dword)
+    const uint32_t o0b = bl0 ? pad0 - 4u * (d + 1) : (br0 ? pad0 + (uint32_t)(2 * P.w - 2 - xb - ((wr & 1) ? 0 : 2)) : slack0);
+    const uint32_t sel_br = (wr & 1) ? 0x01020304u : 0x03040506u;
+    // the last column's dword = its wr image pixels followed by the border pixels p[w], p[w+1].. = p[w-2], p[w-3]..; identity elsewhere
+    const uint32_t sel_fix = (last_col && wr) ? (wr == 1 ? 0x01020304u : (wr == 2 ? 0x03040504u : 0x05060504u)) : 0x07060504u;
+    // p[xb + 4] of the last column (byte 0): the mirror image of pixel 2 (w - 1) - xb - 4
+    const uint32_t sel_rt = wr == 0 ? 0x0c0c0c06u : (wr == 1 ? 0x0c0c0c00u : (wr == 2 ? 0x0c0c0c02u : 0x0c0c0c04u));
     const uint32_t o1 = core ? pad1 + 2u * d : slack1;
-    const uint32_t o1b = bl1 ? pad1 - 2u * d : (br1 ? pad1 + (uint32_t)P.l1_w + 2u * (ndw - 1 - d) : slack1);
+    const uint32_t o1b = bl1 ? pad1 - 2u * d : (br1 ? pad1 + (uint32_t)P.l1_w + 2u * (ndw - 1 - d) - (uint32_t)l1odd : slack1);
+    const bool fix1 = last_col && l1odd;                               // the last pair = (last level-1 pixel, first border pixel)
     uint8_t *d0m = dimg - pad0, *d1m = l1 - pad1;
+    // source dword of this lane: the last column of a width that is no multiple of 4 reads the row's last four bytes and shifts
+    const uint32_t xo = (d == ndw - 1 && wr) ? (uint32_t)(P.w - 4) : (uint32_t)xb;
+    const uint32_t in_sh = (d == ndw - 1 && wr) ? 8u * (4u - (uint32_t)wr) : 0u;
 
     auto cell_row = [&](int y) { return (int)floorf((float)y * P.inv_th - 0.5f) + 1; };
     int cy = -1, y_switch = 0;                                          // rows [.., y_switch) belong to the row of cells cy
@@ -509,9 +533,12 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
         const cu16x2 s0 = __builtin_bit_cast(cu16x2, c0), s1 = __builtin_bit_cast(cu16x2, c1), s2 = __builtin_bit_cast(cu16x2, c2),
                      s3 = __builtin_bit_cast(cu16x2, c3), s4 = __builtin_bit_cast(cu16x2, c4);
         const cu16x2 v = (s2 * (unsigned short)6 + (s1 + s3) * (unsigned short)4 + s0 + s4 + (unsigned short)128) >> (unsigned short)8;
-        const uint32_t o = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, v), 0x0c0c0200u);       // (v0, v1) as two bytes
+        uint32_t o = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, v), 0x0c0c0200u);       // (v0, v1) as two bytes
         uint32_t bv = 0;
-        if (edge_strip) bv = __builtin_amdgcn_perm(c_wave_shr1(o), o, 0x0c0c0500u);    // border pair: (own first pixel, left neighbour's second)
+        if (edge_strip) {
+            bv = __builtin_amdgcn_perm(c_wave_shr1(o), o, 0x0c0c0500u);    // border pair: (own first pixel, left neighbour's second)
+            if (UNAL && fix1) o = bv;                                              // odd level-1 width: the last pair's second pixel is border
+        }
         put1(r1, o, bv);
         r1 += P.l1_pitch;
         if (MIRROR) {
@@ -522,11 +549,10 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
 
     uint32_t hA = 0, hB = 0, hC = 0, hD = 0, hE = 0;                      // horizontal sums of rows y-4 .. y
     const uint8_t *srow = src + (long long)b * P.src_item_stride;        // (uniform) source row of the next prefetch
-    const uint32_t xo = (uint32_t)xb;
     uint8_t *r0 = d0m;                                                  // level-0 row of the next store
     uint32_t inr[CS_UNROLL], nxt[CS_UNROLL];
 #pragma unroll
-    for (int u = 0; u < CS_UNROLL; u++) inr[u] = *(const uint32_t *)(srow + (long long)min(u, P.h - 1) * P.stride + xo);
+    for (int u = 0; u < CS_UNROLL; u++) inr[u] = *(const cs_u32_a1 *)(srow + (long long)min(u, P.h - 1) * P.stride + xo) >> (UNAL ? in_sh : 0u);
     srow += (long long)CS_UNROLL * P.stride;
     // one row: CLAHE blend of the lane's four pixels, level-0 stores, horizontal pyrDown sums into the rolling window.
     // MIRROR: the row may be one the REFLECT_101 border mirrors (-y for 1 <= y <= win, 2 (h-1) - y for h-1-win <= y <= h-2)
@@ -546,14 +572,18 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
         const c_f32x2 m01 = r01 + MAGIC, m23 = r23 + MAGIC;
         const uint32_t u0 = __builtin_bit_cast(uint32_t, (float)m01.x), u1 = __builtin_bit_cast(uint32_t, (float)m01.y);
         const uint32_t u2 = __builtin_bit_cast(uint32_t, (float)m23.x), u3 = __builtin_bit_cast(uint32_t, (float)m23.y);
-        const uint32_t out = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u3, u2, 0x0c0c0400u), __builtin_amdgcn_perm(u1, u0, 0x0c0c0400u), 0x05040100u);
+        uint32_t out = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u3, u2, 0x0c0c0400u), __builtin_amdgcn_perm(u1, u0, 0x0c0c0400u), 0x05040100u);
         // neighbours: pixels xb-2, xb-1 (left lane's bytes 2, 3) and xb+4 (right lane's byte 0); REFLECT_101 at the image edge
         uint32_t lf = c_wave_shr1(out), rt = c_wave_shl1(out);
         if (first_col) lf = __builtin_amdgcn_perm(out, out, 0x01020000u);      // (.., .., p2, p1)
-        if (last_col) rt = out >> 16;                                          // p(w) = p(w-2)
+        if (edge_strip) {
+            if (UNAL) out = __builtin_amdgcn_perm(out, lf, sel_fix);           // (identity except in the last column of a width % 4 != 0)
+        }
+        if (UNAL) { if (last_col) rt = __builtin_amdgcn_perm(out, lf, sel_rt); }   // p[xb + 4] mirrored about w - 1
+        else if (last_col) rt = out >> 16;                                      // p(w) = p(w-2)
         uint32_t bv = 0;                                                        // border dword of the edge lanes:
-        if (edge_strip)                                                         // (p[4d+4], p[4d+3], p[4d+2], p[4d+1]) left, (p[xb+2], p[xb+1], p[xb], p[xb-1]) right
-            bv = bl0 ? __builtin_amdgcn_perm(out, rt, 0x05060700u) : __builtin_amdgcn_perm(out, lf, 0x03040506u);
+        if (edge_strip)                                                         // (p[4d+4], p[4d+3], p[4d+2], p[4d+1]) left, p[top .. top-3] right
+            bv = bl0 ? __builtin_amdgcn_perm(out, rt, 0x05060700u) : __builtin_amdgcn_perm(out, lf, sel_br);
         put0(r0, out, bv);
         r0 += P.dst_stride;
         if (MIRROR) {
@@ -573,11 +603,11 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     for (int yb = 0; yb < P.h; yb += CS_UNROLL) {
         if (yb + 2 * CS_UNROLL <= P.h) {
 #pragma unroll
-            for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = *(const uint32_t *)(srow + xo); srow += P.stride; }
+            for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = *(const cs_u32_a1 *)(srow + xo) >> (UNAL ? in_sh : 0u); srow += P.stride; }
         } else {
 #pragma unroll
             for (int u = 0; u < CS_UNROLL; u++)
-                nxt[u] = *(const uint32_t *)(src + (long long)b * P.src_item_stride + (long long)min(yb + CS_UNROLL + u, P.h - 1) * P.stride + xo);
+                nxt[u] = *(const cs_u32_a1 *)(src + (long long)b * P.src_item_stride + (long long)min(yb + CS_UNROLL + u, P.h - 1) * P.stride + xo) >> (UNAL ? in_sh : 0u);
         }
         if (yb == y_switch) stage(yb);
         // (level-0 rows yb .. yb+5 and the level-1 rows (yb-2)/2 .. (yb+2)/2 they complete are not mirrored by a border)
@@ -651,18 +681,22 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
     // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk
     // (OV2_OPT_CLAHE_STRIPS = 1 forces it for any batch, 0 disables it -- A/B runs, parity tests of both paths)
-    if (pyr && pyr->n_levels >= 2 && border == pyr->win && src_al && (w & 3) == 0 && w >= 64 && h >= 8 &&
+    if (pyr && pyr->n_levels >= 2 && border == pyr->win && w >= 64 && h >= 8 && 2 * ((border + 3) / 4) + 1 <= (w + 3) / 4 &&
         (((size_t)dst_d | (size_t)dst_stride | dst_batch_stride) & 3) == 0 && (pyr->lv[1].img_pitch & 1) == 0) {
-        const int ndw = w / 4, nstrips = ndw <= 64 ? 1 : 2 + (ndw - 126 + 61) / 62;
+        const int ndw = (w + 3) / 4, nstrips = ndw <= 64 ? 1 : 2 + (ndw - 126 + 61) / 62;
         const bool want = ctx->clahe_strips >= 0 ? ctx->clahe_strips == 1 : (long long)batch * nstrips >= 1024;
         if (want && nstrips <= CS_MAX_STRIPS && tiles_x + 1 <= 40) {
             static std::once_flag strip_once;
             static hipError_t strip_err = hipSuccess;
-            std::call_once(strip_once, [] { strip_err = hipFuncSetAttribute((const void *)k_clahe_apply_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024); });
+            std::call_once(strip_once, [] {
+                strip_err = hipFuncSetAttribute((const void *)k_clahe_apply_pyr<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
+                if (strip_err == hipSuccess) strip_err = hipFuncSetAttribute((const void *)k_clahe_apply_pyr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
+            });
             OV2_HIP_CHECK(strip_err);
             P.nstrips = nstrips;
             P.l1_delta = pyr->lv[1].img_roi - pyr->lv[0].img_roi; P.l1_pitch = pyr->lv[1].img_pitch; P.l1_w = pyr->lv[1].w; P.l1_h = pyr->lv[1].h;
-            hipLaunchKernelGGL(k_clahe_apply_pyr, dim3(batch), dim3(64 * nstrips), (size_t)(tiles_x + 1) * 1024, ctx->stream, P, src_d, lut_d, dst_d);
+            const bool unal = (w & 3) != 0 || (pyr->lv[1].w & 1) != 0;
+            hipLaunchKernelGGL(unal ? k_clahe_apply_pyr<true> : k_clahe_apply_pyr<false>, dim3(batch), dim3(64 * nstrips), (size_t)(tiles_x + 1) * 1024, ctx->stream, P, src_d, lut_d, dst_d);
             OV2_HIP_CHECK(hipGetLastError());
             if (level1_done) *level1_done = 1;
             return OV2_OK;
