@@ -272,6 +272,9 @@ static int orc_lk_trip_hist_on = 0;
 static int orc_lk_trip_hist[64];
 void orc_lk_trip_hist_enable(int on) { orc_lk_trip_hist_on = on; if (on) for (int k = 0; k < 64; k++) orc_lk_trip_hist[k] = 0; }
 void orc_lk_trip_hist_get(int *out64) { for (int k = 0; k < 64; k++) out64[k] = orc_lk_trip_hist[k]; }
+/* diagnostics (tools/lk_lockstep.py): per-keypoint, per-level trip counts of the NEXT orc_lk_track call: buf[i * 8 + level] */
+static int *orc_lk_trip_log = 0;
+void orc_lk_trip_log_set(int *buf) { orc_lk_trip_log = buf; }
 
 static void lk_level_range(const lk_job *jb)
 {
@@ -453,6 +456,7 @@ static void lk_level_range(const lk_job *jb)
         if (orc_lk_trip_hist_on) {
             __atomic_fetch_add(&orc_lk_trip_hist[visit_trips < 63 ? visit_trips : 63], 1, __ATOMIC_RELAXED);
         }
+        if (orc_lk_trip_log && level < 8) orc_lk_trip_log[i * 8 + level] = visit_trips;
     }
 }
 
