@@ -4,4 +4,5 @@
 #include "optimizer.hpp"
 #include "camera_calibration.hpp"
 #include "visual_front_end.hpp"
+#include "slam_gpu.hpp"
 int main() { return 0; }

@@ -87,6 +87,16 @@ public:
         // released at once).  Consumers on ANOTHER context wait on the pyramid's ready event themselves.
         return ov2_pyr_build_h(ctx.get(), p_, img.data, img.step, 0);
     }
+    // pclahe_->apply(img_raw, img) followed by cv::buildOpticalFlowPyramid(img, *this, ...)  (src/visual_front_end.cpp:1159-1172,
+    // src/mapper.cpp:75-81) in one enqueue: the equalised image is level 0 of the pyramid and never leaves the device.
+    // Tile grid like src/ov2slam.cpp:85-89: img.cols / 50 x img.rows / 50.
+    int buildClahe(Context &ctx, const Image8 &img, int win, int max_level, double clip_limit) {
+        if (img.empty()) return OV2_EINVAL;
+        int w = 0, h = 0;
+        if (p_ && (ov2_pyr_level_size(p_, 0, &w, &h) != OV2_OK || w != img.cols || h != img.rows || win != win_ || max_level != max_level_)) { ov2_pyr_destroy(p_); p_ = nullptr; }
+        if (!p_) { const int rc = ov2_pyr_create(ctx.get(), img.cols, img.rows, win, max_level, 1, &p_); if (rc != OV2_OK) return rc; win_ = win; max_level_ = max_level; }
+        return ov2_pyr_build_clahe_h(ctx.get(), p_, img.data, img.step, clip_limit, img.cols / 50, img.rows / 50);
+    }
 private:
     ov2_pyr *p_ = nullptr;
     int win_ = 0, max_level_ = -1;

@@ -1,0 +1,38 @@
+// slam_gpu.hpp -- the one object a patched OV2SLAM tree shares between its threads (integration/ov2slam_hip.patch adds
+// `std::shared_ptr<ov2::SlamGpu> pgpu_` to SlamParams, which every class of the reference already holds as pslamstate_).
+// One context per calling thread (SLAM thread / mapper thread / estimator thread), the per-frame tracker of the
+// SLAM thread, the adapters that carry the reference's adaptive detector thresholds, and the two pyramids the mapper thread
+// builds per keyframe.  Construct it where the reference constructs its FeatureExtractor / FeatureTracker, BEFORE the mapper
+// and estimator threads start (src/ov2slam.cpp:91-113): the tracker captures its hipGraphs at construction.
+#pragma once
+#include <memory>
+#include "ov2_types.hpp"
+#include "feature_extractor.hpp"
+#include "feature_tracker.hpp"
+#include "visual_front_end.hpp"
+#include "optimizer.hpp"
+
+namespace ov2 {
+
+struct SlamGpu {
+    Context frontend, mapper, estimator;          // SLAM thread (visualTracking, createKeyframe) / Mapper::run / Estimator::run
+    FeatureExtractor extract;                     // detectGridFAST / detectSingleScale with nfast_th_ / dmaxquality_ adapting as in the reference
+    FeatureTracker track;                         // fbKltTracking / stereoMatching data path
+    Optimizer opt;                                // solveLocalBA (ov2_local_ba)
+    std::unique_ptr<FrameTracker> trk;            // preprocessImage + kltTracking of every frame (SLAM thread)
+    Pyramid kf_left, kf_right;                    // mapper thread: the keyframe's pyramids, rebuilt from the raw images it queued
+
+    // arguments: the SlamParams fields of the same names (include/slam_params.hpp) and the left image size
+    SlamGpu(int device, int img_w, int img_h, int nbmaxkps, int nmaxdist, double dmaxquality, int nfast_th, int nmax_iter,
+            float fmax_px_precision, int nklt_win_size, int nklt_pyr_lvl, float nklt_err, float fmax_fbklt_dist, bool use_clahe,
+            double fclahe_val, double robust_mono_th, bool apply_l2_after_robust)
+        : frontend(device), mapper(device), estimator(device),
+          extract((size_t)nbmaxkps, (size_t)nmaxdist, dmaxquality, nfast_th), track(nmax_iter, fmax_px_precision),
+          opt(robust_mono_th, apply_l2_after_robust),
+          trk(new FrameTracker(frontend, img_w, img_h, nklt_win_size, nklt_pyr_lvl, nmax_iter, fmax_px_precision, nklt_err,
+                               fmax_fbklt_dist, use_clahe, fclahe_val, nbmaxkps))
+    {}
+    ~SlamGpu() { trk.reset(); }                   // the tracker goes before the context it was created on
+};
+
+}  // namespace ov2
