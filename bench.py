@@ -536,7 +536,35 @@ def parity_check(dev_index, views, kps, pri):
                                np.where(hp[:, None] > 0, pri[0, 0], kps[0, 0]).astype(np.float32))
     worst = {"status_flips": max(m["status_flips"] for m in acc["modes"].values()),
              "max_abs_dpx": max(m["max_abs_dpx"] for m in acc["modes"].values()), "points": acc["points"]}
-    return {"lk_bit_exact_vs_oracle": ok_all, "lk_points_compared": n,
+    # the detector: the GPU's keyframe detection on this frame vs the oracle (bit-exact), and the oracle's distance to the arithmetic
+    # variants another OpenCV build would run (blur rounding, getRectSubPix path, accumulator type): this frame here, 1000 keyframes /
+    # 200 k keypoints in profiles/r4_detect_variants.json (tools/detect_variant_campaign.py)
+    det = {}
+    try:
+        ctx2 = ov2slam_amd.Context(dev_index)
+        fx = ov2slam_amd.FeatureExtractor(ctx2, dmaxquality=0.001)
+        img0 = O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES)
+        roi = (5, 5, W - 10, H - 10)
+        gk = fx.detectSingleScale(img0, CELL, np.zeros((0, 2), np.float32), roi)
+        rk, _ = O.detect_singlescale(img0, CELL, np.zeros((0, 2), np.float32), roi, 0.001, True)
+        det["detector_bit_exact_vs_oracle"] = bool(np.array_equal(gk.view(np.uint32), rk.view(np.uint32)))
+        det["detector_points_compared"] = int(len(rk))
+        from scipy.spatial import cKDTree
+        var = {}
+        for name, kw in (("blur_ties_to_even", dict(blur=O.BLUR_HALF_EVEN)), ("getRectSubPix_generic", dict(subpix=O.SUBPIX_GENERIC)),
+                         ("cornerSubPix_float_sums", dict(subpix=O.SUBPIX_FLOAT_ACC))):
+            with O.detect_variant(**kw):
+                vk, _ = O.detect_singlescale(img0, CELL, np.zeros((0, 2), np.float32), roi, 0.001, True)
+            d, _ = cKDTree(vk.astype(np.float64)).query(rk.astype(np.float64))
+            var[name] = {"keypoints_without_counterpart_within_1px": int((d > 1.0).sum()), "max_abs_dpx_of_the_others": float(d[d <= 1.0].max())}
+        det["detector_canonical_vs_other_opencv_arithmetic"] = var
+        det["detector_variant_campaign"] = "profiles/r4_detect_variants.json: 200465 keypoints of 1000 keyframes -- blur ties-to-even: 1.0 % of the keypoints " \
+                                           "move to another arg-max, the others identical; getRectSubPix generic form / float sums: <= 0.062 px, 1 / 0 moved"
+        ctx2.close()
+    except Exception:
+        import traceback
+        det = {"detector_parity_error": traceback.format_exc()[-600:]}
+    return {"lk_bit_exact_vs_oracle": ok_all, "lk_points_compared": n, **det,
             "front_end_oracle_pin": "none: no OpenCV in this image or on the GPU box (gpurun_out/r3probe) -- parity is GPU = oracle, and the "
                                     "oracle's distance to float-accumulator OpenCV builds is bounded by measurement",
             "lk_int64_vs_float_accumulator_opencv_orders": worst}

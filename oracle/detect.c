@@ -157,6 +157,21 @@ void orc_circle_fill0(uint8_t *mask, int w, int h, int cx, int cy, int radius)
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 
+/* ---- version-dependent arithmetic of the detector's OpenCV calls (tools/detect_variant_campaign.py) ----------------
+ * The canonical choices (what the HIP kernels implement bit for bit) next to the variants a different OpenCV build would run; the
+ * switches exist to MEASURE how far apart they are on the keypoint sets, like orc_set_lk_acc_mode does for LK -- nothing is pinned
+ * against a real build (none in this image).
+ *   blur:   GaussianBlur 3x3 on 8U.  FIXED (canonical): the fixed-point paths (ufixedpoint16 in 3.4.2+ / 4.x, FixedPtCastEx before)
+ *           round the exact sum s / 16 half UP, (s + 8) >> 4.  HALF_EVEN: a float-kernel build, cvRound(s / 16.f): ties to even.
+ *   subpix: getRectSubPix 8U -> 32F inside cornerSubPix.  FAST (canonical): the two-tap running form of the optimised path;
+ *           GENERIC: the four-tap form of getRectSubPix_Cn_ for every patch (builds without that path);
+ *           FLOAT_ACC: the five gradient sums accumulated in float instead of double (2.4-era cvFindCornerSubPix).          */
+static int g_blur_mode = ORC_BLUR_FIXED, g_subpix_mode = ORC_SUBPIX_FAST;
+void orc_set_blur_mode(int m) { g_blur_mode = m == ORC_BLUR_HALF_EVEN ? ORC_BLUR_HALF_EVEN : ORC_BLUR_FIXED; }
+int orc_get_blur_mode(void) { return g_blur_mode; }
+void orc_set_subpix_mode(int m) { g_subpix_mode = (m >= ORC_SUBPIX_FAST && m <= ORC_SUBPIX_FLOAT_ACC) ? m : ORC_SUBPIX_FAST; }
+int orc_get_subpix_mode(void) { return g_subpix_mode; }
+
 /* ---- cornerSubPix ------------------------------------------------------ */
 /* getRectSubPix(src u8 -> f32 patch pw x ph, center) (samplers.cpp) */
 static void get_rect_subpix_8u32f(const uint8_t *src, int src_step, int sw, int sh,
@@ -165,7 +180,7 @@ static void get_rect_subpix_8u32f(const uint8_t *src, int src_step, int sw, int 
     /* getRectSubPix_8u32f fast path uses double centre arithmetic */
     double cxd = (double)cx_f - (pw - 1) * 0.5, cyd = (double)cy_f - (ph - 1) * 0.5;
     int ipx = (int)floor(cxd), ipy = (int)floor(cyd);
-    if (0 <= ipx && ipx + pw < sw && 0 <= ipy && ipy + ph < sh && pw > 0 && ph > 0) {
+    if (g_subpix_mode != ORC_SUBPIX_GENERIC && 0 <= ipx && ipx + pw < sw && 0 <= ipy && ipy + ph < sh && pw > 0 && ph > 0) {
         float a = (float)(cxd - ipx), b = (float)(cyd - ipy);
         a = a > 0.0001f ? a : 0.0001f;
         float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
@@ -245,6 +260,20 @@ void orc_corner_subpix(const uint8_t *img, int w, int h, int stride,
             double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
             get_rect_subpix_8u32f(img, stride, w, h, sub, win_w + 2, win_h + 2, cIx, cIy);
             const float *sp = sub + sw + 1;
+            if (g_subpix_mode == ORC_SUBPIX_FLOAT_ACC) {
+                float fa = 0, fb = 0, fc = 0, fb1 = 0, fb2 = 0;
+                for (int i = 0, k = 0; i < win_h; i++, sp += sw) {
+                    float py = (float)(i - half_win);
+                    for (int j = 0; j < win_w; j++, k++) {
+                        float m = mask[k], tgx = sp[j + 1] - sp[j - 1], tgy = sp[j + sw] - sp[j - sw];
+                        float gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m, px = (float)(j - half_win);
+                        fa += gxx; fb += gxy; fc += gyy;
+                        fb1 += gxx * px + gxy * py;
+                        fb2 += gxy * px + gyy * py;
+                    }
+                }
+                a = fa; b = fb; c = fc; bb1 = fb1; bb2 = fb2;
+            } else
             for (int i = 0, k = 0; i < win_h; i++, sp += sw) {
                 double py = i - half_win;
                 for (int j = 0; j < win_w; j++, k++) {
@@ -380,7 +409,8 @@ void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,
                 int wy = dy == 0 ? 2 : 1;
                 s += wy * (row[reflect101(x0 + i - 1, w)] + 2 * row[reflect101(x0 + i, w)] + row[reflect101(x0 + i + 1, w)]);
             }
-            blur[j * cs + i] = (uint8_t)((s + 8) >> 4);
+            if (g_blur_mode == ORC_BLUR_HALF_EVEN) blur[j * cs + i] = (uint8_t)lrintf((float)s / 16.f);     /* (s <= 4080: exact in float) */
+            else blur[j * cs + i] = (uint8_t)((s + 8) >> 4);
         }
     /* cornerMinEigenVal(filtered, hmap, 3, 3): Sobel 3x3 with scale 1/(4*3*255), REFLECT_101 at the cell edges */
     const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));

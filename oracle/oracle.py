@@ -313,6 +313,28 @@ def detect_grid_fast(img, cell, cur_kps, fast_th, mask_mode=MASK_AS_EXECUTED, su
     return out[:n.value].copy(), th.value
 
 
+BLUR_FIXED, BLUR_HALF_EVEN = 0, 1
+SUBPIX_FAST, SUBPIX_GENERIC, SUBPIX_FLOAT_ACC = 0, 1, 2
+
+
+class detect_variant:
+    """with detect_variant(blur=BLUR_HALF_EVEN, subpix=SUBPIX_GENERIC): ...  -- version-dependent arithmetic of the detector's
+    OpenCV calls (detect.c); the canonical choices (what the HIP kernels implement) are the defaults."""
+
+    def __init__(self, blur=BLUR_FIXED, subpix=SUBPIX_FAST):
+        self.blur, self.subpix = int(blur), int(subpix)
+
+    def __enter__(self):
+        L = lib()
+        L.orc_get_blur_mode.restype = C.c_int; L.orc_get_subpix_mode.restype = C.c_int
+        self.prev = (L.orc_get_blur_mode(), L.orc_get_subpix_mode())
+        L.orc_set_blur_mode(self.blur); L.orc_set_subpix_mode(self.subpix)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_blur_mode(self.prev[0]); lib().orc_set_subpix_mode(self.prev[1])
+
+
 def detect_singlescale(img, cell, cur_kps, roi, quality, subpix=True):
     """returns (points (n,2) float32, new dmaxquality)"""
     img = np.ascontiguousarray(img, np.uint8)

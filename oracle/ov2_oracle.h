@@ -152,6 +152,12 @@ int orc_detect_singlescale(const uint8_t *img, int w, int h, int stride, int cel
 /* min-eigenvalue response map of one cell (blur w/ parent pixels + isolated
  * cornerMinEigenVal); exposed for unit tests. hmap is cell*cell floats.      */
 enum { ORC_SOBEL_DY_OPENCV_ROWFILTER = 0, ORC_SOBEL_DY_EXACT_SUM = 1 };
+enum { ORC_BLUR_FIXED = 0, ORC_BLUR_HALF_EVEN = 1 };
+enum { ORC_SUBPIX_FAST = 0, ORC_SUBPIX_GENERIC = 1, ORC_SUBPIX_FLOAT_ACC = 2 };
+void orc_set_blur_mode(int mode);            /* GaussianBlur 3x3 rounding inside detectSingleScale (detect.c) */
+int orc_get_blur_mode(void);
+void orc_set_subpix_mode(int mode);          /* getRectSubPix path / accumulator type inside cornerSubPix (detect.c) */
+int orc_get_subpix_mode(void);
 void orc_set_sobel_dy_order(int order);      /* evaluation order of cv::Sobel(dx=0, dy=1, scale) in the min-eigenvalue map */
 int  orc_get_sobel_dy_order(void);
 void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,

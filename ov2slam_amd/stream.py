@@ -213,12 +213,34 @@ def write_case(path, seq, ba_problems, kf_every=5, cell=35, nbmaxkps=308, prior_
         for v in seq.right_views:
             f.write(np.ascontiguousarray(v, np.uint8).tobytes())
         for pb in ba_problems:
-            f.write(struct.pack("<3i", int(pb["n_kf"]), int(pb["n_lm"]), int(pb["n_res"])))
-            for name, dt in (("poses", np.float64), ("kf_const", np.uint8), ("invdepth", np.float64), ("lm_anchor_kf", np.int32),
-                             ("lm_anchor_uv", np.float64), ("res_type", np.uint8), ("res_kf", np.int32), ("res_lm", np.int32),
-                             ("res_uv", np.float64), ("res_sigma", np.float64), ("calib_l", np.float64), ("calib_r", np.float64),
-                             ("T_rl", np.float64)):
-                f.write(np.ascontiguousarray(pb[name], dt).tobytes())
+            write_ba_problem(f, pb)
+
+
+def write_ba_problem(f, pb):
+    """One flat inverse-depth BA problem (synth.make_ba_problem layout) as little-endian binary: the reader is read_case of
+    tools/stream_driver.cpp and load() of tools/ref_capture/capture_ba.cpp."""
+    import struct
+    f.write(struct.pack("<3i", int(pb["n_kf"]), int(pb["n_lm"]), int(pb["n_res"])))
+    for name, dt in (("poses", np.float64), ("kf_const", np.uint8), ("invdepth", np.float64), ("lm_anchor_kf", np.int32),
+                     ("lm_anchor_uv", np.float64), ("res_type", np.uint8), ("res_kf", np.int32), ("res_lm", np.int32),
+                     ("res_uv", np.float64), ("res_sigma", np.float64), ("calib_l", np.float64), ("calib_r", np.float64),
+                     ("T_rl", np.float64)):
+        f.write(np.ascontiguousarray(pb[name], dt).tobytes())
+
+
+def read_ba_problem(f):
+    """inverse of write_ba_problem: the dict layout of synth.make_ba_problem (without its ground-truth extras)"""
+    import struct
+    n_kf, n_lm, n_res = struct.unpack("<3i", f.read(12))
+    pb = dict(n_kf=n_kf, n_lm=n_lm, n_res=n_res)
+    for name, dt, cnt, shape in (("poses", np.float64, 7 * n_kf, (n_kf, 7)), ("kf_const", np.uint8, n_kf, None), ("invdepth", np.float64, n_lm, None),
+                                 ("lm_anchor_kf", np.int32, n_lm, None), ("lm_anchor_uv", np.float64, 2 * n_lm, (n_lm, 2)), ("res_type", np.uint8, n_res, None),
+                                 ("res_kf", np.int32, n_res, None), ("res_lm", np.int32, n_res, None), ("res_uv", np.float64, 2 * n_res, (n_res, 2)),
+                                 ("res_sigma", np.float64, n_res, None), ("calib_l", np.float64, 4, None), ("calib_r", np.float64, 4, None),
+                                 ("T_rl", np.float64, 7, None)):
+        a = np.frombuffer(f.read(cnt * np.dtype(dt).itemsize), dt).copy()
+        pb[name] = a.reshape(shape) if shape else a
+    return pb
 
 
 def build_native_driver(out_dir):

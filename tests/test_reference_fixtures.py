@@ -19,7 +19,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INP, REF = os.path.join(ROOT, "tests", "golden", "ref_inputs"), os.path.join(ROOT, "tests", "golden", "ref")
 HAVE = bool(glob.glob(os.path.join(REF, "*_clahe.npy"))) and bool(glob.glob(os.path.join(INP, "*_prev.npy")))
-pytestmark = pytest.mark.skipif(not HAVE, reason="no reference fixtures (tools/ref_capture needs OpenCV + Eigen; absent in this image)")
+needs_front_end = pytest.mark.skipif(not HAVE, reason="no reference fixtures (tools/ref_capture needs OpenCV + Eigen; absent in this image)")
+# the Ceres leg (round 4): tools/ref_capture/capture_ba.cpp -- the reference's own factors + the vendored Ceres on five flat problems
+HAVE_BA = bool(glob.glob(os.path.join(REF, "ba_*_final_poses.npy"))) and bool(glob.glob(os.path.join(INP, "ba_*.bin")))
+needs_ba = pytest.mark.skipif(not HAVE_BA, reason="no Ceres fixtures (tools/ref_capture -DOV2_CAPTURE_BA=ON needs Eigen + Ceres + Sophus; absent in this image)")
+BA_TAGS = ["kf8_mono", "kf8_stereo", "kf12_stereo", "kf50_mono", "kf50_stereo"]
 
 TAGS = ["euroc", "kitti"]
 
@@ -49,6 +53,58 @@ def _cmp_pts(a, b, what):
         assert np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-3, what
 
 
+def _ba_case(tag):
+    from ov2slam_amd import stream
+    with open(os.path.join(INP, "ba_%s.bin" % tag), "rb") as f:
+        pb = stream.read_ba_problem(f)
+    ref = {k: np.load(os.path.join(REF, "ba_%s_%s.npy" % (tag, k))) for k in
+           ("pass1_poses", "pass1_invdepth", "pass1_chi2", "pass1_depthpos", "pass1_summary", "final_poses", "final_invdepth", "final_bad_obs", "final_summary")}
+    return pb, ref
+
+
+def _cmp_ba(res, ref, what):
+    """res: the localBA protocol's result dict (pass1 / pass2 / poses / bad_obs); BASELINE.json: poses within 1e-4 relative"""
+    p1 = res["pass1"]
+    assert p1["iterations"] == int(ref["pass1_summary"][0]) and p1["num_successful_steps"] == int(ref["pass1_summary"][1]), what
+    scale = max(1.0, np.abs(ref["final_poses"]).max())
+    assert np.abs(p1["poses"] - ref["pass1_poses"]).max() <= 1e-6 * scale, what
+    assert abs(p1["final_cost"] - ref["pass1_summary"][4]) <= 1e-6 * max(1.0, ref["pass1_summary"][4]), what
+    ok = np.isfinite(ref["pass1_chi2"])
+    assert np.allclose(p1["chi2"][ok], ref["pass1_chi2"][ok], rtol=1e-5, atol=1e-8) and np.array_equal(p1["depthpos"].astype(bool), ref["pass1_depthpos"].astype(bool)), what
+    assert bool(res["l2_done"]) == bool(ref["final_summary"][5]), what
+    if res["l2_done"]:
+        assert res["pass2"]["iterations"] == int(ref["final_summary"][0]), what
+    assert np.array_equal(np.asarray(res["bad_obs"]).astype(bool), ref["final_bad_obs"].astype(bool)), what
+    assert np.abs(res["poses"] - ref["final_poses"]).max() <= 1e-6 * scale, what
+    assert np.allclose(res["invdepth"], ref["final_invdepth"], rtol=1e-5, atol=1e-9), what
+
+
+@needs_ba
+@pytest.mark.parametrize("tag", BA_TAGS)
+def test_oracle_local_ba_vs_ceres(oracle, tag):
+    """the oracle's two-pass localBA (oracle/ba.c through the protocol of ov2slam_amd/optimizer.py) against the REAL reference:
+    its factors on the vendored Ceres (iterations, accepted steps, costs, cached chi2 / depth flags, outlier set, poses)"""
+    import ov2slam_amd
+
+    def solver(prob, res_active, chi2_init, depthpos_init, **kw):
+        return oracle.ba_solve(prob, oracle.ba_default_options(**kw), res_active, chi2_init, depthpos_init)
+    pb, ref = _ba_case(tag)
+    _cmp_ba(ov2slam_amd.Optimizer(None, solver=solver).localBA(pb), ref, tag)
+
+
+@needs_ba
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", BA_TAGS)
+def test_hip_local_ba_vs_ceres(gpu_ctx, tag):
+    import ov2slam_amd
+    pb, ref = _ba_case(tag)
+    _cmp_ba(ov2slam_amd.Optimizer(gpu_ctx).localBA_two_calls(pb), ref, tag)
+    g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)                      # the one-call resident form: final state and outlier set
+    assert np.array_equal(g["bad_obs"], ref["final_bad_obs"].astype(bool))
+    assert np.abs(g["poses"] - ref["final_poses"]).max() <= 1e-6 * max(1.0, np.abs(ref["final_poses"]).max())
+
+
+@needs_front_end
 @pytest.mark.parametrize("tag", TAGS)
 def test_oracle_vs_reference(oracle, tag):
     prev, cur, kps, pri, curkps = (_in(tag, n) for n in ("prev", "cur", "kps", "pri", "curkps"))
@@ -80,6 +136,7 @@ def test_oracle_vs_reference(oracle, tag):
     assert np.allclose(l1[m], _ref(tag, "linesad_l1err")[m], atol=1e-5)
 
 
+@needs_front_end
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", TAGS)
 def test_hip_vs_reference(gpu_ctx, tag):
@@ -106,3 +163,44 @@ def test_hip_vs_reference(gpu_ctx, tag):
         pts = fx.detectGridFAST(prev, 50, np.zeros((0, 2), np.float32) if call == 0 else curkps)
         _cmp_pts(pts, _ref(tag, "gridfast_call%d_pts" % call), "detectGridFAST call %d" % call)
         assert fx.nfast_th_ == _ref(tag, "gridfast_th")[call]
+
+
+def test_ba_fixture_comparison_self_check(oracle, tmp_path, monkeypatch):
+    """The Ceres fixtures do not exist in this image, so the comparison code above would never run here: fabricate fixtures in the
+    capture program's format from the oracle's own protocol run (through the same .bin problem file the capture reads), check that
+    the comparison accepts them and that it REJECTS a pose perturbed by 1e-3 and a flipped outlier flag."""
+    import sys
+    import ov2slam_amd
+    from ov2slam_amd import stream, synth
+    me = sys.modules[__name__]
+    inp, ref = tmp_path / "in", tmp_path / "ref"
+    inp.mkdir(); ref.mkdir()
+    pb0 = synth.make_ba_problem(8, 200, 6, stereo=True, seed=5)
+    with open(inp / "ba_kf8_stereo.bin", "wb") as f:
+        stream.write_ba_problem(f, pb0)
+    monkeypatch.setattr(me, "INP", str(inp)); monkeypatch.setattr(me, "REF", str(ref))
+
+    def solver(prob, res_active, chi2_init, depthpos_init, **kw):
+        return oracle.ba_solve(prob, oracle.ba_default_options(**kw), res_active, chi2_init, depthpos_init)
+    with open(inp / "ba_kf8_stereo.bin", "rb") as f:
+        pb = stream.read_ba_problem(f)
+    for k in ("poses", "invdepth", "res_uv", "res_kf", "res_lm", "res_type", "lm_anchor_kf", "kf_const", "T_rl"):
+        assert np.array_equal(np.asarray(pb[k]).ravel(), np.asarray(pb0[k]).ravel()), k
+    r = ov2slam_amd.Optimizer(None, solver=solver).localBA(pb)
+    assert r["l2_done"]
+    p1, p2 = r["pass1"], r["pass2"]
+
+    def save(name, a):
+        np.save(ref / ("ba_kf8_stereo_%s.npy" % name), np.asarray(a))
+    save("pass1_poses", p1["poses"]); save("pass1_invdepth", p1["invdepth"]); save("pass1_chi2", p1["chi2"]); save("pass1_depthpos", p1["depthpos"])
+    save("pass1_summary", [p1["iterations"], p1["num_successful_steps"], 0, p1["initial_cost"], p1["final_cost"], 0])
+    save("final_poses", r["poses"]); save("final_invdepth", r["invdepth"]); save("final_bad_obs", np.asarray(r["bad_obs"]).astype(np.uint8))
+    save("final_summary", [p2["iterations"], p2["num_successful_steps"], 0, p2["initial_cost"], p2["final_cost"], 1])
+    pbx, fx = _ba_case("kf8_stereo")
+    _cmp_ba(ov2slam_amd.Optimizer(None, solver=solver).localBA(pbx), fx, "self")
+    bad = dict(fx); bad["final_poses"] = fx["final_poses"].copy(); bad["final_poses"][3, 0] += 1e-3
+    with pytest.raises(AssertionError):
+        _cmp_ba(r, bad, "perturbed pose")
+    bad = dict(fx); bad["final_bad_obs"] = fx["final_bad_obs"].copy(); bad["final_bad_obs"][0] ^= 1
+    with pytest.raises(AssertionError):
+        _cmp_ba(r, bad, "flipped outlier flag")

@@ -23,4 +23,10 @@ for tag, (w, h) in (("euroc", (752, 480)), ("kitti", (1241, 376))):
     np.save(os.path.join(out, tag + "_pri.npy"), pri)
     # a third of the cells already occupied: exercises the occupancy / mask prologue of the detectors
     np.save(os.path.join(out, tag + "_curkps.npy"), kps[::3].astype(np.float32))
+# local-BA problems for the Ceres capture (capture_ba.cpp): the flat layout of ov2slam_amd/stream.py
+from ov2slam_amd import stream  # noqa: E402
+for tag, (n_kf, n_lm, obs, stereo, seed) in (("kf8_mono", (8, 200, 6, False, 5)), ("kf8_stereo", (8, 200, 6, True, 5)), ("kf12_stereo", (12, 400, 8, True, 3)),
+                                             ("kf50_mono", (50, 2000, 30, False, 42)), ("kf50_stereo", (50, 2000, 30, True, 42))):
+    with open(os.path.join(out, "ba_%s.bin" % tag), "wb") as f:
+        stream.write_ba_problem(f, synth.make_ba_problem(n_kf, n_lm, obs, stereo=stereo, seed=seed))
 print("wrote", out)
