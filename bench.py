@@ -242,14 +242,15 @@ def config5_plan(world, scale):
     return counts, batch.assign_sequences(counts, world)
 
 
-def run_config5(ctx, rank, world, scale, dry=False, device=0):
+def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2):
     """This rank's share of the 11 EuRoC-length synthetic sequences through the single-sequence path; all-gather of
     (frames, seconds, tracked, attempted, squared tracking error) over torch.distributed -- the only collective."""
     from ov2slam_amd import batch
     counts, plan = config5_plan(world, scale)
     mine = plan[rank]
     loc = dict(frames=0.0, seconds=0.0, tracked=0.0, attempted=0.0, ate_sq_sum=0.0, ate_n=0.0, sequences=float(len(mine)), host_native=0.0,
-               keyframes=0.0, stereo_ok=0.0, stereo_kps=0.0, ba_solves=0.0, ba_iterations=0.0, ba_seconds=0.0, ba_skipped=0.0, device=float(device))
+               keyframes=0.0, stereo_ok=0.0, stereo_kps=0.0, ba_solves=0.0, ba_iterations=0.0, ba_seconds=0.0, ba_skipped=0.0, device=float(device),
+               seconds_one_at_a_time=0.0)
     if dry:
         loc["frames"] = float(sum(counts[s] for s in mine)); loc["seconds"] = 1.0 + 0.25 * rank
         loc["tracked"] = loc["attempted"] = 300.0 * loc["frames"]
@@ -274,13 +275,20 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0):
         except Exception:
             exe = None
             loc["host_native"] = 0.0
+        all_st, conc_seconds = None, None
+        if exe and concurrency > 1 and len(seqs) > 1:
+            # the rank's sequences as concurrent processes on its GPU (each a three-thread keyframe cycle on three contexts)
+            all_st, conc_seconds = stream.run_native_concurrent(exe, cases, device=device, concurrency=concurrency)
         for i, sq in enumerate(seqs):
-            st = stream.run_native(exe, cases[i], device=device) if exe else batch.run_sequence(ctx, sq, ba_problems=windows)
+            st = all_st[i] if all_st else (stream.run_native(exe, cases[i], device=device) if exe else batch.run_sequence(ctx, sq, ba_problems=windows))
             loc["frames"] += st["frames"]; loc["seconds"] += st["seconds"]; loc["tracked"] += st["tracked"]
             loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
             loc["keyframes"] += st["keyframes"]; loc["stereo_ok"] += st["stereo_ok"]; loc["stereo_kps"] += st["stereo_kps"]
             loc["ba_solves"] += st["ba_solves"]; loc["ba_iterations"] += st["ba_iterations"]; loc["ba_seconds"] += st["ba_busy_s"]
             loc["ba_skipped"] += st["ba_skipped_kfs"]
+        loc["seconds_one_at_a_time"] = loc["seconds"]
+        if conc_seconds is not None:
+            loc["seconds"] = conc_seconds                          # wall clock of the concurrent waves (common start, last end)
         td.cleanup()
     stats = batch.gather_stats(loc)
     agg = batch.aggregate(stats)
@@ -292,6 +300,8 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0):
             "fps": agg["fps"], "frames": agg["frames"], "seconds_slowest_rank": agg["seconds"],
             "frames_per_rank": stats["frames"], "seconds_per_rank": stats["seconds"], "sequences_per_rank": stats["sequences"],
             "device_per_rank": [int(d) for d in stats["device"]],
+            "concurrent_sequences_per_gpu": int(concurrency),
+            "sum_of_single_stream_seconds_per_rank": stats["seconds_one_at_a_time"],
             "tracked_fraction": sum(stats["tracked"]) / max(1.0, sum(stats["attempted"])),
             "keyframes": sum(stats["keyframes"]), "stereo_ok_fraction": sum(stats["stereo_ok"]) / max(1.0, sum(stats["stereo_kps"])),
             "ba_solves": sum(stats["ba_solves"]), "ba_keyframes_skipped_while_busy": sum(stats["ba_skipped"]),
@@ -639,6 +649,11 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher + process group + config-5 plan / all-gather only (CPU test)")
     ap.add_argument("--config5-scale", type=int, default=16, help="EuRoC frame counts are divided by this for the config-5 run")
+    ap.add_argument("--config5-concurrency", type=int, default=2,
+                    help="sequences of a rank that stream concurrently on its GPU inside one driver process (1 = one after another).  Measured "
+                         "(tools/r4_conc.py, profiles/r4_stream_concurrency.txt): 1 stream 4.4 k frames/s, 2 streams 7.3 k, 4 streams 6.4 k, 8 streams "
+                         "5.9 k -- the streams are chains of small launches and the aggregate is bound by the rate the GPU's command processor "
+                         "retires them, which is what the lock-step batch entry points (the headline mode) exist to avoid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-sequence / config-5 / BA / detect / parity sections")
     args = ap.parse_args()
@@ -885,7 +900,7 @@ def main():
     if not args.no_extras and args.workload == "euroc":
         try:
             ctx5 = ov2slam_amd.Context(dev.index)
-            c5 = run_config5(ctx5, rank, world, args.config5_scale, device=dev.index)
+            c5 = run_config5(ctx5, rank, world, args.config5_scale, device=dev.index, concurrency=args.config5_concurrency)
             ctx5.close()
         except Exception:
             import traceback

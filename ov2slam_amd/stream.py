@@ -257,8 +257,34 @@ def build_native_driver(out_dir):
 
 def native_argv(exe, case_path, ba_policy="newest", device=0):
     """Command line of tools/stream_driver.cpp: the rank's GPU travels as argv[3] (one process per GPU, SURVEY 8(e);
-    the reference's own protocol starts one process per sequence, benchmark_scripts/euroc_bench.sh:3-27)."""
-    return [exe, case_path, ba_policy, str(int(device))]
+    the reference's own protocol starts one process per sequence, benchmark_scripts/euroc_bench.sh:3-27).  `case_path` may be a
+    list: the sequences then run CONCURRENTLY inside the one process, three threads and three contexts each."""
+    cases = case_path if isinstance(case_path, str) else ",".join(case_path)
+    return [exe, cases, ba_policy, str(int(device))]
+
+
+def run_native_concurrent(exe, case_paths, device=0, ba_policy="newest", concurrency=4):
+    """The sequences of `case_paths` on ONE GPU, `concurrency` at a time inside one driver process (a single stream keeps the GPU
+    ~5 % busy: the offline batch mode runs several).  The sequences of a wave start streaming together once all of them have
+    initialised; the wave lasts from the earliest t_begin to the latest t_end they report.  Returns (per-sequence stats,
+    seconds = sum of the waves)."""
+    import json
+    import subprocess
+    stats, seconds = [None] * len(case_paths), 0.0
+    for w0 in range(0, len(case_paths), max(1, concurrency)):
+        idx = list(range(w0, min(len(case_paths), w0 + max(1, concurrency))))
+        r = subprocess.run(native_argv(exe, [case_paths[i] for i in idx], ba_policy, device), capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise RuntimeError("stream_driver failed (%d): %s" % (r.returncode, r.stderr[-500:]))
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if len(lines) != len(idx):
+            raise RuntimeError("stream_driver returned %d result lines for %d sequences" % (len(lines), len(idx)))
+        for i, l in zip(idx, lines):
+            stats[i] = json.loads(l)
+            if int(stats[i].get("device", -1)) != int(device):
+                raise RuntimeError("stream_driver ran on device %s, asked for %d" % (stats[i].get("device"), device))
+        seconds += max(stats[i]["t_end"] for i in idx) - min(stats[i]["t_begin"] for i in idx)
+    return stats, seconds
 
 
 def run_native(exe, case_path, ba_policy="newest", device=0):

@@ -33,6 +33,7 @@
 static void die(const char *what, int rc) { fprintf(stderr, "stream_driver: %s failed (%d): %s\n", what, rc, ov2_last_error()); exit(3); }
 #define CK(call) do { const int rc_ = (call); if (rc_ != OV2_OK) die(#call, rc_); } while (0)
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double wall() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }   // epoch seconds: comparable across processes
 
 struct BAProb {
     int n_kf, n_lm, n_res;
@@ -113,15 +114,12 @@ template <class T> struct Queue {
     bool try_pop(T &v) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); return true; }
 };
 
-int main(int argc, char **argv)
+// one sequence: its SLAM thread is the caller, its mapper and estimator threads are started here; the result line goes to `json`.
+// `ready` / `go`: several sequences of one process (the batch mode of config 5: a rank's sequences share its GPU) start streaming
+// together once every one of them has initialised.
+static int run_sequence(const char *case_path, bool ba_all, int device, std::atomic<int> *ready, std::atomic<int> *go, std::string &json)
 {
-    if (argc < 2) { fprintf(stderr, "usage: stream_driver <case> [newest|all] [device]\n"); return 2; }
-    if (ov2_version() != OV2_ABI_VERSION) { fprintf(stderr, "stream_driver: header / library ABI mismatch\n"); return 2; }
-    const Case C = read_case(argv[1]);
-    const bool ba_all = argc > 2 && !strcmp(argv[2], "all");
-    // one process per GPU (SURVEY 8(e)): the rank's device index comes from the launcher (argv[3], else OV2_DEVICE, else 0)
-    const char *dev_s = argc > 3 ? argv[3] : getenv("OV2_DEVICE");
-    const int device = dev_s ? atoi(dev_s) : 0;
+    const Case C = read_case(case_path);
     const int w = C.w, h = C.h;
     const double K[4] = {458.654, 457.296, 367.215, 248.375};
     const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[1], -K[3] / K[1], 0, 0, 1};
@@ -214,6 +212,8 @@ int main(int argc, char **argv)
         }
         map_q.push(std::move(j));
     };
+    if (ready) { ready->fetch_add(1); while (!go->load()) std::this_thread::sleep_for(std::chrono::microseconds(100)); }
+    const double t_begin = wall();
     const double t0 = now();
     CK(ov2_tracker_track_frame(trk, C.left[0].data(), w, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr));
     frames = 1;
@@ -259,13 +259,48 @@ int main(int argc, char **argv)
     map_q.close();
     mapper.join(); estimator.join();
     const double total_s = now() - t0;
-    printf("{\"frames\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, \"slam_library_s\": %.6f, \"tracked\": %ld, \"attempted\": %ld, "
+    const double t_end = wall();
+    char line[2048];
+    snprintf(line, sizeof(line), "{\"frames\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, \"slam_library_s\": %.6f, \"tracked\": %ld, \"attempted\": %ld, "
            "\"err_sq_sum\": %.6f, \"err_n\": %ld, \"keyframes\": %ld, \"stereo_kfs\": %ld, \"stereo_ok\": %ld, \"stereo_kps\": %ld, \"mapper_busy_s\": %.6f, "
            "\"ba_solves\": %ld, \"ba_skipped_kfs\": %ld, \"ba_iterations\": %ld, \"ba_busy_s\": %.6f, \"ba_device_ms\": %.4f, \"slam_wait_for_mapper_s\": %.6f, "
-           "\"ba_policy\": \"%s\", \"device\": %d}\n",
+           "\"ba_policy\": \"%s\", \"device\": %d, \"t_begin\": %.6f, \"t_end\": %.6f}",
            frames, total_s, slam_s, slam_lib, tracked, attempted, err_sq, err_n, keyframes, stereo_kfs, stereo_ok, stereo_kps, mapper_busy,
-           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest", device);
+           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest", device, t_begin, t_end);
+    json = line;
     ov2_tracker_destroy(trk); ov2_pyr_destroy(pyrR);
     ov2_ctx_destroy(ctxA); ov2_ctx_destroy(ctxB); ov2_ctx_destroy(ctxC);
     return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: stream_driver <case>[,<case>...] [newest|all] [device]\n"); return 2; }
+    if (ov2_version() != OV2_ABI_VERSION) { fprintf(stderr, "stream_driver: header / library ABI mismatch\n"); return 2; }
+    const bool ba_all = argc > 2 && !strcmp(argv[2], "all");
+    // one process per GPU (SURVEY 8(e)): the rank's device index comes from the launcher (argv[3], else OV2_DEVICE, else 0)
+    const char *dev_s = argc > 3 ? argv[3] : getenv("OV2_DEVICE");
+    const int device = dev_s ? atoi(dev_s) : 0;
+    // several comma-separated cases: the sequences run CONCURRENTLY in this process, three threads and three contexts each
+    std::vector<std::string> cases;
+    for (std::string rest = argv[1]; !rest.empty();) {
+        const size_t c = rest.find(',');
+        cases.push_back(rest.substr(0, c));
+        rest = c == std::string::npos ? "" : rest.substr(c + 1);
+    }
+    std::vector<std::string> out(cases.size());
+    std::vector<int> rc(cases.size(), 0);
+    if (cases.size() == 1) rc[0] = run_sequence(cases[0].c_str(), ba_all, device, nullptr, nullptr, out[0]);
+    else {
+        std::atomic<int> ready{0}, go{0};
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < cases.size(); i++)
+            th.emplace_back([&, i] { rc[i] = run_sequence(cases[i].c_str(), ba_all, device, &ready, &go, out[i]); if (rc[i]) go.store(1); });
+        while (ready.load() < (int)cases.size() && !go.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        go.store(1);
+        for (auto &t : th) t.join();
+    }
+    int bad = 0;
+    for (size_t i = 0; i < cases.size(); i++) { if (rc[i]) bad = rc[i]; else printf("%s\n", out[i].c_str()); }
+    return bad;
 }
