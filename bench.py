@@ -935,6 +935,39 @@ def main():
                          "gn_iterations": iters, "patch_builds": visits},
             "lk_ms_per_step": (ms_A + ms_B) / args.steps, "tracked_fraction": tracked,
         }
+        # ---- pre-processing (everything of the step that is not k_fb_klt3): SURVEY.md 8(d) bytes against the time the step spends
+        # there; per kernel, duration and HBM bytes by the counters of the committed PMC passes (tools/profile.sh, FETCH_SIZE x 2:
+        # the gfx950 correction of the guide, WRITE_SIZE as read), same workload and batch only
+        try:
+            pre_ms = elapsed / args.steps * 1e3 - (ms_A + ms_B) / args.steps
+            px = [(max(1, (W + (1 << l) - 1) >> l)) * (max(1, (H + (1 << l) - 1) >> l)) for l in range(LEVELS + 1)]
+            b_alg = W * H + sum(px[1:]) + 4 * sum(px) + 2 * W * H        # B_pyr (read L0, write L>=1, int16x2 derivatives) + CLAHE 2 W0 H0
+            b_must = 2 * W * H + sum(px)                                # what this design has to move: raw frame twice (histogram, blend), every level once
+            pre = {"ms_per_step": pre_ms, "algorithmic_bytes_per_image": b_alg, "achieved": b_alg * S / (pre_ms * 1e-3) / 1e9, "unit": "GB/s",
+                   "frac": b_alg * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "bytes_the_design_must_move_per_image": b_must, "frac_of_those": b_must * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "8(d) counts the int16x2 derivative pyramid (4 of its 5.33 B/px), which this design never materialises (LK evaluates it in registers)"}
+            for name in ("r4_v1", "r3_v4"):
+                pth = os.path.join(ROOT, "profiles", "%s_rocprof_summary_seqs%d.json" % (name, S))
+                if os.path.exists(pth) and args.workload == "euroc":
+                    sj = json.load(open(pth))
+                    ks = {}
+                    n_steps = max([kv["calls"] for kn, kv in sj.get("kernels", {}).items() if "k_clahe_apply_pyr" in kn] + [1])
+                    for kn, kv in sj.get("kernels", {}).items():
+                        short = kn.replace("void ", "").split("<")[0]
+                        if short in ("k_clahe_lut", "k_clahe_apply_pyr", "k_pyr_level"):
+                            pm = sj.get("pmc", {}).get(kn, {})
+                            rd = 2.0 * pm.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) * 1e3
+                            wr = pm.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) * 1e3
+                            ks[short] = {"avg_us": kv["avg_us"], "launches_per_step": round(kv["calls"] / max(1, n_steps)),
+                                         "hbm_read_bytes_per_launch": rd, "hbm_written_bytes_per_launch": wr,
+                                         "frac_by_counters": (rd + wr) / (kv["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                    pre["kernels"] = ks
+                    pre["kernels_source"] = "profiles/" + os.path.basename(pth)
+                    break
+            out["roofline_pre"] = pre
+        except Exception:
+            pass
         if c5 is not None:
             out["config5"] = c5
         if det_batch is not None:
@@ -948,6 +981,14 @@ def main():
             out["single_sequence_fps"] = ss["pageable"]["fps_incl_pcie"]
             ctx1 = ov2slam_amd.Context(dev.index)
             out["ba"], pb, gpu_poses = ba_section(ctx1)
+            # B_BA = 2 N_res (16 + 12 + 8) + 2 N_lm (8 + 16 + 4) + 2 * 56 N_kf + 8 (6 N_kf_opt)^2 per LM iteration
+            b_ba = 2 * 290000 * 36 + 2 * 10000 * 28 + 2 * 56 * 50 + 8 * (6 * 50) ** 2
+            us_it = out["ba"]["us_per_iteration"]
+            out["ba"]["roofline"] = {"bound": "latency", "algorithmic_bytes_per_iteration": b_ba, "achieved": b_ba / (us_it * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": b_ba / (us_it * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                     "limiter": "a chain of nine launches per LM iteration, half of it the one-work-group fp64 Cholesky of the 300 x 300 reduced system "
+                                                "(262 us: 32-column pivot chains, trailing tiles through L2, triangular solves); profiles/r4_ba_timeline_config4_mono.txt, "
+                                                "profiles/r4_v0_ba_kernel_stats_*.csv; HBM bytes are 0.5 % of the roofline by design (SURVEY 8(d): 'explain, don't hide')"}
             # ---- detection through the host-buffer drop-in API on ONE image: per-call latency incl. PCIe -----
             fx = ov2slam_amd.FeatureExtractor(ctx1, dmaxquality=0.001)
             roi = (5, 5, W - 10, H - 10)
