@@ -72,7 +72,8 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
  *                           (lk3.hip) from 65536 points per call on, the row-per-lane kernel (lk.hip) below
  * OV2_OPT_TRACK_IMPL        ov2_tracker_* / ov2_stereo_match, window 9: wavefront per keypoint (lkw.hip, default) or row per lane
  * OV2_OPT_CLAHE_STRIPS      ov2_pyr_build_clahe_*: the one-walk strip kernel (CLAHE apply + level 1 + borders): -1 auto (batch x
- *                           strips >= 1024), 0 never, 1 whenever the geometry allows
+ *                           strips >= 1024: the fused form), 0 never, 1 whenever the geometry allows, after the LUT kernel,
+ *                           2 whenever the geometry allows, fused with the LUT computation (one launch, LUTs stay in LDS)
  * OV2_OPT_BA_FORCE_LARGE    1: the large-problem BA path (sparse W slots, HBM Cholesky) on a problem of any size
  * OV2_OPT_BA_LIN_DIRECT     1 (with FORCE_LARGE): the lineariser without LDS aggregation of the observer blocks
  * OV2_OPT_BA_SCHUR_CHUNK    columns of the sparse Schur row block kept in LDS per chunk (0 = auto)

@@ -31,7 +31,7 @@ struct ClaheParams {
     int ysplit;          // apply kernel: work-groups per row of interpolation cells (1 in batch mode; a single image is cut
                          // into ~60 short row bands so that it does not run on 10 CUs only -- latency)
     // strip kernel (k_clahe_apply_pyr): column strips per image, level 1 of the pyramid next to the level-0 destination
-    int nstrips;
+    int nstrips, nlut;   // nlut: LUT wavefronts of the fused form (1)
     long long l1_delta;  // byte offset of level 1's ROI pixel (0, 0) from the dst ROI pointer
     int l1_pitch, l1_w, l1_h;
 };
@@ -64,19 +64,14 @@ typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 template <int CTRL>
 __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // out-of-row sources read 0
 
-template <bool SRC_ALIGNED>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
-__global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
+// The tiles t, t + tstride, .. < t_end of ONE image, by one wavefront with its own 256-bin histogram `hw` in LDS; store_lut(t, packed)
+// receives the lane's four LUT bytes (bins 4 lane .. 4 lane + 3) of tile t.  Shared by k_clahe_lut (LUTs to HBM) and the fused
+// strip kernel (LUTs stay in LDS).
+template <bool SRC_ALIGNED, class StoreLut>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
+__device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint8_t *img, uint32_t *hw, int lane, int t, int t_end, int tstride,
+                                                StoreLut store_lut)
 {
-    // four wavefronts = four neighbouring tiles per work-group (no barrier between them): tiles that share cache lines run at
-    // the same time on one CU.  (One wavefront per work-group makes a bin's LDS address a single SDWA shift, but the tiles of a
-    // row then run at different times and the kernel fetches 1.44x the bytes from HBM -- same 635 us, LDS-atomic bound either way.)
-    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
-    const int ntiles = P.tiles_x * P.tiles_y, tstride = 4 * P.gx_lut;
-    int b, bx;
-    ov2_xcd_map(blockIdx.x, P.gx_lut, P.batch, &b, &bx);    // the work-groups of an image share image lines and its LUTs
-    uint32_t *hw = hist_all[wave];
-    const uint8_t *img = src + (long long)b * P.src_item_stride;
+    const int ntiles = t_end;
     const int sub = lane >> 4, l16 = lane & 15;
     uint32_t *hist = hw;
     const bool fast_geom = P.tw <= 61 && P.th <= 64;
@@ -144,7 +139,6 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
     };
 
     uint32_t cur[16], nxt[16], cur_ph = 0, nxt_ph = 0;
-    int t = bx * 4 + wave;
     if (t < ntiles && tile_fast(t)) tile_load(t, cur, cur_ph);
 #pragma nounroll
     for (; t < ntiles; t += tstride) {
@@ -225,11 +219,27 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
             r = r < 0 ? 0 : (r > 255 ? 255 : r);
             packed |= (uint32_t)r << (8 * k);
         }
-        *(uint32_t *)(lut + ((long long)b * ntiles + t) * 256 + 4 * lane) = packed;
+        store_lut(t, packed);
 #pragma unroll
         for (int i = 0; i < 16; i++) cur[i] = nxt[i];
         cur_ph = nxt_ph;
     }
+}
+
+template <bool SRC_ALIGNED>
+__global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8_t *__restrict__ src, uint8_t *__restrict__ lut)
+{
+    // four wavefronts = four neighbouring tiles per work-group (no barrier between them): tiles that share cache lines run at
+    // the same time on one CU.  (One wavefront per work-group makes a bin's LDS address a single SDWA shift, but the tiles of a
+    // row then run at different times and the kernel fetches 1.44x the bytes from HBM -- same 635 us, LDS-atomic bound either way.)
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
+    const int ntiles = P.tiles_x * P.tiles_y;
+    int b, bx;
+    ov2_xcd_map(blockIdx.x, P.gx_lut, P.batch, &b, &bx);    // the work-groups of an image share image lines and its LUTs
+    uint8_t *lb = lut + (long long)b * ntiles * 256 + 4 * lane;
+    clahe_lut_tiles<SRC_ALIGNED>(P, src + (long long)b * P.src_item_stride, hist_all[wave], lane, bx * 4 + wave, ntiles, 4 * P.gx_lut,
+                                 [&](int t, uint32_t packed) { *(uint32_t *)(lb + (long long)t * 256) = packed; });
 }
 
 // One workgroup per (row of interpolation cells, image): the rows whose two surrounding tile rows are
@@ -421,20 +431,73 @@ __device__ __forceinline__ uint32_t c_wave_shr1(uint32_t v) { return (uint32_t)_
 __device__ __forceinline__ uint32_t c_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }   // lane i <- lane i+1
 
 #define CS_UNROLL 6
+#ifndef CS_KO
+#define CS_KO 0           // knock-out timing experiments (tools/build_variant.sh): 1 loads hit one row, 2 no level-0 stores, 4 no level-1
+#endif                    // stores, 8 no LUT look-ups, 16 no blend, 32 no pyrDown sums / level-1 rows
 #define CS_MAX_STRIPS 8
 // UNAL: w % 4 != 0 or an odd level-1 width (the generic right edge); false keeps the w % 4 == 0 instance free of its per-lane
 // selectors (they cost three spilled registers at this kernel's 80-VGPR budget)
-template <bool UNAL>
-__global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
-                                                                          uint8_t *__restrict__ dst)
+// FUSED (round 4): the work-group has one more wavefront, which computes the tile LUTs (clahe_lut_tiles: histogram, clip, scan) of the
+// NEXT row of tiles while the strips walk the current row of cells -- the LDS-atomic-bound half of CLAHE runs beside the store- and
+// latency-bound half on the same CU, the LUTs never leave LDS (a ring of two rows of tiles), the source rows are fetched from HBM once
+// (the strips find them in L2 half a tile later), and k_clahe_lut's launch is gone.  The first row of tiles is shared by all wavefronts
+// before the walk starts.  Every wavefront passes the same 2 (cell rows) barriers.
+template <bool UNAL, bool FUSED>
+__global__ __launch_bounds__(64 * (CS_MAX_STRIPS + 2), 6) void k_clahe_apply_pyr(ClaheParams P, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lut,
+                                                                                uint8_t *__restrict__ dst)
 {
     extern __shared__ __align__(16) unsigned char clahe_smem[];
     uint32_t *lut4 = (uint32_t *)clahe_smem;                            // (tiles_x + 1 cell columns) x 256 packed LUT quadruples
+    uint8_t *ring = clahe_smem + (size_t)(P.tiles_x + 1) * 1024;          // FUSED: LUT bytes of two rows of tiles (row ty in slot ty & 1)
     // one work-group per image, one wavefront per column strip: the strips share the LUT table (two barriers per row of cells),
     // everything else is wave-private
     const int b = blockIdx.x, s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, ndw = (P.w + 3) >> 2, wr = UNAL ? (P.w & 3) : 0;
+    uint32_t *hist_w = (uint32_t *)(ring + (size_t)2 * P.tiles_x * 256) + s * CH_WAVE_DW;       // FUSED: this wavefront's histogram
+    auto lut_row = [&](int ty, int tx0, int txstep) {                   // FUSED: LUTs of the tiles tx0, tx0 + txstep, .. of tile row ty
+        uint8_t *slot = ring + (size_t)(ty & 1) * P.tiles_x * 256 - (size_t)ty * P.tiles_x * 256 + 4 * lane;
+        clahe_lut_tiles<!UNAL>(P, src + (long long)b * P.src_item_stride, hist_w, lane, ty * P.tiles_x + tx0, (ty + 1) * P.tiles_x, txstep,
+                               [&](int t, uint32_t packed) { *(uint32_t *)(slot + (size_t)t * 256) = packed; });
+    };
     typedef uint32_t cs_u32_a1 __attribute__((aligned(1)));             // source rows of any alignment (KITTI: 1241-byte rows)
+    const int cmin = 0, ncell = P.tiles_x + 1;
+    const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;
+    auto cell_row = [&](int y) { return (int)floorf((float)y * P.inv_th - 0.5f) + 1; };
+    int cy = -1, y_switch = 0;                                          // rows [.., y_switch) belong to the row of cells cy
+    auto build = [&](int cyv) {                                         // the packed table of the row of cells cyv, by the whole work-group
+        const int ty1 = max(cyv - 1, 0), ty2 = min(cyv, P.tiles_y - 1);
+        const uint8_t *L1 = FUSED ? ring + (size_t)(ty1 & 1) * P.tiles_x * 256 : L + (size_t)ty1 * P.tiles_x * 256;
+        const uint8_t *L2 = FUSED ? ring + (size_t)(ty2 & 1) * P.tiles_x * 256 : L + (size_t)ty2 * P.tiles_x * 256;
+        __syncthreads();                                                // the previous table's look-ups are done (FUSED: and tile row cyv's LUTs)
+        for (int e = threadIdx.x; e < ncell * 64; e += blockDim.x) {
+            const int cx = cmin + (e >> 6), v4 = (e & 63) * 4;
+            const int tx1 = max(cx - 1, 0), tx2 = min(cx, P.tiles_x - 1);
+            const uint32_t a = *(const uint32_t *)(L1 + tx1 * 256 + v4), bb = *(const uint32_t *)(L1 + tx2 * 256 + v4);
+            const uint32_t c = *(const uint32_t *)(L2 + tx1 * 256 + v4), dd = *(const uint32_t *)(L2 + tx2 * 256 + v4);
+            const uint32_t ab01 = __builtin_amdgcn_perm(bb, a, 0x05010400u), ab23 = __builtin_amdgcn_perm(bb, a, 0x07030602u);
+            const uint32_t cd01 = __builtin_amdgcn_perm(dd, c, 0x05010400u), cd23 = __builtin_amdgcn_perm(dd, c, 0x07030602u);
+            c_u32x4 o;
+            o.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u); o.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
+            o.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u); o.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
+            *(c_u32x4 *)(lut4 + ((e >> 6) << 8) + v4) = o;
+        }
+        __syncthreads();
+    };
+    if (FUSED) {
+        if (!(CS_KO & 1024)) lut_row(0, s, P.nstrips + P.nlut);              // the first row of tiles: all wavefronts
+        if (s >= P.nstrips) {                                           // the LUT wavefront: one row of tiles ahead of the strips
+            const int n_cell_rows = cell_row(P.h - 1) + 1;              // (the strips stage every row of cells once, in order)
+#ifndef CS_LUT_PRIO
+#define CS_LUT_PRIO 3
+#endif
+            __builtin_amdgcn_s_setprio(CS_LUT_PRIO);                    // one wavefront against 3: it must not wait for issue slots
+            for (int c = 0; c < n_cell_rows; c++) {
+                build(c);
+                if (c + 1 < P.tiles_y && !(CS_KO & 512)) lut_row(c + 1, s - P.nstrips, P.nlut);
+            }
+            return;
+        }
+    }
     // core columns of strip s: 63 (first), 62 (middle), <= 63 (last); lane 0 of every strip but the first is the left halo
     const int core0 = s == 0 ? 0 : 63 + 62 * (s - 1);
     const int core1 = s == P.nstrips - 1 ? ndw : 63 + 62 * s;
@@ -443,7 +506,6 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     const int d = min(d_raw, ndw - 1);                                  // lanes beyond the image recompute (and re-store) the last column
     const bool core = d_raw >= core0 && d_raw < core1;
     const int xb = 4 * d;
-    const int cmin = 0, ncell = P.tiles_x + 1;
     float xa[4], xa1[4];
     const uint32_t *lutc[4];
 #pragma unroll
@@ -454,7 +516,6 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
         lutc[k] = lut4 + ((fx + 1 - cmin) << 8);
     }
     const c_f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
-    const uint8_t *L = lut + (long long)b * P.tiles_x * P.tiles_y * 256;
     uint8_t *dimg = dst + (long long)b * P.dst_item_stride;
     uint8_t *l1 = dimg + P.l1_delta;
     const int win = P.border;
@@ -474,7 +535,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     const bool dup = d_raw > ndw - 1;                                   // lanes beyond the image recompute the last column: their stores go to the slack
     const uint32_t pad0 = 4u * nb0, pad1 = 2u * nb1;
     // stores of lanes without a border column: the alignment slack right of the border (never consumed, inside the row pitch)
-    const uint32_t slack0 = pad0 + 4u * (uint32_t)((P.w + win + 3) >> 2), slack1 = pad1 + 2u * (uint32_t)((P.l1_w + win + 3) >> 1);
+    const uint32_t slack0 = pad0 + 4u * (uint32_t)((P.w + win + 3) >> 2) + ((CS_KO & 256) ? 4u * lane : 0u), slack1 = pad1 + 2u * (uint32_t)((P.l1_w + win + 3) >> 1) + ((CS_KO & 256) ? 2u * lane : 0u);
     const uint32_t o0 = dup ? slack0 : pad0 + 4u * d;
     // right border dword of this lane: pixels p[top], p[top-1], p[top-2], p[top-3] at x0 = 2 (w - 1) - top, top = xb + 2 (w even)
     // or xb (w odd): the choice that makes x0 a multiple of 4; both windows lie inside (left neighbour's dword, own dword)
@@ -492,37 +553,23 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     const uint32_t xo = (d == ndw - 1 && wr) ? (uint32_t)(P.w - 4) : (uint32_t)xb;
     const uint32_t in_sh = (d == ndw - 1 && wr) ? 8u * (4u - (uint32_t)wr) : 0u;
 
-    auto cell_row = [&](int y) { return (int)floorf((float)y * P.inv_th - 0.5f) + 1; };
-    int cy = -1, y_switch = 0;                                          // rows [.., y_switch) belong to the row of cells cy
     auto stage = [&](int y) {
         cy = cell_row(y);
         int yn = max(y + 1, (int)(((float)cy + 0.5f) * (float)P.th) - 2);
         while (yn < P.h && cell_row(yn) == cy) yn++;
         y_switch = yn;
-        const int ty1 = max(cy - 1, 0), ty2 = min(cy, P.tiles_y - 1);
-        __syncthreads();                                                // the previous table's look-ups are done
-        for (int e = threadIdx.x; e < ncell * 64; e += blockDim.x) {
-            const int cx = cmin + (e >> 6), v4 = (e & 63) * 4;
-            const int tx1 = max(cx - 1, 0), tx2 = min(cx, P.tiles_x - 1);
-            const uint32_t a = *(const uint32_t *)(L + (ty1 * P.tiles_x + tx1) * 256 + v4), bb = *(const uint32_t *)(L + (ty1 * P.tiles_x + tx2) * 256 + v4);
-            const uint32_t c = *(const uint32_t *)(L + (ty2 * P.tiles_x + tx1) * 256 + v4), dd = *(const uint32_t *)(L + (ty2 * P.tiles_x + tx2) * 256 + v4);
-            const uint32_t ab01 = __builtin_amdgcn_perm(bb, a, 0x05010400u), ab23 = __builtin_amdgcn_perm(bb, a, 0x07030602u);
-            const uint32_t cd01 = __builtin_amdgcn_perm(dd, c, 0x05010400u), cd23 = __builtin_amdgcn_perm(dd, c, 0x07030602u);
-            c_u32x4 o;
-            o.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u); o.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
-            o.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u); o.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
-            *(c_u32x4 *)(lut4 + ((e >> 6) << 8) + v4) = o;
-        }
-        __syncthreads();
+        build(cy);
     };
     // a level-0 row: every lane's dword and, in the edge strips, the border dword
     auto put0 = [&](uint8_t *row, uint32_t v, uint32_t bv) {
+        if ((CS_KO & 2) && v != 0x12345678u) return;
         *(uint32_t *)(row + o0) = v;
-        if (edge_strip) *(uint32_t *)(row + o0b) = bv;
+        if (edge_strip && !(CS_KO & 64)) *(uint32_t *)(row + o0b) = bv;
     };
     auto put1 = [&](uint8_t *row, uint32_t v, uint32_t bv) {               // a level-1 row: pixel pairs
+        if ((CS_KO & 4) && v != 0x12345678u) return;
         *(uint16_t *)(row + o1) = (uint16_t)v;
-        if (edge_strip) *(uint16_t *)(row + o1b) = (uint16_t)bv;
+        if (edge_strip && !(CS_KO & 128)) *(uint16_t *)(row + o1b) = (uint16_t)bv;
     };
     typedef unsigned short cu16x2 __attribute__((ext_vector_type(2)));
     uint8_t *r1 = d1m;                                                  // level-1 row of the next emit
@@ -530,6 +577,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     // The REFLECT_101 border mirrors rows 1 .. win above the image and rows h1-1-win .. h1-2 below it: the same stores once more
     auto emit = [&](int Y, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4, auto mirror_c) {
         constexpr bool MIRROR = decltype(mirror_c)::value;
+        if (CS_KO & 32) { if (c4 == 0x12345678u) *(uint32_t *)r1 = c4; return; }
         const cu16x2 s0 = __builtin_bit_cast(cu16x2, c0), s1 = __builtin_bit_cast(cu16x2, c1), s2 = __builtin_bit_cast(cu16x2, c2),
                      s3 = __builtin_bit_cast(cu16x2, c3), s4 = __builtin_bit_cast(cu16x2, c4);
         const cu16x2 v = (s2 * (unsigned short)6 + (s1 + s3) * (unsigned short)4 + s0 + s4 + (unsigned short)128) >> (unsigned short)8;
@@ -561,7 +609,9 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
         const float tyf = (float)y * P.inv_th - 0.5f;
         const float ya = tyf - (float)(cy - 1), ya1 = 1.0f - ya;
         const c_f32x2 YA = {ya, ya}, YB = {ya1, ya1};
-        const uint32_t q0 = lutc[0][in & 0xFF], q1 = lutc[1][(in >> 8) & 0xFF], q2 = lutc[2][(in >> 16) & 0xFF], q3 = lutc[3][in >> 24];
+        uint32_t q0, q1, q2, q3;
+        if (CS_KO & 8) { q0 = in * 0x01010101u; q1 = in ^ 0x55u; q2 = in + 0x01020304u; q3 = in >> 3; }
+        else { q0 = lutc[0][in & 0xFF]; q1 = lutc[1][(in >> 8) & 0xFF]; q2 = lutc[2][(in >> 16) & 0xFF]; q3 = lutc[3][in >> 24]; }
         const c_f32x2 A11 = {c_ub(q0, 0), c_ub(q1, 0)}, A12 = {c_ub(q0, 1), c_ub(q1, 1)}, A21 = {c_ub(q0, 2), c_ub(q1, 2)}, A22 = {c_ub(q0, 3), c_ub(q1, 3)};
         const c_f32x2 B11 = {c_ub(q2, 0), c_ub(q3, 0)}, B12 = {c_ub(q2, 1), c_ub(q3, 1)}, B21 = {c_ub(q2, 2), c_ub(q3, 2)}, B22 = {c_ub(q2, 3), c_ub(q3, 3)};
         const c_f32x2 r01 = (A11 * XB01 + A12 * XA01) * YB + (A21 * XB01 + A22 * XA01) * YA;
@@ -573,6 +623,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
         const uint32_t u0 = __builtin_bit_cast(uint32_t, (float)m01.x), u1 = __builtin_bit_cast(uint32_t, (float)m01.y);
         const uint32_t u2 = __builtin_bit_cast(uint32_t, (float)m23.x), u3 = __builtin_bit_cast(uint32_t, (float)m23.y);
         uint32_t out = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u3, u2, 0x0c0c0400u), __builtin_amdgcn_perm(u1, u0, 0x0c0c0400u), 0x05040100u);
+        if (CS_KO & 16) out = q0 + q1 + q2 + q3;
         // neighbours: pixels xb-2, xb-1 (left lane's bytes 2, 3) and xb+4 (right lane's byte 0); REFLECT_101 at the image edge
         uint32_t lf = c_wave_shr1(out), rt = c_wave_shl1(out);
         if (first_col) lf = __builtin_amdgcn_perm(out, out, 0x01020000u);      // (.., .., p2, p1)
@@ -591,6 +642,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
             if (y >= P.h - 1 - win && y <= P.h - 2) put0(d0m + (long long)(2 * (P.h - 1) - y) * P.dst_stride, out, bv);
         }
         // pyrDown, horizontal: sums centred on pixels xb and xb + 2
+        if (CS_KO & 32) { hE += out; return; }
         const uint32_t l0 = __builtin_amdgcn_alignbyte(out, lf, 2);
         const uint32_t h0 = __builtin_amdgcn_udot4(l0, 0x04060401u, __builtin_amdgcn_udot4(out, 0x00010000u, 0u, false), false);
         const uint32_t h1 = __builtin_amdgcn_udot4(out, 0x04060401u, __builtin_amdgcn_udot4(rt, 0x00000001u, 0u, false), false);
@@ -603,7 +655,7 @@ __global__ __launch_bounds__(64 * CS_MAX_STRIPS, 6) void k_clahe_apply_pyr(Clahe
     for (int yb = 0; yb < P.h; yb += CS_UNROLL) {
         if (yb + 2 * CS_UNROLL <= P.h) {
 #pragma unroll
-            for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = *(const cs_u32_a1 *)(srow + xo) >> (UNAL ? in_sh : 0u); srow += P.stride; }
+            for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = *(const cs_u32_a1 *)(srow + xo) >> (UNAL ? in_sh : 0u); if (!(CS_KO & 1)) srow += P.stride; }
         } else {
 #pragma unroll
             for (int u = 0; u < CS_UNROLL; u++)
@@ -662,7 +714,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     OV2_HIP_CHECK(attr_err);
     ClaheParams P;
     P.border = border;
-    P.nstrips = 0; P.l1_delta = 0; P.l1_pitch = P.l1_w = P.l1_h = 0;
+    P.nstrips = 0; P.nlut = 0; P.l1_delta = 0; P.l1_pitch = P.l1_w = P.l1_h = 0;
     int ew = w, eh = h;
     if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
     P.w = w; P.h = h; P.stride = stride; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
@@ -678,30 +730,46 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
     const bool src_al = ((stride | (int)(size_t)src_d | (int)src_batch_stride) & 3) == 0;
     P.ysplit = (long long)batch * (tiles_y + 1) >= 256 ? 1 : (P.th >= 48 ? 6 : (P.th >= 16 ? 3 : 1));
     P.batch = batch; P.gx_lut = (tiles_x * tiles_y + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
-    hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
-    // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk
-    // (OV2_OPT_CLAHE_STRIPS = 1 forces it for any batch, 0 disables it -- A/B runs, parity tests of both paths)
+    // Batch mode, destination = level 0 of a pyramid: the strip kernel also writes level 1 and both borders in the same walk, and
+    // in its fused form computes the LUTs as well (OV2_OPT_CLAHE_STRIPS: 2 forces the fused kernel for any batch, 1 the strip kernel
+    // after k_clahe_lut, 0 the separate kernels -- A/B runs, parity tests of all paths)
+    bool lut_launched = false;
+    auto launch_lut = [&] {
+        if (!lut_launched) hipLaunchKernelGGL(src_al ? k_clahe_lut<true> : k_clahe_lut<false>, dim3(P.gx_lut * batch), dim3(256), 0, ctx->stream, P, src_d, lut_d);
+        lut_launched = true;
+    };
     if (pyr && pyr->n_levels >= 2 && border == pyr->win && w >= 64 && h >= 8 && 2 * ((border + 3) / 4) + 1 <= (w + 3) / 4 &&
         (((size_t)dst_d | (size_t)dst_stride | dst_batch_stride) & 3) == 0 && (pyr->lv[1].img_pitch & 1) == 0) {
         const int ndw = (w + 3) / 4, nstrips = ndw <= 64 ? 1 : 2 + (ndw - 126 + 61) / 62;
-        const bool want = ctx->clahe_strips >= 0 ? ctx->clahe_strips == 1 : (long long)batch * nstrips >= 1024;
+        const bool want = ctx->clahe_strips >= 0 ? ctx->clahe_strips >= 1 : (long long)batch * nstrips >= 1024;
         if (want && nstrips <= CS_MAX_STRIPS && tiles_x + 1 <= 40) {
             static std::once_flag strip_once;
             static hipError_t strip_err = hipSuccess;
             std::call_once(strip_once, [] {
-                strip_err = hipFuncSetAttribute((const void *)k_clahe_apply_pyr<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
-                if (strip_err == hipSuccess) strip_err = hipFuncSetAttribute((const void *)k_clahe_apply_pyr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
+                const void *fn[4] = {(const void *)k_clahe_apply_pyr<false, false>, (const void *)k_clahe_apply_pyr<true, false>,
+                                     (const void *)k_clahe_apply_pyr<false, true>, (const void *)k_clahe_apply_pyr<true, true>};
+                for (int i = 0; i < 4 && strip_err == hipSuccess; i++) strip_err = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
             });
             OV2_HIP_CHECK(strip_err);
             P.nstrips = nstrips;
             P.l1_delta = pyr->lv[1].img_roi - pyr->lv[0].img_roi; P.l1_pitch = pyr->lv[1].img_pitch; P.l1_w = pyr->lv[1].w; P.l1_h = pyr->lv[1].h;
             const bool unal = (w & 3) != 0 || (pyr->lv[1].w & 1) != 0;
-            hipLaunchKernelGGL(unal ? k_clahe_apply_pyr<true> : k_clahe_apply_pyr<false>, dim3(batch), dim3(64 * nstrips), (size_t)(tiles_x + 1) * 1024, ctx->stream, P, src_d, lut_d, dst_d);
+            // fused form: the aligned instance takes aligned sources only (its LUT wavefront uses the aligned-dword tile loads)
+            const bool fused = (ctx->clahe_strips == 2 || ctx->clahe_strips < 0) && (unal || src_al);
+            if (fused) {
+                P.nlut = 1;
+                const size_t lds = (size_t)(tiles_x + 1) * 1024 + (size_t)2 * tiles_x * 256 + (size_t)(nstrips + P.nlut) * CH_WAVE_DW * 4;
+                hipLaunchKernelGGL((unal ? k_clahe_apply_pyr<true, true> : k_clahe_apply_pyr<false, true>), dim3(batch), dim3(64 * (nstrips + P.nlut)), lds, ctx->stream, P, src_d, lut_d, dst_d);
+            } else {
+                launch_lut();
+                hipLaunchKernelGGL((unal ? k_clahe_apply_pyr<true, false> : k_clahe_apply_pyr<false, false>), dim3(batch), dim3(64 * nstrips), (size_t)(tiles_x + 1) * 1024, ctx->stream, P, src_d, lut_d, dst_d);
+            }
             OV2_HIP_CHECK(hipGetLastError());
             if (level1_done) *level1_done = 1;
             return OV2_OK;
         }
     }
+    launch_lut();
     const size_t apply_lds = (size_t)(tiles_x + 1) * 1024;
     // one thread per dword column; several column passes only for images wider than 2048 pixels
     const int ndw = (w + 3) / 4, passes = (ndw + 511) / 512;

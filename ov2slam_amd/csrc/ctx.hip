@@ -160,7 +160,7 @@ int ov2_ctx_set_option(ov2_ctx *ctx, int option, int value)
         OV2_REQUIRE(value == OV2_TRACK_IMPL_WAVE || value == OV2_TRACK_IMPL_ROW, OV2_EINVAL, "unknown tracker kernel choice");
         ctx->track_impl = value; return OV2_OK;
     case OV2_OPT_CLAHE_STRIPS:
-        OV2_REQUIRE(value >= -1 && value <= 1, OV2_EINVAL, "OV2_OPT_CLAHE_STRIPS takes -1, 0 or 1");
+        OV2_REQUIRE(value >= -1 && value <= 2, OV2_EINVAL, "OV2_OPT_CLAHE_STRIPS takes -1, 0, 1 or 2");
         ctx->clahe_strips = value; return OV2_OK;
     case OV2_OPT_BA_FORCE_LARGE:     ctx->ba_force_large = value != 0; return OV2_OK;
     case OV2_OPT_BA_LIN_DIRECT:      ctx->ba_lin_direct = value != 0; return OV2_OK;

@@ -112,14 +112,14 @@ def test_fused_preprocess_from_host_image(gpu_ctx, oracle):
                                        ((1241, 376), (24, 7)), ((1242, 375), (24, 7)), ((1226, 370), (24, 7)), ((103, 57), (3, 2)),
                                        ((751, 97), (15, 2)), ((253, 64), (5, 1)), ((66, 40), (2, 1)), ((67, 41), (1, 1))])
 def test_strip_kernel_equals_oracle_pyramid(gpu_ctx, oracle, wh, tiles):
-    """k_clahe_apply_pyr (batch mode's CLAHE apply + level 1 + both borders in one walk, forced here with OV2_OPT_CLAHE_STRIPS = 1):
+    """k_clahe_apply_pyr (batch mode's CLAHE apply + level 1 + both borders in one walk, forced here with OV2_OPT_CLAHE_STRIPS = 1, and = 2: fused with the LUT computation):
     every level, borders included, equals CLAHE (oracle) followed by the pyramid (oracle) -- one to four column strips,
     odd heights, cell columns narrower than a strip."""
     w, h = wh
     rng = np.random.default_rng(w + h)
     for img in (synth.frame_pair(w, h, seed=w + h)[0], rng.integers(0, 256, (h, w), dtype=np.uint8)):
         ref = oracle.Pyramid(oracle.clahe(img, 3.0, tiles[0], tiles[1]), 9, 3)
-        for force in (1, 0):
+        for force in (2, 1, 0):
             with gpu_ctx.options(clahe_strips=force):
                 P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(img, 3.0, tiles[0], tiles[1])
             assert P.levels == ref.levels
@@ -138,10 +138,11 @@ def test_strip_kernel_equals_separate_kernels_random_geometry(gpu_ctx):
         tx = int(rng.integers(1, max(2, min(30, w // 8)))); ty = int(rng.integers(1, max(2, min(12, h // 8))))
         img = rng.integers(0, 256, (h, w), dtype=np.uint8)
         out = {}
-        for force in (1, 0):
+        for force in (2, 1, 0):
             with gpu_ctx.options(clahe_strips=force):
                 P = ov2slam_amd.Pyramid(gpu_ctx, w, h, win, 3).build_clahe(img, 2.5, tx, ty)
             out[force] = [P.download(l, padded=True)[0] for l in range(P.levels)]
             P.close()
-        for l, (a, b) in enumerate(zip(out[1], out[0])):
-            assert np.array_equal(a, b), (case, win, w, h, tx, ty, l, np.argwhere(a != b)[:4].tolist())
+        for force in (1, 2):
+            for l, (a, b) in enumerate(zip(out[force], out[0])):
+                assert np.array_equal(a, b), (case, force, win, w, h, tx, ty, l, np.argwhere(a != b)[:4].tolist())

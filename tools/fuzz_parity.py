@@ -40,7 +40,7 @@ for case in range(N):
     w, h = int(rng.integers(64, 900)), int(rng.integers(48, 520))
     if rng.integers(0, 2): w = 4 * (w // 4)                            # dword-multiple widths: the strip kernel's geometry
     # batch mode's strip kernel (CLAHE apply + level 1 + borders in one walk) forced on / off per case (read at every launch)
-    ctx.set_option(L.OV2_OPT_CLAHE_STRIPS, 1 if rng.integers(0, 2) else 0)
+    ctx.set_option(L.OV2_OPT_CLAHE_STRIPS, int(rng.integers(0, 3)))       # separate kernels / strip kernel / fused strip kernel
     kind = int(rng.integers(0, 4))
     prev = rand_image(w, h, kind)
     shift = rng.uniform(-6, 6, 2)
