@@ -992,6 +992,10 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #define CH_SKIP_W4 0        // 1: wavefront 4 (same SIMD as the factorising wavefront 0) owns no panel rows -- measured: no difference
 #endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
+#define CH_MAX_LDS_N 479   // k_ba_cholesky (512 threads): the right-hand side rides as a panel row, n - 32 + 1 <= 512 - 64; larger systems: HBM path
+// dynamic LDS of k_ba_cholesky: diagonal block, solution vector, panel (rows rounded up to whole 16-row MFMA tiles: the trailing
+// update reads its operand rows unpredicated)
+static inline size_t chol_lds_bytes(int nf, int nfp) { return 8 * ((size_t)CH_NB * CH_LDP + 2 * (size_t)nfp + (size_t)((std::max(0, nf - CH_NB) + 15) & ~15) * CH_LDP) + 64; }
 
 // The two triangular solves L y = rhs, L^T x = y on the factor in S (HBM) with the inverse diagonal blocks in Linv; yv (LDS, nfp
 // doubles) holds rhs on entry and x on return, L11 is a CH_NB x CH_LDP LDS scratch.  One work-group.
@@ -1024,7 +1028,52 @@ __device__ __forceinline__ void chol_trisolve(const BADev &D, double *L11, doubl
         }
         __syncthreads();
     }
-    // backward substitution  L^T x = y:  x_blk = Linv_blk^T (y_blk - L[below, blk]^T x[below])
+    // backward substitution  L^T x = y, right-looking by blocks, last block first:  x_blk = Linv_blk^T y_blk, then
+    // y[0:k0] -= L[blk, 0:k0]^T x_blk.  Nothing the loop loads depends on x: thread t keeps column t of the block row L[blk, 0:k0]
+    // (32 doubles, coalesced over t) and its share of Linv_blk in registers, requested one block ahead, so that a block costs two
+    // barriers and 2 x 32 FMAs instead of a dependent walk over L in L2 with three barriers (round 4: 44 -> ~12 us at n = 300).
+    if (n <= nt && nt >= 256) {
+        const int nblk = (n + CH_NB - 1) / CH_NB;
+        constexpr int NINV = CH_NB * CH_NB / 256;                // Linv doubles per thread at the smallest work-group (256)
+        double cur[CH_NB], nxt[CH_NB], winv[NINV], ninv[NINV];
+        auto load_rows = [&](int k0, int nb, double (&v)[CH_NB]) {
+#pragma unroll
+            for (int i = 0; i < CH_NB; i++) v[i] = (tid < k0 && i < nb) ? S[(long long)(k0 + i) * ld + tid] : 0.0;
+        };
+        auto load_inv = [&](int blk, double (&w)[NINV]) {
+#pragma unroll
+            for (int u = 0; u < NINV; u++) { const int e = tid + u * nt; w[u] = e < CH_NB * CH_NB ? Linv[(long long)blk * CH_NB * CH_NB + e] : 0.0; }
+        };
+        load_rows((nblk - 1) * CH_NB, n - (nblk - 1) * CH_NB, cur);
+        load_inv(nblk - 1, winv);
+        for (int blk = nblk - 1; blk >= 0; blk--) {
+            const int k0 = blk * CH_NB, nb = min(CH_NB, n - k0);
+#pragma unroll
+            for (int u = 0; u < NINV; u++) { const int e = tid + u * nt; if (e < CH_NB * CH_NB) L11[(e >> 5) * CH_LDP + (e & 31)] = winv[u]; }
+            if (blk > 0) { load_rows(k0 - CH_NB, CH_NB, nxt); load_inv(blk - 1, ninv); }
+            __syncthreads();                                     // the inverse block is staged, y carries every later block's update
+            if (tid < CH_NB) {
+                double r = 0;
+                for (int k = tid; k < nb; k++) r += L11[k * CH_LDP + tid] * yv[k0 + k];     // Linv^T
+                s_red[tid][32] = tid < nb ? r : 0.0;
+            }
+            __syncthreads();
+            if (tid < nb) yv[k0 + tid] = s_red[tid][32];
+            if (tid < k0) {
+                double acc = yv[tid];
+#pragma unroll
+                for (int i = 0; i < CH_NB; i++) acc -= cur[i] * s_red[i][32];
+                yv[tid] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < CH_NB; i++) cur[i] = nxt[i];
+#pragma unroll
+            for (int u = 0; u < NINV; u++) winv[u] = ninv[u];
+        }
+        __syncthreads();
+        return;
+    }
+    // (systems wider than the work-group: the large-problem path) left-looking, x_blk = Linv_blk^T (y_blk - L[below, blk]^T x[below])
     for (int k0 = ((n - 1) / CH_NB) * CH_NB; k0 >= 0; k0 -= CH_NB) {
         const int nb = min(CH_NB, n - k0);
         // lanes along the block's columns (coalesced), thread groups along the rows below
@@ -1050,6 +1099,62 @@ __device__ __forceinline__ void chol_trisolve(const BADev &D, double *L11, doubl
     }
 }
 
+// Backward substitution  L^T x = y  on the factor in S WITHOUT inverse diagonal blocks (k_ba_cholesky, round 4): right-looking by
+// blocks, last block first.  Wavefront 0 solves the block itself -- lane j keeps column j of the 32 x 32 diagonal block in registers
+// and the 32 unknowns go by, last first: x_i = y_i / L_ii in lane i, broadcast by v_readlane, y_j -= L_ij x_i in the lanes j < i --;
+// the other wavefronts then take the block's unknowns out of everything above: thread t keeps column t of the block row L[blk, 0:k0]
+// in registers.  Nothing that is loaded depends on x: both register sets are requested one block ahead.  yv holds y on entry and x on
+// return; rd_all = 1 / L_ii of all n unknowns (kept from the factorisation); needs n - 32 <= blockDim - 64.
+__device__ __forceinline__ void chol_backward_blocks(const BADev &D, double *yv, const double *rd_all, double *s_x)
+{
+    const int n = D.nf, ld = D.nfp, tid = threadIdx.x, lane = tid & 63, t = tid - 64;
+    const bool w0 = tid < 64;
+    const double *S = D.S;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    double cur[CH_NB], nxt[CH_NB], nx2[CH_NB];                   // two blocks ahead: a block's own work is ~1 us, its 32 loads per thread ~3 us
+    auto load = [&](int k0, int nb, double (&v)[CH_NB]) {
+        const double *col = S + (long long)k0 * ld + (w0 ? k0 + lane : t);
+        const bool mine = w0 ? lane < nb : t < k0;
+#pragma unroll
+        for (int i = 0; i < CH_NB; i++) v[i] = (mine && i < nb && (!w0 || i > lane)) ? col[(long long)i * ld] : 0.0;   // w0: L[i][lane] of the diagonal block; else L[k0 + i][t]
+    };
+    load((nblk - 1) * CH_NB, n - (nblk - 1) * CH_NB, cur);
+#pragma unroll
+    for (int i = 0; i < CH_NB; i++) nxt[i] = 0.0;
+    if (nblk > 1) load((nblk - 2) * CH_NB, CH_NB, nxt);
+    for (int blk = nblk - 1; blk >= 0; blk--) {
+        const int k0 = blk * CH_NB, nb = min(CH_NB, n - k0);
+#pragma unroll
+        for (int i = 0; i < CH_NB; i++) nx2[i] = 0.0;
+        if (blk > 1) load(k0 - 2 * CH_NB, CH_NB, nx2);
+        __syncthreads();                                         // y carries every later block's update
+        if (w0) {
+            double y = lane < nb ? yv[k0 + lane] : 0.0;
+            const double rd = lane < nb ? rd_all[k0 + lane] : 0.0;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                             // (keeps the 64 lane masks below out of spilled scalar registers)
+#pragma unroll
+            for (int i = CH_NB - 1; i >= 0; i--) {
+                const double xl = y * rd;
+                const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), i), __builtin_amdgcn_readlane(__double2loint(xl), i));
+                y = ln == i ? xi : (ln < i ? y - cur[i] * xi : y);
+            }
+            if (lane < CH_NB) s_x[lane] = y;
+            if (lane < nb) yv[k0 + lane] = y;
+        }
+        __syncthreads();
+        if (!w0 && t < k0) {
+            double acc = yv[t];
+#pragma unroll
+            for (int i = 0; i < CH_NB; i++) acc -= cur[i] * s_x[i];
+            yv[t] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < CH_NB; i++) { cur[i] = nxt[i]; nxt[i] = nx2[i]; }
+    }
+    __syncthreads();
+}
+
 // lower triangle of S, one thread per entry, many workgroups (latency-bound gathers from H and G)
 __global__ __launch_bounds__(256) void k_ba_assemble(BADev D)
 {
@@ -1073,6 +1178,7 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     double *L11 = (double *)smem_raw;                       // CH_NB x CH_LDP : diagonal block / its inverse
     double *yv = L11 + CH_NB * CH_LDP;                      // nfp
     double *P = yv + D.nfp;                                 // (n - CH_NB) x CH_LDP : panel below the diagonal block
+    double *rd_all = P + (size_t)((max(0, D.nf - CH_NB) + 15) & ~15) * CH_LDP;   // nfp: reciprocal pivots of all unknowns (backward substitution)
     const int n = D.nf, ld = D.nfp, tid = threadIdx.x, nt = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63;
     __shared__ int s_fail;
@@ -1129,6 +1235,11 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
 #pragma unroll
             for (int j = 0; j < CH_NB; j++) a[j] = lane < CH_NB ? L11[lane * CH_LDP + j] : 0.0;
             bool fail = false;
+            // (the lane index of THIS panel step: compared against the 32 column numbers below.  Without the laundering the compiler
+            // hoists all 64 lane masks out of the panel loop and parks them in spilled scalar registers -- 470 v_writelane / 1000
+            // v_readlane with their wait states, on the one wavefront everybody waits for)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
             // Column c needs  a[c] - sum_{k<c} a[k] L[c][k]  of every row.  All terms but the last (k = c-1) are known one
             // column earlier: they are accumulated -- in the same order, so bit-identically -- while the previous pivot's
             // sqrt / divide chain is in flight; the pivot itself is broadcast with v_readlane instead of ds_bpermute.
@@ -1139,11 +1250,19 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                 if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];              // row c of L, final for k < c (broadcast read)
                 const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
                 if (c + 1 < CH_NB) {
-                    pnext = a[c + 1];
+                    // four partial sums: ONE accumulator made the column's terms a dependent chain of up to 31 fp64 FMAs on the
+                    // wavefront that every other one waits for (round 4; the factor changes in the last bits, parity is a tolerance)
+                    double p0 = a[c + 1], p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
-                    for (int k = 0; k < c; k++) pnext -= a[k] * L11[(c + 1) * CH_LDP + k];
+                    for (int k = 0; k < c; k++) {
+                        const double t = a[k] * L11[(c + 1) * CH_LDP + k];
+                        if ((k & 3) == 0) p0 -= t; else if ((k & 3) == 1) p1 -= t; else if ((k & 3) == 2) p2 -= t; else p3 -= t;
+                    }
+                    pnext = (p0 + p1) + (p2 + p3);
                 }
+#ifndef CH_EXP
                 if (!(d > 0.0) || !isfinite(d)) fail = true;
+#endif
                 // pivot through 1/sqrt(d): v_rsq_f64 seed (~2^-26) + two Newton steps, then L[c][c] = d r with one Heron
                 // correction and L[i][c] = sacc r -- 9 dependent instructions instead of the ~25 of sqrt() followed by a
                 // division, 32 times per block on the kernel's longest serial chain (and 15 KB less unrolled code)
@@ -1152,11 +1271,11 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                 r = fma(0.5 * r, fma(-(d * r), r, 1.0), r);
                 double dj = d * r;
                 dj = fma(0.5 * r, fma(-dj, dj, d), dj);
-                const double l = lane == c ? dj : sacc * r;
-                a[c] = lane >= c ? l : 0.0;
-                if (lane >= c && lane < CH_NB) L11[lane * CH_LDP + c] = a[c];
+                const double l = ln == c ? dj : sacc * r;
+                a[c] = ln >= c ? l : 0.0;
+                if (ln < CH_NB) L11[ln * CH_LDP + c] = a[c];                 // (lanes < c write the 0 of the upper triangle: never read)
                 // reciprocal pivot 1 / L[c][c]: r refined by one Newton step of the reciprocal (two FMAs, no division)
-                if (lane == c) s_rdiag[c] = fma(r, fma(-dj, r, 1.0), r);
+                if (ln == c) { const double rc = fma(r, fma(-dj, r, 1.0), r); s_rdiag[c] = rc; rd_all[k0 + c] = rc; }
                 wave_lds_sync();
                 if ((c & (CH_GRP - 1)) == CH_GRP - 1) __syncthreads();   // columns c-CH_GRP+1 .. c are published: the panel wavefronts may use them
             }
@@ -1196,20 +1315,18 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             }
         }
         __syncthreads();
-        // rows beyond the pipelined ones (only for reduced systems of more than ~420 unknowns): plain pass, the block is complete
+        // rows beyond the pipelined ones (only for reduced systems of more than ~480 unknowns): plain pass on the LDS rows, the
+        // block is complete.  Rolled on purpose: an unrolled copy of the 496-term row solve is 12 KB of code, and this kernel has
+        // to stay inside the 64 KB instruction cache (round 4: at 77 KB every panel step re-fetched its code from L2).
         for (int t = tid + (CH_SKIP_W4 ? nt - 128 : nt - 64); t < m; t += nt) {
-            double x[CH_NB];
-#pragma unroll
-            for (int j = 0; j < CH_NB; j++) x[j] = P[t * CH_LDP + j];
-#pragma unroll
+            double *xr = P + t * CH_LDP;
+#pragma nounroll
             for (int j = 0; j < CH_NB; j++) {
-                double acc = x[j];
-#pragma unroll
-                for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
-                x[j] = acc * s_rdiag[j];
+                double acc = xr[j];
+#pragma nounroll
+                for (int k = 0; k < j; k++) acc -= xr[k] * L11[j * CH_LDP + k];
+                xr[j] = acc * s_rdiag[j];
             }
-#pragma unroll
-            for (int j = 0; j < CH_NB; j++) P[t * CH_LDP + j] = x[j];
         }
         __syncthreads();
         if (rhs_row) {
@@ -1242,49 +1359,78 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             typedef double d4 __attribute__((ext_vector_type(4)));
             const int mb = (m + 15) >> 4, nwv = nt >> 6;
             const int lr = lane & 15, lk = lane >> 4;
-            // a wavefront takes tiles wave, wave + nwv, ... of the row-major lower-triangle enumeration, two at a time:
-            // the old S values of both tiles are requested first, then the two independent MFMA chains interleave
+            // A wavefront takes the tiles wv, wv + nwv, .. of the row-major lower-triangle enumeration, two at a time (two
+            // independent MFMA chains).  Round 4: the phase was a SUM of its parts (knock-outs: 24 us of tile bookkeeping -- a
+            // double-precision sqrt per tile index, 64-bit multiplies per element address, four predicates per element --, 31 us of
+            // MFMA, 9 us of loads, 6 us of LDS reads, 4 us of stores; two wavefronts per SIMD overlap little).  Now the tile
+            // walk is integer arithmetic on the scalar unit (wave-uniform), an element's address is a uniform base + one of four
+            // per-lane constants, operand rows are read unpredicated (garbage rows >= m only reach rows / columns that are not
+            // stored), and the old values of the next pair are requested before the chains of the current pair run.
             const int ntile = mb * (mb + 1) / 2;
-            auto tile_of = [&](int t, int &bi, int &bj) {            // t -> (bi, bj), bj <= bi
-                bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-                while (bi * (bi + 1) / 2 > t) bi--;
-                while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
-                bj = t - bi * (bi + 1) / 2;
-            };
-            for (int t0 = wave; t0 < ntile; t0 += 2 * nwv) {
-                const int t1 = t0 + nwv;
-                const bool has1 = t1 < ntile;
-                int bi0, bj0, bi1 = 0, bj1 = 0;
-                tile_of(t0, bi0, bj0);
-                if (has1) tile_of(t1, bi1, bj1);
-                double old0[4], old1[4];
-                double *dst0[4], *dst1[4];
-                bool ok0[4], ok1[4];
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            auto advance = [&](int &bi, int &bj, int step) { bj += step; while (bj > bi) { bj -= bi + 1; bi++; } };
+            int lo[4];                                              // element (lk + 4 r, lr) of a tile, in doubles from the tile's corner
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int i0 = bi0 * 16 + lk + 4 * r, j0 = bj0 * 16 + lr;
-                    ok0[r] = i0 < m && j0 <= i0;
-                    dst0[r] = S + (long long)(k0 + nb + i0) * ld + k0 + nb + j0;
-                    old0[r] = ok0[r] ? *dst0[r] : 0.0;
-                    const int i1 = bi1 * 16 + lk + 4 * r, j1 = bj1 * 16 + lr;
-                    ok1[r] = has1 && i1 < m && j1 <= i1;
-                    dst1[r] = S + (long long)(k0 + nb + i1) * ld + k0 + nb + j1;
-                    old1[r] = ok1[r] ? *dst1[r] : 0.0;
-                }
-                const int ra0 = bi0 * 16 + lr, rb0 = bj0 * 16 + lr, ra1 = bi1 * 16 + lr, rb1 = bj1 * 16 + lr;
+            for (int r = 0; r < 4; r++) lo[r] = (lk + 4 * r) * ld + lr;
+            double *Sc = S + (long long)(k0 + nb) * ld + k0 + nb;      // corner of the trailing matrix
+            const double *Pl = P + lr * CH_LDP + lk;                   // this lane's operand element of tile row 0
+            auto corner = [&](int bi, int bj) { return Sc + ((long long)bi * ld + bj) * 16; };
+            auto okmask = [&](int bi, int bj, int r) { return (16 * bi + lk + 4 * r < m) && (bi != bj || lr <= lk + 4 * r); };
+            auto fetch = [&](int bi, int bj, bool has, double (&o)[4]) {
+                const double *c = corner(bi, bj);
+#pragma unroll
+#if defined(CH_EXP) && (CH_EXP & 2)
+                for (int r = 0; r < 4; r++) o[r] = (has && okmask(bi, bj, r)) ? (double)lo[r] : 0.0;
+                (void)c;
+#else
+                for (int r = 0; r < 4; r++) o[r] = (has && okmask(bi, bj, r)) ? c[lo[r]] : 0.0;
+#endif
+            };
+            int bi0 = 0, bj0 = 0, bi1, bj1;
+            advance(bi0, bj0, wv);
+            bi1 = bi0; bj1 = bj0; advance(bi1, bj1, nwv);
+            double old0[4], old1[4];
+            fetch(bi0, bj0, wv < ntile, old0);
+            fetch(bi1, bj1, wv + nwv < ntile, old1);
+            for (int t0 = wv; t0 < ntile; t0 += 2 * nwv) {
+                const bool has1 = t0 + nwv < ntile;
+                int nbi0 = bi1, nbj0 = bj1, nbi1, nbj1;
+                advance(nbi0, nbj0, nwv);
+                nbi1 = nbi0; nbj1 = nbj0; advance(nbi1, nbj1, nwv);
+                double nold0[4], nold1[4];
+                fetch(nbi0, nbj0, t0 + 2 * nwv < ntile, nold0);
+                fetch(nbi1, nbj1, t0 + 3 * nwv < ntile, nold1);
+                const double *pa0 = Pl + bi0 * (16 * CH_LDP), *pb0 = Pl + bj0 * (16 * CH_LDP);
+                const double *pa1 = Pl + (has1 ? bi1 : bi0) * (16 * CH_LDP), *pb1 = Pl + (has1 ? bj1 : bj0) * (16 * CH_LDP);
                 d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
 #pragma unroll
                 for (int kk = 0; kk < CH_NB / 4; kk++) {
-                    const double a0 = ra0 < m ? P[ra0 * CH_LDP + 4 * kk + lk] : 0.0, b0 = rb0 < m ? P[rb0 * CH_LDP + 4 * kk + lk] : 0.0;
-                    const double a1 = (has1 && ra1 < m) ? P[ra1 * CH_LDP + 4 * kk + lk] : 0.0, b1 = (has1 && rb1 < m) ? P[rb1 * CH_LDP + 4 * kk + lk] : 0.0;
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c1, 0, 0, 0);
+#if defined(CH_EXP) && (CH_EXP & 1)
+                    c0[0] += pa0[4 * kk] * pb0[4 * kk]; c1[0] += pa1[4 * kk] * pb1[4 * kk];
+#else
+#if defined(CH_EXP) && (CH_EXP & 8)
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(bi0 + kk), (double)(bj0 - kk), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(bi1 * kk), (double)(bj1 + lk), c1, 0, 0, 0);
+#else
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa0[4 * kk], pb0[4 * kk], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1[4 * kk], pb1[4 * kk], c1, 0, 0, 0);
+#endif
+#endif
                 }
+                double *q0 = corner(bi0, bj0), *q1 = corner(bi1, bj1);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if (ok0[r]) *dst0[r] = old0[r] - c0[r];
-                    if (ok1[r]) *dst1[r] = old1[r] - c1[r];
+#if defined(CH_EXP) && (CH_EXP & 4)
+                    if (okmask(bi0, bj0, r) && c0[r] == 1.2345) q0[lo[r]] = old0[r] - c0[r];
+                    if (has1 && okmask(bi1, bj1, r) && c1[r] == 1.2345) q1[lo[r]] = old1[r] - c1[r];
+#else
+                    if (okmask(bi0, bj0, r)) q0[lo[r]] = old0[r] - c0[r];
+                    if (has1 && okmask(bi1, bj1, r)) q1[lo[r]] = old1[r] - c1[r];
+#endif
                 }
+                bi0 = nbi0; bj0 = nbj0; bi1 = nbi1; bj1 = nbj1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { old0[r] = nold0[r]; old1[r] = nold1[r]; }
             }
         }
         __syncthreads();
@@ -1292,46 +1438,14 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     }
     if (s_fail) { if (tid == 0) ctl->lin_fail = 1; return; }
 
-    // Inverses of the factored diagonal blocks (for the two triangular solves below), all blocks in parallel: a wavefront
-    // pulls one 32 x 32 block of L back from S into its own LDS scratch -- wavefront 0 the L11 area, wavefront w > 0 the
-    // w-th 1056-double chunk of the (now idle) panel area -- and lane j solves L x = e_j.  (Round 1 computed each inverse
-    // on one wavefront next to the panel solve; with the pipelined panel solve that wavefront would be the critical path.)
-    {
-        const int nblk = (n + CH_NB - 1) / CH_NB;
-        const int nwork = min(nt >> 6, max(1, n / CH_NB));                  // scratch areas that exist for this n
-        double *Lw = wave == 0 ? L11 : P + (long long)(wave - 1) * (CH_NB * CH_LDP);
-        for (int blk = wave; blk < nblk && wave < nwork; blk += nwork) {
-            const int k0 = blk * CH_NB, nb = min(CH_NB, n - k0);
-            for (int e = lane; e < CH_NB * CH_NB; e += 64) {
-                const int i = e >> 5, j = e & 31;
-                double v = (i == j) ? 1.0 : 0.0;
-                if (i < nb && j <= i) v = S[(long long)(k0 + i) * ld + k0 + j];
-                Lw[i * CH_LDP + j] = v;
-            }
-            wave_lds_sync();
-            if (lane < CH_NB) Lw[lane * CH_LDP + CH_NB] = 1.0 / Lw[lane * CH_LDP + lane];      // reciprocal pivots in the padding column
-            wave_lds_sync();
-            if (lane < CH_NB) {
-                double x[CH_NB];
-#pragma unroll
-                for (int i = 0; i < CH_NB; i++) {
-                    double acc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; k++) acc -= Lw[i * CH_LDP + k] * x[k];
-                    x[i] = i < lane ? 0.0 : acc * Lw[i * CH_LDP + CH_NB];
-                }
-                double *dst = Linv + (long long)blk * CH_NB * CH_NB;
-#pragma unroll
-                for (int i = 0; i < CH_NB; i++) dst[i * CH_NB + lane] = x[i];            // Linv[i][j], coalesced over j
-            }
-            wave_lds_sync();
-        }
-    }
-    __syncthreads();
-
-    chol_trisolve(D, L11, yv, s_red, rhs_row);
-    for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
     CH_TICK(4);
+    // forward substitution rode along as a panel row (rhs_row: the host sends systems of more than 479 unknowns to the HBM path);
+    // backward substitution from the factor itself -- no inverse diagonal blocks (rounds 1-3 computed them here: 20 us and 12 KB of
+    // unrolled code in a kernel that has to fit the instruction cache)
+    chol_backward_blocks(D, yv, rd_all, &s_red[0][0]);
+
+    for (int i = tid; i < n; i += nt) D.yf[i] = yv[i];
+    CH_TICK(5);
     if (tid == 0) for (int i = 0; i < 6; i++) ctl->dbg[i] = tk[i];
 #undef CH_TICK
 }
@@ -2318,8 +2432,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
     {   // beyond what the LDS-resident lineariser / Cholesky hold (~90 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
         const size_t lin_lds = 8 * (4 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
-        const size_t chol_lds = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
-        D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024) ? 1 : 0;
+        const size_t chol_lds = chol_lds_bytes(nf, nfp);
+        D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024 || nf > CH_MAX_LDS_N) ? 1 : 0;
         if (ctx->ba_force_large) D.big = 1;                                    // OV2_OPT_BA_FORCE_LARGE: the path on small problems (tests)
         // beyond ~570 optimised keyframes the big-path linearisers cannot pre-aggregate the observer blocks in LDS either
         D.lin_direct = (D.big && 8 * ((size_t)n_opt * 27 + 4 * (size_t)LIN_RED) + 64 > 159 * 1024) ? 1 : 0;
@@ -2478,8 +2592,8 @@ static int xyzba_create(ov2_ctx *ctx, const ov2_xyzba_problem *p, ov2_ba_dev **o
         ov2_set_error("too many optimised keyframes (%d) for the 3-D point form (limit ~450: dense W rows in LDS)", n_opt);
         return OV2_EUNSUPPORTED;
     }
-    const size_t chol_lds_res = 8 * ((size_t)CH_NB * CH_LDP + (size_t)nfp + (size_t)std::max(0, nf - CH_NB) * CH_LDP) + 64;
-    int chol_hbm = chol_lds_res > 150 * 1024 ? 1 : 0;
+    const size_t chol_lds_res = chol_lds_bytes(nf, nfp);
+    int chol_hbm = (chol_lds_res > 150 * 1024 || nf > CH_MAX_LDS_N) ? 1 : 0;
     if (ctx->ba_force_large) chol_hbm = 1;                                      // OV2_OPT_BA_FORCE_LARGE (tests: the HBM factorisation on small problems)
     std::vector<int> fill(cnt.begin(), cnt.end() - 1), res_kf(n_act), res_orig(n_act);
     std::vector<uint8_t> res_type(n_act);
@@ -2588,7 +2702,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
                          : D.ldim == 3 ? 8 * (3 * (size_t)D.lin_waves * D.nfp + (size_t)n_opt * 27) + 64
                                        : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = D.chol_hbm ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64  // k_chol_solve: scratch block + the solution vector
-                                  : 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp + (size_t)std::max(0, D.nf - CH_NB) * CH_LDP) + 64;
+                                  : chol_lds_bytes(D.nf, D.nfp);
     OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
     OV2_REQUIRE(chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "reduced system too large for the LDS-panel Cholesky");
     {   // dynamic-LDS limits are per-function, process-wide attributes: raise them once to the hardware maximum (two
@@ -2765,8 +2879,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     r->initial_cost = h_ctl.initial_cost; r->final_cost = h_ctl.minimum_cost; r->termination = h_ctl.termination;
     r->solve_ms = ms;
     if (ctx->debug)
-        fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): copy-in %llu diag %llu panel %llu trail %llu solve %llu\n",
-                h_ctl.dbg[0], h_ctl.dbg[1], h_ctl.dbg[2], h_ctl.dbg[3], h_ctl.dbg[4]);
+        fprintf(stderr, "[ov2 ba] cholesky ticks (100MHz): copy-in %llu pivot+panel %llu write-back %llu trailing %llu block inverses %llu solves %llu\n",
+                h_ctl.dbg[0], h_ctl.dbg[1], h_ctl.dbg[2], h_ctl.dbg[3], h_ctl.dbg[4], h_ctl.dbg[5]);
     return OV2_OK;
 }
 
