@@ -60,6 +60,7 @@ struct BACtl {
 
 struct BADev {                    // device pointers + sizes (passed by value to kernels)
     int n_kf, n_lm, n_act, nf, nfp;
+    int *flag_h;                  // pinned host word: 2 * (iterations whose outcome is known) + done, written by k_ba_iter_begin
     // ldim = 1: anchored inverse depth (one scalar per landmark); ldim = 3: 3-D point landmarks with variable poses
     // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
     // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
@@ -822,9 +823,12 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
 }
 
 // ---------------------------------------------------------------------------------- iteration begin (1 block)
-__global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O)
+__global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int seq)
 {
     BACtl *ctl = D.ctl;
+    // the host's look-ahead control (ba_run): iteration seq is starting, so the outcome of the iterations < seq is final -- one
+    // store into pinned host memory instead of a 4-byte hipMemcpyAsync + event per chunk (~10 us of stream time each)
+    if (seq >= 0 && threadIdx.x == 0) { *(volatile int *)D.flag_h = 2 * seq + (ctl->done ? 1 : 0); __threadfence_system(); }
     if (ctl->done) return;
     __shared__ double s_part[3][16];
     __shared__ double s_gmax;
@@ -988,11 +992,8 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #ifndef CH_GRP
 #define CH_GRP 4           // columns of the diagonal block published per work-group barrier (pipelined panel solve)
 #endif
-#ifndef CH_SKIP_W4
-#define CH_SKIP_W4 0        // 1: wavefront 4 (same SIMD as the factorising wavefront 0) owns no panel rows -- measured: no difference
-#endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
-#define CH_MAX_LDS_N 479   // k_ba_cholesky (512 threads): the right-hand side rides as a panel row, n - 32 + 1 <= 512 - 64; larger systems: HBM path
+#define CH_MAX_LDS_N 415   // k_ba_cholesky (512 threads, six panel wavefronts): the right-hand side rides as a panel row, n - 32 + 1 <= 384; larger: HBM path
 // dynamic LDS of k_ba_cholesky: diagonal block, solution vector, panel (rows rounded up to whole 16-row MFMA tiles: the trailing
 // update reads its operand rows unpredicated)
 static inline size_t chol_lds_bytes(int nf, int nfp) { return 8 * ((size_t)CH_NB * CH_LDP + 2 * (size_t)nfp + (size_t)((std::max(0, nf - CH_NB) + 15) & ~15) * CH_LDP) + 64; }
@@ -1186,11 +1187,10 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     __shared__ double s_rdiag[CH_NB];                        // 1 / L11[j][j] of the current diagonal block
     __shared__ double s_yk[CH_NB];                           // the block's part of the forward solution (the right-hand side as a panel row)
     double *S = D.S;
-    double *Linv = D.Linv;                                  // (nfp / 32) blocks of 32 x 32 (row-major), inverse diagonal blocks
     // The right-hand side rides through the factorisation as one more row of the panel: solving its block against L11 IS the
     // forward substitution of that block, and its trailing update (rhs_rest -= P y_blk) replaces the forward pass of the
     // triangular solves (ten blocks of partial sums over L in L2, three barriers each).  Needs a free panel thread.
-    const bool rhs_row = n - CH_NB + 1 <= nt - 64;
+    const bool rhs_row = n - CH_NB + 1 <= nt - 128;
     // (S was assembled by k_ba_assemble: in here, one workgroup walking the n^2 entries took 85 us of latency)
     for (int i = tid; i < D.nfp; i += nt) yv[i] = i < n ? D.scale_f[i] * (D.bf[i] - D.v[i]) : 0.0;
     if (tid == 0) s_fail = 0;
@@ -1240,25 +1240,33 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
             // v_readlane with their wait states, on the one wavefront everybody waits for)
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            // Column c needs  a[c] - sum_{k<c} a[k] L[c][k]  of every row.  All terms but the last (k = c-1) are known one
-            // column earlier: they are accumulated -- in the same order, so bit-identically -- while the previous pivot's
-            // sqrt / divide chain is in flight; the pivot itself is broadcast with v_readlane instead of ds_bpermute.
+            // Column c needs  a[c] - sum_{k<c} a[k] L[c][k]  of every row.  Round 4: the terms of the columns published two
+            // barriers ago and earlier (k < 4 (c/4 - 1)) are taken out of the future columns by the HELPER wavefront below, in LDS,
+            // while this wavefront works on the current group of four -- it had 90 instructions per column at c = 20, two thirds of
+            // them those terms, and every other wavefront of the kernel waits for it.  What stays here: the 4 .. 7 terms of the last
+            // two groups (this wavefront's own registers), the same order k = 0, 1, .. as ever (bit-identical factor).  All of them
+            // but the last (k = c-1) are known one column earlier and are accumulated while the previous pivot's rsqrt chain is in
+            // flight -- except for the first column of a group, whose LDS value is final only after the barrier just passed.
             double pnext = a[0];
 #pragma unroll
             for (int c = 0; c < CH_NB; c++) {
-                double sacc = pnext;
-                if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];              // row c of L, final for k < c (broadcast read)
-                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
-                if (c + 1 < CH_NB) {
-                    // four partial sums: ONE accumulator made the column's terms a dependent chain of up to 31 fp64 FMAs on the
-                    // wavefront that every other one waits for (round 4; the factor changes in the last bits, parity is a tolerance)
-                    double p0 = a[c + 1], p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                double sacc;
+                if ((c & (CH_GRP - 1)) == 0 && c >= 2 * CH_GRP) {
 #pragma unroll
-                    for (int k = 0; k < c; k++) {
-                        const double t = a[k] * L11[(c + 1) * CH_LDP + k];
-                        if ((k & 3) == 0) p0 -= t; else if ((k & 3) == 1) p1 -= t; else if ((k & 3) == 2) p2 -= t; else p3 -= t;
-                    }
-                    pnext = (p0 + p1) + (p2 + p3);
+                    for (int q = 0; q < CH_GRP; q++) a[c + q] = ln < CH_NB ? L11[ln * CH_LDP + c + q] : 0.0;   // with the helper's terms
+                    sacc = a[c];
+#pragma unroll
+                    for (int k = c - CH_GRP; k < c; k++) sacc -= a[k] * L11[c * CH_LDP + k];
+                } else {
+                    sacc = pnext;
+                    if (c > 0) sacc -= a[c - 1] * L11[c * CH_LDP + c - 1];          // row c of L, final for k < c (broadcast read)
+                }
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), c), __builtin_amdgcn_readlane(__double2loint(sacc), c));
+                if (c + 1 < CH_NB && !(((c + 1) & (CH_GRP - 1)) == 0 && c + 1 >= 2 * CH_GRP)) {
+                    const int kmin = (c + 1) / CH_GRP >= 1 ? CH_GRP * ((c + 1) / CH_GRP - 1) : 0;
+                    pnext = a[c + 1];
+#pragma unroll
+                    for (int k = kmin; k < c; k++) pnext -= a[k] * L11[(c + 1) * CH_LDP + k];
                 }
 #ifndef CH_EXP
                 if (!(d > 0.0) || !isfinite(d)) fail = true;
@@ -1280,13 +1288,36 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                 if ((c & (CH_GRP - 1)) == CH_GRP - 1) __syncthreads();   // columns c-CH_GRP+1 .. c are published: the panel wavefronts may use them
             }
             if (fail && lane == 0) s_fail = 1;
+        } else if (wave == 4) {
+            // the helper (same SIMD as wavefront 0, no panel rows): before barrier g the columns of the groups < g are published; it
+            // takes the terms of group g-1 out of the columns of the groups > g (row per lane, two columns at a time), in place
+            const int hi = lane & 31, hh = lane >> 5;
+#pragma unroll
+            for (int g = 0; g < CH_NB / CH_GRP; g++) {
+                if (g >= 1) {
+                    const int kb = CH_GRP * (g - 1);
+                    double lk4[CH_GRP];
+#pragma unroll
+                    for (int q = 0; q < CH_GRP; q++) lk4[q] = L11[hi * CH_LDP + kb + q];
+#pragma unroll
+                    for (int jj = CH_GRP * (g + 1); jj < CH_NB; jj += 2) {
+                        const int j = jj + hh;
+                        double acc = L11[hi * CH_LDP + j];
+#pragma unroll
+                        for (int q = 0; q < CH_GRP; q++) acc -= lk4[q] * L11[j * CH_LDP + kb + q];
+                        L11[hi * CH_LDP + j] = acc;
+                    }
+                }
+                __syncthreads();
+            }
         } else {
             // left-looking per row (x[32] in registers, row j of L read as one contiguous LDS row).  Every panel wavefront
             // passes the same 8 work-group barriers as wavefront 0, whether its threads own a row or not.
-            // (wavefront 4 shares SIMD 0 with the factorising wavefront 0: it owns no rows, so that the pivot chain has that SIMD's
-            // issue slots to itself; wavefronts 1-3 and 5-7 take rows 0 .. 383)
-            const int t = CH_SKIP_W4 ? (wave < 4 ? tid - 64 : tid - 128) : tid - 64;
-            const bool has = t < m && !(CH_SKIP_W4 && wave == 4);
+            // (wavefronts 1-3 and 5-7 take rows 0 .. 383; two rows per thread on three wavefronts would halve the broadcast reads of
+            // L11 -- 1 KB comes back per ds_read_b128 whatever the number of rows it serves -- but x and z together need more
+            // than the 256 registers the kernel has: measured with spills, 202 us against 89)
+            const int t = wave < 4 ? tid - 64 : tid - 128;
+            const bool has = t < m;
             const bool rhs = rhs_row && t == m;                 // the thread after the last panel row takes the right-hand side
             double x[CH_NB];
 #pragma unroll
@@ -1301,8 +1332,13 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
                     __syncthreads();                           // columns j .. j+3 of L11 and their reciprocal pivots are there
                 }
                 double acc = x[j];
+#if defined(CH_EXP) && (CH_EXP & 16)
+#pragma unroll
+                for (int k = 0; k < j; k += 4) acc -= x[k] * L11[j * CH_LDP + k];
+#else
 #pragma unroll
                 for (int k = 0; k < j; k++) acc -= x[k] * L11[j * CH_LDP + k];
+#endif
                 x[j] = acc * s_rdiag[j];
             }
             if (has) {
@@ -1318,7 +1354,7 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
         // rows beyond the pipelined ones (only for reduced systems of more than ~480 unknowns): plain pass on the LDS rows, the
         // block is complete.  Rolled on purpose: an unrolled copy of the 496-term row solve is 12 KB of code, and this kernel has
         // to stay inside the 64 KB instruction cache (round 4: at 77 KB every panel step re-fetched its code from L2).
-        for (int t = tid + (CH_SKIP_W4 ? nt - 128 : nt - 64); t < m; t += nt) {
+        for (int t = tid + 384; t < m; t += nt) {
             double *xr = P + t * CH_LDP;
 #pragma nounroll
             for (int j = 0; j < CH_NB; j++) {
@@ -2733,13 +2769,11 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         OV2_HIP_CHECK(attr_err);
     }
     struct EvPair {                                        // destroyed on every exit path
-        hipEvent_t e0 = nullptr, e1 = nullptr, chunk[2] = {nullptr, nullptr};
-        ~EvPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); for (auto c : chunk) if (c) (void)hipEventDestroy(c); }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EvPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
     } ev;
     OV2_HIP_CHECK(hipEventCreate(&ev.e0));
     OV2_HIP_CHECK(hipEventCreate(&ev.e1));
-    OV2_HIP_CHECK(hipEventCreateWithFlags(&ev.chunk[0], hipEventDisableTiming));
-    OV2_HIP_CHECK(hipEventCreateWithFlags(&ev.chunk[1], hipEventDisableTiming));
     hipEvent_t e0 = ev.e0, e1 = ev.e1;
     // state reset: x = initial parameters, everything else zero, scales one
     const size_t NL = (size_t)D.n_lm * D.ldim;               // per-landmark state entries (1 inverse depth or 3 coordinates each)
@@ -2801,21 +2835,22 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     };
     linearize();
     OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));    // (every later iteration: cleared by the back-substitution kernel)
-    // The LM loop is enqueued in chunks of BA_CHUNK iterations.  After each chunk the control block's `done` flag is
-    // copied to pinned memory and an event recorded; before enqueuing chunk c+2 the host looks at the flag of chunk c
-    // (one chunk of look-ahead, so the stream never drains).  A solve that converges after 3 iterations of a
-    // 100-iteration fullBA budget no longer pays ~900 empty launches (every kernel starts with `if (ctl->done) return`).
-    constexpr int BA_CHUNK = 2;
-    int rc_h = ctx->reserve_host(2 * sizeof(int));
+    // The LM loop is enqueued with ONE iteration of look-ahead: before iteration `it` is enqueued the host wants the outcome of
+    // iteration it - 2, which k_ba_iter_begin of iteration it - 1 has stored into pinned host memory (the stream never drains: the
+    // GPU is inside iteration it - 1 or still has it queued).  A solve that converges after 3 iterations of a 100-iteration fullBA
+    // budget pays one empty iteration (every kernel starts with `if (ctl->done) return`), not 97 -- and not two, as the two-iteration
+    // chunks of rounds 2-3 did, each with a 4-byte device-to-host copy + event in the stream.
+    int rc_h = ctx->reserve_host(64);
     if (rc_h != OV2_OK) return rc_h;
-    volatile int *done_h = (volatile int *)ctx->h_scratch;
-    done_h[0] = done_h[1] = 0;
-    int chunks = 0;
+    volatile int *flag_h = (volatile int *)ctx->h_scratch;
+    flag_h[0] = -1;
+    D.flag_h = (int *)ctx->h_scratch;
+    DG.flag_h = D.flag_h;
     const auto t_start = std::chrono::steady_clock::now();
     for (int it = 0; it < o->max_iter; it++) {
-        if (it % BA_CHUNK == 0 && it > 0 && o->max_solver_time_s > 0.0) {
-            // Ceres tests total_time >= max_solver_time_in_seconds at the top of every iteration; here between chunks, against
-            // the time the DEVICE has actually spent (wait for the previous chunk first, otherwise only the enqueue is timed)
+        if (it > 0 && o->max_solver_time_s > 0.0) {
+            // Ceres tests total_time >= max_solver_time_in_seconds at the top of every iteration; here against the time the DEVICE
+            // has actually spent (wait for the previous iteration first, otherwise only the enqueue is timed)
             OV2_HIP_CHECK(hipStreamSynchronize(s));
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             if (el >= o->max_solver_time_s) {
@@ -2823,20 +2858,23 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
                 // step count, minimum cost, cost of a fresh linearisation) and terminates with NO_CONVERGENCE
                 BAOpt Ostop = O;
                 Ostop.max_iter = 0;
-                hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, Ostop);
+                hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, Ostop, -1);
                 break;
             }
         }
-        if (it % BA_CHUNK == 0 && it > 0) {
-            const int c = chunks++;                                           // chunk that was just enqueued
-            OV2_HIP_CHECK(hipMemcpyAsync((void *)&done_h[c & 1], &D.ctl->done, sizeof(int), hipMemcpyDeviceToHost, s));
-            OV2_HIP_CHECK(hipEventRecord(ev.chunk[c & 1], s));
-            if (c >= 1) {                                                     // verdict of the chunk before it
-                OV2_HIP_CHECK(hipEventSynchronize(ev.chunk[(c - 1) & 1]));
-                if (done_h[(c - 1) & 1]) break;
+        if (it >= 2) {
+            // outcome of iteration it - 2 (published when iteration it - 1 started)
+            unsigned spins = 0;
+            while (flag_h[0] < 2 * (it - 1)) {
+                if ((++spins & 0x3FFFFFu) == 0) {                                 // (a watchdog, ~every 0.3 s: a query per wait put a 6 us bubble in front of the next launch)
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) break;                               // everything enqueued has run: the word is final
+                    if (q != hipErrorNotReady) OV2_HIP_CHECK(q);
+                }
             }
+            if (flag_h[0] >= 0 && (flag_h[0] & 1)) break;
         }
-        hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);
+        hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O, it);
         if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
         if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split, ss_chunks), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split, ss_ncol);
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_schur_gemm, dim3(n_upper, ksplit), dim3(256), 0, s, DG, ntiles, lm_per_split);
@@ -2862,7 +2900,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D, O);
         linearize();
     }
-    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O);    // final bookkeeping
+    hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O, -1);    // final bookkeeping
     OV2_HIP_CHECK(hipGetLastError());
     }
     OV2_HIP_CHECK(hipEventRecord(e1, s));
