@@ -43,10 +43,13 @@
 #define BA_TILE 32
 #define BA_MAX_NFP 6144     // 1024 optimised keyframes: H, G, S are dense nfp x nfp doubles (302 MB each at the cap)
 
+#define BA_PART_MAX 2048
 struct BACtl {
     // accumulators
     double cost_acc;
     double acc1, acc2, acc3;      // sum_l y_l g'_l ; sum_l (2 y_l s_l t_l + s_l^2 ete_l y_l^2) ; sum_l c_l t_l^2
+    double acc_sn, acc_xn;        // landmark part of |x - candidate|^2 and |candidate|^2 (k_ba_backsub, inverse-depth form)
+    int bad_step;                 // a non-finite landmark step (k_ba_backsub)
     unsigned long long dbg[8];    // phase clocks of the last k_ba_cholesky (wall_clock64 ticks)
     // LM / TR state
     double radius, decrease_factor;
@@ -61,6 +64,10 @@ struct BACtl {
 struct BADev {                    // device pointers + sizes (passed by value to kernels)
     int n_kf, n_lm, n_act, nf, nfp;
     int *flag_h;                  // pinned host word: 2 * (iterations whose outcome is known) + done, written by k_ba_iter_begin
+    // inverse-depth form: per-work-group partial sums of k_ba_backsub (rows 0-4: acc1, acc2, acc3, step norm, candidate norm) and
+    // k_ba_cost (row 5), BA_PART_MAX entries each, summed by the one-work-group kernel that consumes them -- a global atomic per
+    // work-group on five words of the control block was most of those kernels' time (the same addresses, one L2 channel)
+    double *part; int bs_blocks, cost_blocks;
     // ldim = 1: anchored inverse depth (one scalar per landmark); ldim = 3: 3-D point landmarks with variable poses
     // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
     // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
@@ -176,7 +183,7 @@ __device__ __forceinline__ void d_ctl_iter_begin(BACtl &cl, const BAOpt &O, int 
         ctl->step_valid = 0;
         ctl->lin_fail = 0;
         ctl->n_steps++;
-        ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0;
+        ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0; ctl->acc_sn = 0; ctl->acc_xn = 0; ctl->bad_step = 0;
     }
 }
 
@@ -784,14 +791,16 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->step_valid) return;
-    const int lane = threadIdx.x & 63;
+    // half a wavefront per landmark (round 4): a landmark of the local-BA window has ~30 residual blocks -- a wavefront per
+    // landmark left half of its lanes idle
+    const int l32 = threadIdx.x & 31;
     double cost = 0;
-    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
+    for (int lm = blockIdx.x * 8 + (threadIdx.x >> 5); lm < D.n_lm; lm += gridDim.x * 8) {
         const int beg = D.lm_ptr[lm], end = D.lm_ptr[lm + 1];
         const int a = D.lm_anchor[lm];
         const double lam = D.c_lam[lm];
         const double auv[2] = {D.lm_auv[2 * lm], D.lm_auv[2 * lm + 1]};
-        for (int k = beg + lane; k < end; k += 64) {
+        for (int k = beg + l32; k < end; k += 32) {
             if (D.res_off && D.res_off[k]) continue;
             const int type = D.res_type[k];
             const int o = type == OV2_RES_RIGHT_ANCH ? a : D.res_kf[k];
@@ -819,7 +828,7 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
     }
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
-    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+    if (threadIdx.x == 0) D.part[5 * BA_PART_MAX + blockIdx.x] = cost;      // summed by k_ba_decide
 }
 
 // ---------------------------------------------------------------------------------- iteration begin (1 block)
@@ -1904,39 +1913,59 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
     double *sy = (double *)smem_raw;                        // s_j * yf_j
     for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    double a1 = 0, a2 = 0, a3 = 0;
-    for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
-        if (!d_lm_has(D, lm)) { if (lane == 0) D.yl[lm] = 0; continue; }
+    // Sixteen lanes per landmark, four landmarks per wavefront (round 4; a wavefront per landmark walked its ~5 landmarks one after
+    // the other, each a 300-term dot product, a 6-step wave reduction and a tail of dependent scalar loads in lane 0: 32 us).  The
+    // lane that finishes a landmark also forms its candidate x - s y and the landmark's share of the step norms and of the finite
+    // check: the one-work-group kernels k_ba_candidate / k_ba_decide no longer walk the landmarks.
+    const int lane = threadIdx.x & 63, l16 = lane & 15, wave = threadIdx.x >> 6;
+    double a1 = 0, a2 = 0, a3 = 0, sn = 0, xn = 0;
+    int bad = 0;
+    for (int base = blockIdx.x * 16; base < D.n_lm; base += gridDim.x * 16) {
+        const int lm = base + 4 * wave + (lane >> 4);
+        const bool in = lm < D.n_lm;
+        const bool has = in && d_lm_has(D, lm);
         double t = 0;
-        if (D.big) {
-            // sparse W: the landmark's slots
-            for (int j = D.cw_ptr[lm] + lane; j < D.cw_ptr[lm + 1]; j += 64) {
-                const int col = D.cw_col[j];
-                const double *w = D.cww + (long long)6 * j;
-                for (int q = 0; q < 6; q++) t += w[q] * sy[col + q];
+        if (has) {
+            if (D.big) {
+                // sparse W: the landmark's slots
+                for (int j = D.cw_ptr[lm] + l16; j < D.cw_ptr[lm + 1]; j += 16) {
+                    const int col = D.cw_col[j];
+                    const double *w = D.cww + (long long)6 * j;
+                    for (int q = 0; q < 6; q++) t += w[q] * sy[col + q];
+                }
+            } else {
+                const double *wr = D.W + (long long)lm * D.nfp;
+#pragma unroll 4
+                for (int c = l16; c < D.nfp; c += 16) t += wr[c] * sy[c];
             }
-        } else {
-            const double *wr = D.W + (long long)lm * D.nfp;
-            for (int c = lane; c < D.nfp; c += 64) t += wr[c] * sy[c];
         }
-        t = wave_sum(t);
-        if (lane == 0) {
-            const double s = D.scale_l[lm], ete = D.ete[lm], etb = D.etb[lm];
-            const double c = D.cl[lm];                     // s^2 / etep
-            const double y = (c / s) * (etb - t);          // s (etb - t) / etep
-            D.yl[lm] = y;
-            a1 += y * s * etb;
-            a2 += 2.0 * y * s * t + s * s * ete * y * y;
-            a3 += c * t * t;                               // y_f^T G' y_f  (G' = scaled W^T C W)
+        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+        if (l16 == 0 && in) {
+            const double x = D.x_lam[lm];
+            if (!has) { D.yl[lm] = 0; D.c_lam[lm] = x; }
+            else {
+                const double s = D.scale_l[lm], ete = D.ete[lm], etb = D.etb[lm];
+                const double c = D.cl[lm];                     // s^2 / etep
+                const double y = (c / s) * (etb - t);          // s (etb - t) / etep
+                D.yl[lm] = y;
+                a1 += y * s * etb;
+                a2 += 2.0 * y * s * t + s * s * ete * y * y;
+                a3 += c * t * t;                               // y_f^T G' y_f  (G' = scaled W^T C W)
+                const double cand = x - y * s;                 // candidate = Plus(x, step .* scale), step = -y
+                D.c_lam[lm] = cand;
+                if (!isfinite(y)) bad = 1;
+                sn += (x - cand) * (x - cand); xn += cand * cand;
+            }
         }
     }
     __shared__ double s_part[4];
     a1 = block_sum(a1, s_part); a2 = block_sum(a2, s_part); a3 = block_sum(a3, s_part);
+    sn = block_sum(sn, s_part); xn = block_sum(xn, s_part);
+    const int anybad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
-        if (a1 != 0.0) atomicAdd(&ctl->acc1, a1);
-        if (a2 != 0.0) atomicAdd(&ctl->acc2, a2);
-        if (a3 != 0.0) atomicAdd(&ctl->acc3, a3);
+        double *pt = D.part + blockIdx.x;
+        pt[0] = a1; pt[BA_PART_MAX] = a2; pt[2 * BA_PART_MAX] = a3; pt[3 * BA_PART_MAX] = sn; pt[4 * BA_PART_MAX] = xn;
+        if (anybad) atomicOr(&ctl->bad_step, 1);
     }
 }
 
@@ -1960,14 +1989,24 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
             p1 += yi * si * D.bf[i];
             p2 += yi * si * (D.bf[i] - D.v[i]) - (D.diag_f[i] / radius) * yi * yi;
         }
+        if (D.ldim == 1) bad |= ctl->bad_step;                 // (k_ba_backsub looked at every landmark step)
+        else {
 #pragma unroll 4
-        for (int l = tid; l < D.n_lm * D.ldim; l += nt) if (!isfinite(D.yl[l])) bad = 1;
+            for (int l = tid; l < D.n_lm * D.ldim; l += nt) if (!isfinite(D.yl[l])) bad = 1;
+        }
     }
     double P1 = p1, P2 = p2, nbad = (double)bad;
     block_reduce3<false>(P1, P2, nbad, s_part);
     if (nbad > 0) ok = 0;                                  // (thread 0 only: the only consumer)
+    double A1 = 0, A2 = 0, A3 = 0;
+    if (ok && D.ldim == 1 && D.n_lm > 0) {                 // the landmark sums of k_ba_backsub (uniform branch: ok is thread 0's, see below)
+        for (int i = tid; i < D.bs_blocks; i += nt) { A1 += D.part[i]; A2 += D.part[BA_PART_MAX + i]; A3 += D.part[2 * BA_PART_MAX + i]; }
+    }
+    __syncthreads();
+    block_reduce3<false>(A1, A2, A3, s_part);
     if (tid == 0) {
         BACtl cl = *ctl;
+        if (D.ldim == 1 && D.n_lm > 0) { cl.acc1 += A1; cl.acc2 += A2; cl.acc3 += A3; }
         s_flag = d_ctl_candidate(cl, O, ok, P1, P2);
         *D.ctl = cl;
     }
@@ -1985,7 +2024,7 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
         for (int c = 0; c < 7; c++) D.c_pose[7 * k + c] = out[c];
         d_pose_to_RT(out, D.c_RT + 12 * k);
     }
-    {
+    if (D.ldim != 1) {                                      // (inverse-depth form: k_ba_backsub wrote the candidates)
         double *__restrict__ c_lam = D.c_lam; const double *__restrict__ x_lam = D.x_lam, *__restrict__ yl = D.yl, *__restrict__ scale_l = D.scale_l;
 #pragma unroll 4
         for (int l = tid; l < D.n_lm * D.ldim; l += nt) c_lam[l] = x_lam[l] - yl[l] * scale_l[l];
@@ -2009,17 +2048,25 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
             sn += d * d; xn += D.c_pose[7 * k + c] * D.c_pose[7 * k + c];
         }
     }
-#pragma unroll 4
-    for (int l = tid; l < D.n_lm * D.ldim; l += nt) {
-        const int lm = D.ldim == 1 ? l : l / 3;
-        if (!d_lm_has(D, lm)) continue;
-        const double d = D.x_lam[l] - D.c_lam[l];
-        sn += d * d; xn += D.c_lam[l] * D.c_lam[l];
+    double cpart = 0;
+    if (D.ldim == 1) {                                      // (per work-group sums of k_ba_backsub and k_ba_cost)
+        if (D.n_lm > 0) for (int i = tid; i < D.bs_blocks; i += nt) { sn += D.part[3 * BA_PART_MAX + i]; xn += D.part[4 * BA_PART_MAX + i]; }
+        for (int i = tid; i < D.cost_blocks; i += nt) cpart += D.part[5 * BA_PART_MAX + i];
     }
-    double SN = sn, XN = xn, z = 0;
+    else {
+#pragma unroll 4
+        for (int l = tid; l < D.n_lm * D.ldim; l += nt) {
+            const int lm = l / 3;
+            if (!d_lm_has(D, lm)) continue;
+            const double d = D.x_lam[l] - D.c_lam[l];
+            sn += d * d; xn += D.c_lam[l] * D.c_lam[l];
+        }
+    }
+    double SN = sn, XN = xn, z = cpart;
     block_reduce3<false>(SN, XN, z, s_part);
     if (tid == 0) {
         BACtl cl = *ctl;
+        cl.cost_acc += z;
         s_accept = d_ctl_decide(cl, O, SN, XN);
         *D.ctl = cl;
     }
@@ -2518,7 +2565,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl));
-    const size_t o_res_off = take(na), o_bad_obs = take(nr), o_lba_cnt = take(64);
+    const size_t o_res_off = take(na), o_bad_obs = take(nr), o_lba_cnt = take(64), o_part = take(8 * 6 * BA_PART_MAX);
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
@@ -2536,6 +2583,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     D.x_pose = (double *)(b + o_x_pose); D.c_pose = (double *)(b + o_c_pose); D.x_RT = (double *)(b + o_x_RT); D.c_RT = (double *)(b + o_c_RT);
     D.x_lam = (double *)(b + o_x_lam); D.c_lam = (double *)(b + o_c_lam); D.scale_f = (double *)(b + o_scale_f); D.diag_f = (double *)(b + o_diag_f);
     D.scale_l = (double *)(b + o_scale_l); D.diag_l = (double *)(b + o_diag_l); D.ete = (double *)(b + o_ete); D.etb = (double *)(b + o_etb);
+    D.part = (double *)(b + o_part);
     D.cl = (double *)(b + o_cl); D.ce = (double *)(b + o_ce); D.W = (double *)(b + o_W); D.H = (double *)(b + o_H); D.G = (double *)(b + o_G); D.S = (double *)(b + o_S);
     D.Linv = (double *)(b + o_Linv);
     D.cww = (double *)(b + o_cww); D.cw_ptr = (int *)(b + o_cw_ptr); D.cw_col = (int *)(b + o_cw_col); D.cw_lm = (int *)(b + o_cw_lm);
@@ -2814,6 +2862,10 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     int lm_per_split = std::max(BA_TILE, ((DG.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
     ksplit = std::max(1, (DG.n_lm + lm_per_split - 1) / lm_per_split);
     const int ws_blocks = std::max(1, std::min(512, std::max((D.n_lm + 3) / 4, (D.n_po + 255) / 256)));
+    // inverse-depth form: 16 landmarks per work-group pass in the back-substitution, 8 in the cost kernel -- one pass each when the grid allows
+    const int bs_blocks = std::max(1, std::min(2048, (D.n_lm + 15) / 16));
+    const int cost_blocks = std::max(1, std::min(2048, std::max((D.n_lm + 7) / 8, (D.n_po + 255) / 256)));
+    D.bs_blocks = bs_blocks; D.cost_blocks = cost_blocks;
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
     // k_ba_schur_sparse: ~512 work-groups; row block + per-wavefront staging (64 slot blocks + columns)
     const int ss_split = std::max(1, (512 + std::max(1, n_opt) - 1) / std::max(1, n_opt));
@@ -2893,10 +2945,10 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         } else
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
-        else hipLaunchKernelGGL(k_ba_backsub, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
+        else hipLaunchKernelGGL(k_ba_backsub, dim3(bs_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_cost_xyz, dim3(ws_blocks), dim3(256), 0, s, D);
-        else hipLaunchKernelGGL(k_ba_cost, dim3(ws_blocks), dim3(256), 0, s, D);
+        else hipLaunchKernelGGL(k_ba_cost, dim3(cost_blocks), dim3(256), 0, s, D);
         hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D, O);
         linearize();
     }
