@@ -36,7 +36,7 @@
 #include <thread>
 
 #ifndef BA_KO
-#define BA_KO 0      // knock-out timing of the lineariser: 1 no global Hao atomics, 2 no LDS atomics, 4 no wave sums
+#define BA_KO 0      // knock-out timing of the lineariser: 1 no global Hao atomics, 2 no LDS atomics, 4 no wave sums, 8 no landmark pairs
 #endif
 #pragma clang fp contract(fast)   // BA parity is 1e-4 relative in fp64: FMA contraction is fine here
 
@@ -507,7 +507,7 @@ __device__ __forceinline__ void block_reduce3(double &a, double &b, double &c, d
 // per-wave 35 x 33 LDS transpose -- every lane parks its partials, lane q adds up row q -- instead of 35 six-step
 // shuffle butterflies (420 ds_bpermute per landmark: a third of this kernel, knock-out timing BA_KO=4); lane q keeps
 // the running anchor sums q < 27 in ONE register until the anchor changes.
-// dynamic LDS: 4*nfp (W rows) + n_opt*27 + 4*n_opt*36 + 4*LIN_RED doubles
+// dynamic LDS: 8*nfp (two W rows per wavefront) + n_opt*27 + 4*n_opt*36 + 4*LIN_RED doubles
 #define LIN_NRED 35
 #define LIN_RED (LIN_NRED * 33)
 __device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, double v)
@@ -524,12 +524,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->need_lin) return;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int n_opt = D.nf / 6, n_hao = BIG ? 0 : n_opt * 36;      // BIG: no per-wavefront anchor-observer cache, no dense W row
+    const int n_opt = D.nf / 6, n_hao = BIG ? 0 : n_opt * 21;      // BIG: no per-wavefront anchor-observer cache, no dense W row
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool direct = BIG && D.lin_direct;                        // no LDS pre-aggregation of the observer blocks at all
     const int n_agg = direct ? 0 : n_opt;
-    double *wrow = (double *)smem_raw + wave * (BIG ? 0 : D.nfp);
-    double *Hoo = (double *)smem_raw + 4 * (BIG ? 0 : D.nfp);
+    double *wrow = (double *)smem_raw + wave * (BIG ? 0 : 2 * D.nfp);   // two rows: a pair of landmarks (below)
+    double *Hoo = (double *)smem_raw + 8 * (BIG ? 0 : D.nfp);
     double *bo = Hoo + n_agg * 21;
     double *Hao = bo + n_agg * 6 + wave * n_hao;
     double *red = bo + n_agg * 6 + 4 * n_hao + wave * LIN_RED;
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     double dacc = 0;                                        // lane q < 21: Haa entry q, lane 21..26: (F_a^T b)[q - 21] of the current anchor
 
     auto flush_anchor = [&](int ca) {
-        if (ca < 0) return;
+        if (ca < 0 && BIG) return;                                   // (small path: a fixed anchor's blocks still carry the observers' M)
+        if (ca >= 0) {
         // anchor diagonal block + F^T b: lanes 0..26 hold one entry each
         if (lane < 21) {
             int c = 0, d = 0, t = lane;
@@ -553,12 +554,22 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         } else if (lane < 27) {
             if (dacc != 0.0) atomicAdd(&D.bf[ca + lane - 21], dacc);
         }
+        }
+        // (small path, round 4) the per-wavefront cache holds M = sum J_o^T J_o per observer (21 numbers) for the blocks of the current
+        // anchor: in the left-multiplicative tangent J_o = -J_a, so the same numbers are the observer's diagonal block (+M) AND the
+        // anchor-observer block (J_a^T J_o = -M) -- 21 LDS atomics per residual block instead of 21 + 36
         for (int e = lane; e < n_hao; e += 64) {
             const double v = Hao[e];
             if (v != 0.0) {
-                const int ob = e / 36, r = e - ob * 36, d = r / 6, c = r - d * 6;     // (Ja^T Jo)[d][c]
+                const int ob = e / 21;
+                int t = e - ob * 21, c = 0, d = 0;
+                for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
+                atomicAdd(&Hoo[e], v);                                               // block-shared observer blocks (same indexing)
 #if !(BA_KO & 1)
-                h_add_upper(D.H, D.nfp, ca + d, ob * 6 + c, v);
+                if (ca >= 0) {
+                    h_add_upper(D.H, D.nfp, ca + d, ob * 6 + c, -v);
+                    if (d != c) h_add_upper(D.H, D.nfp, ca + c, ob * 6 + d, -v);
+                }
 #endif
                 Hao[e] = 0;
             }
@@ -579,33 +590,52 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         h.lam = D.x_lam[h.lm]; h.au = D.lm_auv[2 * h.lm]; h.av = D.lm_auv[2 * h.lm + 1];
         return h;
     };
-    auto load_rec = [&](const LmHdr &h) {
+    auto load_rec = [&](const LmHdr &hx, const LmHdr &hy, bool pair) {
         ResRec r;
-        const int k = max(0, min(h.beg + lane, h.end - 1));       // (a landmark without residual blocks: nothing is consumed)
+        const bool hi = pair && lane >= 32;                        // (a pair: landmark y's blocks in the lanes 32 .. 63)
+        const int hb = hi ? hy.beg : hx.beg, he = hi ? hy.end : hx.end;
+        const int k = max(0, min(hb + (pair ? lane & 31 : lane), he - 1));       // (a landmark without residual blocks: nothing is consumed)
         r.type = D.res_type[k]; r.kf = D.res_kf[k]; r.orig = D.res_orig[k]; r.off = D.res_off ? D.res_off[k] : 0;
         r.u = D.res_uv[2 * k]; r.v = D.res_uv[2 * k + 1]; r.sigma = D.res_sigma[k];
         return r;
     };
-    LmHdr h_cur, h_nxt;
+    // Round 4: TWO landmarks per wavefront where that is possible -- a landmark of the local-BA window has ~30 residual blocks, a
+    // lane per block left half the wavefront idle on every SIMD's only wavefront.  Consecutive landmarks (the order groups them by
+    // anchor) with the same anchor keyframe and at most 32 blocks each share a step: landmark x in the lanes 0 .. 31, landmark y in
+    // 32 .. 63, one W row each, the same anchor accumulators and anchor-observer cache, and the transpose-reduce's two half-wave
+    // passes deliver the two landmarks' sums.  Anything else (more blocks, a change of anchor, the sparse-W path) goes singly.
+    LmHdr hq0, hq1, hq2, hq3;                                       // headers of the landmarks idx .. idx + 3
     ResRec r_cur;
-    if (i0 < i1) { h_cur = load_hdr(i0); h_nxt = load_hdr(i0 + 1); r_cur = load_rec(h_cur); }
-    for (int idx = i0; idx < i1; idx++) {
-        const ResRec r_nxt = load_rec(h_nxt);
-        const LmHdr h_n2 = load_hdr(idx + 2);
-        const int lm = h_cur.lm;
-        const int beg = h_cur.beg, end = h_cur.end;
-        const int a = h_cur.a;
-        const int ca = h_cur.ca;
+    auto pairable = [&](const LmHdr &x, const LmHdr &y, int ix) { return !(BA_KO & 8) && !BIG && ix + 1 < i1 && x.a == y.a && x.end - x.beg <= 32 && y.end - y.beg <= 32; };
+    bool pair_cur = false;
+    if (i0 < i1) {
+        hq0 = load_hdr(i0); hq1 = load_hdr(i0 + 1); hq2 = load_hdr(i0 + 2); hq3 = load_hdr(i0 + 3);
+        pair_cur = pairable(hq0, hq1, i0);
+        r_cur = load_rec(hq0, hq1, pair_cur);
+    }
+    for (int idx = i0; idx < i1;) {
+        const int nidx = idx + (pair_cur ? 2 : 1);
+        const LmHdr n0 = pair_cur ? hq2 : hq1, n1 = pair_cur ? hq3 : hq2;
+        const bool pair_nxt = nidx < i1 && pairable(n0, n1, nidx);
+        const ResRec r_nxt = load_rec(n0, n1, pair_nxt);
+        const LmHdr hn0 = load_hdr(idx + 4), hn1 = load_hdr(idx + 5);
+        const bool hiB = pair_cur && lane >= 32;                    // this lane works on the second landmark of the pair
+        const int lm0 = hq0.lm, lm1 = hq1.lm;
+        const int beg = hiB ? hq1.beg : hq0.beg, end = hiB ? hq1.end : hq0.end;
+        const int a = hq0.a;
+        const int ca = hq0.ca;
         if (ca != cur_ca) { wave_lds_sync(); flush_anchor(cur_ca); wave_lds_sync(); cur_ca = ca; }
-        if (!BIG) for (int c = lane; c < D.nfp; c += 64) wrow[c] = 0;
+        if (!BIG) for (int c = lane; c < (pair_cur ? 2 : 1) * D.nfp; c += 64) wrow[c] = 0;
         wave_lds_sync();
-        const double lam = h_cur.lam;
-        const double auv[2] = {h_cur.au, h_cur.av};
+        double *my_wrow = wrow + (hiB ? D.nfp : 0);
+        const double lam = hiB ? hq1.lam : hq0.lam;
+        const double auv[2] = {hiB ? hq1.au : hq0.au, hiB ? hq1.av : hq0.av};
         double ete = 0, etb = 0, wa[6] = {0, 0, 0, 0, 0, 0}, ba[6] = {0, 0, 0, 0, 0, 0}, Haa[21];
         for (int k = 0; k < 21; k++) Haa[k] = 0;
-        for (int base = beg; base < end; base += 64) {
-            const int k = base + lane;
-            const bool first = base == beg;                                   // (wave-uniform) records of the first batch were prefetched
+        const int nbatch = pair_cur ? 1 : (hq0.end - hq0.beg + 63) / 64;      // (wave-uniform)
+        for (int bt = 0; bt < nbatch; bt++) {
+            const int k = beg + 64 * bt + (pair_cur ? lane & 31 : lane);
+            const bool first = bt == 0;                                       // (wave-uniform) records of the first batch were prefetched
             if (k < end && !(first ? r_cur.off : (D.res_off ? (int)D.res_off[k] : 0))) {   // removed blocks keep their cached chi2 (N4)
                 const int type = first ? r_cur.type : D.res_type[k];
                 const int o = type == OV2_RES_RIGHT_ANCH ? a : (first ? r_cur.kf : D.res_kf[k]);
@@ -660,23 +690,21 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                     int t = 0;
 #if !(BA_KO & 2)
                     for (int c = 0; c < 6; c++) {
-                        atomicAdd(&wrow[co + c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);      // LDS fp64 atomics
+                        atomicAdd(&my_wrow[co + c], Jl[0] * Jo[c] + Jl[1] * Jo[6 + c]);   // LDS fp64 atomics
                         atomicAdd(&bo[ob * 6 + c], Jo[c] * r[0] + Jo[6 + c] * r[1]);
-                        for (int d = c; d < 6; d++) atomicAdd(&Hoo[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
-                        if (cae >= 0)
-                            for (int d = 0; d < 6; d++) atomicAdd(&Hao[ob * 36 + d * 6 + c], Ja[d] * Jo[c] + Ja[6 + d] * Jo[6 + c]);
+                        for (int d = c; d < 6; d++) atomicAdd(&Hao[ob * 21 + t++], Jo[c] * Jo[d] + Jo[6 + c] * Jo[6 + d]);
                     }
 #else
-                    if (Jo[0] == 1.2345) wrow[co] = Jo[1] + Ja[3] + (double)ob + (double)t;
+                    if (Jo[0] == 1.2345) my_wrow[co] = Jo[1] + Ja[3] + (double)ob + (double)t;
 #endif
                 }
             }
         }
-        // transpose-reduce: slots 0..20 Haa, 21..26 ba, 27..32 wa, 33 E^T E, 34 E^T b; lanes 32..63 only hold
-        // something when the landmark has more than 32 residual blocks
-        double tot = 0;
+        // transpose-reduce: slots 0..20 Haa, 21..26 ba, 27..32 wa, 33 E^T E, 34 E^T b; pass p takes the lanes 32 p .. 32 p + 31: the
+        // second landmark of a pair, or the blocks 32 .. 63 of a single landmark with more than 32 of them
+        double tot = 0, totB = 0;
 #if !(BA_KO & 4)
-        for (int p = 0; p < ((end - beg > 32) ? 2 : 1); p++) {
+        for (int p = 0; p < ((pair_cur || hq0.end - hq0.beg > 32) ? 2 : 1); p++) {
             if ((lane >> 5) == p) {
                 double *col = red + (lane & 31);
 #pragma unroll
@@ -688,28 +716,36 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
             wave_lds_sync();
             if (lane < LIN_NRED) {
                 const double *row = red + lane * 33;
+                double t = 0;
 #pragma unroll
-                for (int j = 0; j < 32; j++) tot += row[j];
+                for (int j = 0; j < 32; j++) t += row[j];
+                if (pair_cur && p == 1) totB += t; else tot += t;
             }
             wave_lds_sync();
         }
 #else
         tot = Haa[lane % 21] + ba[lane % 6] + wa[lane % 6] + ete + etb;
 #endif
-        if (ca >= 0 && lane < 27) dacc += tot;
-        if (lane == 33) D.ete[lm] = tot;
-        if (lane == 34) D.etb[lm] = tot;
+        if (ca >= 0 && lane < 27) dacc += tot + totB;
+        if (lane == 33) { D.ete[lm0] = tot; if (pair_cur) D.ete[lm1] = totB; }
+        if (lane == 34) { D.etb[lm0] = tot; if (pair_cur) D.etb[lm1] = totB; }
         if (BIG) {
-            const int sa = D.lm_cwa[lm];                                                             // the landmark's anchor entry of W
+            const int sa = D.lm_cwa[lm0];                                                            // the landmark's anchor entry of W
             if (sa >= 0 && lane >= 27 && lane < 33) atomicAdd(&D.cww[(long long)6 * sa + lane - 27], tot);
         } else {
-            if (ca >= 0 && lane >= 27 && lane < 33) wrow[ca + lane - 27] += tot;
+            if (ca >= 0 && lane >= 27 && lane < 33) { wrow[ca + lane - 27] += tot; if (pair_cur) wrow[D.nfp + ca + lane - 27] += totB; }
             wave_lds_sync();
-            double *Wg = D.W + (long long)lm * D.nfp;
+            double *Wg = D.W + (long long)lm0 * D.nfp;
             for (int c = lane; c < D.nfp; c += 64) Wg[c] = wrow[c];
+            if (pair_cur) {
+                double *Wh = D.W + (long long)lm1 * D.nfp;
+                for (int c = lane; c < D.nfp; c += 64) Wh[c] = wrow[D.nfp + c];
+            }
         }
         wave_lds_sync();
-        h_cur = h_nxt; h_nxt = h_n2; r_cur = r_nxt;
+        if (pair_cur) { hq0 = hq2; hq1 = hq3; hq2 = hn0; hq3 = hn1; }
+        else { hq0 = hq1; hq1 = hq2; hq2 = hq3; hq3 = hn0; }
+        idx = nidx; pair_cur = pair_nxt; r_cur = r_nxt;
     }
     wave_lds_sync();
     flush_anchor(cur_ca);
@@ -2514,7 +2550,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     memset(&D, 0, sizeof(D));
     D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
     {   // beyond what the LDS-resident lineariser / Cholesky hold (~90 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
-        const size_t lin_lds = 8 * (4 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+        const size_t lin_lds = 8 * (8 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
         const size_t chol_lds = chol_lds_bytes(nf, nfp);
         D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024 || nf > CH_MAX_LDS_N) ? 1 : 0;
         if (ctx->ba_force_large) D.big = 1;                                    // OV2_OPT_BA_FORCE_LARGE: the path on small problems (tests)
@@ -2784,7 +2820,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int n_opt = D.nf / 6;
     const size_t lin_lds = D.big ? 8 * ((D.lin_direct ? 0 : (size_t)(D.nf / 6) * 27) + 4 * (size_t)LIN_RED) + 64
                          : D.ldim == 3 ? 8 * (3 * (size_t)D.lin_waves * D.nfp + (size_t)n_opt * 27) + 64
-                                       : 8 * (4 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+                                       : 8 * (8 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = D.chol_hbm ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64  // k_chol_solve: scratch block + the solution vector
                                   : chol_lds_bytes(D.nf, D.nfp);
     OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
