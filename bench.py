@@ -947,7 +947,7 @@ def main():
                    "frac": b_alg * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "bytes_the_design_must_move_per_image": b_must, "frac_of_those": b_must * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "note": "8(d) counts the int16x2 derivative pyramid (4 of its 5.33 B/px), which this design never materialises (LK evaluates it in registers)"}
-            for name in ("r4_v1", "r3_v4"):
+            for name in ("r4_v2", "r4_v1", "r3_v4"):
                 pth = os.path.join(ROOT, "profiles", "%s_rocprof_summary_seqs%d.json" % (name, S))
                 if os.path.exists(pth) and args.workload == "euroc":
                     sj = json.load(open(pth))

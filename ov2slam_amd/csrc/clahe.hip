@@ -31,7 +31,7 @@ struct ClaheParams {
     int ysplit;          // apply kernel: work-groups per row of interpolation cells (1 in batch mode; a single image is cut
                          // into ~60 short row bands so that it does not run on 10 CUs only -- latency)
     // strip kernel (k_clahe_apply_pyr): column strips per image, level 1 of the pyramid next to the level-0 destination
-    int nstrips, nlut;   // nlut: LUT wavefronts of the fused form (1)
+    int nstrips, nlut;   // nlut: LUT wavefronts of the fused form
     long long l1_delta;  // byte offset of level 1's ROI pixel (0, 0) from the dst ROI pointer
     int l1_pitch, l1_w, l1_h;
 };
@@ -432,8 +432,10 @@ __device__ __forceinline__ uint32_t c_wave_shl1(uint32_t v) { return (uint32_t)_
 
 #define CS_UNROLL 6
 #ifndef CS_KO
-#define CS_KO 0           // knock-out timing experiments (tools/build_variant.sh): 1 loads hit one row, 2 no level-0 stores, 4 no level-1
-#endif                    // stores, 8 no LUT look-ups, 16 no blend, 32 no pyrDown sums / level-1 rows
+#define CS_KO 0           // knock-out timing experiments (tools/build_variant.sh; profiles/r4_strip_kernel_knockouts.txt): 1 loads hit one
+#endif                    // row, 2 no level-0 stores, 4 no level-1 stores, 8 no LUT look-ups, 16 no blend, 32 no pyrDown sums / level-1
+                          // rows, 64 / 128 no border stores of level 0 / 1, 256 distinct slack dwords, 512 / 1024 (fused form) the LUT
+                          // wavefront / the shared first row of tiles computes nothing
 #define CS_MAX_STRIPS 8
 // UNAL: w % 4 != 0 or an odd level-1 width (the generic right edge); false keeps the w % 4 == 0 instance free of its per-lane
 // selectors (they cost three spilled registers at this kernel's 80-VGPR budget)
@@ -755,9 +757,13 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
             P.l1_delta = pyr->lv[1].img_roi - pyr->lv[0].img_roi; P.l1_pitch = pyr->lv[1].img_pitch; P.l1_w = pyr->lv[1].w; P.l1_h = pyr->lv[1].h;
             const bool unal = (w & 3) != 0 || (pyr->lv[1].w & 1) != 0;
             // fused form: the aligned instance takes aligned sources only (its LUT wavefront uses the aligned-dword tile loads)
-            const bool fused = (ctx->clahe_strips == 2 || ctx->clahe_strips < 0) && (unal || src_al);
+            // One LUT wavefront keeps up with the strips of a 752-pixel image (15 tiles per row); wider images get one per ~8 tiles of a row (KITTI, 24 tiles per row: 3 -- with one the
+            // pre-processing of configs[2] took 4.3 instead of 2.6 ms), as far as the work-group's ten wavefronts go; auto mode
+            // leaves geometries with more than 16 tiles per LUT wavefront to the two-kernel form
+            const int nlut = tiles_x <= 16 ? 1 : std::max(1, std::min((tiles_x + 7) / 8, CS_MAX_STRIPS + 2 - nstrips));   // (EuRoC, 15: two are slower than one)
+            const bool fused = (ctx->clahe_strips == 2 || (ctx->clahe_strips < 0 && tiles_x <= 16 * nlut)) && (unal || src_al);
             if (fused) {
-                P.nlut = 1;
+                P.nlut = nlut;
                 const size_t lds = (size_t)(tiles_x + 1) * 1024 + (size_t)2 * tiles_x * 256 + (size_t)(nstrips + P.nlut) * CH_WAVE_DW * 4;
                 hipLaunchKernelGGL((unal ? k_clahe_apply_pyr<true, true> : k_clahe_apply_pyr<false, true>), dim3(batch), dim3(64 * (nstrips + P.nlut)), lds, ctx->stream, P, src_d, lut_d, dst_d);
             } else {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Pre-processing step on the GPU box in isolation: ov2_pyr_build_clahe_d (CLAHE LUT + apply [+ level 1] + pyramid levels) on S
-resident 752x480 frames, HIP-event time per call.  Usage: pre_micro.py [S] [reps] [strips: -1 auto | 0 | 1]; under rocprofv3 for per-kernel counters."""
+resident 752x480 (or, 4th argument "kitti", 1241x376) frames, HIP-event time per call.  Usage: pre_micro.py [S] [reps] [strips: -1 auto | 0 | 1 | 2] [euroc | kitti]; under rocprofv3 for per-kernel counters."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -12,6 +12,7 @@ import bench
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 strips = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+if len(sys.argv) > 4 and sys.argv[4] == "kitti": bench.W, bench.H = 1241, 376        # configs[2]
 views, _, _ = bench.make_inputs(S, 1234)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
