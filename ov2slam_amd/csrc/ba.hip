@@ -50,6 +50,7 @@ struct BACtl {
     double acc1, acc2, acc3;      // sum_l y_l g'_l ; sum_l (2 y_l s_l t_l + s_l^2 ete_l y_l^2) ; sum_l c_l t_l^2
     double acc_sn, acc_xn;        // landmark part of |x - candidate|^2 and |candidate|^2 (k_ba_backsub, inverse-depth form)
     int bad_step;                 // a non-finite landmark step (k_ba_backsub)
+    int reuse_now;                // reuse_diag as this iteration found it (k_ba_iter_begin sets reuse_diag = 1 when it is done)
     unsigned long long dbg[8];    // phase clocks of the last k_ba_cholesky (wall_clock64 ticks)
     // LM / TR state
     double radius, decrease_factor;
@@ -67,7 +68,8 @@ struct BADev {                    // device pointers + sizes (passed by value to
     // inverse-depth form: per-work-group partial sums of k_ba_backsub (rows 0-4: acc1, acc2, acc3, step norm, candidate norm) and
     // k_ba_cost (row 5), BA_PART_MAX entries each, summed by the one-work-group kernel that consumes them -- a global atomic per
     // work-group on five words of the control block was most of those kernels' time (the same addresses, one L2 channel)
-    double *part; int bs_blocks, cost_blocks;
+    double *part; int bs_blocks, cost_blocks, lin_blocks;
+    double min_diag, max_diag;    // clamp of the LM diagonal (BAOpt), for the kernels that form c_l themselves (d_lm_c)
     // ldim = 1: anchored inverse depth (one scalar per landmark); ldim = 3: 3-D point landmarks with variable poses
     // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
     // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
@@ -142,6 +144,18 @@ struct BADev {                    // device pointers + sizes (passed by value to
 __device__ __forceinline__ bool d_lm_has(const BADev &D, int lm)
 {
     return D.lm_live ? D.lm_live[lm] != 0 : D.lm_ptr[lm] != D.lm_ptr[lm + 1];
+}
+
+// c_l = s^2 / (s^2 E^T E + D_l^2 / radius) of an inverse-depth landmark (0 without live blocks), D_l^2 = the clamped diagonal of the
+// scaled E^T E -- kept from the last iteration that did not reuse it (LevenbergMarquardtStrategy).  Formed by its consumers
+// (k_ba_schur_gemm, k_ba_backsub) since round 4: k_ba_iter_begin used to walk the landmarks with one work-group for it.
+__device__ __forceinline__ double d_lm_c(const BADev &D, int l, double radius, int reuse, double *dg_out = nullptr)
+{
+    if (!d_lm_has(D, l)) return 0.0;
+    const double s = D.scale_l[l], e = D.ete[l];
+    const double dg = reuse ? D.diag_l[l] : fmin(fmax(s * s * e, D.min_diag), D.max_diag);
+    if (dg_out) *dg_out = dg;
+    return s * s / (s * s * e + dg / radius);
 }
 
 struct BAOpt {
@@ -542,6 +556,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     double cost = 0;
     int cur_ca = -1;
     double dacc = 0;                                        // lane q < 21: Haa entry q, lane 21..26: (F_a^T b)[q - 21] of the current anchor
+    double gmax_w = 0;                                      // lane 34: max |E^T b| over this wavefront's landmarks (k_ba_iter_begin's gradient norm)
 
     auto flush_anchor = [&](int ca) {
         if (ca < 0 && BIG) return;                                   // (small path: a fixed anchor's blocks still carry the observers' M)
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
 #endif
         if (ca >= 0 && lane < 27) dacc += tot + totB;
         if (lane == 33) { D.ete[lm0] = tot; if (pair_cur) D.ete[lm1] = totB; }
-        if (lane == 34) { D.etb[lm0] = tot; if (pair_cur) D.etb[lm1] = totB; }
+        if (lane == 34) { D.etb[lm0] = tot; if (pair_cur) D.etb[lm1] = totB; gmax_w = fmax(gmax_w, fmax(fabs(tot), fabs(totB))); }
         if (BIG) {
             const int sa = D.lm_cwa[lm0];                                                            // the landmark's anchor entry of W
             if (sa >= 0 && lane >= 27 && lane < 33) atomicAdd(&D.cww[(long long)6 * sa + lane - 27], tot);
@@ -764,6 +779,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
     if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+    // max |E^T b| of this work-group's landmarks: slot blockIdx.x of row 6 of BADev::part (k_ba_iter_begin takes the maximum of
+    // the slots instead of walking the landmarks with one work-group)
+    __shared__ double s_gm[4];
+    if (lane == 34) s_gm[wave] = gmax_w;
+    __syncthreads();
+    if (threadIdx.x == 0 && D.part) D.part[6 * BA_PART_MAX + blockIdx.x] = fmax(fmax(s_gm[0], s_gm[1]), fmax(s_gm[2], s_gm[3]));
 }
 
 // ---------------------------------------------------------------------------------- pose-only residual blocks
@@ -899,9 +920,8 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int se
             for (int c = 0; c < 7; c++) gm = fmax(gm, fabs(D.x_pose[7 * k + c] - out[c]));
         }
         if (D.ldim == 1) {
-#pragma unroll 4
-            for (int l = tid; l < D.n_lm; l += nt)
-                if (d_lm_has(D, l)) gm = fmax(gm, fabs(D.etb[l]));
+            // (per-work-group maxima of the lineariser; landmarks without live blocks have E^T b = 0 there)
+            if (D.n_lm > 0) for (int i = tid; i < D.lin_blocks; i += nt) gm = fmax(gm, D.part[6 * BA_PART_MAX + i]);
         } else {
             for (int l = tid; l < 3 * D.n_lm; l += nt)
                 if (D.lm_ptr[l / 3] != D.lm_ptr[l / 3 + 1]) gm = fmax(gm, fabs(D.etb[l]));      // Plus(x, -g) - x = -g for a Euclidean block
@@ -924,6 +944,7 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int se
     // LevenbergMarquardtStrategy::ComputeStep: diagonal of the (scaled) J^T J, clamped, unless reused
     const double radius = ctl->radius;
     const int reuse = ctl->reuse_diag;
+    if (tid == 0) ctl->reuse_now = reuse;
     for (int c = tid; c < D.nfp; c += nt) {
         if (c < D.nf) {
             if (!reuse) {
@@ -942,7 +963,8 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int se
                 const double s = D.scale_l[l];
                 D.diag_l[l] = fmin(fmax(s * s * D.ete6[6 * (l / 3) + (k == 0 ? 0 : (k == 1 ? 3 : 5))], O.min_diag), O.max_diag);
             }
-    } else {
+    } else if (D.big) {
+        // (large path: k_ba_schur_sparse reads c_l; the small path's consumers form it themselves, d_lm_c)
         // one workgroup walks all landmarks: the loads of four iterations are issued together (restrict-qualified views:
         // without them every store fences the next iteration's loads -- ten dependent L2 round trips per thread)
         const int *__restrict__ lm_ptr = D.lm_ptr;
@@ -973,8 +995,11 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
     while (t >= ntiles - ti) { t -= ntiles - ti; ti++; }
     const int tj = ti + t;
     __shared__ double As[BA_TILE][BA_TILE + 1], Bs[BA_TILE][BA_TILE + 1];
-    __shared__ double ces[BA_TILE];
+    __shared__ double ces[BA_TILE], cs[BA_TILE];
     const int tid = threadIdx.x;
+    // c_l of the step's 32 landmarks by the threads 0..31 (d_lm_c; the 3-D point form comes with C folded into Wp: c = 1)
+    const double radius = D.ctl->radius;
+    const int reuse = D.ctl->reuse_now;
     const int l0 = blockIdx.y * lm_per_split;
     const int l1 = min(D.n_lm, l0 + lm_per_split);
     // each of the 4 wavefronts owns a 16x16 quadrant of the tile on the fp64 matrix cores: per 4 landmarks one
@@ -987,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
     double vacc = 0;                                        // threads 0..31 of diagonal tiles accumulate v
     // 32 landmarks x 32 columns of both panels per step (A pre-multiplied by c_l); the loads of step s+1 are in flight
     // while step s is multiplied
-    double ra[4], rb[4], rc = 0;
+    double ra[4], rb[4], rc = 0, rcl = 0;
     auto fetch = [&](int lb) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -996,12 +1021,13 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
             double a = 0, b = 0;
             if (l < l1) {
                 const double *wr = D.W + (long long)l * D.nfp;
-                a = wr[ti * BA_TILE + cc] * D.cl[l];
+                a = wr[ti * BA_TILE + cc];
                 b = wr[tj * BA_TILE + cc];
             }
             ra[u] = a; rb[u] = b;
         }
         rc = (tid < BA_TILE && lb + tid < l1) ? D.etb[lb + tid] : 0.0;
+        rcl = (tid < BA_TILE && lb + tid < l1) ? (D.ldim == 3 ? 1.0 : d_lm_c(D, lb + tid, radius, reuse)) : 0.0;
     };
     fetch(l0);
     for (int lb = l0; lb < l1; lb += BA_TILE) {
@@ -1010,14 +1036,14 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
             const int e = tid + 256 * u;
             As[e >> 5][e & 31] = ra[u]; Bs[e >> 5][e & 31] = rb[u];
         }
-        if (tid < BA_TILE) ces[tid] = rc;
+        if (tid < BA_TILE) { ces[tid] = rc; cs[tid] = rcl; }
         __syncthreads();
         if (lb + BA_TILE < l1) fetch(lb + BA_TILE);
 #pragma unroll
         for (int g = 0; g < BA_TILE / 4; g++)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[4 * g + lk][16 * qi + lr], Bs[4 * g + lk][16 * qj + lr], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[4 * g + lk][16 * qi + lr] * cs[4 * g + lk], Bs[4 * g + lk][16 * qj + lr], acc, 0, 0, 0);
         if (ti == tj && tid < BA_TILE)
-            for (int kk = 0; kk < BA_TILE; kk++) vacc += As[kk][tid] * ces[kk];
+            for (int kk = 0; kk < BA_TILE; kk++) vacc += As[kk][tid] * cs[kk] * ces[kk];
         __syncthreads();
     }
 #pragma unroll
@@ -1944,7 +1970,14 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
     // G = W^T C W was consumed by k_ba_assemble: clear it for the next iteration's Schur kernels here (many work-groups) instead
     // of a memset launch per iteration
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < (long long)D.nfp * D.nfp; e += (long long)gridDim.x * blockDim.x) D.G[e] = 0;
-    if (ctl->lin_fail) return;
+    const double radius = ctl->radius;
+    const int reuse = ctl->reuse_now;
+    if (ctl->lin_fail) {
+        // (no step: but the LM diagonal of this linearisation has to be on record for the retry that reuses it)
+        if (!D.big && !reuse)
+            for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < D.n_lm; l += gridDim.x * blockDim.x) { double dg; if (d_lm_c(D, l, radius, 0, &dg) != 0.0) D.diag_l[l] = dg; }
+        return;
+    }
     extern __shared__ __align__(16) unsigned char smem_raw[];
     double *sy = (double *)smem_raw;                        // s_j * yf_j
     for (int c = threadIdx.x; c < D.nfp; c += blockDim.x) sy[c] = c < D.nf ? D.scale_f[c] * D.yf[c] : 0.0;
@@ -1981,7 +2014,9 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
             if (!has) { D.yl[lm] = 0; D.c_lam[lm] = x; }
             else {
                 const double s = D.scale_l[lm], ete = D.ete[lm], etb = D.etb[lm];
-                const double c = D.cl[lm];                     // s^2 / etep
+                double dg = 0;
+                const double c = D.big ? D.cl[lm] : d_lm_c(D, lm, radius, reuse, &dg);      // s^2 / etep
+                if (!D.big && !reuse) D.diag_l[lm] = dg;       // (kept for the iterations that reuse it)
                 const double y = (c / s) * (etb - t);          // s (etb - t) / etep
                 D.yl[lm] = y;
                 a1 += y * s * etb;
@@ -2601,7 +2636,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t o_bf = take(8 * (size_t)nfp), o_v = take(8 * (size_t)nfp), o_yf = take(8 * (size_t)nfp), o_yl = take(8 * nl);
     const size_t o_Linv = take(8 * (size_t)nfp * 32);
     const size_t o_chi2 = take(8 * nr), o_dpos = take(nr), o_ctl = take(sizeof(BACtl));
-    const size_t o_res_off = take(na), o_bad_obs = take(nr), o_lba_cnt = take(64), o_part = take(8 * 6 * BA_PART_MAX);
+    const size_t o_res_off = take(na), o_bad_obs = take(nr), o_lba_cnt = take(64), o_part = take(8 * 7 * BA_PART_MAX);
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
@@ -2810,6 +2845,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     BADev D = dev->D;
     D.huber = o->huber_delta;
+    D.min_diag = o->min_lm_diagonal; D.max_diag = o->max_lm_diagonal;
     hipStream_t s = ctx->stream;
     BAOpt O;
     O.max_iter = o->max_iter; O.ftol = o->function_tolerance; O.gtol = o->gradient_tolerance; O.ptol = o->parameter_tolerance;
@@ -2901,7 +2937,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     // inverse-depth form: 16 landmarks per work-group pass in the back-substitution, 8 in the cost kernel -- one pass each when the grid allows
     const int bs_blocks = std::max(1, std::min(2048, (D.n_lm + 15) / 16));
     const int cost_blocks = std::max(1, std::min(2048, std::max((D.n_lm + 7) / 8, (D.n_po + 255) / 256)));
-    D.bs_blocks = bs_blocks; D.cost_blocks = cost_blocks;
+    D.bs_blocks = bs_blocks; D.cost_blocks = cost_blocks; D.lin_blocks = lin_blocks;
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
     // k_ba_schur_sparse: ~512 work-groups; row block + per-wavefront staging (64 slot blocks + columns)
     const int ss_split = std::max(1, (512 + std::max(1, n_opt) - 1) / std::max(1, n_opt));
