@@ -2152,12 +2152,14 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
         for (int l = tid; l < D.n_lm * D.ldim; l += nt) x_lam[l] = c_lam[l];
     }
     if (D.big) return;                                      // k_ba_zero_lin
-    {   // 32-byte stores: this one work-group clears nfp^2 doubles (820 KB for 50 keyframes) on the iteration's critical path
+    {   // 32-byte stores: this one work-group clears H on the iteration's critical path -- the 32 x 32 tiles on and right of the diagonal
+        // only (H is its upper triangle: 450 of the 820 KB for 50 keyframes), a row per wavefront
         typedef double d4 __attribute__((ext_vector_type(4)));
-        d4 *H4 = (d4 *)D.H;                                 // (nfp is a multiple of 32, the pool is 256-byte aligned)
-        const int n4 = D.nfp * D.nfp / 4;
-        const d4 z = {0., 0., 0., 0.};
-        for (int e = tid; e < n4; e += nt) H4[e] = z;
+        const d4 z = {0., 0., 0., 0.};                      // (nfp is a multiple of 32, the pool is 256-byte aligned)
+        for (int r = tid >> 6; r < D.nfp; r += nt >> 6) {
+            d4 *row = (d4 *)(D.H + (long long)r * D.nfp);
+            for (int c4 = (r & ~31) / 4 + (tid & 63); c4 < D.nfp / 4; c4 += 64) row[c4] = z;
+        }
     }
     for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
 }
