@@ -79,6 +79,10 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
  * OV2_OPT_BA_SCHUR_CHUNK    columns of the sparse Schur row block kept in LDS per chunk (0 = auto)
  * OV2_OPT_BA_XYZ_LIN_WAVES  wavefronts per work-group of the 3-D-point lineariser: 0 auto, 1, 2
  * OV2_OPT_BA_POSE_ONLY_FUSED 0: ceresPnP through the multi-kernel LM loop instead of the one-kernel form (default 1)
+ * OV2_OPT_BA_DETERMINISTIC 1: bit-identical results from run to run (the reference solves with num_threads = 1): every sum that the
+ *                           default accumulates with fp64 atomics in arrival order (H, F^T b, W^T C W, the costs) goes through
+ *                           per-work-group buffers added up in a fixed order.  Inverse-depth form on the LDS-resident path (up
+ *                           to ~70 optimised keyframes); other forms answer OV2_EUNSUPPORTED while it is set.  ~1.7x the solve time.
  * OV2_OPT_DEBUG             1: timing laps of ov2_local_ba / detection on stderr (initial value: environment OV2_DEBUG at
  *                           ov2_ctx_create, the only environment variable the library ever reads)                          */
 #define OV2_OPT_LK_IMPL            2
@@ -94,6 +98,7 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
 #define OV2_OPT_BA_SCHUR_CHUNK     7
 #define OV2_OPT_BA_XYZ_LIN_WAVES   8
 #define OV2_OPT_BA_POSE_ONLY_FUSED 9
+#define OV2_OPT_BA_DETERMINISTIC   10
 #define OV2_OPT_DEBUG              11
 int  ov2_ctx_set_option(ov2_ctx *ctx, int option, int value);
 int  ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value);

@@ -70,6 +70,11 @@ struct BADev {                    // device pointers + sizes (passed by value to
     // work-group on five words of the control block was most of those kernels' time (the same addresses, one L2 channel)
     double *part; int bs_blocks, cost_blocks, lin_blocks;
     double min_diag, max_diag;    // clamp of the LM diagonal (BAOpt), for the kernels that form c_l themselves (d_lm_c)
+    // OV2_OPT_BA_DETERMINISTIC: the linearisers (one wavefront per work-group) add into their OWN copy of H / F^T b (Hpart / bfpart,
+    // det_lin + det_po copies) and store their cost in costpart; k_ba_det_reduce adds the copies up in a fixed order.  k_ba_schur_gemm
+    // stores the tiles of each landmark split (Gpart / vpart, det_ksplit copies); k_ba_assemble adds them up in order.
+    int det, det_lin, det_po, det_ksplit;
+    double *Hpart, *bfpart, *costpart, *Gpart, *vpart;
     // ldim = 1: anchored inverse depth (one scalar per landmark); ldim = 3: 3-D point landmarks with variable poses
     // (buse_inv_depth: 0, optimizer.cpp:207-209 / :333-384).  Per-landmark state arrays (x_lam, c_lam, scale_l, diag_l, etb,
     // yl) hold ldim entries per landmark, W holds ldim rows per landmark; the 3x3 e-block data is in ete6 / minv6.
@@ -541,6 +546,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     const int n_opt = D.nf / 6, n_hao = BIG ? 0 : n_opt * 21;      // BIG: no per-wavefront anchor-observer cache, no dense W row
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool direct = BIG && D.lin_direct;                        // no LDS pre-aggregation of the observer blocks at all
+    // (deterministic mode: this work-group is ONE wavefront and owns a copy of H and F^T b -- nothing it adds to races with anything)
+    double *Hout = (!BIG && D.det) ? D.Hpart + (size_t)blockIdx.x * D.nfp * D.nfp : D.H;
+    double *bfout = (!BIG && D.det) ? D.bfpart + (size_t)blockIdx.x * D.nfp : D.bf;
     const int n_agg = direct ? 0 : n_opt;
     double *wrow = (double *)smem_raw + wave * (BIG ? 0 : 2 * D.nfp);   // two rows: a pair of landmarks (below)
     double *Hoo = (double *)smem_raw + 8 * (BIG ? 0 : D.nfp);
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     for (int e = threadIdx.x; e < n_agg * 27 + 4 * n_hao; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
 
-    const int total_waves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int wpb = blockDim.x >> 6, total_waves = gridDim.x * wpb, gw = blockIdx.x * wpb + wave;
     const int chunk = (D.n_lm + total_waves - 1) / total_waves;
     const int i0 = gw * chunk, i1 = min(D.n_lm, i0 + chunk);
     double cost = 0;
@@ -565,9 +573,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
         if (lane < 21) {
             int c = 0, d = 0, t = lane;
             for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
-            if (dacc != 0.0) atomicAdd(&D.H[(long long)(ca + c) * D.nfp + ca + d], dacc);
+            if (dacc != 0.0) atomicAdd(&Hout[(long long)(ca + c) * D.nfp + ca + d], dacc);
         } else if (lane < 27) {
-            if (dacc != 0.0) atomicAdd(&D.bf[ca + lane - 21], dacc);
+            if (dacc != 0.0) atomicAdd(&bfout[ca + lane - 21], dacc);
         }
         }
         // (small path, round 4) the per-wavefront cache holds M = sum J_o^T J_o per observer (21 numbers) for the blocks of the current
@@ -582,8 +590,8 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
                 atomicAdd(&Hoo[e], v);                                               // block-shared observer blocks (same indexing)
 #if !(BA_KO & 1)
                 if (ca >= 0) {
-                    h_add_upper(D.H, D.nfp, ca + d, ob * 6 + c, -v);
-                    if (d != c) h_add_upper(D.H, D.nfp, ca + c, ob * 6 + d, -v);
+                    h_add_upper(Hout, D.nfp, ca + d, ob * 6 + c, -v);
+                    if (d != c) h_add_upper(Hout, D.nfp, ca + c, ob * 6 + d, -v);
                 }
 #endif
                 Hao[e] = 0;
@@ -772,19 +780,19 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
             const int ob = e / 21;
             int t = e - ob * 21, c = 0, d = 0;
             for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
-            atomicAdd(&D.H[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
+            atomicAdd(&Hout[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
         }
     }
-    for (int e = threadIdx.x; e < n_agg * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
+    for (int e = threadIdx.x; e < n_agg * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&bfout[e], v); }
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
-    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+    if (threadIdx.x == 0) { if (!BIG && D.det) D.costpart[blockIdx.x] = cost; else if (cost != 0.0) atomicAdd(&ctl->cost_acc, cost); }
     // max |E^T b| of this work-group's landmarks: slot blockIdx.x of row 6 of BADev::part (k_ba_iter_begin takes the maximum of
     // the slots instead of walking the landmarks with one work-group)
     __shared__ double s_gm[4];
     if (lane == 34) s_gm[wave] = gmax_w;
     __syncthreads();
-    if (threadIdx.x == 0 && D.part) D.part[6 * BA_PART_MAX + blockIdx.x] = fmax(fmax(s_gm[0], s_gm[1]), fmax(s_gm[2], s_gm[3]));
+    if (threadIdx.x == 0 && D.part) { double g = 0; for (int w = 0; w < wpb; w++) g = fmax(g, s_gm[w]); D.part[6 * BA_PART_MAX + blockIdx.x] = g; }
 }
 
 // ---------------------------------------------------------------------------------- pose-only residual blocks
@@ -798,6 +806,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize_po(BADev D)
     const bool direct = D.big && D.lin_direct;
     const int n_opt = direct ? 0 : D.nf / 6;                          // (direct: nothing is pre-aggregated in LDS)
     double *Hoo = (double *)smem_raw, *bo = Hoo + n_opt * 21;
+    // (deterministic mode: one wavefront per work-group, its own copy of H / F^T b -- after the landmark lineariser's copies)
+    double *Hout = D.det ? D.Hpart + (size_t)(D.det_lin + blockIdx.x) * D.nfp * D.nfp : D.H;
+    double *bfout = D.det ? D.bfpart + (size_t)(D.det_lin + blockIdx.x) * D.nfp : D.bf;
     for (int e = threadIdx.x; e < n_opt * 27; e += blockDim.x) Hoo[e] = 0;
     __syncthreads();
     double cost = 0;
@@ -834,13 +845,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize_po(BADev D)
             const int ob = e / 21;
             int t = e - ob * 21, c = 0, d = 0;
             for (c = 0; c < 6; c++) { if (t < 6 - c) { d = c + t; break; } t -= 6 - c; }
-            atomicAdd(&D.H[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
+            atomicAdd(&Hout[(long long)(ob * 6 + c) * D.nfp + ob * 6 + d], v);
         }
     }
-    for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&D.bf[e], v); }
+    for (int e = threadIdx.x; e < n_opt * 6; e += blockDim.x) { const double v = bo[e]; if (v != 0.0) atomicAdd(&bfout[e], v); }
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
-    if (threadIdx.x == 0 && cost != 0.0) atomicAdd(&ctl->cost_acc, cost);
+    if (threadIdx.x == 0) { if (D.det) D.costpart[D.det_lin + blockIdx.x] = cost; else if (cost != 0.0) atomicAdd(&ctl->cost_acc, cost); }
 }
 
 // ---------------------------------------------------------------------------------- cost only
@@ -886,6 +897,34 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
     __shared__ double s_part[4];
     cost = block_sum(cost, s_part);
     if (threadIdx.x == 0) D.part[5 * BA_PART_MAX + blockIdx.x] = cost;      // summed by k_ba_decide
+}
+
+// ---------------------------------------------------------------------------------- deterministic mode: the linearisers' copies, in order
+// H = sum of the det_lin + det_po copies (upper-triangle tiles), F^T b likewise, the cost; the copies are cleared for the next
+// linearisation as they are read.  Runs right after the linearisers, under the same condition.
+__global__ __launch_bounds__(256) void k_ba_det_reduce(BADev D)
+{
+    BACtl *ctl = D.ctl;
+    if (ctl->done || !ctl->need_lin) return;
+    const int ncopy = D.det_lin + D.det_po;
+    const long long nn = (long long)D.nfp * D.nfp, stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nn; e += stride) {
+        const int r = (int)(e / D.nfp), c = (int)(e - (long long)r * D.nfp);
+        if (c < (r & ~31)) continue;                            // (left of the diagonal tile: never written)
+        double t = 0;
+        for (int q = 0; q < ncopy; q++) { double *src = D.Hpart + (size_t)q * nn + e; t += *src; *src = 0; }
+        D.H[e] = t;
+    }
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < D.nfp; e += stride) {
+        double t = 0;
+        for (int q = 0; q < ncopy; q++) { double *src = D.bfpart + (size_t)q * D.nfp + e; t += *src; *src = 0; }
+        D.bf[e] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0;
+        for (int q = 0; q < ncopy; q++) { t += D.costpart[q]; D.costpart[q] = 0; }
+        ctl->cost_acc += t;
+    }
 }
 
 // ---------------------------------------------------------------------------------- iteration begin (1 block)
@@ -1045,6 +1084,18 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
         if (ti == tj && tid < BA_TILE)
             for (int kk = 0; kk < BA_TILE; kk++) vacc += As[kk][tid] * cs[kk] * ces[kk];
         __syncthreads();
+    }
+    if (D.det) {
+        // deterministic mode: this (tile, landmark split) is the only writer of its entries in the split's copy; k_ba_assemble adds the
+        // copies up in order
+        double *Gp = D.Gpart + (size_t)blockIdx.y * D.nfp * D.nfp, *vp = D.vpart + (size_t)blockIdx.y * D.nfp;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int gi = ti * BA_TILE + 16 * qi + lk + 4 * r, gj = tj * BA_TILE + 16 * qj + lr;
+            Gp[(long long)gi * D.nfp + gj] = acc[r];
+        }
+        if (ti == tj && tid < BA_TILE) vp[ti * BA_TILE + tid] = vacc;
+        return;
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -1236,7 +1287,12 @@ __global__ __launch_bounds__(256) void k_ba_assemble(BADev D)
     const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j > i) return;                                      // lower triangle only
     const int gi = (i / BA_TILE <= j / BA_TILE) ? i : j, gj = (i / BA_TILE <= j / BA_TILE) ? j : i;   // G holds upper tiles
-    double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)j * ld + i] - D.G[(long long)gi * ld + gj]);   // H: upper triangle (j <= i)
+    double g = 0;
+    if (D.det) {                                            // the landmark splits' copies of W^T C W (and of v), in order
+        for (int q = 0; q < D.det_ksplit; q++) g += D.Gpart[(size_t)q * ld * ld + (long long)gi * ld + gj];
+        if (j == 0) { double t = 0; for (int q = 0; q < D.det_ksplit; q++) t += D.vpart[(size_t)q * ld + i]; D.v[i] = t; }
+    } else g = D.G[(long long)gi * ld + gj];
+    double val = D.scale_f[i] * D.scale_f[j] * (D.H[(long long)j * ld + i] - g);   // H: upper triangle (j <= i)
     if (i == j) val += D.diag_f[i] / ctl->radius;
     D.S[(long long)i * ld + j] = val;
     (void)n;
@@ -2456,6 +2512,7 @@ struct ov2_ba_dev {
     bool pool_owned = true;             // false: the pool lives in the context's grow-only device scratch (transient small problems)
     int n_res = 0;
     int *lm_order = nullptr;            // landmarks sorted by anchor keyframe (device)
+    void *det_pool = nullptr; size_t det_bytes = 0;    // OV2_OPT_BA_DETERMINISTIC: the per-work-group copies (allocated by the first such solve)
     std::vector<double> h_poses0, h_lam0;
     int device = 0;
 };
@@ -2833,6 +2890,7 @@ static void ba_destroy(ov2_ba_dev *dev)
     if (!dev) return;
     (void)hipSetDevice(dev->device);
     if (dev->pool && dev->pool_owned) (void)hipFree(dev->pool);
+    if (dev->det_pool) (void)hipFree(dev->det_pool);
     delete dev;
 }
 
@@ -2915,7 +2973,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     h_ctl.termination = OV2_TERM_NO_CONVERGENCE;
     // one optimised pose, pose-only residual blocks, no landmarks (ceresPnP): the whole loop in one kernel (OV2_OPT_BA_POSE_ONLY_FUSED
     // = 0 keeps the multi-kernel path for A/B runs)
-    const bool fused_po = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && ctx->ba_pose_only_fused && !(o->max_solver_time_s > 0.0);
+    const bool fused_po = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && ctx->ba_pose_only_fused && !(o->max_solver_time_s > 0.0) && !ctx->ba_deterministic;
     if (fused_po) {
         hipLaunchKernelGGL(k_ba_pose_only, dim3(1), dim3(256), 0, s, D, O, h_ctl);
         OV2_HIP_CHECK(hipGetLastError());
@@ -2940,6 +2998,31 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int bs_blocks = std::max(1, std::min(2048, (D.n_lm + 15) / 16));
     const int cost_blocks = std::max(1, std::min(2048, std::max((D.n_lm + 7) / 8, (D.n_po + 255) / 256)));
     D.bs_blocks = bs_blocks; D.cost_blocks = cost_blocks; D.lin_blocks = lin_blocks;
+    // OV2_OPT_BA_DETERMINISTIC (BADev::det): one-wavefront lineariser work-groups with their own copies of H / F^T b / cost, one copy
+    // of W^T C W / v per landmark split; everything else of the solver is already a fixed-order computation
+    int det_lin = 0, det_po = 0;
+    if (ctx->ba_deterministic) {
+        OV2_REQUIRE(D.ldim == 1 && !D.big, OV2_EUNSUPPORTED, "OV2_OPT_BA_DETERMINISTIC covers the inverse-depth form on the LDS-resident path only");
+        det_lin = D.n_lm > 0 ? std::max(1, std::min(128, (D.n_lm + 15) / 16)) : 0;
+        det_po = D.n_po > 0 ? std::max(1, std::min(32, (D.n_po + 63) / 64)) : 0;
+        const size_t nn = (size_t)D.nfp * D.nfp, ncopy = (size_t)det_lin + det_po;
+        const size_t b_H = al256(8 * ncopy * nn), b_bf = al256(8 * ncopy * D.nfp), b_c = al256(8 * std::max<size_t>(1, ncopy));
+        const size_t b_G = al256(8 * (size_t)ksplit * nn), b_v = al256(8 * (size_t)ksplit * D.nfp);
+        const size_t need = b_H + b_bf + b_c + b_G + b_v;
+        if (need > dev->det_bytes) {
+            if (dev->det_pool) { OV2_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(dev->det_pool); dev->det_pool = nullptr; dev->det_bytes = 0; }
+            hipError_t e = hipMalloc(&dev->det_pool, need);
+            if (e != hipSuccess) { ov2_set_error("hipMalloc(%zu) for the deterministic mode: %s", need, hipGetErrorString(e)); return OV2_ENOMEM; }
+            dev->det_bytes = need;
+        }
+        uint8_t *q = (uint8_t *)dev->det_pool;
+        D.det = 1; D.det_lin = det_lin; D.det_po = det_po; D.det_ksplit = ksplit;
+        D.Hpart = (double *)q; D.bfpart = (double *)(q + b_H); D.costpart = (double *)(q + b_H + b_bf);
+        D.Gpart = (double *)(q + b_H + b_bf + b_c); D.vpart = (double *)(q + b_H + b_bf + b_c + b_G);
+        OV2_HIP_CHECK(hipMemsetAsync(dev->det_pool, 0, b_H + b_bf + b_c, s));      // (the copies are clean between linearisations: k_ba_det_reduce clears as it reads)
+        D.lin_blocks = det_lin;
+        DG.det = 1; DG.det_ksplit = ksplit; DG.Gpart = D.Gpart; DG.vpart = D.vpart;
+    }
     const int po_blocks = std::max(1, std::min(256, (D.n_po + 255) / 256));
     // k_ba_schur_sparse: ~512 work-groups; row block + per-wavefront staging (64 slot blocks + columns)
     const int ss_split = std::max(1, (512 + std::max(1, n_opt) - 1) / std::max(1, n_opt));
@@ -2955,6 +3038,13 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             // (k_ba_decide leaves H, F^T b and the W slots to this kernel on the large path: also for pose-only problems)
             if (D.n_lm > 0 || D.n_po > 0) hipLaunchKernelGGL(k_ba_zero_lin, dim3(1024), dim3(256), 0, s, D);
             if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
+        }
+        else if (D.det) {
+            // one wavefront per work-group, each with its own copy of H / F^T b; then the copies in order
+            if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(det_lin), dim3(64), lin_lds, s, D, dev->lm_order);
+            if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(det_po), dim3(64), (size_t)n_opt * 27 * 8 + 16, s, D);
+            hipLaunchKernelGGL(k_ba_det_reduce, dim3(256), dim3(256), 0, s, D);
+            return;
         }
         else if (D.n_lm > 0) hipLaunchKernelGGL(k_ba_linearize<false>, dim3(lin_blocks), dim3(256), lin_lds, s, D, dev->lm_order);
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (D.big && D.lin_direct ? 0 : (size_t)n_opt * 27 * 8) + 16, s, D);

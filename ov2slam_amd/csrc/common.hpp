@@ -55,6 +55,7 @@ struct ov2_ctx {
     int ba_schur_chunk = 0;                    // OV2_OPT_BA_SCHUR_CHUNK (columns; 0 = auto)
     int ba_xyz_lin_waves = 0;                  // OV2_OPT_BA_XYZ_LIN_WAVES (0 = auto, 1, 2)
     int ba_pose_only_fused = 1;                // OV2_OPT_BA_POSE_ONLY_FUSED
+    int ba_deterministic = 0;                  // OV2_OPT_BA_DETERMINISTIC
     int debug = 0;                             // OV2_OPT_DEBUG; initial value: environment OV2_DEBUG, read once by ov2_ctx_create
     // pinned staging of host images on their way to the device: its own buffer (h_scratch is rewritten by the next call's small
     // arrays while an asynchronous image upload may still be in flight) and an event that says when it may be refilled

@@ -171,6 +171,7 @@ int ov2_ctx_set_option(ov2_ctx *ctx, int option, int value)
         OV2_REQUIRE(value >= 0 && value <= 2, OV2_EINVAL, "OV2_OPT_BA_XYZ_LIN_WAVES takes 0, 1 or 2");
         ctx->ba_xyz_lin_waves = value; return OV2_OK;
     case OV2_OPT_BA_POSE_ONLY_FUSED: ctx->ba_pose_only_fused = value != 0; return OV2_OK;
+    case OV2_OPT_BA_DETERMINISTIC:   ctx->ba_deterministic = value != 0; return OV2_OK;
     case OV2_OPT_DEBUG:              ctx->debug = value != 0; return OV2_OK;
     default:
         ov2_set_error("unknown context option %d", option);
@@ -191,6 +192,7 @@ int ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value)
     case OV2_OPT_BA_SCHUR_CHUNK:     *value = ctx->ba_schur_chunk; return OV2_OK;
     case OV2_OPT_BA_XYZ_LIN_WAVES:   *value = ctx->ba_xyz_lin_waves; return OV2_OK;
     case OV2_OPT_BA_POSE_ONLY_FUSED: *value = ctx->ba_pose_only_fused; return OV2_OK;
+    case OV2_OPT_BA_DETERMINISTIC:   *value = ctx->ba_deterministic; return OV2_OK;
     case OV2_OPT_DEBUG:              *value = ctx->debug; return OV2_OK;
     default:
         ov2_set_error("unknown context option %d", option);

@@ -379,3 +379,43 @@ def test_max_solver_time_stops_between_chunks(gpu_ctx, oracle):
     assert cut["final_cost"] <= cut["initial_cost"] and full["final_cost"] <= cut["final_cost"]
 
 
+
+
+def test_deterministic_mode_is_bit_identical_from_run_to_run(gpu_ctx, oracle):
+    """OV2_OPT_BA_DETERMINISTIC: every sum the default accumulates with fp64 atomics in arrival order goes through per-work-group
+    copies added up in a fixed order -- two solves return the same BITS (poses, inverse depths, costs, chi2), the result matches the
+    oracle like the default path's, ov2_local_ba's two passes included; forms the mode does not cover answer OV2_EUNSUPPORTED."""
+    cases = [synth.make_ba_problem(12, 400, 8, stereo=False, seed=2), synth.make_ba_problem(25, 3000, 12, stereo=True, seed=4)]
+    # landmark factors and pose-only factors in one problem
+    pb = synth.make_ba_problem(8, 200, 5, stereo=True, seed=12)
+    pn = synth.make_pnp_problem(60, seed=4)
+    from tests.test_oracle_ba import np_T
+    T3 = np_T(pb["poses_gt"][3]) @ np.linalg.inv(np_T(pn["poses_gt"][0]))
+    mix = dict(pb)
+    mix["n_res"] = pb["n_res"] + pn["n_res"]
+    for k in ("res_type", "res_lm", "res_uv", "res_sigma"): mix[k] = np.concatenate([pb[k], pn[k]])
+    mix["res_kf"] = np.concatenate([pb["res_kf"], np.full(pn["n_res"], 3, np.int32)])
+    mix["res_xyz"] = np.concatenate([np.zeros((pb["n_res"], 3)), (T3[:3, :3] @ pn["res_xyz"].T).T + T3[:3, 3]])
+    cases.append(mix)
+    with gpu_ctx.options(ba_deterministic=1):
+        for pb in cases:
+            runs = [optimizer.solve(gpu_ctx, pb, optimizer.default_options(gpu_ctx.lib, max_iter=8)) for _ in range(4)]
+            for g in runs[1:]:
+                for k in ("poses", "invdepth", "chi2", "depthpos"):
+                    assert np.array_equal(np.asarray(g[k]), np.asarray(runs[0][k])), k
+                assert g["final_cost"] == runs[0]["final_cost"] and g["initial_cost"] == runs[0]["initial_cost"] and g["iterations"] == runs[0]["iterations"]
+            _cmp(runs[0], oracle.ba_solve(pb, oracle.ba_default_options(max_iter=8)), pb)
+        pb = synth.make_ba_problem(15, 800, 8, stereo=True, seed=7)
+        la = [ov2slam_amd.Optimizer(gpu_ctx).localBA(pb) for _ in range(3)]
+        for g in la[1:]:
+            assert np.array_equal(g["bad_obs"], la[0]["bad_obs"])
+            for k in ("poses", "invdepth"):
+                assert np.array_equal(np.asarray(g[k]), np.asarray(la[0][k])), k
+        # the 3-D point form is not covered: the call says so instead of answering with an unordered sum
+        px = synth.make_xyz_ba_problem(6, 60, 4, stereo=False, seed=1) if hasattr(synth, "make_xyz_ba_problem") else None
+        if px is not None:
+            with pytest.raises(Exception):
+                optimizer.solve_xyz(gpu_ctx, px)
+    # and the default path on the same context is back to normal
+    pb = cases[0]
+    _cmp(optimizer.solve(gpu_ctx, pb), oracle.ba_solve(pb), pb)

@@ -10,8 +10,11 @@ import ov2slam_amd
 from ov2slam_amd import synth, optimizer
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+DET = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # 1: OV2_OPT_BA_DETERMINISTIC (every spread below must then be exactly 0)
 ctx = ov2slam_amd.Context(0)
-out = {}
+from ov2slam_amd import _lib as L
+ctx.set_option(L.OV2_OPT_BA_DETERMINISTIC, DET)
+out = {"deterministic_mode": DET}
 for name, stereo in (("config4_mono", False), ("config4_stereo", True)):
     pb = synth.make_ba_problem(50, 10000, 30, stereo=stereo, seed=42)
     rp = optimizer.ResidentProblem(ctx, pb)
@@ -22,13 +25,16 @@ for name, stereo in (("config4_mono", False), ("config4_stereo", True)):
         bad = (r["chi2"] > 5.9915) | (r["depthpos"] == 0)
         sets.add(hashlib.sha1(np.packbits(bad).tobytes()).hexdigest())
         cost.add(float(r["final_cost"]))
+        sets_bits = hashlib.sha1(r["poses"].tobytes() + r["invdepth"].tobytes()).hexdigest()
+        bits = bits | {sets_bits} if i else {sets_bits}
         if ref is None:
             ref = r["poses"].copy()
         spread = max(spread, float(np.abs(r["poses"] - ref).max()))
     # how close is the closest residual to the outlier threshold? (a flip needs a chi2 within the run-to-run noise of it)
     margin = float(np.min(np.abs(r["chi2"] - 5.9915)))
     out[name] = {"solves": N, "distinct_iteration_termination": len(its), "distinct_outlier_sets": len(sets), "distinct_final_costs": len(cost),
-                 "max_pose_spread_abs": spread, "closest_chi2_to_threshold": margin}
+                 "max_pose_spread_abs": spread, "closest_chi2_to_threshold": margin, "distinct_bit_patterns_of_poses_and_landmarks": len(bits),
+                 "solve_ms_last": r["solve_ms"]}
     rp.close()
 pb = synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7)
 opt = optimizer.Optimizer(ctx)
