@@ -563,6 +563,28 @@ __global__ __launch_bounds__(64 * (CS_MAX_STRIPS + 2), 6) void k_clahe_apply_pyr
         build(cy);
     };
     // a level-0 row: every lane's dword and, in the edge strips, the border dword
+#ifndef CS_BUF
+#define CS_BUF 1          // 0: 64-bit lane addresses (the form the CS_KO store knock-outs are written for)
+#endif
+#if CS_BUF
+    // buffer addressing (round 4): one descriptor per image, the row as a scalar offset, the lane's column as a 32-bit offset -- no
+    // 64-bit address arithmetic per store (the kernel's time is within noise of the pointer form, 1 % in the median; it needs 6-8
+    // registers less, and the instance for unaligned widths no longer spills)
+    uint8_t *dbase = min(d0m - (long long)win * P.dst_stride, d1m - (long long)win * P.l1_pitch) - 256;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, 0x7fffffff, 0x00020000);
+    const uint8_t *sbase = src + (long long)b * P.src_item_stride;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void *)sbase, 0, 0x7fffffff, 0x00020000);
+    auto put0 = [&](uint8_t *row, uint32_t v, uint32_t bv) {
+        const int so = (int)(row - dbase);
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs_dst, (int)o0, so, 0);
+        if (edge_strip) __builtin_amdgcn_raw_buffer_store_b32(bv, rs_dst, (int)o0b, so, 0);
+    };
+    auto put1 = [&](uint8_t *row, uint32_t v, uint32_t bv) {
+        const int so = (int)(row - dbase);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, rs_dst, (int)o1, so, 0);
+        if (edge_strip) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bv, rs_dst, (int)o1b, so, 0);
+    };
+#else
     auto put0 = [&](uint8_t *row, uint32_t v, uint32_t bv) {
         if ((CS_KO & 2) && v != 0x12345678u) return;
         *(uint32_t *)(row + o0) = v;
@@ -573,6 +595,7 @@ __global__ __launch_bounds__(64 * (CS_MAX_STRIPS + 2), 6) void k_clahe_apply_pyr
         *(uint16_t *)(row + o1) = (uint16_t)v;
         if (edge_strip && !(CS_KO & 128)) *(uint16_t *)(row + o1b) = (uint16_t)bv;
     };
+#endif
     typedef unsigned short cu16x2 __attribute__((ext_vector_type(2)));
     uint8_t *r1 = d1m;                                                  // level-1 row of the next emit
     // level-1 row Y from the horizontal sums of level-0 rows 2Y-2 .. 2Y+2 (packed pairs, <= 16 * 255 each); rows are emitted in order.
@@ -657,7 +680,11 @@ __global__ __launch_bounds__(64 * (CS_MAX_STRIPS + 2), 6) void k_clahe_apply_pyr
     for (int yb = 0; yb < P.h; yb += CS_UNROLL) {
         if (yb + 2 * CS_UNROLL <= P.h) {
 #pragma unroll
+#if CS_BUF
+            for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_src, (int)xo, (int)(srow - sbase), 0) >> (UNAL ? in_sh : 0u); srow += P.stride; }
+#else
             for (int u = 0; u < CS_UNROLL; u++) { nxt[u] = *(const cs_u32_a1 *)(srow + xo) >> (UNAL ? in_sh : 0u); if (!(CS_KO & 1)) srow += P.stride; }
+#endif
         } else {
 #pragma unroll
             for (int u = 0; u < CS_UNROLL; u++)
