@@ -64,7 +64,7 @@ struct BACtl {
 
 struct BADev {                    // device pointers + sizes (passed by value to kernels)
     int n_kf, n_lm, n_act, nf, nfp;
-    int *flag_h;                  // pinned host word: 2 * (iterations whose outcome is known) + done, written by k_ba_iter_begin
+    int *flag_h;                  // pinned host word: 2 * (iteration whose outcome is known) + done, written by k_ba_decide
     // inverse-depth form: per-work-group partial sums of k_ba_backsub (rows 0-4: acc1, acc2, acc3, step norm, candidate norm) and
     // k_ba_cost (row 5), BA_PART_MAX entries each, summed by the one-work-group kernel that consumes them -- a global atomic per
     // work-group on five words of the control block was most of those kernels' time (the same addresses, one L2 channel)
@@ -931,9 +931,7 @@ __global__ __launch_bounds__(256) void k_ba_det_reduce(BADev D)
 __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int seq)
 {
     BACtl *ctl = D.ctl;
-    // the host's look-ahead control (ba_run): iteration seq is starting, so the outcome of the iterations < seq is final -- one
-    // store into pinned host memory instead of a 4-byte hipMemcpyAsync + event per chunk (~10 us of stream time each)
-    if (seq >= 0 && threadIdx.x == 0) { *(volatile int *)D.flag_h = 2 * seq + (ctl->done ? 1 : 0); __threadfence_system(); }
+    (void)seq;
     if (ctl->done) return;
     __shared__ double s_part[3][16];
     __shared__ double s_gmax;
@@ -1115,6 +1113,9 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #define CH_GRP 4           // columns of the diagonal block published per work-group barrier (pipelined panel solve)
 #endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
+// CH_EXP (undefined in the product): knock-out timing of k_ba_cholesky's phases (tools/build_variant.sh ... -DCH_EXP=<bits>,
+// profiles/r4_ba_dead_ends.txt): trailing update 1 no MFMA, 2 no loads of the old tile values, 4 no tile stores, 8 no LDS operand
+// reads; 16 the panel solve does a quarter of its terms.  Any value switches the positive-pivot test off (the factor is garbage).
 #define CH_MAX_LDS_N 415   // k_ba_cholesky (512 threads, six panel wavefronts): the right-hand side rides as a panel row, n - 32 + 1 <= 384; larger: HBM path
 // dynamic LDS of k_ba_cholesky: diagonal block, solution vector, panel (rows rounded up to whole 16-row MFMA tiles: the trailing
 // update reads its operand rows unpredicated)
@@ -2159,10 +2160,15 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
 }
 
 // ---------------------------------------------------------------------------------- decision (1 block)
-__global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
+__global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O, int seq)
 {
     BACtl *ctl = D.ctl;
-    if (ctl->done || !ctl->step_valid) return;
+    // The host's look-ahead control (ba_run): the outcome of iteration seq goes into pinned host memory on every way out of this
+    // kernel -- one store instead of a 4-byte hipMemcpyAsync + event in the stream (~10 us of stream time each in rounds 2-3).
+    if (ctl->done || !ctl->step_valid) {
+        if (seq >= 0 && threadIdx.x == 0) { *(volatile int *)D.flag_h = 2 * seq + (ctl->done ? 1 : 0); __threadfence_system(); }
+        return;
+    }
     __shared__ double s_part[3][16];
     __shared__ int s_accept;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -2196,6 +2202,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O)
         cl.cost_acc += z;
         s_accept = d_ctl_decide(cl, O, SN, XN);
         *D.ctl = cl;
+        if (seq >= 0) { *(volatile int *)D.flag_h = 2 * seq + (cl.done ? 1 : 0); __threadfence_system(); }
     }
     __syncthreads();
     if (!s_accept) return;
@@ -3051,45 +3058,19 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     };
     linearize();
     OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));    // (every later iteration: cleared by the back-substitution kernel)
-    // The LM loop is enqueued with ONE iteration of look-ahead: before iteration `it` is enqueued the host wants the outcome of
-    // iteration it - 2, which k_ba_iter_begin of iteration it - 1 has stored into pinned host memory (the stream never drains: the
-    // GPU is inside iteration it - 1 or still has it queued).  A solve that converges after 3 iterations of a 100-iteration fullBA
-    // budget pays one empty iteration (every kernel starts with `if (ctl->done) return`), not 97 -- and not two, as the two-iteration
-    // chunks of rounds 2-3 did, each with a 4-byte device-to-host copy + event in the stream.
+    // The LM loop is enqueued half an iteration ahead.  The first half of iteration `it` (bookkeeping, Schur complement, factorisation:
+    // ~265 us of config 4's ~385) goes into the stream BEFORE the outcome of iteration it - 1 is known; k_ba_decide stores that outcome
+    // into pinned host memory, and the second half (back-substitution .. decision, re-linearisation) follows when the host has seen
+    // it -- while the GPU is still busy with the first half, so the stream never drains.  A solve that converges pays four empty
+    // launches (every kernel starts with `if (ctl->done) return`): the two-iteration chunks of rounds 2-3 paid 18 plus a 4-byte
+    // device-to-host copy + event per chunk, a whole iteration of look-ahead 9.
     int rc_h = ctx->reserve_host(64);
     if (rc_h != OV2_OK) return rc_h;
     volatile int *flag_h = (volatile int *)ctx->h_scratch;
     flag_h[0] = -1;
     D.flag_h = (int *)ctx->h_scratch;
     DG.flag_h = D.flag_h;
-    const auto t_start = std::chrono::steady_clock::now();
-    for (int it = 0; it < o->max_iter; it++) {
-        if (it > 0 && o->max_solver_time_s > 0.0) {
-            // Ceres tests total_time >= max_solver_time_in_seconds at the top of every iteration; here against the time the DEVICE
-            // has actually spent (wait for the previous iteration first, otherwise only the enqueue is timed)
-            OV2_HIP_CHECK(hipStreamSynchronize(s));
-            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-            if (el >= o->max_solver_time_s) {
-                // the regular per-iteration bookkeeping with an iteration budget of zero: it finalises the last step (successful
-                // step count, minimum cost, cost of a fresh linearisation) and terminates with NO_CONVERGENCE
-                BAOpt Ostop = O;
-                Ostop.max_iter = 0;
-                hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, Ostop, -1);
-                break;
-            }
-        }
-        if (it >= 2) {
-            // outcome of iteration it - 2 (published when iteration it - 1 started)
-            unsigned spins = 0;
-            while (flag_h[0] < 2 * (it - 1)) {
-                if ((++spins & 0x3FFFFFu) == 0) {                                 // (a watchdog, ~every 0.3 s: a query per wait put a 6 us bubble in front of the next launch)
-                    const hipError_t q = hipStreamQuery(s);
-                    if (q == hipSuccess) break;                               // everything enqueued has run: the word is final
-                    if (q != hipErrorNotReady) OV2_HIP_CHECK(q);
-                }
-            }
-            if (flag_h[0] >= 0 && (flag_h[0] & 1)) break;
-        }
+    auto first_half = [&](int it) {
         hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O, it);
         if (D.ldim == 3 && D.n_lm > 0) hipLaunchKernelGGL(k_ba_xyz_prep, dim3(ws_blocks), dim3(256), 0, s, D);
         if (D.n_lm > 0 && D.big) hipLaunchKernelGGL(k_ba_schur_sparse, dim3(n_opt * ss_split, ss_chunks), dim3(64 * SS_WAVES), ss_lds, s, D, ss_split, ss_ncol);
@@ -3108,13 +3089,46 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(512), chol_lds, s, D);
         } else
         hipLaunchKernelGGL(k_ba_cholesky, dim3(1), dim3(512), chol_lds, s, D);
+    };
+    auto second_half = [&](int it) {
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_backsub_xyz, dim3(ws_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         else hipLaunchKernelGGL(k_ba_backsub, dim3(bs_blocks), dim3(256), (size_t)D.nfp * 8, s, D);
         hipLaunchKernelGGL(k_ba_candidate, dim3(1), dim3(1024), 0, s, D, O);
         if (D.ldim == 3) hipLaunchKernelGGL(k_ba_cost_xyz, dim3(ws_blocks), dim3(256), 0, s, D);
         else hipLaunchKernelGGL(k_ba_cost, dim3(cost_blocks), dim3(256), 0, s, D);
-        hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D, O);
+        hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D, O, it);
         linearize();
+    };
+    const auto t_start = std::chrono::steady_clock::now();
+    for (int it = 0; it < o->max_iter; it++) {
+        if (it > 0 && o->max_solver_time_s > 0.0) {
+            // Ceres tests total_time >= max_solver_time_in_seconds at the top of every iteration; here against the time the DEVICE
+            // has actually spent (wait for the previous iteration first, otherwise only the enqueue is timed)
+            OV2_HIP_CHECK(hipStreamSynchronize(s));
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            if (el >= o->max_solver_time_s) {
+                // the regular per-iteration bookkeeping with an iteration budget of zero: it finalises the last step (successful
+                // step count, minimum cost, cost of a fresh linearisation) and terminates with NO_CONVERGENCE
+                BAOpt Ostop = O;
+                Ostop.max_iter = 0;
+                hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, Ostop, -1);
+                break;
+            }
+        }
+        first_half(it);
+        if (it >= 1) {
+            // outcome of iteration it - 1 (k_ba_decide of that iteration)
+            unsigned spins = 0;
+            while (flag_h[0] < 2 * (it - 1)) {
+                if ((++spins & 0x3FFFFFu) == 0) {                                 // (a watchdog, ~every 0.3 s: a query per wait put a 6 us bubble in front of the next launch)
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) break;                               // everything enqueued has run: the word is final
+                    if (q != hipErrorNotReady) OV2_HIP_CHECK(q);
+                }
+            }
+            if (flag_h[0] >= 0 && (flag_h[0] & 1)) break;
+        }
+        second_half(it);
     }
     hipLaunchKernelGGL(k_ba_iter_begin, dim3(1), dim3(1024), 0, s, D, O, -1);    // final bookkeeping
     OV2_HIP_CHECK(hipGetLastError());
