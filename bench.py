@@ -947,7 +947,7 @@ def main():
                    "frac": b_alg * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "bytes_the_design_must_move_per_image": b_must, "frac_of_those": b_must * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "note": "8(d) counts the int16x2 derivative pyramid (4 of its 5.33 B/px), which this design never materialises (LK evaluates it in registers)"}
-            for name in ("r4_v2", "r4_v1", "r3_v4"):
+            for name in ("r4_v3", "r4_v2", "r4_v1", "r3_v4"):
                 pth = os.path.join(ROOT, "profiles", "%s_rocprof_summary_seqs%d.json" % (name, S))
                 if os.path.exists(pth) and args.workload == "euroc":
                     sj = json.load(open(pth))
@@ -987,8 +987,9 @@ def main():
             out["ba"]["roofline"] = {"bound": "latency", "algorithmic_bytes_per_iteration": b_ba, "achieved": b_ba / (us_it * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": b_ba / (us_it * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                      "limiter": "a chain of nine launches per LM iteration, half of it the one-work-group fp64 Cholesky of the 300 x 300 reduced system "
-                                                "(262 us: 32-column pivot chains, trailing tiles through L2, triangular solves); profiles/r4_ba_timeline_config4_mono.txt, "
-                                                "profiles/r4_v0_ba_kernel_stats_*.csv; HBM bytes are 0.5 % of the roofline by design (SURVEY 8(d): 'explain, don't hide')"}
+                                                "(208 us: 32-column pivot chains, trailing tiles through L2, backward substitution), then the lineariser (74 us: LDS fp64 "
+                                                "atomics and dependent fp64 chains on one wavefront per SIMD); profiles/r4_v3_ba_timeline_config4_mono.txt, "
+                                                "profiles/r4_v3_ba_kernel_stats_*.csv; HBM bytes are under 1 % of the roofline by design (SURVEY 8(d): 'explain, don't hide')"}
             # ---- detection through the host-buffer drop-in API on ONE image: per-call latency incl. PCIe -----
             fx = ov2slam_amd.FeatureExtractor(ctx1, dmaxquality=0.001)
             roi = (5, 5, W - 10, H - 10)
