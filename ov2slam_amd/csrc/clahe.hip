@@ -138,17 +138,18 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
         }
     };
 
-    uint32_t cur[16], nxt[16], cur_ph = 0, nxt_ph = 0;
-    if (t < ntiles && tile_fast(t)) tile_load(t, cur, cur_ph);
-#pragma nounroll
-    for (; t < ntiles; t += tstride) {
-        const int tn = t + tstride;
-        if (tn < ntiles && tile_fast(tn)) tile_load(tn, nxt, nxt_ph);
-        const int ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+    // Software pipeline over the wavefront's tiles (round 4: one register set instead of two, and the NEXT tile's atomics in flight
+    // during the current tile's clip / scan / LUT arithmetic -- a single LUT wavefront of the fused kernel is a serial chain, the
+    // ~300 instructions of that tail used to run with the LDS idle and the histogram with the VALU idle):
+    //   histogram(t): clear, then every ds_add of tile t is ISSUED (its pixels come from `cur`, read at issue);
+    //   then the loads of the tile after it go into the same registers; nobody waits for either before the next iteration.
+    uint32_t cur[16], cur_ph = 0;
+    auto histogram = [&](int th) {
+        const int ty = th / P.tiles_x, tx = th - ty * P.tiles_x;
         const int x_begin = tx * P.tw;                              // tile columns in padded coordinates
         ((c_u32x4 *)hw)[lane] = (c_u32x4)(0u);
         clahe_wave_sync();
-        if (tile_fast(t)) {
+        if (tile_fast(th)) {
             // byte k of this lane's dword is tile column 4*l16 + k - ph; bytes outside [0, tw) are added with weight 0
             // weight of tile column p (image column x_begin + p): see tile_fast
             const int dbl_lo = 2 * P.w - 2 - (x_begin + P.tw);      // columns in (dbl_lo, w - 2] also stand for a padded column
@@ -178,7 +179,15 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
                 for (int lx = l16; lx < P.tw; lx += 16) atomicAdd(&hist[row[c_reflect101(x_begin + lx, P.w)]], 1u);
             }
         }
-        clahe_wave_sync();
+    };
+    if (t < ntiles) {
+        if (tile_fast(t)) tile_load(t, cur, cur_ph);
+        histogram(t);
+        if (t + tstride < ntiles && tile_fast(t + tstride)) tile_load(t + tstride, cur, cur_ph);
+    }
+#pragma nounroll
+    for (; t < ntiles; t += tstride) {
+        clahe_wave_sync();                                            // the atomics of tile t have landed
         // lane owns bins 4*lane .. 4*lane+3
         int hv[4];
         {
@@ -186,6 +195,11 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
             hv[0] = (int)q.x; hv[1] = (int)q.y; hv[2] = (int)q.z; hv[3] = (int)q.w;
         }
         clahe_wave_sync();                                            // the histogram may be cleared for the next tile
+        const int tn = t + tstride;
+        if (tn < ntiles) {
+            histogram(tn);
+            if (tn + tstride < ntiles && tile_fast(tn + tstride)) tile_load(tn + tstride, cur, cur_ph);
+        }
         if (P.clip > 0 && !(CLAHE_KO & 4)) {
             int over = 0;
 #pragma unroll
@@ -220,9 +234,6 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
             packed |= (uint32_t)r << (8 * k);
         }
         store_lut(t, packed);
-#pragma unroll
-        for (int i = 0; i < 16; i++) cur[i] = nxt[i];
-        cur_ph = nxt_ph;
     }
 }
 
