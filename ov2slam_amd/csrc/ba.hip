@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 // reads the panel from LDS only (each S entry is touched once per panel).
 #define CH_NB 32
 #ifndef CH_GRP
-#define CH_GRP 4           // columns of the diagonal block published per work-group barrier (pipelined panel solve)
+#define CH_GRP 8           // columns of the diagonal block published per work-group barrier (pipelined panel solve): 2 / 4 / 8 -> 102 / 89 / 87 us
 #endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
 // CH_EXP (undefined in the product): knock-out timing of k_ba_cholesky's phases (tools/build_variant.sh ... -DCH_EXP=<bits>,

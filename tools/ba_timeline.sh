@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timeline of one resident local-BA solve: kernel-by-kernel start / duration / gap to the previous kernel (rocprofv3 --kernel-trace).
-#   tools/ba_timeline.sh [config4_mono|config4_stereo|window]
-CFG=${1:-config4_mono}
+#   tools/ba_timeline.sh [config4_mono|config4_stereo|window] [det: OV2_OPT_BA_DETERMINISTIC]
+CFG=${1:-config4_mono}; DET=${2:-0}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/batl_$CFG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 cat > /tmp/ba_tl.py <<PY
 import os, sys
@@ -9,6 +9,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import ov2slam_amd
 from ov2slam_amd import optimizer, synth
 ctx = ov2slam_amd.Context(0)
+if "$DET" == "det": ctx.set_option(ov2slam_amd._lib.OV2_OPT_BA_DETERMINISTIC, 1)
 pb = {"config4_mono": lambda: synth.make_ba_problem(50, 10000, 30, stereo=False, seed=42),
       "config4_stereo": lambda: synth.make_ba_problem(50, 10000, 30, stereo=True, seed=42),
       "window": lambda: synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7)}["$CFG"]()
