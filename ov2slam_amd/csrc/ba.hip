@@ -911,8 +911,19 @@ __global__ __launch_bounds__(256) void k_ba_det_reduce(BADev D)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nn; e += stride) {
         const int r = (int)(e / D.nfp), c = (int)(e - (long long)r * D.nfp);
         if (c < (r & ~31)) continue;                            // (left of the diagonal tile: never written)
+        // (loads first, in batches of eight, then the stores: a load-add-store per copy made every copy a dependent round trip)
+        const double *__restrict__ src = D.Hpart + e;
         double t = 0;
-        for (int q = 0; q < ncopy; q++) { double *src = D.Hpart + (size_t)q * nn + e; t += *src; *src = 0; }
+        int q = 0;
+        for (; q + 8 <= ncopy; q += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(q + u) * nn];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t += v[u];
+        }
+        for (; q < ncopy; q++) t += src[(size_t)q * nn];
+        for (q = 0; q < ncopy; q++) D.Hpart[(size_t)q * nn + e] = 0;
         D.H[e] = t;
     }
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < D.nfp; e += stride) {
