@@ -22,8 +22,9 @@ The same line also carries:
     single_sequence : ONE camera stream through the drop-in entry (ov2_tracker_track_frame: one H2D of the frame, one
                       LK launch, one sync, hipGraph replay) -- PCIe-inclusive per-frame latency and frames/s; this is the
                       mode configs[1], [2] and [4] of BASELINE.json actually use
-    config5         : the 11 synthetic EuRoC-length sequences sharded longest-first over the ranks, each run frame by
-                      frame through the single-sequence path (+ detection at keyframes); aggregate over RCCL all-gather
+    config5         : the 11 synthetic EuRoC-length sequences (full length) sharded longest-first over the ranks; a rank's sequences
+                      advance in lock-step (tools/lockstep_driver.cpp on ov2_btracker_*), keyframes to per-sequence mapper /
+                      estimator contexts; the per-sequence-stream form beside it; aggregate over RCCL all-gather
     ba              : local-BA LM iterations/s on config[3] (50 KF x 10k landmarks x 30 obs) and variants (rank 0, N=1)
     parity          : the tracker's output on one frame vs the oracle (bit-exact) and the BA poses vs the oracle
     cpu_baseline    : the oracle (CPU port of the reference arithmetic) rebuilt -O3 -march=native on this host
@@ -242,71 +243,99 @@ def config5_plan(world, scale):
     return counts, batch.assign_sequences(counts, world)
 
 
-def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2):
-    """This rank's share of the 11 EuRoC-length synthetic sequences through the single-sequence path; all-gather of
-    (frames, seconds, tracked, attempted, squared tracking error) over torch.distributed -- the only collective."""
-    from ov2slam_amd import batch
+def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2, stream_scale=16):
+    """This rank's share of the 11 EuRoC-length synthetic sequences, ALL OF THEM IN LOCK-STEP through one native host process
+    (tools/lockstep_driver.cpp on ov2_btracker_*: one enqueue per frame step covers every sequence of the rank; keyframes go to
+    per-sequence mapper / estimator contexts), at the full frame counts (scale 1).  Beside it, for comparison, the same rank's
+    sequences at 1/stream_scale length through the per-sequence stream driver (tools/stream_driver.cpp, `concurrency` at a time).
+    All-gather of the counters over torch.distributed -- the only collective."""
+    from ov2slam_amd import batch, stream
     counts, plan = config5_plan(world, scale)
     mine = plan[rank]
-    loc = dict(frames=0.0, seconds=0.0, tracked=0.0, attempted=0.0, ate_sq_sum=0.0, ate_n=0.0, sequences=float(len(mine)), host_native=0.0,
-               keyframes=0.0, stereo_ok=0.0, stereo_kps=0.0, ba_solves=0.0, ba_iterations=0.0, ba_seconds=0.0, ba_skipped=0.0, device=float(device),
-               seconds_one_at_a_time=0.0)
+    keys = ("frames", "seconds", "tracked", "attempted", "ate_sq_sum", "ate_n", "sequences", "host_native", "keyframes", "stereo_ok", "stereo_kps",
+            "ba_solves", "ba_iterations", "ba_seconds", "ba_skipped", "device", "steps", "slam_library_s", "slam_wait_loader_s", "slam_wait_mapper_s",
+            "all_frames", "all_seconds", "all_ba_solves", "all_ba_iterations", "all_keyframes",
+            "stream_frames", "stream_seconds", "stream_ba_solves", "stream_ba_skipped", "stream_keyframes")
+    loc = {k: 0.0 for k in keys}
+    loc["sequences"] = float(len(mine)); loc["device"] = float(device)
+    argv_note = stream.lockstep_argv("lockstep_driver", ["<case:%s>" % s for s in mine], "newest", device)
     if dry:
         loc["frames"] = float(sum(counts[s] for s in mine)); loc["seconds"] = 1.0 + 0.25 * rank
-        loc["tracked"] = loc["attempted"] = 300.0 * loc["frames"]
+        loc["tracked"] = loc["attempted"] = 300.0 * loc["frames"]; loc["steps"] = float(max([counts[s] for s in mine] + [0]))
         loc["keyframes"] = loc["frames"] / 5; loc["ba_solves"] = loc["keyframes"]; loc["ba_iterations"] = 5 * loc["ba_solves"]; loc["ba_seconds"] = 0.5
-    else:
+    elif mine:
         from ov2slam_amd import synth
+        import tempfile
         tex = synth.base_texture(1400, 1234)
         names = sorted(batch.EUROC_FRAMES)
-        seqs = [batch.SyntheticSequence(s, counts[s], seed=1000 + names.index(s), tex=tex, stereo=True) for s in mine]   # generation untimed
         windows = [synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7 + i) for i in range(2)]    # local-BA windows (optimizer.cpp:150-188)
-        # host side: the native driver (tools/stream_driver.cpp, what a C++ front-end costs) when g++ is there, else the Python loop
-        import tempfile
-        from ov2slam_amd import stream
         td = tempfile.TemporaryDirectory()
-        try:
-            exe = stream.build_native_driver(td.name)
-            cases = []
-            for i, sq in enumerate(seqs):
-                cases.append(os.path.join(td.name, "case%d.bin" % i)); stream.write_case(cases[-1], sq, windows)
-            stream.run_native(exe, cases[-1], device=device)                          # warm-up (page cache, clocks)
-            loc["host_native"] = 1.0
-        except Exception:
-            exe = None
-            loc["host_native"] = 0.0
-        all_st, conc_seconds = None, None
-        if exe and concurrency > 1 and len(seqs) > 1:
-            # the rank's sequences as concurrent processes on its GPU (each a three-thread keyframe cycle on three contexts)
-            all_st, conc_seconds = stream.run_native_concurrent(exe, cases, device=device, concurrency=concurrency)
-        for i, sq in enumerate(seqs):
-            st = all_st[i] if all_st else (stream.run_native(exe, cases[i], device=device) if exe else batch.run_sequence(ctx, sq, ba_problems=windows))
-            loc["frames"] += st["frames"]; loc["seconds"] += st["seconds"]; loc["tracked"] += st["tracked"]
-            loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
+        exe_l = stream.build_native_driver(td.name, "lockstep_driver")            # no Python fallback: the lock-step host IS the measurement
+        exe_s = stream.build_native_driver(td.name, "stream_driver")
+        loc["host_native"] = 1.0
+
+        seqs = [batch.SyntheticSequence(sname, counts[sname], seed=1000 + names.index(sname), tex=tex, stereo=True) for sname in mine]   # generation untimed
+
+        def cases_for(cnts, tag):
+            out = []
+            for i, (sname, sq) in enumerate(zip(mine, seqs)):
+                sq.n_frames = int(cnts[sname])                                    # the views cycle: the length is a header field
+                out.append(os.path.join(td.name, "%s%d.bin" % (tag, i))); stream.write_case(out[-1], sq, windows)
+            return out
+        cases = cases_for(counts, "full")
+        warm = cases_for({k: 40 for k in counts}, "warm")
+        stream.run_lockstep(exe_l, warm, device=device)                               # warm-up (page cache, clocks, code objects)
+        stats, summ = stream.run_lockstep(exe_l, cases, device=device, ba_policy="newest")
+        loc["frames"] = summ["frames"]; loc["seconds"] = summ["seconds"]; loc["steps"] = summ["steps"]
+        loc["slam_library_s"] = summ["slam_library_s"]; loc["slam_wait_loader_s"] = summ["slam_wait_for_loader_s"]; loc["slam_wait_mapper_s"] = summ["slam_wait_for_mapper_s"]
+        for st in stats:
+            loc["tracked"] += st["tracked"]; loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
             loc["keyframes"] += st["keyframes"]; loc["stereo_ok"] += st["stereo_ok"]; loc["stereo_kps"] += st["stereo_kps"]
             loc["ba_solves"] += st["ba_solves"]; loc["ba_iterations"] += st["ba_iterations"]; loc["ba_seconds"] += st["ba_busy_s"]
             loc["ba_skipped"] += st["ba_skipped_kfs"]
-        loc["seconds_one_at_a_time"] = loc["seconds"]
-        if conc_seconds is not None:
-            loc["seconds"] = conc_seconds                          # wall clock of the concurrent waves (common start, last end)
+        # equal work for CPU / GPU comparisons: every keyframe gets its localBA (the estimator contexts bound this one)
+        stats_a, summ_a = stream.run_lockstep(exe_l, cases, device=device, ba_policy="all")
+        loc["all_frames"] = summ_a["frames"]; loc["all_seconds"] = summ_a["seconds"]
+        loc["all_ba_solves"] = sum(st["ba_solves"] for st in stats_a); loc["all_ba_iterations"] = sum(st["ba_iterations"] for st in stats_a)
+        loc["all_keyframes"] = sum(st["keyframes"] for st in stats_a)
+        # the per-sequence stream form (round 4's config 5) at reduced length, for the comparison
+        small = cases_for({k: max(12, v // max(1, stream_scale)) for k, v in batch.EUROC_FRAMES.items()}, "small")
+        st_s, sec_s = stream.run_native_concurrent(exe_s, small, device=device, concurrency=max(1, concurrency))
+        loc["stream_frames"] = sum(st["frames"] for st in st_s); loc["stream_seconds"] = sec_s
+        loc["stream_ba_solves"] = sum(st["ba_solves"] for st in st_s); loc["stream_ba_skipped"] = sum(st["ba_skipped_kfs"] for st in st_s)
+        loc["stream_keyframes"] = sum(st["keyframes"] for st in st_s)
         td.cleanup()
     stats = batch.gather_stats(loc)
     agg = batch.aggregate(stats)
-    return {"workload": "11 synthetic stereo sequences with EuRoC frame counts / %d (%d frames), longest-first over %d rank(s); every "
-                        "sequence runs the keyframe cycle of ov2slam_amd.stream on three contexts: per frame ov2_tracker_track_frame + "
-                        "ov2_compute_keypoints, every 5th frame detectSingleScale, right-image pyramid + ov2_stereo_match (mapper "
-                        "thread) and a two-pass 25-KF localBA (estimator thread, newest keyframe only like estimator.cpp:195-205)"
+    sec_all, sec_str = max(stats["all_seconds"]), max(stats["stream_seconds"])
+    return {"workload": "11 synthetic stereo sequences with EuRoC frame counts / %d (%d frames), longest-first over %d rank(s); the sequences of a rank "
+                        "advance IN LOCK-STEP through tools/lockstep_driver.cpp: per frame step ONE ov2_btracker_track_frame (frame upload, CLAHE + "
+                        "pyramid, fused kltTracking, computeKeypoint for every sequence of the rank), every 5th step one batched detectSingleScale; "
+                        "keyframes go to per-sequence mapper contexts (right-image pyramid + ov2_stereo_match on an item view) and estimator "
+                        "contexts (two-pass 25-KF localBA, newest keyframe only like estimator.cpp:195-205); sequences that end drop out"
                         % (scale, int(sum(counts.values())), world),
             "fps": agg["fps"], "frames": agg["frames"], "seconds_slowest_rank": agg["seconds"],
             "frames_per_rank": stats["frames"], "seconds_per_rank": stats["seconds"], "sequences_per_rank": stats["sequences"],
+            "steps_per_rank": stats["steps"],
             "device_per_rank": [int(d) for d in stats["device"]],
-            "concurrent_sequences_per_gpu": int(concurrency),
-            "sum_of_single_stream_seconds_per_rank": stats["seconds_one_at_a_time"],
+            "slam_thread_per_rank": {"library_s": stats["slam_library_s"], "wait_for_loader_s": stats["slam_wait_loader_s"], "wait_for_mapper_s": stats["slam_wait_mapper_s"]},
             "tracked_fraction": sum(stats["tracked"]) / max(1.0, sum(stats["attempted"])),
             "keyframes": sum(stats["keyframes"]), "stereo_ok_fraction": sum(stats["stereo_ok"]) / max(1.0, sum(stats["stereo_kps"])),
             "ba_solves": sum(stats["ba_solves"]), "ba_keyframes_skipped_while_busy": sum(stats["ba_skipped"]),
             "ba_iters_per_s": agg.get("ba_iters_per_s", 0.0),
-            "host": "tools/stream_driver.cpp (native, one process per sequence)" if min(stats["host_native"]) > 0 else "Python driver (ov2slam_amd/stream.py)",
+            "every_keyframe_optimised": {"fps": sum(stats["all_frames"]) / sec_all if sec_all > 0 else None, "seconds_slowest_rank": sec_all,
+                                         "ba_solves": sum(stats["all_ba_solves"]), "keyframes": sum(stats["all_keyframes"]),
+                                         "ba_iters_per_s": sum(stats["all_ba_iterations"]) / sec_all if sec_all > 0 else None},
+            "per_sequence_streams": {"what": "round 4's form of this config: each sequence through its own SLAM thread + ov2_tracker (tools/stream_driver.cpp), "
+                                             "%d at a time per GPU, frame counts / %d" % (int(concurrency), int(stream_scale)),
+                                     "fps": sum(stats["stream_frames"]) / sec_str if sec_str > 0 else None, "frames": sum(stats["stream_frames"]),
+                                     "seconds_slowest_rank": sec_str, "ba_solves": sum(stats["stream_ba_solves"]),
+                                     "ba_keyframes_skipped_while_busy": sum(stats["stream_ba_skipped"]), "keyframes": sum(stats["stream_keyframes"])},
+            "lockstep_speedup_vs_streams": (agg["fps"] / (sum(stats["stream_frames"]) / sec_str)) if sec_str > 0 and sum(stats["stream_frames"]) > 0 else None,
+            "host": "tools/lockstep_driver.cpp (native, one process per rank)" if min(stats["host_native"]) > 0 or dry else "none",
+            "lockstep_argv_rank0": argv_note,
+            "parity": "per-sequence results of the lock-step form are bit-identical to the per-stream form (digests of every tracked position, status, "
+                      "undistorted pixel, bearing, detection and stereo match): tests/test_gpu_stream.py",
             "track_rmse_px": agg.get("ate_rmse", 0.0),
             "ate": "not computable on this path: pose estimation (P3P / PnP, motion model) and triangulation stay on the CPU in the "
                    "reference and are outside SURVEY.md section 8; track_rmse_px is the tracking error against the synthetic flow",
@@ -648,7 +677,8 @@ def main():
                          "(1241x376, wide-image stress) -- a side measurement, not the headline")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher + process group + config-5 plan / all-gather only (CPU test)")
-    ap.add_argument("--config5-scale", type=int, default=16, help="EuRoC frame counts are divided by this for the config-5 run")
+    ap.add_argument("--config5-scale", type=int, default=1, help="EuRoC frame counts are divided by this for the lock-step config-5 run (1 = the full 27 049 frames)")
+    ap.add_argument("--config5-stream-scale", type=int, default=16, help="divisor for the per-sequence-stream comparison run of config 5")
     ap.add_argument("--config5-concurrency", type=int, default=2,
                     help="sequences of a rank that stream concurrently on its GPU inside one driver process (1 = one after another).  Measured "
                          "(tools/r4_conc.py, profiles/r4_stream_concurrency.txt): 1 stream 4.4 k frames/s, 2 streams 7.3 k, 4 streams 6.4 k, 8 streams "
@@ -900,7 +930,7 @@ def main():
     if not args.no_extras and args.workload == "euroc":
         try:
             ctx5 = ov2slam_amd.Context(dev.index)
-            c5 = run_config5(ctx5, rank, world, args.config5_scale, device=dev.index, concurrency=args.config5_concurrency)
+            c5 = run_config5(ctx5, rank, world, args.config5_scale, device=dev.index, concurrency=args.config5_concurrency, stream_scale=args.config5_stream_scale)
             ctx5.close()
         except Exception:
             import traceback

@@ -45,7 +45,7 @@ typedef struct ov2_pyr ov2_pyr;
  * (round 2 added ov2_ba_options::max_solver_time_s).  ov2_version() returns the value the library was built with; a caller
  * must refuse to run when the two differ (the C++ adapters' ov2::Context and ov2slam_amd/_lib.py do): a shorter options
  * struct from an older header would otherwise be read past its end.                                                    */
-#define OV2_ABI_VERSION 400
+#define OV2_ABI_VERSION 500
 int  ov2_version(void);
 /* last error message of the calling thread ("" if none); never NULL */
 const char *ov2_last_error(void);
@@ -116,6 +116,11 @@ void ov2_pyr_destroy(ov2_pyr *p);
 int  ov2_pyr_levels(const ov2_pyr *p);                 /* levels actually built */
 int  ov2_pyr_level_size(const ov2_pyr *p, int level, int *w, int *h);
 int  ov2_pyr_batch(const ov2_pyr *p);
+/* A batch-1 pyramid that ALIASES batch item `item` of `p` (no copy, no allocation on the device): what the entry points that
+ * take batch-1 pyramids (ov2_stereo_match, ov2_fb_klt, ov2_detect_*_d ...) need to work on one sequence of a lock-step batch.
+ * The view shares p's `ready` hand-off (a consumer on another context waits for p's last build) and must be destroyed
+ * (ov2_pyr_destroy) before p.                                                                                        */
+int  ov2_pyr_item_view(const ov2_pyr *p, int item, ov2_pyr **out);
 /* (re)build from host images: H2D copy + kernels, asynchronous on ctx's stream.  A batch-1 image is repacked into the context's
  * pinned staging buffer before the call returns (one contiguous DMA whatever the row stride; the caller's buffer is free at
  * once); for batch > 1 the host buffer must stay valid until ov2_ctx_sync / a later blocking call */
@@ -254,6 +259,58 @@ const ov2_pyr *ov2_tracker_cur_pyr(const ov2_tracker *t);
 const ov2_pyr *ov2_tracker_prev_pyr(const ov2_tracker *t);
 int  ov2_tracker_frames(const ov2_tracker *t);     /* frames preprocessed so far */
 int  ov2_tracker_uses_graph(const ov2_tracker *t); /* 1 when the graph path is active */
+
+/* ---- lock-step tracker: `batch` camera streams advance ONE FRAME PER CALL ---------------------------------
+ * The offline / batch mode of the reference's benchmark protocol (benchmark_scripts/euroc_bench.sh:3-27 runs whole sequences one
+ * after the other; BASELINE.json configs[4] shards them over GPUs): a rank that owns several sequences does not need their frames
+ * one stream at a time.  One stream is a chain of ~10 small dependent launches per frame and a rank's streams together saturate
+ * the launch rate with the CUs ~5 % busy (profiles/r4_stream_concurrency.txt); here every launch of the per-frame enqueue --
+ * frame upload, CLAHE, pyramid, the fused kltTracking kernel (both fbKltTracking calls + retry), Frame::computeKeypoint -- covers
+ * all streams at once: same kernels as ov2_tracker_*, grid extended by the batch item, ONE synchronisation per step.
+ * Results per item are bit-identical to an ov2_tracker fed the same frames / keypoints (tests/test_gpu_lockstep.py).
+ *   items [0, n_active) take part in a call (sequences of different length: order them longest first and shrink n_active as
+ *   they end); the state of the other items is not touched.
+ *   point arrays hold cfg->n_max slots per item: item b's points are [b*n_max, b*n_max + n_h[b]); n_h[b] <= n_max.
+ *   images: img_h[b] = frame of item b, rows `stride` bytes apart.  Two pinned staging sets exist (which = 0 / 1,
+ *   ov2_btracker_image_buffer): a reader thread fills set (f+1)&1 while step f runs; frames passed from a pinned slot are not
+ *   copied on the host.  ov2_btracker_upload starts the H2D of a filled set on a copy stream of its own (overlapping the
+ *   previous step's kernels); a step whose frames were not uploaded that way uploads them itself.
+ * hipGraph replay (cfg->use_graph) is not used here: n_active changes the grids.                                          */
+typedef struct ov2_btracker ov2_btracker;
+int  ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, ov2_btracker **out);
+void ov2_btracker_destroy(ov2_btracker *t);
+int  ov2_btracker_batch(const ov2_btracker *t);
+int  ov2_btracker_frames(const ov2_btracker *t);
+/* pinned slot of item `item` in staging set `which` (0 / 1); *stride receives its pitch */
+uint8_t *ov2_btracker_image_buffer(ov2_btracker *t, int which, int item, int *stride);
+/* asynchronous H2D of items [0, n_active) of staging set `which` (the caller has filled the slots); the next
+ * ov2_btracker_track_frame whose img_h[] are exactly those slots consumes the uploaded copy                   */
+int  ov2_btracker_upload(ov2_btracker *t, int which, int n_active);
+/* Frame::computeKeypoint inside the per-step enqueue, as ov2_tracker_set_calibration (one calibration: the sequences of a batch
+ * come from one camera rig)                                                                                            */
+int  ov2_btracker_set_calibration(ov2_btracker *t, int model, const double K[4], const double *D, int nD, const double iK[9]);
+/* preprocessImage + kltTracking of items [0, n_active): the lock-step form of ov2_tracker_track_frame, same per-item semantics
+ * (first frame: pyramids only; has_prior_h / klt_use_prior / status bits / p3p_req[b] as there, the "motion model is wrong" retry
+ * of visual_front_end.cpp:225-230 included).  Blocking: one synchronisation.                                             */
+int  ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const *img_h, int stride, const float *kps_xy_h,
+                              const float *prior_xy_h, const uint8_t *has_prior_h, const int *n_h, int klt_use_prior,
+                              float *out_xy_h, uint8_t *status_h, int *p3p_req);
+/* unpx (2 floats) / bv (3 doubles) of the first n keypoints of item `item` from the LAST ov2_btracker_track_frame */
+int  ov2_btracker_last_keypoints(const ov2_btracker *t, int item, int n, float *unpx_xy_h, double *bv_xyz_h);
+/* MapManager::extractKeypoints on the current frame of items [0, n_active) in one call (all sequences of a lock-step batch reach
+ * their keyframes together): ov2_detect_singlescale_batch_d / ov2_detect_grid_fast_batch_d on level 0 of the current pyramids
+ * with host buffers -- cur_xy_h: n_max slots per item, ncur_h[b] of them valid; out_xy_h: out_cap slots per item
+ * (>= 2*(w/cell)*(h/cell), FAST: (w/cell)*(h/cell)); quality_inout / fast_th_inout: one adaptive state per item.          */
+int  ov2_btracker_detect_singlescale(ov2_btracker *t, int n_active, int cell, const float *cur_xy_h, const int *ncur_h, const int roi[4],
+                                     double *quality_inout, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
+int  ov2_btracker_detect_grid_fast(ov2_btracker *t, int n_active, int cell, const float *cur_xy_h, const int *ncur_h, int *fast_th_inout,
+                                   int mask_mode, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
+/* the current / previous frame's pyramids: the whole batch, or item `item` as a batch-1 view (owned by the tracker; valid until the
+ * step after next overwrites that pyramid) -- what the mapper context passes to ov2_stereo_match as `left`                  */
+const ov2_pyr *ov2_btracker_cur_pyr(const ov2_btracker *t);
+const ov2_pyr *ov2_btracker_prev_pyr(const ov2_btracker *t);
+const ov2_pyr *ov2_btracker_cur_item(const ov2_btracker *t, int item);
+const ov2_pyr *ov2_btracker_prev_item(const ov2_btracker *t, int item);
 
 /* ---- keypoint detection ---------------------------------------------
  * mask_mode for the FAST grid detector: the reference passes a

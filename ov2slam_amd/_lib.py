@@ -144,6 +144,7 @@ SIGNATURES = {
     "ov2_pyr_levels": (_i, [_vp]),
     "ov2_pyr_level_size": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ov2_pyr_batch": (_i, [_vp]),
+    "ov2_pyr_item_view": (_i, [_vp, _i, _pp]),
     "ov2_pyr_build_h": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "ov2_pyr_build_d": (_i, [_vp, _vp, _vp, _i, C.c_size_t]),
     "ov2_pyr_download": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
@@ -170,6 +171,21 @@ SIGNATURES = {
     "ov2_tracker_prev_pyr": (_vp, [_vp]),
     "ov2_tracker_frames": (_i, [_vp]),
     "ov2_tracker_uses_graph": (_i, [_vp]),
+    "ov2_btracker_create": (_i, [_vp, C.POINTER(TrackerConfig), _i, _pp]),
+    "ov2_btracker_destroy": (None, [_vp]),
+    "ov2_btracker_batch": (_i, [_vp]),
+    "ov2_btracker_frames": (_i, [_vp]),
+    "ov2_btracker_image_buffer": (_vp, [_vp, _i, _i, C.POINTER(_i)]),
+    "ov2_btracker_upload": (_i, [_vp, _i, _i]),
+    "ov2_btracker_set_calibration": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "ov2_btracker_track_frame": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "ov2_btracker_last_keypoints": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ov2_btracker_detect_singlescale": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(_i), _vp, _i, _vp, _i, _vp]),
+    "ov2_btracker_detect_grid_fast": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "ov2_btracker_cur_pyr": (_vp, [_vp]),
+    "ov2_btracker_prev_pyr": (_vp, [_vp]),
+    "ov2_btracker_cur_item": (_vp, [_vp, _i]),
+    "ov2_btracker_prev_item": (_vp, [_vp, _i]),
     "ov2_lk_track": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_fb_klt": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
     "ov2_fb_klt_d": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -191,7 +207,7 @@ SIGNATURES = {
     "ov2_local_ba": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(LocalBAOptions), C.POINTER(LocalBAResult)]),
 }
 
-OV2_ABI_VERSION = 400          # include/ov2slam_hip.h
+OV2_ABI_VERSION = 500          # include/ov2slam_hip.h
 
 _lib = None
 

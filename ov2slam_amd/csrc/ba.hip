@@ -526,7 +526,7 @@ __device__ __forceinline__ void block_reduce3(double &a, double &b, double &c, d
 // per-wave 35 x 33 LDS transpose -- every lane parks its partials, lane q adds up row q -- instead of 35 six-step
 // shuffle butterflies (420 ds_bpermute per landmark: a third of this kernel, knock-out timing BA_KO=4); lane q keeps
 // the running anchor sums q < 27 in ONE register until the anchor changes.
-// dynamic LDS: 8*nfp (two W rows per wavefront) + n_opt*27 + 4*n_opt*36 + 4*LIN_RED doubles
+// dynamic LDS: 8*nfp (two W rows per wavefront) + n_opt*27 + 4*n_opt*21 + 4*LIN_RED doubles
 #define LIN_NRED 35
 #define LIN_RED (LIN_NRED * 33)
 __device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, double v)
@@ -2530,7 +2530,6 @@ struct ov2_ba_dev {
     bool pool_owned = true;             // false: the pool lives in the context's grow-only device scratch (transient small problems)
     int n_res = 0;
     int *lm_order = nullptr;            // landmarks sorted by anchor keyframe (device)
-    void *det_pool = nullptr; size_t det_bytes = 0;    // OV2_OPT_BA_DETERMINISTIC: the per-work-group copies (allocated by the first such solve)
     std::vector<double> h_poses0, h_lam0;
     int device = 0;
 };
@@ -2581,6 +2580,10 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
             const int lm = p->res_lm[i];
             if (lm < 0 || lm >= p->n_lm) { err = "res_lm out of range"; break; }
             if (p->res_type[i] != OV2_RES_RIGHT_ANCH && (p->res_kf[i] < 0 || p->res_kf[i] >= p->n_kf)) { err = "res_kf out of range"; break; }
+            // The observer of a LEFT / RIGHT block is never the landmark's anchor keyframe (the reference skips the anchor's own
+            // mono observation, src/optimizer.cpp:290-296, and gives its right-camera observation the RIGHT_ANCH factor): the lineariser
+            // relies on it (J_observer = -J_anchor serves both the observer's diagonal block and the anchor-observer block)
+            if (p->res_type[i] != OV2_RES_RIGHT_ANCH && p->res_kf[i] == p->lm_anchor_kf[lm]) { err = "a LEFT / RIGHT block observes its landmark from the anchor keyframe (use OV2_RES_RIGHT_ANCH)"; break; }
             cn[lm]++; na_t++;
         }
         nactT[(size_t)t] = na_t; npoT[(size_t)t] = np_t; errT[(size_t)t] = err;
@@ -2662,7 +2665,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     memset(&D, 0, sizeof(D));
     D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
     {   // beyond what the LDS-resident lineariser / Cholesky hold (~90 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
-        const size_t lin_lds = 8 * (8 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+        const size_t lin_lds = 8 * (8 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 21 + 4 * (size_t)LIN_RED) + 64;
         const size_t chol_lds = chol_lds_bytes(nf, nfp);
         D.big = (lin_lds > 159 * 1024 || chol_lds > 150 * 1024 || nf > CH_MAX_LDS_N) ? 1 : 0;
         if (ctx->ba_force_large) D.big = 1;                                    // OV2_OPT_BA_FORCE_LARGE: the path on small problems (tests)
@@ -2908,7 +2911,6 @@ static void ba_destroy(ov2_ba_dev *dev)
     if (!dev) return;
     (void)hipSetDevice(dev->device);
     if (dev->pool && dev->pool_owned) (void)hipFree(dev->pool);
-    if (dev->det_pool) (void)hipFree(dev->det_pool);
     delete dev;
 }
 
@@ -2934,7 +2936,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     const int n_opt = D.nf / 6;
     const size_t lin_lds = D.big ? 8 * ((D.lin_direct ? 0 : (size_t)(D.nf / 6) * 27) + 4 * (size_t)LIN_RED) + 64
                          : D.ldim == 3 ? 8 * (3 * (size_t)D.lin_waves * D.nfp + (size_t)n_opt * 27) + 64
-                                       : 8 * (8 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 36 + 4 * (size_t)LIN_RED) + 64;
+                                       : 8 * (8 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 21 + 4 * (size_t)LIN_RED) + 64;
     const size_t chol_lds = D.chol_hbm ? 8 * ((size_t)CH_NB * CH_LDP + (size_t)D.nfp) + 64  // k_chol_solve: scratch block + the solution vector
                                   : chol_lds_bytes(D.nf, D.nfp);
     OV2_REQUIRE(lin_lds <= 159 * 1024, OV2_EUNSUPPORTED, "too many optimised keyframes for the LDS-aggregating lineariser");
@@ -3027,17 +3029,18 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         const size_t b_H = al256(8 * ncopy * nn), b_bf = al256(8 * ncopy * D.nfp), b_c = al256(8 * std::max<size_t>(1, ncopy));
         const size_t b_G = al256(8 * (size_t)ksplit * nn), b_v = al256(8 * (size_t)ksplit * D.nfp);
         const size_t need = b_H + b_bf + b_c + b_G + b_v;
-        if (need > dev->det_bytes) {
-            if (dev->det_pool) { OV2_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(dev->det_pool); dev->det_pool = nullptr; dev->det_bytes = 0; }
-            hipError_t e = hipMalloc(&dev->det_pool, need);
+        // the copies live in the CONTEXT (grow-only, like d_scratch): ov2_local_ba / ov2_ba_solve create a transient problem per call
+        if (need > ctx->ba_det_bytes) {
+            if (ctx->ba_det_pool) { OV2_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(ctx->ba_det_pool); ctx->ba_det_pool = nullptr; ctx->ba_det_bytes = 0; }
+            hipError_t e = hipMalloc(&ctx->ba_det_pool, need);
             if (e != hipSuccess) { ov2_set_error("hipMalloc(%zu) for the deterministic mode: %s", need, hipGetErrorString(e)); return OV2_ENOMEM; }
-            dev->det_bytes = need;
+            ctx->ba_det_bytes = need;
         }
-        uint8_t *q = (uint8_t *)dev->det_pool;
+        uint8_t *q = (uint8_t *)ctx->ba_det_pool;
         D.det = 1; D.det_lin = det_lin; D.det_po = det_po; D.det_ksplit = ksplit;
         D.Hpart = (double *)q; D.bfpart = (double *)(q + b_H); D.costpart = (double *)(q + b_H + b_bf);
         D.Gpart = (double *)(q + b_H + b_bf + b_c); D.vpart = (double *)(q + b_H + b_bf + b_c + b_G);
-        OV2_HIP_CHECK(hipMemsetAsync(dev->det_pool, 0, b_H + b_bf + b_c, s));      // (the copies are clean between linearisations: k_ba_det_reduce clears as it reads)
+        OV2_HIP_CHECK(hipMemsetAsync(ctx->ba_det_pool, 0, b_H + b_bf + b_c, s));      // (the copies are clean between linearisations: k_ba_det_reduce clears as it reads)
         D.lin_blocks = det_lin;
         DG.det = 1; DG.det_ksplit = ksplit; DG.Gpart = D.Gpart; DG.vpart = D.vpart;
     }
@@ -3131,6 +3134,9 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
             // outcome of iteration it - 1 (k_ba_decide of that iteration)
             unsigned spins = 0;
             while (flag_h[0] < 2 * (it - 1)) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+                __builtin_ia32_pause();                                               // the estimator thread shares its core's siblings with the SLAM / mapper threads
+#endif
                 if ((++spins & 0x3FFFFFu) == 0) {                                 // (a watchdog, ~every 0.3 s: a query per wait put a 6 us bubble in front of the next launch)
                     const hipError_t q = hipStreamQuery(s);
                     if (q == hipSuccess) break;                               // everything enqueued has run: the word is final

@@ -56,6 +56,7 @@ struct ov2_ctx {
     int ba_xyz_lin_waves = 0;                  // OV2_OPT_BA_XYZ_LIN_WAVES (0 = auto, 1, 2)
     int ba_pose_only_fused = 1;                // OV2_OPT_BA_POSE_ONLY_FUSED
     int ba_deterministic = 0;                  // OV2_OPT_BA_DETERMINISTIC
+    void *ba_det_pool = nullptr; size_t ba_det_bytes = 0;   // OV2_OPT_BA_DETERMINISTIC: per-work-group copies of H / F^T b / G (grow-only)
     int debug = 0;                             // OV2_OPT_DEBUG; initial value: environment OV2_DEBUG, read once by ov2_ctx_create
     // pinned staging of host images on their way to the device: its own buffer (h_scratch is rewritten by the next call's small
     // arrays while an asynchronous image upload may still be in flight) and an event that says when it may be refilled
@@ -107,6 +108,8 @@ struct ov2_pyr {
     hipEvent_t ready = nullptr;
     hipStream_t producer = nullptr;
     bool built = false;
+    // ov2_pyr_item_view: a batch-1 alias of one item of `parent` (owns neither the memory nor the event; the hand-off state is the parent's)
+    const ov2_pyr *parent = nullptr;
 };
 int ov2_pyr_mark_ready(ov2_ctx *ctx, ov2_pyr *p);              // after the last kernel of a build was enqueued
 int ov2_pyr_wait_ready(ov2_ctx *ctx, const ov2_pyr *p);        // before the first kernel of a consumer
@@ -123,4 +126,5 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
                          const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
                          const float *sad_x = nullptr, float sad_up = 0.f,       // sad_x: stereo mode (lk.hip: k_track_klt)
-                         int track_impl = OV2_TRACK_IMPL_WAVE);
+                         int track_impl = OV2_TRACK_IMPL_WAVE,
+                         int items = 1);   // items > 1 (trackb.hip): batch items [0, items) of both pyramids, n_max point slots and one n_dev entry per item

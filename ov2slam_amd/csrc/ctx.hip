@@ -29,7 +29,7 @@ int ov2_ctx::reserve_host(size_t bytes)
     if (bytes <= h_scratch_bytes) return OV2_OK;
     if (h_scratch) { OV2_HIP_CHECK(hipStreamSynchronize(stream)); OV2_HIP_CHECK(hipHostFree(h_scratch)); h_scratch = nullptr; h_scratch_bytes = 0; }
     size_t cap = bytes + bytes / 2 + 4096;
-    OV2_HIP_CHECK(hipHostMalloc(&h_scratch, cap, hipHostMallocDefault));
+    OV2_HIP_CHECK(hipHostMalloc(&h_scratch, cap, hipHostMallocCoherent));   // (ba_run polls a flag word the device writes: coherence stated, not left to HIP_HOST_COHERENT)
     h_scratch_bytes = cap;
     return OV2_OK;
 }
@@ -131,6 +131,7 @@ void ov2_ctx_destroy(ov2_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->stat_slots) (void)hipFree(ctx->stat_slots);
+    if (ctx->ba_det_pool) (void)hipFree(ctx->ba_det_pool);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_img) (void)hipHostFree(ctx->h_img);
     if (ctx->img_ev) (void)hipEventDestroy(ctx->img_ev);

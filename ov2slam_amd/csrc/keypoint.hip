@@ -16,9 +16,12 @@
 __global__ __launch_bounds__(256) void k_compute_keypoints(KpCalib c, const float2 *__restrict__ px, int n,
                                                            float2 *__restrict__ unpx, double *__restrict__ bv, const int *__restrict__ n_dev)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) n = min(n, *n_dev);                        // the tracker's graph is launched over its capacity: the count lives on the device
-    if (i >= n) return;
+    const int il = blockIdx.x * blockDim.x + threadIdx.x;
+    const int item = blockIdx.y;                          // lock-step tracker (trackb.hip): n point slots and one count per batch item
+    const int slots = n;                                  // point slots per item
+    if (n_dev) n = min(n, n_dev[item]);                   // the tracker's graph is launched over its capacity: the count lives on the device
+    if (il >= n) return;
+    const int i = item * slots + il;
     const float2 p = px[i];
     const float2 u = kp_undistort_image_point(c, p);
     unpx[i] = u;
@@ -49,9 +52,9 @@ int ov2_kp_calib(int model, const double K[4], const double *D, int nD, const do
 }
 
 // launcher for track.hip: Frame::computeKeypoint of the tracker's output positions inside its per-frame enqueue
-int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d)
+int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d, int items)
 {
-    hipLaunchKernelGGL(k_compute_keypoints, dim3((n_max + 255) / 256), dim3(256), 0, s, c, (const float2 *)px_d, n_max, (float2 *)unpx_d, bv_d, n_dev);
+    hipLaunchKernelGGL(k_compute_keypoints, dim3((n_max + 255) / 256, items), dim3(256), 0, s, c, (const float2 *)px_d, n_max, (float2 *)unpx_d, bv_d, n_dev);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }

@@ -460,11 +460,14 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
                                                   float2 *__restrict__ out_xy, uint8_t *__restrict__ status,
                                                   int *__restrict__ iters_out, const float *__restrict__ sad_x, float sad_up)
 {
-    const int n = n_dev ? *n_dev : prm.n_max;
+    const int item = blockIdx.y;                                     // batch item (lock-step tracker, trackb.hip); 0 for one camera
+    const int n = n_dev ? n_dev[item] : prm.n_max;
     const int r = threadIdx.x & 15;
     // blockDim.x = 64: four keypoints per wavefront; blockDim.x = 16: one (A/B switch of the launcher)
-    const int i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    if (i >= n) return;
+    const int il = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    if (il >= n) return;
+    const int i = item * prm.n_max + il;
+    const uint8_t *pb = P.base + (long long)item * P.item_stride, *cb = C.base + (long long)item * C.item_stride;
     const float2 kp = kps[i];
     float2 pr = priors[i];
     const bool has_prior = (flags[i] & 1) != 0;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
     float fx = 0.f, fy = 0.f;
     for (int attempt = 0; attempt < 2; attempt++) {
         LKPointState st;
-        ok = fb_track_point<WIN>(P.base, C.base, P, C, prm, max_level, kp, pr, r, fx, fy, st);
+        ok = fb_track_point<WIN>(pb, cb, P, C, prm, max_level, kp, pr, r, fx, fy, st);
         iters += st.iters;
         if (ok || !has_prior || attempt == 1) break;
         pr = make_float2(fx, fy);                                         // visual_front_end.cpp:213-217, map_manager.cpp:533-538
@@ -602,11 +605,12 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
                          const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                         const float *sad_x, float sad_up, int track_impl)
+                         const float *sad_x, float sad_up, int track_impl, int items)
 {
     const PyrDesc &P = prev->d, &C = cur->d;
-    OV2_REQUIRE(P.n_levels == C.n_levels && P.batch == 1 && C.batch == 1 && P.win == C.win && win == P.win, OV2_EINVAL,
+    OV2_REQUIRE(P.n_levels == C.n_levels && items >= 1 && P.batch >= items && C.batch >= items && P.win == C.win && win == P.win, OV2_EINVAL,
                 "tracker pyramids differ in geometry");
+    OV2_REQUIRE(items == 1 || sad_x == nullptr, OV2_EINVAL, "the stereo mode takes one item");
     LKParams prm = make_params(prev, win, lvl_full, max_iter, eps, OV2_LK_USE_INITIAL_FLOW | OV2_LK_GET_MIN_EIGENVALS,
                                err_th, fb_dist, 1, n_max);
     const int lf = prm.max_level;                                  // clamped to the pyramid like feature_tracker.cpp:50-52
@@ -615,9 +619,9 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
     // level's search block requested while the current level iterates.  Other windows (and OV2_OPT_TRACK_IMPL = ROW): the
     // row-per-lane kernel, four keypoints per wavefront
     if (win == 9 && track_impl == OV2_TRACK_IMPL_WAVE)
-        return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up);
+        return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up, items);
     constexpr int kpw = 4;
-    dim3 grid((n_max + kpw - 1) / kpw), block(16 * kpw);
+    dim3 grid((n_max + kpw - 1) / kpw, items), block(16 * kpw);
 #define OV2_TK(W) hipLaunchKernelGGL(k_track_klt<W>, grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
                                      (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up)
     switch (win) {

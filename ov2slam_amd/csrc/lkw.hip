@@ -251,14 +251,16 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
 }
 
 // fbKltTracking for this wavefront's keypoint (feature_tracker.cpp:35-137): forward levels, filter, backward level 0, fb test
-__device__ __forceinline__ int w_fb_track_point(const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int max_level, float2 kp, float2 pr,
+// pb / cb: the batch item of the previous / current pyramid this keypoint belongs to
+__device__ __forceinline__ int w_fb_track_point(const uint8_t *__restrict__ pb, const uint8_t *__restrict__ cb, const PyrDesc &P, const PyrDesc &C,
+                                                const LKParams &prm, int max_level, float2 kp, float2 pr,
                                                 int lane, uint32_t *lds, float &fx, float &fy, int &iters)
 {
     WState st;
     st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0;
     bool pre_ok = false; int pre_x0 = 0, pre_y0 = 0; uint32_t pre_v[2] = {0u, 0u};
     for (int level = max_level; level >= 0; level--)
-        w_level(P.base, P.lv[level], C.base, C.lv[level], level > 0 ? &C.lv[level - 1] : nullptr, prm, level, max_level,
+        w_level(pb, P.lv[level], cb, C.lv[level], level > 0 ? &C.lv[level - 1] : nullptr, prm, level, max_level,
                 (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, lane, lds, st, pre_ok, pre_x0, pre_y0, pre_v);
     fx = st.nx; fy = st.ny;
     iters = st.iters;
@@ -271,7 +273,7 @@ __device__ __forceinline__ int w_fb_track_point(const PyrDesc &P, const PyrDesc 
             WState sb;                                                                     // backward: cur -> prev at level 0 from the keypoint (:113-116)
             sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0;
             pre_ok = false;
-            w_level(C.base, C.lv[0], P.base, P.lv[0], nullptr, prm, 0, 0, true, fx, fy, lane, lds, sb, pre_ok, pre_x0, pre_y0, pre_v);
+            w_level(cb, C.lv[0], pb, P.lv[0], nullptr, prm, 0, 0, true, fx, fy, lane, lds, sb, pre_ok, pre_x0, pre_y0, pre_v);
             iters += sb.iters;
             if (!sb.status) ok = 0;
             else {
@@ -292,9 +294,13 @@ __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKPara
                                                     int *__restrict__ iters_out, const float *__restrict__ sad_x, float sad_up)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[W_IROWS * 4 + W_JROWS * 5 + W_GRID * W_GRID + 4];
-    const int n = n_dev ? *n_dev : prm.n_max;
-    const int lane = threadIdx.x, i = blockIdx.x;
-    if (i >= n) return;
+    // blockIdx.y: batch item (lock-step tracker, trackb.hip: n_max point slots and one count per item; 0 for one camera)
+    const int item = blockIdx.y;
+    const int n = n_dev ? n_dev[item] : prm.n_max;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n) return;
+    const int i = item * prm.n_max + blockIdx.x;
+    const uint8_t *pb = P.base + (long long)item * P.item_stride, *cb = C.base + (long long)item * C.item_stride;
     const float2 kp = kps[i];
     float2 pr = priors[i];
     const bool has_prior = (flags[i] & 1) != 0;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKPara
     float fx = 0.f, fy = 0.f;
     for (int attempt = 0; attempt < 2; attempt++) {
         int it = 0;
-        ok = w_fb_track_point(P, C, prm, max_level, kp, pr, lane, lds, fx, fy, it);
+        ok = w_fb_track_point(pb, cb, P, C, prm, max_level, kp, pr, lane, lds, fx, fy, it);
         iters += it;
         if (ok || !has_prior || attempt == 1) break;
         pr = make_float2(fx, fy);                                   // visual_front_end.cpp:213-217, map_manager.cpp:533-538
@@ -324,9 +330,9 @@ __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKPara
 
 int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int lp, int lf, int n_max, const int *n_dev,
                            const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                           const float *sad_x, float sad_up)
+                           const float *sad_x, float sad_up, int items)
 {
-    hipLaunchKernelGGL(k_track_klt_w, dim3(n_max), dim3(64), 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, (const float2 *)priors, flags,
+    hipLaunchKernelGGL(k_track_klt_w, dim3(n_max, items), dim3(64), 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, (const float2 *)priors, flags,
                        (float2 *)out_xy, status, iters, sad_x, sad_up);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;

@@ -324,6 +324,7 @@ int ov2_launch_pyr_build(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int str
 // ---- producer / consumer ordering across contexts ---------------------------------
 int ov2_pyr_mark_ready(ov2_ctx *ctx, ov2_pyr *p)
 {
+    OV2_REQUIRE(p->parent == nullptr, OV2_EINVAL, "an item view (ov2_pyr_item_view) is read-only: build the batch pyramid it aliases");
     OV2_HIP_CHECK(hipEventRecord(p->ready, ctx->stream));
     p->producer = ctx->stream;
     p->built = true;
@@ -332,6 +333,7 @@ int ov2_pyr_mark_ready(ov2_ctx *ctx, ov2_pyr *p)
 
 int ov2_pyr_wait_ready(ov2_ctx *ctx, const ov2_pyr *p)
 {
+    if (p->parent) p = p->parent;                 // an item view: the batch pyramid's hand-off state
     if (p->producer != ctx->stream && p->ready) OV2_HIP_CHECK(hipStreamWaitEvent(ctx->stream, p->ready, 0));
     return OV2_OK;
 }
@@ -387,9 +389,28 @@ int ov2_pyr_create(ov2_ctx *ctx, int w, int h, int win, int max_level, int batch
     return OV2_OK;
 }
 
+int ov2_pyr_item_view(const ov2_pyr *p, int item, ov2_pyr **out)
+{
+    OV2_REQUIRE(p && out, OV2_EINVAL, "NULL argument");
+    *out = nullptr;
+    OV2_REQUIRE(p->parent == nullptr, OV2_EINVAL, "views of views are not supported");
+    OV2_REQUIRE(item >= 0 && item < p->d.batch, OV2_EINVAL, "batch item out of range");
+    ov2_pyr *v = new (std::nothrow) ov2_pyr();
+    OV2_REQUIRE(v != nullptr, OV2_ENOMEM, "out of host memory");
+    v->d = p->d;
+    v->d.base = p->d.base + (long long)item * p->d.item_stride;
+    v->d.batch = 1;
+    v->w = p->w; v->h = p->h; v->max_level = p->max_level; v->device = p->device;
+    v->bytes = (size_t)p->d.item_stride;
+    v->parent = p;
+    *out = v;
+    return OV2_OK;
+}
+
 void ov2_pyr_destroy(ov2_pyr *p)
 {
     if (!p) return;
+    if (p->parent) { delete p; return; }          // a view owns nothing
     (void)hipSetDevice(p->device);
     if (p->ready) { (void)hipEventSynchronize(p->ready); (void)hipEventDestroy(p->ready); }   // a consumer may still be reading
     if (p->d.base) (void)hipFree(p->d.base);

@@ -12,7 +12,7 @@
 #include <new>
 #include <vector>
 
-int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d);
+int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d, int items = 1);
 
 struct ov2_tracker {
     ov2_ctx *ctx = nullptr;

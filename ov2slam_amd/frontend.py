@@ -352,6 +352,114 @@ class VisualFrontEndTracker:
             pass
 
 
+class LockstepTracker:
+    """`batch` camera streams in lock-step (ov2_btracker_*, csrc/trackb.hip): the offline batch-of-sequences form of
+    VisualFrontEndTracker.  Every call advances items [0, n_active) by one frame with ONE enqueue over all of them; results per
+    item are bit-identical to a VisualFrontEndTracker fed the same frames and keypoints.  Point arrays are (batch, n_max, 2) with
+    n[b] valid rows per item."""
+
+    def __init__(self, ctx, batch, w, h, nklt_win_size=9, nklt_pyr_lvl=3, nmax_iter=30, fmax_px_precision=0.01, nklt_err=30.0,
+                 fmax_fbklt_dist=0.5, use_clahe=True, fclahe_val=3.0, nbmaxkps=512, prior_pyr_lvl=1):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.batch, self.w, self.h, self.win, self.n_max = int(batch), int(w), int(h), int(nklt_win_size), int(nbmaxkps)
+        cfg = L.TrackerConfig(self.w, self.h, self.win, int(nklt_pyr_lvl), int(prior_pyr_lvl), int(nmax_iter),
+                              float(np.float32(fmax_px_precision)), float(nklt_err), float(fmax_fbklt_dist),
+                              int(bool(use_clahe)), float(fclahe_val), self.w // 50, self.h // 50, self.n_max, 0)
+        ht = C.c_void_p()
+        L.check(self.lib.ov2_btracker_create(ctx.h, C.byref(cfg), self.batch, C.byref(ht)))
+        self.h_trk = ht
+        ctx._children.add(self)
+        stride = C.c_int()
+        self.image_buffers = []                       # [which][item] -> numpy view of the pinned slot
+        for which in range(2):
+            row = []
+            for b in range(self.batch):
+                ptr = self.lib.ov2_btracker_image_buffer(ht, which, b, C.byref(stride))
+                row.append(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(self.h, stride.value)))
+            self.image_buffers.append(row)
+        self.stride = stride.value
+
+    def setCalibration(self, calib):
+        L.check(self.lib.ov2_btracker_set_calibration(self.h_trk, calib.model, _ptr(calib.K), _ptr(calib.D) if calib.D is not None else None,
+                                                      0 if calib.D is None else len(calib.D), _ptr(calib.iK)))
+
+    def upload(self, which, n_active):
+        """start the H2D of staging set `which` (already filled through image_buffers[which]) on the copy stream"""
+        L.check(self.lib.ov2_btracker_upload(self.h_trk, int(which), int(n_active)))
+
+    def trackFrame(self, imgs, kps, pri, hasprior, n, klt_use_prior=True):
+        """imgs: list of n_active (h, >=w) uint8 arrays of one row pitch (or pinned slots of one staging set); kps / pri:
+        (batch, n_max, 2) float32; hasprior: (batch, n_max) uint8 or None; n: per-item counts (len n_active).
+        -> (out (batch, n_max, 2), status bits (batch, n_max), p3p_req (n_active,) bool)"""
+        na = len(imgs)
+        imgs = [im if im.dtype == np.uint8 and im.strides[1] == 1 else np.ascontiguousarray(im, np.uint8) for im in imgs]
+        stride = imgs[0].strides[0]
+        for im in imgs:
+            if im.ndim != 2 or im.shape[0] != self.h or im.shape[1] < self.w or im.strides[0] != stride:
+                raise ValueError("frames must be %d rows of >= %d bytes with one common row pitch" % (self.h, self.w))
+        ptrs = (C.c_void_p * na)(*[im.ctypes.data for im in imgs])
+        kps = np.ascontiguousarray(kps, np.float32).reshape(self.batch, self.n_max, 2)
+        pri = np.ascontiguousarray(pri, np.float32).reshape(self.batch, self.n_max, 2)
+        hp = None if hasprior is None else np.ascontiguousarray(hasprior, np.uint8).reshape(self.batch, self.n_max)
+        nn = np.ascontiguousarray(n, np.int32)
+        if len(nn) != na:
+            raise ValueError("one keypoint count per active item")
+        out = np.zeros((self.batch, self.n_max, 2), np.float32); st = np.zeros((self.batch, self.n_max), np.uint8)
+        p3p = np.zeros(na, np.int32)
+        L.check(self.lib.ov2_btracker_track_frame(self.h_trk, na, ptrs, stride, _ptr(kps), _ptr(pri), _ptr(hp), _ptr(nn),
+                                                  int(bool(klt_use_prior)), _ptr(out), _ptr(st), _ptr(p3p)))
+        return out, st, p3p.astype(bool)
+
+    def lastKeypoints(self, item, n, want_bv=True):
+        unpx = np.empty((n, 2), np.float32)
+        bv = np.empty((n, 3), np.float64) if want_bv else None
+        L.check(self.lib.ov2_btracker_last_keypoints(self.h_trk, int(item), int(n), _ptr(unpx), _ptr(bv) if want_bv else None))
+        return unpx, bv
+
+    def detectSingleScale(self, n_active, ncellsize, cur, ncur, roi, quality, subpix=True):
+        """MapManager::extractKeypoints of items [0, n_active) on their current frames.  cur: (batch, n_max, 2); ncur: counts;
+        quality: float64 array, one dmaxquality_ per item, updated in place.  -> list of (k, 2) arrays"""
+        cap = max(1, 2 * (self.w // ncellsize) * (self.h // ncellsize))
+        cur = np.ascontiguousarray(cur, np.float32).reshape(self.batch, self.n_max, 2)
+        nc = np.ascontiguousarray(ncur, np.int32)
+        q = np.ascontiguousarray(quality, np.float64)
+        assert q is quality or np.shares_memory(q, quality), "quality must be a contiguous float64 array (updated in place)"
+        out = np.zeros((n_active, cap, 2), np.float32); on = np.zeros(n_active, np.int32)
+        r = (C.c_int * 4)(*[int(v) for v in roi])
+        L.check(self.lib.ov2_btracker_detect_singlescale(self.h_trk, int(n_active), int(ncellsize), _ptr(cur), _ptr(nc), r, _ptr(q),
+                                                         1 if subpix else 0, _ptr(out), cap, _ptr(on)))
+        return [out[b, :on[b]].copy() for b in range(n_active)]
+
+    def detectGridFAST(self, n_active, ncellsize, cur, ncur, fast_th, mask_mode=L.OV2_MASK_AS_EXECUTED, subpix=True):
+        cap = max(1, (self.w // ncellsize) * (self.h // ncellsize))
+        cur = np.ascontiguousarray(cur, np.float32).reshape(self.batch, self.n_max, 2)
+        nc = np.ascontiguousarray(ncur, np.int32)
+        t = np.ascontiguousarray(fast_th, np.int32)
+        assert t is fast_th or np.shares_memory(t, fast_th), "fast_th must be a contiguous int32 array (updated in place)"
+        out = np.zeros((n_active, cap, 2), np.float32); on = np.zeros(n_active, np.int32)
+        L.check(self.lib.ov2_btracker_detect_grid_fast(self.h_trk, int(n_active), int(ncellsize), _ptr(cur), _ptr(nc), _ptr(t), int(mask_mode),
+                                                       1 if subpix else 0, _ptr(out), cap, _ptr(on)))
+        return [out[b, :on[b]].copy() for b in range(n_active)]
+
+    def cur_item(self, item):
+        return _PyrView(self.ctx, C.c_void_p(self.lib.ov2_btracker_cur_item(self.h_trk, int(item))), self.w, self.h, self.win)
+
+    def prev_item(self, item):
+        return _PyrView(self.ctx, C.c_void_p(self.lib.ov2_btracker_prev_item(self.h_trk, int(item))), self.w, self.h, self.win)
+
+    def close(self):
+        if getattr(self, "h_trk", None):
+            self.image_buffers = None
+            self.lib.ov2_btracker_destroy(self.h_trk)
+            self.h_trk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FeatureExtractor:
     """Mirror of /root/reference/include/feature_extractor.hpp:30-54: holds the
     adaptive thresholds nfast_th_ and dmaxquality_ that the two grid detectors update."""

@@ -96,6 +96,10 @@ class Optimizer {
 public:
     Optimizer(double robust_mono_th, bool apply_l2_after_robust) : robust_mono_th_(robust_mono_th), apply_l2_after_robust_(apply_l2_after_robust) {}
     void signalStopLocalBA() { bstop_localba_ = 1; }        // optimizer.hpp:48 (called by the estimator thread while localBA runs)
+    // The reference clears bstop_localba_ at the END of localBA (src/optimizer.cpp:896), after the map write-back: a signal raised
+    // during the write-back (Optimizer::signalStopLocalBA fires whenever blocalba_is_on_) is dropped there and must not reach the
+    // next localBA.  The caller of solveLocalBA clears this copy at the same place (integration/ov2slam_hip.patch does).
+    void clearStopLocalBA() { bstop_localba_ = 0; }
     bool stopLocalBA() const { return bstop_localba_ != 0; } // optimizer.hpp:49
     // Ceres' max_solver_time_in_seconds of the first pass: the reference sets 0.2 s, doubled unless force_realtime
     // (src/optimizer.cpp:463-467), and halves it for the L2 pass (:612).  0 (default) = no limit.
@@ -105,7 +109,7 @@ public:
     // robust and the L2 pass, outlier tests and block removal run on the device (ov2_local_ba).  want_chi2: also download the
     // per-block chi2err_ / isdepthpositive_ values (the reference's write-back only needs bad_obs).
     // The stop flag is handed over LIVE (ov2_local_ba_options::stop_flag): the library reads it after pass 1, where the
-    // reference evaluates !stopLocalBA() (:603-604), and it is cleared when the call is over (:896).
+    // reference evaluates !stopLocalBA() (:603-604).  It is NOT cleared here: see clearStopLocalBA().
     LocalBAResult solveLocalBA(Context &ctx, FlatProblem &fp, bool buse_robust_cost, bool want_chi2 = false)
     {
         LocalBAResult R;
@@ -122,7 +126,6 @@ public:
         if (want_chi2) { res.chi2_last_eval = R.chi2.data(); res.depthpos_last_eval = R.depthpos.data(); }
         ov2_ba_problem p = fp.view(nullptr);
         R.error_code = ov2_local_ba(ctx.get(), &p, &opt, &res);
-        bstop_localba_ = 0;                                                                                                      // :896
         if (R.error_code != OV2_OK) { R.error = ov2_last_error(); return R; }       // BA skipped: caller logs R.error
         R.ok = true; R.l2_done = res.l2_done != 0;
         if (res.pass2_error != OV2_OK) { R.error_code = res.pass2_error; R.error = ov2_last_error(); }     // pass 1's result is valid and kept

@@ -243,14 +243,15 @@ def read_ba_problem(f):
     return pb
 
 
-def build_native_driver(out_dir):
-    """g++ tools/stream_driver.cpp against the in-tree library; returns the executable's path (raises on failure)."""
+def build_native_driver(out_dir, name="stream_driver"):
+    """g++ tools/<name>.cpp (stream_driver: one camera stream per SLAM thread; lockstep_driver: a rank's sequences in lock-step)
+    against the in-tree library; returns the executable's path (raises on failure)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(out_dir, "stream_driver")
+    exe = os.path.join(out_dir, name)
     libdir = os.path.join(root, "ov2slam_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(root, "tools", "stream_driver.cpp"), "-I", root,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(root, "tools", name + ".cpp"), "-I", root,
                            "-L", libdir, "-lov2slam_hip", "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -297,3 +298,27 @@ def run_native(exe, case_path, ba_policy="newest", device=0):
     if int(st.get("device", -1)) != int(device):
         raise RuntimeError("stream_driver ran on device %s, asked for %d" % (st.get("device"), device))
     return st
+
+
+def lockstep_argv(exe, case_paths, ba_policy="newest", device=0, loader_threads=4):
+    """Command line of tools/lockstep_driver.cpp: ALL of the rank's sequences in one process, advanced one frame per step through
+    the lock-step tracker (ov2_btracker_*); the rank's GPU travels as argv[3] like stream_driver's."""
+    return [exe, ",".join(case_paths), ba_policy, str(int(device)), str(int(loader_threads))]
+
+
+def run_lockstep(exe, case_paths, device=0, ba_policy="newest", loader_threads=4, timeout=1800):
+    """-> (per-sequence stats in the order of case_paths, summary dict with frames / seconds / steps of the whole rank)"""
+    import json
+    import subprocess
+    r = subprocess.run(lockstep_argv(exe, case_paths, ba_policy, device, loader_threads), capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError("lockstep_driver failed (%d): %s" % (r.returncode, r.stderr[-500:]))
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    summary = [l for l in lines if l.get("lockstep_summary")]
+    stats = [l for l in lines if not l.get("lockstep_summary")]
+    if len(summary) != 1 or len(stats) != len(case_paths):
+        raise RuntimeError("lockstep_driver returned %d result lines for %d sequences" % (len(stats), len(case_paths)))
+    for st in stats + summary:
+        if int(st.get("device", -1)) != int(device):
+            raise RuntimeError("lockstep_driver ran on device %s, asked for %d" % (st.get("device"), device))
+    return stats, summary[0]

@@ -112,6 +112,18 @@ int main(int argc, char **argv)
             const int flags[4] = {R.ok, R.l2_done, R.iterations[0], R.iterations[1]};
             wr(fo, flags, 4); wr(fo, R.poses.data(), R.poses.size()); wr(fo, R.invdepth.data(), R.invdepth.size());
             wr(fo, R.bad_obs.data(), R.bad_obs.size());
+            // The stop flag's lifetime is the reference's (src/optimizer.cpp:896): a signal raised AFTER the solve (the write-back
+            // window) stays set until the caller clears it where the reference clears its own -- it must not leak into the next
+            // localBA once cleared, and it must still be visible before that.
+            opt.signalStopLocalBA();
+            const int still_set = opt.stopLocalBA() ? 1 : 0;
+            ov2::FlatProblem fp2 = fp;
+            const ov2::LocalBAResult Rs = opt.solveLocalBA(ctx, fp2, true);            // flag still up: no L2 pass
+            opt.clearStopLocalBA();
+            ov2::FlatProblem fp3 = fp;
+            const ov2::LocalBAResult Rc = opt.solveLocalBA(ctx, fp3, true);            // cleared: same as the first call
+            const int stop_flags[4] = {still_set, Rs.ok && !Rs.l2_done, Rc.ok && Rc.l2_done == R.l2_done, Rc.iterations[1] == R.iterations[1]};
+            wr(fo, stop_flags, 4);
         }
         fclose(fi); fclose(fo);
     } catch (const std::exception &e) {

@@ -98,6 +98,11 @@ def test_bench_launcher_dry_gloo():
     assert abs(c5["seconds_slowest_rank"] - max(c5["seconds_per_rank"])) < 1e-12
     assert abs(out["elapsed_max_over_ranks"] - 1.1) < 1e-12                # max over ranks of (1.0, 1.1)
     assert c5["device_per_rank"] == [0, 1]                                  # every rank's config-5 worker on ITS GPU
+    # the lock-step driver: ONE process per rank takes all of the rank's sequences (full EuRoC lengths by default) and its device
+    argv = c5["lockstep_argv_rank0"]
+    assert argv[1].split(",") == ["<case:%s>" % s for s in c5["assignment"][0]] and argv[2] == "newest" and argv[3] == "0"
+    assert c5["frames"] == sum(batch.EUROC_FRAMES.values())
+    assert c5["steps_per_rank"] == [max(batch.EUROC_FRAMES[s] for s in plan) for plan in c5["assignment"]]    # a rank steps as long as its longest sequence
 
 
 def test_native_driver_receives_the_ranks_device():
@@ -107,6 +112,9 @@ def test_native_driver_receives_the_ranks_device():
     assert stream.native_argv("drv", "case.bin", "newest", 5) == ["drv", "case.bin", "newest", "5"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "tools", "stream_driver.cpp")).read()
+    assert "ov2_ctx_create(0" not in src and src.count("ov2_ctx_create(device") == 3
+    assert stream.lockstep_argv("drv", ["a.bin", "b.bin"], "all", 3, 2) == ["drv", "a.bin,b.bin", "all", "3", "2"]
+    src = open(os.path.join(root, "tools", "lockstep_driver.cpp")).read()          # the rank's lock-step host: SLAM, mapper and estimator contexts
     assert "ov2_ctx_create(0" not in src and src.count("ov2_ctx_create(device") == 3
     import inspect
     import bench

@@ -65,6 +65,7 @@ def test_cpp_adapters_run_and_match(gpu_ctx, oracle, tmp_path):
         c_fb, c_fbst = _rd(f, np.float32).reshape(-1, 2), _rd(f, np.uint8)
         c_sr, c_sok = _rd(f, np.float32).reshape(-1, 2), _rd(f, np.uint8)
         c_flags, c_poses, c_lam, c_badobs = _rd(f, np.int32), _rd(f, np.float64), _rd(f, np.float64), _rd(f, np.uint8)
+        c_stop = _rd(f, np.int32)
 
     # ---- FrameTracker vs the ctypes mirror and vs the oracle ----
     roi = (5, 5, w - 10, h - 10)
@@ -106,6 +107,8 @@ def test_cpp_adapters_run_and_match(gpu_ctx, oracle, tmp_path):
     # ---- Optimizer::localBA: same protocol, same library ----
     g = ov2slam_amd.Optimizer(gpu_ctx).localBA(pb)
     assert c_flags[0] == 1 and bool(c_flags[1]) == bool(g["l2_done"])
+    # the adapter's stop flag lives as long as the reference's (cleared where src/optimizer.cpp:896 clears its own, by the caller)
+    assert g["l2_done"] and list(c_stop) == [1, 1, 1, 1], c_stop
     assert c_flags[2] == g["iterations"][0] and (not g["l2_done"] or c_flags[3] == g["iterations"][1])
     assert np.array_equal(c_badobs.astype(bool), np.asarray(g["bad_obs"]).astype(bool))
     assert np.allclose(c_poses.reshape(-1, 7), g["poses"], rtol=0, atol=1e-9) and np.allclose(c_lam, g["invdepth"], rtol=1e-9, atol=1e-12)

@@ -1,0 +1,342 @@
+// lockstep_driver.cpp -- a rank's sequences of BASELINE.json configs[4] advanced IN LOCK-STEP: the offline / batch form of the
+// keyframe cycle tools/stream_driver.cpp runs per camera stream.
+//
+// The reference's benchmark protocol plays whole sequences (benchmark_scripts/euroc_bench.sh:3-27); a rank that owns several does
+// not need their frames one stream at a time.  tools/stream_driver.cpp gives every sequence its own SLAM thread and tracker: each
+// stream is a chain of ~10 small dependent launches per frame, and a rank's streams together saturate the launch rate with the
+// CUs ~5 % busy (profiles/r4_stream_concurrency.txt).  Here ONE SLAM thread steps all sequences of the rank through the lock-step
+// tracker (ov2_btracker_*, csrc/trackb.hip): per step one frame upload, one CLAHE + pyramid enqueue, one fused kltTracking launch
+// and one computeKeypoint launch cover every sequence; at the common keyframes one batched detectSingleScale call; the keyframes
+// then go to the sequences' own mapper threads (right-image CLAHE + pyramid + ov2_stereo_match on an item view of the tracker's
+// pyramid) and estimator threads (ov2_local_ba, newest keyframe only like src/estimator.cpp:195-205, or every keyframe with
+// policy "all") -- one context each, exactly as in stream_driver.  Sequences that end drop out of the batch (they are ordered
+// longest first, so the active ones are always items [0, n_active)).
+// Image "decoding" (here: a copy of the synthetic view into the tracker's pinned slot) runs on loader threads one step ahead,
+// the frames' H2D on the tracker's copy stream beside the previous step's kernels.
+// Per-sequence inputs (frames, keypoints, priors, random streams) are those of stream_driver, so the per-sequence results must be
+// bit-identical: both programs print FNV-1a digests of everything the library returned (tests/test_gpu_stream.py compares them).
+//
+//   lockstep_driver <case>[,<case>...] [newest|all] [device]     -> one JSON line per sequence (input order) + one summary line
+// Build: g++ -O2 -std=c++17 -pthread tools/lockstep_driver.cpp -I. -Lov2slam_amd -lov2slam_hip -Wl,-rpath,<dir>
+#define OV2_DRIVER_NAME "lockstep_driver"
+#include "tools/driver_common.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+struct Seq {
+    int id = 0;                                    // position on the command line
+    Case C;
+    // SLAM-side state of the sequence
+    std::mt19937 rng{12345};
+    std::normal_distribution<float> gauss{0.f, 1.f};
+    std::vector<float> kps; std::vector<int> age;
+    double quality = 0.001;
+    long frames = 0, tracked = 0, attempted = 0, err_n = 0, keyframes = 0;
+    double err_sq = 0;
+    Fnv tdig, ddig, sdig;
+    // mapper / estimator threads of the sequence (one context each)
+    ov2_ctx *ctxB = nullptr, *ctxC = nullptr; ov2_pyr *pyrR = nullptr;
+    Queue<std::unique_ptr<KfJob>> map_q; Queue<int> ba_q;
+    std::mutex done_m; std::condition_variable done_cv; int mapper_done_kf = -1;
+    long stereo_kfs = 0, stereo_ok = 0, stereo_kps = 0, ba_solves = 0, ba_skipped = 0, ba_iterations = 0;
+    double mapper_busy = 0, ba_busy = 0, ba_device_ms = 0;
+    std::thread mapper, estimator;
+    double t_last_frame = 0, t_drained = 0;
+};
+
+// loader threads: "decode" frame f of every active sequence into the tracker's pinned slots of set f & 1
+struct Loader {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    int want = -1, done_count = 0, n_threads = 0; bool quit = false;
+    std::vector<int> seen;
+};
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads]\n"); return 2; }
+    if (ov2_version() != OV2_ABI_VERSION) { fprintf(stderr, "lockstep_driver: header / library ABI mismatch\n"); return 2; }
+    const bool ba_all = argc > 2 && !strcmp(argv[2], "all");
+    const char *dev_s = argc > 3 ? argv[3] : getenv("OV2_DEVICE");      // one process per GPU: the rank's device from the launcher
+    const int device = dev_s ? atoi(dev_s) : 0;
+    const int n_load = argc > 4 ? std::max(1, atoi(argv[4])) : 4;
+    std::vector<std::string> paths;
+    for (std::string rest = argv[1]; !rest.empty();) {
+        const size_t c = rest.find(',');
+        paths.push_back(rest.substr(0, c));
+        rest = c == std::string::npos ? "" : rest.substr(c + 1);
+    }
+    const int N = (int)paths.size();
+    std::vector<std::unique_ptr<Seq>> S;
+    for (int i = 0; i < N; i++) { S.emplace_back(new Seq()); S.back()->id = i; S.back()->C = read_case(paths[(size_t)i].c_str()); }
+    // longest first: the sequences still running are always items [0, n_active) of the batch
+    std::stable_sort(S.begin(), S.end(), [](const std::unique_ptr<Seq> &a, const std::unique_ptr<Seq> &b) { return a->C.n_frames > b->C.n_frames; });
+    const Case &C0 = S[0]->C;
+    const int w = C0.w, h = C0.h, kf_every = C0.kf_every, cell = C0.cell, nbmaxkps = C0.nbmaxkps;
+    for (auto &s : S)
+        if (s->C.w != w || s->C.h != h || s->C.kf_every != kf_every || s->C.cell != cell || s->C.nbmaxkps != nbmaxkps) {
+            fprintf(stderr, "lockstep_driver: the sequences of a batch must share image size, keyframe cadence and detector geometry\n"); return 2;
+        }
+    const double K[4] = {458.654, 457.296, 367.215, 248.375};
+    const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[1], -K[3] / K[1], 0, 0, 1};
+    ov2_ctx *ctxA;
+    CK(ov2_ctx_create(device, &ctxA));
+    ov2_tracker_config tc{};
+    tc.w = w; tc.h = h; tc.win = 9; tc.nklt_pyr_lvl = 3; tc.prior_pyr_lvl = 1; tc.max_iter = 30; tc.eps = 0.01f; tc.err_th = 30.f; tc.fb_dist = 0.5f;
+    tc.use_clahe = 1; tc.clahe_clip = 3.0; tc.tiles_x = w / 50; tc.tiles_y = h / 50; tc.n_max = 2 * nbmaxkps; tc.use_graph = 0;
+    const int NM = tc.n_max;
+    ov2_btracker *trk;
+    CK(ov2_btracker_create(ctxA, &tc, N, &trk));
+    CK(ov2_btracker_set_calibration(trk, OV2_CAM_PINHOLE, K, nullptr, 0, iK));
+    int pitch = 0;
+    (void)ov2_btracker_image_buffer(trk, 0, 0, &pitch);
+
+    // ---- per-sequence mapper / estimator threads (same bodies as stream_driver) ---------------------------------------
+    for (auto &sp : S) {
+        Seq *s = sp.get();
+        CK(ov2_ctx_create(device, &s->ctxB)); CK(ov2_ctx_create(device, &s->ctxC));
+        CK(ov2_pyr_create(s->ctxB, w, h, 9, 3, 1, &s->pyrR));
+        s->mapper = std::thread([s, w, h, &K] {
+            std::unique_ptr<KfJob> j;
+            while (s->map_q.pop(j)) {
+                const double t0 = now();
+                const int n = (int)j->hp.size();
+                CK(ov2_pyr_build_clahe_h(s->ctxB, s->pyrR, j->right_img, w, 3.0, w / 50, h / 50));                      // asynchronous
+                std::vector<float> right(2 * (size_t)n); std::vector<uint8_t> ok(n);
+                CK(ov2_stereo_match(s->ctxB, j->left, s->pyrR, 9, 3, 30, 0.01f, 30.f, 0.5f, 1, nullptr, OV2_CAM_PINHOLE, K, nullptr, 0, j->kps.data(),
+                                    j->unpx.data(), j->p3.data(), j->hp.data(), n, right.data(), ok.data()));
+                s->mapper_busy += now() - t0;
+                s->sdig.val(j->f); s->sdig.val(n); s->sdig.add(right.data(), 8 * (size_t)n); s->sdig.add(ok.data(), (size_t)n);
+                { std::lock_guard<std::mutex> l(s->done_m); s->mapper_done_kf = j->f; }
+                s->done_cv.notify_all();
+                s->stereo_kfs++; s->stereo_kps += n;
+                for (int i = 0; i < n; i++) s->stereo_ok += ok[i];
+                if (!s->C.ba.empty()) s->ba_q.push(j->f);
+            }
+            s->ba_q.close();
+        });
+        s->estimator = std::thread([s, ba_all] {
+            int f, nsolve = 0;
+            while (s->ba_q.pop(f)) {
+                if (!ba_all) { int g; while (s->ba_q.try_pop(g)) { s->ba_skipped++; f = g; } }      // only the last received keyframe (estimator.cpp:195-205)
+                const BAProb &p = s->C.ba[(size_t)nsolve++ % s->C.ba.size()];
+                ov2_ba_problem P; fill_ba_problem(p, P);
+                ov2_local_ba_options O; ov2_local_ba_default_options(&O);
+                std::vector<double> poses(7 * (size_t)p.n_kf), lam(p.n_lm);
+                std::vector<uint8_t> bad(p.n_res);
+                ov2_local_ba_result R{};
+                R.poses_out = poses.data(); R.invdepth_out = lam.data(); R.bad_obs = bad.data();
+                const double t0 = now();
+                CK(ov2_local_ba(s->ctxC, &P, &O, &R));
+                s->ba_busy += now() - t0;
+                s->ba_solves++; s->ba_iterations += R.iterations[0] + R.iterations[1]; s->ba_device_ms += R.solve_ms[0] + R.solve_ms[1];
+            }
+            s->t_drained = now();
+        });
+    }
+
+    auto n_active_at = [&](int f) { int n = 0; while (n < N && S[(size_t)n]->C.n_frames > f) n++; return n; };
+    const int F = S[0]->C.n_frames;
+
+    // ---- loader threads -------------------------------------------------------------------------------------------------
+    Loader LD; LD.n_threads = n_load; LD.seen.assign((size_t)n_load, -1);
+    for (int tid = 0; tid < n_load; tid++)
+        LD.th.emplace_back([&, tid] {
+            for (;;) {
+                int f;
+                { std::unique_lock<std::mutex> l(LD.m); LD.cv_go.wait(l, [&] { return LD.quit || LD.want > LD.seen[(size_t)tid]; }); if (LD.quit) return; f = LD.want; }
+                const int na = n_active_at(f);
+                for (int b = tid; b < na; b += n_load) {
+                    const Case &C = S[(size_t)b]->C;
+                    int st = 0;
+                    uint8_t *dst = ov2_btracker_image_buffer(trk, f & 1, b, &st);
+                    const uint8_t *src = C.left[(size_t)view_index(C, f)].data();
+                    if (st == w) memcpy(dst, src, (size_t)w * h);
+                    else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * st, src + (size_t)y * w, (size_t)w);
+                }
+                { std::lock_guard<std::mutex> l(LD.m); LD.seen[(size_t)tid] = f; LD.done_count++; }
+                LD.cv_done.notify_all();
+            }
+        });
+    auto load_kick = [&](int f) { { std::lock_guard<std::mutex> l(LD.m); LD.want = f; LD.done_count = 0; } LD.cv_go.notify_all(); };
+    auto load_wait = [&] { std::unique_lock<std::mutex> l(LD.m); LD.cv_done.wait(l, [&] { return LD.done_count == LD.n_threads; }); };
+
+    // ---- the SLAM thread of the rank ------------------------------------------------------------------------------------------
+    const size_t BN = (size_t)N * NM;
+    std::vector<float> kps(2 * BN), pri(2 * BN), out(2 * BN);
+    std::vector<uint8_t> hp(BN), st(BN);
+    std::vector<int> nper((size_t)N), p3p((size_t)N), ncur((size_t)N), out_n((size_t)N);
+    std::vector<double> gt(2 * BN), quality((size_t)N, 0.001);
+    std::vector<const uint8_t *> imgs((size_t)N);
+    std::vector<float> unpx, nk; std::vector<double> bv; std::vector<int> na_;
+    const int cap = 2 * (w / cell) * (h / cell);
+    std::vector<float> det((size_t)N * 2 * cap);
+    const int roi[4] = {5, 5, w - 10, h - 10};
+    double lib_s = 0, wait_loader = 0, wait_mapper = 0;
+
+    auto keyframe = [&](int f, int na) {
+        for (int b = 0; b < na; b++) {
+            Seq &s = *S[(size_t)b];
+            ncur[(size_t)b] = (int)s.age.size();
+            if (!s.kps.empty()) memcpy(&kps[2 * (size_t)b * NM], s.kps.data(), 4 * s.kps.size());
+        }
+        double tl = now();
+        CK(ov2_btracker_detect_singlescale(trk, na, cell, kps.data(), ncur.data(), roi, quality.data(), 1, det.data(), cap, out_n.data()));
+        lib_s += now() - tl;
+        size_t total = 0;
+        for (int b = 0; b < na; b++) {
+            Seq &s = *S[(size_t)b];
+            int nn = out_n[(size_t)b];
+            const float *nw = &det[(size_t)b * 2 * cap];
+            s.keyframes++;
+            s.ddig.val(f); s.ddig.val(nn); s.ddig.add(nw, 8 * (size_t)nn); s.ddig.val(quality[(size_t)b]);
+            nn = std::max(0, std::min(nn, nbmaxkps - ncur[(size_t)b]));
+            s.kps.insert(s.kps.end(), nw, nw + 2 * (size_t)nn);
+            s.age.insert(s.age.end(), nn, 0);
+            total += s.age.size();
+        }
+        // createKeyframe: undistorted pixels of every keypoint of every sequence, one call
+        std::vector<float> all(2 * total), un(2 * total);
+        size_t o = 0;
+        for (int b = 0; b < na; b++) { const Seq &s = *S[(size_t)b]; if (!s.kps.empty()) memcpy(&all[2 * o], s.kps.data(), 4 * s.kps.size()); o += s.age.size(); }
+        tl = now();
+        if (total) CK(ov2_compute_keypoints(ctxA, OV2_CAM_PINHOLE, K, nullptr, 0, iK, all.data(), (int)total, un.data(), nullptr));
+        lib_s += now() - tl;
+        o = 0;
+        for (int b = 0; b < na; b++) {
+            Seq &s = *S[(size_t)b];
+            const int n = (int)s.age.size();
+            auto j = std::make_unique<KfJob>();
+            j->f = f; j->left = ov2_btracker_cur_item(trk, b); j->right_img = s.C.right[(size_t)view_index(s.C, f)].data();
+            j->kps = s.kps; j->unpx.assign(un.begin() + 2 * o, un.begin() + 2 * (o + n)); j->p3.resize(2 * (size_t)n); j->hp.resize(n);
+            for (int i = 0; i < n; i++) {
+                j->hp[i] = s.age[i] > 0;
+                j->p3[2 * i] = s.kps[2 * i] - (float)s.C.disparity + s.gauss(s.rng); j->p3[2 * i + 1] = s.kps[2 * i + 1] + s.gauss(s.rng);
+            }
+            o += (size_t)n;
+            s.map_q.push(std::move(j));
+        }
+    };
+
+    load_kick(0); load_wait();
+    const double t_begin = wall();
+    const double t0 = now();
+    {
+        const int na = N;
+        for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, 0, b, nullptr);
+        if (F > 1) { load_kick(1); load_wait(); CK(ov2_btracker_upload(trk, 1, n_active_at(1))); }    // frame 1 travels while frame 0 is processed
+        std::fill(nper.begin(), nper.end(), 0);
+        double tl = now();
+        CK(ov2_btracker_track_frame(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1, out.data(), st.data(), p3p.data()));
+        lib_s += now() - tl;
+        if (F > 2) load_kick(2);                                                        // set 0 is free again
+        for (int b = 0; b < na; b++) S[(size_t)b]->frames = 1;
+        keyframe(0, na);
+    }
+    long steps = 1;
+    for (int f = 1; f < F; f++) {
+        const int na = n_active_at(f);
+        // priors of this step (the motion model's stand-in): true flow + noise for the keypoints that were tracked before
+        for (int b = 0; b < na; b++) {
+            Seq &s = *S[(size_t)b];
+            const int n = (int)s.age.size();
+            const size_t o = (size_t)b * NM;
+            nper[(size_t)b] = n;
+            const Flow flow(s.C, f - 1, f);
+            for (int i = 0; i < n; i++) {
+                const float x = s.kps[2 * i], y = s.kps[2 * i + 1];
+                double gx, gy; flow(x, y, gx, gy);
+                gt[2 * (o + i)] = gx; gt[2 * (o + i) + 1] = gy;
+                const uint8_t hpi = s.age[i] > 0;
+                hp[o + i] = hpi;
+                kps[2 * (o + i)] = x; kps[2 * (o + i) + 1] = y;
+                pri[2 * (o + i)] = hpi ? (float)(gx + s.C.prior_sigma * s.gauss(s.rng)) : x;
+                pri[2 * (o + i) + 1] = hpi ? (float)(gy + s.C.prior_sigma * s.gauss(s.rng)) : y;
+            }
+        }
+        if (f >= 2 && (f - 2) % kf_every == 0) {   // this step overwrites the pyramids of frame f - 2 (two alternate): the mappers may still read them
+            const double tw = now();
+            for (int b = 0; b < n_active_at(f - 2); b++) {
+                Seq &s = *S[(size_t)b];
+                std::unique_lock<std::mutex> l(s.done_m);
+                s.done_cv.wait(l, [&] { return s.mapper_done_kf >= f - 2; });
+            }
+            wait_mapper += now() - tw;
+        }
+        // Pipeline: frame f was uploaded to set f & 1 during step f - 1; frame f + 1 (loaded by the loader threads since step f - 1
+        // returned) starts its H2D on the copy stream now, beside this step's kernels; once the step returns, set f & 1 is free for
+        // the loaders' frame f + 2.
+        double tl;
+        if (f + 1 < F) {
+            const double tw = now(); load_wait(); wait_loader += now() - tw;
+            tl = now();
+            CK(ov2_btracker_upload(trk, (f + 1) & 1, n_active_at(f + 1)));
+            lib_s += now() - tl;
+        }
+        for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, f & 1, b, nullptr);
+        tl = now();
+        CK(ov2_btracker_track_frame(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1, out.data(), st.data(), p3p.data()));
+        lib_s += now() - tl;
+        if (f + 2 < F) load_kick(f + 2);
+        steps++;
+        for (int b = 0; b < na; b++) {
+            Seq &s = *S[(size_t)b];
+            const int n = nper[(size_t)b];
+            const size_t o = (size_t)b * NM;
+            unpx.resize(2 * (size_t)n); bv.resize(3 * (size_t)n);
+            if (n) CK(ov2_btracker_last_keypoints(trk, b, n, unpx.data(), bv.data()));
+            s.tdig.val(f); s.tdig.val(n); s.tdig.val(p3p[(size_t)b]); s.tdig.add(&out[2 * o], 8 * (size_t)n); s.tdig.add(&st[o], (size_t)n);
+            s.tdig.add(unpx.data(), 8 * (size_t)n); s.tdig.add(bv.data(), 24 * (size_t)n);
+            s.frames++; s.attempted += n;
+            nk.clear(); na_.clear();
+            for (int i = 0; i < n; i++) {
+                if (!(st[o + i] & 1)) continue;
+                s.tracked++;
+                const float x = out[2 * (o + i)], y = out[2 * (o + i) + 1];
+                const double ex = x - gt[2 * (o + i)], ey = y - gt[2 * (o + i) + 1];
+                s.err_sq += ex * ex + ey * ey; s.err_n++;
+                if (x > 8 && x < w - 9 && y > 8 && y < h - 9) { nk.push_back(x); nk.push_back(y); na_.push_back(s.age[i] + 1); }
+            }
+            s.kps.swap(nk); s.age.swap(na_);
+            if (f == s.C.n_frames - 1) s.t_last_frame = now();
+        }
+        if (f % kf_every == 0) keyframe(f, na);
+        for (int b = 0; b < na; b++) if (f == S[(size_t)b]->C.n_frames - 1) S[(size_t)b]->map_q.close();   // the sequence ended: its mapper drains
+    }
+    CK(ov2_ctx_sync(ctxA));
+    const double slam_s = now() - t0;
+    for (auto &s : S) { s->map_q.close(); s->mapper.join(); s->estimator.join(); }
+    const double total_s = now() - t0;
+    const double t_end = wall();
+    { std::lock_guard<std::mutex> l(LD.m); LD.quit = true; }
+    LD.cv_go.notify_all();
+    for (auto &t : LD.th) t.join();
+
+    // ---- results: one line per sequence in input order, then the rank's summary ---------------------------------------------
+    std::vector<std::string> lines((size_t)N);
+    long frames = 0;
+    for (auto &sp : S) {
+        const Seq &s = *sp;
+        frames += s.frames;
+        char line[2048];
+        snprintf(line, sizeof(line), "{\"frames\": %ld, \"seconds\": %.6f, \"tracked\": %ld, \"attempted\": %ld, \"err_sq_sum\": %.6f, \"err_n\": %ld, "
+                 "\"keyframes\": %ld, \"stereo_kfs\": %ld, \"stereo_ok\": %ld, \"stereo_kps\": %ld, \"mapper_busy_s\": %.6f, \"ba_solves\": %ld, "
+                 "\"ba_skipped_kfs\": %ld, \"ba_iterations\": %ld, \"ba_busy_s\": %.6f, \"ba_device_ms\": %.4f, \"ba_policy\": \"%s\", \"device\": %d, "
+                 "\"t_begin\": %.6f, \"t_end\": %.6f, \"mode\": \"lockstep\", \"batch_item\": %d, \"track_digest\": \"%016llx\", \"detect_digest\": \"%016llx\", "
+                 "\"stereo_digest\": \"%016llx\"}",
+                 s.frames, (s.t_drained > 0 ? s.t_drained : now()) - t0, s.tracked, s.attempted, s.err_sq, s.err_n, s.keyframes, s.stereo_kfs, s.stereo_ok,
+                 s.stereo_kps, s.mapper_busy, s.ba_solves, s.ba_skipped, s.ba_iterations, s.ba_busy, s.ba_device_ms, ba_all ? "all" : "newest", device,
+                 t_begin, t_end, (int)(&sp - &S[0]), (unsigned long long)s.tdig.h, (unsigned long long)s.ddig.h, (unsigned long long)s.sdig.h);
+        lines[(size_t)s.id] = line;
+    }
+    for (auto &l : lines) printf("%s\n", l.c_str());
+    printf("{\"lockstep_summary\": true, \"sequences\": %d, \"frames\": %ld, \"steps\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, "
+           "\"slam_library_s\": %.6f, \"slam_wait_for_loader_s\": %.6f, \"slam_wait_for_mapper_s\": %.6f, \"loader_threads\": %d, \"device\": %d, "
+           "\"t_begin\": %.6f, \"t_end\": %.6f}\n",
+           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, device, t_begin, t_end);
+
+    for (auto &s : S) { ov2_pyr_destroy(s->pyrR); ov2_ctx_destroy(s->ctxB); ov2_ctx_destroy(s->ctxC); }
+    ov2_btracker_destroy(trk);
+    ov2_ctx_destroy(ctxA);
+    return 0;
+}

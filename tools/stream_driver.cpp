@@ -13,106 +13,8 @@
 //   stream_driver <case file> [policy: newest|all]         -> one JSON line on stdout
 // Case file (written by bench.py: little-endian, see read_case): image size, views, flow offsets, BA problems.
 // Build: g++ -O2 -std=c++17 -pthread tools/stream_driver.cpp -I. -Lov2slam_amd -lov2slam_hip -Wl,-rpath,<dir>
-#include "include/ov2slam_hip.h"
-
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <memory>
-#include <mutex>
-#include <random>
-#include <string>
-#include <thread>
-#include <vector>
-
-static void die(const char *what, int rc) { fprintf(stderr, "stream_driver: %s failed (%d): %s\n", what, rc, ov2_last_error()); exit(3); }
-#define CK(call) do { const int rc_ = (call); if (rc_ != OV2_OK) die(#call, rc_); } while (0)
-static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static double wall() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }   // epoch seconds: comparable across processes
-
-struct BAProb {
-    int n_kf, n_lm, n_res;
-    std::vector<double> poses, invdepth, lm_auv, res_uv, res_sigma;
-    std::vector<uint8_t> kf_const, res_type;
-    std::vector<int> lm_anchor, res_kf, res_lm;
-    double calib_l[4], calib_r[4], T_rl[7];
-};
-struct Case {
-    int w, h, n_views, n_frames, kf_every, cell, nbmaxkps;
-    double disparity, prior_sigma;
-    std::vector<std::vector<uint8_t>> left, right;
-    std::vector<double> offs;                      // n_views x (ox, oy, theta)
-    std::vector<BAProb> ba;
-};
-
-template <class T> static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "stream_driver: short case file\n"); exit(2); } }
-static Case read_case(const char *path)
-{
-    FILE *f = fopen(path, "rb");
-    if (!f) { perror(path); exit(2); }
-    Case c;
-    int hdr[8]; rd(f, hdr, 8);
-    c.w = hdr[0]; c.h = hdr[1]; c.n_views = hdr[2]; c.n_frames = hdr[3]; c.kf_every = hdr[4]; c.cell = hdr[5]; c.nbmaxkps = hdr[6];
-    const int n_ba = hdr[7];
-    double dd[2]; rd(f, dd, 2); c.disparity = dd[0]; c.prior_sigma = dd[1];
-    c.offs.resize(3 * (size_t)c.n_views); rd(f, c.offs.data(), c.offs.size());
-    for (int side = 0; side < 2; side++)
-        for (int v = 0; v < c.n_views; v++) {
-            std::vector<uint8_t> img((size_t)c.w * c.h); rd(f, img.data(), img.size());
-            (side ? c.right : c.left).push_back(std::move(img));
-        }
-    for (int b = 0; b < n_ba; b++) {
-        BAProb p; int s[3]; rd(f, s, 3); p.n_kf = s[0]; p.n_lm = s[1]; p.n_res = s[2];
-        p.poses.resize(7 * (size_t)p.n_kf); rd(f, p.poses.data(), p.poses.size());
-        p.kf_const.resize(p.n_kf); rd(f, p.kf_const.data(), p.kf_const.size());
-        p.invdepth.resize(p.n_lm); rd(f, p.invdepth.data(), p.invdepth.size());
-        p.lm_anchor.resize(p.n_lm); rd(f, p.lm_anchor.data(), p.lm_anchor.size());
-        p.lm_auv.resize(2 * (size_t)p.n_lm); rd(f, p.lm_auv.data(), p.lm_auv.size());
-        p.res_type.resize(p.n_res); rd(f, p.res_type.data(), p.res_type.size());
-        p.res_kf.resize(p.n_res); rd(f, p.res_kf.data(), p.res_kf.size());
-        p.res_lm.resize(p.n_res); rd(f, p.res_lm.data(), p.res_lm.size());
-        p.res_uv.resize(2 * (size_t)p.n_res); rd(f, p.res_uv.data(), p.res_uv.size());
-        p.res_sigma.resize(p.n_res); rd(f, p.res_sigma.data(), p.res_sigma.size());
-        rd(f, p.calib_l, 4); rd(f, p.calib_r, 4); rd(f, p.T_rl, 7);
-        c.ba.push_back(std::move(p));
-    }
-    fclose(f);
-    return c;
-}
-
-static int view_index(const Case &c, int f) { const int n = c.n_views, k = f % (2 * n - 2); return k < n ? k : 2 * n - 2 - k; }
-// ground-truth position in frame fb of pixel (x, y) of frame fa (batch.SyntheticSequence.flow); the trigonometry is per frame pair
-struct Flow {
-    double cx, cy, ca, sa, ax, ay, cb, sb, bx, by;
-    Flow(const Case &c, int fa, int fb)
-    {
-        cx = (c.w - 1) / 2.0; cy = (c.h - 1) / 2.0;
-        const double *a = &c.offs[3 * (size_t)view_index(c, fa)], *b = &c.offs[3 * (size_t)view_index(c, fb)];
-        ca = cos(a[2]); sa = sin(a[2]); ax = a[0]; ay = a[1];
-        cb = cos(-b[2]); sb = sin(-b[2]); bx = b[0]; by = b[1];
-    }
-    void operator()(float x, float y, double &ox, double &oy) const
-    {
-        double dx = x - cx, dy = y - cy;
-        const double tx = ca * dx - sa * dy + cx + ax, ty = sa * dx + ca * dy + cy + ay;
-        dx = tx - cx - bx; dy = ty - cy - by;
-        ox = cb * dx - sb * dy + cx; oy = sb * dx + cb * dy + cy;
-    }
-};
-
-struct KfJob { int f; const ov2_pyr *left; const uint8_t *right_img; std::vector<float> kps, unpx, p3; std::vector<uint8_t> hp; };
-template <class T> struct Queue {
-    std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false;
-    void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(v)); } cv.notify_one(); }
-    void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
-    bool pop(T &v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); return true; }
-    bool try_pop(T &v) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); return true; }
-};
+#define OV2_DRIVER_NAME "stream_driver"
+#include "tools/driver_common.hpp"
 
 // one sequence: its SLAM thread is the caller, its mapper and estimator threads are started here; the result line goes to `json`.
 // `ready` / `go`: several sequences of one process (the batch mode of config 5: a rank's sequences share its GPU) start streaming
@@ -138,6 +40,7 @@ static int run_sequence(const char *case_path, bool ba_all, int device, std::ato
     long frames = 0, tracked = 0, attempted = 0, err_n = 0, keyframes = 0, stereo_kfs = 0, stereo_ok = 0, stereo_kps = 0;
     long ba_solves = 0, ba_skipped = 0, ba_iterations = 0;
     double err_sq = 0, mapper_busy = 0, ba_busy = 0, ba_device_ms = 0, slam_wait = 0, slam_lib = 0;
+    Fnv tdig, ddig, sdig;       // what the library returned (tracking + computeKeypoint / detection / stereo matching), for tests
 
     Queue<std::unique_ptr<KfJob>> map_q;
     Queue<int> ba_q;
@@ -153,6 +56,7 @@ static int run_sequence(const char *case_path, bool ba_all, int device, std::ato
             CK(ov2_stereo_match(ctxB, j->left, pyrR, 9, 3, 30, 0.01f, 30.f, 0.5f, 1, nullptr, OV2_CAM_PINHOLE, K, nullptr, 0, j->kps.data(),
                                 j->unpx.data(), j->p3.data(), j->hp.data(), n, right.data(), ok.data()));
             mapper_busy += now() - t0;
+            sdig.val(j->f); sdig.val(n); sdig.add(right.data(), 8 * (size_t)n); sdig.add(ok.data(), (size_t)n);
             { std::lock_guard<std::mutex> l(done_m); mapper_done_kf = j->f; }
             done_cv.notify_all();
             stereo_kfs++; stereo_kps += n;
@@ -166,11 +70,7 @@ static int run_sequence(const char *case_path, bool ba_all, int device, std::ato
         while (ba_q.pop(f)) {
             if (!ba_all) { int g; while (ba_q.try_pop(g)) { ba_skipped++; f = g; } }      // only the last received keyframe (estimator.cpp:195-205)
             const BAProb &p = C.ba[nsolve++ % C.ba.size()];
-            ov2_ba_problem P{};
-            P.n_kf = p.n_kf; P.poses = p.poses.data(); P.kf_const = p.kf_const.data(); P.n_lm = p.n_lm; P.invdepth = p.invdepth.data();
-            P.lm_anchor_kf = p.lm_anchor.data(); P.lm_anchor_uv = p.lm_auv.data(); P.n_res = p.n_res; P.res_type = p.res_type.data();
-            P.res_kf = p.res_kf.data(); P.res_lm = p.res_lm.data(); P.res_uv = p.res_uv.data(); P.res_sigma = p.res_sigma.data();
-            memcpy(P.calib_l, p.calib_l, 32); memcpy(P.calib_r, p.calib_r, 32); memcpy(P.T_rl, p.T_rl, 56);
+            ov2_ba_problem P; fill_ba_problem(p, P);
             ov2_local_ba_options O; ov2_local_ba_default_options(&O);
             std::vector<double> poses(7 * (size_t)p.n_kf), lam(p.n_lm);
             std::vector<uint8_t> bad(p.n_res);
@@ -196,6 +96,7 @@ static int run_sequence(const char *case_path, bool ba_all, int device, std::ato
         CK(ov2_detect_singlescale_d(ctxA, ov2_tracker_cur_pyr(trk), 0, C.cell, kps.data(), ncur, roi, &quality, 1, nw.data(), &nn));
         slam_lib += now() - tl;
         keyframes++;
+        ddig.val(f); ddig.val(nn); ddig.add(nw.data(), 8 * (size_t)nn); ddig.val(quality);
         nn = std::max(0, std::min(nn, C.nbmaxkps - ncur));
         kps.insert(kps.end(), nw.begin(), nw.begin() + 2 * (size_t)nn);
         age.insert(age.end(), nn, 0);
@@ -241,6 +142,8 @@ static int run_sequence(const char *case_path, bool ba_all, int device, std::ato
         unpx.resize(2 * (size_t)n); bv.resize(3 * (size_t)n);
         if (n) CK(ov2_tracker_last_keypoints(trk, n, unpx.data(), bv.data()));      // Frame::computeKeypoint of the tracked positions (same enqueue)
         slam_lib += now() - tl;
+        tdig.val(f); tdig.val(n); tdig.val(p3p); tdig.add(out.data(), 8 * (size_t)n); tdig.add(st.data(), (size_t)n);
+        tdig.add(unpx.data(), 8 * (size_t)n); tdig.add(bv.data(), 24 * (size_t)n);
         frames++; attempted += n;
         nk.clear(); na.clear();
         for (int i = 0; i < n; i++) {
@@ -264,9 +167,11 @@ static int run_sequence(const char *case_path, bool ba_all, int device, std::ato
     snprintf(line, sizeof(line), "{\"frames\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, \"slam_library_s\": %.6f, \"tracked\": %ld, \"attempted\": %ld, "
            "\"err_sq_sum\": %.6f, \"err_n\": %ld, \"keyframes\": %ld, \"stereo_kfs\": %ld, \"stereo_ok\": %ld, \"stereo_kps\": %ld, \"mapper_busy_s\": %.6f, "
            "\"ba_solves\": %ld, \"ba_skipped_kfs\": %ld, \"ba_iterations\": %ld, \"ba_busy_s\": %.6f, \"ba_device_ms\": %.4f, \"slam_wait_for_mapper_s\": %.6f, "
-           "\"ba_policy\": \"%s\", \"device\": %d, \"t_begin\": %.6f, \"t_end\": %.6f}",
+           "\"ba_policy\": \"%s\", \"device\": %d, \"t_begin\": %.6f, \"t_end\": %.6f, \"mode\": \"stream\", "
+           "\"track_digest\": \"%016llx\", \"detect_digest\": \"%016llx\", \"stereo_digest\": \"%016llx\"}",
            frames, total_s, slam_s, slam_lib, tracked, attempted, err_sq, err_n, keyframes, stereo_kfs, stereo_ok, stereo_kps, mapper_busy,
-           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest", device, t_begin, t_end);
+           ba_solves, ba_skipped, ba_iterations, ba_busy, ba_device_ms, slam_wait, ba_all ? "all" : "newest", device, t_begin, t_end,
+           (unsigned long long)tdig.h, (unsigned long long)ddig.h, (unsigned long long)sdig.h);
     json = line;
     ov2_tracker_destroy(trk); ov2_pyr_destroy(pyrR);
     ov2_ctx_destroy(ctxA); ov2_ctx_destroy(ctxB); ov2_ctx_destroy(ctxC);
