@@ -51,6 +51,11 @@ int  ov2_version(void);
 const char *ov2_last_error(void);
 /* creates a context with its own non-blocking HIP stream on `device` */
 int  ov2_ctx_create(int device, ov2_ctx **out);
+/* same with a stream priority: > 0 the device's highest, < 0 its lowest, 0 = ov2_ctx_create.  A host that runs several contexts on one
+ * GPU states what is latency-critical: the reference's SLAM thread is real time while its estimator thread works on whatever
+ * keyframe is newest when it gets round to it (src/estimator.cpp:195-205) -- tools/lockstep_driver.cpp gives the tracking context the
+ * high priority and the localBA contexts the low one, so that a dozen concurrent solves do not stretch the per-frame enqueue */
+int  ov2_ctx_create_with_priority(int device, int priority, ov2_ctx **out);
 /* same, but enqueue on an existing hipStream_t (e.g. torch's current stream) */
 int  ov2_ctx_create_on_stream(int device, void *hip_stream, ov2_ctx **out);
 void ov2_ctx_destroy(ov2_ctx *ctx);
@@ -305,8 +310,11 @@ int  ov2_btracker_detect_singlescale(ov2_btracker *t, int n_active, int cell, co
                                      double *quality_inout, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
 int  ov2_btracker_detect_grid_fast(ov2_btracker *t, int n_active, int cell, const float *cur_xy_h, const int *ncur_h, int *fast_th_inout,
                                    int mask_mode, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
-/* the current / previous frame's pyramids: the whole batch, or item `item` as a batch-1 view (owned by the tracker; valid until the
- * step after next overwrites that pyramid) -- what the mapper context passes to ov2_stereo_match as `left`                  */
+/* the current / previous frame's pyramids: the whole batch, or item `item` as a batch-1 view (owned by the tracker; valid until that
+ * pyramid set comes round again, see ov2_btracker_pyramid_sets) -- what the mapper context passes to ov2_stereo_match as `left` */
+/* How many pyramid sets the tracker rotates through (3): the pyramids of frame f are overwritten by step f + sets.  A consumer on
+ * another context (the mapper's stereo matching of keyframe f) must be done before the caller issues that step. */
+int  ov2_btracker_pyramid_sets(const ov2_btracker *t);
 const ov2_pyr *ov2_btracker_cur_pyr(const ov2_btracker *t);
 const ov2_pyr *ov2_btracker_prev_pyr(const ov2_btracker *t);
 const ov2_pyr *ov2_btracker_cur_item(const ov2_btracker *t, int item);

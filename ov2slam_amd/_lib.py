@@ -133,6 +133,7 @@ SIGNATURES = {
     "ov2_version": (_i, []),
     "ov2_last_error": (C.c_char_p, []),
     "ov2_ctx_create": (_i, [_i, _pp]),
+    "ov2_ctx_create_with_priority": (_i, [_i, _i, _pp]),
     "ov2_ctx_create_on_stream": (_i, [_i, _vp, _pp]),
     "ov2_ctx_destroy": (None, [_vp]),
     "ov2_ctx_sync": (_i, [_vp]),
@@ -182,6 +183,7 @@ SIGNATURES = {
     "ov2_btracker_last_keypoints": (_i, [_vp, _i, _i, _vp, _vp]),
     "ov2_btracker_detect_singlescale": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(_i), _vp, _i, _vp, _i, _vp]),
     "ov2_btracker_detect_grid_fast": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "ov2_btracker_pyramid_sets": (_i, [_vp]),
     "ov2_btracker_cur_pyr": (_vp, [_vp]),
     "ov2_btracker_prev_pyr": (_vp, [_vp]),
     "ov2_btracker_cur_item": (_vp, [_vp, _i]),

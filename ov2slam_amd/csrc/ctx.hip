@@ -80,7 +80,7 @@ int ov2_version(void) { return OV2_ABI_VERSION; }
 
 const char *ov2_last_error(void) { return g_err; }
 
-static int ctx_create_common(int device, hipStream_t stream, bool own, ov2_ctx **out)
+static int ctx_create_common(int device, hipStream_t stream, bool own, ov2_ctx **out, int priority = 0)
 {
     OV2_REQUIRE(out != nullptr, OV2_EINVAL, "out == NULL");
     *out = nullptr;
@@ -97,7 +97,14 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, ov2_ctx *
     c->device = device;
     if (const char *e = getenv("OV2_DEBUG")) c->debug = e[0] == '1';     // the one environment read of the library
     if (own) {
-        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        hipError_t se;
+        if (priority == 0) se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        else {
+            // HIP numbers priorities downwards: `greatest` (the numerically smallest value) is served first
+            int least = 0, greatest = 0;
+            se = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority > 0 ? greatest : least);
+        }
         if (se != hipSuccess) { delete c; ov2_set_error("hipStreamCreate: %s", hipGetErrorString(se)); return OV2_EHIP; }
         c->owns_stream = true;
     } else {
@@ -118,6 +125,8 @@ int ov2_ctx::reserve_stat_slots()
 }
 
 int ov2_ctx_create(int device, ov2_ctx **out) { return ctx_create_common(device, nullptr, true, out); }
+
+int ov2_ctx_create_with_priority(int device, int priority, ov2_ctx **out) { return ctx_create_common(device, nullptr, true, out, priority); }
 
 int ov2_ctx_create_on_stream(int device, void *hip_stream, ov2_ctx **out)
 {

@@ -17,13 +17,18 @@
 
 int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d, int items = 1);
 
+#define BT_SETS 3
+
 struct ov2_btracker {
     ov2_ctx *ctx = nullptr;
     ov2_tracker_config cfg;
     int batch = 0;
-    ov2_pyr *pyr[2] = {nullptr, nullptr};
-    std::vector<ov2_pyr *> view[2];    // batch-1 aliases of the items (stereo matching, the p3p retry, single-item detection)
-    int cur = 0;                       // index of cur_pyr_; prev_pyr_ = pyr[cur ^ 1]
+    // THREE pyramid sets in rotation (cur_pyr_, prev_pyr_ and the one before): a keyframe's pyramids stay valid for two more steps, so
+    // the mapper contexts that stereo-match it rarely hold the SLAM thread up (two sets: 12 % of the lock-step wall clock was that wait)
+    ov2_pyr *pyr[BT_SETS] = {nullptr, nullptr, nullptr};
+    std::vector<ov2_pyr *> view[BT_SETS];    // batch-1 aliases of the items (stereo matching, the p3p retry, single-item detection)
+    int cur = 0;                       // index of cur_pyr_; prev_pyr_ = pyr[(cur + BT_SETS - 1) % BT_SETS]
+    int prev() const { return (cur + BT_SETS - 1) % BT_SETS; }
     int frames = 0;
     // frames: two pinned staging sets + their device mirrors; a copy stream for uploads started ahead of the step
     uint8_t *himg[2] = {nullptr, nullptr}, *dimg[2] = {nullptr, nullptr};
@@ -52,9 +57,11 @@ static void btracker_free(ov2_btracker *t)
     if (!t) return;
     if (t->ctx) { (void)hipSetDevice(t->ctx->device); (void)hipStreamSynchronize(t->ctx->stream); }
     if (t->cs) { (void)hipStreamSynchronize(t->cs); (void)hipStreamDestroy(t->cs); }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < BT_SETS; i++) {
         for (ov2_pyr *v : t->view[i]) ov2_pyr_destroy(v);
         ov2_pyr_destroy(t->pyr[i]);
+    }
+    for (int i = 0; i < 2; i++) {
         if (t->up_ev[i]) (void)hipEventDestroy(t->up_ev[i]);
         if (t->used_ev[i]) (void)hipEventDestroy(t->used_ev[i]);
         if (t->himg[i]) (void)hipHostFree(t->himg[i]);
@@ -183,7 +190,7 @@ static int apply_p3p_rule(ov2_btracker *t, int b, const float *kps, const uint8_
             std::vector<uint8_t> s2((size_t)m);
             for (int j = 0; j < m; j++) { k2[2 * j] = p2[2 * j] = kps[2 * idx[j]]; k2[2 * j + 1] = p2[2 * j + 1] = kps[2 * idx[j] + 1]; }
             const ov2_tracker_config &c = t->cfg;
-            const int rc = ov2_fb_klt(t->ctx, t->view[t->cur ^ 1][b], t->view[t->cur][b], c.win, c.nklt_pyr_lvl, c.max_iter, c.eps, c.err_th,
+            const int rc = ov2_fb_klt(t->ctx, t->view[t->prev()][b], t->view[t->cur][b], c.win, c.nklt_pyr_lvl, c.max_iter, c.eps, c.err_th,
                                       c.fb_dist, k2.data(), p2.data(), m, s2.data(), nullptr);
             if (rc != OV2_OK) return rc;
             for (int j = 0; j < m; j++) {
@@ -266,7 +273,7 @@ int ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, 
     t->ctx = ctx; t->cfg = *cfg; t->batch = batch;
     t->last_n.assign((size_t)batch, 0);
     int rc = OV2_OK;
-    for (int i = 0; i < 2 && rc == OV2_OK; i++) {
+    for (int i = 0; i < BT_SETS && rc == OV2_OK; i++) {
         rc = ov2_pyr_create(ctx, cfg->w, cfg->h, cfg->win, cfg->nklt_pyr_lvl, batch, &t->pyr[i]);
         for (int b = 0; b < batch && rc == OV2_OK; b++) {
             ov2_pyr *v = nullptr;
@@ -368,9 +375,9 @@ int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const
     if (rc != OV2_OK) return rc;
     if (t->frames == 0 || n_total == 0) {
         // first frame (trackMono returns right after preprocessImage) or nothing to track anywhere
-        if (t->frames > 0) t->cur ^= 1;                                  // prev_pyr_.swap(cur_pyr_)  (:1169)
+        if (t->frames > 0) t->cur = (t->cur + 1) % BT_SETS;              // prev_pyr_.swap(cur_pyr_)  (:1169)
         rc = enqueue_preprocess(t, t->pyr[t->cur], which, n_active);
-        if (rc != OV2_OK) { if (t->frames > 0) t->cur ^= 1; return rc; }
+        if (rc != OV2_OK) { if (t->frames > 0) t->cur = t->prev(); return rc; }
         t->frames++;
         rc = ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
         if (rc != OV2_OK) return rc;
@@ -378,10 +385,10 @@ int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const
         return ov2_ctx_sync(ctx);
     }
     stage_points(t, n_active, kps_xy_h, prior_xy_h, has_prior_h, n_h, klt_use_prior);
-    t->cur ^= 1;                                                         // prev_pyr_.swap(cur_pyr_)  (:1169)
+    t->cur = (t->cur + 1) % BT_SETS;                                     // prev_pyr_.swap(cur_pyr_)  (:1169)
     rc = enqueue_preprocess(t, t->pyr[t->cur], which, n_active);
-    if (rc == OV2_OK) rc = enqueue_klt(t, t->pyr[t->cur ^ 1], t->pyr[t->cur], n_active);
-    if (rc != OV2_OK) { t->cur ^= 1; return rc; }
+    if (rc == OV2_OK) rc = enqueue_klt(t, t->pyr[t->prev()], t->pyr[t->cur], n_active);
+    if (rc != OV2_OK) { t->cur = t->prev(); return rc; }
     t->frames++;
     rc = ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
     if (rc != OV2_OK) return rc;
@@ -425,8 +432,9 @@ int ov2_btracker_detect_grid_fast(ov2_btracker *t, int n_active, int cell, const
 }
 
 const ov2_pyr *ov2_btracker_cur_pyr(const ov2_btracker *t) { return t ? t->pyr[t->cur] : nullptr; }
-const ov2_pyr *ov2_btracker_prev_pyr(const ov2_btracker *t) { return t ? t->pyr[t->cur ^ 1] : nullptr; }
+const ov2_pyr *ov2_btracker_prev_pyr(const ov2_btracker *t) { return t ? t->pyr[t->prev()] : nullptr; }
+int ov2_btracker_pyramid_sets(const ov2_btracker *t) { return t ? BT_SETS : 0; }
 const ov2_pyr *ov2_btracker_cur_item(const ov2_btracker *t, int item) { return t && item >= 0 && item < t->batch ? t->view[t->cur][(size_t)item] : nullptr; }
-const ov2_pyr *ov2_btracker_prev_item(const ov2_btracker *t, int item) { return t && item >= 0 && item < t->batch ? t->view[t->cur ^ 1][(size_t)item] : nullptr; }
+const ov2_pyr *ov2_btracker_prev_item(const ov2_btracker *t, int item) { return t && item >= 0 && item < t->batch ? t->view[t->prev()][(size_t)item] : nullptr; }
 
 } // extern "C"

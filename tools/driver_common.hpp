@@ -109,10 +109,18 @@ template <class T> struct Queue {
 };
 
 
-// FNV-1a over the bytes the library returned: equal digests <=> the two drivers saw bit-identical results
+// FNV-1a style digest over the bytes the library returned, eight bytes per round (a byte-serial FNV cost 0.14 ms per lock-step frame
+// step -- as much as the GPU work it was checking): equal digests <=> the two drivers saw bit-identical results
 struct Fnv {
     uint64_t h = 1469598103934665603ull;
-    void add(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } }
+    void add(const void *p, size_t n)
+    {
+        const uint8_t *b = (const uint8_t *)p;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h ^= w; h *= 1099511628211ull; }
+        if (i < n) { uint64_t w = 0; memcpy(&w, b + i, n - i); h ^= w; h *= 1099511628211ull; }
+        h ^= (uint64_t)n; h *= 1099511628211ull;
+    }
     template <class T> void val(T v) { add(&v, sizeof(v)); }
 };
 

@@ -16,7 +16,7 @@
 // Per-sequence inputs (frames, keypoints, priors, random streams) are those of stream_driver, so the per-sequence results must be
 // bit-identical: both programs print FNV-1a digests of everything the library returned (tests/test_gpu_stream.py compares them).
 //
-//   lockstep_driver <case>[,<case>...] [newest|all] [device]     -> one JSON line per sequence (input order) + one summary line
+//   lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads] [stream priorities 0|1]     -> one JSON line per sequence (input order) + one summary line
 // Build: g++ -O2 -std=c++17 -pthread tools/lockstep_driver.cpp -I. -Lov2slam_amd -lov2slam_hip -Wl,-rpath,<dir>
 #define OV2_DRIVER_NAME "lockstep_driver"
 #include "tools/driver_common.hpp"
@@ -60,6 +60,9 @@ int main(int argc, char **argv)
     const char *dev_s = argc > 3 ? argv[3] : getenv("OV2_DEVICE");      // one process per GPU: the rank's device from the launcher
     const int device = dev_s ? atoi(dev_s) : 0;
     const int n_load = argc > 4 ? std::max(1, atoi(argv[4])) : 4;
+    // stream priorities (argv[5], default on): tracking context high, localBA contexts low -- the SLAM thread is the real-time one
+    // (the reference's estimator takes whatever keyframe is newest when it is free, src/estimator.cpp:195-205)
+    const bool use_prio = argc > 5 ? atoi(argv[5]) != 0 : true;
     std::vector<std::string> paths;
     for (std::string rest = argv[1]; !rest.empty();) {
         const size_t c = rest.find(',');
@@ -80,7 +83,7 @@ int main(int argc, char **argv)
     const double K[4] = {458.654, 457.296, 367.215, 248.375};
     const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[1], -K[3] / K[1], 0, 0, 1};
     ov2_ctx *ctxA;
-    CK(ov2_ctx_create(device, &ctxA));
+    CK(ov2_ctx_create_with_priority(device, use_prio ? 1 : 0, &ctxA));
     ov2_tracker_config tc{};
     tc.w = w; tc.h = h; tc.win = 9; tc.nklt_pyr_lvl = 3; tc.prior_pyr_lvl = 1; tc.max_iter = 30; tc.eps = 0.01f; tc.err_th = 30.f; tc.fb_dist = 0.5f;
     tc.use_clahe = 1; tc.clahe_clip = 3.0; tc.tiles_x = w / 50; tc.tiles_y = h / 50; tc.n_max = 2 * nbmaxkps; tc.use_graph = 0;
@@ -90,11 +93,12 @@ int main(int argc, char **argv)
     CK(ov2_btracker_set_calibration(trk, OV2_CAM_PINHOLE, K, nullptr, 0, iK));
     int pitch = 0;
     (void)ov2_btracker_image_buffer(trk, 0, 0, &pitch);
+    const int sets = ov2_btracker_pyramid_sets(trk);            // step f overwrites the pyramids of frame f - sets
 
     // ---- per-sequence mapper / estimator threads (same bodies as stream_driver) ---------------------------------------
     for (auto &sp : S) {
         Seq *s = sp.get();
-        CK(ov2_ctx_create(device, &s->ctxB)); CK(ov2_ctx_create(device, &s->ctxC));
+        CK(ov2_ctx_create_with_priority(device, 0, &s->ctxB)); CK(ov2_ctx_create_with_priority(device, use_prio ? -1 : 0, &s->ctxC));
         CK(ov2_pyr_create(s->ctxB, w, h, 9, 3, 1, &s->pyrR));
         s->mapper = std::thread([s, w, h, &K] {
             std::unique_ptr<KfJob> j;
@@ -254,12 +258,12 @@ int main(int argc, char **argv)
                 pri[2 * (o + i) + 1] = hpi ? (float)(gy + s.C.prior_sigma * s.gauss(s.rng)) : y;
             }
         }
-        if (f >= 2 && (f - 2) % kf_every == 0) {   // this step overwrites the pyramids of frame f - 2 (two alternate): the mappers may still read them
+        if (f >= sets && (f - sets) % kf_every == 0) {   // this step overwrites the pyramids of frame f - sets: the mappers may still read them
             const double tw = now();
-            for (int b = 0; b < n_active_at(f - 2); b++) {
+            for (int b = 0; b < n_active_at(f - sets); b++) {
                 Seq &s = *S[(size_t)b];
                 std::unique_lock<std::mutex> l(s.done_m);
-                s.done_cv.wait(l, [&] { return s.mapper_done_kf >= f - 2; });
+                s.done_cv.wait(l, [&] { return s.mapper_done_kf >= f - sets; });
             }
             wait_mapper += now() - tw;
         }
@@ -331,9 +335,9 @@ int main(int argc, char **argv)
     }
     for (auto &l : lines) printf("%s\n", l.c_str());
     printf("{\"lockstep_summary\": true, \"sequences\": %d, \"frames\": %ld, \"steps\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, "
-           "\"slam_library_s\": %.6f, \"slam_wait_for_loader_s\": %.6f, \"slam_wait_for_mapper_s\": %.6f, \"loader_threads\": %d, \"device\": %d, "
+           "\"slam_library_s\": %.6f, \"slam_wait_for_loader_s\": %.6f, \"slam_wait_for_mapper_s\": %.6f, \"loader_threads\": %d, \"stream_priorities\": %d, \"device\": %d, "
            "\"t_begin\": %.6f, \"t_end\": %.6f}\n",
-           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, device, t_begin, t_end);
+           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, t_begin, t_end);
 
     for (auto &s : S) { ov2_pyr_destroy(s->pyrR); ov2_ctx_destroy(s->ctxB); ov2_ctx_destroy(s->ctxC); }
     ov2_btracker_destroy(trk);
