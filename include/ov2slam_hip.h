@@ -276,21 +276,31 @@ int  ov2_tracker_uses_graph(const ov2_tracker *t); /* 1 when the graph path is a
  *   items [0, n_active) take part in a call (sequences of different length: order them longest first and shrink n_active as
  *   they end); the state of the other items is not touched.
  *   point arrays hold cfg->n_max slots per item: item b's points are [b*n_max, b*n_max + n_h[b]); n_h[b] <= n_max.
- *   images: img_h[b] = frame of item b, rows `stride` bytes apart.  Two pinned staging sets exist (which = 0 / 1,
- *   ov2_btracker_image_buffer): a reader thread fills set (f+1)&1 while step f runs; frames passed from a pinned slot are not
- *   copied on the host.  ov2_btracker_upload starts the H2D of a filled set on a copy stream of its own (overlapping the
- *   previous step's kernels); a step whose frames were not uploaded that way uploads them itself.
+ *   images: img_h[b] = frame of item b, rows `stride` bytes apart.  Three pinned staging sets exist (which = 0 / 1 / 2,
+ *   ov2_btracker_image_buffer); frames passed from the slots of one set are not copied on the host.
+ *   Look-ahead (optional; an offline host knows the next frames): the step is a three-stage pipeline on three streams --
+ *     ov2_btracker_upload(which)    H2D of a filled staging set on the tracker's copy stream
+ *     ov2_btracker_prepare(which)   preprocessImage (CLAHE + pyramid) of that set on the tracker's prep stream, into the pyramid set
+ *                                   that becomes cur_pyr_ when the frame is tracked
+ *     ov2_btracker_track_frame      with exactly those slots as img_h[]: only kltTracking + computeKeypoint remain (its stream waits
+ *                                   for the pyramids); with other frames, or without the look-ahead calls, everything runs in order.
+ *   A host loop: fill set (f+2)%3 [reader threads] -> upload((f+2)%3) -> prepare((f+1)%3) -> track_frame(frame f = set f%3).
+ *   Results do not depend on which form is used.
  * hipGraph replay (cfg->use_graph) is not used here: n_active changes the grids.                                          */
 typedef struct ov2_btracker ov2_btracker;
 int  ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, ov2_btracker **out);
 void ov2_btracker_destroy(ov2_btracker *t);
 int  ov2_btracker_batch(const ov2_btracker *t);
 int  ov2_btracker_frames(const ov2_btracker *t);
-/* pinned slot of item `item` in staging set `which` (0 / 1); *stride receives its pitch */
+/* pinned slot of item `item` in staging set `which` (0 / 1 / 2); *stride receives its pitch */
 uint8_t *ov2_btracker_image_buffer(ov2_btracker *t, int which, int item, int *stride);
 /* asynchronous H2D of items [0, n_active) of staging set `which` (the caller has filled the slots); the next
- * ov2_btracker_track_frame whose img_h[] are exactly those slots consumes the uploaded copy                   */
+ * ov2_btracker_prepare / ov2_btracker_track_frame of exactly those slots consumes the uploaded copy                   */
 int  ov2_btracker_upload(ov2_btracker *t, int which, int n_active);
+/* asynchronous preprocessImage of items [0, n_active) of staging set `which` for an ov2_btracker_track_frame to come: frames are
+ * prepared in order, at most two may wait (the one about to be tracked and the one after it), and once a frame is prepared the
+ * track_frame calls must consume exactly the prepared slots.  It overwrites the oldest pyramid set: see ov2_btracker_pyramid_sets   */
+int  ov2_btracker_prepare(ov2_btracker *t, int which, int n_active);
 /* Frame::computeKeypoint inside the per-step enqueue, as ov2_tracker_set_calibration (one calibration: the sequences of a batch
  * come from one camera rig)                                                                                            */
 int  ov2_btracker_set_calibration(ov2_btracker *t, int model, const double K[4], const double *D, int nD, const double iK[9]);
@@ -312,8 +322,9 @@ int  ov2_btracker_detect_grid_fast(ov2_btracker *t, int n_active, int cell, cons
                                    int mask_mode, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
 /* the current / previous frame's pyramids: the whole batch, or item `item` as a batch-1 view (owned by the tracker; valid until that
  * pyramid set comes round again, see ov2_btracker_pyramid_sets) -- what the mapper context passes to ov2_stereo_match as `left` */
-/* How many pyramid sets the tracker rotates through (3): the pyramids of frame f are overwritten by step f + sets.  A consumer on
- * another context (the mapper's stereo matching of keyframe f) must be done before the caller issues that step. */
+/* How many pyramid sets the tracker rotates through (4): the pyramids of frame f are overwritten by the pre-processing of frame
+ * f + sets -- ov2_btracker_track_frame of that frame, or the ov2_btracker_prepare call for it.  A consumer on another context (the
+ * mapper's stereo matching of keyframe f) must be done before the caller issues that call. */
 int  ov2_btracker_pyramid_sets(const ov2_btracker *t);
 const ov2_pyr *ov2_btracker_cur_pyr(const ov2_btracker *t);
 const ov2_pyr *ov2_btracker_prev_pyr(const ov2_btracker *t);

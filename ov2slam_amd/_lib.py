@@ -178,6 +178,7 @@ SIGNATURES = {
     "ov2_btracker_frames": (_i, [_vp]),
     "ov2_btracker_image_buffer": (_vp, [_vp, _i, _i, C.POINTER(_i)]),
     "ov2_btracker_upload": (_i, [_vp, _i, _i]),
+    "ov2_btracker_prepare": (_i, [_vp, _i, _i]),
     "ov2_btracker_set_calibration": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "ov2_btracker_track_frame": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "ov2_btracker_last_keypoints": (_i, [_vp, _i, _i, _vp, _vp]),

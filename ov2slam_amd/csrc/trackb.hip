@@ -7,36 +7,52 @@
 // Here the per-frame enqueue of VisualFrontEnd::preprocessImage + VisualFrontEnd::kltTracking (+ Frame::computeKeypoint)
 // (src/visual_front_end.cpp:1143-1177, :132-275; src/frame.cpp:246-254) is issued ONCE for all streams: the same kernels as
 // track.hip -- CLAHE, pyramid levels, the fused kltTracking kernel (lkw.hip / lk.hip), k_compute_keypoints -- with the grid
-// extended by the batch item.  Per step: one H2D of the frames (optionally started ahead on a copy stream), the kernels, one
-// synchronisation.  Items [0, n_active) take part (sequences of different length drop out from the tail).
+// extended by the batch item.  Per step: one H2D of the frames, the kernels, one synchronisation.  Items [0, n_active) take part
+// (sequences of different length drop out from the tail).
+// An offline host knows frame f + 1 while frame f is tracked: the step is a three-stage pipeline on three streams --
+//   copy stream      H2D of frame f + 2                       (ov2_btracker_upload)
+//   prep stream      CLAHE + pyramid of frame f + 1           (ov2_btracker_prepare; into the NEXT pyramid set)
+//   context stream   kltTracking + computeKeypoint of frame f (ov2_btracker_track_frame: waits for its pyramids, one sync)
+// with three pinned staging sets and four pyramid sets in rotation; events order producer -> consumer and consumer -> the producer
+// that reuses a buffer.  A caller that uses neither look-ahead call gets the same results from the plain in-order enqueue.
 // Results per item are bit-identical to an ov2_tracker fed the same frames and keypoints (tests/test_gpu_lockstep.py).
 #include "common.hpp"
 #include "keypoint_dev.hpp"
+#include <deque>
 #include <new>
 #include <vector>
 
 int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d, int items = 1);
 
-#define BT_SETS 3
+#define BT_SETS 4       // pyramid sets in rotation: cur, prev, the one being prepared for the next frame, one of slack for the mappers
+#define BT_IMG_SETS 3   // staging sets: frame f (read by its pre-processing), f + 1 (arriving), f + 2 (being filled by the host)
 
 struct ov2_btracker {
     ov2_ctx *ctx = nullptr;
     ov2_tracker_config cfg;
     int batch = 0;
-    // THREE pyramid sets in rotation (cur_pyr_, prev_pyr_ and the one before): a keyframe's pyramids stay valid for two more steps, so
-    // the mapper contexts that stereo-match it rarely hold the SLAM thread up (two sets: 12 % of the lock-step wall clock was that wait)
-    ov2_pyr *pyr[BT_SETS] = {nullptr, nullptr, nullptr};
+    // pyramid sets in rotation (cur_pyr_, prev_pyr_, ...): a keyframe's pyramids stay valid for BT_SETS - 1 more steps (BT_SETS - 2
+    // when the next frame is prepared ahead), so the mapper contexts that stereo-match it rarely hold the SLAM thread up (with two
+    // sets 12 % of the lock-step wall clock was that wait)
+    ov2_pyr *pyr[BT_SETS] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<ov2_pyr *> view[BT_SETS];    // batch-1 aliases of the items (stereo matching, the p3p retry, single-item detection)
-    int cur = 0;                       // index of cur_pyr_; prev_pyr_ = pyr[(cur + BT_SETS - 1) % BT_SETS]
+    int cur = 0;                       // index of cur_pyr_ (= (frames - 1) % BT_SETS); prev_pyr_ = pyr[(cur + BT_SETS - 1) % BT_SETS]
     int prev() const { return (cur + BT_SETS - 1) % BT_SETS; }
-    int frames = 0;
-    // frames: two pinned staging sets + their device mirrors; a copy stream for uploads started ahead of the step
-    uint8_t *himg[2] = {nullptr, nullptr}, *dimg[2] = {nullptr, nullptr};
+    long frames = 0;
+    // frames: pinned staging sets + their device mirrors; a copy stream for uploads and a stream for pre-processing started ahead
+    uint8_t *himg[BT_IMG_SETS] = {nullptr, nullptr, nullptr}, *dimg[BT_IMG_SETS] = {nullptr, nullptr, nullptr};
     size_t img_pitch = 0, img_bytes = 0;          // per item (img_bytes a multiple of 256)
-    hipStream_t cs = nullptr;
-    hipEvent_t up_ev[2] = {nullptr, nullptr};     // set `which` has arrived in dimg[which] (copy stream)
-    hipEvent_t used_ev[2] = {nullptr, nullptr};   // the kernels that read dimg[which] are done (main stream)
-    int up_n[2] = {0, 0};                         // items covered by the pending upload of the set (0: none pending)
+    hipStream_t cs = nullptr, ps = nullptr;
+    ov2_ctx side;                                 // what the launchers of clahe.hip / pyramid.hip see when they enqueue on `ps`
+    uint8_t *lut = nullptr;                       // CLAHE tables of a step (the context's scratch is busy with the detector on the main stream)
+    hipEvent_t up_ev[BT_IMG_SETS] = {nullptr, nullptr, nullptr};     // set `which` has arrived in dimg[which] (copy stream)
+    hipEvent_t used_ev[BT_IMG_SETS] = {nullptr, nullptr, nullptr};   // the kernels that read dimg[which] are done (main or prep stream)
+    int up_n[BT_IMG_SETS] = {0, 0, 0};            // items covered by the pending upload of the set (0: none pending)
+    // Frame k lives in pyramid set k % BT_SETS.  pre_count = frames whose preprocessImage has been enqueued (ahead or in order);
+    // frames prepared ahead wait in prepq (at most two: the one about to be tracked and the one after it)
+    struct Prep { int which, n, set; };
+    std::deque<Prep> prepq;
+    long pre_count = 0;
     // keypoint block: pinned + mapped (the kernels read / write it through its device alias) or mirrored on the device
     uint8_t *hblk = nullptr, *dblk = nullptr, *kblk = nullptr;
     bool zero_copy = false;
@@ -57,11 +73,13 @@ static void btracker_free(ov2_btracker *t)
     if (!t) return;
     if (t->ctx) { (void)hipSetDevice(t->ctx->device); (void)hipStreamSynchronize(t->ctx->stream); }
     if (t->cs) { (void)hipStreamSynchronize(t->cs); (void)hipStreamDestroy(t->cs); }
+    if (t->ps) { (void)hipStreamSynchronize(t->ps); (void)hipStreamDestroy(t->ps); }
+    if (t->lut) (void)hipFree(t->lut);
     for (int i = 0; i < BT_SETS; i++) {
         for (ov2_pyr *v : t->view[i]) ov2_pyr_destroy(v);
         ov2_pyr_destroy(t->pyr[i]);
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < BT_IMG_SETS; i++) {
         if (t->up_ev[i]) (void)hipEventDestroy(t->up_ev[i]);
         if (t->used_ev[i]) (void)hipEventDestroy(t->used_ev[i]);
         if (t->himg[i]) (void)hipHostFree(t->himg[i]);
@@ -79,26 +97,24 @@ static void btracker_free(ov2_btracker *t)
 // a pyramid handle that covers items [0, n) of `p` (host-side descriptor copy: the launchers size their grids from d.batch)
 static inline ov2_pyr prefix_of(const ov2_pyr *p, int n) { ov2_pyr q = *p; q.d.batch = n; return q; }
 
-// preprocessImage of items [0, n) into pyramid `dst` from dimg[which]
-static int enqueue_preprocess(ov2_btracker *t, ov2_pyr *dst, int which, int n)
+// preprocessImage of items [0, n) into pyramid `dst` from dimg[which], enqueued on `on` (the caller's context, or the tracker's
+// prep-stream context when the frame is prepared ahead)
+static int enqueue_preprocess(ov2_btracker *t, ov2_ctx *on, ov2_pyr *dst, int which, int n)
 {
-    ov2_ctx *ctx = t->ctx;
     const ov2_tracker_config &c = t->cfg;
     ov2_pyr q = prefix_of(dst, n);
     int rc;
     if (c.use_clahe) {
-        rc = ctx->reserve_device((size_t)n * c.tiles_x * c.tiles_y * 256);
-        if (rc != OV2_OK) return rc;
         const PyrLevelDesc &L0 = q.d.lv[0];
         int l1_done = 0;
-        rc = ov2_launch_clahe(ctx, t->dimg[which], c.w, c.h, (int)t->img_pitch, t->img_bytes, n, c.clahe_clip, c.tiles_x, c.tiles_y,
-                              q.d.base + L0.img_roi, L0.img_pitch, (size_t)q.d.item_stride, (uint8_t *)ctx->d_scratch, q.d.win, &q.d, &l1_done);
+        rc = ov2_launch_clahe(on, t->dimg[which], c.w, c.h, (int)t->img_pitch, t->img_bytes, n, c.clahe_clip, c.tiles_x, c.tiles_y,
+                              q.d.base + L0.img_roi, L0.img_pitch, (size_t)q.d.item_stride, t->lut, q.d.win, &q.d, &l1_done);
         if (rc != OV2_OK) return rc;
-        rc = ov2_launch_pyr_build(ctx, &q, nullptr, 0, 0, l1_done);
+        rc = ov2_launch_pyr_build(on, &q, nullptr, 0, 0, l1_done);
     } else
-        rc = ov2_launch_pyr_build(ctx, &q, t->dimg[which], (int)t->img_pitch, t->img_bytes);
+        rc = ov2_launch_pyr_build(on, &q, t->dimg[which], (int)t->img_pitch, t->img_bytes);
     if (rc != OV2_OK) return rc;
-    OV2_HIP_CHECK(hipEventRecord(t->used_ev[which], ctx->stream));
+    OV2_HIP_CHECK(hipEventRecord(t->used_ev[which], on->stream));
     return OV2_OK;
 }
 
@@ -124,20 +140,30 @@ static int enqueue_klt(ov2_btracker *t, const ov2_pyr *prev, const ov2_pyr *cur,
 }
 
 // Frames of items [0, n) -> dimg[which] on the main stream, `which` = the staging set the step reads.  Frames that already sit in
-// a pinned slot are not copied on the host; a set uploaded ahead (ov2_btracker_upload) is only waited for.
-static int stage_and_upload(ov2_btracker *t, int n, const uint8_t *const *img_h, int stride, int *which_out)
+// a pinned slot are not copied on the host; a set uploaded ahead (ov2_btracker_upload) is only waited for; *prepared: the set was
+// pre-processed ahead as well (ov2_btracker_prepare) -- nothing is enqueued for it here.
+static int stage_and_upload(ov2_btracker *t, int n, const uint8_t *const *img_h, int stride, int *which_out, bool *prepared)
 {
+    *prepared = false;
     const int w = t->cfg.w, h = t->cfg.h;
     int which = -1;
-    for (int s = 0; s < 2 && which < 0; s++) {
+    for (int s = 0; s < BT_IMG_SETS && which < 0; s++) {
         bool all = (size_t)stride == t->img_pitch;
         for (int b = 0; b < n && all; b++) all = img_h[b] == t->himg[s] + (size_t)b * t->img_bytes;
         if (all) which = s;
     }
     const bool in_place = which >= 0;
-    if (!in_place) which = t->frames & 1;
+    if (!in_place) which = (int)(t->frames % BT_IMG_SETS);
     // the set's previous H2D (an upload started ahead, or the inline copy of an earlier step) must have left the pinned slots before
     // they are rewritten, and a pending look-ahead upload of a set that is now filled differently is void
+    if (!t->prepq.empty()) {
+        // frames were prepared ahead: the step must consume the oldest of them, exactly
+        const ov2_btracker::Prep &pf = t->prepq.front();
+        OV2_REQUIRE(in_place && pf.which == which && pf.n >= n && pf.set == (int)(t->frames % BT_SETS), OV2_EINVAL,
+                    "ov2_btracker_track_frame: the frames passed are not the ones ov2_btracker_prepare was called for");
+        *prepared = true; *which_out = which;
+        return OV2_OK;
+    }
     if (!in_place) {
         if (t->up_n[which]) { OV2_HIP_CHECK(hipEventSynchronize(t->up_ev[which])); t->up_n[which] = 0; }
         for (int b = 0; b < n; b++) {
@@ -289,7 +315,7 @@ int ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, 
     t->o_out = t->in_bytes; t->o_st = t->o_out + 8 * nm; t->o_unpx = up256(t->o_st + nm); t->o_bv = up256(t->o_unpx + 8 * nm); t->blk_bytes = t->o_bv + 24 * nm;
     t->det_in_bytes = up256(4 * (size_t)batch) + 8 * nm;
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    for (int i = 0; i < BT_IMG_SETS && e == hipSuccess; i++) {
         e = hipHostMalloc((void **)&t->himg[i], t->img_bytes * batch + 256, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&t->dimg[i], t->img_bytes * batch + 256);
         if (e == hipSuccess) e = hipMemsetAsync(t->dimg[i], 0, t->img_bytes * batch + 256, ctx->stream);
@@ -297,7 +323,13 @@ int ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, 
         if (e == hipSuccess) e = hipEventCreateWithFlags(&t->used_ev[i], hipEventDisableTiming);
         if (e == hipSuccess) memset(t->himg[i], 0, t->img_bytes * batch + 256);
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->cs, hipStreamNonBlocking);
+    {   // the look-ahead streams inherit the priority of the context's stream
+        int prio = 0;
+        if (e == hipSuccess) e = hipStreamGetPriority(ctx->stream, &prio);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&t->cs, hipStreamNonBlocking, prio);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&t->ps, hipStreamNonBlocking, prio);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&t->lut, (size_t)batch * (cfg->use_clahe ? (size_t)cfg->tiles_x * cfg->tiles_y : 1) * 256 + 256);
     if (e == hipSuccess) e = hipHostMalloc((void **)&t->hblk, t->blk_bytes, hipHostMallocMapped);
     if (e == hipSuccess) e = hipMalloc((void **)&t->dblk, t->blk_bytes);
     if (e == hipSuccess) e = hipMemsetAsync(t->dblk, 0, t->blk_bytes, ctx->stream);
@@ -307,6 +339,7 @@ int ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, 
     if (e != hipSuccess) { ov2_set_error("ov2_btracker_create: %s", hipGetErrorString(e)); btracker_free(t); return OV2_ENOMEM; }
     memset(t->hblk, 0, t->blk_bytes);
     memset(t->h_det, 0, t->det_in_bytes);
+    t->side.device = ctx->device; t->side.stream = t->ps; t->side.owns_stream = false;
     t->kblk = t->dblk;
     {   // the kernels read / write the pinned block through its device alias (no staging copies); the device block is the fallback
         void *alias = nullptr;
@@ -319,24 +352,52 @@ int ov2_btracker_create(ov2_ctx *ctx, const ov2_tracker_config *cfg, int batch, 
 
 void ov2_btracker_destroy(ov2_btracker *t) { btracker_free(t); }
 int ov2_btracker_batch(const ov2_btracker *t) { return t ? t->batch : 0; }
-int ov2_btracker_frames(const ov2_btracker *t) { return t ? t->frames : 0; }
+int ov2_btracker_frames(const ov2_btracker *t) { return t ? (int)t->frames : 0; }
 
 uint8_t *ov2_btracker_image_buffer(ov2_btracker *t, int which, int item, int *stride)
 {
-    if (!t || which < 0 || which > 1 || item < 0 || item >= t->batch) return nullptr;
+    if (!t || which < 0 || which >= BT_IMG_SETS || item < 0 || item >= t->batch) return nullptr;
     if (stride) *stride = (int)t->img_pitch;
     return t->himg[which] + (size_t)item * t->img_bytes;
 }
 
 int ov2_btracker_upload(ov2_btracker *t, int which, int n_active)
 {
-    OV2_REQUIRE(t && (which == 0 || which == 1), OV2_EINVAL, "bad staging set");
+    OV2_REQUIRE(t && which >= 0 && which < BT_IMG_SETS, OV2_EINVAL, "bad staging set");
     OV2_REQUIRE(n_active >= 1 && n_active <= t->batch, OV2_EINVAL, "n_active out of range");
     OV2_HIP_CHECK(hipSetDevice(t->ctx->device));
     OV2_HIP_CHECK(hipStreamWaitEvent(t->cs, t->used_ev[which], 0));      // the step that read dimg[which] last (no-op before the first record)
     OV2_HIP_CHECK(hipMemcpyAsync(t->dimg[which], t->himg[which], (size_t)n_active * t->img_bytes, hipMemcpyHostToDevice, t->cs));
     OV2_HIP_CHECK(hipEventRecord(t->up_ev[which], t->cs));
     t->up_n[which] = n_active;
+    return OV2_OK;
+}
+
+int ov2_btracker_prepare(ov2_btracker *t, int which, int n_active)
+{
+    OV2_REQUIRE(t && which >= 0 && which < BT_IMG_SETS, OV2_EINVAL, "bad staging set");
+    OV2_REQUIRE(n_active >= 1 && n_active <= t->batch, OV2_EINVAL, "n_active out of range");
+    OV2_REQUIRE(t->prepq.size() < 2, OV2_EINVAL, "two prepared frames are already waiting for their ov2_btracker_track_frame");
+    OV2_HIP_CHECK(hipSetDevice(t->ctx->device));
+    // the frames: uploaded ahead (wait for the copy stream) or copied here, on the prep stream
+    if (t->up_n[which] >= n_active) OV2_HIP_CHECK(hipStreamWaitEvent(t->ps, t->up_ev[which], 0));
+    else {
+        if (t->up_n[which]) OV2_HIP_CHECK(hipStreamWaitEvent(t->ps, t->up_ev[which], 0));
+        OV2_HIP_CHECK(hipStreamWaitEvent(t->ps, t->used_ev[which], 0));
+        OV2_HIP_CHECK(hipMemcpyAsync(t->dimg[which], t->himg[which], (size_t)n_active * t->img_bytes, hipMemcpyHostToDevice, t->ps));
+    }
+    t->up_n[which] = 0;
+    // target: the pyramid set of frame pre_count.  Its last readers on the context's stream -- the tracking kernels of the step that
+    // had it as prev_pyr_ -- finished before that step's synchronisation (at most two frames are ever ahead of the tracked one);
+    // consumers on other contexts are the caller's to wait for (ov2_btracker_pyramid_sets)
+    const int set = (int)(t->pre_count % BT_SETS);
+    t->side.clahe_strips = t->ctx->clahe_strips;
+    int rc = enqueue_preprocess(t, &t->side, t->pyr[set], which, n_active);
+    if (rc != OV2_OK) return rc;
+    rc = ov2_pyr_mark_ready(&t->side, t->pyr[set]);
+    if (rc != OV2_OK) return rc;
+    t->prepq.push_back({which, n_active, set});
+    t->pre_count++;
     return OV2_OK;
 }
 
@@ -371,27 +432,32 @@ int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const
     ov2_ctx *ctx = t->ctx;
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     int which = 0;
-    int rc = stage_and_upload(t, n_active, img_h, stride, &which);
+    bool prepared = false;
+    int rc = stage_and_upload(t, n_active, img_h, stride, &which, &prepared);
     if (rc != OV2_OK) return rc;
+    // preprocessImage: already under way on the prep stream (the context's stream waits for the pyramids' event), or in order here
+    const int old_cur = t->cur;
+    auto preprocess = [&]() -> int {
+        if (prepared) { t->prepq.pop_front(); return ov2_pyr_wait_ready(ctx, t->pyr[t->cur]); }
+        const int rcp = enqueue_preprocess(t, ctx, t->pyr[t->cur], which, n_active);
+        if (rcp != OV2_OK) return rcp;
+        t->pre_count++;
+        return ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
+    };
+    t->cur = (int)(t->frames % BT_SETS);                                 // prev_pyr_.swap(cur_pyr_)  (:1169): frame k lives in set k % BT_SETS
     if (t->frames == 0 || n_total == 0) {
         // first frame (trackMono returns right after preprocessImage) or nothing to track anywhere
-        if (t->frames > 0) t->cur = (t->cur + 1) % BT_SETS;              // prev_pyr_.swap(cur_pyr_)  (:1169)
-        rc = enqueue_preprocess(t, t->pyr[t->cur], which, n_active);
-        if (rc != OV2_OK) { if (t->frames > 0) t->cur = t->prev(); return rc; }
+        rc = preprocess();
+        if (rc != OV2_OK) { t->cur = old_cur; return rc; }
         t->frames++;
-        rc = ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
-        if (rc != OV2_OK) return rc;
         if (status_h && n_h) for (int b = 0; b < n_active; b++) if (n_h[b] > 0) memset(status_h + nm * b, 0, (size_t)n_h[b]);
         return ov2_ctx_sync(ctx);
     }
     stage_points(t, n_active, kps_xy_h, prior_xy_h, has_prior_h, n_h, klt_use_prior);
-    t->cur = (t->cur + 1) % BT_SETS;                                     // prev_pyr_.swap(cur_pyr_)  (:1169)
-    rc = enqueue_preprocess(t, t->pyr[t->cur], which, n_active);
+    rc = preprocess();
     if (rc == OV2_OK) rc = enqueue_klt(t, t->pyr[t->prev()], t->pyr[t->cur], n_active);
-    if (rc != OV2_OK) { t->cur = t->prev(); return rc; }
+    if (rc != OV2_OK) { t->cur = old_cur; return rc; }
     t->frames++;
-    rc = ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
-    if (rc != OV2_OK) return rc;
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < n_active; b++) {
         const size_t n = (size_t)n_h[b], o = nm * (size_t)b;

@@ -371,7 +371,7 @@ class LockstepTracker:
         ctx._children.add(self)
         stride = C.c_int()
         self.image_buffers = []                       # [which][item] -> numpy view of the pinned slot
-        for which in range(2):
+        for which in range(3):
             row = []
             for b in range(self.batch):
                 ptr = self.lib.ov2_btracker_image_buffer(ht, which, b, C.byref(stride))
@@ -386,6 +386,10 @@ class LockstepTracker:
     def upload(self, which, n_active):
         """start the H2D of staging set `which` (already filled through image_buffers[which]) on the copy stream"""
         L.check(self.lib.ov2_btracker_upload(self.h_trk, int(which), int(n_active)))
+
+    def prepare(self, which, n_active):
+        """preprocessImage of staging set `which` for the NEXT trackFrame, on the tracker's prep stream"""
+        L.check(self.lib.ov2_btracker_prepare(self.h_trk, int(which), int(n_active)))
 
     def trackFrame(self, imgs, kps, pri, hasprior, n, klt_use_prior=True):
         """imgs: list of n_active (h, >=w) uint8 arrays of one row pitch (or pinned slots of one staging set); kps / pri:

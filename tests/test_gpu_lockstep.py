@@ -58,11 +58,13 @@ def test_lockstep_equals_single_trackers(gpu_ctx, oracle, wh, use_clahe, impl):
                 per[1] = (per[1][0][:0], per[1][1][:0], per[1][2][:0])      # an item with nothing to track this frame
             kps, pri, hp, n = _pack(batch, n_max, per)
             imgs = [seqs[b][0][f + 1] for b in range(na)]
-            if f % 2 == 1:                                        # frames written into the pinned slots + look-ahead upload
-                which = f & 1
+            if f % 2 == 1:                                        # frames written into the pinned slots + look-ahead upload / pre-processing
+                which = f % 3
                 for b in range(na):
                     bt.image_buffers[which][b][:, :w] = imgs[b]
                 bt.upload(which, na)
+                if f == 3:
+                    bt.prepare(which, na)
                 imgs = [bt.image_buffers[which][b] for b in range(na)]
             out, st, p3p = bt.trackFrame(imgs, kps, pri, hp, n)
             for b in range(na):
@@ -112,6 +114,65 @@ def test_lockstep_equals_single_trackers(gpu_ctx, oracle, wh, use_clahe, impl):
         for t in singles:
             t.close()
         bt.close()
+
+
+def test_lockstep_pipeline(gpu_ctx):
+    """The three-stage look-ahead schedule of tools/lockstep_driver.cpp -- upload(f + 2), prepare(f + 1), track_frame(f), two prepared
+    frames in flight -- gives the in-order results; a track_frame on other frames than the prepared ones is refused."""
+    w, h, batch, n_max, nframes = 752, 480, 4, 400, 9
+    seqs = [_sequence(w, h, nframes, seed=90 + b) for b in range(batch)]
+    length = [9, 9, 7, 5]
+    rngs = [np.random.default_rng(300 + b) for b in range(batch)]
+    cal = ov2slam_amd.CameraCalibration(gpu_ctx, "pinhole", *K_EUROC, D=D_EUROC)
+    bt = ov2slam_amd.LockstepTracker(gpu_ctx, batch, w, h, fclahe_val=CLIP, nbmaxkps=n_max)
+    bt.setCalibration(cal)
+    singles = []
+    for b in range(batch):
+        t = ov2slam_amd.VisualFrontEndTracker(gpu_ctx, w, h, fclahe_val=CLIP, nbmaxkps=n_max, use_graph=False)
+        t.setCalibration(cal)
+        singles.append(t)
+    na_at = lambda f: sum(1 for b in range(batch) if length[b] > f)
+
+    def fill(f):
+        for b in range(na_at(f)):
+            bt.image_buffers[f % 3][b][:, :w] = seqs[b][0][f]
+    for f in range(3):
+        fill(f)
+    bt.upload(0, na_at(0)); bt.prepare(0, na_at(0)); bt.upload(1, na_at(1))
+    z = np.zeros((batch, n_max, 2), np.float32)
+    for f in range(nframes):
+        na = na_at(f)
+        if f + 2 < nframes and na_at(f + 2):
+            bt.upload((f + 2) % 3, na_at(f + 2))
+        if f + 1 < nframes and na_at(f + 1):
+            bt.prepare((f + 1) % 3, na_at(f + 1))
+        imgs = [bt.image_buffers[f % 3][b] for b in range(na)]
+        if f == 0:
+            bt.trackFrame(imgs, z, z, None, np.zeros(na, np.int32))
+            for b in range(batch):
+                singles[b].trackFrame(seqs[b][0][0], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+        else:
+            per = [_points(w, h, seqs[b][1], f - 1, rngs[b], 1.0, bad_frac=0.2) for b in range(na)]
+            kps, pri, hp, n = _pack(batch, n_max, per)
+            if f == 4:                                            # not the prepared frames: refused, nothing consumed
+                with pytest.raises(ov2slam_amd.Ov2Error):
+                    bt.trackFrame([seqs[b][0][f] for b in range(na)], kps, pri, hp, n)
+            out, st, p3p = bt.trackFrame(imgs, kps, pri, hp, n)
+            for b in range(na):
+                so, ss, sp = singles[b].trackFrame(seqs[b][0][f], *per[b])
+                m = len(per[b][0])
+                assert np.array_equal(_bits(out[b, :m]), _bits(so)) and np.array_equal(st[b, :m], ss) and bool(p3p[b]) == sp, "frame %d item %d" % (f, b)
+                bu, bb = bt.lastKeypoints(b, m)
+                su, sb = singles[b].lastKeypoints(m)
+                assert np.array_equal(_bits(bu), _bits(su)) and np.array_equal(bb.view(np.uint64), sb.view(np.uint64))
+                gi, _ = bt.cur_item(b).download(1)
+                si, _ = singles[b].cur_pyr.download(1)
+                assert np.array_equal(gi, si)
+        if f + 3 < nframes:
+            fill(f + 3)                                           # staging set f % 3 is free again
+    for t in singles:
+        t.close()
+    bt.close()
 
 
 def test_lockstep_p3p_rule(gpu_ctx):

@@ -45,7 +45,7 @@ struct Seq {
     double t_last_frame = 0, t_drained = 0;
 };
 
-// loader threads: "decode" frame f of every active sequence into the tracker's pinned slots of set f & 1
+// loader threads: "decode" frame f of every active sequence into the tracker's pinned slots of set f % 3
 struct Loader {
     std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
     int want = -1, done_count = 0, n_threads = 0; bool quit = false;
@@ -153,7 +153,7 @@ int main(int argc, char **argv)
                 for (int b = tid; b < na; b += n_load) {
                     const Case &C = S[(size_t)b]->C;
                     int st = 0;
-                    uint8_t *dst = ov2_btracker_image_buffer(trk, f & 1, b, &st);
+                    uint8_t *dst = ov2_btracker_image_buffer(trk, f % 3, b, &st);
                     const uint8_t *src = C.left[(size_t)view_index(C, f)].data();
                     if (st == w) memcpy(dst, src, (size_t)w * h);
                     else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * st, src + (size_t)y * w, (size_t)w);
@@ -222,18 +222,34 @@ int main(int argc, char **argv)
         }
     };
 
-    load_kick(0); load_wait();
+    // Pipeline (ov2_btracker_upload / _prepare / _track_frame): while frame f is tracked, frame f + 1 is pre-processed on the tracker's
+    // prep stream, frame f + 2 travels on its copy stream and the loader threads fill the staging set of frame f + 3.
+    // wait until the mappers have consumed keyframe g (its pyramid set is about to be overwritten)
+    auto wait_mappers = [&](int g) {
+        if (g < 0 || g % kf_every != 0) return;
+        const double tw = now();
+        for (int b = 0; b < n_active_at(g); b++) {
+            Seq &s = *S[(size_t)b];
+            std::unique_lock<std::mutex> l(s.done_m);
+            s.done_cv.wait(l, [&] { return s.mapper_done_kf >= g; });
+        }
+        wait_mapper += now() - tw;
+    };
+    for (int f = 0; f < 3 && f < F; f++) { load_kick(f); load_wait(); }                 // the three staging sets start full
     const double t_begin = wall();
     const double t0 = now();
     {
         const int na = N;
         for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, 0, b, nullptr);
-        if (F > 1) { load_kick(1); load_wait(); CK(ov2_btracker_upload(trk, 1, n_active_at(1))); }    // frame 1 travels while frame 0 is processed
         std::fill(nper.begin(), nper.end(), 0);
         double tl = now();
+        CK(ov2_btracker_upload(trk, 0, na)); CK(ov2_btracker_prepare(trk, 0, na));        // (prologue of the pipeline)
+        if (F > 1) CK(ov2_btracker_upload(trk, 1, n_active_at(1)));
+        if (F > 2) CK(ov2_btracker_upload(trk, 2, n_active_at(2)));
+        if (F > 1) CK(ov2_btracker_prepare(trk, 1, n_active_at(1)));
         CK(ov2_btracker_track_frame(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1, out.data(), st.data(), p3p.data()));
         lib_s += now() - tl;
-        if (F > 2) load_kick(2);                                                        // set 0 is free again
+        if (F > 3) load_kick(3);                                                        // staging set 0 is free again
         for (int b = 0; b < na; b++) S[(size_t)b]->frames = 1;
         keyframe(0, na);
     }
@@ -258,30 +274,24 @@ int main(int argc, char **argv)
                 pri[2 * (o + i) + 1] = hpi ? (float)(gy + s.C.prior_sigma * s.gauss(s.rng)) : y;
             }
         }
-        if (f >= sets && (f - sets) % kf_every == 0) {   // this step overwrites the pyramids of frame f - sets: the mappers may still read them
-            const double tw = now();
-            for (int b = 0; b < n_active_at(f - sets); b++) {
-                Seq &s = *S[(size_t)b];
-                std::unique_lock<std::mutex> l(s.done_m);
-                s.done_cv.wait(l, [&] { return s.mapper_done_kf >= f - sets; });
-            }
-            wait_mapper += now() - tw;
-        }
-        // Pipeline: frame f was uploaded to set f & 1 during step f - 1; frame f + 1 (loaded by the loader threads since step f - 1
-        // returned) starts its H2D on the copy stream now, beside this step's kernels; once the step returns, set f & 1 is free for
-        // the loaders' frame f + 2.
         double tl;
-        if (f + 1 < F) {
+        if (f + 2 < F) {                                                                // frame f + 2 has been loaded since step f - 1 returned
             const double tw = now(); load_wait(); wait_loader += now() - tw;
             tl = now();
-            CK(ov2_btracker_upload(trk, (f + 1) & 1, n_active_at(f + 1)));
+            CK(ov2_btracker_upload(trk, (f + 2) % 3, n_active_at(f + 2)));
             lib_s += now() - tl;
         }
-        for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, f & 1, b, nullptr);
+        if (f + 1 < F) {
+            wait_mappers(f + 1 - sets);                                                  // the pyramid set frame f + 1 goes into
+            tl = now();
+            CK(ov2_btracker_prepare(trk, (f + 1) % 3, n_active_at(f + 1)));
+            lib_s += now() - tl;
+        } else wait_mappers(f - sets);
+        for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, f % 3, b, nullptr);
         tl = now();
         CK(ov2_btracker_track_frame(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1, out.data(), st.data(), p3p.data()));
         lib_s += now() - tl;
-        if (f + 2 < F) load_kick(f + 2);
+        if (f + 3 < F) load_kick(f + 3);                                                // staging set f % 3 is free again
         steps++;
         for (int b = 0; b < na; b++) {
             Seq &s = *S[(size_t)b];
