@@ -160,6 +160,10 @@ int ov2_pyr_build_clahe_d(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_d, int st
 /* same from a host image (batch-1 pyramid): one H2D of the raw frame, asynchronous on ctx's stream -- the
  * single-sequence form of VisualFrontEnd::preprocessImage (the image is staged in pinned memory before the call returns) */
 int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int stride, double clip_limit, int tiles_x, int tiles_y);
+/* the same for `n_items` host images (one pointer each, rows `stride` apart) into items [0, n_items) of a batch pyramid: one repack into
+ * pinned memory, ONE H2D, the batched kernels -- the right images of the keyframes a lock-step batch reaches together
+ * (src/mapper.cpp:74-81 per keyframe).  clip_limit < 0: no CLAHE (use_clahe: 0).  Asynchronous like ov2_pyr_build_clahe_h.        */
+int ov2_pyr_build_clahe_hb(ov2_ctx *ctx, ov2_pyr *p, int n_items, const uint8_t *const *img_h, int stride, double clip_limit, int tiles_x, int tiles_y);
 
 /* ---- Lucas-Kanade --------------------------------------------------
  * ov2_lk_track replaces one cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts,
@@ -322,7 +326,7 @@ int  ov2_btracker_detect_grid_fast(ov2_btracker *t, int n_active, int cell, cons
                                    int mask_mode, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
 /* the current / previous frame's pyramids: the whole batch, or item `item` as a batch-1 view (owned by the tracker; valid until that
  * pyramid set comes round again, see ov2_btracker_pyramid_sets) -- what the mapper context passes to ov2_stereo_match as `left` */
-/* How many pyramid sets the tracker rotates through (4): the pyramids of frame f are overwritten by the pre-processing of frame
+/* How many pyramid sets the tracker rotates through (6): the pyramids of frame f are overwritten by the pre-processing of frame
  * f + sets -- ov2_btracker_track_frame of that frame, or the ov2_btracker_prepare call for it.  A consumer on another context (the
  * mapper's stereo matching of keyframe f) must be done before the caller issues that call. */
 int  ov2_btracker_pyramid_sets(const ov2_btracker *t);
@@ -645,6 +649,15 @@ int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
                      float eps, float nklt_err, float fmax_fbklt_dist, int rect, const double Frl[9], int model, const double K[4],
                      const double *D, int nD, const float *kps_px_h, const float *kps_unpx_h, const float *priors3d_h,
                      const uint8_t *has_prior3d_h, int n, float *right_px_h, uint8_t *stereo_ok_h);
+
+/* ov2_stereo_match for the keyframes of a lock-step batch (all sequences of a rank reach their keyframes together): items [0, n_items) of
+ * two batch pyramids (left: e.g. ov2_btracker_cur_pyr at the keyframe; right: ov2_pyr_build_clahe_hb), n_max point slots per item
+ * (item b's points are [b*n_max, b*n_max + n_h[b])), ONE enqueue and ONE synchronisation for all items -- the same kernels with the grid
+ * extended by the item.  Per item the outputs equal ov2_stereo_match on that item.                                                */
+int ov2_stereo_match_batch(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int n_items, int nklt_win_size, int nklt_pyr_lvl, int max_iter,
+                           float eps, float nklt_err, float fmax_fbklt_dist, int rect, const double Frl[9], int model, const double K[4],
+                           const double *D, int nD, int n_max, const float *kps_px_h, const float *kps_unpx_h, const float *priors3d_h,
+                           const uint8_t *has_prior3d_h, const int *n_h, float *right_px_h, uint8_t *stereo_ok_h);
 
 #ifdef __cplusplus
 }

@@ -160,6 +160,8 @@ SIGNATURES = {
     "ov2_stereo_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ov2_pyr_build_clahe_d": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _d, _i, _i]),
     "ov2_pyr_build_clahe_h": (_i, [_vp, _vp, _vp, _i, _d, _i, _i]),
+    "ov2_pyr_build_clahe_hb": (_i, [_vp, _vp, _i, _vp, _i, _d, _i, _i]),
+    "ov2_stereo_match_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ov2_tracker_create": (_i, [_vp, C.POINTER(TrackerConfig), _pp]),
     "ov2_tracker_destroy": (None, [_vp]),
     "ov2_tracker_image_buffer": (_vp, [_vp, C.POINTER(_i)]),

@@ -887,6 +887,40 @@ int ov2_pyr_build_clahe_h(ov2_ctx *ctx, ov2_pyr *p, const uint8_t *img_h, int st
     return ov2_pyr_mark_ready(ctx, p);
 }
 
+// preprocessImage of `n_items` host images into items [0, n_items) of a batch pyramid in one enqueue (the right images of the keyframes a
+// lock-step batch reaches together, src/mapper.cpp:74-81 per keyframe): one repack into pinned memory, ONE H2D, the batched kernels.
+// clip_limit < 0: no CLAHE (use_clahe: 0), plain cv::buildOpticalFlowPyramid.  Items beyond n_items keep their contents.
+int ov2_pyr_build_clahe_hb(ov2_ctx *ctx, ov2_pyr *p, int n_items, const uint8_t *const *img_h, int stride, double clip_limit, int tiles_x, int tiles_y)
+{
+    OV2_REQUIRE(ctx && p && img_h, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(p->parent == nullptr, OV2_EINVAL, "an item view is read-only");
+    OV2_REQUIRE(n_items >= 1 && n_items <= p->d.batch, OV2_EINVAL, "n_items out of range");
+    const bool use_clahe = clip_limit >= 0.0;
+    OV2_REQUIRE(stride >= p->w && (!use_clahe || (tiles_x > 0 && tiles_y > 0 && tiles_x <= p->w && tiles_y <= p->h)), OV2_EINVAL, "bad geometry");
+    for (int b = 0; b < n_items; b++) OV2_REQUIRE(img_h[b] != nullptr, OV2_EINVAL, "NULL image");
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t pitch = ((size_t)p->w + 15) & ~(size_t)15;
+    const size_t img = (pitch * p->h + 255) & ~(size_t)255, lut_bytes = use_clahe ? (size_t)n_items * tiles_x * tiles_y * 256 : 0;
+    int rc = ctx->reserve_device(img * (size_t)n_items + lut_bytes);
+    if (rc != OV2_OK) return rc;
+    uint8_t *ds = (uint8_t *)ctx->d_scratch;
+    rc = ctx->upload_images(ds, pitch, img, img_h, n_items, (size_t)stride, (size_t)p->w, (size_t)p->h);
+    if (rc != OV2_OK) return rc;
+    ov2_pyr q = *p;                                   // items [0, n_items): the launchers size their grids from d.batch
+    q.d.batch = n_items;
+    if (use_clahe) {
+        const PyrLevelDesc &L0 = q.d.lv[0];
+        int l1_done = 0;
+        rc = ov2_launch_clahe(ctx, ds, p->w, p->h, (int)pitch, img, n_items, clip_limit, tiles_x, tiles_y, q.d.base + L0.img_roi, L0.img_pitch,
+                              (size_t)q.d.item_stride, ds + img * (size_t)n_items, q.d.win, &q.d, &l1_done);
+        if (rc != OV2_OK) return rc;
+        rc = ov2_launch_pyr_build(ctx, &q, nullptr, 0, 0, l1_done);
+    } else
+        rc = ov2_launch_pyr_build(ctx, &q, ds, (int)pitch, img);
+    if (rc != OV2_OK) return rc;
+    return ov2_pyr_mark_ready(ctx, p);
+}
+
 int ov2_clahe_h(ov2_ctx *ctx, const uint8_t *src_h, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
                 uint8_t *dst_h, int dst_stride)
 {

@@ -68,6 +68,8 @@ struct ov2_ctx {
     // host image (any row stride, pageable or pinned) -> device buffer with pitch dst_pitch, asynchronous on the stream; the
     // caller's buffer is free again when this returns
     int upload_image(void *dst_d, size_t dst_pitch, const uint8_t *src_h, size_t src_stride, size_t w, size_t h);
+    // n images (one pointer each) into device slots `item_bytes` apart: one repack into the pinned staging buffer, ONE DMA
+    int upload_images(void *dst_d, size_t dst_pitch, size_t item_bytes, const uint8_t *const *src_h, int n, size_t src_stride, size_t w, size_t h);
     // the reverse, synchronous: h rows of w bytes at device pitch src_pitch -> host rows at dst_stride (one contiguous DMA into the
     // pinned staging buffer, then a host-side repack)
     int download_image(uint8_t *dst_h, size_t dst_stride, const void *src_d, size_t src_pitch, size_t w, size_t h);

@@ -56,6 +56,27 @@ int ov2_ctx::upload_image(void *dst_d, size_t dst_pitch, const uint8_t *src_h, s
     return OV2_OK;
 }
 
+int ov2_ctx::upload_images(void *dst_d, size_t dst_pitch, size_t item_bytes, const uint8_t *const *src_h, int n, size_t src_stride, size_t w, size_t h)
+{
+    const size_t bytes = item_bytes * (size_t)n;
+    if (img_pending) { OV2_HIP_CHECK(hipEventSynchronize(img_ev)); img_pending = false; }
+    if (!img_ev) OV2_HIP_CHECK(hipEventCreateWithFlags(&img_ev, hipEventDisableTiming));
+    if (bytes > h_img_bytes) {
+        if (h_img) { OV2_HIP_CHECK(hipHostFree(h_img)); h_img = nullptr; h_img_bytes = 0; }
+        OV2_HIP_CHECK(hipHostMalloc(&h_img, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        h_img_bytes = bytes + bytes / 4 + 4096;
+    }
+    for (int b = 0; b < n; b++) {
+        uint8_t *st = (uint8_t *)h_img + item_bytes * (size_t)b;
+        if (src_stride == dst_pitch) memcpy(st, src_h[b], dst_pitch * (h - 1) + w);
+        else for (size_t y = 0; y < h; y++) memcpy(st + y * dst_pitch, src_h[b] + y * src_stride, w);
+    }
+    OV2_HIP_CHECK(hipMemcpyAsync(dst_d, h_img, bytes, hipMemcpyHostToDevice, stream));
+    OV2_HIP_CHECK(hipEventRecord(img_ev, stream));
+    img_pending = true;
+    return OV2_OK;
+}
+
 int ov2_ctx::download_image(uint8_t *dst_h, size_t dst_stride, const void *src_d, size_t src_pitch, size_t w, size_t h)
 {
     if (w == 0 || h == 0) return OV2_OK;

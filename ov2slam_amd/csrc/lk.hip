@@ -610,7 +610,6 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
     const PyrDesc &P = prev->d, &C = cur->d;
     OV2_REQUIRE(P.n_levels == C.n_levels && items >= 1 && P.batch >= items && C.batch >= items && P.win == C.win && win == P.win, OV2_EINVAL,
                 "tracker pyramids differ in geometry");
-    OV2_REQUIRE(items == 1 || sad_x == nullptr, OV2_EINVAL, "the stereo mode takes one item");
     LKParams prm = make_params(prev, win, lvl_full, max_iter, eps, OV2_LK_USE_INITIAL_FLOW | OV2_LK_GET_MIN_EIGENVALS,
                                err_th, fb_dist, 1, n_max);
     const int lf = prm.max_level;                                  // clamped to the pyramid like feature_tracker.cpp:50-52

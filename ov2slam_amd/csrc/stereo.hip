@@ -35,17 +35,19 @@ __device__ __forceinline__ int sad_subpix(const uint8_t *__restrict__ img, int p
     return ((t + (1 << 15)) >> 16) & 0xFF;
 }
 
+// blockIdx.y: batch item (ov2_stereo_match_batch: n point slots and one entry of n_dev per item; 0 for one keyframe)
 __global__ __launch_bounds__(256) void k_line_min_sad(PyrDesc PL, PyrDesc PR, int level, int nwinsize, int go_left,
                                                       const float2 *__restrict__ pts, int n, float *__restrict__ xprior,
-                                                      float *__restrict__ l1err)
+                                                      float *__restrict__ l1err, const int *__restrict__ n_dev)
 {
     __shared__ uint8_t patch_all[4][SAD_MAX_WS * SAD_MAX_WS + 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= n) return;                                              // whole wavefront
+    const int item = blockIdx.y, il = blockIdx.x * 4 + wave;
+    if (il >= (n_dev ? n_dev[item] : n)) return;                     // whole wavefront
+    const int i = item * n + il;
     uint8_t *patch = patch_all[wave];
     const PyrLevelDesc L = PL.lv[level];
-    const uint8_t *iml = PL.base + L.img_roi, *imr = PR.base + PR.lv[level].img_roi;
+    const uint8_t *iml = PL.base + (long long)item * PL.item_stride + L.img_roi, *imr = PR.base + (long long)item * PR.item_stride + PR.lv[level].img_roi;
     const int pitch_l = L.img_pitch, pitch_r = PR.lv[level].img_pitch, w = L.w, h = L.h;
     const float x = pts[i].x, y = pts[i].y;
     float best_e = 255.f, best_c = -1.f;
@@ -139,10 +141,12 @@ __device__ __forceinline__ float sampson(const double *F, float lx, float ly, fl
 struct EpiParams { double F[9]; int rect; };
 
 __global__ __launch_bounds__(256) void k_epipolar_check(EpiParams E, KpCalib c, const float2 *__restrict__ lunpx, float2 *__restrict__ rkps,
-                                                        int n, float2 *__restrict__ runpx, float *__restrict__ epi_err, uint8_t *__restrict__ ok)
+                                                        int n, float2 *__restrict__ runpx, float *__restrict__ epi_err, uint8_t *__restrict__ ok,
+                                                        const int *__restrict__ n_dev)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int item = blockIdx.y, il = blockIdx.x * blockDim.x + threadIdx.x;
+    if (il >= (n_dev ? min(n, n_dev[item]) : n)) return;
+    const int i = item * n + il;
     const float2 l = lunpx[i];
     float2 rk = rkps[i];
     const float2 ru = kp_undistort_image_point(c, rk);
@@ -181,7 +185,7 @@ int ov2_line_min_sad(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
     memcpy(hs, pts_xy_h, 8 * (size_t)n);
     OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_line_min_sad, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, left->d, right->d, level, nwinsize, go_left ? 1 : 0,
-                       (const float2 *)ds, n, (float *)(ds + 8 * (size_t)n), (float *)(ds + 12 * (size_t)n));
+                       (const float2 *)ds, n, (float *)(ds + 8 * (size_t)n), (float *)(ds + 12 * (size_t)n), (const int *)nullptr);
     OV2_HIP_CHECK(hipGetLastError());
     OV2_HIP_CHECK(hipMemcpyAsync(hs + 8 * (size_t)n, ds + 8 * (size_t)n, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -214,7 +218,7 @@ int ov2_stereo_epipolar_check(ov2_ctx *ctx, int rect, const double Frl[9], int m
     memcpy(hs + o_r, rkps_xy_inout_h, 8 * N);
     OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, 16 * N, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_epipolar_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_l),
-                       (float2 *)(ds + o_r), n, (float2 *)(ds + o_u), (float *)(ds + o_e), ds + o_k);
+                       (float2 *)(ds + o_r), n, (float2 *)(ds + o_u), (float *)(ds + o_e), ds + o_k, (const int *)nullptr);
     OV2_HIP_CHECK(hipGetLastError());
     OV2_HIP_CHECK(hipMemcpyAsync(hs + o_r, ds + o_r, total - o_r, hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -272,7 +276,7 @@ int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
     const float *sad_d = nullptr;
     if (rect) {
         hipLaunchKernelGGL(k_line_min_sad, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, left->d, right->d, lvl, 7, 1,
-                           (const float2 *)(ds + o_t), n, (float *)(ds + o_s), (float *)(ds + o_l));
+                           (const float2 *)(ds + o_t), n, (float *)(ds + o_s), (float *)(ds + o_l), (const int *)nullptr);
         sad_d = (const float *)(ds + o_s);
     } else {
         // not rectified: no line search, every keypoint without a 3-D prior starts from its own position (:440-466): a prior
@@ -284,7 +288,7 @@ int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
                               (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr, sad_d, up, ctx->track_impl);
     if (rc != OV2_OK) return rc;
     hipLaunchKernelGGL(k_epipolar_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_u),
-                       (float2 *)(ds + o_o), n, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok);
+                       (float2 *)(ds + o_o), n, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok, (const int *)nullptr);
     OV2_HIP_CHECK(hipGetLastError());
     OV2_HIP_CHECK(hipMemcpyAsync(hs + o_o, ds + o_o, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipMemcpyAsync(hs + o_st, ds + o_st, 2 * N, hipMemcpyDeviceToHost, ctx->stream));
@@ -295,6 +299,80 @@ int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
         right_px_h[2 * i] = tracked ? ((const float *)(hs + o_o))[2 * i] : 0.f;
         right_px_h[2 * i + 1] = tracked ? ((const float *)(hs + o_o))[2 * i + 1] : 0.f;
     }
+    return OV2_OK;
+}
+
+// ov2_stereo_match for the keyframes of a lock-step batch (all sequences of a rank reach their keyframes together): items [0, n_items)
+// of two batch pyramids, n_max point slots per item, ONE enqueue and ONE synchronisation for all of them -- the same three kernels with
+// the grid extended by the item.  Per item the results are those of ov2_stereo_match on that item (tests/test_gpu_stereo.py).
+int ov2_stereo_match_batch(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int n_items, int nklt_win_size, int nklt_pyr_lvl, int max_iter,
+                           float eps, float nklt_err, float fmax_fbklt_dist, int rect, const double Frl[9], int model, const double K[4],
+                           const double *D, int nD, int n_max, const float *kps_px_h, const float *kps_unpx_h, const float *priors3d_h,
+                           const uint8_t *has_prior3d_h, const int *n_h, float *right_px_h, uint8_t *stereo_ok_h)
+{
+    OV2_REQUIRE(ctx && left && right && n_h, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(n_items >= 1 && n_items <= left->d.batch && n_items <= right->d.batch && n_max >= 1, OV2_EINVAL, "n_items / n_max out of range");
+    OV2_REQUIRE(kps_px_h && kps_unpx_h && right_px_h && stereo_ok_h, OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(has_prior3d_h == nullptr || priors3d_h != nullptr, OV2_EINVAL, "has_prior3d given without priors3d");
+    OV2_REQUIRE(rect || Frl, OV2_EINVAL, "Frl == NULL for a non-rectified pair");
+    int n_total = 0;
+    for (int b = 0; b < n_items; b++) { OV2_REQUIRE(n_h[b] >= 0 && n_h[b] <= n_max, OV2_EINVAL, "an item carries more keypoints than n_max slots"); n_total += n_h[b]; }
+    if (n_total == 0) return OV2_OK;
+    KpCalib c;
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int rc = ov2_kp_calib(model, K, D, nD, I3, c);
+    if (rc != OV2_OK) return rc;
+    EpiParams E;
+    for (int i = 0; i < 9; i++) E.F[i] = Frl ? Frl[i] : 0.;
+    E.rect = rect ? 1 : 0;
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rcw = ov2_pyr_wait_ready(ctx, left)) return rcw;
+    if (int rcw = ov2_pyr_wait_ready(ctx, right)) return rcw;
+    const int lvl = nklt_pyr_lvl > left->d.n_levels - 1 ? left->d.n_levels - 1 : (nklt_pyr_lvl < 0 ? 0 : nklt_pyr_lvl);
+    // layout (N = n_items * n_max slots): [kps 8N][unpx 8N][pri 8N][pts_top 8N][flags N][counts 4*items, 256-aligned] | [out 8N][runpx 8N][sadx 4N][l1 4N][err 4N][st N][ok N]
+    const size_t N = (size_t)n_items * n_max, o_k = 0, o_u = 8 * N, o_p = 16 * N, o_t = 24 * N, o_f = 32 * N, o_n = (33 * N + 255) & ~(size_t)255;
+    const size_t in_bytes = (o_n + 4 * (size_t)n_items + 255) & ~(size_t)255;
+    const size_t o_o = in_bytes, o_r = o_o + 8 * N, o_s = o_r + 8 * N, o_l = o_s + 4 * N, o_e = o_l + 4 * N, o_st = o_e + 4 * N, o_ok = o_st + N, total = o_ok + N;
+    rc = ctx->reserve_device(total);  if (rc) return rc;
+    rc = ctx->reserve_host(total);    if (rc) return rc;
+    uint8_t *hs = (uint8_t *)ctx->h_scratch, *ds = (uint8_t *)ctx->d_scratch;
+    const float up = (float)(1 << lvl), down = 1.f / up;                  // pow(2, nklt_pyr_lvl) and its inverse (:417-418)
+    for (int b = 0; b < n_items; b++) {
+        const size_t o = (size_t)b * n_max, n = (size_t)n_h[b];
+        ((int *)(hs + o_n))[b] = n_h[b];
+        memcpy(hs + o_k + 8 * o, kps_px_h + 2 * o, 8 * n);
+        memcpy(hs + o_u + 8 * o, kps_unpx_h + 2 * o, 8 * n);
+        for (size_t i = o; i < o + n; i++) {
+            const bool hp = has_prior3d_h && has_prior3d_h[i];
+            hs[o_f + i] = hp ? 1 : 0;
+            ((float *)(hs + o_p))[2 * i] = hp ? priors3d_h[2 * i] : kps_px_h[2 * i];
+            ((float *)(hs + o_p))[2 * i + 1] = hp ? priors3d_h[2 * i + 1] : kps_px_h[2 * i + 1];
+            ((float *)(hs + o_t))[2 * i] = kps_px_h[2 * i] * down;             // the keypoint on the coarsest level (:427)
+            ((float *)(hs + o_t))[2 * i + 1] = kps_px_h[2 * i + 1] * down;
+        }
+    }
+    OV2_HIP_CHECK(hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const int *n_d = (const int *)(ds + o_n);
+    if (rect) hipLaunchKernelGGL(k_line_min_sad, dim3((n_max + 3) / 4, n_items), dim3(256), 0, ctx->stream, left->d, right->d, lvl, 7, 1,
+                                 (const float2 *)(ds + o_t), n_max, (float *)(ds + o_s), (float *)(ds + o_l), n_d);
+    else OV2_HIP_CHECK(hipMemsetAsync(ds + o_s, 0xBF, 4 * N, ctx->stream));                       // "nothing found" (see ov2_stereo_match)
+    rc = ov2_launch_track_klt(ctx->stream, left, right, nklt_win_size, 1, lvl, max_iter, eps, nklt_err, fmax_fbklt_dist, n_max, n_d,
+                              (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr,
+                              (const float *)(ds + o_s), up, ctx->track_impl, n_items);
+    if (rc != OV2_OK) return rc;
+    hipLaunchKernelGGL(k_epipolar_check, dim3((n_max + 255) / 256, n_items), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_u),
+                       (float2 *)(ds + o_o), n_max, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok, n_d);
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_o, ds + o_o, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipMemcpyAsync(hs + o_st, ds + o_st, 2 * N, hipMemcpyDeviceToHost, ctx->stream));
+    OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < n_items; b++)
+        for (size_t i = (size_t)b * n_max; i < (size_t)b * n_max + (size_t)n_h[b]; i++) {
+            const bool tracked = (hs[o_st + i] & 1) != 0;
+            stereo_ok_h[i] = (tracked && hs[o_ok + i]) ? 1 : 0;
+            right_px_h[2 * i] = tracked ? ((const float *)(hs + o_o))[2 * i] : 0.f;
+            right_px_h[2 * i + 1] = tracked ? ((const float *)(hs + o_o))[2 * i + 1] : 0.f;
+        }
     return OV2_OK;
 }
 

@@ -24,7 +24,8 @@
 
 int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d, int items = 1);
 
-#define BT_SETS 4       // pyramid sets in rotation: cur, prev, the one being prepared for the next frame, one of slack for the mappers
+#define BT_SETS 6       // pyramid sets in rotation: cur, prev, the one being prepared for the next frame, three of slack for the mapper
+                        // context (a keyframe's pyramids outlive it by BT_SETS - 1 steps: the keyframe period of the shipped parameter files)
 #define BT_IMG_SETS 3   // staging sets: frame f (read by its pre-processing), f + 1 (arriving), f + 2 (being filled by the host)
 
 struct ov2_btracker {
@@ -34,7 +35,7 @@ struct ov2_btracker {
     // pyramid sets in rotation (cur_pyr_, prev_pyr_, ...): a keyframe's pyramids stay valid for BT_SETS - 1 more steps (BT_SETS - 2
     // when the next frame is prepared ahead), so the mapper contexts that stereo-match it rarely hold the SLAM thread up (with two
     // sets 12 % of the lock-step wall clock was that wait)
-    ov2_pyr *pyr[BT_SETS] = {nullptr, nullptr, nullptr, nullptr};
+    ov2_pyr *pyr[BT_SETS] = {};
     std::vector<ov2_pyr *> view[BT_SETS];    // batch-1 aliases of the items (stereo matching, the p3p retry, single-item detection)
     int cur = 0;                       // index of cur_pyr_ (= (frames - 1) % BT_SETS); prev_pyr_ = pyr[(cur + BT_SETS - 1) % BT_SETS]
     int prev() const { return (cur + BT_SETS - 1) % BT_SETS; }

@@ -132,6 +132,17 @@ class Pyramid:
         L.check(self.lib.ov2_pyr_build_clahe_h(self.ctx.h, self.h_pyr, _ptr(img), self.w, float(clip_limit), int(tiles_x), int(tiles_y)))
         return self
 
+    def build_clahe_batch(self, imgs, clip_limit, tiles_x, tiles_y):
+        """preprocessImage of len(imgs) host images into items [0, len(imgs)) of this batch pyramid in one enqueue (ov2_pyr_build_clahe_hb);
+        clip_limit < 0: no CLAHE"""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+        for im in imgs:
+            assert im.shape == (self.h, self.w)
+        self._keep = imgs
+        ptrs = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+        L.check(self.lib.ov2_pyr_build_clahe_hb(self.ctx.h, self.h_pyr, len(imgs), ptrs, self.w, float(clip_limit), int(tiles_x), int(tiles_y)))
+        return self
+
     def build_clahe_from_device(self, dev_ptr, clip_limit, tiles_x, tiles_y, stride=None, batch_stride=None):
         """preprocessImage: CLAHE written straight into level 0, then the coarser levels (one call)."""
         stride = stride or self.w
@@ -444,6 +455,13 @@ class LockstepTracker:
         L.check(self.lib.ov2_btracker_detect_grid_fast(self.h_trk, int(n_active), int(ncellsize), _ptr(cur), _ptr(nc), _ptr(t), int(mask_mode),
                                                        1 if subpix else 0, _ptr(out), cap, _ptr(on)))
         return [out[b, :on[b]].copy() for b in range(n_active)]
+
+    @property
+    def cur_pyr(self):
+        """the current frame's pyramids, all items (e.g. `left` of stereo.stereo_match_batch_arrays)"""
+        v = _PyrView(self.ctx, C.c_void_p(self.lib.ov2_btracker_cur_pyr(self.h_trk)), self.w, self.h, self.win)
+        v.batch = self.batch
+        return v
 
     def cur_item(self, item):
         return _PyrView(self.ctx, C.c_void_p(self.lib.ov2_btracker_cur_item(self.h_trk, int(item))), self.w, self.h, self.win)

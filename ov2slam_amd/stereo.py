@@ -88,6 +88,27 @@ def stereo_match_arrays(tracker, leftpyr, rightpyr, kps_px, kps_unpx, priors3d_x
     return ok.astype(bool), right
 
 
+def stereo_match_batch_arrays(tracker, leftpyr, rightpyr, n_items, n_max, kps_px, kps_unpx, priors3d_xy, has_prior3d, n, right_calib, *, rect,
+                              Frl=None, nklt_win_size=9, nklt_pyr_lvl=3, nklt_err=30.0, fmax_fbklt_dist=0.5):
+    """ov2_stereo_match_batch: items [0, n_items) of two batch pyramids in one call.  Arrays are (batch, n_max, ...) with n[b] valid rows.
+    Returns (stereo_ok (batch, n_max) bool, right_px (batch, n_max, 2) float32); rows beyond n[b] are zero."""
+    ctx = tracker.ctx
+    kps_px = np.ascontiguousarray(kps_px, dtype=np.float32).reshape(-1, n_max, 2)
+    kps_unpx = np.ascontiguousarray(kps_unpx, dtype=np.float32).reshape(-1, n_max, 2)
+    p3 = np.ascontiguousarray(priors3d_xy, dtype=np.float32).reshape(-1, n_max, 2)
+    hp = np.ascontiguousarray(has_prior3d, dtype=np.uint8).reshape(-1, n_max)
+    nn = np.ascontiguousarray(n, np.int32)
+    right = np.zeros(kps_px.shape, np.float32); ok = np.zeros(hp.shape, np.uint8)
+    F = None if Frl is None else np.ascontiguousarray(Frl, dtype=np.float64).reshape(9)
+    D = right_calib.D
+    L.check(ctx.lib.ov2_stereo_match_batch(ctx.h, leftpyr.h_pyr, rightpyr.h_pyr, int(n_items), int(nklt_win_size), int(nklt_pyr_lvl), int(tracker.nmax_iter),
+                                           float(tracker.fmax_px_precision), float(nklt_err), float(fmax_fbklt_dist), int(bool(rect)),
+                                           _ptr(F) if F is not None else None, right_calib.model, _ptr(right_calib.K),
+                                           _ptr(D) if D is not None else None, 0 if D is None else len(D), int(n_max), _ptr(kps_px), _ptr(kps_unpx),
+                                           _ptr(p3), _ptr(hp), _ptr(nn), _ptr(right), _ptr(ok)))
+    return ok.astype(bool), right
+
+
 def stereo_matching_fused(tracker, leftpyr, rightpyr, kps_px, kps_unpx, right_calib, *, rect, Frl=None, nklt_win_size=9,
                           nklt_pyr_lvl=3, nklt_err=30.0, fmax_fbklt_dist=0.5, priors3d=None):
     """ov2_stereo_match: the same flow as stereo_matching() in ONE enqueue and ONE synchronisation (SAD priors, both

@@ -229,6 +229,37 @@ def test_item_view_in_stereo_matching(gpu_ctx):
         ok2, r2 = stereo.stereo_match_arrays(ftrk, pl, pr, kps, unpx, p3, hp, cal, rect=True)
         assert np.array_equal(ok1, ok2) and np.array_equal(_bits(r1), _bits(r2)) and ok1.mean() > 0.5
         pl.close(); pr.close()
+    # the whole batch in ONE call (ov2_pyr_build_clahe_hb + ov2_stereo_match_batch: the mapper of a lock-step rank): per item the
+    # results of the single-item entry point, for both LK kernels, with different counts per item and an item that has no keypoint
+    n_max = 400
+    per = []
+    for b in range(batch):
+        kps = synth.grid_keypoints(w, h, 35, rng)[:273 - 31 * b]
+        if b == 1:
+            kps = kps[:0]
+        unpx, _ = cal.computeKeypoints(kps) if len(kps) else (kps.copy(), None)
+        hp = (rng.uniform(size=len(kps)) < 0.5).astype(np.uint8)
+        p3 = kps.copy(); p3[:, 0] -= 20.0; p3 += rng.normal(0, 1.0, p3.shape).astype(np.float32)
+        per.append((kps, unpx, p3, hp))
+    K = np.zeros((batch, n_max, 2), np.float32); U = K.copy(); P = K.copy(); H = np.zeros((batch, n_max), np.uint8); nn = np.zeros(batch, np.int32)
+    for b, (kps, unpx, p3, hp) in enumerate(per):
+        m = len(kps); nn[b] = m; K[b, :m] = kps; U[b, :m] = unpx; P[b, :m] = p3; H[b, :m] = hp
+    prb = ov2slam_amd.Pyramid(ctxB, w, h, 9, 3, batch=batch)
+    for impl in (L.OV2_TRACK_IMPL_WAVE, L.OV2_TRACK_IMPL_ROW):
+        with ctxB.options(track_impl=impl):
+            prb.build_clahe_batch(rights, CLIP, w // 50, h // 50)
+            okb, rb = stereo.stereo_match_batch_arrays(ftrk, bt.cur_pyr, prb, batch, n_max, K, U, P, H, nn, cal, rect=True)
+            for b, (kps, unpx, p3, hp) in enumerate(per):
+                if not len(kps):
+                    continue
+                pr = ov2slam_amd.Pyramid(ctxB, w, h, 9, 3).build_clahe(rights[b], CLIP, w // 50, h // 50)
+                ok1, r1 = stereo.stereo_match_arrays(ftrk, bt.cur_item(b), pr, kps, unpx, p3, hp, cal, rect=True)
+                assert np.array_equal(okb[b, :len(kps)], ok1) and np.array_equal(_bits(rb[b, :len(kps)]), _bits(r1)), "item %d" % b
+                gi, _ = prb.download(2, b=b)
+                si, _ = pr.download(2)
+                assert np.array_equal(gi, si)
+                pr.close()
+    prb.close()
     view = bt.cur_item(0)
     with pytest.raises(ov2slam_amd.Ov2Error):
         L.check(gpu_ctx.lib.ov2_pyr_build_h(gpu_ctx.h, view.h_pyr, lefts[0].ctypes.data, w, 0))

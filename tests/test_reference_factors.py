@@ -1,0 +1,205 @@
+"""The oracle's (and the device's) reprojection factors against THE REFERENCE'S OWN CODE: /root/reference/src/ceres_parametrization.cpp is
+compiled from where it lies, unchanged, against stand-in Eigen / Sophus / Ceres headers (oracle/ref/standin: the real libraries are not
+in this image) into oracle/_ref/libref_factors.so (recipe: oracle/ref/Makefile).  Every Evaluate() of namespace DirectLeftSE3
+(src/ceres_parametrization.cpp:104-712) and SE3LeftParameterization (se3left_parametrization.hpp:39-73) is then called on random inputs
+and compared with oracle/ba.c / oracle/xyz_ba.c / oracle/struct_ba.c -- residuals, chi2err_, isdepthpositive_, every Jacobian block.
+
+Tolerance 1e-11 relative: the stand-in evaluates the reference's expressions with plain loops, not with Eigen's evaluation order, so
+agreement is to rounding, not bit for bit.  What this pins is the reference's FORMULAS (signs, frames, which block gets which
+derivative) without anybody reading them.  The library is built here (where /root/reference exists) and travels to the GPU box."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_factors.so")
+RTOL = 1e-11
+
+SIZES = {0: (4, 7, 7, 1), 1: (4, 4, 7, 7, 7, 1), 2: (4, 4, 7, 1), 3: (7,), 4: (4, 7, 3), 5: (4, 7, 7, 3)}
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "ref")])
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref/libref_factors.so is absent and /root/reference is not here to build it from")
+    lib = C.CDLL(REF_SO)
+    lib.ref_invdepth_block.restype = C.c_double
+    lib.ref_invdepth_block.argtypes = [C.c_double]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ref_eval(lib, ftype, params, uv, anch_uv=(0., 0.), sigma=1.0, K=(1., 1., 0., 0.), xyz=(0., 0., 1.), want_jac=True):
+    """-> (r (2,), [J_block (2, size)], chi2, depthpos) from the reference's Evaluate"""
+    params = [np.ascontiguousarray(p, np.float64) for p in params]
+    assert tuple(len(p) for p in params) == SIZES[ftype]
+    pp = (C.c_void_p * len(params))(*[p.ctypes.data for p in params])
+    J = [np.full((2, len(p)), np.nan) for p in params]
+    jp = (C.c_void_p * len(params))(*[j.ctypes.data for j in J])
+    r = np.zeros(2); chi2 = C.c_double(0); dp = C.c_int(0)
+    uv = np.ascontiguousarray(uv, np.float64); auv = np.ascontiguousarray(anch_uv, np.float64)
+    Kk = np.ascontiguousarray(K, np.float64); X = np.ascontiguousarray(xyz, np.float64)
+    rc = lib.ref_factor_eval(int(ftype), pp, _p(uv), _p(auv), C.c_double(sigma), _p(Kk), _p(X), _p(r), jp if want_jac else None, C.byref(chi2), C.byref(dp))
+    assert rc == 0
+    return r, J, chi2.value, bool(dp.value)
+
+
+def _rand_pose(rng, t_scale=1.0, rot=0.4):
+    w = rng.normal(0, rot, 3)
+    th = np.linalg.norm(w)
+    q = np.concatenate([np.sin(th / 2) * w / th, [np.cos(th / 2)]])
+    return np.concatenate([rng.normal(0, t_scale, 3), q])
+
+
+def _close(a, b, scale=None):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = max(1.0, float(np.abs(b).max()) if b.size else 1.0) if scale is None else scale
+    return float(np.abs(a - b).max()) <= RTOL * s
+
+
+CAL_L = np.array([458.654, 457.296, 367.215, 248.375])
+CAL_R = np.array([457.587, 456.134, 379.999, 255.238])
+
+
+def _case(rng):
+    anchor, obs = _rand_pose(rng), _rand_pose(rng)
+    T_rl = _rand_pose(rng, 0.1, 0.05); T_rl[0] -= 0.11
+    lam = 1.0 / rng.uniform(0.6, 15.0)
+    if rng.uniform() < 0.1:
+        lam = -lam                                                   # behind the camera: isdepthpositive_ false somewhere
+    auv = np.array([rng.uniform(0, 752), rng.uniform(0, 480)])
+    uv = np.array([rng.uniform(0, 752), rng.uniform(0, 480)])
+    return anchor, obs, T_rl, lam, auv, uv, float(rng.choice([1.0, 2.0, 4.0]))
+
+
+def test_inverse_depth_factors_match_the_reference_source(ref, oracle):
+    rng = np.random.default_rng(11)
+    n_neg = 0
+    for _ in range(300):
+        anchor, obs, T_rl, lam, auv, uv, sigma = _case(rng)
+        lm = np.array([lam])
+        # ---- LEFT: ReprojectionErrorKSE3AnchInvDepth {calib, anchor, obs, lambda}   (:361-473)
+        r, J, chi2, dp = ref_eval(ref, 0, [CAL_L, anchor, obs, lm], uv, auv, sigma)
+        o_r, o_Ja, o_Jo, o_Jl, o_chi2, o_dp = oracle.ba_residual(0, CAL_L, CAL_R, T_rl, anchor, obs, lam, auv, uv, sigma)
+        assert _close(o_r, r) and _close(o_chi2, chi2, max(1.0, chi2)) and o_dp == dp
+        assert _close(o_Ja, J[1][:, :6]) and _close(o_Jo, J[2][:, :6]) and _close(o_Jl, J[3][:, 0])
+        assert np.all(J[1][:, 6] == 0) and np.all(J[2][:, 6] == 0) and np.all(J[0] == 0)          # 7th column / calib block: zero (TODO in the reference)
+        n_neg += not dp
+        # ---- RIGHT: ReprojectionErrorRightCamKSE3AnchInvDepth {calib_l, calib_r, anchor, obs, T_rl, lambda}   (:579-712)
+        r, J, chi2, dp = ref_eval(ref, 1, [CAL_L, CAL_R, anchor, obs, T_rl, lm], uv, auv, sigma)
+        o_r, o_Ja, o_Jo, o_Jl, o_chi2, o_dp = oracle.ba_residual(1, CAL_L, CAL_R, T_rl, anchor, obs, lam, auv, uv, sigma)
+        assert _close(o_r, r) and _close(o_chi2, chi2, max(1.0, chi2)) and o_dp == dp
+        assert _close(o_Ja, J[2][:, :6]) and _close(o_Jo, J[3][:, :6]) and _close(o_Jl, J[5][:, 0])
+        assert np.all(J[4] == 0) and np.all(J[0] == 0)                                               # extrinsic / left calib: zero
+        # ---- RIGHT_ANCH: ReprojectionErrorRightAnchCamKSE3AnchInvDepth {calib_l, calib_r, T_rl, lambda}   (:476-577)
+        r, J, chi2, dp = ref_eval(ref, 2, [CAL_L, CAL_R, T_rl, lm], uv, auv, sigma)
+        o_r, o_Ja, o_Jo, o_Jl, o_chi2, o_dp = oracle.ba_residual(2, CAL_L, CAL_R, T_rl, anchor, obs, lam, auv, uv, sigma)
+        assert _close(o_r, r) and _close(o_chi2, chi2, max(1.0, chi2)) and o_dp == dp and _close(o_Jl, J[3][:, 0])
+        assert np.all(o_Ja == 0) and np.all(J[2] == 0)                                               # no pose enters this factor
+    assert n_neg > 5
+
+
+def test_xyz_and_pnp_factors_match_the_reference_source(ref, oracle):
+    rng = np.random.default_rng(12)
+    for _ in range(300):
+        _, pose, T_rl, _, _, uv, sigma = _case(rng)
+        X = rng.normal(0, 3.0, 3)
+        # ---- ReprojectionErrorKSE3XYZ {calib, pose, X}   (:107-195)
+        r, J, chi2, dp = ref_eval(ref, 4, [CAL_L, pose, X], uv, sigma=sigma)
+        o_r, o_Jp, o_Jx, o_chi2, o_dp = oracle.xyzba_residual(0, CAL_L, CAL_R, T_rl, pose, X, uv, sigma)
+        assert _close(o_r, r) and _close(o_chi2, chi2, max(1.0, chi2)) and o_dp == dp
+        assert _close(o_Jp, J[1][:, :6]) and _close(o_Jx, J[2]) and np.all(J[1][:, 6] == 0)
+        s_r, s_J, s_chi2, s_dp = oracle.xyz_residual(0, CAL_L, CAL_R, T_rl, pose, X, uv, sigma)     # structureOnlyBA's restatement of the same factor
+        assert _close(s_r, r) and _close(s_J, J[2]) and s_dp == dp
+        # ---- ReprojectionErrorSE3 {pose}, K and the world point in the constructor (ceresPnP)   (:301-358): the same projection
+        rp, Jp, chi2p, dpp = ref_eval(ref, 3, [pose], uv, sigma=sigma, K=CAL_L, xyz=X)
+        assert _close(o_r, rp) and _close(o_Jp, Jp[0][:, :6]) and dpp == o_dp and np.all(Jp[0][:, 6] == 0)
+        # ---- ReprojectionErrorRightCamKSE3XYZ {calib_r, pose, T_rl, X}   (:198-298)
+        r, J, chi2, dp = ref_eval(ref, 5, [CAL_R, pose, T_rl, X], uv, sigma=sigma)
+        o_r, o_Jp, o_Jx, o_chi2, o_dp = oracle.xyzba_residual(1, CAL_L, CAL_R, T_rl, pose, X, uv, sigma)
+        assert _close(o_r, r) and _close(o_chi2, chi2, max(1.0, chi2)) and o_dp == dp
+        assert _close(o_Jp, J[1][:, :6]) and _close(o_Jx, J[3]) and np.all(J[2] == 0)
+        s_r, s_J, s_chi2, s_dp = oracle.xyz_residual(1, CAL_L, CAL_R, T_rl, pose, X, uv, sigma)
+        assert _close(s_r, r) and _close(s_J, J[3]) and s_dp == dp
+
+
+def test_se3_left_parameterization_matches_the_reference_source(ref, oracle):
+    rng = np.random.default_rng(13)
+    gs, ls = C.c_int(0), C.c_int(0)
+    ref.ref_se3_sizes(C.byref(gs), C.byref(ls))
+    assert (gs.value, ls.value) == (7, 6)
+    for k in range(300):
+        x = _rand_pose(rng)
+        d = rng.normal(0, [0.05, 0.3, 1e-6, 1e-12][k % 4], 6)          # down to Sophus' small-angle branch (theta^2 < 1e-20)
+        if k % 7 == 0:
+            d[3:] = 0.0
+        out = np.zeros(7)
+        assert ref.ref_se3_plus(_p(x), _p(d), _p(out)) == 0
+        o = oracle.se3_left_plus(x, d)
+        assert _close(o, out), (k, o, out)
+        J = np.full(42, np.nan)
+        assert ref.ref_se3_plus_jacobian(_p(x), _p(J)) == 0
+        assert np.array_equal(J.reshape(7, 6), np.vstack([np.eye(6), np.zeros((1, 6))]))             # Jacobian of the local map: [I6; 0]
+    # the parameter-block holders: [tx ty tz qx qy qz qw], inverse depth = 1 / depth
+    x = _rand_pose(rng)
+    vals, back = np.zeros(7), np.zeros(7)
+    ref.ref_pose_block_roundtrip(_p(x), _p(vals), _p(back))
+    assert _close(vals, x) and _close(back, x)
+    assert ref.ref_invdepth_block(4.0) == 0.25
+
+
+def test_reference_jacobians_are_the_derivatives_of_the_reference_residuals(ref):
+    """independent of the oracle: central differences of the reference's own residual through the reference's own Plus"""
+    rng = np.random.default_rng(14)
+    h = 1e-6
+    for _ in range(40):
+        anchor, obs, T_rl, lam, auv, uv, sigma = _case(rng)
+        lam = abs(lam)
+        blocks = [CAL_L, CAL_R, anchor, obs, T_rl, np.array([lam])]
+        r0, J, _, _ = ref_eval(ref, 1, blocks, uv, auv, sigma)
+        if np.abs(r0).max() > 1e5:
+            continue
+        for bi in (2, 3):                                                      # the two pose blocks
+            num = np.zeros((2, 6))
+            for k in range(6):
+                d = np.zeros(6); d[k] = h
+                xp, xm = np.zeros(7), np.zeros(7)
+                ref.ref_se3_plus(_p(np.ascontiguousarray(blocks[bi])), _p(d), _p(xp)); ref.ref_se3_plus(_p(np.ascontiguousarray(blocks[bi])), _p(-d), _p(xm))
+                bp = list(blocks); bp[bi] = xp; bm = list(blocks); bm[bi] = xm
+                num[:, k] = (ref_eval(ref, 1, bp, uv, auv, sigma, want_jac=False)[0] - ref_eval(ref, 1, bm, uv, auv, sigma, want_jac=False)[0]) / (2 * h)
+            assert np.abs(num - J[bi][:, :6]).max() <= 2e-4 * max(1.0, np.abs(num).max()), (bi, num, J[bi])
+        bp = list(blocks); bp[5] = np.array([lam * (1 + h)]); bm = list(blocks); bm[5] = np.array([lam * (1 - h)])
+        num = (ref_eval(ref, 1, bp, uv, auv, sigma, want_jac=False)[0] - ref_eval(ref, 1, bm, uv, auv, sigma, want_jac=False)[0]) / (2 * h * lam)
+        assert np.abs(num - J[5][:, 0]).max() <= 2e-4 * max(1.0, np.abs(num).max())
+
+
+@pytest.mark.gpu
+def test_device_residuals_match_the_reference_source(ref, gpu_ctx):
+    """The DEVICE's evaluation at the initial point (ov2_ba_solve with a zero iteration budget returns the chi2err_ / isdepthpositive_
+    of every residual block) against the reference's Evaluate on the same blocks -- no oracle in between."""
+    from ov2slam_amd import optimizer, synth
+    pb = synth.make_ba_problem(12, 500, 8, stereo=True, seed=21)
+    o = optimizer.default_options(gpu_ctx.lib)
+    o.max_iter = 0
+    g = optimizer.solve(gpu_ctx, pb, o)
+    poses = np.asarray(pb["poses"], np.float64).reshape(-1, 7)
+    n = 0
+    for i in range(0, int(pb["n_res"]), 3):
+        t, kf, lm = int(pb["res_type"][i]), int(pb["res_kf"][i]), int(pb["res_lm"][i])
+        anchor = poses[int(pb["lm_anchor_kf"][lm])]; lam = np.array([float(pb["invdepth"][lm])])
+        auv = np.asarray(pb["lm_anchor_uv"], np.float64).reshape(-1, 2)[lm]; uv = np.asarray(pb["res_uv"], np.float64).reshape(-1, 2)[i]
+        sig = float(pb["res_sigma"][i]); cl, cr, T = np.asarray(pb["calib_l"], np.float64), np.asarray(pb["calib_r"], np.float64), np.asarray(pb["T_rl"], np.float64)
+        blocks = {0: [cl, anchor, poses[kf], lam], 1: [cl, cr, anchor, poses[kf], T, lam], 2: [cl, cr, T, lam]}[t]
+        _, _, chi2, dp = ref_eval(ref, t, blocks, uv, auv, sig, want_jac=False)
+        assert abs(g["chi2"][i] - chi2) <= 1e-10 * max(1.0, chi2), (i, t, g["chi2"][i], chi2)
+        assert bool(g["depthpos"][i]) == dp
+        n += 1
+    assert n > 3000

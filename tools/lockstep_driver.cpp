@@ -7,10 +7,11 @@
 // CUs ~5 % busy (profiles/r4_stream_concurrency.txt).  Here ONE SLAM thread steps all sequences of the rank through the lock-step
 // tracker (ov2_btracker_*, csrc/trackb.hip): per step one frame upload, one CLAHE + pyramid enqueue, one fused kltTracking launch
 // and one computeKeypoint launch cover every sequence; at the common keyframes one batched detectSingleScale call; the keyframes
-// then go to the sequences' own mapper threads (right-image CLAHE + pyramid + ov2_stereo_match on an item view of the tracker's
-// pyramid) and estimator threads (ov2_local_ba, newest keyframe only like src/estimator.cpp:195-205, or every keyframe with
-// policy "all") -- one context each, exactly as in stream_driver.  Sequences that end drop out of the batch (they are ordered
-// longest first, so the active ones are always items [0, n_active)).
+// then go to the rank's mapper thread -- ONE batched right-image CLAHE + pyramid (ov2_pyr_build_clahe_hb) and ONE
+// ov2_stereo_match_batch on the tracker's pyramids for all sequences -- and from there to the sequences' own estimator threads
+// (ov2_local_ba, newest keyframe only like src/estimator.cpp:195-205, or every keyframe with policy "all"; one context each, exactly
+// as in stream_driver: the windows are independent problems).  Sequences that end drop out of the batch (they are ordered longest
+// first, so the active ones are always items [0, n_active)).
 // Image "decoding" (here: a copy of the synthetic view into the tracker's pinned slot) runs on loader threads one step ahead,
 // the frames' H2D on the tracker's copy stream beside the previous step's kernels.
 // Per-sequence inputs (frames, keypoints, priors, random streams) are those of stream_driver, so the per-sequence results must be
@@ -35,14 +36,21 @@ struct Seq {
     long frames = 0, tracked = 0, attempted = 0, err_n = 0, keyframes = 0;
     double err_sq = 0;
     Fnv tdig, ddig, sdig;
-    // mapper / estimator threads of the sequence (one context each)
-    ov2_ctx *ctxB = nullptr, *ctxC = nullptr; ov2_pyr *pyrR = nullptr;
-    Queue<std::unique_ptr<KfJob>> map_q; Queue<int> ba_q;
-    std::mutex done_m; std::condition_variable done_cv; int mapper_done_kf = -1;
+    // estimator thread of the sequence (its own context)
+    ov2_ctx *ctxC = nullptr;
+    Queue<int> ba_q;
     long stereo_kfs = 0, stereo_ok = 0, stereo_kps = 0, ba_solves = 0, ba_skipped = 0, ba_iterations = 0;
     double mapper_busy = 0, ba_busy = 0, ba_device_ms = 0;
-    std::thread mapper, estimator;
+    std::thread estimator;
     double t_last_frame = 0, t_drained = 0;
+};
+
+// a keyframe step of the whole batch for the rank's mapper thread
+struct KfBatch {
+    int f, na;
+    const ov2_pyr *left;                             // the tracker's pyramids of frame f (all items)
+    std::vector<const uint8_t *> right_img;
+    std::vector<float> kps, unpx, p3; std::vector<uint8_t> hp; std::vector<int> n;     // n_max slots per item
 };
 
 // loader threads: "decode" frame f of every active sequence into the tracker's pinned slots of set f % 3
@@ -95,30 +103,43 @@ int main(int argc, char **argv)
     (void)ov2_btracker_image_buffer(trk, 0, 0, &pitch);
     const int sets = ov2_btracker_pyramid_sets(trk);            // step f overwrites the pyramids of frame f - sets
 
-    // ---- per-sequence mapper / estimator threads (same bodies as stream_driver) ---------------------------------------
+    // ---- the rank's mapper thread (one batched job per keyframe step) and the per-sequence estimator threads -------------
+    ov2_ctx *ctxB;
+    CK(ov2_ctx_create_with_priority(device, use_prio ? 1 : 0, &ctxB));
+    ov2_pyr *pyrR;
+    CK(ov2_pyr_create(ctxB, w, h, 9, 3, N, &pyrR));
+    Queue<std::unique_ptr<KfBatch>> map_q;
+    std::mutex done_m; std::condition_variable done_cv; int mapper_done_kf = -1;
+    double mapper_busy_total = 0;
+    std::thread mapper([&] {
+        std::unique_ptr<KfBatch> j;
+        std::vector<float> right(2 * (size_t)N * NM); std::vector<uint8_t> ok((size_t)N * NM);
+        while (map_q.pop(j)) {
+            const double t0 = now();
+            CK(ov2_pyr_build_clahe_hb(ctxB, pyrR, j->na, j->right_img.data(), w, 3.0, w / 50, h / 50));                  // asynchronous
+            CK(ov2_stereo_match_batch(ctxB, j->left, pyrR, j->na, 9, 3, 30, 0.01f, 30.f, 0.5f, 1, nullptr, OV2_CAM_PINHOLE, K, nullptr, 0, NM,
+                                      j->kps.data(), j->unpx.data(), j->p3.data(), j->hp.data(), j->n.data(), right.data(), ok.data()));
+            const double dt = now() - t0;
+            mapper_busy_total += dt;
+            { std::lock_guard<std::mutex> l(done_m); mapper_done_kf = j->f; }
+            done_cv.notify_all();
+            for (int b = 0; b < j->na; b++) {
+                Seq &s = *S[(size_t)b];
+                const int n = j->n[(size_t)b];
+                const size_t o = (size_t)b * NM;
+                s.mapper_busy += dt / j->na;
+                s.sdig.val(j->f); s.sdig.val(n); s.sdig.add(&right[2 * o], 8 * (size_t)n); s.sdig.add(&ok[o], (size_t)n);
+                s.stereo_kfs++; s.stereo_kps += n;
+                for (int i = 0; i < n; i++) s.stereo_ok += ok[o + i];
+                if (!s.C.ba.empty()) s.ba_q.push(j->f);
+                if (j->f + kf_every > s.C.n_frames - 1) s.ba_q.close();                // the sequence's last keyframe
+            }
+        }
+        for (auto &s : S) s->ba_q.close();
+    });
     for (auto &sp : S) {
         Seq *s = sp.get();
-        CK(ov2_ctx_create_with_priority(device, 0, &s->ctxB)); CK(ov2_ctx_create_with_priority(device, use_prio ? -1 : 0, &s->ctxC));
-        CK(ov2_pyr_create(s->ctxB, w, h, 9, 3, 1, &s->pyrR));
-        s->mapper = std::thread([s, w, h, &K] {
-            std::unique_ptr<KfJob> j;
-            while (s->map_q.pop(j)) {
-                const double t0 = now();
-                const int n = (int)j->hp.size();
-                CK(ov2_pyr_build_clahe_h(s->ctxB, s->pyrR, j->right_img, w, 3.0, w / 50, h / 50));                      // asynchronous
-                std::vector<float> right(2 * (size_t)n); std::vector<uint8_t> ok(n);
-                CK(ov2_stereo_match(s->ctxB, j->left, s->pyrR, 9, 3, 30, 0.01f, 30.f, 0.5f, 1, nullptr, OV2_CAM_PINHOLE, K, nullptr, 0, j->kps.data(),
-                                    j->unpx.data(), j->p3.data(), j->hp.data(), n, right.data(), ok.data()));
-                s->mapper_busy += now() - t0;
-                s->sdig.val(j->f); s->sdig.val(n); s->sdig.add(right.data(), 8 * (size_t)n); s->sdig.add(ok.data(), (size_t)n);
-                { std::lock_guard<std::mutex> l(s->done_m); s->mapper_done_kf = j->f; }
-                s->done_cv.notify_all();
-                s->stereo_kfs++; s->stereo_kps += n;
-                for (int i = 0; i < n; i++) s->stereo_ok += ok[i];
-                if (!s->C.ba.empty()) s->ba_q.push(j->f);
-            }
-            s->ba_q.close();
-        });
+        CK(ov2_ctx_create_with_priority(device, use_prio ? -1 : 0, &s->ctxC));
         s->estimator = std::thread([s, ba_all] {
             int f, nsolve = 0;
             while (s->ba_q.pop(f)) {
@@ -206,20 +227,25 @@ int main(int argc, char **argv)
         tl = now();
         if (total) CK(ov2_compute_keypoints(ctxA, OV2_CAM_PINHOLE, K, nullptr, 0, iK, all.data(), (int)total, un.data(), nullptr));
         lib_s += now() - tl;
+        auto j = std::make_unique<KfBatch>();
+        j->f = f; j->na = na; j->left = ov2_btracker_cur_pyr(trk);
+        j->right_img.resize((size_t)na); j->n.resize((size_t)na);
+        j->kps.resize(2 * (size_t)na * NM); j->unpx.resize(2 * (size_t)na * NM); j->p3.resize(2 * (size_t)na * NM); j->hp.resize((size_t)na * NM);
         o = 0;
         for (int b = 0; b < na; b++) {
             Seq &s = *S[(size_t)b];
             const int n = (int)s.age.size();
-            auto j = std::make_unique<KfJob>();
-            j->f = f; j->left = ov2_btracker_cur_item(trk, b); j->right_img = s.C.right[(size_t)view_index(s.C, f)].data();
-            j->kps = s.kps; j->unpx.assign(un.begin() + 2 * o, un.begin() + 2 * (o + n)); j->p3.resize(2 * (size_t)n); j->hp.resize(n);
+            const size_t ob = (size_t)b * NM;
+            j->n[(size_t)b] = n;
+            j->right_img[(size_t)b] = s.C.right[(size_t)view_index(s.C, f)].data();
+            if (n) { memcpy(&j->kps[2 * ob], s.kps.data(), 8 * (size_t)n); memcpy(&j->unpx[2 * ob], &un[2 * o], 8 * (size_t)n); }
             for (int i = 0; i < n; i++) {
-                j->hp[i] = s.age[i] > 0;
-                j->p3[2 * i] = s.kps[2 * i] - (float)s.C.disparity + s.gauss(s.rng); j->p3[2 * i + 1] = s.kps[2 * i + 1] + s.gauss(s.rng);
+                j->hp[ob + i] = s.age[i] > 0;
+                j->p3[2 * (ob + i)] = s.kps[2 * i] - (float)s.C.disparity + s.gauss(s.rng); j->p3[2 * (ob + i) + 1] = s.kps[2 * i + 1] + s.gauss(s.rng);
             }
             o += (size_t)n;
-            s.map_q.push(std::move(j));
         }
+        map_q.push(std::move(j));
     };
 
     // Pipeline (ov2_btracker_upload / _prepare / _track_frame): while frame f is tracked, frame f + 1 is pre-processed on the tracker's
@@ -228,11 +254,7 @@ int main(int argc, char **argv)
     auto wait_mappers = [&](int g) {
         if (g < 0 || g % kf_every != 0) return;
         const double tw = now();
-        for (int b = 0; b < n_active_at(g); b++) {
-            Seq &s = *S[(size_t)b];
-            std::unique_lock<std::mutex> l(s.done_m);
-            s.done_cv.wait(l, [&] { return s.mapper_done_kf >= g; });
-        }
+        { std::unique_lock<std::mutex> l(done_m); done_cv.wait(l, [&] { return mapper_done_kf >= g; }); }
         wait_mapper += now() - tw;
     };
     for (int f = 0; f < 3 && f < F; f++) { load_kick(f); load_wait(); }                 // the three staging sets start full
@@ -315,11 +337,11 @@ int main(int argc, char **argv)
             if (f == s.C.n_frames - 1) s.t_last_frame = now();
         }
         if (f % kf_every == 0) keyframe(f, na);
-        for (int b = 0; b < na; b++) if (f == S[(size_t)b]->C.n_frames - 1) S[(size_t)b]->map_q.close();   // the sequence ended: its mapper drains
     }
     CK(ov2_ctx_sync(ctxA));
     const double slam_s = now() - t0;
-    for (auto &s : S) { s->map_q.close(); s->mapper.join(); s->estimator.join(); }
+    map_q.close(); mapper.join();
+    for (auto &s : S) s->estimator.join();
     const double total_s = now() - t0;
     const double t_end = wall();
     { std::lock_guard<std::mutex> l(LD.m); LD.quit = true; }
@@ -349,7 +371,8 @@ int main(int argc, char **argv)
            "\"t_begin\": %.6f, \"t_end\": %.6f}\n",
            N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, t_begin, t_end);
 
-    for (auto &s : S) { ov2_pyr_destroy(s->pyrR); ov2_ctx_destroy(s->ctxB); ov2_ctx_destroy(s->ctxC); }
+    for (auto &s : S) ov2_ctx_destroy(s->ctxC);
+    ov2_pyr_destroy(pyrR); ov2_ctx_destroy(ctxB);
     ov2_btracker_destroy(trk);
     ov2_ctx_destroy(ctxA);
     return 0;
