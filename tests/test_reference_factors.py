@@ -148,6 +148,21 @@ def test_se3_left_parameterization_matches_the_reference_source(ref, oracle):
         J = np.full(42, np.nan)
         assert ref.ref_se3_plus_jacobian(_p(x), _p(J)) == 0
         assert np.array_equal(J.reshape(7, 6), np.vstack([np.eye(6), np.zeros((1, 6))]))             # Jacobian of the local map: [I6; 0]
+    # the tangent vectors the vendored Sophus tests hold (Thirdparty/Sophus/test/core/test_so3.cpp:53-60: zero, unit axes, pi / 2 pairs,
+    # many turns), as rotation parts of the update, on the group elements of :32-51 (near-pi, tiny-angle and exact-pi rotations)
+    pi = np.pi
+    tangents = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (pi / 2, pi / 2, 0), (-1, 1, 0), (20, -1, 0), (30, 5, -1)]
+    quats = [(0., 1., 0., 0.1e-11), (0.00001, 0., 0., -1.), (0., 0., 0., 1.)]       # (x, y, z, w) of test_so3.cpp:32-35 + identity
+    for om in [(0.2, 0.5, 0.0), (0.2, 0.5, -1.0), (0., 0., 0.00001), (pi, 0, 0)]:
+        th = np.linalg.norm(om)
+        quats.append(tuple(np.sin(th / 2) * np.array(om) / th) + (np.cos(th / 2),))
+    for q in quats:
+        for w in tangents:
+            for v in ((0., 0., 0.), (1., -3., 0.5)):
+                x = np.array([1., 2., 4.] + list(q)); d = np.array(list(v) + list(w), np.float64)
+                out = np.zeros(7)
+                assert ref.ref_se3_plus(_p(x), _p(d), _p(out)) == 0
+                assert _close(oracle.se3_left_plus(x, d), out), (q, w, v)
     # the parameter-block holders: [tx ty tz qx qy qz qw], inverse depth = 1 / depth
     x = _rand_pose(rng)
     vals, back = np.zeros(7), np.zeros(7)
@@ -202,4 +217,4 @@ def test_device_residuals_match_the_reference_source(ref, gpu_ctx):
         assert abs(g["chi2"][i] - chi2) <= 1e-10 * max(1.0, chi2), (i, t, g["chi2"][i], chi2)
         assert bool(g["depthpos"][i]) == dp
         n += 1
-    assert n > 3000
+    assert n > 2000
