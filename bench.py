@@ -167,6 +167,8 @@ def cpu_baseline(views, kps, pri, ba_problem, budget_s=8.0):
            "build": flags,
            "slices_ms": {"2.FE_TM_preprocessImage": t_pre / frames * 1e3, "2.FE_TM_KLT-Tracking": t_lk / frames * 1e3},
            "threads": {"2.FE_TM_preprocessImage": nt_pre, "2.FE_TM_KLT-Tracking": nt_lk, "2.BA_Optimize": 1},
+           # every thread count that was timed, median ms per call: the slice runs on its fastest one
+           "threads_tried": {"2.FE_TM_preprocessImage": {str(n): pre_t[n] * 1e3 for n in cand}, "2.FE_TM_KLT-Tracking": {str(n): lk_t[n] * 1e3 for n in cand}},
            "sample": "%d frames of the same synthetic 752x480 step through the oracle (a C restatement of the OpenCV / Ceres "
                      "arithmetic the reference calls -- NOT OpenCV / Ceres themselves, which are absent from this image), "
                      "persistent thread pool, CLAHE + pyramid over tiles / rows on %d threads, LK over keypoints on %d threads "
@@ -236,6 +238,33 @@ def launch(args):
     return rc
 
 
+# ------------------------------------------------------------------------------------------------ who is here
+def ranks_and_devices(world, device_index, dry):
+    """Proof that the collective backend saw `world` ranks on `world` distinct GPUs: an all-reduce(SUM) of ones over the process group
+    (RCCL when the backend is nccl) and every rank's PCI bus id, all-gathered.  Returns (ranks_seen, [bus id per rank])."""
+    import torch
+    import torch.distributed as dist
+    bus = "n/a (dry run, no GPU)"
+    if not dry:
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id"), getattr(pr, "pci_bus_id"), getattr(pr, "pci_device_id"))
+        except Exception:
+            try:
+                hip = C.CDLL("libamdhip64.so")
+                buf = C.create_string_buffer(64)
+                bus = buf.value.decode() if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0 else "unknown"
+            except Exception:
+                bus = "unknown"
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return 1, [bus]
+    one = torch.ones(1, dtype=torch.float64, device=("cuda:%d" % device_index) if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    ids = [None] * world
+    dist.all_gather_object(ids, bus)
+    return int(round(float(one.item()))), ids
+
+
 # ------------------------------------------------------------------------------------------------ config 5
 def config5_plan(world, scale):
     from ov2slam_amd import batch
@@ -291,8 +320,9 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2, str
         for st in stats:
             loc["tracked"] += st["tracked"]; loc["attempted"] += st["attempted"]; loc["ate_sq_sum"] += st["err_sq_sum"]; loc["ate_n"] += st["err_n"]
             loc["keyframes"] += st["keyframes"]; loc["stereo_ok"] += st["stereo_ok"]; loc["stereo_kps"] += st["stereo_kps"]
-            loc["ba_solves"] += st["ba_solves"]; loc["ba_iterations"] += st["ba_iterations"]; loc["ba_seconds"] += st["ba_busy_s"]
+            loc["ba_solves"] += st["ba_solves"]; loc["ba_iterations"] += st["ba_iterations"]
             loc["ba_skipped"] += st["ba_skipped_kfs"]
+        loc["ba_seconds"] = summ["seconds"]                                          # the estimator contexts run beside each other: wall clock
         # equal work for CPU / GPU comparisons: every keyframe gets its localBA (the estimator contexts bound this one)
         stats_a, summ_a = stream.run_lockstep(exe_l, cases, device=device, ba_policy="all")
         loc["all_frames"] = summ_a["frames"]; loc["all_seconds"] = summ_a["seconds"]
@@ -569,7 +599,7 @@ def parity_check(dev_index, views, kps, pri):
         n += len(k); prevp = curp
     trk.close(); ctx.close()
     # the oracle (and therefore the HIP path) accumulates the LK sums in int64; stock OpenCV builds accumulate in float: the measured
-    # distance on this frame pair (the 44 856-track campaign is profiles/r3_lk_acc_modes.json, tools/lk_acc_campaign.py)
+    # distance on this frame pair (the 44 856-track campaign is profiles/archive/r3_lk_acc_modes.json, tools/lk_acc_campaign.py)
     acc = O.lk_acc_mode_report(O.Pyramid(O.clahe(views[0], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS),
                                O.Pyramid(O.clahe(views[1], CLAHE_CLIP, *CLAHE_TILES), WIN, LEVELS), kps[0, 0],
                                np.where(hp[:, None] > 0, pri[0, 0], kps[0, 0]).astype(np.float32))
@@ -577,7 +607,7 @@ def parity_check(dev_index, views, kps, pri):
              "max_abs_dpx": max(m["max_abs_dpx"] for m in acc["modes"].values()), "points": acc["points"]}
     # the detector: the GPU's keyframe detection on this frame vs the oracle (bit-exact), and the oracle's distance to the arithmetic
     # variants another OpenCV build would run (blur rounding, getRectSubPix path, accumulator type): this frame here, 1000 keyframes /
-    # 200 k keypoints in profiles/r4_detect_variants.json (tools/detect_variant_campaign.py)
+    # 200 k keypoints in profiles/archive/r4_detect_variants.json (tools/detect_variant_campaign.py)
     det = {}
     try:
         ctx2 = ov2slam_amd.Context(dev_index)
@@ -597,7 +627,7 @@ def parity_check(dev_index, views, kps, pri):
             d, _ = cKDTree(vk.astype(np.float64)).query(rk.astype(np.float64))
             var[name] = {"keypoints_without_counterpart_within_1px": int((d > 1.0).sum()), "max_abs_dpx_of_the_others": float(d[d <= 1.0].max())}
         det["detector_canonical_vs_other_opencv_arithmetic"] = var
-        det["detector_variant_campaign"] = "profiles/r4_detect_variants.json: 200465 keypoints of 1000 keyframes -- blur ties-to-even: 1.0 % of the keypoints " \
+        det["detector_variant_campaign"] = "profiles/archive/r4_detect_variants.json: 200465 keypoints of 1000 keyframes -- blur ties-to-even: 1.0 % of the keypoints " \
                                            "move to another arg-max, the others identical; getRectSubPix generic form / float sums: <= 0.062 px, 1 / 0 moved"
         ctx2.close()
     except Exception:
@@ -681,7 +711,7 @@ def main():
     ap.add_argument("--config5-stream-scale", type=int, default=16, help="divisor for the per-sequence-stream comparison run of config 5")
     ap.add_argument("--config5-concurrency", type=int, default=2,
                     help="sequences of a rank that stream concurrently on its GPU inside one driver process (1 = one after another).  Measured "
-                         "(tools/r4_conc.py, profiles/r4_stream_concurrency.txt): 1 stream 4.4 k frames/s, 2 streams 7.3 k, 4 streams 6.4 k, 8 streams "
+                         "(tools/r4_conc.py, profiles/archive/r4_stream_concurrency.txt): 1 stream 4.4 k frames/s, 2 streams 7.3 k, 4 streams 6.4 k, 8 streams "
                          "5.9 k -- the streams are chains of small launches and the aggregate is bound by the rate the GPU's command processor "
                          "retires them, which is what the lock-step batch entry points (the headline mode) exist to avoid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -719,10 +749,11 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c5 = run_config5(None, rank, world, args.config5_scale, dry=True, device=local_rank if world > 1 else 0)
+        seen, bus_ids = ranks_and_devices(world, local_rank if world > 1 else 0, True)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "dry": True, "backend": args.backend, "elapsed_max_over_ranks": float(t.item()),
-                              "config5": c5}))
+                              "ranks_seen": seen, "pci_bus_id_per_rank": bus_ids, "config5": c5}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -815,6 +846,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                  # RCCL: 8 bytes, timings only
     elapsed = float(t.item())
+    ranks_seen, bus_ids = ranks_and_devices(world, dev.index, False)     # (after the timed region: an all-reduce of ones + the PCI bus ids)
 
     # ---- roofline of the dominant kernel: k_fb_klt3 (lk3.hip) -------------------------------------------
     iters, visits = [int(v) for v in stats_d.tolist()]
@@ -831,12 +863,20 @@ def main():
     # is committed under profiles/ (same workload and seqs_per_gpu, else null)
     traffic, traffic_note, limiter_kind, valu_frac = None, None, None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))
-        if tj.get("seqs_per_gpu") == S and args.workload == "euroc":
-            traffic = tj["hbm_bytes_per_launch"]; traffic_note = tj.get("limiter")
+        import hashlib
+        tj = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))["current"]
+        sha = hashlib.sha256(open(os.path.join(ROOT, "ov2slam_amd", "csrc", "lk3.hip"), "rb").read()).hexdigest()
+        if tj.get("kernel_source_sha256") != sha:
+            # counters of another kernel: refuse them (null + reason) instead of carrying stale numbers in the line
+            traffic_note = ("counters refused: profiles/lk_traffic.json was measured on lk3.hip %s..., the tree has %s... -- re-run tools/profile.sh and "
+                            "tools/summarize_profile.py --update-lk-traffic" % (str(tj.get("kernel_source_sha256"))[:12], sha[:12]))
+        elif tj.get("seqs_per_gpu") != S or args.workload != "euroc":
+            traffic_note = "no committed PMC pass for this workload / batch (profiles/lk_traffic.json holds euroc at %s sequences per GPU)" % tj.get("seqs_per_gpu")
+        else:
+            traffic = tj["hbm_bytes_per_launch"]; traffic_note = tj.get("limiter") + "; source: " + str(tj.get("source"))
             limiter_kind, valu_frac = tj.get("limiter_kind"), tj.get("valu_issue_frac")
-    except Exception:
-        pass
+    except Exception as e:
+        traffic_note = "profiles/lk_traffic.json unreadable: %r" % (e,)
 
     # ---- the same K steps with pre-processing and tracking on TWO streams (side measurement, never `value`) ------------------
     # Offline batch mode knows frame t+1 while frame t is tracked: preprocessImage of the next frame (LDS-atomic bound histogram,
@@ -944,6 +984,8 @@ def main():
             "metric": METRIC,
             "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # what the process group actually spanned: all_reduce(SUM) of ones over the backend (RCCL), and the PCI bus id of every rank's GPU
+            "ranks_seen": ranks_seen, "pci_bus_id_per_rank": bus_ids, "distinct_gpus": len(set(bus_ids)) == world,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 fixed point + f32 (LK), f64 (BA)", "data": "synthetic",
             "config": {"workload": "%s stereo 'accurate' tracking step on synthetic %dx%d frames: CLAHE + pyramid "
@@ -977,24 +1019,32 @@ def main():
                    "frac": b_alg * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "bytes_the_design_must_move_per_image": b_must, "frac_of_those": b_must * S / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "note": "8(d) counts the int16x2 derivative pyramid (4 of its 5.33 B/px), which this design never materialises (LK evaluates it in registers)"}
-            for name in ("r4_v3", "r4_v2", "r4_v1", "r3_v4"):
-                pth = os.path.join(ROOT, "profiles", "%s_rocprof_summary_seqs%d.json" % (name, S))
-                if os.path.exists(pth) and args.workload == "euroc":
-                    sj = json.load(open(pth))
-                    ks = {}
-                    n_steps = max([kv["calls"] for kn, kv in sj.get("kernels", {}).items() if "k_clahe_apply_pyr" in kn] + [1])
-                    for kn, kv in sj.get("kernels", {}).items():
-                        short = kn.replace("void ", "").split("<")[0]
-                        if short in ("k_clahe_lut", "k_clahe_apply_pyr", "k_pyr_level"):
-                            pm = sj.get("pmc", {}).get(kn, {})
-                            rd = 2.0 * pm.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) * 1e3
-                            wr = pm.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) * 1e3
-                            ks[short] = {"avg_us": kv["avg_us"], "launches_per_step": round(kv["calls"] / max(1, n_steps)),
-                                         "hbm_read_bytes_per_launch": rd, "hbm_written_bytes_per_launch": wr,
-                                         "frac_by_counters": (rd + wr) / (kv["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
-                    pre["kernels"] = ks
-                    pre["kernels_source"] = "profiles/" + os.path.basename(pth)
-                    break
+            # per kernel: duration and HBM bytes by the counters of the newest committed PMC summary WHOSE KERNEL SOURCES ARE THE TREE'S
+            # (tools/summarize_profile.py records the sha256 of clahe.hip / pyramid.hip): anything else is refused, not quoted
+            import glob
+            import hashlib
+            tree = {f: hashlib.sha256(open(os.path.join(ROOT, "ov2slam_amd", "csrc", f), "rb").read()).hexdigest() for f in ("clahe.hip", "pyramid.hip")}
+            pre["kernels"] = None
+            pre["kernels_source"] = "no committed rocprofv3 summary matches the kernel sources in the tree (run tools/profile.sh + tools/summarize_profile.py)"
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary_seqs%d.json" % S)), key=os.path.getmtime, reverse=True)
+            for pth in cands if args.workload == "euroc" else []:
+                sj = json.load(open(pth))
+                if any(sj.get("source_sha256", {}).get(f) != h for f, h in tree.items()):
+                    continue
+                ks = {}
+                n_steps = max([kv["calls"] for kn, kv in sj.get("kernels", {}).items() if "k_clahe_apply_pyr" in kn] + [1])
+                for kn, kv in sj.get("kernels", {}).items():
+                    short = kn.replace("void ", "").split("<")[0]
+                    if short in ("k_clahe_lut", "k_clahe_apply_pyr", "k_pyr_level"):
+                        pm = sj.get("pmc", {}).get(kn, {})
+                        rd = 2.0 * pm.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) * 1e3
+                        wr = pm.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) * 1e3
+                        ks[short] = {"avg_us": kv["avg_us"], "launches_per_step": round(kv["calls"] / max(1, n_steps)),
+                                     "hbm_read_bytes_per_launch": rd, "hbm_written_bytes_per_launch": wr,
+                                     "frac_by_counters": (rd + wr) / (kv["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                pre["kernels"] = ks
+                pre["kernels_source"] = "profiles/" + os.path.basename(pth)
+                break
             out["roofline_pre"] = pre
         except Exception:
             pass
@@ -1018,8 +1068,8 @@ def main():
                                      "unit": "GB/s", "frac": b_ba / (us_it * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                      "limiter": "a chain of nine launches per LM iteration, half of it the one-work-group fp64 Cholesky of the 300 x 300 reduced system "
                                                 "(208 us: 32-column pivot chains, trailing tiles through L2, backward substitution), then the lineariser (74 us: LDS fp64 "
-                                                "atomics and dependent fp64 chains on one wavefront per SIMD); profiles/r4_v3_ba_timeline_config4_mono.txt, "
-                                                "profiles/r4_v3_ba_kernel_stats_*.csv; HBM bytes are under 1 % of the roofline by design (SURVEY 8(d): 'explain, don't hide')"}
+                                                "atomics and dependent fp64 chains on one wavefront per SIMD); profiles/archive/r4_v3_ba_timeline_config4_mono.txt, "
+                                                "profiles/archive/r4_v3_ba_kernel_stats_*.csv; HBM bytes are under 1 % of the roofline by design (SURVEY 8(d): 'explain, don't hide')"}
             # ---- detection through the host-buffer drop-in API on ONE image: per-call latency incl. PCIe -----
             fx = ov2slam_amd.FeatureExtractor(ctx1, dmaxquality=0.001)
             roi = (5, 5, W - 10, H - 10)

@@ -273,7 +273,7 @@ int  ov2_tracker_uses_graph(const ov2_tracker *t); /* 1 when the graph path is a
  * The offline / batch mode of the reference's benchmark protocol (benchmark_scripts/euroc_bench.sh:3-27 runs whole sequences one
  * after the other; BASELINE.json configs[4] shards them over GPUs): a rank that owns several sequences does not need their frames
  * one stream at a time.  One stream is a chain of ~10 small dependent launches per frame and a rank's streams together saturate
- * the launch rate with the CUs ~5 % busy (profiles/r4_stream_concurrency.txt); here every launch of the per-frame enqueue --
+ * the launch rate with the CUs ~5 % busy (profiles/archive/r4_stream_concurrency.txt); here every launch of the per-frame enqueue --
  * frame upload, CLAHE, pyramid, the fused kltTracking kernel (both fbKltTracking calls + retry), Frame::computeKeypoint -- covers
  * all streams at once: same kernels as ov2_tracker_*, grid extended by the batch item, ONE synchronisation per step.
  * Results per item are bit-identical to an ov2_tracker fed the same frames / keypoints (tests/test_gpu_lockstep.py).

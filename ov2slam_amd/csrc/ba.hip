@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
 #endif
 #define CH_LDP 33          // padded leading dimension (doubles) of the LDS panel rows
 // CH_EXP (undefined in the product): knock-out timing of k_ba_cholesky's phases (tools/build_variant.sh ... -DCH_EXP=<bits>,
-// profiles/r4_ba_dead_ends.txt): trailing update 1 no MFMA, 2 no loads of the old tile values, 4 no tile stores, 8 no LDS operand
+// profiles/archive/r4_ba_dead_ends.txt): trailing update 1 no MFMA, 2 no loads of the old tile values, 4 no tile stores, 8 no LDS operand
 // reads; 16 the panel solve does a quarter of its terms.  Any value switches the positive-pivot test off (the factor is garbage).
 #define CH_MAX_LDS_N 415   // k_ba_cholesky (512 threads, six panel wavefronts): the right-hand side rides as a panel row, n - 32 + 1 <= 384; larger: HBM path
 // dynamic LDS of k_ba_cholesky: diagonal block, solution vector, panel (rows rounded up to whole 16-row MFMA tiles: the trailing
@@ -1813,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_ba_zero_lin(BADev D)
 // are computed (tile of the column >= tile of the row, i.e. roughly the upper half: work-groups are issued first rows first,
 // longest first).  nsplit > 1 (few keyframes): several work-groups share a row block and flush it with global atomics.
 // First version: one wavefront per landmark, lane per entry, 36 E^2 GLOBAL atomics per landmark -- 44 ms per iteration on the
-// 50 KF x 10 k x 30 stereo problem, 50 ms at 300 KF (profiles/r2_ba_big_*).
+// 50 KF x 10 k x 30 stereo problem, 50 ms at 300 KF (profiles/archive/r2_ba_big_*).
 #define SS_WAVES 8
 // Beyond 341 keyframes the row block no longer fits the LDS: blockIdx.y walks over column chunks of `ncol` columns (a multiple of
 // 6: pose blocks never straddle a chunk); a work-group accumulates the part [col0, col0 + ncol) of its row block only, and the

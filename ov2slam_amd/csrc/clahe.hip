@@ -443,7 +443,7 @@ __device__ __forceinline__ uint32_t c_wave_shl1(uint32_t v) { return (uint32_t)_
 
 #define CS_UNROLL 6
 #ifndef CS_KO
-#define CS_KO 0           // knock-out timing experiments (tools/build_variant.sh; profiles/r4_strip_kernel_knockouts.txt): 1 loads hit one
+#define CS_KO 0           // knock-out timing experiments (tools/build_variant.sh; profiles/archive/r4_strip_kernel_knockouts.txt): 1 loads hit one
 #endif                    // row, 2 no level-0 stores, 4 no level-1 stores, 8 no LUT look-ups, 16 no blend, 32 no pyrDown sums / level-1
                           // rows, 64 / 128 no border stores of level 0 / 1, 256 distinct slack dwords, 512 / 1024 (fused form) the LUT
                           // wavefront / the shared first row of tiles computes nothing

@@ -3,7 +3,7 @@
 // The offline / batch mode of the reference's benchmark protocol (/root/reference/benchmark_scripts/euroc_bench.sh:3-27 plays whole
 // sequences; BASELINE.json configs[4] shards 11 of them over the GPUs of a node).  A rank that owns several sequences can push
 // each through its own ov2_tracker (track.hip) -- every stream is then a chain of ~10 small dependent launches per frame and the
-// streams together saturate the command processor's launch rate with the CUs ~5 % busy (profiles/r4_stream_concurrency.txt).
+// streams together saturate the command processor's launch rate with the CUs ~5 % busy (profiles/archive/r4_stream_concurrency.txt).
 // Here the per-frame enqueue of VisualFrontEnd::preprocessImage + VisualFrontEnd::kltTracking (+ Frame::computeKeypoint)
 // (src/visual_front_end.cpp:1143-1177, :132-275; src/frame.cpp:246-254) is issued ONCE for all streams: the same kernels as
 // track.hip -- CLAHE, pyramid levels, the fused kltTracking kernel (lkw.hip / lk.hip), k_compute_keypoints -- with the grid

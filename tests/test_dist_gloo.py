@@ -92,6 +92,7 @@ def test_bench_launcher_dry_gloo():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["dry"] is True
+    assert out["ranks_seen"] == 2 and len(out["pci_bus_id_per_rank"]) == 2      # all_reduce(SUM) of ones over the process group
     c5 = out["config5"]
     assert sorted(sum(c5["assignment"], [])) == sorted(batch.EUROC_FRAMES)
     assert len(c5["frames_per_rank"]) == 2 and c5["frames"] == sum(c5["frames_per_rank"])

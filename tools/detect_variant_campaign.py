@@ -10,7 +10,7 @@ up a tracked keypoint set (the keyframe case), under
   all                the first three together
 Per variant (sets matched by nearest neighbour): keypoints without a counterpart within 1 px (another arg-max of the min-eigenvalue
 map won the cell, or the selection that follows changed), the largest distance of the others (sub-pixel refinement), bit-identical
-fraction, frames with a different keypoint COUNT.  Output: profiles/r4_detect_variants.json.
+fraction, frames with a different keypoint COUNT.  Output: profiles/archive/r4_detect_variants.json.
 The variants are restated from the public sources: this bounds the deviation on restated code, it does not pin it (no OpenCV here)."""
 import json
 import multiprocessing as mp

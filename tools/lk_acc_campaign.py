@@ -2,7 +2,7 @@
 """How far is the canonical int64-accumulator LK (what the HIP kernels compute bit-exactly) from the float-accumulator
 variants stock OpenCV builds execute?  CPU only (oracle): fbKltTracking on the synthetic EuRoC / KITTI sets -- raw, CLAHE'd,
 and a worst case of hard-edged binary blocks (the strongest gradients an 8-bit image can have) -- under every accumulator
-mode of oracle/frontend.c; status flips and position deltas against the int64 variant go to profiles/r3_lk_acc_modes.json.
+mode of oracle/frontend.c; status flips and position deltas against the int64 variant go to profiles/archive/r3_lk_acc_modes.json.
 The float orders are restated from the public lkpyramid.cpp (3.4 SSE2 intrinsics, 4.x universal intrinsics, scalar): no
 OpenCV exists in this image or on the GPU box (gpurun_out/r3probe/probe.txt), so this bounds the deviation, it does not pin it."""
 import json

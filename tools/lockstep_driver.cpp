@@ -4,7 +4,7 @@
 // The reference's benchmark protocol plays whole sequences (benchmark_scripts/euroc_bench.sh:3-27); a rank that owns several does
 // not need their frames one stream at a time.  tools/stream_driver.cpp gives every sequence its own SLAM thread and tracker: each
 // stream is a chain of ~10 small dependent launches per frame, and a rank's streams together saturate the launch rate with the
-// CUs ~5 % busy (profiles/r4_stream_concurrency.txt).  Here ONE SLAM thread steps all sequences of the rank through the lock-step
+// CUs ~5 % busy (profiles/archive/r4_stream_concurrency.txt).  Here ONE SLAM thread steps all sequences of the rank through the lock-step
 // tracker (ov2_btracker_*, csrc/trackb.hip): per step one frame upload, one CLAHE + pyramid enqueue, one fused kltTracking launch
 // and one computeKeypoint launch cover every sequence; at the common keyframes one batched detectSingleScale call; the keyframes
 // then go to the rank's mapper thread -- ONE batched right-image CLAHE + pyramid (ov2_pyr_build_clahe_hb) and ONE
