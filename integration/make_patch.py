@@ -14,9 +14,18 @@ What the patch wires (INTEGRATION.md has the reasoning):
   src/map_manager.cpp           extractKeypoints' detectors (:312-320) on the tracker's pyramid; stereoMatching (:367-611): the
                                 map walk stays, SAD priors + both fbKltTracking calls + the epipolar gate -> ov2_stereo_match
   src/mapper.cpp                the keyframe's two pyramids (:75-81) on the mapper thread's context
-  src/optimizer.cpp             localBA (:43-897): the map walk also fills an ov2::FlatProblem, the two ceres::Solve calls and
-                                the outlier loops between them -> ov2_local_ba; signalStopLocalBA reaches the library's live flag
-Not wired (they keep OpenCV / Ceres): btrack_keyframetoframe, buse_inv_depth: 0, looseBA / fullBA / ceresPnP (entry points exist).
+  src/optimizer.cpp             localBA (:34-897), looseBA (:900-1672), fullBA (:1674-2332), structureOnlyBA (:2594-2781): the map walk
+                                fills an ov2::FlatProblem / FlatXYZProblem / FlatStructureProblem INSTEAD of the Ceres problem (no factor is
+                                allocated), the ceres::Solve calls and the outlier loops between them -> ov2_local_ba / ov2_ba_solve /
+                                ov2_xyz_ba_solve / ov2_structure_ba; if the library refuses a problem the function re-enters itself once with
+                                the Ceres problem built.  Both landmark forms (buse_inv_depth 1 / 0) in localBA; looseBA / fullBA take the
+                                library for the inverse-depth form (what every shipped parameter file selects) and Ceres otherwise.
+                                signalStopLocalBA reaches the library's live flag, which is cleared where the reference clears its own (:896)
+  src/multi_view_geometry.cpp   ceresPnP (:492-586) -> ov2::ceresPnP (ov2_ba_solve on OV2_RES_PNP blocks) on the calling thread's context
+  src/visual_front_end.cpp      also kltTrackingFromKF (btrack_keyframetoframe: 1): both fbKltTracking calls on (kf_front, cur) device pyramids
+  include/slam_params.hpp, src/slam_params.cpp   `hip_deterministic_ba` (optional key): OV2_OPT_BA_DETERMINISTIC on the estimator context
+Not wired: nothing of SURVEY section 8 -- do_klt: 0 (descriptor matching instead of KLT, not a shipped mode) still detects through the
+library's host-image entry points; the pose-graph solvers and OpenGV RANSAC are outside the hot path.
 """
 import os
 import shutil
@@ -25,8 +34,8 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = ["CMakeLists.txt", "include/slam_params.hpp", "src/ov2slam.cpp", "src/visual_front_end.cpp", "src/map_manager.cpp",
-         "src/mapper.cpp", "src/optimizer.cpp"]
+FILES = ["CMakeLists.txt", "include/slam_params.hpp", "src/slam_params.cpp", "src/ov2slam.cpp", "src/visual_front_end.cpp", "src/map_manager.cpp",
+         "src/mapper.cpp", "src/optimizer.cpp", "src/multi_view_geometry.cpp"]
 
 
 def span(s, anchor):
@@ -97,6 +106,18 @@ namespace ov2 { struct SlamGpu; }      // slam_gpu.hpp of ov2slam_amd/host
 #ifdef OV2SLAM_HIP
     // libov2slam_hip.so: one context per thread, the per-frame tracker, the detector / tracker / optimizer adapters
     std::shared_ptr<ov2::SlamGpu> pgpu_;
+    // yaml key hip_deterministic_ba (optional, default 0): bundle adjustments bit-identical from run to run, like the reference's
+    // single-threaded Ceres (the library's default accumulates with fp64 atomics in arrival order: 1.7x faster, spread 1e-13)
+    bool bhip_deterministic_ba_ = false;
+#endif
+""")
+
+
+def edit_slam_params_cpp(s):
+    return after(s, """    apply_l2_after_robust_ = static_cast<int>(fsSettings["apply_l2_after_robust"]);
+""", """#ifdef OV2SLAM_HIP
+    if( !fsSettings["hip_deterministic_ba"].empty() )
+        bhip_deterministic_ba_ = static_cast<int>(fsSettings["hip_deterministic_ba"]);
 #endif
 """)
 
@@ -118,6 +139,7 @@ def edit_ov2slam(s):
                                 pslamstate_->nklt_err_, pslamstate_->fmax_fbklt_dist_,
                                 pslamstate_->use_clahe_, pslamstate_->fclahe_val_,
                                 pslamstate_->robust_mono_th_, pslamstate_->apply_l2_after_robust_) );
+    pslamstate_->pgpu_->setDeterministicBA(pslamstate_->bhip_deterministic_ba_);
 #endif
 
 """)
@@ -193,7 +215,7 @@ def edit_front_end(s):
         Profiler::Start("2.FE_TM_preprocessImage");
 """, """
 #ifdef OV2SLAM_HIP
-    if( pslamstate_->do_klt_ && !pslamstate_->btrack_keyframetoframe_ )
+    if( pslamstate_->do_klt_ )
     {
         // H2D + CLAHE + pyramid of the new frame in one asynchronous enqueue; the tracker swaps its prev / cur pyramids
         // itself.  The equalised image stays on the device (level 0 of the pyramid): cur_img_ keeps the raw frame for the
@@ -209,6 +231,83 @@ def edit_front_end(s):
     }
 #endif
 """)
+    # btrack_keyframetoframe: 1 -- the keyframe's pyramid (kf_pyr_, :52) lives on the device next to the tracker's pair
+    s = replace(s, """        if( pslamstate_->btrack_keyframetoframe_ ) {
+            cv::buildOpticalFlowPyramid(cur_img_, kf_pyr_, pslamstate_->klt_win_size_, pslamstate_->nklt_pyr_lvl_);
+        }
+""", """        if( pslamstate_->btrack_keyframetoframe_ ) {
+#ifdef OV2SLAM_HIP
+            // (cur_img_ holds the RAW frame under OV2SLAM_HIP: the equalised image never leaves the device)
+            auto &gpu = *pslamstate_->pgpu_;
+            const int rckf = pslamstate_->use_clahe_
+                    ? gpu.kf_front.buildClahe(gpu.frontend, cur_img_, pslamstate_->nklt_win_size_, pslamstate_->nklt_pyr_lvl_, pslamstate_->fclahe_val_)
+                    : gpu.kf_front.build(gpu.frontend, cur_img_, pslamstate_->nklt_win_size_, pslamstate_->nklt_pyr_lvl_);
+            if( rckf != OV2_OK )
+                std::cerr << "\\n [ov2slam_hip] keyframe pyramid : " << ov2_last_error();
+#else
+            cv::buildOpticalFlowPyramid(cur_img_, kf_pyr_, pslamstate_->klt_win_size_, pslamstate_->nklt_pyr_lvl_);
+#endif
+        }
+""")
+    # kltTrackingFromKF (:277-480): its two fbKltTracking calls on (keyframe pyramid, current pyramid), both on the device
+    lo = once(s, "void VisualFrontEnd::kltTrackingFromKF()")
+    hi = once(s, "void VisualFrontEnd::epipolar2d2dFiltering()")
+    head, f, tail = s[:lo], s[lo:hi], s[hi:]
+    f = replace(f, """        ptracker_->fbKltTracking(
+                    kf_pyr_, 
+                    cur_pyr_, 
+                    pslamstate_->nklt_win_size_, 
+                    nbpyrlvl, 
+                    pslamstate_->nklt_err_, 
+                    pslamstate_->fmax_fbklt_dist_, 
+                    v3dkps, 
+                    v3dpriors, 
+                    vkpstatus);
+""", """#ifdef OV2SLAM_HIP
+        pslamstate_->pgpu_->track.fbKltTracking(pslamstate_->pgpu_->frontend, pslamstate_->pgpu_->kf_front.get(), pslamstate_->pgpu_->trk->curPyr(),
+                    pslamstate_->nklt_win_size_, nbpyrlvl, pslamstate_->nklt_err_, pslamstate_->fmax_fbklt_dist_,
+                    v3dkps, v3dpriors, vkpstatus);
+#else
+        ptracker_->fbKltTracking(
+                    kf_pyr_, 
+                    cur_pyr_, 
+                    pslamstate_->nklt_win_size_, 
+                    nbpyrlvl, 
+                    pslamstate_->nklt_err_, 
+                    pslamstate_->fmax_fbklt_dist_, 
+                    v3dkps, 
+                    v3dpriors, 
+                    vkpstatus);
+#endif
+""")
+    f = replace(f, """        ptracker_->fbKltTracking(
+                    kf_pyr_, 
+                    cur_pyr_, 
+                    pslamstate_->nklt_win_size_, 
+                    pslamstate_->nklt_pyr_lvl_, 
+                    pslamstate_->nklt_err_, 
+                    pslamstate_->fmax_fbklt_dist_, 
+                    vkps, 
+                    vpriors, 
+                    vkpstatus);
+""", """#ifdef OV2SLAM_HIP
+        pslamstate_->pgpu_->track.fbKltTracking(pslamstate_->pgpu_->frontend, pslamstate_->pgpu_->kf_front.get(), pslamstate_->pgpu_->trk->curPyr(),
+                    pslamstate_->nklt_win_size_, pslamstate_->nklt_pyr_lvl_, pslamstate_->nklt_err_, pslamstate_->fmax_fbklt_dist_,
+                    vkps, vpriors, vkpstatus);
+#else
+        ptracker_->fbKltTracking(
+                    kf_pyr_, 
+                    cur_pyr_, 
+                    pslamstate_->nklt_win_size_, 
+                    pslamstate_->nklt_pyr_lvl_, 
+                    pslamstate_->nklt_err_, 
+                    pslamstate_->fmax_fbklt_dist_, 
+                    vkps, 
+                    vpriors, 
+                    vkpstatus);
+#endif
+""")
+    s = head + f + tail
     return s
 
 
@@ -222,7 +321,13 @@ def edit_map_manager(s):
     # detectors: on level 0 of the pyramid the front end has just built (no upload)
     s = replace(s, """            vnewpts = pfeatextract_->detectGridFAST(im, pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
 """, """#ifdef OV2SLAM_HIP
-            vnewpts = pslamstate_->pgpu_->extract.detectGridFAST(pslamstate_->pgpu_->frontend, pslamstate_->pgpu_->trk->curPyr(),
+            // level 0 of the pyramid preprocessImage has just built (do_klt: the equalised frame, no upload); without KLT tracking the
+            // front end kept the OpenCV path and `im` is the image to upload
+            if( pslamstate_->do_klt_ )
+                vnewpts = pslamstate_->pgpu_->extract.detectGridFAST(pslamstate_->pgpu_->frontend, pslamstate_->pgpu_->trk->curPyr(),
+                            pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
+            else
+                vnewpts = pslamstate_->pgpu_->extract.detectGridFAST(pslamstate_->pgpu_->frontend, im,
                             pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
 #else
             vnewpts = pfeatextract_->detectGridFAST(im, pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
@@ -230,7 +335,11 @@ def edit_map_manager(s):
 """)
     s = replace(s, """            vnewpts = pfeatextract_->detectSingleScale(im, pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
 """, """#ifdef OV2SLAM_HIP
-            vnewpts = pslamstate_->pgpu_->extract.detectSingleScale(pslamstate_->pgpu_->frontend, pslamstate_->pgpu_->trk->curPyr(),
+            if( pslamstate_->do_klt_ )
+                vnewpts = pslamstate_->pgpu_->extract.detectSingleScale(pslamstate_->pgpu_->frontend, pslamstate_->pgpu_->trk->curPyr(),
+                            pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
+            else
+                vnewpts = pslamstate_->pgpu_->extract.detectSingleScale(pslamstate_->pgpu_->frontend, im,
                             pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
 #else
             vnewpts = pfeatextract_->detectSingleScale(im, pslamstate_->nmaxdist_, vpts, pcurframe_->pcalib_leftcam_->roi_rect_);
@@ -334,103 +443,201 @@ def edit_mapper(s):
     return s
 
 
-def edit_optimizer(s):
-    """localBA (the first function of the file: the anchors are searched inside its text only) + signalStopLocalBA"""
-    s = after(s, """#include "ceres_parametrization.hpp"
-""", """
+HIP_DECL = """
 #ifdef OV2SLAM_HIP
-#include "slam_gpu.hpp"
-#endif
-""")
-    lo = once(s, "void Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)")
-    hi = once(s, "void Optimizer::looseBA(int inikfid, const int nkfid, const bool buse_robust_cost)")
-    head, f, tail = s[:lo], s[lo:hi], s[hi:]
-
-    f = after(f, """    auto ordering = new ceres::ParameterBlockOrdering;
-""", """
-#ifdef OV2SLAM_HIP
-    // The same problem in the flat form libov2slam_hip.so takes: one push per AddParameterBlock / AddResidualBlock below
-    // (inverse-depth form; buse_inv_depth: 0 keeps Ceres).
-    ov2::FlatProblem fp;
+    // The same problem in the flat form libov2slam_hip.so takes.  bhipwalk: the library solves it, and the map walk below then fills ONLY
+    // the flat problem -- no Ceres factor or parameter block is allocated for the observations (their construction is a third of this
+    // function on the CPU).  If the library refuses the problem the function re-enters itself ONCE with the Ceres problem built.
+    auto &hipgpu = *pslamstate_->pgpu_;
+    const bool bhipwalk = !ov2::SlamGpu::forceCeres()%(extra_cond)s;
+    std::unique_ptr<ceres::LossFunctionWrapper> hiploss_guard(bhipwalk ? loss_function : nullptr);   // (no residual block will own it)
+    ov2::FlatProblem fp;                                 // buse_inv_depth: 1 -- anchored inverse depths
+    ov2::FlatXYZProblem fpx;                             // buse_inv_depth: 0 -- 3-D points
     std::unordered_map<int,int> map_kfid_fpidx, map_lmid_fpidx;
     std::vector<std::pair<int,int>> vfp_kfid_lmid;      // per flat residual block: (kfid, lmid) ...
-    std::vector<int> vfp_list;                           // ... and its list: 0 left, 1 right, 2 right of the anchor
+    std::vector<int> vfp_list;                           // ... and the list its Ceres twin would be in: 0 left, 1 right, 2 right of the anchor
     bool bhipdone = false;
     ov2::LocalBAResult hipres;
 #endif
-""")
+"""
+
+HIP_OBS = """#ifdef OV2SLAM_HIP
+            if( bhipwalk )
+            {
+                // this observation as flat residual block(s); `continue` skips the Ceres factor construction below
+                const double hipsig = std::pow(2.,kp.scale_);
+                const int hipkf = map_kfid_fpidx.at(kfid);
+                if( pslamstate_->buse_inv_depth_ ) {
+                    if( kfanchid < 0 ) {
+                        kfanchid = kfid;
+                        unanch_u = kp.unpx_.x;
+                        unanch_v = kp.unpx_.y;
+                        double zanch = (pkf->getTcw() * plm->getPoint()).z();
+                        map_id_invptspar_.emplace(lmid, InvDepthParametersBlock(lmid, kfanchid, zanch));
+                        map_lmid_fpidx[lmid] = fp.addLandmark(map_id_invptspar_.at(lmid).getInvDepth(), hipkf, unanch_u, unanch_v);
+                        if( kp.is_stereo_ ) {
+                            fp.addResidual(OV2_RES_RIGHT_ANCH, hipkf, map_lmid_fpidx.at(lmid), kp.runpx_.x, kp.runpx_.y, hipsig);
+                            vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(%(anch_list)d);
+                        }
+%(count_anchor)s                        continue;
+                    }
+                    fp.addResidual(OV2_RES_LEFT, hipkf, map_lmid_fpidx.at(lmid), kp.unpx_.x, kp.unpx_.y, hipsig);
+                    vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(0);
+                    if( kp.is_stereo_ ) {
+                        fp.addResidual(OV2_RES_RIGHT, hipkf, map_lmid_fpidx.at(lmid), kp.runpx_.x, kp.runpx_.y, hipsig);
+                        vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(1);
+                    }
+                } else {
+                    fpx.addResidual(OV2_XYZ_LEFT, hipkf, map_lmid_fpidx.at(lmid), kp.unpx_.x, kp.unpx_.y, hipsig);
+                    vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(0);
+                    if( kp.is_stereo_ ) {
+                        fpx.addResidual(OV2_XYZ_RIGHT, hipkf, map_lmid_fpidx.at(lmid), kp.runpx_.x, kp.runpx_.y, hipsig);
+                        vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(1);
+                    }
+                }
+%(count_obs)s                continue;
+            }
+#endif
+"""
+
+HIP_COPY_BACK = """            // poses / landmarks into the parameter blocks the write-back at the end of this function reads
+            for( const auto &id_idx : map_kfid_fpidx )
+                std::copy(hipres.poses.begin() + 7 * id_idx.second, hipres.poses.begin() + 7 * id_idx.second + 7, map_id_posespar_.at(id_idx.first).values());
+            if( pslamstate_->buse_inv_depth_ ) {
+                for( const auto &id_idx : map_lmid_fpidx )
+                    map_id_invptspar_.at(id_idx.first).values()[0] = hipres.invdepth[id_idx.second];
+            } else {
+                for( const auto &id_idx : map_lmid_fpidx )
+                    std::copy(hipres.invdepth.begin() + 3 * id_idx.second, hipres.invdepth.begin() + 3 * id_idx.second + 3, map_id_pointspar_.at(id_idx.first).values());
+            }
+"""
+
+
+def wire_ba(f, kind):
+    """the common edits of localBA / looseBA / fullBA (same code shape in the reference); kind: "local" | "loose" | "full" """
+    count = kind != "full"                      # fullBA keeps no nbmono / nbstereo tally in this part of the walk
+    f = after(f, """    auto ordering = new ceres::ParameterBlockOrdering;
+""", HIP_DECL % {"extra_cond": "" if kind == "local" else " && pslamstate_->buse_inv_depth_"})
     f = after(f, """    problem.SetParameterBlockConstant(calibpar.values());
 """, """
 #ifdef OV2SLAM_HIP
     fp.calib_l[0] = pcalibleft->fx_; fp.calib_l[1] = pcalibleft->fy_; fp.calib_l[2] = pcalibleft->cx_; fp.calib_l[3] = pcalibleft->cy_;
+    std::copy(fp.calib_l, fp.calib_l + 4, fpx.calib_l);
 #endif
 """)
     f = after(f, """        problem.SetParameterBlockConstant(rlextrinpose.values());
 """, """
 #ifdef OV2SLAM_HIP
         fp.calib_r[0] = pcalibright->fx_; fp.calib_r[1] = pcalibright->fy_; fp.calib_r[2] = pcalibright->cx_; fp.calib_r[3] = pcalibright->cy_;
+        std::copy(fp.calib_r, fp.calib_r + 4, fpx.calib_r);
         std::copy(rlextrinpose.values(), rlextrinpose.values() + 7, fp.T_rl);
+        std::copy(rlextrinpose.values(), rlextrinpose.values() + 7, fpx.T_rl);
 #endif
 """)
-    # keyframes of the covisibility walk (free or constant, decided right below)
-    f = before(f, """        // For those to optimize, get their 3D MPs
+    # keyframes of the window (free or constant, decided right below)
+    if kind == "local":
+        f = before(f, """        // For those to optimize, get their 3D MPs
         // for the others, set them as constant""", """#ifdef OV2SLAM_HIP
         map_kfid_fpidx[kfid] = fp.addKeyframe(map_id_posespar_.at(kfid).values(), false);
+        fpx.addKeyframe(map_id_posespar_.at(kfid).values(), false);
 #endif
 
 """)
-    f = after(f, """            set_cstkfids.insert(kfid);
+        f = after(f, """            set_cstkfids.insert(kfid);
             problem.SetParameterBlockConstant(map_id_posespar_.at(kfid).values());
             all_cst = true;
 """, """#ifdef OV2SLAM_HIP
-            fp.kf_const[map_kfid_fpidx.at(kfid)] = 1;
+            fp.kf_const[map_kfid_fpidx.at(kfid)] = 1; fpx.kf_const[map_kfid_fpidx.at(kfid)] = 1;
 #endif
 """)
-    # observing keyframes outside the covisibility window: constant
+    else:
+        f = after(f, """        ordering->AddElementToGroup(map_id_posespar_.at(pkf->kfid_).values(), 1);
+""", """#ifdef OV2SLAM_HIP
+        map_kfid_fpidx[pkf->kfid_] = fp.addKeyframe(map_id_posespar_.at(pkf->kfid_).values(), false);
+        fpx.addKeyframe(map_id_posespar_.at(pkf->kfid_).values(), false);
+#endif
+""")
+        f = after(f, """            set_cstkfids.insert(pkf->kfid_);
+            problem.SetParameterBlockConstant(map_id_posespar_.at(pkf->kfid_).values());
+""", """#ifdef OV2SLAM_HIP
+            fp.kf_const[map_kfid_fpidx.at(pkf->kfid_)] = 1; fpx.kf_const[map_kfid_fpidx.at(pkf->kfid_)] = 1;
+#endif
+""")
+    # observing keyframes outside the window: constant
     f = after(f, """                set_cstkfids.insert(kfid);
                 problem.SetParameterBlockConstant(map_id_posespar_.at(kfid).values());
 """, """#ifdef OV2SLAM_HIP
                 map_kfid_fpidx[kfid] = fp.addKeyframe(map_id_posespar_.at(kfid).values(), true);
+                fpx.addKeyframe(map_id_posespar_.at(kfid).values(), true);
 #endif
 """)
-    # anchored inverse depth + the anchor's right-camera block
-    f = after(f, """                    problem.AddParameterBlock(map_id_invptspar_.at(lmid).values(), 1);
-                    ordering->AddElementToGroup(map_id_invptspar_.at(lmid).values(), 0);
+    # 3-D point landmarks: the parameter block is the flat problem's under bhipwalk
+    f = before(f, """        if( !pslamstate_->buse_inv_depth_ )
+        {
+            map_id_pointspar_.emplace(lmid, PointXYZParametersBlock(lmid, plm->getPoint()));
 """, """#ifdef OV2SLAM_HIP
-                    map_lmid_fpidx[lmid] = fp.addLandmark(map_id_invptspar_.at(lmid).getInvDepth(), map_kfid_fpidx.at(kfanchid), unanch_u, unanch_v);
+        if( bhipwalk ) {
+            if( !pslamstate_->buse_inv_depth_ ) {
+                map_id_pointspar_.emplace(lmid, PointXYZParametersBlock(lmid, plm->getPoint()));
+                map_lmid_fpidx[lmid] = fpx.addPoint(map_id_pointspar_.at(lmid).values());
+            }
+        } else
 #endif
 """)
-    f = after(f, """                        vanchright_reprojerr_kfid_lmid.push_back(std::make_pair(f, std::make_pair(rid, std::make_pair(kfid,lmid))));
-""", """#ifdef OV2SLAM_HIP
-                        fp.addResidual(OV2_RES_RIGHT_ANCH, map_kfid_fpidx.at(kfid), map_lmid_fpidx.at(lmid), kp.runpx_.x, kp.runpx_.y, std::pow(2.,kp.scale_));
-                        vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(2);
-#endif
-""")
-    # stereo observation: left + right block
-    f = after(f, """                    vreprojerr_kfid_lmid.push_back(std::make_pair(f, std::make_pair(rid, std::make_pair(kfid, lmid))));
-""", """#ifdef OV2SLAM_HIP
-                    fp.addResidual(OV2_RES_LEFT, map_kfid_fpidx.at(kfid), map_lmid_fpidx.at(lmid), kp.unpx_.x, kp.unpx_.y, std::pow(2.,kp.scale_));
-                    vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(0);
-                    fp.addResidual(OV2_RES_RIGHT, map_kfid_fpidx.at(kfid), map_lmid_fpidx.at(lmid), kp.runpx_.x, kp.runpx_.y, std::pow(2.,kp.scale_));
-                    vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(1);
-#endif
-""")
-    # mono observation
-    f = after(f, """                vreprojerr_kfid_lmid.push_back(std::make_pair(f, std::make_pair(rid, std::make_pair(kfid,kp.lmid_))));
-""", """#ifdef OV2SLAM_HIP
-                if( pslamstate_->buse_inv_depth_ ) {
-                    fp.addResidual(OV2_RES_LEFT, map_kfid_fpidx.at(kfid), map_lmid_fpidx.at(lmid), kp.unpx_.x, kp.unpx_.y, std::pow(2.,kp.scale_));
-                    vfp_kfid_lmid.push_back(std::make_pair(kfid,lmid)); vfp_list.push_back(0);
+    # every observation
+    obs = HIP_OBS % {"anch_list": 1 if kind == "full" else 2,        # fullBA files the anchor's right-camera block under the right list (:1892)
+                     "count_anchor": ("""                        if( kp.is_stereo_ ) {
+                            nbstereo++;
+                        } else {
+                            nbmono++;
+                        }
+""" if count else ""),
+                     "count_obs": ("""                if( kp.is_stereo_ ) {
+                    nbstereo++;
+                } else {
+                    nbmono++;
                 }
-#endif
-""")
+""" if count else "")}
+    if kind == "full":
+        f = after(f, """            if( kp.lmid_ < 0 ) {
+                pmap_->removeMapPointObs(lmid, kfid);
+                continue;
+            }
+""", obs)
+    else:
+        f = after(f, """            if( kp.lmid_ != lmid ) {
+                pmap_->removeMapPointObs(lmid, kfid);
+                continue;
+            }
+""", obs)
     # gauge fix
     f = after(f, """            problem.SetParameterBlockConstant(map_id_posespar_.at(it->first).values());
             set_cstkfids.insert(it->first);
 """, """#ifdef OV2SLAM_HIP
-            fp.kf_const[map_kfid_fpidx.at(it->first)] = 1;
+            fp.kf_const[map_kfid_fpidx.at(it->first)] = 1; fpx.kf_const[map_kfid_fpidx.at(it->first)] = 1;
 #endif
 """)
+    return f
+
+
+def edit_optimizer(s):
+    """localBA, looseBA, fullBA, structureOnlyBA (anchors are searched inside each function's text only) + the stop flag"""
+    s = after(s, """#include "ceres_parametrization.hpp"
+""", """
+#ifdef OV2SLAM_HIP
+#include "slam_gpu.hpp"
+#endif
+""")
+    cut = [once(s, "void Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)"),
+           once(s, "void Optimizer::looseBA(int inikfid, const int nkfid, const bool buse_robust_cost)"),
+           once(s, "void Optimizer::fullBA(const bool buse_robust_cost)"),
+           once(s, "void Optimizer::signalStopLocalBA()"),
+           once(s, "void Optimizer::structureOnlyBA(const std::vector<int> &vlm2optids)"),
+           once(s, "bool Optimizer::fullPoseGraph(")]
+    head, f_local, f_loose, f_full, mid, f_struct, tail = s[:cut[0]], s[cut[0]:cut[1]], s[cut[1]:cut[2]], s[cut[2]:cut[3]], s[cut[3]:cut[4]], s[cut[4]:cut[5]], s[cut[5]:]
+
+    # ------------------------------------------------------------------------------------------------ localBA
+    f = wire_ba(f_local, "local")
     # the solve stage: both ceres::Solve calls + the outlier logic between them in ONE library call on the estimator thread's context
     f = replace(f, """    ceres::Solver::Summary summary;
     ceres::Solve(options, &problem, &summary);
@@ -442,21 +649,24 @@ def edit_optimizer(s):
         Profiler::StopAndDisplay(pslamstate_->debug_, "2.BA_Optimize");
 """, """    ceres::Solver::Summary summary;
 #ifdef OV2SLAM_HIP
-    if( pslamstate_->buse_inv_depth_ )
+    if( bhipwalk )
     {
-        auto &gpu = *pslamstate_->pgpu_;
         // (same wall-clock budget as the two solves below: t for the robust pass, t / 2 for the L2 pass)
-        gpu.opt.setMaxSolverTime(options.max_solver_time_in_seconds);
-        hipres = gpu.opt.solveLocalBA(gpu.estimator, fp, buse_robust_cost);
+        hipgpu.opt.setMaxSolverTime(options.max_solver_time_in_seconds);
+        if( pslamstate_->buse_inv_depth_ )
+            hipres = hipgpu.opt.solveLocalBA(hipgpu.estimator, fp, buse_robust_cost);
+        else
+            hipres = hipgpu.opt.solveLocalBAXYZ(hipgpu.estimator, fpx, buse_robust_cost);
         bhipdone = hipres.ok;
         if( bhipdone ) {
-            // poses / inverse depths into the parameter blocks the write-back at the end of this function reads
-            for( const auto &id_idx : map_kfid_fpidx )
-                std::copy(hipres.poses.begin() + 7 * id_idx.second, hipres.poses.begin() + 7 * id_idx.second + 7, map_id_posespar_.at(id_idx.first).values());
-            for( const auto &id_idx : map_lmid_fpidx )
-                map_id_invptspar_.at(id_idx.first).values()[0] = hipres.invdepth[id_idx.second];
-        } else {
+""" + HIP_COPY_BACK + """        } else {
             std::cerr << "\\n [ov2slam_hip] localBA falls back to Ceres : " << hipres.error;
+            if( pslamstate_->debug_ || pslamstate_->log_timings_ )
+                Profiler::StopAndDisplay(pslamstate_->debug_, "2.BA_Optimize");
+            ov2::SlamGpu::forceCeres() = true;          // (this thread only)
+            localBA(newframe, buse_robust_cost);
+            ov2::SlamGpu::forceCeres() = false;
+            return;
         }
     }
     if( !bhipdone )
@@ -469,14 +679,12 @@ def edit_optimizer(s):
     if( pslamstate_->debug_ || pslamstate_->log_timings_ )
         Profiler::StopAndDisplay(pslamstate_->debug_, "2.BA_Optimize");
 """)
-    f = after(f, """    vbadkflmids.reserve(vreprojerr_kfid_lmid.size() / 10);
-    vbadstereokflmids.reserve(vright_reprojerr_kfid_lmid.size() / 10);
-""", """
+    bad_lists = """
 #ifdef OV2SLAM_HIP
     if( bhipdone )
     {
-        // One flag per residual block says what both outlier tests (below, and after the L2 pass) decided; the three factor
-        // lists are emptied so that the loops that read chi2err_ / isdepthpositive_ from the Ceres factors have nothing to do.
+        // One flag per residual block says what the outlier tests decided; the three factor lists are empty (bhipwalk created no
+        // Ceres factor), so the loops below that read chi2err_ / isdepthpositive_ from the factors have nothing to do.
         for( size_t i = 0 ; i < hipres.bad_obs.size() ; i++ ) {
             if( !hipres.bad_obs[i] )
                 continue;
@@ -489,12 +697,12 @@ def edit_optimizer(s):
                 nbbadobsrightcam++;
             }
         }
-        vreprojerr_kfid_lmid.clear();
-        vright_reprojerr_kfid_lmid.clear();
-        vanchright_reprojerr_kfid_lmid.clear();
     }
 #endif
-""")
+"""
+    f = after(f, """    vbadkflmids.reserve(vreprojerr_kfid_lmid.size() / 10);
+    vbadstereokflmids.reserve(vright_reprojerr_kfid_lmid.size() / 10);
+""", bad_lists)
     f = replace(f, """    if( pslamstate_->apply_l2_after_robust_ && buse_robust_cost
         && !stopLocalBA() && nbbadobs > 0 )
     {
@@ -505,7 +713,188 @@ def edit_optimizer(s):
         && !stopLocalBA() && nbbadobs > 0 )
     {
         if( !vreprojerr_kfid_lmid.empty() && !vright_reprojerr_kfid_lmid.empty() ) {""")
-    s = head + f + tail
+    # the adapter's copy of the stop flag lives as long as the reference's: cleared HERE, after the map write-back (a signal raised
+    # during the write-back is dropped, like the reference's own)
+    f = replace(f, """    bstop_localba_ = false;
+}
+""", """    bstop_localba_ = false;
+#ifdef OV2SLAM_HIP
+    pslamstate_->pgpu_->opt.clearStopLocalBA();
+#endif
+}
+""")
+    f_local = f
+
+    # ------------------------------------------------------------------------------------------------ looseBA (loop closer's thread)
+    f = wire_ba(f_loose, "loose")
+    f = replace(f, """    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+""", """    ceres::Solver::Summary summary;
+#ifdef OV2SLAM_HIP
+    if( bhipwalk )
+    {
+        hipres = hipgpu.lc_opt.solveLooseBA(hipgpu.threadContext(), fp, buse_robust_cost);
+        bhipdone = hipres.ok;
+        if( bhipdone ) {
+""" + HIP_COPY_BACK + """        } else {
+            std::cerr << "\\n [ov2slam_hip] looseBA falls back to Ceres : " << hipres.error;
+            if( pslamstate_->debug_ || pslamstate_->log_timings_ )
+                Profiler::StopAndDisplay(pslamstate_->debug_, "2.LC_LooseBA_Optimize");
+            ov2::SlamGpu::forceCeres() = true;          // (this thread only)
+            looseBA(inikfid, nkfid, buse_robust_cost);
+            ov2::SlamGpu::forceCeres() = false;
+            return;
+        }
+    }
+    if( !bhipdone )
+#endif
+    ceres::Solve(options, &problem, &summary);
+""")
+    f = after(f, """    vbadkflmids.reserve(vreprojerr_kfid_lmid.size() / 10);
+    vbadstereokflmids.reserve(vright_reprojerr_kfid_lmid.size() / 10);
+""", bad_lists)
+    f_loose = f
+
+    # ------------------------------------------------------------------------------------------------ fullBA (mapper thread, end of the run)
+    f = wire_ba(f_full, "full")
+    f = replace(f, """    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+""", """    ceres::Solver::Summary summary;
+#ifdef OV2SLAM_HIP
+    if( bhipwalk )
+    {
+        // both passes and both outlier tests (left / right lists) in the adapter: Optimizer::fullBA's protocol, :2055-2262
+        hipres = hipgpu.lc_opt.solveFullBA(hipgpu.threadContext(), fp, buse_robust_cost);
+        bhipdone = hipres.ok;
+        if( bhipdone ) {
+""" + HIP_COPY_BACK + """        } else {
+            std::cerr << "\\n [ov2slam_hip] fullBA falls back to Ceres : " << hipres.error;
+            ov2::SlamGpu::forceCeres() = true;          // (this thread only)
+            fullBA(buse_robust_cost);
+            ov2::SlamGpu::forceCeres() = false;
+            return;
+        }
+    }
+    if( !bhipdone )
+#endif
+    ceres::Solve(options, &problem, &summary);
+""")
+    f = after(f, """    size_t nbbadobsmono = 0;
+    size_t nbbadobsrightcam = 0;
+""", """
+#ifdef OV2SLAM_HIP
+    if( bhipdone )
+    {
+        // what the two outlier loops below do for a bad left / right observation (their lists are empty under bhipwalk)
+        for( size_t i = 0 ; i < hipres.bad_obs.size() ; i++ ) {
+            if( !hipres.bad_obs[i] )
+                continue;
+            const int kfid = vfp_kfid_lmid[i].first, lmid = vfp_kfid_lmid[i].second;
+            if( vfp_list[i] == 0 ) {
+                pmap_->removeMapPointObs(lmid,kfid);
+                nbbadobsmono++;
+            } else {
+                map_local_pkfs.at(kfid)->removeStereoKeypointById(lmid);
+                nbbadobsrightcam++;
+            }
+            set_badlmids.insert(lmid);
+        }
+    }
+#endif
+""")
+    f = replace(f, """    if( pslamstate_->apply_l2_after_robust_ && nbbadobs > 0 ) 
+    {""", """#ifdef OV2SLAM_HIP
+    if( !bhipdone )         // (the L2 pass ran inside solveFullBA, on the same conditions)
+#endif
+    if( pslamstate_->apply_l2_after_robust_ && nbbadobs > 0 ) 
+    {""")
+    f_full = f
+
+    # ------------------------------------------------------------------------------------------------ structureOnlyBA (loop closer's thread)
+    f = f_struct
+    f = after(f, """    auto ordering = new ceres::ParameterBlockOrdering;
+""", """
+#ifdef OV2SLAM_HIP
+    // 3-D points against constant keyframes: the flat problem of ov2_structure_ba (see localBA above for bhipwalk)
+    auto &hipgpu = *pslamstate_->pgpu_;
+    const bool bhipwalk = !ov2::SlamGpu::forceCeres();
+    std::unique_ptr<ceres::LossFunctionWrapper> hiploss_guard(bhipwalk ? loss_function : nullptr);
+    ov2::FlatStructureProblem sp;
+    std::unordered_map<int,int> map_kfid_fpidx, map_lmid_fpidx;
+#endif
+""")
+    f = after(f, """    problem.SetParameterBlockConstant(calibpar.values());
+""", """
+#ifdef OV2SLAM_HIP
+    sp.calib_l[0] = pcalibleft->fx_; sp.calib_l[1] = pcalibleft->fy_; sp.calib_l[2] = pcalibleft->cx_; sp.calib_l[3] = pcalibleft->cy_;
+#endif
+""")
+    f = after(f, """        problem.SetParameterBlockConstant(rlextrinpose.values());
+""", """
+#ifdef OV2SLAM_HIP
+        sp.calib_r[0] = pcalibright->fx_; sp.calib_r[1] = pcalibright->fy_; sp.calib_r[2] = pcalibright->cx_; sp.calib_r[3] = pcalibright->cy_;
+        std::copy(rlextrinpose.values(), rlextrinpose.values() + 7, sp.T_rl);
+#endif
+""")
+    f = replace(f, """        problem.AddParameterBlock(map_id_pointspar_.at(lmid).values(), 3);
+        ordering->AddElementToGroup(map_id_pointspar_.at(lmid).values(), 0);
+""", """#ifdef OV2SLAM_HIP
+        if( bhipwalk ) {
+            map_lmid_fpidx[lmid] = sp.addPoint(map_id_pointspar_.at(lmid).values());
+        } else {
+#endif
+        problem.AddParameterBlock(map_id_pointspar_.at(lmid).values(), 3);
+        ordering->AddElementToGroup(map_id_pointspar_.at(lmid).values(), 0);
+#ifdef OV2SLAM_HIP
+        }
+#endif
+""")
+    f = after(f, """            if( kp.lmid_ != lmid ) {
+                continue;
+            }
+""", """#ifdef OV2SLAM_HIP
+            if( bhipwalk )
+            {
+                if( !map_id_posespar_.count(kfid) ) {
+                    map_id_posespar_.emplace(kfid, PoseParametersBlock(kfid, pkf->getTwc()));
+                    map_kfid_fpidx[kfid] = sp.addKeyframe(map_id_posespar_.at(kfid).values());
+                }
+                sp.addResidual(OV2_XYZ_LEFT, map_kfid_fpidx.at(kfid), map_lmid_fpidx.at(lmid), kp.unpx_.x, kp.unpx_.y, std::pow(2.,kp.scale_));
+                if( kp.is_stereo_ )
+                    sp.addResidual(OV2_XYZ_RIGHT, map_kfid_fpidx.at(kfid), map_lmid_fpidx.at(lmid), kp.runpx_.x, kp.runpx_.y, std::pow(2.,kp.scale_));
+                continue;
+            }
+#endif
+""")
+    f = replace(f, """    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+""", """    ceres::Solver::Summary summary;
+#ifdef OV2SLAM_HIP
+    bool bhipdone = false;
+    if( bhipwalk )
+    {
+        std::vector<double> vhipxyz;
+        bhipdone = hipgpu.lc_opt.solveStructureOnlyBA(hipgpu.threadContext(), sp, vhipxyz);
+        if( bhipdone ) {
+            for( const auto &id_idx : map_lmid_fpidx )
+                std::copy(vhipxyz.begin() + 3 * id_idx.second, vhipxyz.begin() + 3 * id_idx.second + 3, map_id_pointspar_.at(id_idx.first).values());
+        } else {
+            std::cerr << "\\n [ov2slam_hip] structureOnlyBA falls back to Ceres : " << ov2_last_error();
+            if( pslamstate_->debug_ || pslamstate_->log_timings_ )
+                Profiler::StopAndDisplay(pslamstate_->debug_, "2.LC_StructBA_Optimize");
+            ov2::SlamGpu::forceCeres() = true;          // (this thread only)
+            structureOnlyBA(vlm2optids);
+            ov2::SlamGpu::forceCeres() = false;
+            return;
+        }
+    }
+    if( !bhipdone )
+#endif
+    ceres::Solve(options, &problem, &summary);
+""")
+    f_struct = f
+
+    s = head + f_local + f_loose + f_full + mid + f_struct + tail
     # Estimator::addNewKf raises the stop flag while a localBA runs: the library polls the adapter's flag after its first pass
     s = replace(s, """    std::lock_guard<std::mutex> lock(localba_mutex_);
     bstop_localba_ = true;
@@ -519,9 +908,47 @@ def edit_optimizer(s):
     return s
 
 
-EDITS = {"CMakeLists.txt": edit_cmake, "include/slam_params.hpp": edit_slam_params, "src/ov2slam.cpp": edit_ov2slam,
+def edit_multi_view_geometry(s):
+    s = after(s, """#include "multi_view_geometry.hpp"
+""", """
+#ifdef OV2SLAM_HIP
+#include <iostream>
+#include "ceres_parametrization.hpp"
+#include "slam_gpu.hpp"
+#endif
+""")
+    return after(s, """    const float fx, const float fy, const float cx, const float cy, 
+    std::vector<int> &voutliersidx)
+{
+    assert( vunkps.size() == vwpts.size() );
+""", """
+#ifdef OV2SLAM_HIP
+    if( ov2::SlamGpu::global() != nullptr && !vunkps.empty() )
+    {
+        // Motion-only BA on the calling thread's context (this function is static and runs on the SLAM thread and on the loop closer's).
+        // Eigen::Vector2d / Vector3d are two / three packed doubles: the vectors ARE the flat arrays the library takes.
+        PoseParametersBlock hippose(0, Twc);
+        std::vector<int> vhipoutliers;
+        bool bhiplibok = true;
+        std::string hiperr;
+        const bool bhipsuccess = ov2::ceresPnP(ov2::SlamGpu::global()->threadContext(), vunkps[0].data(), vwpts[0].data(), vscales.data(),
+                                               vunkps.size(), hippose.values(), nmaxiter, chi2th, buse_robust, bapply_l2_after_robust,
+                                               fx, fy, cx, cy, vhipoutliers, 0.005, &bhiplibok, &hiperr);
+        if( bhiplibok ) {
+            voutliersidx.insert(voutliersidx.end(), vhipoutliers.begin(), vhipoutliers.end());
+            if( vhipoutliers.size() != vunkps.size() )      // (every observation bad: the reference returns before touching Twc, :562-564)
+                Twc = hippose.getPose();
+            return bhipsuccess;
+        }
+        std::cerr << "\\n [ov2slam_hip] ceresPnP falls back to Ceres : " << hiperr;
+    }
+#endif
+""")
+
+
+EDITS = {"CMakeLists.txt": edit_cmake, "include/slam_params.hpp": edit_slam_params, "src/slam_params.cpp": edit_slam_params_cpp, "src/ov2slam.cpp": edit_ov2slam,
          "src/visual_front_end.cpp": edit_front_end, "src/map_manager.cpp": edit_map_manager, "src/mapper.cpp": edit_mapper,
-         "src/optimizer.cpp": edit_optimizer}
+         "src/optimizer.cpp": edit_optimizer, "src/multi_view_geometry.cpp": edit_multi_view_geometry}
 
 
 def generate(ref_root):

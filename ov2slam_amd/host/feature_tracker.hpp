@@ -21,12 +21,20 @@ public:
                        float ferr, float fmax_fbklt_dist, std::vector<Point2f> &vkps, std::vector<Point2f> &vpriorkps,
                        std::vector<bool> &vkpstatus) const
     {
+        fbKltTracking(ctx, vprevpyr.get(), vcurpyr.get(), nwinsize, nbpyrlvl, ferr, fmax_fbklt_dist, vkps, vpriorkps, vkpstatus);
+    }
+    // the same on raw handles (e.g. prev = SlamGpu::kf_front, cur = FrameTracker::curPyr(): VisualFrontEnd::kltTrackingFromKF,
+    // src/visual_front_end.cpp:363, :409)
+    void fbKltTracking(Context &ctx, const ov2_pyr *vprevpyr, const ov2_pyr *vcurpyr, int nwinsize, int nbpyrlvl,
+                       float ferr, float fmax_fbklt_dist, std::vector<Point2f> &vkps, std::vector<Point2f> &vpriorkps,
+                       std::vector<bool> &vkpstatus) const
+    {
         if (vkps.empty()) return;                                   // :43-46
         const size_t n = vkps.size();
         vkpstatus.reserve(vkpstatus.size() + n);
         std::vector<uint8_t> st(n, 0);
         std::vector<Point2f> priors(vpriorkps);
-        const int rc = ov2_fb_klt(ctx.get(), vprevpyr.get(), vcurpyr.get(), nwinsize, nbpyrlvl, nmax_iter_, fmax_px_precision_,
+        const int rc = ov2_fb_klt(ctx.get(), vprevpyr, vcurpyr, nwinsize, nbpyrlvl, nmax_iter_, fmax_px_precision_,
                                   ferr, fmax_fbklt_dist, &vkps[0].x, &priors[0].x, (int)n, st.data(), nullptr);
         if (rc == OV2_OK) vpriorkps.swap(priors);
         for (size_t i = 0; i < n; i++) vkpstatus.push_back(rc == OV2_OK && st[i] != 0);

@@ -87,5 +87,72 @@ bool site_optimizer(ov2::SlamGpu &gpu, double *pose_values, double invdepth, dou
         std::cerr << hipres.error;
     }
     gpu.opt.signalStopLocalBA();
+    gpu.opt.clearStopLocalBA();
     return hipres.ok && invdepth > 0;
+}
+
+// src/optimizer.cpp: the buse_inv_depth: 0 form of localBA, looseBA / fullBA / structureOnlyBA, the per-thread fallback flag
+bool site_optimizer_other(ov2::SlamGpu &gpu, double *pose_values, double *point_values, double u, double v, double scale, bool buse_robust_cost)
+{
+    const bool bhipwalk = !ov2::SlamGpu::forceCeres();
+    ov2::FlatXYZProblem fpx;
+    ov2::FlatProblem fp;
+    std::unordered_map<int, int> map_kfid_fpidx, map_lmid_fpidx;
+    std::copy(fp.calib_l, fp.calib_l + 4, fpx.calib_l);
+    std::copy(pose_values, pose_values + 7, fpx.T_rl);
+    map_kfid_fpidx[3] = fp.addKeyframe(pose_values, false);
+    fpx.addKeyframe(pose_values, false);
+    fp.kf_const[map_kfid_fpidx.at(3)] = 1; fpx.kf_const[map_kfid_fpidx.at(3)] = 1;
+    map_lmid_fpidx[7] = fpx.addPoint(point_values);
+    fpx.addResidual(OV2_XYZ_LEFT, map_kfid_fpidx.at(3), map_lmid_fpidx.at(7), u, v, std::pow(2., scale));
+    fpx.addResidual(OV2_XYZ_RIGHT, map_kfid_fpidx.at(3), map_lmid_fpidx.at(7), u, v, std::pow(2., scale));
+    ov2::LocalBAResult hipres = gpu.opt.solveLocalBAXYZ(gpu.estimator, fpx, buse_robust_cost);
+    if (hipres.ok) std::copy(hipres.invdepth.begin() + 3 * map_lmid_fpidx.at(7), hipres.invdepth.begin() + 3 * map_lmid_fpidx.at(7) + 3, point_values);
+    hipres = gpu.lc_opt.solveLooseBA(gpu.threadContext(), fp, buse_robust_cost);
+    hipres = gpu.lc_opt.solveFullBA(gpu.threadContext(), fp, buse_robust_cost);
+    ov2::FlatStructureProblem sp;
+    map_kfid_fpidx[5] = sp.addKeyframe(pose_values);
+    map_lmid_fpidx[9] = sp.addPoint(point_values);
+    sp.addResidual(OV2_XYZ_LEFT, map_kfid_fpidx.at(5), map_lmid_fpidx.at(9), u, v, std::pow(2., scale));
+    std::vector<double> vhipxyz;
+    const bool bhipdone = gpu.lc_opt.solveStructureOnlyBA(gpu.threadContext(), sp, vhipxyz);
+    ov2::SlamGpu::forceCeres() = true;
+    ov2::SlamGpu::forceCeres() = false;
+    gpu.setDeterministicBA(true);
+    return bhipwalk && bhipdone && hipres.ok;
+}
+
+// src/multi_view_geometry.cpp: ceresPnP (the reference passes std::vector<Eigen::Vector2d / Vector3d>: packed doubles)
+bool site_ceres_pnp(const std::vector<double> &vunkps, const std::vector<double> &vwpts, const std::vector<int> &vscales, double *pose_values, int nmaxiter,
+                    float chi2th, bool buse_robust, bool bapply_l2_after_robust, float fx, float fy, float cx, float cy, std::vector<int> &voutliersidx)
+{
+    if (ov2::SlamGpu::global() == nullptr) return false;
+    std::vector<int> vhipoutliers;
+    bool bhiplibok = true;
+    std::string hiperr;
+    const bool bhipsuccess = ov2::ceresPnP(ov2::SlamGpu::global()->threadContext(), vunkps.data(), vwpts.data(), vscales.data(), vscales.size(), pose_values,
+                                           nmaxiter, chi2th, buse_robust, bapply_l2_after_robust, fx, fy, cx, cy, vhipoutliers, 0.005, &bhiplibok, &hiperr);
+    if (bhiplibok) voutliersidx.insert(voutliersidx.end(), vhipoutliers.begin(), vhipoutliers.end());
+    else std::cerr << hiperr;
+    return bhipsuccess;
+}
+
+// src/visual_front_end.cpp: btrack_keyframetoframe (the keyframe's pyramid on the device, both fbKltTracking calls of kltTrackingFromKF)
+size_t site_track_from_kf(ov2::SlamGpu &gpu, const cv::Mat &cur_img, bool use_clahe, int nklt_win_size, int nklt_pyr_lvl, float fclahe_val, int nklt_err,
+                          float fmax_fbklt_dist, std::vector<cv::Point2f> &vkps, std::vector<cv::Point2f> &vpriors)
+{
+    const int rckf = use_clahe ? gpu.kf_front.buildClahe(gpu.frontend, cur_img, nklt_win_size, nklt_pyr_lvl, fclahe_val)
+                               : gpu.kf_front.build(gpu.frontend, cur_img, nklt_win_size, nklt_pyr_lvl);
+    if (rckf != OV2_OK) std::cerr << ov2_last_error();
+    std::vector<bool> vkpstatus;
+    gpu.track.fbKltTracking(gpu.frontend, gpu.kf_front.get(), gpu.trk->curPyr(), nklt_win_size, nklt_pyr_lvl, nklt_err, fmax_fbklt_dist, vkps, vpriors, vkpstatus);
+    return vkpstatus.size();
+}
+
+// src/map_manager.cpp: detectors on a host image (do_klt: 0)
+size_t site_detect_host(ov2::SlamGpu &gpu, const cv::Mat &im, int nmaxdist, const std::vector<cv::Point2f> &vpts, const cv::Rect &roi_rect)
+{
+    std::vector<cv::Point2f> vnewpts = gpu.extract.detectGridFAST(gpu.frontend, im, nmaxdist, vpts, roi_rect);
+    vnewpts = gpu.extract.detectSingleScale(gpu.frontend, im, nmaxdist, vpts, roi_rect);
+    return vnewpts.size();
 }

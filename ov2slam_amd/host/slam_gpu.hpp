@@ -11,6 +11,7 @@
 #include "feature_tracker.hpp"
 #include "visual_front_end.hpp"
 #include "optimizer.hpp"
+#include "multi_view_geometry.hpp"
 
 namespace ov2 {
 
@@ -21,6 +22,9 @@ struct SlamGpu {
     Optimizer opt;                                // solveLocalBA (ov2_local_ba)
     std::unique_ptr<FrameTracker> trk;            // preprocessImage + kltTracking of every frame (SLAM thread)
     Pyramid kf_left, kf_right;                    // mapper thread: the keyframe's pyramids, rebuilt from the raw images it queued
+    Pyramid kf_front;                             // SLAM thread, btrack_keyframetoframe: the last keyframe's pyramid (kf_pyr_, visual_front_end.cpp:52)
+    Optimizer lc_opt;                             // the loop closer's own Optimizer instance (include/loop_closer.hpp:78): looseBA / structureOnlyBA
+    int device;
 
     // arguments: the SlamParams fields of the same names (include/slam_params.hpp) and the left image size
     SlamGpu(int device, int img_w, int img_h, int nbmaxkps, int nmaxdist, double dmaxquality, int nfast_th, int nmax_iter,
@@ -30,9 +34,31 @@ struct SlamGpu {
           extract((size_t)nbmaxkps, (size_t)nmaxdist, dmaxquality, nfast_th), track(nmax_iter, fmax_px_precision),
           opt(robust_mono_th, apply_l2_after_robust),
           trk(new FrameTracker(frontend, img_w, img_h, nklt_win_size, nklt_pyr_lvl, nmax_iter, fmax_px_precision, nklt_err,
-                               fmax_fbklt_dist, use_clahe, fclahe_val, nbmaxkps))
-    {}
-    ~SlamGpu() { trk.reset(); }                   // the tracker goes before the context it was created on
+                               fmax_fbklt_dist, use_clahe, fclahe_val, nbmaxkps)),
+          lc_opt(robust_mono_th, apply_l2_after_robust), device(device)
+    { global() = this; }
+    ~SlamGpu() { trk.reset(); if (global() == this) global() = nullptr; }   // the tracker goes before the context it was created on
+
+    // the one instance, for the reference's static functions that have no SlamParams at hand (MultiViewGeometry::ceresPnP)
+    static SlamGpu *&global() { static SlamGpu *p = nullptr; return p; }
+    // Per thread: a bundle adjustment whose library call failed re-enters the reference function once with this flag up, and that pass
+    // builds and solves the Ceres problem as the unpatched code would (localBA: estimator thread; looseBA / structureOnlyBA: loop
+    // closer; fullBA: mapper thread)
+    static bool &forceCeres() { static thread_local bool f = false; return f; }
+
+    // One context per calling thread for the reference's STATIC entry points (MultiViewGeometry::ceresPnP runs on the SLAM thread
+    // and on the loop closer's, src/visual_front_end.cpp:791, src/loop_closer.cpp:882) and for the threads that have no member
+    // context above (LoopCloser::run, the final fullBA on the mapper thread uses `mapper`): created on first use, destroyed with the thread.
+    Context &threadContext() const
+    {
+        static thread_local std::unique_ptr<Context> tls;
+        if (!tls) tls.reset(new Context(device));
+        return *tls;
+    }
+    // OV2_OPT_BA_DETERMINISTIC on the contexts that run bundle adjustments (SlamParams::bhip_deterministic_ba_): the reference solves
+    // with num_threads = 1 and is reproducible from run to run; the library's default accumulates with fp64 atomics (1.7x faster)
+    void setDeterministicBA(bool on) { ov2_ctx_set_option(estimator.get(), OV2_OPT_BA_DETERMINISTIC, on ? 1 : 0); deterministic_ba = on; }
+    bool deterministic_ba = false;
 };
 
 }  // namespace ov2
