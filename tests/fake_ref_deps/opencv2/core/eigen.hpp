@@ -1,0 +1,2 @@
+#pragma once
+#include <opencv2/core.hpp>
