@@ -38,6 +38,10 @@ struct ClaheParams {
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
 // tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
+//   * (round 5: FOUR staggered copies again for the wavefronts that histogram most of the tiles, and whole-dword aggregation -- the
+//     measurement below was taken on band-limited noise, where a wavefront's 64 pixels hit ~60 different bins; on a constant, an
+//     over- or an under-exposed frame they hit a handful, the ds_adds serialise and the fused kernel took 3.0x / 2.4x / 1.5x as long
+//     (tools/pre_micro.py .. entropy, profiles/r5_pre_entropy.txt).  See clahe_lut_tiles.)
 //   * ONE 256-bin histogram per wavefront.  Rounds 1-2 kept 8 staggered copies against same-address / same-bank collisions
 //     of neighbouring pixels; measured in round 3 (OV2SLAM_HIP_LIB A/B builds, tools/pre_micro.py): 16, 8, 4, 2 and 1 copies run
 //     within noise of each other (16: slower, occupancy), and so does a build with 27 % fewer vector instructions: the kernel is
@@ -58,7 +62,10 @@ __device__ __forceinline__ void clahe_wave_sync()
 #ifndef CLAHE_KO
 #define CLAHE_KO 0        // knock-out timing experiments. lut: 1 loads hit one line, 2 no ds_add, 4 no clip/scan tail;
 #endif                    // apply: 8 loads hit, 16 no stores, 32 no LUT look-ups, 64 no blend
-#define CH_WAVE_DW 256               // one 256-bin histogram per wavefront (see the kernel comment)
+#define CH_WAVE_DW 256               // dwords of a one-copy histogram
+#define CH_CSTRIDE 264               // dwords between the copies of a multi-copy histogram: bin b of copy c sits in LDS bank (b + 8 c) % 64
+#define CH_NCOPY 4                   // copies of the wavefronts that histogram most tiles (k_clahe_lut; the LUT wavefronts of the fused kernel)
+#define CH_MULTI_DW (CH_NCOPY * CH_CSTRIDE)
 typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
@@ -67,13 +74,17 @@ __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dp
 // The tiles t, t + tstride, .. < t_end of ONE image, by one wavefront with its own 256-bin histogram `hw` in LDS; store_lut(t, packed)
 // receives the lane's four LUT bytes (bins 4 lane .. 4 lane + 3) of tile t.  Shared by k_clahe_lut (LUTs to HBM) and the fused
 // strip kernel (LUTs stay in LDS).
+// ncopy (wave-uniform, 1 or CH_NCOPY): copies of the histogram, CH_CSTRIDE dwords apart; a lane adds into copy (lane ^ lane >> 4) % ncopy
+// (horizontal and vertical neighbours -- similar grey levels -- go to different copies and different banks).  Low-entropy frames:
+// with one copy every equal pair of the 64 pixels of a ds_add serialises; four copies bound that, and a dword that many lanes hold
+// (flat, saturated or black regions: 0xFFFFFFFF, 0x00000000) is added ONCE per byte with the lane count as weight.
 template <bool SRC_ALIGNED, class StoreLut>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
 __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint8_t *img, uint32_t *hw, int lane, int t, int t_end, int tstride,
-                                                StoreLut store_lut)
+                                                StoreLut store_lut, int ncopy = 1)
 {
     const int ntiles = t_end;
     const int sub = lane >> 4, l16 = lane & 15;
-    uint32_t *hist = hw;
+    uint32_t *hist = hw + ((lane ^ (lane >> 4)) & (ncopy - 1)) * CH_CSTRIDE;        // this lane's copy
     const bool fast_geom = P.tw <= 61 && P.th <= 64;
     // Rows are fetched as ALIGNED dwords whatever the alignment of the image (KITTI: 1241-byte rows): dword l16 of
     // the row segment starts `ph` bytes before the first tile byte, ph = (address of that byte) & 3, per row.
@@ -147,7 +158,8 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
     auto histogram = [&](int th) {
         const int ty = th / P.tiles_x, tx = th - ty * P.tiles_x;
         const int x_begin = tx * P.tw;                              // tile columns in padded coordinates
-        ((c_u32x4 *)hw)[lane] = (c_u32x4)(0u);
+        if (ncopy == 1) ((c_u32x4 *)hw)[lane] = (c_u32x4)(0u);
+        else for (int q = lane; q < CH_MULTI_DW / 4; q += 64) ((c_u32x4 *)hw)[q] = (c_u32x4)(0u);
         clahe_wave_sync();
         if (tile_fast(th)) {
             // byte k of this lane's dword is tile column 4*l16 + k - ph; bytes outside [0, tw) are added with weight 0
@@ -157,6 +169,14 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
             const int p_same = 4 * l16 - (int)(cur_ph & 3);
             uint32_t w0 = wgt(p_same), w1 = wgt(p_same + 1), w2 = wgt(p_same + 2), w3 = wgt(p_same + 3);
             bool mine = p_same < P.tw;                              // this lane's dword holds at least one tile byte
+            // which lanes weigh byte k of their dword once / twice (wave-uniform masks: the weights depend on the lane's column only)
+            uint64_t m1[4], m2[4];
+            if (same_phase) {
+                m1[0] = __builtin_amdgcn_ballot_w64(mine && w0 >= 1u); m2[0] = __builtin_amdgcn_ballot_w64(mine && w0 == 2u);
+                m1[1] = __builtin_amdgcn_ballot_w64(mine && w1 >= 1u); m2[1] = __builtin_amdgcn_ballot_w64(mine && w1 == 2u);
+                m1[2] = __builtin_amdgcn_ballot_w64(mine && w2 >= 1u); m2[2] = __builtin_amdgcn_ballot_w64(mine && w2 == 2u);
+                m1[3] = __builtin_amdgcn_ballot_w64(mine && w3 >= 1u); m2[3] = __builtin_amdgcn_ballot_w64(mine && w3 == 2u);
+            }
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (!same_phase) {                                   // wave-uniform: rows of an unaligned image differ in phase
@@ -164,13 +184,33 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
                     w0 = wgt(p0); w1 = wgt(p0 + 1); w2 = wgt(p0 + 2); w3 = wgt(p0 + 3);
                     mine = p0 < P.tw;
                 }
-                if (mine && 4 * i + sub < P.th) {
-                    const uint32_t v = cur[i];
-                    if (CLAHE_KO & 2) { if (v == 0x12345678u) hw[0] = 1; continue; }
-                    atomicAdd(&hw[v & 0xFF], w0);
-                    atomicAdd(&hw[(v >> 8) & 0xFF], w1);
-                    atomicAdd(&hw[(v >> 16) & 0xFF], w2);
-                    atomicAdd(&hw[v >> 24], w3);
+                const bool act = mine && 4 * i + sub < P.th;
+                const uint32_t v = cur[i];
+                if (CLAHE_KO & 2) { if (act && v == 0x12345678u) hw[0] = 1; continue; }
+                bool todo = act;
+                if (same_phase) {
+                    // one dword shared by many lanes (a flat region): its four bytes go in once, weighted by the lanes that hold it
+                    const uint64_t m_act = __builtin_amdgcn_ballot_w64(act);
+                    if (m_act != 0) {
+                        const int ld = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m_act));
+                        const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)v, ld);
+                        const uint64_t m_eq = __builtin_amdgcn_ballot_w64(act && v == v0);
+                        if (__builtin_popcountll(m_eq) >= 12) {
+                            if (lane == ld) {
+                                atomicAdd(&hist[v0 & 0xFF], (uint32_t)(__builtin_popcountll(m_eq & m1[0]) + __builtin_popcountll(m_eq & m2[0])));
+                                atomicAdd(&hist[(v0 >> 8) & 0xFF], (uint32_t)(__builtin_popcountll(m_eq & m1[1]) + __builtin_popcountll(m_eq & m2[1])));
+                                atomicAdd(&hist[(v0 >> 16) & 0xFF], (uint32_t)(__builtin_popcountll(m_eq & m1[2]) + __builtin_popcountll(m_eq & m2[2])));
+                                atomicAdd(&hist[v0 >> 24], (uint32_t)(__builtin_popcountll(m_eq & m1[3]) + __builtin_popcountll(m_eq & m2[3])));
+                            }
+                            todo = act && v != v0;
+                        }
+                    }
+                }
+                if (todo) {
+                    atomicAdd(&hist[v & 0xFF], w0);
+                    atomicAdd(&hist[(v >> 8) & 0xFF], w1);
+                    atomicAdd(&hist[(v >> 16) & 0xFF], w2);
+                    atomicAdd(&hist[v >> 24], w3);
                 }
             }
         } else {
@@ -191,7 +231,8 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
         // lane owns bins 4*lane .. 4*lane+3
         int hv[4];
         {
-            const c_u32x4 q = *(const c_u32x4 *)(hw + 4 * lane);
+            c_u32x4 q = *(const c_u32x4 *)(hw + 4 * lane);
+            for (int c = 1; c < ncopy; c++) q += *(const c_u32x4 *)(hw + c * CH_CSTRIDE + 4 * lane);
             hv[0] = (int)q.x; hv[1] = (int)q.y; hv[2] = (int)q.z; hv[3] = (int)q.w;
         }
         clahe_wave_sync();                                            // the histogram may be cleared for the next tile
@@ -243,14 +284,14 @@ __global__ __launch_bounds__(256, 4) void k_clahe_lut(ClaheParams P, const uint8
     // four wavefronts = four neighbouring tiles per work-group (no barrier between them): tiles that share cache lines run at
     // the same time on one CU.  (One wavefront per work-group makes a bin's LDS address a single SDWA shift, but the tiles of a
     // row then run at different times and the kernel fetches 1.44x the bytes from HBM -- same 635 us, LDS-atomic bound either way.)
-    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_WAVE_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][CH_MULTI_DW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar: all tile arithmetic on the SALU
     const int ntiles = P.tiles_x * P.tiles_y;
     int b, bx;
     ov2_xcd_map(blockIdx.x, P.gx_lut, P.batch, &b, &bx);    // the work-groups of an image share image lines and its LUTs
     uint8_t *lb = lut + (long long)b * ntiles * 256 + 4 * lane;
     clahe_lut_tiles<SRC_ALIGNED>(P, src + (long long)b * P.src_item_stride, hist_all[wave], lane, bx * 4 + wave, ntiles, 4 * P.gx_lut,
-                                 [&](int t, uint32_t packed) { *(uint32_t *)(lb + (long long)t * 256) = packed; });
+                                 [&](int t, uint32_t packed) { *(uint32_t *)(lb + (long long)t * 256) = packed; }, CH_NCOPY);
 }
 
 // One workgroup per (row of interpolation cells, image): the rows whose two surrounding tile rows are
@@ -466,11 +507,13 @@ __global__ __launch_bounds__(64 * (CS_MAX_STRIPS + 2), 6) void k_clahe_apply_pyr
     // everything else is wave-private
     const int b = blockIdx.x, s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, ndw = (P.w + 3) >> 2, wr = UNAL ? (P.w & 3) : 0;
-    uint32_t *hist_w = (uint32_t *)(ring + (size_t)2 * P.tiles_x * 256) + s * CH_WAVE_DW;       // FUSED: this wavefront's histogram
+    // FUSED: this wavefront's histogram -- one copy for the strips (they histogram the first row of tiles only), CH_NCOPY for the LUT wavefronts
+    uint32_t *hist_w = (uint32_t *)(ring + (size_t)2 * P.tiles_x * 256) + (s < P.nstrips ? s * CH_WAVE_DW : P.nstrips * CH_WAVE_DW + (s - P.nstrips) * CH_MULTI_DW);
+    const int hist_copies = s < P.nstrips ? 1 : CH_NCOPY;
     auto lut_row = [&](int ty, int tx0, int txstep) {                   // FUSED: LUTs of the tiles tx0, tx0 + txstep, .. of tile row ty
         uint8_t *slot = ring + (size_t)(ty & 1) * P.tiles_x * 256 - (size_t)ty * P.tiles_x * 256 + 4 * lane;
         clahe_lut_tiles<!UNAL>(P, src + (long long)b * P.src_item_stride, hist_w, lane, ty * P.tiles_x + tx0, (ty + 1) * P.tiles_x, txstep,
-                               [&](int t, uint32_t packed) { *(uint32_t *)(slot + (size_t)t * 256) = packed; });
+                               [&](int t, uint32_t packed) { *(uint32_t *)(slot + (size_t)t * 256) = packed; }, hist_copies);
     };
     typedef uint32_t cs_u32_a1 __attribute__((aligned(1)));             // source rows of any alignment (KITTI: 1241-byte rows)
     const int cmin = 0, ncell = P.tiles_x + 1;
@@ -802,7 +845,7 @@ int ov2_launch_clahe(ov2_ctx *ctx, const uint8_t *src_d, int w, int h, int strid
             const bool fused = (ctx->clahe_strips == 2 || (ctx->clahe_strips < 0 && tiles_x <= 16 * nlut)) && (unal || src_al);
             if (fused) {
                 P.nlut = nlut;
-                const size_t lds = (size_t)(tiles_x + 1) * 1024 + (size_t)2 * tiles_x * 256 + (size_t)(nstrips + P.nlut) * CH_WAVE_DW * 4;
+                const size_t lds = (size_t)(tiles_x + 1) * 1024 + (size_t)2 * tiles_x * 256 + ((size_t)nstrips * CH_WAVE_DW + (size_t)P.nlut * CH_MULTI_DW) * 4;
                 hipLaunchKernelGGL((unal ? k_clahe_apply_pyr<true, true> : k_clahe_apply_pyr<false, true>), dim3(batch), dim3(64 * (nstrips + P.nlut)), lds, ctx->stream, P, src_d, lut_d, dst_d);
             } else {
                 launch_lut();

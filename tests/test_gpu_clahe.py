@@ -146,3 +146,31 @@ def test_strip_kernel_equals_separate_kernels_random_geometry(gpu_ctx):
         for force in (1, 2):
             for l, (a, b) in enumerate(zip(out[force], out[0])):
                 assert np.array_equal(a, b), (case, force, win, w, h, tx, ty, l, np.argwhere(a != b)[:4].tolist())
+
+
+@pytest.mark.parametrize("wh,tiles", [((752, 480), (15, 9)), ((1241, 376), (24, 7)), ((376, 240), (7, 4)), ((103, 57), (3, 2))])
+def test_low_entropy_frames_bit_exact(gpu_ctx, oracle, wh, tiles):
+    """Frames whose histograms have a handful of bins (constant, over- / under-exposed, posterised, flat blocks with a texture island):
+    the inputs on which a wavefront's ds_adds collide.  Round 5 gave the histogram wavefronts four staggered copies and adds a dword that
+    many lanes share once per byte with the lane count as weight (clahe_lut_tiles) -- every CLAHE path must still equal the oracle."""
+    w, h = wh
+    rng = np.random.default_rng(w * 7 + h)
+    base, _, _ = synth.frame_pair(w, h, seed=w + 11 * h)
+    base = base.astype(np.int32)
+    sel = rng.uniform(size=base.shape) < 0.8
+    blocks = np.repeat(np.repeat(rng.integers(0, 256, ((h + 31) // 32, (w + 47) // 48)), 32, 0), 48, 1)[:h, :w]       # flat 48 x 32 patches
+    island = blocks.copy(); island[h // 3:h // 3 + 40, w // 4:w // 4 + 90] = base[h // 3:h // 3 + 40, w // 4:w // 4 + 90]
+    frames = {"constant": np.full_like(base, 128), "black": np.zeros_like(base), "white": np.full_like(base, 255),
+              "saturated": np.where(sel, 255, 255 - base // 8), "dark": np.where(sel, base // 32, base // 4),
+              "levels16": np.where(sel, (base // 16) * 16 + 8, base), "two_levels": np.where(base > 128, 200, 17),
+              "flat_blocks": blocks, "flat_blocks_with_island": island}
+    for name, f in frames.items():
+        img = np.clip(f, 0, 255).astype(np.uint8)
+        ref = oracle.Pyramid(oracle.clahe(img, 3.0, tiles[0], tiles[1]), 9, 3)
+        for force in (2, 1, 0):
+            with gpu_ctx.options(clahe_strips=force):
+                P = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build_clahe(img, 3.0, tiles[0], tiles[1])
+            for lvl in range(P.levels):
+                assert np.array_equal(P.download(lvl, padded=True)[0], ref.level(lvl, padded=True)[0]), (name, w, h, force, lvl)
+            P.close()
+        assert np.array_equal(ov2slam_amd.CLAHE(gpu_ctx, 3.0, tiles).apply(img), oracle.clahe(img, 3.0, tiles[0], tiles[1])), name
