@@ -38,10 +38,12 @@ struct ClaheParams {
 
 // One WAVEFRONT per (tile, image), four tiles per workgroup, no workgroup barriers: 16 lanes cover one
 // tile row as aligned dwords (<= 64 bytes), so a wavefront histograms 4 rows per trip.
-//   * (round 5: FOUR staggered copies again for the wavefronts that histogram most of the tiles, and whole-dword aggregation -- the
-//     measurement below was taken on band-limited noise, where a wavefront's 64 pixels hit ~60 different bins; on a constant, an
-//     over- or an under-exposed frame they hit a handful, the ds_adds serialise and the fused kernel took 3.0x / 2.4x / 1.5x as long
-//     (tools/pre_micro.py .. entropy, profiles/r5_pre_entropy.txt).  See clahe_lut_tiles.)
+//   * (round 5: FOUR staggered copies again for the wavefronts that histogram most of the tiles.  The measurement below was taken on
+//     band-limited noise, where a wavefront's 64 pixels hit ~60 different bins; on a constant, an over- or an under-exposed frame they
+//     hit a handful, the ds_adds serialise and the fused pre-processing took 3.0x / 2.5x / 1.45x as long (tools/pre_micro.py .. entropy).
+//     Four copies: 1.30x / 1.20x / 0.98x, +1.5 % on noise.  Adding a dword that many lanes share once with the lane count as weight
+//     was built as well: tested per row group it costs 15 % on noise, tested per tile it gains nothing over the copies -- not kept;
+//     two copies leave 1.5x, eight lose to their LDS footprint: profiles/r5_clahe_histogram_variants.txt.)
 //   * ONE 256-bin histogram per wavefront.  Rounds 1-2 kept 8 staggered copies against same-address / same-bank collisions
 //     of neighbouring pixels; measured in round 3 (OV2SLAM_HIP_LIB A/B builds, tools/pre_micro.py): 16, 8, 4, 2 and 1 copies run
 //     within noise of each other (16: slower, occupancy), and so does a build with 27 % fewer vector instructions: the kernel is
@@ -64,7 +66,10 @@ __device__ __forceinline__ void clahe_wave_sync()
 #endif                    // apply: 8 loads hit, 16 no stores, 32 no LUT look-ups, 64 no blend
 #define CH_WAVE_DW 256               // dwords of a one-copy histogram
 #define CH_CSTRIDE 264               // dwords between the copies of a multi-copy histogram: bin b of copy c sits in LDS bank (b + 8 c) % 64
+#ifndef CH_NCOPY
 #define CH_NCOPY 4                   // copies of the wavefronts that histogram most tiles (k_clahe_lut; the LUT wavefronts of the fused kernel)
+#endif
+                                     // (A/B builds: tools/build_variant.sh .. -DCH_NCOPY=..; profiles/r5_clahe_histogram_variants.txt)
 #define CH_MULTI_DW (CH_NCOPY * CH_CSTRIDE)
 typedef uint32_t c_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -76,8 +81,7 @@ __device__ __forceinline__ int c_dpp0(int v) { return __builtin_amdgcn_update_dp
 // strip kernel (LUTs stay in LDS).
 // ncopy (wave-uniform, 1 or CH_NCOPY): copies of the histogram, CH_CSTRIDE dwords apart; a lane adds into copy (lane ^ lane >> 4) % ncopy
 // (horizontal and vertical neighbours -- similar grey levels -- go to different copies and different banks).  Low-entropy frames:
-// with one copy every equal pair of the 64 pixels of a ds_add serialises; four copies bound that, and a dword that many lanes hold
-// (flat, saturated or black regions: 0xFFFFFFFF, 0x00000000) is added ONCE per byte with the lane count as weight.
+// with one copy every equal pair of the 64 pixels of a ds_add serialises; four copies bound the serialisation at 16 lanes.
 template <bool SRC_ALIGNED, class StoreLut>          // true: rows and base are 4-byte aligned (phase 0 everywhere: cheap addressing)
 __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint8_t *img, uint32_t *hw, int lane, int t, int t_end, int tstride,
                                                 StoreLut store_lut, int ncopy = 1)
@@ -169,14 +173,6 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
             const int p_same = 4 * l16 - (int)(cur_ph & 3);
             uint32_t w0 = wgt(p_same), w1 = wgt(p_same + 1), w2 = wgt(p_same + 2), w3 = wgt(p_same + 3);
             bool mine = p_same < P.tw;                              // this lane's dword holds at least one tile byte
-            // which lanes weigh byte k of their dword once / twice (wave-uniform masks: the weights depend on the lane's column only)
-            uint64_t m1[4], m2[4];
-            if (same_phase) {
-                m1[0] = __builtin_amdgcn_ballot_w64(mine && w0 >= 1u); m2[0] = __builtin_amdgcn_ballot_w64(mine && w0 == 2u);
-                m1[1] = __builtin_amdgcn_ballot_w64(mine && w1 >= 1u); m2[1] = __builtin_amdgcn_ballot_w64(mine && w1 == 2u);
-                m1[2] = __builtin_amdgcn_ballot_w64(mine && w2 >= 1u); m2[2] = __builtin_amdgcn_ballot_w64(mine && w2 == 2u);
-                m1[3] = __builtin_amdgcn_ballot_w64(mine && w3 >= 1u); m2[3] = __builtin_amdgcn_ballot_w64(mine && w3 == 2u);
-            }
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (!same_phase) {                                   // wave-uniform: rows of an unaligned image differ in phase
@@ -184,29 +180,9 @@ __device__ __forceinline__ void clahe_lut_tiles(const ClaheParams &P, const uint
                     w0 = wgt(p0); w1 = wgt(p0 + 1); w2 = wgt(p0 + 2); w3 = wgt(p0 + 3);
                     mine = p0 < P.tw;
                 }
-                const bool act = mine && 4 * i + sub < P.th;
-                const uint32_t v = cur[i];
-                if (CLAHE_KO & 2) { if (act && v == 0x12345678u) hw[0] = 1; continue; }
-                bool todo = act;
-                if (same_phase) {
-                    // one dword shared by many lanes (a flat region): its four bytes go in once, weighted by the lanes that hold it
-                    const uint64_t m_act = __builtin_amdgcn_ballot_w64(act);
-                    if (m_act != 0) {
-                        const int ld = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m_act));
-                        const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)v, ld);
-                        const uint64_t m_eq = __builtin_amdgcn_ballot_w64(act && v == v0);
-                        if (__builtin_popcountll(m_eq) >= 12) {
-                            if (lane == ld) {
-                                atomicAdd(&hist[v0 & 0xFF], (uint32_t)(__builtin_popcountll(m_eq & m1[0]) + __builtin_popcountll(m_eq & m2[0])));
-                                atomicAdd(&hist[(v0 >> 8) & 0xFF], (uint32_t)(__builtin_popcountll(m_eq & m1[1]) + __builtin_popcountll(m_eq & m2[1])));
-                                atomicAdd(&hist[(v0 >> 16) & 0xFF], (uint32_t)(__builtin_popcountll(m_eq & m1[2]) + __builtin_popcountll(m_eq & m2[2])));
-                                atomicAdd(&hist[v0 >> 24], (uint32_t)(__builtin_popcountll(m_eq & m1[3]) + __builtin_popcountll(m_eq & m2[3])));
-                            }
-                            todo = act && v != v0;
-                        }
-                    }
-                }
-                if (todo) {
+                if (mine && 4 * i + sub < P.th) {
+                    const uint32_t v = cur[i];
+                    if (CLAHE_KO & 2) { if (v == 0x12345678u) hw[0] = 1; continue; }
                     atomicAdd(&hist[v & 0xFF], w0);
                     atomicAdd(&hist[(v >> 8) & 0xFF], w1);
                     atomicAdd(&hist[(v >> 16) & 0xFF], w2);
