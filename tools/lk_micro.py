@@ -24,7 +24,10 @@ L.check(lib.ov2_pyr_build_d(ctx.h, P0.h_pyr, vp(fr[0]), W, W * H)); L.check(lib.
 k = torch.from_numpy(kps[0]).to(dev); p0 = torch.from_numpy(pri[0]).to(dev); p = p0.clone()
 st = torch.zeros((S, NK), dtype=torch.uint8, device=dev); stats = torch.zeros(2, dtype=torch.int64, device=dev)
 print("S=%d points=%d" % (S, S * NK))
-for lvl, mi in ((3, 30), (3, 1), (3, 0), (0, 30), (0, 1), (0, 0), (1, 30)):
+cases = ((3, 30), (3, 1), (3, 0), (0, 30), (0, 1), (0, 0), (1, 30))
+if len(sys.argv) > 2 and sys.argv[2] == "cap":          # Gauss-Newton trip cap sweep: the upper bound of what "cap in-wave, finish the stragglers in a second launch" can gain
+    cases = tuple((lv, mi) for lv in (3, 1) for mi in (30, 12, 8, 6, 5, 4, 3, 2, 1, 0))
+for lvl, mi in cases:
     ts = []
     for rep in range(6):
         p.copy_(p0); stats.zero_()
