@@ -515,6 +515,18 @@ typedef struct {
 } ov2_local_ba_result;
 void ov2_local_ba_default_options(ov2_local_ba_options *o);
 int  ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r);
+/* The same protocol for n problems at once -- the estimator side of the lock-step batch of sequences (BASELINE configs[4]; the
+ * reference runs one Optimizer::localBA per sequence on that sequence's estimator thread, src/estimator.cpp:71-93).  Every kernel
+ * of the solver is launched ONCE for the batch (grid.z = problem; a problem that has converged, or takes no second pass, drops
+ * out inside the kernels), so n solves cost the launches of one and the one-work-group kernels (factorisation, trust-region
+ * bookkeeping) run side by side.  p, o, r: n entries each; the entries of o share robust_mono_th, use_robust_cost,
+ * apply_l2_after_robust, pass1 and pass2 (OV2_EINVAL otherwise) -- stop_requested / stop_flag are per problem and read after the
+ * first pass of the batch.  Per problem the result is what ov2_local_ba returns for it (same device code; floating-point sums
+ * over work-groups are grouped by the batch's grid: parity 1e-7, tests/test_gpu_ba_batch.py); solve_ms is the device time of
+ * the batch's pass.  Problems the shared launches do not cover (more optimised keyframes than the LDS-resident path holds,
+ * OV2_RES_PNP blocks, no landmarks, OV2_OPT_BA_DETERMINISTIC) are solved one after the other through ov2_local_ba in the same
+ * call; *n_batched (or NULL) = how many shared the launches.  max_solver_time_s bounds the batch's pass.                      */
+int  ov2_local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r, int *n_batched);
 
 /* ------------------------------------------------------------------ */
 /* Optimizer::structureOnlyBA                                           */

@@ -210,6 +210,7 @@ SIGNATURES = {
     "ov2_ba_destroy": (None, [_vp]),
     "ov2_local_ba_default_options": (None, [C.POINTER(LocalBAOptions)]),
     "ov2_local_ba": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(LocalBAOptions), C.POINTER(LocalBAResult)]),
+    "ov2_local_ba_batch": (_i, [_vp, _i, C.POINTER(BAProblem), C.POINTER(LocalBAOptions), C.POINTER(LocalBAResult), C.POINTER(_i)]),
 }
 
 OV2_ABI_VERSION = 500          # include/ov2slam_hip.h

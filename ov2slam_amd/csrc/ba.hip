@@ -144,6 +144,13 @@ struct BADev {                    // device pointers + sizes (passed by value to
     uint8_t *bad_obs;             // n_res (caller order): outlier verdicts of k_ba_mark_outliers
     int *lba_cnt;                 // 8 counters of k_ba_mark_outliers
     BACtl *ctl;
+    // lock-step batch of problems (ov2_local_ba_batch: one launch per kernel, blockIdx.z = problem): what the single-problem launches
+    // pass as kernel arguments or decide on the host, per problem
+    int g_ntiles, g_nupper, g_lmps, g_ksplit;     // k_ba_schur_gemm's tile count / upper tiles / landmarks per split / splits
+    const int *lm_order_b;                        // the lineariser's anchor-sorted landmark order
+    const double *pose0, *lam0;                   // the problem's initial parameters (7 n_kf, n_lm)
+    int n_res;                                    // residual blocks of the caller's arrays (chi2 / dpos / bad_obs entries)
+    int skip2;                                    // the problem takes no second pass (no outliers / stop requested): its second outlier test is skipped
 };
 
 __device__ __forceinline__ bool d_lm_has(const BADev &D, int lm)
@@ -538,7 +545,7 @@ __device__ __forceinline__ void h_add_upper(double *H, int ld, int r, int c, dou
 // the per-wave reduction scratch and the observers' diagonal blocks / F^T b; anchor-observer blocks go to H with global atomics,
 // the landmark's W entries to their slots in cww.
 template <bool BIG>
-__global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__restrict__ lm_order)
+__device__ __forceinline__ void b_ba_linearize(const BADev &D, const int *__restrict__ lm_order)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->need_lin) return;
@@ -794,6 +801,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__rest
     __syncthreads();
     if (threadIdx.x == 0 && D.part) { double g = 0; for (int w = 0; w < wpb; w++) g = fmax(g, s_gm[w]); D.part[6 * BA_PART_MAX + blockIdx.x] = g; }
 }
+template <bool BIG>
+__global__ __launch_bounds__(256) void k_ba_linearize(BADev D, const int *__restrict__ lm_order) { b_ba_linearize<BIG>(D, lm_order); }
+__global__ __launch_bounds__(256) void k_ba_linearize_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; b_ba_linearize<false>(D, D.lm_order_b); }
 
 // ---------------------------------------------------------------------------------- pose-only residual blocks
 // rows without an e-block (Ceres: SchurEliminator::NoEBlockRowsUpdate): F^T F / F^T b pre-aggregated per workgroup in LDS.
@@ -855,7 +865,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize_po(BADev D)
 }
 
 // ---------------------------------------------------------------------------------- cost only
-__global__ __launch_bounds__(256) void k_ba_cost(BADev D)
+__device__ __forceinline__ void b_ba_cost(const BADev &D)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done || !ctl->step_valid) return;
@@ -898,6 +908,8 @@ __global__ __launch_bounds__(256) void k_ba_cost(BADev D)
     cost = block_sum(cost, s_part);
     if (threadIdx.x == 0) D.part[5 * BA_PART_MAX + blockIdx.x] = cost;      // summed by k_ba_decide
 }
+__global__ __launch_bounds__(256) void k_ba_cost(BADev D) { b_ba_cost(D); }
+__global__ __launch_bounds__(256) void k_ba_cost_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; b_ba_cost(D); }
 
 // ---------------------------------------------------------------------------------- deterministic mode: the linearisers' copies, in order
 // H = sum of the det_lin + det_po copies (upper-triangle tiles), F^T b likewise, the cost; the copies are cleared for the next
@@ -939,7 +951,7 @@ __global__ __launch_bounds__(256) void k_ba_det_reduce(BADev D)
 }
 
 // ---------------------------------------------------------------------------------- iteration begin (1 block)
-__global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int seq)
+__device__ __forceinline__ void b_ba_iter_begin(const BADev &D, BAOpt O, int seq)
 {
     BACtl *ctl = D.ctl;
     (void)seq;
@@ -1032,10 +1044,12 @@ __global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int se
     __syncthreads();
     if (tid == 0) ctl->reuse_diag = 1;
 }
+__global__ __launch_bounds__(1024) void k_ba_iter_begin(BADev D, BAOpt O, int seq) { b_ba_iter_begin(D, O, seq); }
+__global__ __launch_bounds__(1024) void k_ba_iter_begin_B(const BADev *__restrict__ arr, BAOpt O, int seq) { const BADev &D = arr[blockIdx.z]; b_ba_iter_begin(D, O, seq); }
 
 // ---------------------------------------------------------------------------------- W^T C W (+ W^T (c etb))
 // grid: (n_upper_tiles, ksplit); block 256 threads, each thread a 2x2 patch of a 32x32 tile
-__global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int lm_per_split)
+__device__ __forceinline__ void b_ba_schur_gemm(const BADev &D, int ntiles, int lm_per_split)
 {
     if (D.ctl->done) return;
     // decode upper-triangular tile index
@@ -1113,6 +1127,8 @@ __global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int 
     }
     if (ti == tj && tid < BA_TILE && vacc != 0.0) atomicAdd(&D.v[ti * BA_TILE + tid], vacc);
 }
+__global__ __launch_bounds__(256) void k_ba_schur_gemm(BADev D, int ntiles, int lm_per_split) { b_ba_schur_gemm(D, ntiles, lm_per_split); }
+__global__ __launch_bounds__(256) void k_ba_schur_gemm_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; if ((int)blockIdx.x >= D.g_nupper || (int)blockIdx.y >= D.g_ksplit) return; b_ba_schur_gemm(D, D.g_ntiles, D.g_lmps); }
 
 // ---------------------------------------------------------------------------------- reduced system (1 block)
 // S = s_i s_j (H_ij - G_ij) + delta_ij diag_i / radius ; rhs = s_i (b_i - v_i); blocked Cholesky; solve.
@@ -1291,7 +1307,7 @@ __device__ __forceinline__ void chol_backward_blocks(const BADev &D, double *yv,
 }
 
 // lower triangle of S, one thread per entry, many workgroups (latency-bound gathers from H and G)
-__global__ __launch_bounds__(256) void k_ba_assemble(BADev D)
+__device__ __forceinline__ void b_ba_assemble(const BADev &D)
 {
     const BACtl *ctl = D.ctl;
     if (ctl->done) return;
@@ -1309,8 +1325,10 @@ __global__ __launch_bounds__(256) void k_ba_assemble(BADev D)
     D.S[(long long)i * ld + j] = val;
     (void)n;
 }
+__global__ __launch_bounds__(256) void k_ba_assemble(BADev D) { b_ba_assemble(D); }
+__global__ __launch_bounds__(256) void k_ba_assemble_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; if ((int)blockIdx.y >= D.nf) return; b_ba_assemble(D); }
 
-__global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
+__device__ __forceinline__ void b_ba_cholesky(const BADev &D)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
@@ -1624,6 +1642,8 @@ __global__ __launch_bounds__(512) void k_ba_cholesky(BADev D)
     if (tid == 0) for (int i = 0; i < 6; i++) ctl->dbg[i] = tk[i];
 #undef CH_TICK
 }
+__global__ __launch_bounds__(512) void k_ba_cholesky(BADev D) { b_ba_cholesky(D); }
+__global__ __launch_bounds__(512) void k_ba_cholesky_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; b_ba_cholesky(D); }
 
 // ================================================================================== pose-only problems in ONE kernel
 // MultiViewGeometry::ceresPnP (src/multi_view_geometry.cpp:492-586): one free pose, a few hundred fixed world points.  The
@@ -2031,7 +2051,7 @@ __global__ __launch_bounds__(512) void k_chol_solve(BADev D)
 
 // ---------------------------------------------------------------------------------- back substitution
 // one wavefront per landmark: t_l = W_l . (s .* yf); y_l = s_l (etb_l - t_l) / etep_l
-__global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
+__device__ __forceinline__ void b_ba_backsub(const BADev &D)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
@@ -2107,9 +2127,11 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BADev D)
         if (anybad) atomicOr(&ctl->bad_step, 1);
     }
 }
+__global__ __launch_bounds__(256) void k_ba_backsub(BADev D) { b_ba_backsub(D); }
+__global__ __launch_bounds__(256) void k_ba_backsub_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; b_ba_backsub(D); }
 
 // ---------------------------------------------------------------------------------- candidate (1 block)
-__global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
+__device__ __forceinline__ void b_ba_candidate(const BADev &D, BAOpt O)
 {
     BACtl *ctl = D.ctl;
     if (ctl->done) return;
@@ -2169,9 +2191,11 @@ __global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O)
         for (int l = tid; l < D.n_lm * D.ldim; l += nt) c_lam[l] = x_lam[l] - yl[l] * scale_l[l];
     }
 }
+__global__ __launch_bounds__(1024) void k_ba_candidate(BADev D, BAOpt O) { b_ba_candidate(D, O); }
+__global__ __launch_bounds__(1024) void k_ba_candidate_B(const BADev *__restrict__ arr, BAOpt O) { const BADev &D = arr[blockIdx.z]; b_ba_candidate(D, O); }
 
 // ---------------------------------------------------------------------------------- decision (1 block)
-__global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O, int seq)
+__device__ __forceinline__ void b_ba_decide(const BADev &D, BAOpt O, int seq)
 {
     BACtl *ctl = D.ctl;
     // The host's look-ahead control (ba_run): the outcome of iteration seq goes into pinned host memory on every way out of this
@@ -2237,6 +2261,8 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O, int seq)
     }
     for (int e = tid; e < D.nfp; e += nt) D.bf[e] = 0;
 }
+__global__ __launch_bounds__(1024) void k_ba_decide(BADev D, BAOpt O, int seq) { b_ba_decide(D, O, seq); }
+__global__ __launch_bounds__(1024) void k_ba_decide_B(const BADev *__restrict__ arr, BAOpt O, int seq) { const BADev &D = arr[blockIdx.z]; b_ba_decide(D, O, seq); }
 
 // ================================================================================== 3-D point landmarks (ldim = 3)
 // Optimizer::localBA / looseBA / fullBA with buse_inv_depth: 0 (src/optimizer.cpp:207-209, :333-384): every observation is
@@ -2466,7 +2492,7 @@ __global__ __launch_bounds__(256) void k_ba_cost_xyz(BADev D)
 }
 
 // cached R | t of every pose; scales = 1 (Jacobi scaling, when on, overwrites them at the first k_ba_iter_begin)
-__global__ __launch_bounds__(256) void k_ba_init(BADev D)
+__device__ __forceinline__ void b_ba_init(const BADev &D)
 {
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     for (long long k = i0; k < D.n_kf; k += stride) d_pose_to_RT(D.x_pose + 7 * k, D.x_RT + 12 * k);
@@ -2474,6 +2500,8 @@ __global__ __launch_bounds__(256) void k_ba_init(BADev D)
     const long long NL = (long long)D.n_lm * D.ldim;
     for (long long l = i0; l < NL; l += stride) { D.scale_l[l] = 1.0; if (D.ldim == 3) D.ones[l] = 1.0; }
 }
+__global__ __launch_bounds__(256) void k_ba_init(BADev D) { b_ba_init(D); }
+__global__ __launch_bounds__(256) void k_ba_init_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; b_ba_init(D); }
 
 // ---------------------------------------------------------------------------------- host
 // ---------------------------------------------------------------------------------- resident two-pass localBA
@@ -2481,7 +2509,7 @@ __global__ __launch_bounds__(256) void k_ba_init(BADev D)
 // device: a residual block still in the problem is an outlier when its cached chi2err_ (the value of the LAST Evaluate, N4)
 // exceeds the threshold or its depth was not positive; with `deactivate` it is removed from the problem.
 // cnt[0] = outliers found by this call, cnt[1] / cnt[2] = a left / right-camera block remains in the problem (:606-608).
-__global__ __launch_bounds__(256) void k_ba_mark_outliers(BADev D, double th, int deactivate, uint8_t *__restrict__ snapshot)
+__device__ __forceinline__ void b_ba_mark_outliers(const BADev &D, double th, int deactivate, uint8_t *__restrict__ snapshot)
 {
     int nbad = 0, left = 0, right = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < D.n_act; k += gridDim.x * blockDim.x) {
@@ -2511,9 +2539,11 @@ __global__ __launch_bounds__(256) void k_ba_mark_outliers(BADev D, double th, in
         if (s_cnt[2]) atomicOr(&D.lba_cnt[2], 1);
     }
 }
+__global__ __launch_bounds__(256) void k_ba_mark_outliers(BADev D, double th, int deactivate, uint8_t *__restrict__ snapshot) { b_ba_mark_outliers(D, th, deactivate, snapshot); }
+__global__ __launch_bounds__(256) void k_ba_mark_outliers_B(const BADev *__restrict__ arr, double th, int deactivate, uint8_t *__restrict__ snapshot) { const BADev &D = arr[blockIdx.z]; if (D.skip2) return; b_ba_mark_outliers(D, th, deactivate, snapshot); }
 
 // a landmark whose residual blocks were all removed leaves the program (its inverse depth keeps its value)
-__global__ __launch_bounds__(256) void k_ba_lm_live(BADev D)
+__device__ __forceinline__ void b_ba_lm_live(const BADev &D)
 {
     const int lane = threadIdx.x & 63;
     for (int lm = blockIdx.x * 4 + (threadIdx.x >> 6); lm < D.n_lm; lm += gridDim.x * 4) {
@@ -2523,6 +2553,8 @@ __global__ __launch_bounds__(256) void k_ba_lm_live(BADev D)
         if (lane == 0) D.lm_live[lm] = (uint8_t)live;
     }
 }
+__global__ __launch_bounds__(256) void k_ba_lm_live(BADev D) { b_ba_lm_live(D); }
+__global__ __launch_bounds__(256) void k_ba_lm_live_B(const BADev *__restrict__ arr) { const BADev &D = arr[blockIdx.z]; if (D.skip2) return; b_ba_lm_live(D); }
 
 struct ov2_ba_dev {
     BADev D;
@@ -2537,9 +2569,13 @@ struct ov2_ba_dev {
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static void ba_destroy(ov2_ba_dev *dev);
 
+// lock-step batch (ov2_local_ba_batch): the problems' pools and staging mirrors are consecutive slices of ONE device / pinned block
+struct BASlice { uint8_t *dev_base; size_t dev_cap, dev_used; uint8_t *host_base; size_t host_cap, host_used; };
+#define BA_SLICE_FULL (-12345)          // (internal: the caller grows the blocks and starts over)
+
 // transient: the problem lives for one ov2_ba_solve call -- small pools then come out of the context's device scratch instead of
 // a hipMalloc / hipFree pair (~100 us, more than a whole ceresPnP solve)
-static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bool transient = false)
+static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bool transient = false, BASlice *ext = nullptr)
 {
     OV2_REQUIRE(p && out, OV2_EINVAL, "NULL problem");
     OV2_REQUIRE(p->n_kf > 0 && p->n_lm >= 0 && p->n_res >= 0, OV2_EINVAL, "bad problem sizes");
@@ -2621,6 +2657,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t o_pose_col = take(4 * (size_t)p->n_kf), o_lm_ptr = take(4 * (nl + 1)), o_lm_anchor = take(4 * nl), o_lm_auv = take(16 * nl);
     const size_t o_res_type = take(na), o_res_kf = take(4 * na), o_res_orig = take(4 * na), o_res_uv = take(16 * na), o_res_sigma = take(8 * na);
     const size_t o_lm_order = take(4 * nl), o_lm_live = take(nl);
+    const size_t o_pose0 = take(56 * (size_t)p->n_kf), o_lam0 = take(8 * nl);      // initial parameters (the batch's reset kernel copies them on the device)
     const size_t up_bytes = off;                                       // [0, up_bytes) of the pool = the staging buffer
     uint8_t *hs = nullptr;
     {
@@ -2628,9 +2665,14 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         size_t hoff = up_bytes;
         auto htake = [&](size_t bytes) { const size_t o = hoff; hoff += (bytes + 255) & ~(size_t)255; return o; };
         const size_t h6 = htake(4 * np_h), h7 = htake(4 * np_h), h8 = htake(24 * np_h), h9 = htake(16 * np_h), h10 = htake(8 * np_h);
+        if (ext) {
+            if (ext->host_used + hoff > ext->host_cap) return BA_SLICE_FULL;
+            hs = ext->host_base + ext->host_used; ext->host_used += al256(hoff);
+        } else {
         const int rch = ctx->reserve_host(hoff);
         if (rch != OV2_OK) return rch;
         hs = (uint8_t *)ctx->h_scratch;
+        }
         res_kf = (int *)(hs + o_res_kf); res_orig = (int *)(hs + o_res_orig); res_type = hs + o_res_type; res_uv = (double *)(hs + o_res_uv); res_sigma = (double *)(hs + o_res_sigma);
         po_kf = (int *)(hs + h6); po_orig = (int *)(hs + h7); po_xyz = (double *)(hs + h8); po_uv = (double *)(hs + h9); po_sigma = (double *)(hs + h10);
     }
@@ -2659,11 +2701,11 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     ov2_ba_dev *dev = new (std::nothrow) ov2_ba_dev();
     OV2_REQUIRE(dev != nullptr, OV2_ENOMEM, "out of host memory");
     dev->device = ctx->device; dev->n_res = p->n_res;
-    dev->h_poses0.assign(p->poses, p->poses + 7 * (size_t)p->n_kf);
-    dev->h_lam0.assign(p->invdepth, p->invdepth + (p->n_lm > 0 ? p->n_lm : 0));
+    if (!ext) dev->h_poses0.assign(p->poses, p->poses + 7 * (size_t)p->n_kf);
+    if (!ext) dev->h_lam0.assign(p->invdepth, p->invdepth + (p->n_lm > 0 ? p->n_lm : 0));
     BADev &D = dev->D;
     memset(&D, 0, sizeof(D));
-    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1;
+    D.n_kf = p->n_kf; D.n_lm = p->n_lm; D.n_act = n_act; D.nf = nf; D.nfp = nfp; D.n_po = n_po; D.ldim = 1; D.n_res = p->n_res;
     {   // beyond what the LDS-resident lineariser / Cholesky hold (~90 optimised keyframes): sparse W + HBM Cholesky (BADev::big)
         const size_t lin_lds = 8 * (8 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 21 + 4 * (size_t)LIN_RED) + 64;
         const size_t chol_lds = chol_lds_bytes(nf, nfp);
@@ -2720,7 +2762,10 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t npo = (size_t)std::max(1, n_po);
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
-    if (transient && off <= ((size_t)64 << 20)) {                      // (the context keeps the largest pool it has seen: grow-only scratch)
+    if (ext) {
+        if (ext->dev_used + off > ext->dev_cap) { delete dev; return BA_SLICE_FULL; }
+        dev->pool = ext->dev_base + ext->dev_used; dev->pool_owned = false; ext->dev_used += al256(off);
+    } else if (transient && off <= ((size_t)64 << 20)) {               // (the context keeps the largest pool it has seen: grow-only scratch)
         const int rcs = ctx->reserve_device(off);
         if (rcs != OV2_OK) { delete dev; return rcs; }
         dev->pool = ctx->d_scratch; dev->pool_owned = false;
@@ -2742,6 +2787,7 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     D.bf = (double *)(b + o_bf); D.v = (double *)(b + o_v); D.yf = (double *)(b + o_yf); D.yl = (double *)(b + o_yl);
     D.chi2 = (double *)(b + o_chi2); D.dpos = b + o_dpos; D.ctl = (BACtl *)(b + o_ctl);
     dev->lm_order = (int *)(b + o_lm_order);
+    D.lm_order_b = dev->lm_order; D.pose0 = (const double *)(b + o_pose0); D.lam0 = (const double *)(b + o_lam0);
     D.res_off = b + o_res_off; D.lm_live = b + o_lm_live; D.bad_obs = b + o_bad_obs; D.lba_cnt = (int *)(b + o_lba_cnt);
     D.po_kf = (int *)(b + o_po_kf); D.po_orig = (int *)(b + o_po_orig); D.po_xyz = (double *)(b + o_po_xyz); D.po_uv = (double *)(b + o_po_uv); D.po_sigma = (double *)(b + o_po_sigma);
     for (int i = 0; i < 4; i++) { D.calib_l[i] = p->calib_l[i]; D.calib_r[i] = p->calib_r[i]; }
@@ -2767,9 +2813,11 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         memcpy(hs + o_pose_col, pose_col.data(), 4 * (size_t)p->n_kf);
         memcpy(hs + o_lm_ptr, cnt.data(), 4 * ((size_t)p->n_lm + 1));
         if (p->n_lm > 0) { memcpy(hs + o_lm_anchor, p->lm_anchor_kf, 4 * (size_t)p->n_lm); memcpy(hs + o_lm_auv, p->lm_anchor_uv, 16 * (size_t)p->n_lm); }
+        memcpy(hs + o_pose0, p->poses, 56 * (size_t)p->n_kf);
+        if (p->n_lm > 0) memcpy(hs + o_lam0, p->invdepth, 8 * (size_t)p->n_lm);
     }
-    UP(b, hs, up_bytes);                                               // ONE copy: pose_col .. lm_live
-    {
+    UP(b, hs, up_bytes);                                               // ONE copy: pose_col .. lam0
+    if (!ext) {                                                        // (batch: k_ba_reset_B clears them)
         hipError_t em = hipMemsetAsync(D.res_off, 0, na, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.bad_obs, 0, nr, s);
         if (em == hipSuccess) em = hipMemsetAsync(D.lba_cnt, 0, 64, s);
@@ -2783,8 +2831,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         UP(D.kfl_ptr, kfl_ptr.data(), 4 * ((size_t)n_opt + 1)); UP(D.kfl_idx, kfl_idx.data(), 4 * (size_t)D.n_cw);
     }
 #undef UP
-    // the staging vectors die at return: make sure the copies are done
-    {
+    // the staging vectors die at return: make sure the copies are done (a batch slice's staging lives until the batch is through)
+    if (!ext || D.big) {
         const hipError_t es = hipStreamSynchronize(s);
         if (es != hipSuccess) { ov2_set_error("hipStreamSynchronize: %s", hipGetErrorString(es)); ba_destroy(dev); return OV2_EHIP; }
     }
@@ -3169,6 +3217,330 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     return OV2_OK;
 }
 
+
+// ================================================================================== lock-step batch of local-BA problems
+// BASELINE configs[4]: eleven sequences advance in lock step on one GPU (ov2_btracker_*), their keyframes arrive together -- and
+// eleven estimator threads with a stream each then push ~100 launches per solve through the command processor, where they queue
+// behind each other and behind the front end's (round 5: 5.8 ms of wall clock per 0.9 ms solve, the SLAM thread 1.8x slower).
+// Here the problems of one step share every launch: blockIdx.z = problem, the kernels read their BADev from an array in device
+// memory instead of the kernel arguments, a problem that has converged (or takes no second pass) leaves through the kernels'
+// `if (ctl->done) return`.  The one-work-group kernels (factorisation, bookkeeping) so run on as many CUs as there are problems.
+// The arithmetic of a problem is that of ov2_local_ba (same device functions); grids are the largest any problem of the batch
+// needs, the per-work-group partial sums are added in a different grouping when a problem runs on a larger grid than alone.
+__global__ __launch_bounds__(256) void k_ba_reset_B(const BADev *__restrict__ arr, BACtl ctl0, int keep_state)
+{
+    const BADev &D = arr[blockIdx.z];
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (i0 == 0) { BACtl c = ctl0; if (keep_state && D.skip2) { c.done = 1; c.need_lin = 0; } *D.ctl = c; }
+    if (keep_state && D.skip2) return;
+    if (!keep_state) {
+        for (long long e = i0; e < 7LL * D.n_kf; e += stride) D.x_pose[e] = D.pose0[e];
+        for (long long e = i0; e < D.n_lm; e += stride) D.x_lam[e] = D.lam0[e];
+        unsigned long long *chi = (unsigned long long *)D.chi2;
+        for (long long e = i0; e < D.n_res; e += stride) { chi[e] = ~0ULL; D.dpos[e] = 0; D.bad_obs[e] = 0; }     // (NaN pattern: never evaluated)
+        for (long long e = i0; e < D.n_act; e += stride) D.res_off[e] = 0;
+    }
+    const long long nn = (long long)D.nfp * D.nfp;
+    for (long long e = i0; e < nn; e += stride) { D.H[e] = 0; D.G[e] = 0; }
+    for (long long e = i0; e < D.nfp; e += stride) { D.bf[e] = 0; D.yf[e] = 0; }
+}
+
+static bool ba_small_path(int n_opt)
+{
+    const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
+    const size_t lin_lds = 8 * (8 * (size_t)nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 21 + 4 * (size_t)LIN_RED) + 64;
+    return !(lin_lds > 159 * 1024 || chol_lds_bytes(nf, nfp) > 150 * 1024 || nf > CH_MAX_LDS_N);
+}
+
+struct BABatch {
+    std::vector<ov2_ba_dev *> devs;
+    BADev *h_arr = nullptr, *d_arr = nullptr;           // the problems' device views: pinned staging / device copy
+    BACtl *h_ctl = nullptr, *d_ctl = nullptr;           // control blocks, consecutive (one download per pass)
+    int *h_cnt = nullptr, *d_cnt = nullptr;             // 16 counters per problem (k_ba_mark_outliers)
+    volatile int *h_flag = nullptr;                     // the look-ahead words of k_ba_decide
+    bool lm_live_first = false;                         // second pass: landmarks that lost all their blocks leave the program first
+    ~BABatch() { for (ov2_ba_dev *d : devs) ba_destroy(d); }
+};
+
+// one LM solve of every problem of the batch (ba_run's loop on batched launches); skip[i]: the problem sits this pass out
+static int ba_run_batch(ov2_ctx *ctx, BABatch &B, const ov2_ba_options *o, const double *huber, const uint8_t *skip, bool keep_state, float *ms_out)
+{
+    OV2_REQUIRE(o->max_iter >= 0 && o->initial_radius > 0 && o->min_lm_diagonal > 0 && o->min_lm_diagonal <= o->max_lm_diagonal,
+                OV2_EINVAL, "bad solver options");
+    const int N = (int)B.devs.size();
+    hipStream_t s = ctx->stream;
+    BAOpt O;
+    O.max_iter = o->max_iter; O.ftol = o->function_tolerance; O.gtol = o->gradient_tolerance; O.ptol = o->parameter_tolerance;
+    O.max_radius = o->max_radius; O.min_radius = o->min_radius; O.min_diag = o->min_lm_diagonal; O.max_diag = o->max_lm_diagonal;
+    O.min_rel_decrease = o->min_relative_decrease; O.jacobi = o->jacobi_scaling; O.max_invalid = o->max_consecutive_invalid_steps;
+    int lin_blocks = 1, bs_blocks = 1, cost_blocks = 1, nupper = 1, ksplit_max = 1, nf_max = 0, nfp_max = 0, reset_blocks = 1, init_blocks = 1;
+    size_t lin_lds = 0, chol_lds = 0;
+    for (int i = 0; i < N; i++) {
+        const BADev &D = B.devs[(size_t)i]->D;
+        const int n_opt = D.nf / 6;
+        lin_lds = std::max(lin_lds, 8 * (8 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 21 + 4 * (size_t)LIN_RED) + 64);
+        chol_lds = std::max(chol_lds, chol_lds_bytes(D.nf, D.nfp));
+        lin_blocks = std::max(lin_blocks, std::min(256, (D.n_lm + 15) / 16));
+        bs_blocks = std::max(bs_blocks, std::min(2048, (D.n_lm + 15) / 16));
+        cost_blocks = std::max(cost_blocks, std::min(2048, (D.n_lm + 7) / 8));
+        nf_max = std::max(nf_max, D.nf); nfp_max = std::max(nfp_max, D.nfp);
+        reset_blocks = std::max(reset_blocks, (int)std::min<size_t>(256, ((size_t)std::max(D.n_res, D.nfp * D.nfp) + 1023) / 1024));
+        init_blocks = std::max(init_blocks, (int)std::min<size_t>(1024, ((size_t)std::max(std::max(D.n_kf, D.nfp), D.n_lm) + 255) / 256));
+    }
+    OV2_REQUIRE(lin_lds <= 159 * 1024 && chol_lds <= 150 * 1024, OV2_EUNSUPPORTED, "a problem of the batch is too large for the LDS-resident path");
+    for (int i = 0; i < N; i++) {
+        BADev D = B.devs[(size_t)i]->D;
+        D.huber = huber[i]; D.min_diag = o->min_lm_diagonal; D.max_diag = o->max_lm_diagonal;
+        D.bs_blocks = bs_blocks; D.cost_blocks = cost_blocks; D.lin_blocks = lin_blocks;
+        const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
+        int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
+        const int lmps = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
+        ksplit = std::max(1, (D.n_lm + lmps - 1) / lmps);
+        D.g_ntiles = ntiles; D.g_nupper = n_upper; D.g_lmps = lmps; D.g_ksplit = ksplit;
+        nupper = std::max(nupper, n_upper); ksplit_max = std::max(ksplit_max, ksplit);
+        D.skip2 = skip && skip[i] ? 1 : 0;
+        D.flag_h = (int *)(B.h_flag + i);
+        D.ctl = B.d_ctl + i; D.lba_cnt = B.d_cnt + 16 * i;
+        B.h_arr[i] = D;
+        B.h_flag[i] = -1;
+    }
+    OV2_HIP_CHECK(hipMemcpyAsync(B.d_arr, B.h_arr, sizeof(BADev) * (size_t)N, hipMemcpyHostToDevice, s));
+    struct EvPair { hipEvent_t e0 = nullptr, e1 = nullptr; ~EvPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); } } ev;
+    OV2_HIP_CHECK(hipEventCreate(&ev.e0));
+    OV2_HIP_CHECK(hipEventCreate(&ev.e1));
+    OV2_HIP_CHECK(hipEventRecord(ev.e0, s));
+    BACtl c0;
+    memset(&c0, 0, sizeof(c0));
+    c0.radius = o->initial_radius; c0.decrease_factor = 2.0; c0.x_norm = -1.0;
+    c0.need_lin = 1; c0.step_successful = 1; c0.termination = OV2_TERM_NO_CONVERGENCE;
+    const BADev *A = B.d_arr;
+    const unsigned Z = (unsigned)N;
+    if (B.lm_live_first) {
+        int ll = 1;
+        for (int i = 0; i < N; i++) ll = std::max(ll, std::min(512, (B.devs[(size_t)i]->D.n_lm + 3) / 4));
+        hipLaunchKernelGGL(k_ba_lm_live_B, dim3(ll, 1, Z), dim3(256), 0, s, A);
+    }
+    hipLaunchKernelGGL(k_ba_reset_B, dim3(reset_blocks, 1, Z), dim3(256), 0, s, A, c0, keep_state ? 1 : 0);
+    hipLaunchKernelGGL(k_ba_init_B, dim3(init_blocks, 1, Z), dim3(256), 0, s, A);
+    auto linearize = [&]() { hipLaunchKernelGGL(k_ba_linearize_B, dim3(lin_blocks, 1, Z), dim3(256), lin_lds, s, A); };
+    auto first_half = [&](int it) {
+        hipLaunchKernelGGL(k_ba_iter_begin_B, dim3(1, 1, Z), dim3(1024), 0, s, A, O, it);
+        hipLaunchKernelGGL(k_ba_schur_gemm_B, dim3(nupper, ksplit_max, Z), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_ba_assemble_B, dim3((nf_max + 255) / 256, nf_max, Z), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_ba_cholesky_B, dim3(1, 1, Z), dim3(512), chol_lds, s, A);
+    };
+    auto second_half = [&](int it) {
+        hipLaunchKernelGGL(k_ba_backsub_B, dim3(bs_blocks, 1, Z), dim3(256), (size_t)nfp_max * 8, s, A);
+        hipLaunchKernelGGL(k_ba_candidate_B, dim3(1, 1, Z), dim3(1024), 0, s, A, O);
+        hipLaunchKernelGGL(k_ba_cost_B, dim3(cost_blocks, 1, Z), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_ba_decide_B, dim3(1, 1, Z), dim3(1024), 0, s, A, O, it);
+        linearize();
+    };
+    linearize();
+    const auto t_start = std::chrono::steady_clock::now();
+    for (int it = 0; it < o->max_iter; it++) {
+        if (it > 0 && o->max_solver_time_s > 0.0) {
+            // (the budget of ba_run, against the time the device has spent on the batch)
+            OV2_HIP_CHECK(hipStreamSynchronize(s));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= o->max_solver_time_s) {
+                BAOpt Ostop = O;
+                Ostop.max_iter = 0;
+                hipLaunchKernelGGL(k_ba_iter_begin_B, dim3(1, 1, Z), dim3(1024), 0, s, A, Ostop, -1);
+                break;
+            }
+        }
+        first_half(it);
+        if (it >= 1) {
+            // the outcome of iteration it - 1 of EVERY problem (a finished problem's k_ba_decide reports `done` on its way out)
+            unsigned spins = 0;
+            bool all_done = false;
+            for (;;) {
+                int known = 0, done = 0;
+                for (int i = 0; i < N; i++) { const int f = B.h_flag[i]; known += f >= 2 * (it - 1); done += f >= 0 && (f & 1); }
+                if (known == N) { all_done = done == N; break; }
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if ((++spins & 0xFFFFFu) == 0) {
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) {
+                        all_done = true;
+                        for (int i = 0; i < N; i++) all_done = all_done && B.h_flag[i] >= 0 && (B.h_flag[i] & 1);
+                        break;
+                    }
+                    if (q != hipErrorNotReady) OV2_HIP_CHECK(q);
+                }
+            }
+            if (all_done) break;
+        }
+        second_half(it);
+    }
+    hipLaunchKernelGGL(k_ba_iter_begin_B, dim3(1, 1, Z), dim3(1024), 0, s, A, O, -1);    // final bookkeeping
+    OV2_HIP_CHECK(hipGetLastError());
+    OV2_HIP_CHECK(hipEventRecord(ev.e1, s));
+    OV2_HIP_CHECK(hipMemcpyAsync(B.h_ctl, B.d_ctl, sizeof(BACtl) * (size_t)N, hipMemcpyDeviceToHost, s));
+    OV2_HIP_CHECK(hipStreamSynchronize(s));
+    OV2_HIP_CHECK(hipEventElapsedTime(ms_out, ev.e0, ev.e1));
+    return OV2_OK;
+}
+
+static bool same_solver_options(const ov2_ba_options &a, const ov2_ba_options &b)
+{
+    return a.max_iter == b.max_iter && a.function_tolerance == b.function_tolerance && a.gradient_tolerance == b.gradient_tolerance &&
+           a.parameter_tolerance == b.parameter_tolerance && a.initial_radius == b.initial_radius && a.max_radius == b.max_radius &&
+           a.min_radius == b.min_radius && a.min_lm_diagonal == b.min_lm_diagonal && a.max_lm_diagonal == b.max_lm_diagonal &&
+           a.min_relative_decrease == b.min_relative_decrease && a.jacobi_scaling == b.jacobi_scaling &&
+           a.max_consecutive_invalid_steps == b.max_consecutive_invalid_steps && a.max_solver_time_s == b.max_solver_time_s;
+}
+
+static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r, int *n_batched)
+{
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    for (int i = 0; i < n; i++) {
+        OV2_REQUIRE(o[i].robust_mono_th > 0, OV2_EINVAL, "robust_mono_th must be positive");
+        OV2_REQUIRE(o[i].robust_mono_th == o[0].robust_mono_th && o[i].use_robust_cost == o[0].use_robust_cost && o[i].apply_l2_after_robust == o[0].apply_l2_after_robust &&
+                    same_solver_options(o[i].pass1, o[0].pass1) && same_solver_options(o[i].pass2, o[0].pass2), OV2_EINVAL,
+                    "ov2_local_ba_batch: the problems of a batch share the protocol and solver options (only the stop request is per problem)");
+        ov2_local_ba_result &ri = r[i];
+        ri.l2_done = 0; ri.pass2_error = OV2_OK; ri.n_bad_pass1 = 0; ri.n_bad_total = 0;
+        for (int q = 0; q < 2; q++) { ri.iterations[q] = 0; ri.num_successful_steps[q] = 0; ri.termination[q] = OV2_TERM_NO_CONVERGENCE; ri.initial_cost[q] = ri.final_cost[q] = 0; ri.solve_ms[q] = 0; }
+    }
+    // which problems can share launches: inverse-depth problems of the LDS-resident path with landmarks and optimised keyframes
+    std::vector<int> idx;                                   // batch slot -> problem
+    std::vector<uint8_t> alone((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        int n_opt = 0;
+        if (p[i].n_kf > 0 && p[i].kf_const) for (int k = 0; k < p[i].n_kf; k++) n_opt += !p[i].kf_const[k];
+        const bool ok = !ctx->ba_deterministic && !ctx->ba_force_large && p[i].n_lm > 0 && p[i].n_res > 0 && n_opt > 0 && ba_small_path(n_opt);
+        if (ok) idx.push_back(i); else alone[(size_t)i] = 1;
+    }
+    BABatch B;
+    int N = (int)idx.size();
+    if (N > 0) {
+        // header of the pinned block: look-ahead words, counters, control blocks, device views; then the staging mirrors
+        const size_t hb_flag = 0, hb_cnt = al256(4 * (size_t)N), hb_ctl = hb_cnt + al256(64 * (size_t)N), hb_arr = hb_ctl + al256(sizeof(BACtl) * (size_t)N);
+        const size_t header = hb_arr + al256(sizeof(BADev) * (size_t)N);
+        size_t host_need = header, dev_need = header;
+        for (;;) {
+            int rc = ctx->reserve_host(std::max(host_need, ctx->h_scratch_bytes));
+            if (rc == OV2_OK) rc = ctx->reserve_device(std::max(dev_need, ctx->d_scratch_bytes));
+            if (rc != OV2_OK) return rc;
+            uint8_t *hb = (uint8_t *)ctx->h_scratch, *db = (uint8_t *)ctx->d_scratch;
+            B.h_flag = (volatile int *)(hb + hb_flag); B.h_cnt = (int *)(hb + hb_cnt); B.h_ctl = (BACtl *)(hb + hb_ctl); B.h_arr = (BADev *)(hb + hb_arr);
+            B.d_cnt = (int *)(db + hb_cnt); B.d_ctl = (BACtl *)(db + hb_ctl); B.d_arr = (BADev *)(db + hb_arr);
+            BASlice sl{db, ctx->d_scratch_bytes, header, hb, ctx->h_scratch_bytes, header};
+            bool full = false;
+            for (size_t k = 0; k < idx.size() && !full; k++) {
+                ov2_ba_dev *dev = nullptr;
+                rc = ba_create(ctx, &p[idx[k]], &dev, true, &sl);
+                if (rc == BA_SLICE_FULL) { full = true; break; }
+                if (rc != OV2_OK) return rc;
+                B.devs.push_back(dev);
+            }
+            if (!full) break;
+            // grow-only blocks: twice what was in use when a slice did not fit, and start over (the first batches of a run only)
+            OV2_HIP_CHECK(hipStreamSynchronize(s));
+            for (ov2_ba_dev *d : B.devs) ba_destroy(d);
+            B.devs.clear();
+            host_need = std::max(2 * ctx->h_scratch_bytes, (size_t)1 << 20); dev_need = std::max(2 * ctx->d_scratch_bytes, (size_t)1 << 22);
+        }
+        // problems that turn out to carry pose-only blocks leave the batch
+        for (size_t k = 0; k < B.devs.size();) {
+            if (B.devs[k]->D.n_po > 0 || B.devs[k]->D.big) { alone[(size_t)idx[k]] = 1; OV2_HIP_CHECK(hipStreamSynchronize(s)); ba_destroy(B.devs[k]); B.devs.erase(B.devs.begin() + (long)k); idx.erase(idx.begin() + (long)k); }
+            else k++;
+        }
+        N = (int)idx.size();
+    }
+    if (n_batched) *n_batched = N;
+    if (N > 0) {
+        const ov2_local_ba_options &o0 = o[0];
+        const double hub = o0.use_robust_cost ? sqrt(o0.robust_mono_th) : -1.0;
+        std::vector<double> huber((size_t)N, hub);
+        std::vector<uint8_t> skip((size_t)N, 0);
+        OV2_HIP_CHECK(hipMemsetAsync(B.d_cnt, 0, 64 * (size_t)N, s));
+        ov2_ba_options o1 = o0.pass1;
+        float ms = 0;
+        int rc = ba_run_batch(ctx, B, &o1, huber.data(), nullptr, false, &ms);
+        if (rc != OV2_OK) return rc;
+        for (int k = 0; k < N; k++) {
+            ov2_local_ba_result &ri = r[idx[(size_t)k]];
+            const BACtl &c = B.h_ctl[k];
+            ri.iterations[0] = c.n_steps; ri.num_successful_steps[0] = c.n_success; ri.termination[0] = c.termination;
+            ri.initial_cost[0] = c.initial_cost; ri.final_cost[0] = c.minimum_cost; ri.solve_ms[0] = ms;
+        }
+        int mk_blocks = 1;
+        for (int k = 0; k < N; k++) mk_blocks = std::max(mk_blocks, std::min(1024, (B.devs[(size_t)k]->D.n_act + 255) / 256));
+        hipLaunchKernelGGL(k_ba_mark_outliers_B, dim3(mk_blocks, 1, (unsigned)N), dim3(256), 0, s, (const BADev *)B.d_arr, o0.robust_mono_th, o0.apply_l2_after_robust ? 1 : 0, (uint8_t *)nullptr);
+        OV2_HIP_CHECK(hipGetLastError());
+        OV2_HIP_CHECK(hipMemcpyAsync(B.h_cnt, B.d_cnt, 64 * (size_t)N, hipMemcpyDeviceToHost, s));
+        for (int k = 0; k < N; k++) {
+            ov2_local_ba_result &ri = r[idx[(size_t)k]];
+            const ov2_ba_dev *dev = B.devs[(size_t)k];
+            if (ri.bad_after_pass1 && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.bad_after_pass1, dev->D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+        }
+        OV2_HIP_CHECK(hipStreamSynchronize(s));
+        // the stop request of each problem is read HERE, after its first solve (src/optimizer.cpp:603-604)
+        int n_pass2 = 0;
+        std::vector<int> bad1((size_t)N, 0);
+        for (int k = 0; k < N; k++) {
+            const ov2_local_ba_options &ok = o[idx[(size_t)k]];
+            ov2_local_ba_result &ri = r[idx[(size_t)k]];
+            const int nbbad = B.h_cnt[16 * k], left = B.h_cnt[16 * k + 1], right = B.h_cnt[16 * k + 2];
+            bad1[(size_t)k] = nbbad; ri.n_bad_pass1 = nbbad; ri.n_bad_total = nbbad;
+            const bool stop = ok.stop_requested || (ok.stop_flag && *ok.stop_flag);
+            const bool go = o0.apply_l2_after_robust && o0.use_robust_cost && !stop && nbbad > 0;
+            skip[(size_t)k] = go ? 0 : 1;
+            huber[(size_t)k] = (left && right) ? -1.0 : hub;                   // (:606-608: mono runs keep Huber)
+            n_pass2 += go;
+        }
+        if (n_pass2 > 0) {
+            // (skip2 reaches the device with ba_run_batch's upload of the views: k_ba_lm_live_B runs after it, as part of the reset)
+            OV2_HIP_CHECK(hipMemsetAsync(B.d_cnt, 0, 64 * (size_t)N, s));
+            ov2_ba_options o2 = o0.pass2;
+            B.lm_live_first = true;
+            rc = ba_run_batch(ctx, B, &o2, huber.data(), skip.data(), true, &ms);
+            B.lm_live_first = false;
+            if (rc != OV2_OK) {
+                for (int k = 0; k < N; k++) if (!skip[(size_t)k]) r[idx[(size_t)k]].pass2_error = rc;
+            } else {
+                for (int k = 0; k < N; k++) {
+                    if (skip[(size_t)k]) continue;
+                    ov2_local_ba_result &ri = r[idx[(size_t)k]];
+                    const BACtl &c = B.h_ctl[k];
+                    ri.l2_done = 1;
+                    ri.iterations[1] = c.n_steps; ri.num_successful_steps[1] = c.n_success; ri.termination[1] = c.termination;
+                    ri.initial_cost[1] = c.initial_cost; ri.final_cost[1] = c.minimum_cost; ri.solve_ms[1] = ms;
+                }
+                hipLaunchKernelGGL(k_ba_mark_outliers_B, dim3(mk_blocks, 1, (unsigned)N), dim3(256), 0, s, (const BADev *)B.d_arr, o0.robust_mono_th, 0, (uint8_t *)nullptr);
+                OV2_HIP_CHECK(hipGetLastError());
+                OV2_HIP_CHECK(hipMemcpyAsync(B.h_cnt, B.d_cnt, 64 * (size_t)N, hipMemcpyDeviceToHost, s));
+            }
+        }
+        for (int k = 0; k < N; k++) {
+            ov2_local_ba_result &ri = r[idx[(size_t)k]];
+            const ov2_ba_dev *dev = B.devs[(size_t)k];
+            const BADev &D = dev->D;
+            if (ri.poses_out) OV2_HIP_CHECK(hipMemcpyAsync(ri.poses_out, D.x_pose, 56 * (size_t)D.n_kf, hipMemcpyDeviceToHost, s));
+            if (ri.invdepth_out) OV2_HIP_CHECK(hipMemcpyAsync(ri.invdepth_out, D.x_lam, 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost, s));
+            if (ri.bad_obs && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.bad_obs, D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+            if (ri.chi2_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.chi2_last_eval, D.chi2, 8 * (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+            if (ri.depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+        }
+        OV2_HIP_CHECK(hipStreamSynchronize(s));
+        for (int k = 0; k < N; k++) if (r[idx[(size_t)k]].l2_done) r[idx[(size_t)k]].n_bad_total = bad1[(size_t)k] + B.h_cnt[16 * k];
+        for (ov2_ba_dev *d : B.devs) ba_destroy(d);
+        B.devs.clear();
+    }
+    // what cannot share launches (large windows, pose-only blocks, the deterministic mode): one problem at a time
+    for (int i = 0; i < n; i++) {
+        if (!alone[(size_t)i]) continue;
+        const int rc = ov2_local_ba(ctx, &p[i], &o[i], &r[i]);
+        if (rc != OV2_OK) return rc;
+    }
+    return OV2_OK;
+}
+
 extern "C" {
 
 void ov2_ba_default_options(ov2_ba_options *o)
@@ -3297,6 +3669,14 @@ download:
     if (r->l2_done) r->n_bad_total = nbbad + cnt_h[0];
     lap("outlier test 2 + download");
     return OV2_OK;
+}
+
+int ov2_local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r, int *n_batched)
+{
+    if (n_batched) *n_batched = 0;
+    OV2_REQUIRE(ctx && n >= 0 && (n == 0 || (p && o && r)), OV2_EINVAL, "NULL argument");
+    if (n == 0) return OV2_OK;
+    return local_ba_batch(ctx, n, p, o, r, n_batched);
 }
 
 int ov2_xyz_ba_solve(ov2_ctx *ctx, const ov2_xyzba_problem *p, const ov2_ba_options *o, ov2_xyzba_result *r)

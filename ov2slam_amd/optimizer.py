@@ -266,6 +266,48 @@ class Optimizer:
             out.update(chi2=chi2[:n_res], depthpos=dpos[:n_res])
         return out
 
+    def localBA_batch(self, probs, buse_robust_cost=True, want_chi2=True, stop=None):
+        """Optimizer::localBA's solve stage for a lock-step batch of sequences (BASELINE configs[4]): one ov2_local_ba_batch call,
+        every kernel of the solver launched once for all problems.  `probs`: inverse-depth problems (make_ba_problem layout);
+        `stop`: per-problem stop requests (the estimators' bstop_localba_, read after the first pass) or None.
+        Returns (list of per-problem dicts as localBA returns them, number of problems that shared the launches)."""
+        lib = self.ctx.lib
+        n = len(probs)
+        PA = (L.BAProblem * n)(); OA = (L.LocalBAOptions * n)(); RA = (L.LocalBAResult * n)()
+        keep, outs = [], []
+        for i, prob in enumerate(probs):
+            P, k = pack_problem(prob)
+            keep.append((P, k)); PA[i] = P
+            O = OA[i]
+            lib.ov2_local_ba_default_options(C.byref(O))
+            O.robust_mono_th = self.robust_mono_th; O.use_robust_cost = int(bool(buse_robust_cost))
+            O.apply_l2_after_robust = int(self.apply_l2_after_robust)
+            O.stop_requested = int(bool(stop[i])) if stop is not None else 0
+            O.pass1.max_solver_time_s = self.max_solver_time_s; O.pass2.max_solver_time_s = 0.5 * self.max_solver_time_s
+            n_res = P.n_res
+            o = dict(poses=np.zeros((P.n_kf, 7)), _lam=np.zeros(max(1, P.n_lm)), _bad=np.zeros(max(1, n_res), np.uint8), _bad1=np.zeros(max(1, n_res), np.uint8),
+                     _n_res=n_res, _n_lm=P.n_lm)
+            R = RA[i]
+            R.poses_out = _dp(o["poses"]); R.invdepth_out = _dp(o["_lam"]); R.bad_obs = _u8p(o["_bad"]); R.bad_after_pass1 = _u8p(o["_bad1"])
+            if want_chi2:
+                o["_chi2"] = np.full(max(1, n_res), np.nan); o["_dpos"] = np.zeros(max(1, n_res), np.uint8)
+                R.chi2_last_eval = _dp(o["_chi2"]); R.depthpos_last_eval = _u8p(o["_dpos"])
+            outs.append(o)
+        nb = C.c_int(0)
+        L.check(lib.ov2_local_ba_batch(self.ctx.h, n, PA, OA, RA, C.byref(nb)))
+        res = []
+        for i, o in enumerate(outs):
+            R = RA[i]; n_res = o["_n_res"]
+            d = dict(poses=o["poses"], invdepth=o["_lam"][:o["_n_lm"]], bad_obs=o["_bad"][:n_res].astype(bool), bad_after_pass1=o["_bad1"][:n_res].astype(bool),
+                     l2_done=bool(R.l2_done), pass2_error=int(R.pass2_error), iterations=(R.iterations[0], R.iterations[1]),
+                     num_successful_steps=(R.num_successful_steps[0], R.num_successful_steps[1]), termination=(R.termination[0], R.termination[1]),
+                     initial_cost=(R.initial_cost[0], R.initial_cost[1]), final_cost=(R.final_cost[0], R.final_cost[1]),
+                     solve_ms=(R.solve_ms[0], R.solve_ms[1]), n_bad=(R.n_bad_pass1, R.n_bad_total))
+            if want_chi2:
+                d.update(chi2=o["_chi2"][:n_res], depthpos=o["_dpos"][:n_res])
+            res.append(d)
+        return res, int(nb.value)
+
     def localBA_two_calls(self, prob, buse_robust_cost=True):
         """Inverse-depth problems (make_ba_problem layout) or, with buse_inv_depth: 0, 3-D point problems
         (make_xyz_ba_problem layout): the protocol is the same, the landmark state is `invdepth` resp. `xyz`."""
