@@ -284,7 +284,8 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2, str
     keys = ("frames", "seconds", "tracked", "attempted", "ate_sq_sum", "ate_n", "sequences", "host_native", "keyframes", "stereo_ok", "stereo_kps",
             "ba_solves", "ba_iterations", "ba_seconds", "ba_skipped", "device", "steps", "slam_library_s", "slam_wait_loader_s", "slam_wait_mapper_s",
             "all_frames", "all_seconds", "all_ba_solves", "all_ba_iterations", "all_keyframes",
-            "stream_frames", "stream_seconds", "stream_ba_solves", "stream_ba_skipped", "stream_keyframes")
+            "stream_frames", "stream_seconds", "stream_ba_solves", "stream_ba_skipped", "stream_keyframes",
+            "ba_batches", "thr_frames", "thr_seconds", "thr_ba_solves")
     loc = {k: 0.0 for k in keys}
     loc["sequences"] = float(len(mine)); loc["device"] = float(device)
     argv_note = stream.lockstep_argv("lockstep_driver", ["<case:%s>" % s for s in mine], "newest", device)
@@ -322,12 +323,16 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2, str
             loc["keyframes"] += st["keyframes"]; loc["stereo_ok"] += st["stereo_ok"]; loc["stereo_kps"] += st["stereo_kps"]
             loc["ba_solves"] += st["ba_solves"]; loc["ba_iterations"] += st["ba_iterations"]
             loc["ba_skipped"] += st["ba_skipped_kfs"]
-        loc["ba_seconds"] = summ["seconds"]                                          # the estimator contexts run beside each other: wall clock
+        loc["ba_seconds"] = summ["seconds"]                                          # the estimator runs beside the SLAM thread: wall clock
+        loc["ba_batches"] = summ.get("ba_batches", 0)
         # equal work for CPU / GPU comparisons: every keyframe gets its localBA (the estimator contexts bound this one)
         stats_a, summ_a = stream.run_lockstep(exe_l, cases, device=device, ba_policy="all")
         loc["all_frames"] = summ_a["frames"]; loc["all_seconds"] = summ_a["seconds"]
         loc["all_ba_solves"] = sum(st["ba_solves"] for st in stats_a); loc["all_ba_iterations"] = sum(st["ba_iterations"] for st in stats_a)
         loc["all_keyframes"] = sum(st["keyframes"] for st in stats_a)
+        # the first lock-step form of this round (an estimator thread + context per sequence calling ov2_local_ba, stream priorities), full length
+        stats_t, summ_t = stream.run_lockstep(exe_l, cases, device=device, ba_policy="newest", priorities=True, batched_estimator=False)
+        loc["thr_frames"] = summ_t["frames"]; loc["thr_seconds"] = summ_t["seconds"]; loc["thr_ba_solves"] = sum(st["ba_solves"] for st in stats_t)
         # the per-sequence stream form (round 4's config 5) at reduced length, for the comparison
         small = cases_for({k: max(12, v // max(1, stream_scale)) for k, v in batch.EUROC_FRAMES.items()}, "small")
         st_s, sec_s = stream.run_native_concurrent(exe_s, small, device=device, concurrency=max(1, concurrency))
@@ -337,12 +342,13 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2, str
         td.cleanup()
     stats = batch.gather_stats(loc)
     agg = batch.aggregate(stats)
-    sec_all, sec_str = max(stats["all_seconds"]), max(stats["stream_seconds"])
+    sec_all, sec_str, sec_thr = max(stats["all_seconds"]), max(stats["stream_seconds"]), max(stats["thr_seconds"])
     return {"workload": "11 synthetic stereo sequences with EuRoC frame counts / %d (%d frames), longest-first over %d rank(s); the sequences of a rank "
                         "advance IN LOCK-STEP through tools/lockstep_driver.cpp: per frame step ONE ov2_btracker_track_frame (frame upload, CLAHE + "
                         "pyramid, fused kltTracking, computeKeypoint for every sequence of the rank), every 5th step one batched detectSingleScale; "
-                        "keyframes go to per-sequence mapper contexts (right-image pyramid + ov2_stereo_match on an item view) and estimator "
-                        "contexts (two-pass 25-KF localBA, newest keyframe only like estimator.cpp:195-205); sequences that end drop out"
+                        "keyframes go to the rank's mapper thread (one batched right-image CLAHE + pyramid, one ov2_stereo_match_batch) and to the "
+                        "rank's estimator thread (ONE ov2_local_ba_batch per round over the sequences with a keyframe waiting: two-pass 25-KF "
+                        "localBA, per sequence the newest keyframe only like estimator.cpp:195-205); sequences that end drop out"
                         % (scale, int(sum(counts.values())), world),
             "fps": agg["fps"], "frames": agg["frames"], "seconds_slowest_rank": agg["seconds"],
             "frames_per_rank": stats["frames"], "seconds_per_rank": stats["seconds"], "sequences_per_rank": stats["sequences"],
@@ -351,11 +357,15 @@ def run_config5(ctx, rank, world, scale, dry=False, device=0, concurrency=2, str
             "slam_thread_per_rank": {"library_s": stats["slam_library_s"], "wait_for_loader_s": stats["slam_wait_loader_s"], "wait_for_mapper_s": stats["slam_wait_mapper_s"]},
             "tracked_fraction": sum(stats["tracked"]) / max(1.0, sum(stats["attempted"])),
             "keyframes": sum(stats["keyframes"]), "stereo_ok_fraction": sum(stats["stereo_ok"]) / max(1.0, sum(stats["stereo_kps"])),
-            "ba_solves": sum(stats["ba_solves"]), "ba_keyframes_skipped_while_busy": sum(stats["ba_skipped"]),
+            "ba_solves": sum(stats["ba_solves"]), "ba_keyframes_skipped_while_busy": sum(stats["ba_skipped"]), "ba_batches": sum(stats["ba_batches"]),
             "ba_iters_per_s": agg.get("ba_iters_per_s", 0.0),
             "every_keyframe_optimised": {"fps": sum(stats["all_frames"]) / sec_all if sec_all > 0 else None, "seconds_slowest_rank": sec_all,
                                          "ba_solves": sum(stats["all_ba_solves"]), "keyframes": sum(stats["all_keyframes"]),
                                          "ba_iters_per_s": sum(stats["all_ba_iterations"]) / sec_all if sec_all > 0 else None},
+            "estimator_thread_per_sequence": {"what": "the same lock-step front end with an estimator thread + context per sequence calling ov2_local_ba "
+                                                      "(stream priorities on), full length: this round's first form",
+                                              "fps": sum(stats["thr_frames"]) / sec_thr if sec_thr > 0 else None, "seconds_slowest_rank": sec_thr,
+                                              "ba_solves": sum(stats["thr_ba_solves"])},
             "per_sequence_streams": {"what": "round 4's form of this config: each sequence through its own SLAM thread + ov2_tracker (tools/stream_driver.cpp), "
                                              "%d at a time per GPU, frame counts / %d" % (int(concurrency), int(stream_scale)),
                                      "fps": sum(stats["stream_frames"]) / sec_str if sec_str > 0 else None, "frames": sum(stats["stream_frames"]),

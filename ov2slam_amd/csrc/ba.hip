@@ -2570,7 +2570,7 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static void ba_destroy(ov2_ba_dev *dev);
 
 // lock-step batch (ov2_local_ba_batch): the problems' pools and staging mirrors are consecutive slices of ONE device / pinned block
-struct BASlice { uint8_t *dev_base; size_t dev_cap, dev_used; uint8_t *host_base; size_t host_cap, host_used; };
+struct BASlice { uint8_t *dev_base; size_t dev_cap, dev_used; uint8_t *host_base; size_t host_cap, host_used; std::mutex m; };      // (the problems of a batch are prepared on several host threads)
 #define BA_SLICE_FULL (-12345)          // (internal: the caller grows the blocks and starts over)
 
 // transient: the problem lives for one ov2_ba_solve call -- small pools then come out of the context's device scratch instead of
@@ -2666,7 +2666,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
         auto htake = [&](size_t bytes) { const size_t o = hoff; hoff += (bytes + 255) & ~(size_t)255; return o; };
         const size_t h6 = htake(4 * np_h), h7 = htake(4 * np_h), h8 = htake(24 * np_h), h9 = htake(16 * np_h), h10 = htake(8 * np_h);
         if (ext) {
-            if (ext->host_used + hoff > ext->host_cap) return BA_SLICE_FULL;
+            std::lock_guard<std::mutex> l(ext->m);
+            if (ext->host_used + hoff > ext->host_cap) { ext->host_used += al256(hoff); return BA_SLICE_FULL; }    // (keeps counting: the caller learns the total)
             hs = ext->host_base + ext->host_used; ext->host_used += al256(hoff);
         } else {
         const int rch = ctx->reserve_host(hoff);
@@ -2763,7 +2764,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     const size_t o_po_kf = take(4 * npo), o_po_orig = take(4 * npo), o_po_xyz = take(24 * npo), o_po_uv = take(16 * npo), o_po_sigma = take(8 * npo);
     dev->pool_bytes = off;
     if (ext) {
-        if (ext->dev_used + off > ext->dev_cap) { delete dev; return BA_SLICE_FULL; }
+        std::lock_guard<std::mutex> l(ext->m);
+        if (ext->dev_used + off > ext->dev_cap) { ext->dev_used += al256(off); delete dev; return BA_SLICE_FULL; }
         dev->pool = ext->dev_base + ext->dev_used; dev->pool_owned = false; ext->dev_used += al256(off);
     } else if (transient && off <= ((size_t)64 << 20)) {               // (the context keeps the largest pool it has seen: grow-only scratch)
         const int rcs = ctx->reserve_device(off);
@@ -3417,6 +3419,11 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
     }
     BABatch B;
     int N = (int)idx.size();
+    const bool dbg = ctx->debug != 0;
+    const auto tw0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg) fprintf(stderr, "[ov2 local_ba_batch] %-28s %8.3f ms since entry (%d problems)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), N);
+    };
     if (N > 0) {
         // header of the pinned block: look-ahead words, counters, control blocks, device views; then the staging mirrors
         const size_t hb_flag = 0, hb_cnt = al256(4 * (size_t)N), hb_ctl = hb_cnt + al256(64 * (size_t)N), hb_arr = hb_ctl + al256(sizeof(BACtl) * (size_t)N);
@@ -3429,21 +3436,40 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             uint8_t *hb = (uint8_t *)ctx->h_scratch, *db = (uint8_t *)ctx->d_scratch;
             B.h_flag = (volatile int *)(hb + hb_flag); B.h_cnt = (int *)(hb + hb_cnt); B.h_ctl = (BACtl *)(hb + hb_ctl); B.h_arr = (BADev *)(hb + hb_arr);
             B.d_cnt = (int *)(db + hb_cnt); B.d_ctl = (BACtl *)(db + hb_ctl); B.d_arr = (BADev *)(db + hb_arr);
-            BASlice sl{db, ctx->d_scratch_bytes, header, hb, ctx->h_scratch_bytes, header};
-            bool full = false;
-            for (size_t k = 0; k < idx.size() && !full; k++) {
-                ov2_ba_dev *dev = nullptr;
-                rc = ba_create(ctx, &p[idx[k]], &dev, true, &sl);
-                if (rc == BA_SLICE_FULL) { full = true; break; }
-                if (rc != OV2_OK) return rc;
-                B.devs.push_back(dev);
+            BASlice sl;
+            sl.dev_base = db; sl.dev_cap = ctx->d_scratch_bytes; sl.dev_used = header; sl.host_base = hb; sl.host_cap = ctx->h_scratch_bytes; sl.host_used = header;
+            // the host side of a problem (validation, the landmark sort, the staging mirror; ~0.4 ms for a 69 k-block window) on a thread of
+            // its own, up to eight at a time -- on one thread it was more than the batch's device time.  Each thread enqueues its
+            // problem's upload on the context's stream itself (the order of the uploads does not matter).
+            const int NT = std::min(8, (int)idx.size());
+            std::vector<ov2_ba_dev *> made(idx.size(), nullptr);
+            std::vector<int> rcs(idx.size(), OV2_OK);
+            std::vector<std::string> errs(idx.size());
+            auto work = [&](int t) {
+                (void)hipSetDevice(ctx->device);
+                for (size_t k = (size_t)t; k < idx.size(); k += (size_t)NT) {
+                    rcs[k] = ba_create(ctx, &p[idx[k]], &made[k], true, &sl);
+                    if (rcs[k] != OV2_OK && rcs[k] != BA_SLICE_FULL) errs[k] = ov2_last_error();          // (the message is per thread)
+                }
+            };
+            {
+                std::vector<std::thread> th;
+                for (int t = 1; t < NT; t++) th.emplace_back(work, t);
+                work(0);
+                for (auto &x : th) x.join();
             }
-            if (!full) break;
-            // grow-only blocks: twice what was in use when a slice did not fit, and start over (the first batches of a run only)
+            bool full = false;
+            int bad_rc = OV2_OK; size_t bad_k = 0;
+            for (size_t k = 0; k < idx.size(); k++) {
+                if (rcs[k] == BA_SLICE_FULL) full = true;
+                else if (rcs[k] != OV2_OK && bad_rc == OV2_OK) { bad_rc = rcs[k]; bad_k = k; }
+            }
+            if (bad_rc == OV2_OK && !full) { B.devs = made; break; }
             OV2_HIP_CHECK(hipStreamSynchronize(s));
-            for (ov2_ba_dev *d : B.devs) ba_destroy(d);
-            B.devs.clear();
-            host_need = std::max(2 * ctx->h_scratch_bytes, (size_t)1 << 20); dev_need = std::max(2 * ctx->d_scratch_bytes, (size_t)1 << 22);
+            for (ov2_ba_dev *d : made) ba_destroy(d);
+            if (bad_rc != OV2_OK) { ov2_set_error("ov2_local_ba_batch: problem %d: %s", idx[bad_k], errs[bad_k].c_str()); return bad_rc; }
+            // grow-only blocks: twice what this batch would have taken, and start over (the first batches of a run only)
+            host_need = 2 * sl.host_used; dev_need = 2 * sl.dev_used;
         }
         // problems that turn out to carry pose-only blocks leave the batch
         for (size_t k = 0; k < B.devs.size();) {
@@ -3453,6 +3479,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
         N = (int)idx.size();
     }
     if (n_batched) *n_batched = N;
+    lap("sort + upload (ba_create)");
     if (N > 0) {
         const ov2_local_ba_options &o0 = o[0];
         const double hub = o0.use_robust_cost ? sqrt(o0.robust_mono_th) : -1.0;
@@ -3463,6 +3490,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
         float ms = 0;
         int rc = ba_run_batch(ctx, B, &o1, huber.data(), nullptr, false, &ms);
         if (rc != OV2_OK) return rc;
+        lap("pass 1");
         for (int k = 0; k < N; k++) {
             ov2_local_ba_result &ri = r[idx[(size_t)k]];
             const BACtl &c = B.h_ctl[k];
@@ -3480,6 +3508,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             if (ri.bad_after_pass1 && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.bad_after_pass1, dev->D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
         }
         OV2_HIP_CHECK(hipStreamSynchronize(s));
+        lap("outlier test 1");
         // the stop request of each problem is read HERE, after its first solve (src/optimizer.cpp:603-604)
         int n_pass2 = 0;
         std::vector<int> bad1((size_t)N, 0);
@@ -3501,6 +3530,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             B.lm_live_first = true;
             rc = ba_run_batch(ctx, B, &o2, huber.data(), skip.data(), true, &ms);
             B.lm_live_first = false;
+            lap("pass 2");
             if (rc != OV2_OK) {
                 for (int k = 0; k < N; k++) if (!skip[(size_t)k]) r[idx[(size_t)k]].pass2_error = rc;
             } else {
@@ -3528,6 +3558,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             if (ri.depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
         }
         OV2_HIP_CHECK(hipStreamSynchronize(s));
+        lap("outlier test 2 + download");
         for (int k = 0; k < N; k++) if (r[idx[(size_t)k]].l2_done) r[idx[(size_t)k]].n_bad_total = bad1[(size_t)k] + B.h_cnt[16 * k];
         for (ov2_ba_dev *d : B.devs) ba_destroy(d);
         B.devs.clear();

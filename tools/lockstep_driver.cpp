@@ -8,16 +8,19 @@
 // tracker (ov2_btracker_*, csrc/trackb.hip): per step one frame upload, one CLAHE + pyramid enqueue, one fused kltTracking launch
 // and one computeKeypoint launch cover every sequence; at the common keyframes one batched detectSingleScale call; the keyframes
 // then go to the rank's mapper thread -- ONE batched right-image CLAHE + pyramid (ov2_pyr_build_clahe_hb) and ONE
-// ov2_stereo_match_batch on the tracker's pyramids for all sequences -- and from there to the sequences' own estimator threads
-// (ov2_local_ba, newest keyframe only like src/estimator.cpp:195-205, or every keyframe with policy "all"; one context each, exactly
-// as in stream_driver: the windows are independent problems).  Sequences that end drop out of the batch (they are ordered longest
-// first, so the active ones are always items [0, n_active)).
+// ov2_stereo_match_batch on the tracker's pyramids for all sequences -- and from there to the rank's estimator thread, which solves
+// the windows of the sequences that have a keyframe waiting in ONE ov2_local_ba_batch call (per sequence the newest keyframe only,
+// like src/estimator.cpp:195-205, or every keyframe with policy "all").  [estimator 0: the round-4 form, an estimator thread and
+// context per sequence calling ov2_local_ba: ~100 launches per solve from eleven threads queue behind each other and behind the
+// front end's in the command processor.]  Sequences that end drop out of the batch (they are ordered longest first, so the
+// active ones are always items [0, n_active)).
 // Image "decoding" (here: a copy of the synthetic view into the tracker's pinned slot) runs on loader threads one step ahead,
 // the frames' H2D on the tracker's copy stream beside the previous step's kernels.
 // Per-sequence inputs (frames, keypoints, priors, random streams) are those of stream_driver, so the per-sequence results must be
 // bit-identical: both programs print FNV-1a digests of everything the library returned (tests/test_gpu_stream.py compares them).
 //
-//   lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads] [stream priorities 0|1]     -> one JSON line per sequence (input order) + one summary line
+//   lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads] [stream priorities 0|1] [batched estimator 0|1]
+//                                                                     -> one JSON line per sequence (input order) + one summary line
 // Build: g++ -O2 -std=c++17 -pthread tools/lockstep_driver.cpp -I. -Lov2slam_amd -lov2slam_hip -Wl,-rpath,<dir>
 #define OV2_DRIVER_NAME "lockstep_driver"
 #include "tools/driver_common.hpp"
@@ -68,9 +71,17 @@ int main(int argc, char **argv)
     const char *dev_s = argc > 3 ? argv[3] : getenv("OV2_DEVICE");      // one process per GPU: the rank's device from the launcher
     const int device = dev_s ? atoi(dev_s) : 0;
     const int n_load = argc > 4 ? std::max(1, atoi(argv[4])) : 4;
-    // stream priorities (argv[5], default on): tracking context high, localBA contexts low -- the SLAM thread is the real-time one
+    // stream priorities (argv[5]): tracking context high, localBA contexts low -- the SLAM thread is the real-time one
     // (the reference's estimator takes whatever keyframe is newest when it is free, src/estimator.cpp:195-205)
-    const bool use_prio = argc > 5 ? atoi(argv[5]) != 0 : true;
+    // ("a,b,e": the priorities of the tracking, mapper and estimator contexts one by one, for experiments)
+    // Default: ON with per-sequence estimator threads (their ~1000 launches per step then yield to the tracker's: 13.5k -> 19.5k fps), OFF with
+    // the batched estimator -- any non-default priority on any of the three contexts then costs the SLAM thread a third of its
+    // speed (profiles/r5_lockstep_priorities.json: 30.0k fps at 0,0,0, 21.3k-23.3k with every other combination).
+    const bool est_batch_dflt = argc > 6 ? atoi(argv[6]) != 0 : true;
+    const bool use_prio = argc > 5 ? atoi(argv[5]) != 0 || strchr(argv[5], ',') : !est_batch_dflt;
+    int prioA = use_prio ? 1 : 0, prioB = use_prio ? 1 : 0, prioE = use_prio ? -1 : 0;
+    if (argc > 5 && strchr(argv[5], ',')) sscanf(argv[5], "%d,%d,%d", &prioA, &prioB, &prioE);
+    const bool est_batch = argc > 6 ? atoi(argv[6]) != 0 : true;
     std::vector<std::string> paths;
     for (std::string rest = argv[1]; !rest.empty();) {
         const size_t c = rest.find(',');
@@ -91,7 +102,7 @@ int main(int argc, char **argv)
     const double K[4] = {458.654, 457.296, 367.215, 248.375};
     const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[1], -K[3] / K[1], 0, 0, 1};
     ov2_ctx *ctxA;
-    CK(ov2_ctx_create_with_priority(device, use_prio ? 1 : 0, &ctxA));
+    CK(ov2_ctx_create_with_priority(device, prioA, &ctxA));
     ov2_tracker_config tc{};
     tc.w = w; tc.h = h; tc.win = 9; tc.nklt_pyr_lvl = 3; tc.prior_pyr_lvl = 1; tc.max_iter = 30; tc.eps = 0.01f; tc.err_th = 30.f; tc.fb_dist = 0.5f;
     tc.use_clahe = 1; tc.clahe_clip = 3.0; tc.tiles_x = w / 50; tc.tiles_y = h / 50; tc.n_max = 2 * nbmaxkps; tc.use_graph = 0;
@@ -105,10 +116,11 @@ int main(int argc, char **argv)
 
     // ---- the rank's mapper thread (one batched job per keyframe step) and the per-sequence estimator threads -------------
     ov2_ctx *ctxB;
-    CK(ov2_ctx_create_with_priority(device, use_prio ? 1 : 0, &ctxB));
+    CK(ov2_ctx_create_with_priority(device, prioB, &ctxB));
     ov2_pyr *pyrR;
     CK(ov2_pyr_create(ctxB, w, h, 9, 3, N, &pyrR));
     Queue<std::unique_ptr<KfBatch>> map_q;
+    Queue<std::pair<int, int>> est_q;                           // (batch item, keyframe) for the rank's estimator thread
     std::mutex done_m; std::condition_variable done_cv; int mapper_done_kf = -1;
     double mapper_busy_total = 0;
     std::thread mapper([&] {
@@ -131,15 +143,63 @@ int main(int argc, char **argv)
                 s.sdig.val(j->f); s.sdig.val(n); s.sdig.add(&right[2 * o], 8 * (size_t)n); s.sdig.add(&ok[o], (size_t)n);
                 s.stereo_kfs++; s.stereo_kps += n;
                 for (int i = 0; i < n; i++) s.stereo_ok += ok[o + i];
-                if (!s.C.ba.empty()) s.ba_q.push(j->f);
+                if (!s.C.ba.empty()) { if (est_batch) est_q.push({b, j->f}); else s.ba_q.push(j->f); }
                 if (j->f + kf_every > s.C.n_frames - 1) s.ba_q.close();                // the sequence's last keyframe
             }
         }
         for (auto &s : S) s->ba_q.close();
+        est_q.close();
     });
+    ov2_ctx *ctxE = nullptr;
+    std::thread estimator_b;
+    long est_batches = 0, est_problems = 0;
+    if (est_batch) {
+        CK(ov2_ctx_create_with_priority(device, prioE, &ctxE));
+        estimator_b = std::thread([&] {
+            std::vector<std::deque<int>> pending((size_t)N);
+            std::vector<int> nsolve((size_t)N, 0), who;
+            std::vector<ov2_ba_problem> P; std::vector<ov2_local_ba_options> O; std::vector<ov2_local_ba_result> R;
+            std::vector<std::vector<double>> poses((size_t)N), lam((size_t)N);
+            std::vector<std::vector<uint8_t>> bad((size_t)N);
+            std::pair<int, int> it;
+            for (;;) {
+                bool any = false;
+                for (auto &q : pending) any = any || !q.empty();
+                if (!any) { if (!est_q.pop(it)) break; pending[(size_t)it.first].push_back(it.second); }
+                while (est_q.try_pop(it)) pending[(size_t)it.first].push_back(it.second);
+                who.clear(); P.clear(); O.clear(); R.clear();
+                for (int b = 0; b < N; b++) {
+                    std::deque<int> &q = pending[(size_t)b];
+                    if (q.empty()) continue;
+                    Seq &s = *S[(size_t)b];
+                    if (!ba_all) { s.ba_skipped += (long)q.size() - 1; q.clear(); }      // only the last received keyframe (estimator.cpp:195-205)
+                    else q.pop_front();
+                    const BAProb &p = s.C.ba[(size_t)nsolve[(size_t)b]++ % s.C.ba.size()];
+                    ov2_ba_problem Pb; fill_ba_problem(p, Pb);
+                    ov2_local_ba_options Ob; ov2_local_ba_default_options(&Ob);
+                    poses[(size_t)b].resize(7 * (size_t)p.n_kf); lam[(size_t)b].resize((size_t)p.n_lm); bad[(size_t)b].resize((size_t)p.n_res);
+                    ov2_local_ba_result Rb{};
+                    Rb.poses_out = poses[(size_t)b].data(); Rb.invdepth_out = lam[(size_t)b].data(); Rb.bad_obs = bad[(size_t)b].data();
+                    who.push_back(b); P.push_back(Pb); O.push_back(Ob); R.push_back(Rb);
+                }
+                const double t0 = now();
+                int nb = 0;
+                CK(ov2_local_ba_batch(ctxE, (int)who.size(), P.data(), O.data(), R.data(), &nb));
+                const double dt = now() - t0, t1 = now();
+                est_batches++; est_problems += (long)who.size();
+                for (size_t k = 0; k < who.size(); k++) {
+                    Seq &s = *S[(size_t)who[k]];
+                    s.ba_busy += dt / who.size();
+                    s.ba_solves++; s.ba_iterations += R[k].iterations[0] + R[k].iterations[1]; s.ba_device_ms += (R[k].solve_ms[0] + R[k].solve_ms[1]) / who.size();
+                    s.t_drained = t1;
+                }
+            }
+        });
+    }
     for (auto &sp : S) {
+        if (est_batch) break;
         Seq *s = sp.get();
-        CK(ov2_ctx_create_with_priority(device, use_prio ? -1 : 0, &s->ctxC));
+        CK(ov2_ctx_create_with_priority(device, prioE, &s->ctxC));
         s->estimator = std::thread([s, ba_all] {
             int f, nsolve = 0;
             while (s->ba_q.pop(f)) {
@@ -341,7 +401,8 @@ int main(int argc, char **argv)
     CK(ov2_ctx_sync(ctxA));
     const double slam_s = now() - t0;
     map_q.close(); mapper.join();
-    for (auto &s : S) s->estimator.join();
+    if (est_batch) estimator_b.join();
+    else for (auto &s : S) s->estimator.join();
     const double total_s = now() - t0;
     const double t_end = wall();
     { std::lock_guard<std::mutex> l(LD.m); LD.quit = true; }
@@ -368,10 +429,11 @@ int main(int argc, char **argv)
     for (auto &l : lines) printf("%s\n", l.c_str());
     printf("{\"lockstep_summary\": true, \"sequences\": %d, \"frames\": %ld, \"steps\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, "
            "\"slam_library_s\": %.6f, \"slam_wait_for_loader_s\": %.6f, \"slam_wait_for_mapper_s\": %.6f, \"loader_threads\": %d, \"stream_priorities\": %d, \"device\": %d, "
-           "\"t_begin\": %.6f, \"t_end\": %.6f}\n",
-           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, t_begin, t_end);
+           "\"batched_estimator\": %d, \"ba_batches\": %ld, \"ba_problems\": %ld, \"t_begin\": %.6f, \"t_end\": %.6f}\n",
+           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, est_batch ? 1 : 0, est_batches, est_problems, t_begin, t_end);
 
-    for (auto &s : S) ov2_ctx_destroy(s->ctxC);
+    for (auto &s : S) if (s->ctxC) ov2_ctx_destroy(s->ctxC);
+    if (ctxE) ov2_ctx_destroy(ctxE);
     ov2_pyr_destroy(pyrR); ov2_ctx_destroy(ctxB);
     ov2_btracker_destroy(trk);
     ov2_ctx_destroy(ctxA);

@@ -30,10 +30,12 @@ def main():
     exe_s = stream.build_native_driver(d, "stream_driver")
     res = {"scale": scale, "frames": sum(max(12, batch.EUROC_FRAMES[s] // scale) for s in order), "runs": []}
     stream.run_lockstep(exe_l, cases[:3], ba_policy="newest")                       # warm-up
-    for policy, loaders, prio in (("newest", 4, True), ("newest", 4, False), ("newest", 1, True), ("all", 4, True), ("all", 4, False)):
+    for policy, loaders, prio, eb in (("newest", 4, True, True), ("all", 4, True, True), ("newest", 4, False, True), ("newest", 1, True, True), ("all", 4, False, True),
+                                      ("newest", 4, True, False), ("all", 4, True, False), ("newest", 4, True, True), ("all", 4, True, True)):
         if True:
-            st, sm = stream.run_lockstep(exe_l, cases, ba_policy=policy, loader_threads=loaders, priorities=prio)
-            r = {"mode": "lockstep", "policy": policy, "loader_threads": loaders, "stream_priorities": prio, "fps": sm["frames"] / sm["seconds"], "seconds": sm["seconds"],
+            st, sm = stream.run_lockstep(exe_l, cases, ba_policy=policy, loader_threads=loaders, priorities=prio, batched_estimator=eb)
+            r = {"mode": "lockstep", "policy": policy, "loader_threads": loaders, "stream_priorities": prio, "batched_estimator": eb, "ba_batches": sm.get("ba_batches"),
+                 "fps": sm["frames"] / sm["seconds"], "seconds": sm["seconds"],
                  "slam_thread_seconds": sm["slam_thread_seconds"], "slam_library_s": sm["slam_library_s"],
                  "wait_loader_s": sm["slam_wait_for_loader_s"], "wait_mapper_s": sm["slam_wait_for_mapper_s"], "steps": sm["steps"],
                  "us_per_step_library": 1e6 * sm["slam_library_s"] / sm["steps"],
