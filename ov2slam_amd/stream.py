@@ -303,7 +303,7 @@ def run_native(exe, case_path, ba_policy="newest", device=0):
 def lockstep_argv(exe, case_paths, ba_policy="newest", device=0, loader_threads=4, priorities=False, batched_estimator=True):
     """Command line of tools/lockstep_driver.cpp: ALL of the rank's sequences in one process, advanced one frame per step through
     the lock-step tracker (ov2_btracker_*); the rank's GPU travels as argv[3] like stream_driver's."""
-    return [exe, ",".join(case_paths), ba_policy, str(int(device)), str(int(loader_threads)), priorities if isinstance(priorities, str) else ("1" if priorities else "0"), "1" if batched_estimator else "0"]
+    return [exe, ",".join(case_paths), ba_policy, str(int(device)), str(int(loader_threads)), priorities if isinstance(priorities, str) else ("1" if priorities else "0"), str(int(batched_estimator))]
 
 
 def run_lockstep(exe, case_paths, device=0, ba_policy="newest", loader_threads=4, timeout=1800, priorities=False, batched_estimator=True):

@@ -26,6 +26,7 @@
 #include "tools/driver_common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 
 struct Seq {
@@ -82,6 +83,9 @@ int main(int argc, char **argv)
     int prioA = use_prio ? 1 : 0, prioB = use_prio ? 1 : 0, prioE = use_prio ? -1 : 0;
     if (argc > 5 && strchr(argv[5], ',')) sscanf(argv[5], "%d,%d,%d", &prioA, &prioB, &prioE);
     const bool est_batch = argc > 6 ? atoi(argv[6]) != 0 : true;
+    // (argv[6] > 1: that many estimator threads, each batching the sequences b with b % groups == its number -- while one group's batch
+    // is on the GPU the next one's problems are sorted and staged on the host)
+    const int est_groups = est_batch ? std::max(1, argc > 6 ? atoi(argv[6]) : 1) : 0;
     std::vector<std::string> paths;
     for (std::string rest = argv[1]; !rest.empty();) {
         const size_t c = rest.find(',');
@@ -120,7 +124,8 @@ int main(int argc, char **argv)
     ov2_pyr *pyrR;
     CK(ov2_pyr_create(ctxB, w, h, 9, 3, N, &pyrR));
     Queue<std::unique_ptr<KfBatch>> map_q;
-    Queue<std::pair<int, int>> est_q;                           // (batch item, keyframe) for the rank's estimator thread
+    std::vector<std::unique_ptr<Queue<std::pair<int, int>>>> est_q;      // (batch item, keyframe) for the rank's estimator thread(s)
+    for (int g = 0; g < std::max(1, est_groups); g++) est_q.emplace_back(new Queue<std::pair<int, int>>());
     std::mutex done_m; std::condition_variable done_cv; int mapper_done_kf = -1;
     double mapper_busy_total = 0;
     std::thread mapper([&] {
@@ -143,19 +148,21 @@ int main(int argc, char **argv)
                 s.sdig.val(j->f); s.sdig.val(n); s.sdig.add(&right[2 * o], 8 * (size_t)n); s.sdig.add(&ok[o], (size_t)n);
                 s.stereo_kfs++; s.stereo_kps += n;
                 for (int i = 0; i < n; i++) s.stereo_ok += ok[o + i];
-                if (!s.C.ba.empty()) { if (est_batch) est_q.push({b, j->f}); else s.ba_q.push(j->f); }
+                if (!s.C.ba.empty()) { if (est_batch) est_q[(size_t)(b % est_groups)]->push({b, j->f}); else s.ba_q.push(j->f); }
                 if (j->f + kf_every > s.C.n_frames - 1) s.ba_q.close();                // the sequence's last keyframe
             }
         }
         for (auto &s : S) s->ba_q.close();
-        est_q.close();
+        for (auto &q : est_q) q->close();
     });
-    ov2_ctx *ctxE = nullptr;
-    std::thread estimator_b;
-    long est_batches = 0, est_problems = 0;
-    if (est_batch) {
-        CK(ov2_ctx_create_with_priority(device, prioE, &ctxE));
-        estimator_b = std::thread([&] {
+    auto est_q_ptr = [&](int g) { return est_q[(size_t)g].get(); };
+    std::vector<ov2_ctx *> ctxE((size_t)est_groups, nullptr);
+    std::vector<std::thread> estimator_b;
+    std::atomic<long> est_batches{0}, est_problems{0};
+    for (int g = 0; g < est_groups; g++) {
+        CK(ov2_ctx_create_with_priority(device, prioE, &ctxE[(size_t)g]));
+        estimator_b.emplace_back([&, g] {
+            Queue<std::pair<int, int>> &est_q = *est_q_ptr(g);
             std::vector<std::deque<int>> pending((size_t)N);
             std::vector<int> nsolve((size_t)N, 0), who;
             std::vector<ov2_ba_problem> P; std::vector<ov2_local_ba_options> O; std::vector<ov2_local_ba_result> R;
@@ -184,7 +191,7 @@ int main(int argc, char **argv)
                 }
                 const double t0 = now();
                 int nb = 0;
-                CK(ov2_local_ba_batch(ctxE, (int)who.size(), P.data(), O.data(), R.data(), &nb));
+                CK(ov2_local_ba_batch(ctxE[(size_t)g], (int)who.size(), P.data(), O.data(), R.data(), &nb));
                 const double dt = now() - t0, t1 = now();
                 est_batches++; est_problems += (long)who.size();
                 for (size_t k = 0; k < who.size(); k++) {
@@ -401,7 +408,7 @@ int main(int argc, char **argv)
     CK(ov2_ctx_sync(ctxA));
     const double slam_s = now() - t0;
     map_q.close(); mapper.join();
-    if (est_batch) estimator_b.join();
+    if (est_batch) for (auto &t : estimator_b) t.join();
     else for (auto &s : S) s->estimator.join();
     const double total_s = now() - t0;
     const double t_end = wall();
@@ -430,10 +437,10 @@ int main(int argc, char **argv)
     printf("{\"lockstep_summary\": true, \"sequences\": %d, \"frames\": %ld, \"steps\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, "
            "\"slam_library_s\": %.6f, \"slam_wait_for_loader_s\": %.6f, \"slam_wait_for_mapper_s\": %.6f, \"loader_threads\": %d, \"stream_priorities\": %d, \"device\": %d, "
            "\"batched_estimator\": %d, \"ba_batches\": %ld, \"ba_problems\": %ld, \"t_begin\": %.6f, \"t_end\": %.6f}\n",
-           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, est_batch ? 1 : 0, est_batches, est_problems, t_begin, t_end);
+           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, est_groups, est_batches.load(), est_problems.load(), t_begin, t_end);
 
     for (auto &s : S) if (s->ctxC) ov2_ctx_destroy(s->ctxC);
-    if (ctxE) ov2_ctx_destroy(ctxE);
+    for (ov2_ctx *c : ctxE) if (c) ov2_ctx_destroy(c);
     ov2_pyr_destroy(pyrR); ov2_ctx_destroy(ctxB);
     ov2_btracker_destroy(trk);
     ov2_ctx_destroy(ctxA);
