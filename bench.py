@@ -712,6 +712,20 @@ def ba_section(ctx):
                     "two_ov2_ba_solve_calls_wall_ms": wall2 * 1e3, "same_outlier_set_as_two_calls": bool(np.array_equal(r["bad_obs"], r2["bad_obs"])),
                     "workload": "Optimizer.localBA on " + what + ": robust pass (<=5 it) + outlier removal + L2 pass (<=10 it) + second "
                                 "test in ONE ov2_local_ba call, host arrays in, poses / inverse depths / outlier flags out"}
+    # the estimator side of configs[4]: the windows of a rank's eleven sequences in ONE ov2_local_ba_batch call (grid.z = problem)
+    wins = [synth.make_ba_problem(25, 3000, 12, stereo=True, seed=7 + i) for i in range(11)]
+    wall_b, rb = wall_of(lambda: opt.localBA_batch(wins, want_chi2=False), reps=5)
+    wall_s, rs = wall_of(lambda: [opt.localBA(w, want_chi2=False) for w in wins], reps=2)
+    res_b, n_shared = rb
+    its_b = sum(sum(r["iterations"]) for r in res_b)
+    out["localba_batch_11_windows"] = {
+        "wall_ms_incl_h2d_d2h": wall_b * 1e3, "device_ms": sum(res_b[0]["solve_ms"]), "problems_sharing_the_launches": n_shared,
+        "iterations_total": its_b, "iters_per_s_wall": its_b / wall_b,
+        "eleven_ov2_local_ba_calls_wall_ms": wall_s * 1e3, "eleven_calls_device_ms": sum(sum(r["solve_ms"]) for r in rs),
+        "same_outlier_sets_as_single_calls": bool(all(np.array_equal(a["bad_obs"], b["bad_obs"]) for a, b in zip(res_b, rs))),
+        "same_iteration_counts_as_single_calls": bool(all(a["iterations"] == b["iterations"] for a, b in zip(res_b, rs))),
+        "workload": "eleven 25 KF x 3000 landmark x 12 obs stereo windows (different seeds), two-pass localBA each, host arrays in / results out; "
+                    "wall clock includes the Python packing of the eleven problems"}
     return out, pb, gpu_poses
 
 
