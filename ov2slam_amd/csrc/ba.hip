@@ -150,6 +150,7 @@ struct BADev {                    // device pointers + sizes (passed by value to
     const int *lm_order_b;                        // the lineariser's anchor-sorted landmark order
     const double *pose0, *lam0;                   // the problem's initial parameters (7 n_kf, n_lm)
     int n_res;                                    // residual blocks of the caller's arrays (chi2 / dpos / bad_obs entries)
+    uint8_t *out_b; int out_flags;                // the problem's slot of the batch's result block (k_ba_gather_B); 1: + chi2, 2: + depth flags
     int skip2;                                    // the problem takes no second pass (no outliers / stop requested): its second outlier test is skipped
 };
 
@@ -3247,6 +3248,23 @@ __global__ __launch_bounds__(256) void k_ba_reset_B(const BADev *__restrict__ ar
     for (long long e = i0; e < D.nfp; e += stride) { D.bf[e] = 0; D.yf[e] = 0; }
 }
 
+// results of the batch into ONE block (poses | inverse depths | outlier verdicts [| chi2] [| depth flags] per problem, 256-byte
+// aligned parts): one download instead of three to five small ones per problem
+__global__ __launch_bounds__(256) void k_ba_gather_B(const BADev *__restrict__ arr)
+{
+    const BADev &D = arr[blockIdx.z];
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    uint8_t *o = D.out_b;
+    for (long long e = i0; e < 7LL * D.n_kf; e += stride) ((double *)o)[e] = D.x_pose[e];
+    o += (56 * (size_t)D.n_kf + 255) & ~(size_t)255;
+    for (long long e = i0; e < D.n_lm; e += stride) ((double *)o)[e] = D.x_lam[e];
+    o += (8 * (size_t)max(1, D.n_lm) + 255) & ~(size_t)255;
+    for (long long e = i0; e < D.n_res; e += stride) o[e] = D.bad_obs[e];
+    o += ((size_t)D.n_res + 255) & ~(size_t)255;
+    if (D.out_flags & 1) { for (long long e = i0; e < D.n_res; e += stride) ((double *)o)[e] = D.chi2[e]; o += (8 * (size_t)D.n_res + 255) & ~(size_t)255; }
+    if (D.out_flags & 2) for (long long e = i0; e < D.n_res; e += stride) o[e] = D.dpos[e];
+}
+
 static bool ba_small_path(int n_opt)
 {
     const int nf = 6 * n_opt, nfp = std::max(BA_TILE, (nf + BA_TILE - 1) / BA_TILE * BA_TILE);
@@ -3424,10 +3442,20 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
     auto lap = [&](const char *what) {
         if (dbg) fprintf(stderr, "[ov2 local_ba_batch] %-28s %8.3f ms since entry (%d problems)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(), N);
     };
+    size_t out_base = 0, out_total = 0;                     // the batch's result block (k_ba_gather_B) inside the header
+    std::vector<size_t> out_off;
     if (N > 0) {
         // header of the pinned block: look-ahead words, counters, control blocks, device views; then the staging mirrors
         const size_t hb_flag = 0, hb_cnt = al256(4 * (size_t)N), hb_ctl = hb_cnt + al256(64 * (size_t)N), hb_arr = hb_ctl + al256(sizeof(BACtl) * (size_t)N);
-        const size_t header = hb_arr + al256(sizeof(BADev) * (size_t)N);
+        out_base = hb_arr + al256(sizeof(BADev) * (size_t)N);
+        out_off.assign(idx.size(), 0);
+        for (size_t k = 0; k < idx.size(); k++) {
+            const ov2_ba_problem &q = p[idx[k]];
+            const size_t nk = (size_t)std::max(0, q.n_kf), nl = (size_t)std::max(1, q.n_lm), nr = (size_t)std::max(0, q.n_res);
+            out_off[k] = out_total;
+            out_total += al256(56 * nk) + al256(8 * nl) + al256(nr) + (r[idx[k]].chi2_last_eval ? al256(8 * nr) : 0) + (r[idx[k]].depthpos_last_eval ? al256(nr) : 0);
+        }
+        const size_t header = out_base + al256(out_total);          // (look-ahead words | counters | control blocks | views | results), then the problems' slices
         size_t host_need = header, dev_need = header;
         for (;;) {
             int rc = ctx->reserve_host(std::max(host_need, ctx->h_scratch_bytes));
@@ -3439,9 +3467,9 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             BASlice sl;
             sl.dev_base = db; sl.dev_cap = ctx->d_scratch_bytes; sl.dev_used = header; sl.host_base = hb; sl.host_cap = ctx->h_scratch_bytes; sl.host_used = header;
             // the host side of a problem (validation, the landmark sort, the staging mirror; ~0.4 ms for a 69 k-block window) on a thread of
-            // its own, up to eight at a time -- on one thread it was more than the batch's device time.  Each thread enqueues its
+            // its own, up to sixteen at a time -- on one thread it was more than the batch's device time.  Each thread enqueues its
             // problem's upload on the context's stream itself (the order of the uploads does not matter).
-            const int NT = std::min(8, (int)idx.size());
+            const int NT = std::min(16, (int)idx.size());
             std::vector<ov2_ba_dev *> made(idx.size(), nullptr);
             std::vector<int> rcs(idx.size(), OV2_OK);
             std::vector<std::string> errs(idx.size());
@@ -3464,7 +3492,14 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
                 if (rcs[k] == BA_SLICE_FULL) full = true;
                 else if (rcs[k] != OV2_OK && bad_rc == OV2_OK) { bad_rc = rcs[k]; bad_k = k; }
             }
-            if (bad_rc == OV2_OK && !full) { B.devs = made; break; }
+            if (bad_rc == OV2_OK && !full) {
+                for (size_t k = 0; k < idx.size(); k++) {
+                    made[k]->D.out_b = db + out_base + out_off[k];
+                    made[k]->D.out_flags = (r[idx[k]].chi2_last_eval ? 1 : 0) | (r[idx[k]].depthpos_last_eval ? 2 : 0);
+                }
+                B.devs = made;
+                break;
+            }
             OV2_HIP_CHECK(hipStreamSynchronize(s));
             for (ov2_ba_dev *d : made) ba_destroy(d);
             if (bad_rc != OV2_OK) { ov2_set_error("ov2_local_ba_batch: problem %d: %s", idx[bad_k], errs[bad_k].c_str()); return bad_rc; }
@@ -3473,7 +3508,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
         }
         // problems that turn out to carry pose-only blocks leave the batch
         for (size_t k = 0; k < B.devs.size();) {
-            if (B.devs[k]->D.n_po > 0 || B.devs[k]->D.big) { alone[(size_t)idx[k]] = 1; OV2_HIP_CHECK(hipStreamSynchronize(s)); ba_destroy(B.devs[k]); B.devs.erase(B.devs.begin() + (long)k); idx.erase(idx.begin() + (long)k); }
+            if (B.devs[k]->D.n_po > 0 || B.devs[k]->D.big) { alone[(size_t)idx[k]] = 1; OV2_HIP_CHECK(hipStreamSynchronize(s)); ba_destroy(B.devs[k]); B.devs.erase(B.devs.begin() + (long)k); idx.erase(idx.begin() + (long)k); out_off.erase(out_off.begin() + (long)k); }
             else k++;
         }
         N = (int)idx.size();
@@ -3547,17 +3582,29 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
                 OV2_HIP_CHECK(hipMemcpyAsync(B.h_cnt, B.d_cnt, 64 * (size_t)N, hipMemcpyDeviceToHost, s));
             }
         }
-        for (int k = 0; k < N; k++) {
-            ov2_local_ba_result &ri = r[idx[(size_t)k]];
-            const ov2_ba_dev *dev = B.devs[(size_t)k];
-            const BADev &D = dev->D;
-            if (ri.poses_out) OV2_HIP_CHECK(hipMemcpyAsync(ri.poses_out, D.x_pose, 56 * (size_t)D.n_kf, hipMemcpyDeviceToHost, s));
-            if (ri.invdepth_out) OV2_HIP_CHECK(hipMemcpyAsync(ri.invdepth_out, D.x_lam, 8 * (size_t)D.n_lm, hipMemcpyDeviceToHost, s));
-            if (ri.bad_obs && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.bad_obs, D.bad_obs, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
-            if (ri.chi2_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.chi2_last_eval, D.chi2, 8 * (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
-            if (ri.depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(ri.depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
+        {
+            int gb = 1;
+            for (int k = 0; k < N; k++) gb = std::max(gb, std::min(64, (std::max(B.devs[(size_t)k]->D.n_res, B.devs[(size_t)k]->D.n_lm) + 1023) / 1024));
+            hipLaunchKernelGGL(k_ba_gather_B, dim3(gb, 1, (unsigned)N), dim3(256), 0, s, (const BADev *)B.d_arr);
+            OV2_HIP_CHECK(hipGetLastError());
+            uint8_t *hb = (uint8_t *)ctx->h_scratch, *db = (uint8_t *)ctx->d_scratch;
+            OV2_HIP_CHECK(hipMemcpyAsync(hb + out_base, db + out_base, out_total, hipMemcpyDeviceToHost, s));
+            OV2_HIP_CHECK(hipStreamSynchronize(s));
+            for (int k = 0; k < N; k++) {
+                ov2_local_ba_result &ri = r[idx[(size_t)k]];
+                const BADev &D = B.devs[(size_t)k]->D;
+                const uint8_t *o = hb + out_base + out_off[(size_t)k];
+                const size_t nr = (size_t)D.n_res;
+                if (ri.poses_out) memcpy(ri.poses_out, o, 56 * (size_t)D.n_kf);
+                o += al256(56 * (size_t)D.n_kf);
+                if (ri.invdepth_out) memcpy(ri.invdepth_out, o, 8 * (size_t)D.n_lm);
+                o += al256(8 * (size_t)std::max(1, D.n_lm));
+                if (ri.bad_obs && nr > 0) memcpy(ri.bad_obs, o, nr);
+                o += al256(nr);
+                if (ri.chi2_last_eval) { if (nr > 0) memcpy(ri.chi2_last_eval, o, 8 * nr); o += al256(8 * nr); }
+                if (ri.depthpos_last_eval && nr > 0) memcpy(ri.depthpos_last_eval, o, nr);
+            }
         }
-        OV2_HIP_CHECK(hipStreamSynchronize(s));
         lap("outlier test 2 + download");
         for (int k = 0; k < N; k++) if (r[idx[(size_t)k]].l2_done) r[idx[(size_t)k]].n_bad_total = bad1[(size_t)k] + B.h_cnt[16 * k];
         for (ov2_ba_dev *d : B.devs) ba_destroy(d);

@@ -17,6 +17,7 @@ rng = np.random.default_rng(SEED)
 ctx = ov2slam_amd.Context(0)
 trk = ov2slam_amd.FeatureTracker(ctx, 30, 0.01)
 fails, loose = [], []
+ba_pool = []
 
 
 def rand_image(w, h, kind):
@@ -205,6 +206,23 @@ for case in range(N):
                 loose.append(("local_ba", dict(binfo, its=(tuple(gl["iterations"]), rits)))); print("LOOSE local_ba", loose[-1][1], flush=True)
             else:
                 check("local_ba", False, dict(binfo, its=(tuple(gl["iterations"]), rits), nbad=(int(gl["bad_obs"].sum()), int(rl["bad_obs"].sum()))))
+        # round 5: the lock-step batch (ov2_local_ba_batch) -- the last few random windows in ONE call against their one-problem results
+        ba_pool.append((pb, gl, dict(binfo)))
+        if len(ba_pool) >= 5:
+            stop = [bool(rng.integers(0, 4) == 0) for _ in ba_pool]
+            gb, nb = optimizer.Optimizer(ctx).localBA_batch([q[0] for q in ba_pool], stop=stop)
+            for (pq, g1, inf), b, st_ in zip(ba_pool, gb, stop):
+                if st_:                                                     # a stopped problem keeps pass 1: compare with a stopped single call
+                    o1 = optimizer.Optimizer(ctx); o1.signalStopLocalBA(); g1 = o1.localBA(pq)
+                okb = (b["l2_done"] == g1["l2_done"] and tuple(b["iterations"]) == tuple(g1["iterations"]) and np.array_equal(b["bad_obs"], g1["bad_obs"])
+                       and np.abs(b["poses"] - g1["poses"]).max() <= 1e-6 * max(1.0, np.abs(g1["poses"]).max()))
+                if not okb:
+                    if np.abs(b["poses"] - g1["poses"]).max() <= 1e-4 * max(1.0, np.abs(g1["poses"]).max()) and int((b["bad_obs"] != g1["bad_obs"]).sum()) <= 2:
+                        loose.append(("local_ba_batch", dict(inf, its=(tuple(b["iterations"]), tuple(g1["iterations"]))))); print("LOOSE local_ba_batch", loose[-1][1], flush=True)
+                    else:
+                        check("local_ba_batch", False, dict(inf, stop=st_, shared=nb, its=(tuple(b["iterations"]), tuple(g1["iterations"])),
+                                                            nbad=(int(b["bad_obs"].sum()), int(g1["bad_obs"].sum()))))
+            ba_pool.clear()
         pb = synth.make_xyz_ba_problem(n_kf, n_lm, min(obs, n_kf), stereo=stereo, seed=bseed)
         g = optimizer.solve_xyz(ctx, pb, optimizer.default_options(ctx.lib, **kw)); r = O.xyz_ba_solve(pb, O.ba_default_options(**kw))
         ba_check("ba_xyz", g, r, "xyz")
