@@ -3295,12 +3295,18 @@ static int ba_run_batch(ov2_ctx *ctx, BABatch &B, const ov2_ba_options *o, const
     O.min_rel_decrease = o->min_relative_decrease; O.jacobi = o->jacobi_scaling; O.max_invalid = o->max_consecutive_invalid_steps;
     int lin_blocks = 1, bs_blocks = 1, cost_blocks = 1, nupper = 1, ksplit_max = 1, nf_max = 0, nfp_max = 0, reset_blocks = 1, init_blocks = 1;
     size_t lin_lds = 0, chol_lds = 0;
+    // a single problem spreads over the whole chip for latency (16 landmarks per lineariser work-group, 1024 Schur work-groups); a batch
+    // fills it anyway: ~768 lineariser and ~2048 Schur work-groups over ALL problems -- fewer flushes of the LDS aggregates and fewer
+    // atomic adds into G per problem (eleven windows: 2.31 -> 2.07 ms of device time; tools/r5_ba_batch_grid.sh swept 512 .. 4096 / 1024 .. 16384)
+    const int lin_total = 768, schur_total = 2048;
+    const int lin_cap = std::max(16, std::min(256, (lin_total + N - 1) / N));
+    const int schur_wgs = std::max(64, std::min(1024, (schur_total + N - 1) / N));
     for (int i = 0; i < N; i++) {
         const BADev &D = B.devs[(size_t)i]->D;
         const int n_opt = D.nf / 6;
         lin_lds = std::max(lin_lds, 8 * (8 * (size_t)D.nfp + (size_t)n_opt * 27 + 4 * (size_t)n_opt * 21 + 4 * (size_t)LIN_RED) + 64);
         chol_lds = std::max(chol_lds, chol_lds_bytes(D.nf, D.nfp));
-        lin_blocks = std::max(lin_blocks, std::min(256, (D.n_lm + 15) / 16));
+        lin_blocks = std::max(lin_blocks, std::min(lin_cap, (D.n_lm + 15) / 16));
         bs_blocks = std::max(bs_blocks, std::min(2048, (D.n_lm + 15) / 16));
         cost_blocks = std::max(cost_blocks, std::min(2048, (D.n_lm + 7) / 8));
         nf_max = std::max(nf_max, D.nf); nfp_max = std::max(nfp_max, D.nfp);
@@ -3313,7 +3319,7 @@ static int ba_run_batch(ov2_ctx *ctx, BABatch &B, const ov2_ba_options *o, const
         D.huber = huber[i]; D.min_diag = o->min_lm_diagonal; D.max_diag = o->max_lm_diagonal;
         D.bs_blocks = bs_blocks; D.cost_blocks = cost_blocks; D.lin_blocks = lin_blocks;
         const int ntiles = D.nfp / BA_TILE, n_upper = ntiles * (ntiles + 1) / 2;
-        int ksplit = std::max(1, std::min(64, (1024 + n_upper - 1) / n_upper));
+        int ksplit = std::max(1, std::min(64, (schur_wgs + n_upper - 1) / n_upper));
         const int lmps = std::max(BA_TILE, ((D.n_lm + ksplit - 1) / ksplit + BA_TILE - 1) / BA_TILE * BA_TILE);
         ksplit = std::max(1, (D.n_lm + lmps - 1) / lmps);
         D.g_ntiles = ntiles; D.g_nupper = n_upper; D.g_lmps = lmps; D.g_ksplit = ksplit;
