@@ -89,6 +89,15 @@ def test_batch_falls_back_for_problems_it_does_not_cover(gpu_ctx):
     _same(res[0], ov2slam_amd.Optimizer(gpu_ctx).localBA(small))
     _same(res[1], ov2slam_amd.Optimizer(gpu_ctx).localBA(large), tight=1e-6)
     _same(res[2], res[0])
+    # the deterministic mode is a one-problem-at-a-time mode: the batch call falls back for every problem and returns its bit patterns
+    from ov2slam_amd import _lib as L
+    gpu_ctx.set_option(L.OV2_OPT_BA_DETERMINISTIC, 1)
+    try:
+        res, nb = ov2slam_amd.Optimizer(gpu_ctx).localBA_batch([small, small])
+        one = ov2slam_amd.Optimizer(gpu_ctx).localBA(small)
+    finally:
+        gpu_ctx.set_option(L.OV2_OPT_BA_DETERMINISTIC, 0)
+    assert nb == 0 and np.array_equal(res[0]["poses"], one["poses"]) and np.array_equal(res[1]["poses"], one["poses"])
     # an empty batch is a no-op; invalid input is rejected
     res, nb = ov2slam_amd.Optimizer(gpu_ctx).localBA_batch([])
     assert res == [] and nb == 0
