@@ -13,7 +13,7 @@
 //   copy stream      H2D of frame f + 2                       (ov2_btracker_upload)
 //   prep stream      CLAHE + pyramid of frame f + 1           (ov2_btracker_prepare; into the NEXT pyramid set)
 //   context stream   kltTracking + computeKeypoint of frame f (ov2_btracker_track_frame: waits for its pyramids, one sync)
-// with three pinned staging sets and four pyramid sets in rotation; events order producer -> consumer and consumer -> the producer
+// with three pinned staging sets and six pyramid sets in rotation; events order producer -> consumer and consumer -> the producer
 // that reuses a buffer.  A caller that uses neither look-ahead call gets the same results from the plain in-order enqueue.
 // Results per item are bit-identical to an ov2_tracker fed the same frames and keypoints (tests/test_gpu_lockstep.py).
 #include "common.hpp"
