@@ -314,6 +314,14 @@ int  ov2_btracker_set_calibration(ov2_btracker *t, int model, const double K[4],
 int  ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const *img_h, int stride, const float *kps_xy_h,
                               const float *prior_xy_h, const uint8_t *has_prior_h, const int *n_h, int klt_use_prior,
                               float *out_xy_h, uint8_t *status_h, int *p3p_req);
+/* The same step in two halves: _begin enqueues it (frames, pre-processing or the wait for the prepared pyramids, the tracking
+ * kernels) and returns; _end waits for it, returns the results and applies the p3p rule.  Between the two the host is free -- an
+ * offline driver issues ov2_btracker_upload / ov2_btracker_prepare of the frames to come there, so that their enqueue cost runs beside
+ * the tracking kernels instead of before them.  kps_xy_h / has_prior_h must stay valid until _end (the p3p rule re-reads them).
+ * ov2_btracker_track_frame = _begin + _end.                                                                              */
+int  ov2_btracker_track_frame_begin(ov2_btracker *t, int n_active, const uint8_t *const *img_h, int stride, const float *kps_xy_h,
+                                    const float *prior_xy_h, const uint8_t *has_prior_h, const int *n_h, int klt_use_prior);
+int  ov2_btracker_track_frame_end(ov2_btracker *t, float *out_xy_h, uint8_t *status_h, int *p3p_req);
 /* unpx (2 floats) / bv (3 doubles) of the first n keypoints of item `item` from the LAST ov2_btracker_track_frame */
 int  ov2_btracker_last_keypoints(const ov2_btracker *t, int item, int n, float *unpx_xy_h, double *bv_xyz_h);
 /* MapManager::extractKeypoints on the current frame of items [0, n_active) in one call (all sequences of a lock-step batch reach

@@ -183,6 +183,8 @@ SIGNATURES = {
     "ov2_btracker_prepare": (_i, [_vp, _i, _i]),
     "ov2_btracker_set_calibration": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "ov2_btracker_track_frame": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "ov2_btracker_track_frame_begin": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    "ov2_btracker_track_frame_end": (_i, [_vp, _vp, _vp, _vp]),
     "ov2_btracker_last_keypoints": (_i, [_vp, _i, _i, _vp, _vp]),
     "ov2_btracker_detect_singlescale": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(_i), _vp, _i, _vp, _i, _vp]),
     "ov2_btracker_detect_grid_fast": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),

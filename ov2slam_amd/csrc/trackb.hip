@@ -13,7 +13,7 @@
 //   copy stream      H2D of frame f + 2                       (ov2_btracker_upload)
 //   prep stream      CLAHE + pyramid of frame f + 1           (ov2_btracker_prepare; into the NEXT pyramid set)
 //   context stream   kltTracking + computeKeypoint of frame f (ov2_btracker_track_frame: waits for its pyramids, one sync)
-// with three pinned staging sets and six pyramid sets in rotation; events order producer -> consumer and consumer -> the producer
+// with three pinned staging sets and eight pyramid sets in rotation; events order producer -> consumer and consumer -> the producer
 // that reuses a buffer.  A caller that uses neither look-ahead call gets the same results from the plain in-order enqueue.
 // Results per item are bit-identical to an ov2_tracker fed the same frames and keypoints (tests/test_gpu_lockstep.py).
 #include "common.hpp"
@@ -24,7 +24,7 @@
 
 int ov2_launch_compute_keypoints(hipStream_t s, const KpCalib &c, const float *px_d, int n_max, const int *n_dev, float *unpx_d, double *bv_d, int items = 1);
 
-#define BT_SETS 6       // pyramid sets in rotation: cur, prev, the one being prepared for the next frame, three of slack for the mapper
+#define BT_SETS 8       // pyramid sets in rotation: cur, prev, the one being prepared for the next frame, five of slack for the mapper
                         // context (a keyframe's pyramids outlive it by BT_SETS - 1 steps: the keyframe period of the shipped parameter files)
 #define BT_IMG_SETS 3   // staging sets: frame f (read by its pre-processing), f + 1 (arriving), f + 2 (being filled by the host)
 
@@ -64,6 +64,8 @@ struct ov2_btracker {
     // keyframe detection: device mirrors of the items' current keypoints and of the detector's output, pinned staging
     uint8_t *d_det = nullptr, *h_det = nullptr; size_t det_in_bytes = 0;
     float *d_out = nullptr; uint8_t *h_out = nullptr; int out_cap = 0;
+    // a step between ov2_btracker_track_frame_begin and _end: what _end needs to finish it
+    struct Pending { bool on = false, tracked = false; int n_active = 0, use_prior = 0; const float *kps = nullptr; const uint8_t *has_prior = nullptr; std::vector<int> n; } pend;
 };
 
 static inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -412,11 +414,11 @@ int ov2_btracker_set_calibration(ov2_btracker *t, int model, const double K[4], 
     return OV2_OK;
 }
 
-int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const *img_h, int stride, const float *kps_xy_h,
-                             const float *prior_xy_h, const uint8_t *has_prior_h, const int *n_h, int klt_use_prior,
-                             float *out_xy_h, uint8_t *status_h, int *p3p_req)
+int ov2_btracker_track_frame_begin(ov2_btracker *t, int n_active, const uint8_t *const *img_h, int stride, const float *kps_xy_h,
+                                   const float *prior_xy_h, const uint8_t *has_prior_h, const int *n_h, int klt_use_prior)
 {
     OV2_REQUIRE(t && img_h, OV2_EINVAL, "NULL argument");
+    OV2_REQUIRE(!t->pend.on, OV2_EINVAL, "ov2_btracker_track_frame_begin: the previous step has not been finished (ov2_btracker_track_frame_end)");
     OV2_REQUIRE(n_active >= 1 && n_active <= t->batch, OV2_EINVAL, "n_active out of range");
     OV2_REQUIRE(stride >= t->cfg.w, OV2_EINVAL, "stride < width");
     const size_t nm = (size_t)t->cfg.n_max;
@@ -426,9 +428,8 @@ int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const
         const int n = n_h ? n_h[b] : 0;
         OV2_REQUIRE(n >= 0 && (size_t)n <= nm, OV2_EINVAL, "an item carries more keypoints than cfg.n_max slots");
         n_total += n;
-        if (p3p_req) p3p_req[b] = 0;
     }
-    OV2_REQUIRE(n_total == 0 || (kps_xy_h && prior_xy_h && out_xy_h && status_h && n_h), OV2_EINVAL, "NULL point buffer");
+    OV2_REQUIRE(n_total == 0 || (kps_xy_h && prior_xy_h && n_h), OV2_EINVAL, "NULL point buffer");
     for (int b = 0; b < t->batch; b++) t->last_n[(size_t)b] = 0;
     ov2_ctx *ctx = t->ctx;
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
@@ -446,31 +447,68 @@ int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const
         return ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
     };
     t->cur = (int)(t->frames % BT_SETS);                                 // prev_pyr_.swap(cur_pyr_)  (:1169): frame k lives in set k % BT_SETS
+    ov2_btracker::Pending &P = t->pend;
+    P.n_active = n_active; P.use_prior = klt_use_prior; P.kps = kps_xy_h; P.has_prior = has_prior_h;
+    P.n.assign((size_t)n_active, 0);
+    if (n_h) for (int b = 0; b < n_active; b++) P.n[(size_t)b] = n_h[b];
     if (t->frames == 0 || n_total == 0) {
         // first frame (trackMono returns right after preprocessImage) or nothing to track anywhere
         rc = preprocess();
         if (rc != OV2_OK) { t->cur = old_cur; return rc; }
         t->frames++;
-        if (status_h && n_h) for (int b = 0; b < n_active; b++) if (n_h[b] > 0) memset(status_h + nm * b, 0, (size_t)n_h[b]);
-        return ov2_ctx_sync(ctx);
+        P.tracked = false; P.on = true;
+        return OV2_OK;
     }
     stage_points(t, n_active, kps_xy_h, prior_xy_h, has_prior_h, n_h, klt_use_prior);
     rc = preprocess();
     if (rc == OV2_OK) rc = enqueue_klt(t, t->pyr[t->prev()], t->pyr[t->cur], n_active);
     if (rc != OV2_OK) { t->cur = old_cur; return rc; }
     t->frames++;
+    P.tracked = true; P.on = true;
+    return OV2_OK;
+}
+
+int ov2_btracker_track_frame_end(ov2_btracker *t, float *out_xy_h, uint8_t *status_h, int *p3p_req)
+{
+    OV2_REQUIRE(t, OV2_EINVAL, "NULL tracker");
+    ov2_btracker::Pending &P = t->pend;
+    OV2_REQUIRE(P.on, OV2_EINVAL, "ov2_btracker_track_frame_end without ov2_btracker_track_frame_begin");
+    P.on = false;
+    const size_t nm = (size_t)t->cfg.n_max;
+    ov2_ctx *ctx = t->ctx;
+    OV2_HIP_CHECK(hipSetDevice(ctx->device));
+    if (p3p_req) for (int b = 0; b < P.n_active; b++) p3p_req[b] = 0;
+    if (!P.tracked) {
+        if (status_h) for (int b = 0; b < P.n_active; b++) if (P.n[(size_t)b] > 0) memset(status_h + nm * b, 0, (size_t)P.n[(size_t)b]);
+        return ov2_ctx_sync(ctx);
+    }
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < n_active; b++) {
-        const size_t n = (size_t)n_h[b], o = nm * (size_t)b;
+    OV2_REQUIRE(out_xy_h && status_h, OV2_EINVAL, "NULL result buffer");
+    for (int b = 0; b < P.n_active; b++) {
+        const size_t n = (size_t)P.n[(size_t)b], o = nm * (size_t)b;
         if (!n) continue;
         memcpy(out_xy_h + 2 * o, t->hblk + t->o_out + 8 * o, 8 * n);
         memcpy(status_h + o, t->hblk + t->o_st + o, n);
-        rc = apply_p3p_rule(t, b, kps_xy_h + 2 * o, has_prior_h ? has_prior_h + o : nullptr, klt_use_prior, (int)n, out_xy_h + 2 * o,
-                            status_h + o, p3p_req ? p3p_req + b : nullptr);
+        const int rc = apply_p3p_rule(t, b, P.kps + 2 * o, P.has_prior ? P.has_prior + o : nullptr, P.use_prior, (int)n, out_xy_h + 2 * o,
+                                      status_h + o, p3p_req ? p3p_req + b : nullptr);
         if (rc != OV2_OK) return rc;
         if (t->has_calib) t->last_n[(size_t)b] = (int)n;
     }
     return OV2_OK;
+}
+
+int ov2_btracker_track_frame(ov2_btracker *t, int n_active, const uint8_t *const *img_h, int stride, const float *kps_xy_h,
+                             const float *prior_xy_h, const uint8_t *has_prior_h, const int *n_h, int klt_use_prior,
+                             float *out_xy_h, uint8_t *status_h, int *p3p_req)
+{
+    if (t && n_active >= 1 && n_active <= t->batch && n_h) {              // (the one-call form checks its result buffers before anything is enqueued)
+        int n_total = 0;
+        for (int b = 0; b < n_active; b++) n_total += n_h[b] > 0 ? n_h[b] : 0;
+        OV2_REQUIRE(n_total == 0 || (out_xy_h && status_h), OV2_EINVAL, "NULL point buffer");
+    }
+    const int rc = ov2_btracker_track_frame_begin(t, n_active, img_h, stride, kps_xy_h, prior_xy_h, has_prior_h, n_h, klt_use_prior);
+    if (rc != OV2_OK) return rc;
+    return ov2_btracker_track_frame_end(t, out_xy_h, status_h, p3p_req);
 }
 
 int ov2_btracker_last_keypoints(const ov2_btracker *t, int item, int n, float *unpx_xy_h, double *bv_xyz_h)

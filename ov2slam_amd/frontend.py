@@ -425,6 +425,28 @@ class LockstepTracker:
                                                   int(bool(klt_use_prior)), _ptr(out), _ptr(st), _ptr(p3p)))
         return out, st, p3p.astype(bool)
 
+    def trackFrameBegin(self, imgs, kps, pri, hasprior, n, klt_use_prior=True):
+        """first half of trackFrame: enqueue the step and return (upload / prepare of the frames to come go between the halves)"""
+        na = len(imgs)
+        imgs = [im if im.dtype == np.uint8 and im.strides[1] == 1 else np.ascontiguousarray(im, np.uint8) for im in imgs]
+        stride = imgs[0].strides[0]
+        ptrs = (C.c_void_p * na)(*[im.ctypes.data for im in imgs])
+        kps = np.ascontiguousarray(kps, np.float32).reshape(self.batch, self.n_max, 2)
+        pri = np.ascontiguousarray(pri, np.float32).reshape(self.batch, self.n_max, 2)
+        hp = None if hasprior is None else np.ascontiguousarray(hasprior, np.uint8).reshape(self.batch, self.n_max)
+        nn = np.ascontiguousarray(n, np.int32)
+        self._pending = (imgs, kps, pri, hp, nn)                                  # (kps / hasprior are re-read by trackFrameEnd: keep them alive)
+        L.check(self.lib.ov2_btracker_track_frame_begin(self.h_trk, na, ptrs, stride, _ptr(kps), _ptr(pri), _ptr(hp), _ptr(nn), int(bool(klt_use_prior))))
+
+    def trackFrameEnd(self):
+        """second half: wait, results, p3p rule -> (out, status bits, p3p_req) as trackFrame"""
+        na = len(self._pending[0])
+        out = np.zeros((self.batch, self.n_max, 2), np.float32); st = np.zeros((self.batch, self.n_max), np.uint8)
+        p3p = np.zeros(na, np.int32)
+        L.check(self.lib.ov2_btracker_track_frame_end(self.h_trk, _ptr(out), _ptr(st), _ptr(p3p)))
+        self._pending = None
+        return out, st, p3p.astype(bool)
+
     def lastKeypoints(self, item, n, want_bv=True):
         unpx = np.empty((n, 2), np.float32)
         bv = np.empty((n, 3), np.float64) if want_bv else None

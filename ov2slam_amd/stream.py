@@ -300,17 +300,17 @@ def run_native(exe, case_path, ba_policy="newest", device=0):
     return st
 
 
-def lockstep_argv(exe, case_paths, ba_policy="newest", device=0, loader_threads=4, priorities=False, batched_estimator=True):
+def lockstep_argv(exe, case_paths, ba_policy="newest", device=0, loader_threads=4, priorities=False, batched_estimator=True, host_workers=3):
     """Command line of tools/lockstep_driver.cpp: ALL of the rank's sequences in one process, advanced one frame per step through
     the lock-step tracker (ov2_btracker_*); the rank's GPU travels as argv[3] like stream_driver's."""
-    return [exe, ",".join(case_paths), ba_policy, str(int(device)), str(int(loader_threads)), priorities if isinstance(priorities, str) else ("1" if priorities else "0"), str(int(batched_estimator))]
+    return [exe, ",".join(case_paths), ba_policy, str(int(device)), str(int(loader_threads)), priorities if isinstance(priorities, str) else ("1" if priorities else "0"), str(int(batched_estimator)), str(int(host_workers))]
 
 
-def run_lockstep(exe, case_paths, device=0, ba_policy="newest", loader_threads=4, timeout=1800, priorities=False, batched_estimator=True):
+def run_lockstep(exe, case_paths, device=0, ba_policy="newest", loader_threads=4, timeout=1800, priorities=False, batched_estimator=True, host_workers=3):
     """-> (per-sequence stats in the order of case_paths, summary dict with frames / seconds / steps of the whole rank)"""
     import json
     import subprocess
-    r = subprocess.run(lockstep_argv(exe, case_paths, ba_policy, device, loader_threads, priorities, batched_estimator), capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run(lockstep_argv(exe, case_paths, ba_policy, device, loader_threads, priorities, batched_estimator, host_workers), capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError("lockstep_driver failed (%d): %s" % (r.returncode, r.stderr[-500:]))
     lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]

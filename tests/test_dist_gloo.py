@@ -115,8 +115,8 @@ def test_native_driver_receives_the_ranks_device():
     src = open(os.path.join(root, "tools", "stream_driver.cpp")).read()
     assert "ov2_ctx_create(0" not in src and src.count("ov2_ctx_create(device") == 3
     # (defaults: no stream priorities, the rank's estimator batched over its sequences; the round's first form stays selectable)
-    assert stream.lockstep_argv("drv", ["a.bin", "b.bin"], "all", 3, 2) == ["drv", "a.bin,b.bin", "all", "3", "2", "0", "1"]
-    assert stream.lockstep_argv("drv", ["a.bin"], "newest", 0, 4, True, False)[-2:] == ["1", "0"]
+    assert stream.lockstep_argv("drv", ["a.bin", "b.bin"], "all", 3, 2) == ["drv", "a.bin,b.bin", "all", "3", "2", "0", "1", "3"]
+    assert stream.lockstep_argv("drv", ["a.bin"], "newest", 0, 4, True, False)[-3:] == ["1", "0", "3"]
     src = open(os.path.join(root, "tools", "lockstep_driver.cpp")).read()          # the rank's lock-step host: SLAM, mapper and estimator contexts
     assert "ov2_ctx_create(0" not in src and "ov2_ctx_create_with_priority(0" not in src and src.count("ov2_ctx_create_with_priority(device") == 4     # (+ the batched estimator's)
     import inspect

@@ -116,9 +116,11 @@ def test_lockstep_equals_single_trackers(gpu_ctx, oracle, wh, use_clahe, impl):
         bt.close()
 
 
-def test_lockstep_pipeline(gpu_ctx):
-    """The three-stage look-ahead schedule of tools/lockstep_driver.cpp -- upload(f + 2), prepare(f + 1), track_frame(f), two prepared
-    frames in flight -- gives the in-order results; a track_frame on other frames than the prepared ones is refused."""
+@pytest.mark.parametrize("split", [False, True])
+def test_lockstep_pipeline(gpu_ctx, split):
+    """The three-stage look-ahead schedules of tools/lockstep_driver.cpp -- upload(f + 2), prepare(f + 1), track_frame(f) with two prepared
+    frames in flight; or (split) track_frame_begin(f), upload(f + 2), prepare(f + 1), track_frame_end(f): the enqueue of the frames to come
+    beside the tracking kernels -- give the in-order results; a track_frame on other frames than the prepared ones is refused."""
     w, h, batch, n_max, nframes = 752, 480, 4, 400, 9
     seqs = [_sequence(w, h, nframes, seed=90 + b) for b in range(batch)]
     length = [9, 9, 7, 5]
@@ -140,12 +142,16 @@ def test_lockstep_pipeline(gpu_ctx):
         fill(f)
     bt.upload(0, na_at(0)); bt.prepare(0, na_at(0)); bt.upload(1, na_at(1))
     z = np.zeros((batch, n_max, 2), np.float32)
-    for f in range(nframes):
-        na = na_at(f)
+
+    def look_ahead(f):
         if f + 2 < nframes and na_at(f + 2):
             bt.upload((f + 2) % 3, na_at(f + 2))
         if f + 1 < nframes and na_at(f + 1):
             bt.prepare((f + 1) % 3, na_at(f + 1))
+    for f in range(nframes):
+        na = na_at(f)
+        if not split or f == 0:
+            look_ahead(f)
         imgs = [bt.image_buffers[f % 3][b] for b in range(na)]
         if f == 0:
             bt.trackFrame(imgs, z, z, None, np.zeros(na, np.int32))
@@ -157,7 +163,14 @@ def test_lockstep_pipeline(gpu_ctx):
             if f == 4:                                            # not the prepared frames: refused, nothing consumed
                 with pytest.raises(ov2slam_amd.Ov2Error):
                     bt.trackFrame([seqs[b][0][f] for b in range(na)], kps, pri, hp, n)
-            out, st, p3p = bt.trackFrame(imgs, kps, pri, hp, n)
+            if split:
+                bt.trackFrameBegin(imgs, kps, pri, hp, n)
+                with pytest.raises(ov2slam_amd.Ov2Error):         # one step at a time
+                    bt.trackFrameBegin(imgs, kps, pri, hp, n)
+                look_ahead(f)
+                out, st, p3p = bt.trackFrameEnd()
+            else:
+                out, st, p3p = bt.trackFrame(imgs, kps, pri, hp, n)
             for b in range(na):
                 so, ss, sp = singles[b].trackFrame(seqs[b][0][f], *per[b])
                 m = len(per[b][0])

@@ -49,8 +49,9 @@ def test_lockstep_driver_is_bit_identical_to_the_per_stream_driver(tmp_path):
     exe_l = stream.build_native_driver(str(tmp_path), "lockstep_driver")
     ref = [stream.run_native(exe_s, c, ba_policy="all") for c in cases]
     # (estimator forms: one batch over the rank's sequences, two groups, the round's first form -- a thread and context per sequence)
-    for loaders, est, prio in ((1, 1, False), (3, 1, False), (2, 2, False), (2, 0, True)):
-        got, summary = stream.run_lockstep(exe_l, cases, ba_policy="all", loader_threads=loaders, batched_estimator=est, priorities=prio)
+    # and the per-sequence host work of a step on 0 .. 4 worker threads beside the SLAM thread
+    for loaders, est, prio, workers in ((1, 1, False, 3), (3, 1, False, 0), (2, 2, False, 4), (2, 0, True, 1)):
+        got, summary = stream.run_lockstep(exe_l, cases, ba_policy="all", loader_threads=loaders, batched_estimator=est, priorities=prio, host_workers=workers)
         assert summary["batched_estimator"] == est and (summary["ba_problems"] == sum(b["ba_solves"] for b in got)) == (est > 0)
         assert summary["frames"] == sum(lengths) and summary["steps"] == max(lengths) and summary["sequences"] == len(lengths)
         for i, (a, b) in enumerate(zip(ref, got)):

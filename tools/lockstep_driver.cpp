@@ -26,6 +26,7 @@
 #include "tools/driver_common.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <numeric>
 
@@ -40,6 +41,7 @@ struct Seq {
     long frames = 0, tracked = 0, attempted = 0, err_n = 0, keyframes = 0;
     double err_sq = 0;
     Fnv tdig, ddig, sdig;
+    std::vector<float> tmp_unpx, tmp_kps; std::vector<double> tmp_bv; std::vector<int> tmp_age;     // (per-sequence scratch of the pool's workers)
     // estimator thread of the sequence (its own context)
     ov2_ctx *ctxC = nullptr;
     Queue<int> ba_q;
@@ -64,6 +66,35 @@ struct Loader {
     std::vector<int> seen;
 };
 
+// worker threads for the per-sequence host work of a step (priors, bookkeeping, digests: what each sequence's own SLAM thread does in
+// stream_driver -- one thread doing it for eleven sequences was 40 % of the step).  run(n, fn): fn(0..n-1), the caller takes part.
+struct Pool {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    std::function<void(int)> fn; int n = 0, gen = 0, busy = 0; std::atomic<int> next{0}; bool quit = false;
+    void start(int nt)
+    {
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([this] {
+                int seen = 0;
+                for (;;) {
+                    { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
+                    for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+                    { std::lock_guard<std::mutex> l(m); busy--; }
+                    cv_done.notify_one();
+                }
+            });
+    }
+    void run(int count, const std::function<void(int)> &f)
+    {
+        if (th.empty() || count <= 1) { for (int i = 0; i < count; i++) f(i); return; }
+        { std::lock_guard<std::mutex> l(m); fn = f; n = count; next.store(0); busy = (int)th.size(); gen++; }
+        cv_go.notify_all();
+        for (int i; (i = next.fetch_add(1)) < count;) f(i);
+        std::unique_lock<std::mutex> l(m); cv_done.wait(l, [&] { return busy == 0; });
+    }
+    void stop() { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); th.clear(); }
+};
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads]\n"); return 2; }
@@ -85,6 +116,7 @@ int main(int argc, char **argv)
     const bool est_batch = argc > 6 ? atoi(argv[6]) != 0 : true;
     // (argv[6] > 1: that many estimator threads, each batching the sequences b with b % groups == its number -- while one group's batch
     // is on the GPU the next one's problems are sorted and staged on the host)
+    const int n_work = argc > 7 ? std::max(0, atoi(argv[7])) : 3;           // worker threads for the per-sequence host work of a step (+ the SLAM thread)
     const int est_groups = est_batch ? std::max(1, argc > 6 ? atoi(argv[6]) : 1) : 0;
     std::vector<std::string> paths;
     for (std::string rest = argv[1]; !rest.empty();) {
@@ -260,7 +292,6 @@ int main(int argc, char **argv)
     std::vector<int> nper((size_t)N), p3p((size_t)N), ncur((size_t)N), out_n((size_t)N);
     std::vector<double> gt(2 * BN), quality((size_t)N, 0.001);
     std::vector<const uint8_t *> imgs((size_t)N);
-    std::vector<float> unpx, nk; std::vector<double> bv; std::vector<int> na_;
     const int cap = 2 * (w / cell) * (h / cell);
     std::vector<float> det((size_t)N * 2 * cap);
     const int roi[4] = {5, 5, w - 10, h - 10};
@@ -343,27 +374,57 @@ int main(int argc, char **argv)
         keyframe(0, na);
     }
     long steps = 1;
+    Pool pool; pool.start(n_work);
+    // priors of step f for sequence b (the motion model's stand-in): true flow + noise for the keypoints that were tracked before
+    auto make_priors = [&](int b, int f) {
+        Seq &s = *S[(size_t)b];
+        const int n = (int)s.age.size();
+        const size_t o = (size_t)b * NM;
+        nper[(size_t)b] = n;
+        const Flow flow(s.C, f - 1, f);
+        for (int i = 0; i < n; i++) {
+            const float x = s.kps[2 * i], y = s.kps[2 * i + 1];
+            double gx, gy; flow(x, y, gx, gy);
+            gt[2 * (o + i)] = gx; gt[2 * (o + i) + 1] = gy;
+            const uint8_t hpi = s.age[i] > 0;
+            hp[o + i] = hpi;
+            kps[2 * (o + i)] = x; kps[2 * (o + i) + 1] = y;
+            pri[2 * (o + i)] = hpi ? (float)(gx + s.C.prior_sigma * s.gauss(s.rng)) : x;
+            pri[2 * (o + i) + 1] = hpi ? (float)(gy + s.C.prior_sigma * s.gauss(s.rng)) : y;
+        }
+    };
+    // results of step f for sequence b: digests, counters, the surviving keypoints
+    auto take_results = [&](int b, int f) {
+        Seq &s = *S[(size_t)b];
+        const int n = nper[(size_t)b];
+        const size_t o = (size_t)b * NM;
+        std::vector<float> &unpx = s.tmp_unpx, &nk = s.tmp_kps; std::vector<double> &bv = s.tmp_bv; std::vector<int> &na_ = s.tmp_age;
+        unpx.resize(2 * (size_t)n); bv.resize(3 * (size_t)n);
+        if (n) CK(ov2_btracker_last_keypoints(trk, b, n, unpx.data(), bv.data()));
+        s.tdig.val(f); s.tdig.val(n); s.tdig.val(p3p[(size_t)b]); s.tdig.add(&out[2 * o], 8 * (size_t)n); s.tdig.add(&st[o], (size_t)n);
+        s.tdig.add(unpx.data(), 8 * (size_t)n); s.tdig.add(bv.data(), 24 * (size_t)n);
+        s.frames++; s.attempted += n;
+        nk.clear(); na_.clear();
+        for (int i = 0; i < n; i++) {
+            if (!(st[o + i] & 1)) continue;
+            s.tracked++;
+            const float x = out[2 * (o + i)], y = out[2 * (o + i) + 1];
+            const double ex = x - gt[2 * (o + i)], ey = y - gt[2 * (o + i) + 1];
+            s.err_sq += ex * ex + ey * ey; s.err_n++;
+            if (x > 8 && x < w - 9 && y > 8 && y < h - 9) { nk.push_back(x); nk.push_back(y); na_.push_back(s.age[i] + 1); }
+        }
+        s.kps.swap(nk); s.age.swap(na_);
+        if (f == s.C.n_frames - 1) s.t_last_frame = now();
+    };
+    if (F > 1) pool.run(n_active_at(1), [&](int b) { make_priors(b, 1); });
     for (int f = 1; f < F; f++) {
         const int na = n_active_at(f);
-        // priors of this step (the motion model's stand-in): true flow + noise for the keypoints that were tracked before
-        for (int b = 0; b < na; b++) {
-            Seq &s = *S[(size_t)b];
-            const int n = (int)s.age.size();
-            const size_t o = (size_t)b * NM;
-            nper[(size_t)b] = n;
-            const Flow flow(s.C, f - 1, f);
-            for (int i = 0; i < n; i++) {
-                const float x = s.kps[2 * i], y = s.kps[2 * i + 1];
-                double gx, gy; flow(x, y, gx, gy);
-                gt[2 * (o + i)] = gx; gt[2 * (o + i) + 1] = gy;
-                const uint8_t hpi = s.age[i] > 0;
-                hp[o + i] = hpi;
-                kps[2 * (o + i)] = x; kps[2 * (o + i) + 1] = y;
-                pri[2 * (o + i)] = hpi ? (float)(gx + s.C.prior_sigma * s.gauss(s.rng)) : x;
-                pri[2 * (o + i) + 1] = hpi ? (float)(gy + s.C.prior_sigma * s.gauss(s.rng)) : y;
-            }
-        }
-        double tl;
+        // the step is enqueued first (frame f was prepared during step f - 1); the enqueue cost of the frames to come -- upload of f + 2,
+        // pre-processing of f + 1 -- then runs beside its kernels instead of before them
+        for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, f % 3, b, nullptr);
+        double tl = now();
+        CK(ov2_btracker_track_frame_begin(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1));
+        lib_s += now() - tl;
         if (f + 2 < F) {                                                                // frame f + 2 has been loaded since step f - 1 returned
             const double tw = now(); load_wait(); wait_loader += now() - tw;
             tl = now();
@@ -376,35 +437,21 @@ int main(int argc, char **argv)
             CK(ov2_btracker_prepare(trk, (f + 1) % 3, n_active_at(f + 1)));
             lib_s += now() - tl;
         } else wait_mappers(f - sets);
-        for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, f % 3, b, nullptr);
         tl = now();
-        CK(ov2_btracker_track_frame(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1, out.data(), st.data(), p3p.data()));
+        CK(ov2_btracker_track_frame_end(trk, out.data(), st.data(), p3p.data()));
         lib_s += now() - tl;
         if (f + 3 < F) load_kick(f + 3);                                                // staging set f % 3 is free again
         steps++;
-        for (int b = 0; b < na; b++) {
-            Seq &s = *S[(size_t)b];
-            const int n = nper[(size_t)b];
-            const size_t o = (size_t)b * NM;
-            unpx.resize(2 * (size_t)n); bv.resize(3 * (size_t)n);
-            if (n) CK(ov2_btracker_last_keypoints(trk, b, n, unpx.data(), bv.data()));
-            s.tdig.val(f); s.tdig.val(n); s.tdig.val(p3p[(size_t)b]); s.tdig.add(&out[2 * o], 8 * (size_t)n); s.tdig.add(&st[o], (size_t)n);
-            s.tdig.add(unpx.data(), 8 * (size_t)n); s.tdig.add(bv.data(), 24 * (size_t)n);
-            s.frames++; s.attempted += n;
-            nk.clear(); na_.clear();
-            for (int i = 0; i < n; i++) {
-                if (!(st[o + i] & 1)) continue;
-                s.tracked++;
-                const float x = out[2 * (o + i)], y = out[2 * (o + i) + 1];
-                const double ex = x - gt[2 * (o + i)], ey = y - gt[2 * (o + i) + 1];
-                s.err_sq += ex * ex + ey * ey; s.err_n++;
-                if (x > 8 && x < w - 9 && y > 8 && y < h - 9) { nk.push_back(x); nk.push_back(y); na_.push_back(s.age[i] + 1); }
-            }
-            s.kps.swap(nk); s.age.swap(na_);
-            if (f == s.C.n_frames - 1) s.t_last_frame = now();
-        }
-        if (f % kf_every == 0) keyframe(f, na);
+        // per-sequence host work on the pool: the results of this step and -- unless a keyframe's detection comes in between -- the priors of the next
+        const int na1 = f + 1 < F ? n_active_at(f + 1) : 0;
+        if (f % kf_every == 0) {
+            pool.run(na, [&](int b) { take_results(b, f); });
+            keyframe(f, na);
+            pool.run(na1, [&](int b) { make_priors(b, f + 1); });
+        } else
+            pool.run(na, [&](int b) { take_results(b, f); if (b < na1) make_priors(b, f + 1); });
     }
+    pool.stop();
     CK(ov2_ctx_sync(ctxA));
     const double slam_s = now() - t0;
     map_q.close(); mapper.join();

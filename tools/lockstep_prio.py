@@ -29,10 +29,13 @@ def main():
     combos = [(p, 1) for p in ("0,0,0", "1,1,-1", "1,0,0", "1,1,0", "0,0,-1", "1,0,-1", "0,1,0", "0,0,0")]
     if len(sys.argv) > 2 and sys.argv[2] == "groups":
         combos = [("0,0,0", g) for g in (1, 2, 3, 4, 6, 1, 2)]
-    for prio, groups in combos:
+    workers = [3]
+    if len(sys.argv) > 2 and sys.argv[2] == "workers":
+        combos = [("0,0,0", 1)]; workers = [0, 1, 2, 3, 5, 8, 0, 3]
+    for prio, groups, nw in [(p, g, w) for (p, g) in combos for w in workers]:
         for policy in ("newest", "all"):
-            st, sm = stream.run_lockstep(exe, cases, ba_policy=policy, loader_threads=4, priorities=prio, batched_estimator=groups)
-            r = {"priorities_tracker_mapper_estimator": prio, "estimator_groups": groups, "policy": policy, "fps": round(sm["frames"] / sm["seconds"], 1), "seconds": sm["seconds"], "slam_library_s": sm["slam_library_s"],
+            st, sm = stream.run_lockstep(exe, cases, ba_policy=policy, loader_threads=4, priorities=prio, batched_estimator=groups, host_workers=nw)
+            r = {"priorities_tracker_mapper_estimator": prio, "estimator_groups": groups, "host_workers": nw, "policy": policy, "fps": round(sm["frames"] / sm["seconds"], 1), "seconds": sm["seconds"], "slam_library_s": sm["slam_library_s"],
                  "wait_mapper_s": sm["slam_wait_for_mapper_s"], "ba_solves": sum(s["ba_solves"] for s in st), "ba_batches": sm.get("ba_batches"), "ba_busy_s_sum": round(sum(s["ba_busy_s"] for s in st), 4)}
             res.append(r); print(json.dumps(r), flush=True)
     if out_path:
