@@ -15,11 +15,14 @@
 // front end's in the command processor.]  Sequences that end drop out of the batch (they are ordered longest first, so the
 // active ones are always items [0, n_active)).
 // Image "decoding" (here: a copy of the synthetic view into the tracker's pinned slot) runs on loader threads one step ahead,
-// the frames' H2D on the tracker's copy stream beside the previous step's kernels.
+// the frames' H2D on the tracker's copy stream beside the previous step's kernels.  A step is ov2_btracker_track_frame_begin (enqueue)
+// -> upload of frame f + 2, pre-processing of frame f + 1 (their enqueue cost runs beside the tracking kernels) -> _end (wait,
+// results); the per-sequence host work around it (priors from the motion model's stand-in, bookkeeping, digests -- what each sequence's
+// own SLAM thread does in stream_driver) runs on a small worker pool (argv[7], default 3 threads + the SLAM thread).
 // Per-sequence inputs (frames, keypoints, priors, random streams) are those of stream_driver, so the per-sequence results must be
 // bit-identical: both programs print FNV-1a digests of everything the library returned (tests/test_gpu_stream.py compares them).
 //
-//   lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads] [stream priorities 0|1] [batched estimator 0|1]
+//   lockstep_driver <case>[,<case>...] [newest|all] [device] [loader threads] [stream priorities 0|1] [estimator groups, 0 = a thread per sequence] [host workers]
 //                                                                     -> one JSON line per sequence (input order) + one summary line
 // Build: g++ -O2 -std=c++17 -pthread tools/lockstep_driver.cpp -I. -Lov2slam_amd -lov2slam_hip -Wl,-rpath,<dir>
 #define OV2_DRIVER_NAME "lockstep_driver"
