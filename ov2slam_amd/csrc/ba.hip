@@ -31,6 +31,9 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <chrono>
 #include <thread>
@@ -3285,6 +3288,34 @@ static bool ba_small_path(int n_opt)
     return !(lin_lds > 159 * 1024 || chol_lds_bytes(nf, nfp) > 150 * 1024 || nf > CH_MAX_LDS_N);
 }
 
+// persistent host threads of a context's batches (ov2_ctx::ba_host_pool): spawning sixteen threads per batch was 0.3 ms of its first millisecond
+struct BAHostPool {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    const std::function<void(int)> *fn = nullptr; int n = 0, gen = 0, busy = 0; std::atomic<int> next{0}; bool quit = false;
+    explicit BAHostPool(int nt)
+    {
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([this] {
+                int seen = 0;
+                for (;;) {
+                    { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
+                    for (int i; (i = next.fetch_add(1)) < n;) (*fn)(i);
+                    { std::lock_guard<std::mutex> l(m); busy--; }
+                    cv_done.notify_one();
+                }
+            });
+    }
+    ~BAHostPool() { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); }
+    void run(int count, const std::function<void(int)> &f)              // f(0 .. count-1); the caller takes part
+    {
+        if (th.empty() || count <= 1) { for (int i = 0; i < count; i++) f(i); return; }
+        { std::lock_guard<std::mutex> l(m); fn = &f; n = count; next.store(0); busy = (int)th.size(); gen++; }
+        cv_go.notify_all();
+        for (int i; (i = next.fetch_add(1)) < count;) f(i);
+        std::unique_lock<std::mutex> l(m); cv_done.wait(l, [&] { return busy == 0; });
+    }
+};
+
 struct BABatch {
     std::vector<ov2_ba_dev *> devs;
     BADev *h_arr = nullptr, *d_arr = nullptr;           // the problems' device views: pinned staging / device copy
@@ -3486,25 +3517,22 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             BASlice sl;
             sl.dev_base = db; sl.dev_cap = ctx->d_scratch_bytes; sl.dev_used = header; sl.host_base = hb; sl.host_cap = ctx->h_scratch_bytes; sl.host_used = header;
             // the host side of a problem (validation, the landmark sort, the staging mirror; ~0.4 ms for a 69 k-block window) on a thread of
-            // its own, up to sixteen at a time -- on one thread it was more than the batch's device time.  Each thread enqueues its
+            // its own (sixteen persistent threads of the context) -- on one thread it was more than the batch's device time.  Each thread enqueues its
             // problem's upload on the context's stream itself (the order of the uploads does not matter).
-            const int NT = std::min(16, (int)idx.size());
             std::vector<ov2_ba_dev *> made(idx.size(), nullptr);
             std::vector<int> rcs(idx.size(), OV2_OK);
             std::vector<std::string> errs(idx.size());
-            auto work = [&](int t) {
-                (void)hipSetDevice(ctx->device);
-                for (size_t k = (size_t)t; k < idx.size(); k += (size_t)NT) {
-                    rcs[k] = ba_create(ctx, &p[idx[k]], &made[k], true, &sl);
-                    if (rcs[k] != OV2_OK && rcs[k] != BA_SLICE_FULL) errs[k] = ov2_last_error();          // (the message is per thread)
-                }
-            };
-            {
-                std::vector<std::thread> th;
-                for (int t = 1; t < NT; t++) th.emplace_back(work, t);
-                work(0);
-                for (auto &x : th) x.join();
+            if (!ctx->ba_host_pool && idx.size() > 1) {
+                ctx->ba_host_pool = new (std::nothrow) BAHostPool(15);
+                ctx->ba_host_pool_free = [](void *q) { delete (BAHostPool *)q; };
             }
+            const std::function<void(int)> work = [&](int k) {
+                (void)hipSetDevice(ctx->device);
+                rcs[(size_t)k] = ba_create(ctx, &p[idx[(size_t)k]], &made[(size_t)k], true, &sl);
+                if (rcs[(size_t)k] != OV2_OK && rcs[(size_t)k] != BA_SLICE_FULL) errs[(size_t)k] = ov2_last_error();          // (the message is per thread)
+            };
+            if (ctx->ba_host_pool) ((BAHostPool *)ctx->ba_host_pool)->run((int)idx.size(), work);
+            else for (size_t k = 0; k < idx.size(); k++) work((int)k);
             bool full = false;
             int bad_rc = OV2_OK; size_t bad_k = 0;
             for (size_t k = 0; k < idx.size(); k++) {

@@ -57,6 +57,8 @@ struct ov2_ctx {
     int ba_pose_only_fused = 1;                // OV2_OPT_BA_POSE_ONLY_FUSED
     int ba_deterministic = 0;                  // OV2_OPT_BA_DETERMINISTIC
     void *ba_det_pool = nullptr; size_t ba_det_bytes = 0;   // OV2_OPT_BA_DETERMINISTIC: per-work-group copies of H / F^T b / G (grow-only)
+    // ov2_local_ba_batch: persistent host threads that prepare the problems of a batch (created with the first batch; ba.hip owns the type)
+    void *ba_host_pool = nullptr; void (*ba_host_pool_free)(void *) = nullptr;
     int debug = 0;                             // OV2_OPT_DEBUG; initial value: environment OV2_DEBUG, read once by ov2_ctx_create
     // pinned staging of host images on their way to the device: its own buffer (h_scratch is rewritten by the next call's small
     // arrays while an asynchronous image upload may still be in flight) and an event that says when it may be refilled
