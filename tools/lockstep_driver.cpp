@@ -299,6 +299,7 @@ int main(int argc, char **argv)
     std::vector<float> det((size_t)N * 2 * cap);
     const int roi[4] = {5, 5, w - 10, h - 10};
     double lib_s = 0, wait_loader = 0, wait_mapper = 0;
+    double t_begin_s = 0, t_upload_s = 0, t_prepare_s = 0, t_end_s = 0, t_detect_s = 0, t_host_s = 0;      // where the SLAM thread's step goes
 
     auto keyframe = [&](int f, int na) {
         for (int b = 0; b < na; b++) {
@@ -427,32 +428,36 @@ int main(int argc, char **argv)
         for (int b = 0; b < na; b++) imgs[(size_t)b] = ov2_btracker_image_buffer(trk, f % 3, b, nullptr);
         double tl = now();
         CK(ov2_btracker_track_frame_begin(trk, na, imgs.data(), pitch, kps.data(), pri.data(), hp.data(), nper.data(), 1));
-        lib_s += now() - tl;
+        lib_s += now() - tl; t_begin_s += now() - tl;
         if (f + 2 < F) {                                                                // frame f + 2 has been loaded since step f - 1 returned
             const double tw = now(); load_wait(); wait_loader += now() - tw;
             tl = now();
             CK(ov2_btracker_upload(trk, (f + 2) % 3, n_active_at(f + 2)));
-            lib_s += now() - tl;
+            lib_s += now() - tl; t_upload_s += now() - tl;
         }
         if (f + 1 < F) {
             wait_mappers(f + 1 - sets);                                                  // the pyramid set frame f + 1 goes into
             tl = now();
             CK(ov2_btracker_prepare(trk, (f + 1) % 3, n_active_at(f + 1)));
-            lib_s += now() - tl;
+            lib_s += now() - tl; t_prepare_s += now() - tl;
         } else wait_mappers(f - sets);
         tl = now();
         CK(ov2_btracker_track_frame_end(trk, out.data(), st.data(), p3p.data()));
-        lib_s += now() - tl;
+        lib_s += now() - tl; t_end_s += now() - tl;
         if (f + 3 < F) load_kick(f + 3);                                                // staging set f % 3 is free again
         steps++;
         // per-sequence host work on the pool: the results of this step and -- unless a keyframe's detection comes in between -- the priors of the next
         const int na1 = f + 1 < F ? n_active_at(f + 1) : 0;
+        tl = now();
         if (f % kf_every == 0) {
             pool.run(na, [&](int b) { take_results(b, f); });
+            const double lib0 = lib_s, tk = now();
             keyframe(f, na);
+            t_detect_s += lib_s - lib0; tl += now() - tk;                                // (the keyframe's library calls are counted there)
             pool.run(na1, [&](int b) { make_priors(b, f + 1); });
         } else
             pool.run(na, [&](int b) { take_results(b, f); if (b < na1) make_priors(b, f + 1); });
+        t_host_s += now() - tl;
     }
     pool.stop();
     CK(ov2_ctx_sync(ctxA));
@@ -486,8 +491,11 @@ int main(int argc, char **argv)
     for (auto &l : lines) printf("%s\n", l.c_str());
     printf("{\"lockstep_summary\": true, \"sequences\": %d, \"frames\": %ld, \"steps\": %ld, \"seconds\": %.6f, \"slam_thread_seconds\": %.6f, "
            "\"slam_library_s\": %.6f, \"slam_wait_for_loader_s\": %.6f, \"slam_wait_for_mapper_s\": %.6f, \"loader_threads\": %d, \"stream_priorities\": %d, \"device\": %d, "
-           "\"batched_estimator\": %d, \"ba_batches\": %ld, \"ba_problems\": %ld, \"t_begin\": %.6f, \"t_end\": %.6f}\n",
-           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, est_groups, est_batches.load(), est_problems.load(), t_begin, t_end);
+           "\"batched_estimator\": %d, \"ba_batches\": %ld, \"ba_problems\": %ld, \"host_workers\": %d, "
+           "\"slam_step_breakdown_s\": {\"track_frame_begin\": %.6f, \"upload\": %.6f, \"prepare\": %.6f, \"track_frame_end\": %.6f, \"keyframe_library_calls\": %.6f, "
+           "\"per_sequence_host_work_on_the_pool\": %.6f}, \"t_begin\": %.6f, \"t_end\": %.6f}\n",
+           N, frames, steps, total_s, slam_s, lib_s, wait_loader, wait_mapper, n_load, use_prio ? 1 : 0, device, est_groups, est_batches.load(), est_problems.load(), n_work,
+           t_begin_s, t_upload_s, t_prepare_s, t_end_s, t_detect_s, t_host_s, t_begin, t_end);
 
     for (auto &s : S) if (s->ctxC) ov2_ctx_destroy(s->ctxC);
     for (ov2_ctx *c : ctxE) if (c) ov2_ctx_destroy(c);
