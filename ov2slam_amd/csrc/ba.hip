@@ -3523,7 +3523,8 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             std::vector<int> rcs(idx.size(), OV2_OK);
             std::vector<std::string> errs(idx.size());
             if (!ctx->ba_host_pool && idx.size() > 1) {
-                ctx->ba_host_pool = new (std::nothrow) BAHostPool(15);
+                try { ctx->ba_host_pool = new BAHostPool(15); }           // (no threads to be had: the problems are prepared one after the other)
+                catch (...) { ctx->ba_host_pool = nullptr; }
                 ctx->ba_host_pool_free = [](void *q) { delete (BAHostPool *)q; };
             }
             const std::function<void(int)> work = [&](int k) {
