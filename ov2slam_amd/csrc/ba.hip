@@ -3294,6 +3294,11 @@ struct BAHostPool {
     const std::function<void(int)> *fn = nullptr; int n = 0, gen = 0, busy = 0; std::atomic<int> next{0}; bool quit = false;
     explicit BAHostPool(int nt)
     {
+        try { spawn(nt); }
+        catch (...) { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); th.clear(); throw; }
+    }
+    void spawn(int nt)
+    {
         for (int t = 0; t < nt; t++)
             th.emplace_back([this] {
                 int seen = 0;
