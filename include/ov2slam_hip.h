@@ -334,7 +334,7 @@ int  ov2_btracker_detect_grid_fast(ov2_btracker *t, int n_active, int cell, cons
                                    int mask_mode, int do_subpix, float *out_xy_h, int out_cap, int *out_n_h);
 /* the current / previous frame's pyramids: the whole batch, or item `item` as a batch-1 view (owned by the tracker; valid until that
  * pyramid set comes round again, see ov2_btracker_pyramid_sets) -- what the mapper context passes to ov2_stereo_match as `left` */
-/* How many pyramid sets the tracker rotates through (6): the pyramids of frame f are overwritten by the pre-processing of frame
+/* How many pyramid sets the tracker rotates through (8): the pyramids of frame f are overwritten by the pre-processing of frame
  * f + sets -- ov2_btracker_track_frame of that frame, or the ov2_btracker_prepare call for it.  A consumer on another context (the
  * mapper's stereo matching of keyframe f) must be done before the caller issues that call. */
 int  ov2_btracker_pyramid_sets(const ov2_btracker *t);
