@@ -2577,6 +2577,50 @@ static void ba_destroy(ov2_ba_dev *dev);
 struct BASlice { uint8_t *dev_base; size_t dev_cap, dev_used; uint8_t *host_base; size_t host_cap, host_used; std::mutex m; };      // (the problems of a batch are prepared on several host threads)
 #define BA_SLICE_FULL (-12345)          // (internal: the caller grows the blocks and starts over)
 
+// persistent host threads of a context (ov2_ctx::ba_host_pool): the problems of a batch are prepared on them (spawning sixteen threads per
+// batch was 0.3 ms of its first millisecond), and so are the slices of one large problem's sort (ba_create)
+struct BAHostPool {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    const std::function<void(int)> *fn = nullptr; int n = 0, gen = 0, busy = 0; std::atomic<int> next{0}; bool quit = false;
+    explicit BAHostPool(int nt)
+    {
+        try { spawn(nt); }
+        catch (...) { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); th.clear(); throw; }
+    }
+    void spawn(int nt)
+    {
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([this] {
+                int seen = 0;
+                for (;;) {
+                    { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
+                    for (int i; (i = next.fetch_add(1)) < n;) (*fn)(i);
+                    { std::lock_guard<std::mutex> l(m); busy--; }
+                    cv_done.notify_one();
+                }
+            });
+    }
+    ~BAHostPool() { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); }
+    void run(int count, const std::function<void(int)> &f)              // f(0 .. count-1); the caller takes part
+    {
+        if (th.empty() || count <= 1) { for (int i = 0; i < count; i++) f(i); return; }
+        { std::lock_guard<std::mutex> l(m); fn = &f; n = count; next.store(0); busy = (int)th.size(); gen++; }
+        cv_go.notify_all();
+        for (int i; (i = next.fetch_add(1)) < count;) f(i);
+        std::unique_lock<std::mutex> l(m); cv_done.wait(l, [&] { return busy == 0; });
+    }
+};
+
+static BAHostPool *ba_host_pool_of(ov2_ctx *ctx)
+{
+    if (!ctx->ba_host_pool) {
+        try { ctx->ba_host_pool = new BAHostPool(15); }               // (no threads to be had: the caller works serially)
+        catch (...) { ctx->ba_host_pool = nullptr; }
+        ctx->ba_host_pool_free = [](void *q) { delete (BAHostPool *)q; };
+    }
+    return (BAHostPool *)ctx->ba_host_pool;
+}
+
 // transient: the problem lives for one ov2_ba_solve call -- small pools then come out of the context's device scratch instead of
 // a hipMalloc / hipFree pair (~100 us, more than a whole ceresPnP solve)
 static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bool transient = false, BASlice *ext = nullptr)
@@ -2590,7 +2634,10 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     // caller's order); pose-only blocks (OV2_RES_PNP) go to their own list.  Large problems (a 590 k-block localBA: 3.8 ms of the
     // call were this sort and the staging fill) split the residual range over a few host threads: per-thread counts, offsets
     // = landmark prefix + the counts of the lower-numbered threads, so the result is identical to the serial sort.
-    const int NT = p->n_res >= (1 << 16) ? std::min(8, p->n_res >> 15) : 1;   // (a 25-KF window of 69 k blocks: 2 threads)
+    // (a 25-KF window of 69 k blocks: 2 threads; the problems of a batch are prepared side by side already: one thread each)
+    int NT = (p->n_res >= (1 << 16) && !ext) ? std::min(8, p->n_res >> 15) : 1;
+    BAHostPool *hpool = NT > 1 ? ba_host_pool_of(ctx) : nullptr;
+    if (!hpool) NT = 1;
     const bool dbg_laps = ctx->debug != 0 && !ext;
     const auto tc0 = std::chrono::steady_clock::now();
     auto clap = [&](const char *what) {
@@ -2602,10 +2649,8 @@ static int ba_create(ov2_ctx *ctx, const ov2_ba_problem *p, ov2_ba_dev **out, bo
     auto range_of = [&](int t, int &b, int &e) { b = (int)((long long)p->n_res * t / NT); e = (int)((long long)p->n_res * (t + 1) / NT); };
     auto run_threads = [&](auto &&fn) {
         if (NT == 1) { fn(0); return; }
-        std::vector<std::thread> th;
-        for (int t = 1; t < NT; t++) th.emplace_back(fn, t);
-        fn(0);
-        for (auto &x : th) x.join();
+        const std::function<void(int)> f = fn;                          // (the context's persistent threads: two spawns per call were 0.1 - 0.3 ms)
+        hpool->run(NT, f);
     };
     run_threads([&](int t) {
         int b, e; range_of(t, b, e);
@@ -3288,39 +3333,6 @@ static bool ba_small_path(int n_opt)
     return !(lin_lds > 159 * 1024 || chol_lds_bytes(nf, nfp) > 150 * 1024 || nf > CH_MAX_LDS_N);
 }
 
-// persistent host threads of a context's batches (ov2_ctx::ba_host_pool): spawning sixteen threads per batch was 0.3 ms of its first millisecond
-struct BAHostPool {
-    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
-    const std::function<void(int)> *fn = nullptr; int n = 0, gen = 0, busy = 0; std::atomic<int> next{0}; bool quit = false;
-    explicit BAHostPool(int nt)
-    {
-        try { spawn(nt); }
-        catch (...) { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); th.clear(); throw; }
-    }
-    void spawn(int nt)
-    {
-        for (int t = 0; t < nt; t++)
-            th.emplace_back([this] {
-                int seen = 0;
-                for (;;) {
-                    { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
-                    for (int i; (i = next.fetch_add(1)) < n;) (*fn)(i);
-                    { std::lock_guard<std::mutex> l(m); busy--; }
-                    cv_done.notify_one();
-                }
-            });
-    }
-    ~BAHostPool() { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &t : th) t.join(); }
-    void run(int count, const std::function<void(int)> &f)              // f(0 .. count-1); the caller takes part
-    {
-        if (th.empty() || count <= 1) { for (int i = 0; i < count; i++) f(i); return; }
-        { std::lock_guard<std::mutex> l(m); fn = &f; n = count; next.store(0); busy = (int)th.size(); gen++; }
-        cv_go.notify_all();
-        for (int i; (i = next.fetch_add(1)) < count;) f(i);
-        std::unique_lock<std::mutex> l(m); cv_done.wait(l, [&] { return busy == 0; });
-    }
-};
-
 struct BABatch {
     std::vector<ov2_ba_dev *> devs;
     BADev *h_arr = nullptr, *d_arr = nullptr;           // the problems' device views: pinned staging / device copy
@@ -3527,17 +3539,13 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
             std::vector<ov2_ba_dev *> made(idx.size(), nullptr);
             std::vector<int> rcs(idx.size(), OV2_OK);
             std::vector<std::string> errs(idx.size());
-            if (!ctx->ba_host_pool && idx.size() > 1) {
-                try { ctx->ba_host_pool = new BAHostPool(15); }           // (no threads to be had: the problems are prepared one after the other)
-                catch (...) { ctx->ba_host_pool = nullptr; }
-                ctx->ba_host_pool_free = [](void *q) { delete (BAHostPool *)q; };
-            }
+            BAHostPool *hp = idx.size() > 1 ? ba_host_pool_of(ctx) : nullptr;
             const std::function<void(int)> work = [&](int k) {
                 (void)hipSetDevice(ctx->device);
                 rcs[(size_t)k] = ba_create(ctx, &p[idx[(size_t)k]], &made[(size_t)k], true, &sl);
                 if (rcs[(size_t)k] != OV2_OK && rcs[(size_t)k] != BA_SLICE_FULL) errs[(size_t)k] = ov2_last_error();          // (the message is per thread)
             };
-            if (ctx->ba_host_pool) ((BAHostPool *)ctx->ba_host_pool)->run((int)idx.size(), work);
+            if (hp) hp->run((int)idx.size(), work);
             else for (size_t k = 0; k < idx.size(); k++) work((int)k);
             bool full = false;
             int bad_rc = OV2_OK; size_t bad_k = 0;
