@@ -3026,6 +3026,30 @@ static void ba_destroy(ov2_ba_dev *dev)
     delete dev;
 }
 
+// state reset of a solve in ONE launch (round 5; single problems: it replaces two pageable H2D copies of the initial parameters, six
+// memsets and the upload of the control block -- 60-80 us of host time per pass): x = initial parameters, chi2 = "never evaluated",
+// verdicts and removal flags clear (unless keep_state: second pass of localBA), H / G / F^T b / y_f zero, the control block.
+// host_chi2: the caller seeds chi2 / depth flags itself (ov2_ba_solve with inactive residual blocks)
+__device__ __forceinline__ void b_ba_reset(const BADev &D, const BACtl &ctl0, int keep_state, int host_chi2)
+{
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (i0 == 0) { BACtl c = ctl0; if (keep_state && D.skip2) { c.done = 1; c.need_lin = 0; } *D.ctl = c; }
+    if (keep_state && D.skip2) return;
+    if (!keep_state) {
+        for (long long e = i0; e < 7LL * D.n_kf; e += stride) D.x_pose[e] = D.pose0[e];
+        for (long long e = i0; e < D.n_lm; e += stride) D.x_lam[e] = D.lam0[e];
+        unsigned long long *chi = (unsigned long long *)D.chi2;
+        if (!host_chi2) for (long long e = i0; e < D.n_res; e += stride) { chi[e] = ~0ULL; D.dpos[e] = 0; }          // (NaN pattern: never evaluated)
+        for (long long e = i0; e < D.n_res; e += stride) D.bad_obs[e] = 0;
+        for (long long e = i0; e < D.n_act; e += stride) D.res_off[e] = 0;
+    }
+    const long long nn = (long long)D.nfp * D.nfp;
+    for (long long e = i0; e < nn; e += stride) { D.H[e] = 0; D.G[e] = 0; }
+    for (long long e = i0; e < D.nfp; e += stride) { D.bf[e] = 0; D.yf[e] = 0; }
+}
+__global__ __launch_bounds__(256) void k_ba_reset(BADev D, BACtl ctl0, int keep_state, int host_chi2) { b_ba_reset(D, ctl0, keep_state, host_chi2); }
+__global__ __launch_bounds__(256) void k_ba_reset_B(const BADev *__restrict__ arr, BACtl ctl0, int keep_state) { b_ba_reset(arr[blockIdx.z], ctl0, keep_state, 0); }
+
 // keep_state: continue from the parameters and the cached chi2 / depth flags that are on the device (second pass of
 // ov2_local_ba) instead of resetting to the problem's initial values
 static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba_result *r,
@@ -3089,7 +3113,17 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     hipEvent_t e0 = ev.e0, e1 = ev.e1;
     // state reset: x = initial parameters, everything else zero, scales one
     const size_t NL = (size_t)D.n_lm * D.ldim;               // per-landmark state entries (1 inverse depth or 3 coordinates each)
-    if (!keep_state) {
+    // small inverse-depth problems: one reset kernel instead of the copies / memsets below (b_ba_reset); pose-only fused solves and the
+    // other forms keep the round-1 sequence
+    const bool fused_po_path = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && ctx->ba_pose_only_fused && !(o->max_solver_time_s > 0.0) && !ctx->ba_deterministic;
+    const bool one_reset = D.ldim == 1 && !D.big && D.pose0 != nullptr && !fused_po_path;
+    if (!keep_state && one_reset) {
+        if (chi2_init) OV2_HIP_CHECK(hipMemcpyAsync(D.chi2, chi2_init, 8 * (size_t)dev->n_res, hipMemcpyHostToDevice, s));
+        else if (dpos_init) OV2_HIP_CHECK(hipMemsetAsync(D.chi2, 0xFF, 8 * (size_t)std::max(1, dev->n_res), s));
+        if (dpos_init) OV2_HIP_CHECK(hipMemcpyAsync(D.dpos, dpos_init, (size_t)dev->n_res, hipMemcpyHostToDevice, s));
+        else if (chi2_init) OV2_HIP_CHECK(hipMemsetAsync(D.dpos, 0, (size_t)std::max(1, dev->n_res), s));
+    }
+    if (!keep_state && !one_reset) {
     OV2_HIP_CHECK(hipMemcpyAsync(D.x_pose, dev->h_poses0.data(), 56 * (size_t)D.n_kf, hipMemcpyHostToDevice, s));
     if (D.n_lm > 0) OV2_HIP_CHECK(hipMemcpyAsync(D.x_lam, dev->h_lam0.data(), 8 * NL, hipMemcpyHostToDevice, s));
     if (chi2_init) OV2_HIP_CHECK(hipMemcpyAsync(D.chi2, chi2_init, 8 * (size_t)dev->n_res, hipMemcpyHostToDevice, s));
@@ -3105,15 +3139,20 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     h_ctl.termination = OV2_TERM_NO_CONVERGENCE;
     // one optimised pose, pose-only residual blocks, no landmarks (ceresPnP): the whole loop in one kernel (OV2_OPT_BA_POSE_ONLY_FUSED
     // = 0 keeps the multi-kernel path for A/B runs)
-    const bool fused_po = D.n_lm == 0 && D.n_po > 0 && D.nf == 6 && D.ldim == 1 && ctx->ba_pose_only_fused && !(o->max_solver_time_s > 0.0) && !ctx->ba_deterministic;
+    const bool fused_po = fused_po_path;
     if (fused_po) {
         hipLaunchKernelGGL(k_ba_pose_only, dim3(1), dim3(256), 0, s, D, O, h_ctl);
         OV2_HIP_CHECK(hipGetLastError());
+    } else {
+    if (one_reset) {
+        const int rb = (int)std::min<size_t>(256, ((size_t)std::max(std::max(D.n_res, D.nfp * D.nfp), D.n_lm) + 1023) / 1024);
+        hipLaunchKernelGGL(k_ba_reset, dim3(std::max(1, rb)), dim3(256), 0, s, D, h_ctl, keep_state ? 1 : 0, (chi2_init || dpos_init) ? 1 : 0);
     } else {
     OV2_HIP_CHECK(hipMemcpyAsync(D.ctl, &h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.H, 0, 8 * (size_t)D.nfp * D.nfp, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.bf, 0, 8 * (size_t)D.nfp, s));
     OV2_HIP_CHECK(hipMemsetAsync(D.yf, 0, 8 * (size_t)D.nfp, s));
+    }
     // poses -> R | t, scales = 1 (round 1 filled the scales through a host staging vector: three copies and a synchronisation)
     hipLaunchKernelGGL(k_ba_init, dim3((int)std::min<size_t>(1024, (std::max<size_t>(std::max<size_t>(D.n_kf, D.nfp), NL) + 255) / 256)), dim3(256), 0, s, D);
 
@@ -3183,7 +3222,7 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         if (D.n_po > 0) hipLaunchKernelGGL(k_ba_linearize_po, dim3(po_blocks), dim3(256), (D.big && D.lin_direct ? 0 : (size_t)n_opt * 27 * 8) + 16, s, D);
     };
     linearize();
-    OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));    // (every later iteration: cleared by the back-substitution kernel)
+    if (!one_reset) OV2_HIP_CHECK(hipMemsetAsync(D.G, 0, 8 * (size_t)D.nfp * D.nfp, s));    // (every later iteration: cleared by the back-substitution kernel)
     // The LM loop is enqueued half an iteration ahead.  The first half of iteration `it` (bookkeeping, Schur complement, factorisation:
     // ~265 us of config 4's ~385) goes into the stream BEFORE the outcome of iteration it - 1 is known; k_ba_decide stores that outcome
     // into pinned host memory, and the second half (back-substitution .. decision, re-linearisation) follows when the host has seen
@@ -3291,23 +3330,6 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
 // `if (ctl->done) return`.  The one-work-group kernels (factorisation, bookkeeping) so run on as many CUs as there are problems.
 // The arithmetic of a problem is that of ov2_local_ba (same device functions); grids are the largest any problem of the batch
 // needs, the per-work-group partial sums are added in a different grouping when a problem runs on a larger grid than alone.
-__global__ __launch_bounds__(256) void k_ba_reset_B(const BADev *__restrict__ arr, BACtl ctl0, int keep_state)
-{
-    const BADev &D = arr[blockIdx.z];
-    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    if (i0 == 0) { BACtl c = ctl0; if (keep_state && D.skip2) { c.done = 1; c.need_lin = 0; } *D.ctl = c; }
-    if (keep_state && D.skip2) return;
-    if (!keep_state) {
-        for (long long e = i0; e < 7LL * D.n_kf; e += stride) D.x_pose[e] = D.pose0[e];
-        for (long long e = i0; e < D.n_lm; e += stride) D.x_lam[e] = D.lam0[e];
-        unsigned long long *chi = (unsigned long long *)D.chi2;
-        for (long long e = i0; e < D.n_res; e += stride) { chi[e] = ~0ULL; D.dpos[e] = 0; D.bad_obs[e] = 0; }     // (NaN pattern: never evaluated)
-        for (long long e = i0; e < D.n_act; e += stride) D.res_off[e] = 0;
-    }
-    const long long nn = (long long)D.nfp * D.nfp;
-    for (long long e = i0; e < nn; e += stride) { D.H[e] = 0; D.G[e] = 0; }
-    for (long long e = i0; e < D.nfp; e += stride) { D.bf[e] = 0; D.yf[e] = 0; }
-}
 
 // results of the batch into ONE block (poses | inverse depths | outlier verdicts [| chi2] [| depth flags] per problem, 256-byte
 // aligned parts): one download instead of three to five small ones per problem
