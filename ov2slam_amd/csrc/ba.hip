@@ -3104,13 +3104,8 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
         });
         OV2_HIP_CHECK(attr_err);
     }
-    struct EvPair {                                        // destroyed on every exit path
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ~EvPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
-    } ev;
-    OV2_HIP_CHECK(hipEventCreate(&ev.e0));
-    OV2_HIP_CHECK(hipEventCreate(&ev.e1));
-    hipEvent_t e0 = ev.e0, e1 = ev.e1;
+    for (int i = 0; i < 2; i++) if (!ctx->ba_ev[i]) OV2_HIP_CHECK(hipEventCreate(&ctx->ba_ev[i]));      // (the context's: destroyed with it)
+    hipEvent_t e0 = ctx->ba_ev[0], e1 = ctx->ba_ev[1];
     // state reset: x = initial parameters, everything else zero, scales one
     const size_t NL = (size_t)D.n_lm * D.ldim;               // per-landmark state entries (1 inverse depth or 3 coordinates each)
     // small inverse-depth problems: one reset kernel instead of the copies / memsets below (b_ba_reset); pose-only fused solves and the
@@ -3414,9 +3409,8 @@ static int ba_run_batch(ov2_ctx *ctx, BABatch &B, const ov2_ba_options *o, const
         B.h_flag[i] = -1;
     }
     OV2_HIP_CHECK(hipMemcpyAsync(B.d_arr, B.h_arr, sizeof(BADev) * (size_t)N, hipMemcpyHostToDevice, s));
-    struct EvPair { hipEvent_t e0 = nullptr, e1 = nullptr; ~EvPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); } } ev;
-    OV2_HIP_CHECK(hipEventCreate(&ev.e0));
-    OV2_HIP_CHECK(hipEventCreate(&ev.e1));
+    for (int i = 0; i < 2; i++) if (!ctx->ba_ev[i]) OV2_HIP_CHECK(hipEventCreate(&ctx->ba_ev[i]));
+    struct { hipEvent_t e0, e1; } ev{ctx->ba_ev[0], ctx->ba_ev[1]};
     OV2_HIP_CHECK(hipEventRecord(ev.e0, s));
     BACtl c0;
     memset(&c0, 0, sizeof(c0));

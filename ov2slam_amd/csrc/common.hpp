@@ -59,6 +59,7 @@ struct ov2_ctx {
     void *ba_det_pool = nullptr; size_t ba_det_bytes = 0;   // OV2_OPT_BA_DETERMINISTIC: per-work-group copies of H / F^T b / G (grow-only)
     // ov2_local_ba_batch: persistent host threads that prepare the problems of a batch (created with the first batch; ba.hip owns the type)
     void *ba_host_pool = nullptr; void (*ba_host_pool_free)(void *) = nullptr;
+    hipEvent_t ba_ev[2] = {nullptr, nullptr};              // the two timing events of a solve (created with the first one: a pair per pass was 25 us)
     int debug = 0;                             // OV2_OPT_DEBUG; initial value: environment OV2_DEBUG, read once by ov2_ctx_create
     // pinned staging of host images on their way to the device: its own buffer (h_scratch is rewritten by the next call's small
     // arrays while an asynchronous image upload may still be in flight) and an event that says when it may be refilled

@@ -163,6 +163,7 @@ void ov2_ctx_destroy(ov2_ctx *ctx)
     if (ctx->stat_slots) (void)hipFree(ctx->stat_slots);
     if (ctx->ba_det_pool) (void)hipFree(ctx->ba_det_pool);
     if (ctx->ba_host_pool && ctx->ba_host_pool_free) ctx->ba_host_pool_free(ctx->ba_host_pool);
+    for (int i = 0; i < 2; i++) if (ctx->ba_ev[i]) (void)hipEventDestroy(ctx->ba_ev[i]);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_img) (void)hipHostFree(ctx->h_img);
     if (ctx->img_ev) (void)hipEventDestroy(ctx->img_ev);
