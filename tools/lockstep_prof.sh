@@ -6,6 +6,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r5}; KIND=${2:-nob}; OUT=$ROOT/gpurun_
 D=$TMPDIR/ov2_lockstep_cases
 CASES=$(ls $D/${KIND}*.bin | tr '\n' ',' | sed 's/,$//')
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- $D/lockstep_driver $CASES newest 0 4 1 > $OUT/driver.json 2> $OUT/err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- $D/lockstep_driver $CASES newest 0 4 0 1 3 > $OUT/driver.json 2> $OUT/err
 tail -1 $OUT/driver.json
 python $ROOT/tools/step_gaps.py $OUT | head -24 | tee $OUT/gaps.txt
