@@ -9,6 +9,7 @@
 // Everything evaluates eagerly into a Matrix; aliasing is handled by value semantics of the temporaries.
 #pragma once
 #include <cmath>
+#include <type_traits>
 #include <cstddef>
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -40,6 +41,8 @@ struct Dense {
     double &y() { return (*this)(1); }
     double &z() { return (*this)(2); }
     double &w() { return (*this)(3); }
+    // a 1 x 1 result is a scalar (float num = r.transpose() * F * l;)
+    operator double() const { static_assert(R == 1 && C == 1, "only a 1 x 1 expression converts to a scalar"); return (*this)(0, 0); }
     int rows() const { return R; }
     int cols() const { return C; }
     Matrix<double, R, C> eval() const;

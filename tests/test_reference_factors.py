@@ -196,6 +196,106 @@ def test_reference_jacobians_are_the_derivatives_of_the_reference_residuals(ref)
         assert np.abs(num - J[5][:, 0]).max() <= 2e-4 * max(1.0, np.abs(num).max())
 
 
+def test_sampson_distance_matches_the_reference_source(ref, oracle):
+    """MultiViewGeometry::computeSampsonDistance (src/multi_view_geometry.cpp:798-821, the epipolar gate of MapManager::stereoMatching,
+    src/map_manager.cpp:595): the reference's own function text, cut out of its file at build time (oracle/ref/Makefile) and compiled against
+    the stand-in Eigen, against oracle/stereo.c -- BIT FOR BIT: the function mixes double products with float storage (num, x1, x2, y1, y2,
+    den are floats), and the threshold test `<= 2` sits on its float result."""
+    ref.ref_sampson_distance.restype = C.c_float
+    ref.ref_sampson_distance.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    rng = np.random.default_rng(11)
+    K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1.0]])
+    n_close = 0
+    for it in range(4000):
+        if it % 2 == 0:                                       # a stereo rig's fundamental matrix (frame.cpp:62), small rotation, 11 cm baseline
+            w = rng.normal(0, 0.01, 3); th = np.linalg.norm(w); k = w / th
+            Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+            t = np.array([-0.11, 0, 0]) + rng.normal(0, 0.002, 3)
+            tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+            F = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+        else:
+            F = rng.normal(0, 1.0, (3, 3)) * 10.0 ** rng.integers(-6, 2)
+        l = rng.uniform([0, 0], [752, 480]).astype(np.float32)
+        r = (l + rng.normal(0, [20, 1.5])).astype(np.float32)
+        Fc = np.ascontiguousarray(F, np.float64)
+        a = np.float32(ref.ref_sampson_distance(_p(Fc), l[0], l[1], r[0], r[1]))
+        b = np.float32(oracle.sampson_distance(Fc, l, r))
+        assert a.view(np.uint32) == b.view(np.uint32) or (np.isnan(a) and np.isnan(b)), (it, a, b)
+        n_close += abs(float(a) - 2.0) < 0.5
+    assert n_close > 100                                      # the gate's threshold region is exercised
+
+
+REF_FT_SO = os.path.join(ROOT, "oracle", "_ref", "libref_feature_tracker.so")
+
+
+@pytest.fixture(scope="module")
+def ref_ft(ref, oracle):
+    if not os.path.exists(REF_FT_SO):
+        pytest.skip("oracle/_ref/libref_feature_tracker.so is absent and /root/reference is not here to build it from")
+    oracle.lib()                                              # (its three OpenCV stand-ins resolve into liboracle.so)
+    lib = C.CDLL(REF_FT_SO)
+    lib.ref_fb_klt.restype = C.c_int
+    lib.ref_fb_klt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.ref_line_min_sad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ref_in_border.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
+    return lib
+
+
+def test_fb_klt_tracking_control_flow_matches_the_reference_source(ref_ft, oracle):
+    """FeatureTracker::fbKltTracking (src/feature_tracker.cpp:35-137) AS THE REFERENCE WROTE IT -- the file is compiled from where it lies
+    against a stand-in OpenCV whose calcOpticalFlowPyrLK is the oracle's (oracle/ref/standin_cv) -- against the oracle's restatement of the
+    whole function (orc_fb_klt): the level clamp for short pyramids, the status / error / inBorder filters after the forward pass, the
+    level-0 backward pass from the forward result, the forward-backward distance in double.  Status and float bits must be equal.
+    (What this does NOT pin is OpenCV's LK arithmetic itself: both sides run the oracle's.)"""
+    from ov2slam_amd import synth
+    rng = np.random.default_rng(5)
+    for case in range(12):
+        w, h = [(752, 480), (640, 400), (321, 243)][case % 3]
+        prev, cur, flow = synth.frame_pair(w, h, seed=700 + case)
+        levels = [3, 3, 1, 0][case % 4]                       # pyramids of 4 / 4 / 2 / 1 levels
+        P, Cc = oracle.Pyramid(prev, 9, levels), oracle.Pyramid(cur, 9, levels)
+        n = 300
+        kps = np.stack([rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)], 1).astype(np.float32)      # some outside the image
+        gt = flow(np.clip(kps, 0, [w - 1, h - 1]))
+        pri = (gt + rng.normal(0, [0.5, 1.5, 6.0][case % 3], gt.shape)).astype(np.float32)
+        pri[::7] = kps[::7]                                   # no prior: starts from the keypoint
+        for nbpyrlvl in (0, 1, 3, 5):                         # 5: more than any pyramid here holds (:50-52)
+            for ferr, fbdist in ((30.0, 0.5), (8.0, 0.25)):
+                o_xy, o_st, _ = oracle.fb_klt(P, Cc, 9, nbpyrlvl, ferr, fbdist, kps, pri)
+                r_xy = pri.copy(); r_st = np.zeros(n, np.uint8)
+                rc = ref_ft.ref_fb_klt(C.addressof(P.p), C.addressof(Cc.p), P.levels, 9, nbpyrlvl, 30, 0.01, ferr, fbdist, _p(kps), _p(r_xy), n, _p(r_st))
+                assert rc == 0
+                assert np.array_equal(r_st.astype(bool), o_st), (case, nbpyrlvl, int((r_st.astype(bool) != o_st).sum()))
+                assert np.array_equal(r_xy.view(np.uint32), o_xy.view(np.uint32)), (case, nbpyrlvl)
+                assert 0 < o_st.sum() < n
+    # inBorder (:216-221) on the edges
+    for x, y, w, h in ((0.999, 5, 100, 50), (1.0, 1.0, 100, 50), (98.999, 48.999, 100, 50), (99.0, 10, 100, 50), (50, 49.0, 100, 50), (-1, -1, 100, 50)):
+        assert bool(ref_ft.ref_in_border(x, y, w, h)) == (1.0 <= x < w - 1.0 and 1.0 <= y < h - 1.0)
+
+
+def test_line_min_sad_matches_the_reference_source(ref_ft, oracle):
+    """FeatureTracker::getLineMinSAD (src/feature_tracker.cpp:138-206) as the reference wrote it (cv::getRectSubPix / cv::norm = the oracle's
+    restatements) against orc_line_min_sad: the window shrinking near the borders (`int += float`), the scan bounds in both directions, the
+    first minimum winning ties, the even-window and the degenerate-window early returns."""
+    from ov2slam_amd import synth
+    rng = np.random.default_rng(9)
+    w, h = 376, 240
+    left, _, _ = synth.frame_pair(w, h, seed=41)
+    right = np.roll(left, -13, axis=1).copy()
+    right[:, -13:] = 7
+    pts = np.concatenate([np.stack([rng.uniform(0, w, 150), rng.uniform(0, h, 150)], 1),
+                          [[0.2, 0.3], [1.9, 100.0], [w - 1.0, h - 1.0], [w - 2.5, 3.0], [3.0, h - 0.6], [w / 2, 0.0], [5.0, 5.0]]]).astype(np.float32)
+    for nwin in (7, 9, 15, 8, 1, 3):
+        for go_left in (True, False):
+            ox, oe = oracle.line_min_sad(left, right, pts, nwin, go_left)
+            for i, (x, y) in enumerate(pts):
+                xp = np.zeros(1, np.float32); er = np.zeros(1, np.float32)
+                ref_ft.ref_line_min_sad(_p(left), w, _p(right), w, w, h, float(x), float(y), nwin, int(go_left), _p(xp), _p(er))
+                assert xp.view(np.uint32)[0] == np.float32(ox[i]).view(np.uint32), (nwin, go_left, i, xp[0], ox[i])
+                assert er.view(np.uint32)[0] == np.float32(oe[i]).view(np.uint32), (nwin, go_left, i, er[0], oe[i])
+
+
 @pytest.mark.gpu
 def test_device_residuals_match_the_reference_source(ref, gpu_ctx):
     """The DEVICE's evaluation at the initial point (ov2_ba_solve with a zero iteration budget returns the chi2err_ / isdepthpositive_
