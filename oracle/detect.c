@@ -329,6 +329,72 @@ static void grid_init(grid_state *g, int w, int h, int cell, const float *cur_xy
 
 static void grid_free(grid_state *g) { free(g->occ); free(g->mask); }
 
+/* ---- std::sort(vkps.begin(), vkps.end(), compare_response) as libstdc++ runs it (bits/stl_algo.h: __introsort_loop with the median-of-three
+ * pivot moved to the front, __unguarded_partition, __final_insertion_sort with its 16-element threshold) on (x, y, score) records, comparator
+ * a.score > b.score.  Only the order of EQUAL scores depends on these details -- which is the point (ORC_FAST_TIE_LIBSTDCXX). */
+typedef struct { int x, y, s; } fkp;
+static int g_fast_tie_mode = ORC_FAST_TIE_SCAN_ORDER, g_fast_tie_fallbacks = 0;
+void orc_set_fast_tie_mode(int mode) { g_fast_tie_mode = mode == ORC_FAST_TIE_LIBSTDCXX ? ORC_FAST_TIE_LIBSTDCXX : ORC_FAST_TIE_SCAN_ORDER; }
+int orc_get_fast_tie_mode(void) { return g_fast_tie_mode; }
+int orc_fast_tie_sort_fallbacks(void) { return g_fast_tie_fallbacks; }
+#define FK_LESS(a, b) ((a).s > (b).s)                      /* compare_response(first, second) = first.response > second.response */
+static void fk_swap(fkp *a, fkp *b) { fkp t = *a; *a = *b; *b = t; }
+static void fk_unguarded_linear_insert(fkp *last)
+{
+    fkp val = *last, *next = last - 1;
+    while (FK_LESS(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+static void fk_insertion_sort(fkp *first, fkp *last)
+{
+    if (first == last) return;
+    for (fkp *i = first + 1; i != last; ++i) {
+        if (FK_LESS(*i, *first)) { fkp val = *i; memmove(first + 1, first, (size_t)(i - first) * sizeof(fkp)); *first = val; }
+        else fk_unguarded_linear_insert(i);
+    }
+}
+static void fk_move_median_to_first(fkp *result, fkp *a, fkp *b, fkp *c)
+{
+    if (FK_LESS(*a, *b)) {
+        if (FK_LESS(*b, *c)) fk_swap(result, b);
+        else if (FK_LESS(*a, *c)) fk_swap(result, c);
+        else fk_swap(result, a);
+    } else if (FK_LESS(*a, *c)) fk_swap(result, a);
+    else if (FK_LESS(*b, *c)) fk_swap(result, c);
+    else fk_swap(result, b);
+}
+static fkp *fk_unguarded_partition(fkp *first, fkp *last, fkp *pivot)
+{
+    for (;;) {
+        while (FK_LESS(*first, *pivot)) ++first;
+        --last;
+        while (FK_LESS(*pivot, *last)) --last;
+        if (!(first < last)) return first;
+        fk_swap(first, last);
+        ++first;
+    }
+}
+static void fk_introsort_loop(fkp *first, fkp *last, int depth_limit)
+{
+    while (last - first > 16) {
+        if (depth_limit == 0) { g_fast_tie_fallbacks++; fk_insertion_sort(first, last); return; }      /* (libstdc++: heap sort; never reached on cells) */
+        --depth_limit;
+        fkp *mid = first + (last - first) / 2;
+        fk_move_median_to_first(first, first + 1, mid, last - 1);
+        fkp *cut = fk_unguarded_partition(first + 1, last, first);
+        fk_introsort_loop(cut, last, depth_limit);
+        last = cut;
+    }
+}
+static void fk_std_sort(fkp *first, int n)
+{
+    if (n <= 0) return;
+    int lg = 0; for (int m = n; m > 1; m >>= 1) lg++;                         /* std::__lg(n) */
+    fk_introsort_loop(first, first + n, 2 * lg);
+    if (n > 16) { fk_insertion_sort(first, first + 16); for (fkp *i = first + 16; i != first + n; ++i) fk_unguarded_linear_insert(i); }
+    else fk_insertion_sort(first, first + n);
+}
+
 /* ---- detectGridFAST ------------------------------------------------------ */
 int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
                          const float *cur_xy, int ncur, int *fast_th_inout,
@@ -343,6 +409,7 @@ int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
     int nboccup = 0, nbempty = 0, nbkps = 0;
     const int cap = cell * cell;
     int *xs = (int *)malloc(sizeof(int) * cap * 3), *ys = xs + cap, *sc = ys + cap;
+    fkp *sorted = (fkp *)malloc(sizeof(fkp) * (size_t)cap);
     for (int i = 0; i < g.nbcells; i++) {
         int r = i / g.nwcells, c = i % g.nwcells;
         if (g.occ[r * (g.nwcells + 1) + c]) { nboccup++; continue; }
@@ -350,7 +417,7 @@ int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
         int x0 = c * cell, y0 = r * cell;
         if (!(x0 + cell < w - 1 && y0 + cell < h - 1)) continue;            /* :510 */
         int n = orc_fast9_16(img + (size_t)y0 * stride + x0, cell, cell, stride, th, 1, xs, ys, sc, cap);
-        int best = -1, best_score = -1;
+        int best = -1, best_score = -1, nkeep = 0;
         for (int k = 0; k < n; k++) {                       /* runByPixelsMask + sort by response (desc) */
             int lx = xs[k], ly = ys[k], keep;
             if (mask_mode == ORC_MASK_AS_EXECUTED)
@@ -360,8 +427,13 @@ int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
             else
                 keep = g.mask[(size_t)(y0 + ly) * w + x0 + lx];
             if (keep && sc[k] > best_score) { best_score = sc[k]; best = k; }
+            if (keep && g_fast_tie_mode == ORC_FAST_TIE_LIBSTDCXX) { sorted[nkeep].x = lx; sorted[nkeep].y = ly; sorted[nkeep].s = sc[k]; nkeep++; }
         }
         if (best < 0) continue;
+        if (g_fast_tie_mode == ORC_FAST_TIE_LIBSTDCXX) {     /* the element std::sort leaves in front */
+            fk_std_sort(sorted, nkeep);
+            for (int k = 0; k < n; k++) if (xs[k] == sorted[0].x && ys[k] == sorted[0].y) { best = k; break; }
+        }
         if (best_score >= 20) {                                              /* :521 */
             int px = xs[best] + x0, py = ys[best] + y0;
             orc_circle_fill0(g.mask, w, h, px, py, g.nhalfcell);             /* :527 */
@@ -374,7 +446,7 @@ int orc_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell,
     else if (nbkps == nbempty) *fast_th_inout = (int)(th * 1.5);
     if (nbkps > 0 && do_subpix) orc_corner_subpix(img, w, h, stride, out_xy, nbkps, 3, 30, 0.01);
     *out_n = nbkps;
-    free(xs);
+    free(xs); free(sorted);
     grid_free(&g);
     return 0;
 }

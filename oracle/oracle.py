@@ -313,6 +313,33 @@ def detect_grid_fast(img, cell, cur_kps, fast_th, mask_mode=MASK_AS_EXECUTED, su
     return out[:n.value].copy(), th.value
 
 
+FAST_TIE_SCAN_ORDER, FAST_TIE_LIBSTDCXX = 0, 1
+
+
+class fast_tie_mode:
+    """with fast_tie_mode(FAST_TIE_LIBSTDCXX): ...  -- which of several equal best FAST responses of a cell wins in detect_grid_fast: the
+    first in scan order (canonical, the HIP kernels) or the one libstdc++'s std::sort leaves in front (the reference as built with g++)."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        L = lib()
+        L.orc_get_fast_tie_mode.restype = C.c_int
+        self.prev = L.orc_get_fast_tie_mode()
+        L.orc_set_fast_tie_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_fast_tie_mode(self.prev)
+
+
+def fast_tie_sort_fallbacks():
+    f = lib().orc_fast_tie_sort_fallbacks
+    f.restype = C.c_int
+    return int(f())
+
+
 BLUR_FIXED, BLUR_HALF_EVEN = 0, 1
 SUBPIX_FAST, SUBPIX_GENERIC, SUBPIX_FLOAT_ACC = 0, 1, 2
 

@@ -158,6 +158,16 @@ void orc_set_blur_mode(int mode);            /* GaussianBlur 3x3 rounding inside
 int orc_get_blur_mode(void);
 void orc_set_subpix_mode(int mode);          /* getRectSubPix path / accumulator type inside cornerSubPix (detect.c) */
 int orc_get_subpix_mode(void);
+/* detectGridFAST: which of several EQUAL best FAST responses of a cell wins.  The reference sorts the cell's keypoints with std::sort
+ * (src/feature_extractor.cpp:518, not stable) and takes the first: with more than 16 of them the winner among ties is the standard
+ * library's choice.  SCAN_ORDER (canonical: what the HIP kernels implement): the first in scan order, which is also what every
+ * insertion-sort-sized cell gives.  LIBSTDCXX: libstdc++'s introsort restated (bits/stl_algo.h) -- with it the oracle equals the reference's
+ * own code compiled with g++ on every cell (tests/test_reference_factors.py); exists to MEASURE the difference (0.4 % of the cells of a dense
+ * synthetic texture at threshold 20, none at 30). */
+enum { ORC_FAST_TIE_SCAN_ORDER = 0, ORC_FAST_TIE_LIBSTDCXX = 1 };
+void orc_set_fast_tie_mode(int mode);
+int orc_get_fast_tie_mode(void);
+int orc_fast_tie_sort_fallbacks(void);      /* times the emulated introsort ran out of depth (its heap-sort branch is not restated): must stay 0 */
 void orc_set_sobel_dy_order(int order);      /* evaluation order of cv::Sobel(dx=0, dy=1, scale) in the min-eigenvalue map */
 int  orc_get_sobel_dy_order(void);
 void orc_cell_mineig(const uint8_t *img, int w, int h, int stride,

@@ -40,8 +40,7 @@ void ref_line_min_sad(const uint8_t *iml, int lstride, const uint8_t *imr, int r
                       float *xprior, float *l1err)
 {
     FeatureTracker trk(30, 0.01f, nullptr);
-    cv::Mat L, R;
-    L.rows = R.rows = h; L.cols = R.cols = w; L.data = iml; L.step = (size_t)lstride; R.data = imr; R.step = (size_t)rstride;
+    const cv::Mat L = cv::Mat::wrap(iml, h, w, (size_t)lstride), R = cv::Mat::wrap(imr, h, w, (size_t)rstride);
     *l1err = 255.f;                                             // (the reference leaves it unset on its early returns; the oracle writes 255)
     trk.getLineMinSAD(L, R, cv::Point2f(x, y), nwinsize, *xprior, *l1err, go_left != 0);
 }

@@ -226,19 +226,23 @@ def test_sampson_distance_matches_the_reference_source(ref, oracle):
     assert n_close > 100                                      # the gate's threshold region is exercised
 
 
-REF_FT_SO = os.path.join(ROOT, "oracle", "_ref", "libref_feature_tracker.so")
+REF_FT_SO = os.path.join(ROOT, "oracle", "_ref", "libref_frontend.so")
 
 
 @pytest.fixture(scope="module")
 def ref_ft(ref, oracle):
     if not os.path.exists(REF_FT_SO):
-        pytest.skip("oracle/_ref/libref_feature_tracker.so is absent and /root/reference is not here to build it from")
+        pytest.skip("oracle/_ref/libref_frontend.so is absent and /root/reference is not here to build it from")
     oracle.lib()                                              # (its three OpenCV stand-ins resolve into liboracle.so)
     lib = C.CDLL(REF_FT_SO)
     lib.ref_fb_klt.restype = C.c_int
     lib.ref_fb_klt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.ref_line_min_sad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.ref_in_border.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
+    lib.ref_detect_singlescale.restype = C.c_int
+    lib.ref_detect_singlescale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.ref_detect_grid_fast.restype = C.c_int
+    lib.ref_detect_grid_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     return lib
 
 
@@ -294,6 +298,79 @@ def test_line_min_sad_matches_the_reference_source(ref_ft, oracle):
                 ref_ft.ref_line_min_sad(_p(left), w, _p(right), w, w, h, float(x), float(y), nwin, int(go_left), _p(xp), _p(er))
                 assert xp.view(np.uint32)[0] == np.float32(ox[i]).view(np.uint32), (nwin, go_left, i, xp[0], ox[i])
                 assert er.view(np.uint32)[0] == np.float32(oe[i]).view(np.uint32), (nwin, go_left, i, er[0], oe[i])
+
+
+def _detector_inputs(case):
+    from ov2slam_amd import synth
+    rng = np.random.default_rng(100 + case)
+    w, h = [(752, 480), (640, 400), (321, 243), (1241, 376)][case % 4]
+    img, _, _ = synth.frame_pair(w, h, seed=900 + case)
+    if case % 3 == 1:
+        img = (img.astype(np.float32) * 0.35 + 90).astype(np.uint8)                 # low contrast: thresholds adapt downwards
+    if case % 5 == 2:
+        img[: h // 3] = 120                                                          # a flat band: empty cells
+    cell = [35, 45, 50, 35, 25][case % 5]
+    ncur = [0, 40, 150, 5][case % 4]
+    cur = np.stack([rng.uniform(0, w - 1, ncur), rng.uniform(0, h - 1, ncur)], 1).astype(np.float32).reshape(-1, 2)
+    return img, w, h, cell, cur
+
+
+def test_detect_singlescale_matches_the_reference_source(ref_ft, oracle):
+    """FeatureExtractor::detectSingleScale (src/feature_extractor.cpp:288-440) AS THE REFERENCE WROTE IT -- the file is compiled from where it
+    lies against the stand-in OpenCV (GaussianBlur + cornerMinEigenVal, circle, minMaxLoc, cornerSubPix = the oracle's restatements; cv::Mat
+    with OpenCV's sharing semantics) -- against oracle/detect.c: orc_detect_singlescale.  Pins the first-party code: the cell walk and the
+    occupancy table (`px.y / ncellsize` on floats), the in-image test, the float mask and its two masked arg-max passes, the roi test's
+    `continue` (which also drops the cell's second detection), the top-up from the secondary detections (`back()`, the count), the quality
+    adaptation.  Keypoint lists (float bits, order) and the adapted quality must be equal."""
+    for case in range(16):
+        img, w, h, cell, cur = _detector_inputs(case)
+        roi = [(0, 0, w, h), (5, 5, w - 10, h - 10), (w // 4, h // 4, w // 2, h // 2)][case % 3]
+        for q0 in (0.001, 0.02, 1e-5):
+            o_pts, o_q = oracle.detect_singlescale(img, cell, cur, roi, q0)
+            out = np.zeros((4 * (w // cell) * (h // cell) + 8, 2), np.float32); q = C.c_double(q0)
+            roi_a = (C.c_int * 4)(*roi)
+            n = ref_ft.ref_detect_singlescale(_p(img), w, h, w, cell, _p(cur) if len(cur) else None, len(cur), roi_a, C.byref(q), _p(out), len(out))
+            assert n == len(o_pts), (case, q0, n, len(o_pts))
+            assert np.array_equal(out[:n].view(np.uint32), o_pts.view(np.uint32)), (case, q0)
+            assert q.value == o_q, (case, q0, q.value, o_q)
+
+
+def test_detect_grid_fast_matches_the_reference_source(ref_ft, oracle):
+    """FeatureExtractor::detectGridFAST (src/feature_extractor.cpp:443-570) as the reference wrote it against orc_detect_grid_fast in the
+    AS-EXECUTED mask mode: the reference hands FAST a CV_32F mask, OpenCV's keypoint filter reads it byte-wise
+    (`mask.at<uchar>`) -- the stand-in restates that filter on a real float buffer, so the aliasing is executed here, not assumed: a
+    keypoint at ROI column x survives iff x mod 4 >= 2 and the float at column x / 4 is 1.0.  Also pinned: occupancy, the in-image test,
+    `std::sort` by response and the `>= 20` gate on the best one, the circle written into the mask for the following cells, both
+    threshold adaptations (`int *= double`).
+    The reference's std::sort is not stable: with more than 16 keypoints left in a cell the winner among EQUAL best responses is the
+    standard library's choice.  With libstdc++'s introsort restated (ORC_FAST_TIE_LIBSTDCXX) the oracle equals the reference's own code,
+    compiled here with g++, on EVERY cell; in its canonical mode (first in scan order: what the HIP kernels implement) it differs exactly
+    where such a tie exists -- counted below."""
+    n_tie_cells, n_cells = {7: 0, 20: 0, 45: 0}, {7: 0, 20: 0, 45: 0}
+    for case in range(16):
+        img, w, h, cell, cur = _detector_inputs(case)
+        for th0 in (20, 7, 45):
+            out = np.zeros(((w // cell) * (h // cell) + 8, 2), np.float32); th = C.c_int(th0)
+            n = ref_ft.ref_detect_grid_fast(_p(img), w, h, w, cell, _p(cur) if len(cur) else None, len(cur), C.byref(th), _p(out), len(out))
+            with oracle.fast_tie_mode(oracle.FAST_TIE_LIBSTDCXX):
+                s_pts, s_th = oracle.detect_grid_fast(img, cell, cur, th0)
+            assert th.value == s_th and n == len(s_pts), (case, th0, th.value, s_th, n, len(s_pts))
+            assert np.array_equal(out[:n].view(np.uint32), s_pts.view(np.uint32)), (case, th0)
+            # canonical mode: same count and threshold; points differ only where an equal-score tie exists in a cell with > 16 corners
+            o_pts, o_th = oracle.detect_grid_fast(img, cell, cur, th0)
+            assert o_th == s_th and len(o_pts) == n
+            n_cells[th0] += n
+            if not np.array_equal(o_pts.view(np.uint32), s_pts.view(np.uint32)):
+                o_raw, _ = oracle.detect_grid_fast(img, cell, cur, th0, subpix=False)
+                for b in np.nonzero((s_pts != o_pts).any(1))[0]:
+                    x0, y0 = int(o_raw[b, 0]) // cell * cell, int(o_raw[b, 1]) // cell * cell
+                    xs, ys, sc = oracle.fast9_16(np.ascontiguousarray(img[y0:y0 + cell, x0:x0 + cell]), th0)
+                    best = sc[(xs + x0 == int(o_raw[b, 0])) & (ys + y0 == int(o_raw[b, 1]))][0]
+                    assert len(xs) > 16 and int((sc == best).sum()) >= 2, (case, th0, b)
+                    n_tie_cells[th0] += 1
+    assert oracle.fast_tie_sort_fallbacks() == 0
+    # dense synthetic texture: ~2 % of the cells at threshold 7, ~0.4 % at the shipped 20, none at 45
+    assert n_tie_cells[45] == 0 and n_tie_cells[20] <= 0.01 * n_cells[20] and n_tie_cells[7] <= 0.04 * n_cells[7], (n_tie_cells, n_cells)
 
 
 @pytest.mark.gpu
