@@ -88,6 +88,11 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
  *                           default accumulates with fp64 atomics in arrival order (H, F^T b, W^T C W, the costs) goes through
  *                           per-work-group buffers added up in a fixed order.  Inverse-depth form on the LDS-resident path (up
  *                           to ~70 optimised keyframes); other forms answer OV2_EUNSUPPORTED while it is set.  ~1.7x the solve time.
+ * OV2_OPT_FAST_TIE          detectGridFAST: which of several EQUAL best FAST responses of a cell wins.  The reference sorts the cell's corners
+ *                           with std::sort (src/feature_extractor.cpp:518, not stable) and takes the first: with more than 16 corners left
+ *                           the winner among ties is the standard library's choice.  OV2_FAST_TIE_LIBSTDCXX (default): libstdc++'s
+ *                           introsort restated -- the reference as built with g++, cell for cell (tests/test_reference_factors.py runs
+ *                           the reference's own source); OV2_FAST_TIE_SCAN_ORDER: the first in scan order (what a stable sort gives)
  * OV2_OPT_DEBUG             1: timing laps of ov2_local_ba / detection on stderr (initial value: environment OV2_DEBUG at
  *                           ov2_ctx_create, the only environment variable the library ever reads)                          */
 #define OV2_OPT_LK_IMPL            2
@@ -105,6 +110,9 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
 #define OV2_OPT_BA_POSE_ONLY_FUSED 9
 #define OV2_OPT_BA_DETERMINISTIC   10
 #define OV2_OPT_DEBUG              11
+#define OV2_OPT_FAST_TIE           12
+#define OV2_FAST_TIE_SCAN_ORDER    0
+#define OV2_FAST_TIE_LIBSTDCXX     1
 int  ov2_ctx_set_option(ov2_ctx *ctx, int option, int value);
 int  ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value);
 

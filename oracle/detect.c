@@ -333,7 +333,7 @@ static void grid_free(grid_state *g) { free(g->occ); free(g->mask); }
  * pivot moved to the front, __unguarded_partition, __final_insertion_sort with its 16-element threshold) on (x, y, score) records, comparator
  * a.score > b.score.  Only the order of EQUAL scores depends on these details -- which is the point (ORC_FAST_TIE_LIBSTDCXX). */
 typedef struct { int x, y, s; } fkp;
-static int g_fast_tie_mode = ORC_FAST_TIE_SCAN_ORDER, g_fast_tie_fallbacks = 0;
+static int g_fast_tie_mode = ORC_FAST_TIE_LIBSTDCXX, g_fast_tie_fallbacks = 0;
 void orc_set_fast_tie_mode(int mode) { g_fast_tie_mode = mode == ORC_FAST_TIE_LIBSTDCXX ? ORC_FAST_TIE_LIBSTDCXX : ORC_FAST_TIE_SCAN_ORDER; }
 int orc_get_fast_tie_mode(void) { return g_fast_tie_mode; }
 int orc_fast_tie_sort_fallbacks(void) { return g_fast_tie_fallbacks; }

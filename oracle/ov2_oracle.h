@@ -160,10 +160,10 @@ void orc_set_subpix_mode(int mode);          /* getRectSubPix path / accumulator
 int orc_get_subpix_mode(void);
 /* detectGridFAST: which of several EQUAL best FAST responses of a cell wins.  The reference sorts the cell's keypoints with std::sort
  * (src/feature_extractor.cpp:518, not stable) and takes the first: with more than 16 of them the winner among ties is the standard
- * library's choice.  SCAN_ORDER (canonical: what the HIP kernels implement): the first in scan order, which is also what every
- * insertion-sort-sized cell gives.  LIBSTDCXX: libstdc++'s introsort restated (bits/stl_algo.h) -- with it the oracle equals the reference's
- * own code compiled with g++ on every cell (tests/test_reference_factors.py); exists to MEASURE the difference (0.4 % of the cells of a dense
- * synthetic texture at threshold 20, none at 30). */
+ * library's choice.  LIBSTDCXX (canonical: what the HIP kernels implement by default, OV2_OPT_FAST_TIE): libstdc++'s introsort restated
+ * (bits/stl_algo.h) -- with it the oracle equals the reference's own code compiled with g++ on every cell
+ * (tests/test_reference_factors.py).  SCAN_ORDER: the first in scan order (what a stable sort, and every insertion-sort-sized cell,
+ * gives); the two differ on 0.4 % of the cells of a dense synthetic texture at threshold 20, none at 30. */
 enum { ORC_FAST_TIE_SCAN_ORDER = 0, ORC_FAST_TIE_LIBSTDCXX = 1 };
 void orc_set_fast_tie_mode(int mode);
 int orc_get_fast_tie_mode(void);

@@ -207,10 +207,25 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         if ((mask_mode != OV2_MASK_AS_EXECUTED || (lx & 3) >= 2) && v > bv) { bv = v; bi = p; }
     }
     block_argmax_f(bv, bi, s_v, s_i);
+    // how many corners FAST's mask filter lets through on an untouched mask, and how many of them share the best response: the reference
+    // sorts them with std::sort (src/feature_extractor.cpp:518), whose choice among equal responses depends on the count (k_grid_select)
+    __shared__ int s_cnt[2];
+    if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    int n_l = 0, t_l = 0;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        const int ly = p / cs, lx = p - ly * cs;
+        const float v = (float)tile[p];
+        if ((mask_mode != OV2_MASK_AS_EXECUTED || (lx & 3) >= 2) && v > 0.f) { n_l++; t_l += v == bv; }
+    }
+    if (n_l) atomicAdd(&s_cnt[0], n_l);
+    if (t_l) atomicAdd(&s_cnt[1], t_l);
+    __syncthreads();
     if (threadIdx.x == 0) {
         CellCand cd;
         const int by = bi / cs, bx = bi - by * cs;
-        cd.p1 = bv > 0.f ? (bx | (by << 16)) : -1; cd.v1 = bv; cd.p2 = -1; cd.v2 = 0.f;
+        cd.p1 = bv > 0.f ? (bx | (by << 16)) : -1; cd.v1 = bv;
+        cd.p2 = min(s_cnt[0], 0xFFFF) | (min(s_cnt[1], 0x7FFF) << 16); cd.v2 = 0.f;       // (FAST cells have no second candidate: the slot carries the counts)
         cand_out[cell] = cd;
     }
 }
@@ -354,6 +369,7 @@ struct SelectParams {
     int w, h, cs, nwcells, nhcells, radius, mask_words_per_row;
     int mode;            // 0 = FAST, 1 = single scale
     int mask_mode;       // OV2_MASK_AS_EXECUTED / OV2_MASK_INTENDED (FAST only)
+    int fast_tie;        // OV2_FAST_TIE_SCAN_ORDER / OV2_FAST_TIE_LIBSTDCXX (FAST only): which of several equal best responses wins
     int ncur;
     int roi_x, roi_y, roi_w, roi_h;
     double quality;
@@ -400,6 +416,66 @@ __device__ __forceinline__ int mask_test(const unsigned *mask, int wpr, int x, i
     return (mask[y * wpr + (x >> 5)] >> (x & 31)) & 1u;
 }
 
+// std::sort(vkps.begin(), vkps.end(), compare_response) as libstdc++ runs it (bits/stl_algo.h: introsort with the median of three moved to the
+// front, unguarded partition, final insertion sort with its 16-element threshold), on packed records score << 16 | ly << 8 | lx in LDS,
+// comparator a.score > b.score; one lane.  Only the order of EQUAL scores depends on these details: the reference takes element 0
+// (src/feature_extractor.cpp:518-522), so among equal best responses of a cell with more than 16 corners it takes libstdc++'s pick.
+// (oracle/detect.c: fk_std_sort is the same code on the CPU; tests/test_reference_factors.py runs the reference's own source against it.)
+#define FK_LESS(a, b) (((a) >> 16) > ((b) >> 16))
+__device__ __forceinline__ void d_fk_unguarded_linear_insert(int *last)
+{
+    const int val = *last; int *next = last - 1;
+    while (FK_LESS(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+__device__ __forceinline__ void d_fk_insertion_sort(int *first, int *last)
+{
+    if (first == last) return;
+    for (int *i = first + 1; i != last; ++i) {
+        if (FK_LESS(*i, *first)) { const int val = *i; for (int *q = i; q != first; --q) *q = *(q - 1); *first = val; }
+        else d_fk_unguarded_linear_insert(i);
+    }
+}
+__device__ __forceinline__ void d_fk_swap(int *a, int *b) { const int t = *a; *a = *b; *b = t; }
+__device__ void d_fk_std_sort(int *first, int n, int *stk)
+{
+    if (n <= 0) return;
+    int lg = 0; for (int m = n; m > 1; m >>= 1) lg++;
+    // __introsort_loop, its recursion on the right part unrolled onto a small stack of (first, last, depth) offsets (in LDS: `stk`, 3 x 24 ints)
+    int sp = 0;
+    stk[0] = 0; stk[1] = n; stk[2] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int *f = first + stk[3 * sp], *l = first + stk[3 * sp + 1]; int depth = stk[3 * sp + 2];
+        while (l - f > 16) {
+            if (depth == 0) { d_fk_insertion_sort(f, l); break; }                 // (libstdc++: heap sort; never reached on cells -- the oracle counts it)
+            --depth;
+            int *mid = f + (l - f) / 2, *a = f + 1, *b = mid, *c = l - 1;
+            if (FK_LESS(*a, *b)) { if (FK_LESS(*b, *c)) d_fk_swap(f, b); else if (FK_LESS(*a, *c)) d_fk_swap(f, c); else d_fk_swap(f, a); }
+            else if (FK_LESS(*a, *c)) d_fk_swap(f, a);
+            else if (FK_LESS(*b, *c)) d_fk_swap(f, c);
+            else d_fk_swap(f, b);
+            int *pf = f + 1, *pl = l;
+            for (;;) {
+                while (FK_LESS(*pf, *f)) ++pf;
+                --pl;
+                while (FK_LESS(*f, *pl)) --pl;
+                if (!(pf < pl)) break;
+                d_fk_swap(pf, pl);
+                ++pf;
+            }
+            // __introsort_loop(cut, last, depth) first, then the loop goes on with [first, cut): the order of the two does not change the
+            // result (disjoint ranges), so the right part waits on the stack
+            if (sp < 24) { stk[3 * sp] = (int)(pf - first); stk[3 * sp + 1] = (int)(l - first); stk[3 * sp + 2] = depth; sp++; }
+            l = pf;
+        }
+    }
+    if (n > 16) { d_fk_insertion_sort(first, first + 16); for (int *i = first + 16; i != first + n; ++i) d_fk_unguarded_linear_insert(i); }
+    else d_fk_insertion_sort(first, first + n);
+}
+#undef FK_LESS
+#define DET_SORT_CAP 512        // corners of a cell that can enter the emulated sort (non-adjacent after NMS: <= 32 x 32 / 2 for cs = 64, halved again by N3)
+
 // MODE 0 = FAST scores (bytes), 1 = min-eigenvalue (floats); a cell row (<= MAXROW * CHUNKS columns) is held in registers
 // MAXROW columns at a time: (36,1) and (52,1) cover the reference cell sizes with compile-time column indices, (32,2) the rest
 template <int MODE, int MAXROW, int CHUNKS>
@@ -436,6 +512,7 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     for (int i = tid; i < 4 * ncells; i += nthreads) s_cand[i] = ((const int *)cand)[i];
     for (int i = tid; i < P.nhcells; i += nthreads) progress[i] = 0;
     __shared__ int s_nslow;
+    __shared__ int s_sort[MODE == 0 ? 16 * (DET_SORT_CAP + 72) : 1];    // FAST tie-break (fast_tie): a wavefront's corners of the current cell + the sort's stack
     if (tid == 0) s_nslow = 0;
     for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
@@ -528,7 +605,11 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                 // AS_EXECUTED: the CV_32F ones-mask read as bytes -- byte (lx & 3) of float lx >> 2 (N3)
                 const int mcol = P.mask_mode == OV2_MASK_AS_EXECUTED ? (p1x >> 2) : p1x;
                 int mx_ = p1x, my_ = p1y;
-                if (mask_test(mask, P.mask_words_per_row, x0 + mcol, y0 + p1y)) bv = c_v1;
+                // fast_tie: the candidate (first of the best responses in scan order) is what std::sort puts in front unless the cell
+                // keeps more than 16 corners AND several share the best response -- the counts of the untouched mask bound both
+                const bool tie_mode = P.fast_tie == OV2_FAST_TIE_LIBSTDCXX;
+                const bool hard = tie_mode && c_p2 >= 0 && (c_p2 & 0xFFFF) > 16 && (c_p2 >> 16) >= 2;
+                if (!hard && mask_test(mask, P.mask_words_per_row, x0 + mcol, y0 + p1y)) bv = c_v1;
                 else {
                     // best response among the mask-surviving FAST corners, raster order on ties
                     if (lane == 0) atomicAdd(&s_nslow, 1);
@@ -547,6 +628,48 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                     }
                     wave_argmax_f(bv, bi);
                     my_ = bi / P.cs; mx_ = bi - my_ * P.cs;
+                    if (tie_mode && bv > 0.f) {
+                        // the cell's corners that pass the mask, and how many of them share the best response
+                        int ns = 0, nt = 0;
+#pragma unroll
+                        for (int ch = 0; ch < CHUNKS; ch++) {
+                            const int jb = ch * MAXROW;
+                            if (!single) { SEL_LOAD_CHUNK(jb) }
+#pragma unroll
+                            for (int q = 0; q < MAXROW; q++) {
+                                const int lx = jb + q;
+                                const unsigned long long bit = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) ? (mb >> (lx >> 2)) : 0ull) : (mb >> (lx & 63));
+                                if ((bit & 1ull) && curv[q] > 0.f) { ns++; nt += curv[q] == bv; }
+                            }
+                        }
+                        int off = ns;                                         // inclusive prefix over the rows (lane = row)
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(off, d, 64); if (lane >= d) off += t; }
+                        const int total = __shfl(off, 63, 64);
+                        int ntie = nt;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) ntie += __shfl_xor(ntie, d, 64);
+                        if (total > 16 && ntie >= 2 && total <= DET_SORT_CAP) {
+                            int *srt = s_sort + wave * (DET_SORT_CAP + 72);
+                            int w_ = off - ns;                                // scan order: rows ascending, columns ascending inside a row
+#pragma unroll
+                            for (int ch = 0; ch < CHUNKS; ch++) {
+                                const int jb = ch * MAXROW;
+                                if (!single) { SEL_LOAD_CHUNK(jb) }
+#pragma unroll
+                                for (int q = 0; q < MAXROW; q++) {
+                                    const int lx = jb + q;
+                                    const unsigned long long bit = P.mask_mode == OV2_MASK_AS_EXECUTED ? (((lx & 3) >= 2) ? (mb >> (lx >> 2)) : 0ull) : (mb >> (lx & 63));
+                                    if ((bit & 1ull) && curv[q] > 0.f) srt[w_++] = ((int)curv[q] << 16) | (ly << 8) | lx;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (lane == 0) d_fk_std_sort(srt, total, srt + DET_SORT_CAP);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const int win = srt[0];
+                            mx_ = win & 0xFF; my_ = (win >> 8) & 0xFF;
+                        }
+                    }
                 }
                 if (bv >= 20.f) {                                         // :521
                     const int px = x0 + mx_, py = y0 + my_;
@@ -893,6 +1016,7 @@ static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int 
     SelectParams P;
     P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
     P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
+    P.fast_tie = ctx->det_fast_tie;
     P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
     P.quality = quality;
 #define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                               \

@@ -47,6 +47,37 @@ def test_grid_fast_bit_exact(gpu_ctx, oracle, name, cell, mode):
     assert len(r) > 10
 
 
+@pytest.mark.parametrize("tie", [L.OV2_FAST_TIE_SCAN_ORDER, L.OV2_FAST_TIE_LIBSTDCXX])
+def test_grid_fast_ties_among_equal_responses(gpu_ctx, oracle, tie):
+    """detectGridFAST's std::sort (src/feature_extractor.cpp:518): with more than 16 corners left in a cell the winner among EQUAL best
+    responses is the standard library's choice.  OV2_OPT_FAST_TIE selects libstdc++'s introsort restated on the device (what the reference
+    built with g++ does -- tests/test_reference_factors.py runs the reference's own source against the oracle's copy of it) or the first
+    in scan order; both against the oracle in the same mode, bit for bit, at thresholds that leave many corners per cell."""
+    prev = gpu_ctx.get_option(L.OV2_OPT_FAST_TIE)
+    gpu_ctx.set_option(L.OV2_OPT_FAST_TIE, tie)
+    n_diff = 0
+    try:
+        for name, img in IMAGES:
+            h, w = img.shape
+            rng = np.random.default_rng(23)
+            for cell in (35, 50, 64):
+                cur = synth.grid_keypoints(w, h, cell, rng)[::4]
+                for th0 in (5, 9, 20):
+                    for mode in (L.OV2_MASK_AS_EXECUTED, L.OV2_MASK_INTENDED):
+                        fx = ov2slam_amd.FeatureExtractor(gpu_ctx, nfast_th=th0, mask_mode=mode)
+                        g = fx.detectGridFAST(img, cell, cur, subpix=False)
+                        with oracle.fast_tie_mode(tie):
+                            r, rth = oracle.detect_grid_fast(img, cell, cur, th0, mode, subpix=False)
+                        assert g.shape == r.shape and np.array_equal(_bits(g), _bits(r)), (name, cell, th0, mode, int((g != r).any(1).sum()) if g.shape == r.shape else -1)
+                        assert fx.nfast_th_ == rth
+                        with oracle.fast_tie_mode(1 - tie):
+                            o, _ = oracle.detect_grid_fast(img, cell, cur, th0, mode, subpix=False)
+                        n_diff += int((o != r).any(1).sum()) if o.shape == r.shape else 1
+    finally:
+        gpu_ctx.set_option(L.OV2_OPT_FAST_TIE, prev)
+    assert n_diff > 20 and oracle.fast_tie_sort_fallbacks() == 0        # the two modes do differ on these inputs: the test bites
+
+
 @pytest.mark.parametrize("name", [n for n, _ in IMAGES])
 @pytest.mark.parametrize("cell", [35, 45, 53, 58])
 def test_singlescale_bit_exact(gpu_ctx, oracle, name, cell):

@@ -343,9 +343,9 @@ def test_detect_grid_fast_matches_the_reference_source(ref_ft, oracle):
     `std::sort` by response and the `>= 20` gate on the best one, the circle written into the mask for the following cells, both
     threshold adaptations (`int *= double`).
     The reference's std::sort is not stable: with more than 16 keypoints left in a cell the winner among EQUAL best responses is the
-    standard library's choice.  With libstdc++'s introsort restated (ORC_FAST_TIE_LIBSTDCXX) the oracle equals the reference's own code,
-    compiled here with g++, on EVERY cell; in its canonical mode (first in scan order: what the HIP kernels implement) it differs exactly
-    where such a tie exists -- counted below."""
+    standard library's choice.  With libstdc++'s introsort restated (ORC_FAST_TIE_LIBSTDCXX: the oracle's and the HIP kernels' default since
+    this was found) the oracle equals the reference's own code, compiled here with g++, on EVERY cell; first-in-scan-order
+    (ORC_FAST_TIE_SCAN_ORDER, the default until then) differs exactly where such a tie exists -- counted below."""
     n_tie_cells, n_cells = {7: 0, 20: 0, 45: 0}, {7: 0, 20: 0, 45: 0}
     for case in range(16):
         img, w, h, cell, cur = _detector_inputs(case)
@@ -356,12 +356,14 @@ def test_detect_grid_fast_matches_the_reference_source(ref_ft, oracle):
                 s_pts, s_th = oracle.detect_grid_fast(img, cell, cur, th0)
             assert th.value == s_th and n == len(s_pts), (case, th0, th.value, s_th, n, len(s_pts))
             assert np.array_equal(out[:n].view(np.uint32), s_pts.view(np.uint32)), (case, th0)
-            # canonical mode: same count and threshold; points differ only where an equal-score tie exists in a cell with > 16 corners
-            o_pts, o_th = oracle.detect_grid_fast(img, cell, cur, th0)
+            # scan-order mode: same count and threshold; points differ only where an equal-score tie exists in a cell with > 16 corners
+            with oracle.fast_tie_mode(oracle.FAST_TIE_SCAN_ORDER):
+                o_pts, o_th = oracle.detect_grid_fast(img, cell, cur, th0)
             assert o_th == s_th and len(o_pts) == n
             n_cells[th0] += n
             if not np.array_equal(o_pts.view(np.uint32), s_pts.view(np.uint32)):
-                o_raw, _ = oracle.detect_grid_fast(img, cell, cur, th0, subpix=False)
+                with oracle.fast_tie_mode(oracle.FAST_TIE_SCAN_ORDER):
+                    o_raw, _ = oracle.detect_grid_fast(img, cell, cur, th0, subpix=False)
                 for b in np.nonzero((s_pts != o_pts).any(1))[0]:
                     x0, y0 = int(o_raw[b, 0]) // cell * cell, int(o_raw[b, 1]) // cell * cell
                     xs, ys, sc = oracle.fast9_16(np.ascontiguousarray(img[y0:y0 + cell, x0:x0 + cell]), th0)
