@@ -45,7 +45,7 @@ typedef struct ov2_pyr ov2_pyr;
  * (round 2 added ov2_ba_options::max_solver_time_s).  ov2_version() returns the value the library was built with; a caller
  * must refuse to run when the two differ (the C++ adapters' ov2::Context and ov2slam_amd/_lib.py do): a shorter options
  * struct from an older header would otherwise be read past its end.                                                    */
-#define OV2_ABI_VERSION 500
+#define OV2_ABI_VERSION 600
 int  ov2_version(void);
 /* last error message of the calling thread ("" if none); never NULL */
 const char *ov2_last_error(void);
@@ -528,6 +528,9 @@ typedef struct {
     int iterations[2], num_successful_steps[2], termination[2];
     double initial_cost[2], final_cost[2];
     double solve_ms[2];          /* device time of each pass                                              */
+    int status;                  /* OV2_OK, or this problem's error code (ABI 600).  ov2_local_ba: the value it returns.  ov2_local_ba_batch:
+                                    every problem is attempted; r[i].status tells which results are valid and the call returns the
+                                    first non-OK status (OV2_OK when all are)                                                        */
 } ov2_local_ba_result;
 void ov2_local_ba_default_options(ov2_local_ba_options *o);
 int  ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r);
@@ -541,7 +544,10 @@ int  ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_opti
  * over work-groups are grouped by the batch's grid: parity 1e-7, tests/test_gpu_ba_batch.py); solve_ms is the device time of
  * the batch's pass.  Problems the shared launches do not cover (more optimised keyframes than the LDS-resident path holds,
  * OV2_RES_PNP blocks, no landmarks, OV2_OPT_BA_DETERMINISTIC) are solved one after the other through ov2_local_ba in the same
- * call; *n_batched (or NULL) = how many shared the launches.  max_solver_time_s bounds the batch's pass.                      */
+ * call; *n_batched (or NULL) = how many shared the launches; a failure of one of them (r[i].status) does not stop the others.
+ * max_solver_time_s is ONE host-clock budget for the batch's shared pass (the batch advances iteration by iteration, so a slow
+ * window ends the pass for all): a caller that wants the reference's per-problem limit leaves it at 0 here, or calls ov2_local_ba
+ * per problem.                                                                                                                 */
 int  ov2_local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r, int *n_batched);
 
 /* ------------------------------------------------------------------ */

@@ -79,7 +79,7 @@ class LocalBAResult(C.Structure):
         ("bad_after_pass1", C.POINTER(C.c_uint8)), ("chi2_last_eval", C.POINTER(C.c_double)),
         ("depthpos_last_eval", C.POINTER(C.c_uint8)), ("l2_done", C.c_int), ("pass2_error", C.c_int), ("n_bad_pass1", C.c_int), ("n_bad_total", C.c_int),
         ("iterations", C.c_int * 2), ("num_successful_steps", C.c_int * 2), ("termination", C.c_int * 2), ("initial_cost", C.c_double * 2),
-        ("final_cost", C.c_double * 2), ("solve_ms", C.c_double * 2),
+        ("final_cost", C.c_double * 2), ("solve_ms", C.c_double * 2), ("status", C.c_int),
     ]
 
 
@@ -217,7 +217,7 @@ SIGNATURES = {
     "ov2_local_ba_batch": (_i, [_vp, _i, C.POINTER(BAProblem), C.POINTER(LocalBAOptions), C.POINTER(LocalBAResult), C.POINTER(_i)]),
 }
 
-OV2_ABI_VERSION = 500          # include/ov2slam_hip.h
+OV2_ABI_VERSION = 600          # include/ov2slam_hip.h
 
 _lib = None
 

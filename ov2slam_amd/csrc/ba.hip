@@ -3506,7 +3506,7 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
                     same_solver_options(o[i].pass1, o[0].pass1) && same_solver_options(o[i].pass2, o[0].pass2), OV2_EINVAL,
                     "ov2_local_ba_batch: the problems of a batch share the protocol and solver options (only the stop request is per problem)");
         ov2_local_ba_result &ri = r[i];
-        ri.l2_done = 0; ri.pass2_error = OV2_OK; ri.n_bad_pass1 = 0; ri.n_bad_total = 0;
+        ri.l2_done = 0; ri.pass2_error = OV2_OK; ri.n_bad_pass1 = 0; ri.n_bad_total = 0; ri.status = OV2_OK;
         for (int q = 0; q < 2; q++) { ri.iterations[q] = 0; ri.num_successful_steps[q] = 0; ri.termination[q] = OV2_TERM_NO_CONVERGENCE; ri.initial_cost[q] = ri.final_cost[q] = 0; ri.solve_ms[q] = 0; }
     }
     // which problems can share launches: inverse-depth problems of the LDS-resident path with landmarks and optimised keyframes
@@ -3688,12 +3688,15 @@ static int local_ba_batch(ov2_ctx *ctx, int n, const ov2_ba_problem *p, const ov
         B.devs.clear();
     }
     // what cannot share launches (large windows, pose-only blocks, the deterministic mode): one problem at a time
+    // every one of them is attempted: r[i].status says which results are valid, the call returns the first failure
+    int first_err = OV2_OK;
     for (int i = 0; i < n; i++) {
         if (!alone[(size_t)i]) continue;
         const int rc = ov2_local_ba(ctx, &p[i], &o[i], &r[i]);
-        if (rc != OV2_OK) return rc;
+        r[i].status = rc;
+        if (rc != OV2_OK && first_err == OV2_OK) first_err = rc;
     }
-    return OV2_OK;
+    return first_err;
 }
 
 extern "C" {
@@ -3747,9 +3750,16 @@ void ov2_local_ba_default_options(ov2_local_ba_options *o)
 
 // Optimizer::localBA's solve stage (src/optimizer.cpp:436-735) with the problem RESIDENT between the two passes: one
 // counting sort + one upload, the outlier tests and the removal of residual blocks on the device, one download.
+static int local_ba_one(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r);
 int ov2_local_ba(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r)
 {
     OV2_REQUIRE(ctx && p && o && r, OV2_EINVAL, "NULL argument");
+    const int rc = local_ba_one(ctx, p, o, r);
+    r->status = rc;
+    return rc;
+}
+static int local_ba_one(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_local_ba_options *o, ov2_local_ba_result *r)
+{
     OV2_REQUIRE(o->robust_mono_th > 0, OV2_EINVAL, "robust_mono_th must be positive");
     r->l2_done = 0; r->pass2_error = OV2_OK; r->n_bad_pass1 = 0; r->n_bad_total = 0;
     for (int i = 0; i < 2; i++) { r->iterations[i] = 0; r->num_successful_steps[i] = 0; r->termination[i] = OV2_TERM_NO_CONVERGENCE; r->initial_cost[i] = r->final_cost[i] = 0; r->solve_ms[i] = 0; }

@@ -370,6 +370,7 @@ struct SelectParams {
     int mode;            // 0 = FAST, 1 = single scale
     int mask_mode;       // OV2_MASK_AS_EXECUTED / OV2_MASK_INTENDED (FAST only)
     int fast_tie;        // OV2_FAST_TIE_SCAN_ORDER / OV2_FAST_TIE_LIBSTDCXX (FAST only): which of several equal best responses wins
+    int sort_slots;      // LIBSTDCXX tie order: sort scratch areas at the end of the dynamic LDS (1..16; 16 = one per wavefront, never contended)
     int ncur;
     int roi_x, roi_y, roi_w, roi_h;
     double quality;
@@ -512,7 +513,12 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
     for (int i = tid; i < 4 * ncells; i += nthreads) s_cand[i] = ((const int *)cand)[i];
     for (int i = tid; i < P.nhcells; i += nthreads) progress[i] = 0;
     __shared__ int s_nslow;
-    __shared__ int s_sort[MODE == 0 ? 16 * (DET_SORT_CAP + 72) : 1];    // FAST tie-break (fast_tie): a wavefront's corners of the current cell + the sort's stack
+    // FAST tie-break (fast_tie): a wavefront's corners of the current cell + the sort's stack.  Carved out of the DYNAMIC allocation
+    // (sort_slots areas, 0 unless the libstdc++ order is asked for) so that the host's LDS guard sees it; an area is taken under
+    // its lock for the duration of one sort (with 16 areas wavefront w owns area w and the lock is never contended)
+    int *s_sort = sec + ncells;
+    __shared__ int s_sort_lock[16];
+    if (tid < 16) s_sort_lock[tid] = 0;
     if (tid == 0) s_nslow = 0;
     for (int i = tid; i < mask_words; i += nthreads) mask[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nocc; i += nthreads) occ[i] = 0;
@@ -650,7 +656,12 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
 #pragma unroll
                         for (int d = 32; d >= 1; d >>= 1) ntie += __shfl_xor(ntie, d, 64);
                         if (total > 16 && ntie >= 2 && total <= DET_SORT_CAP) {
-                            int *srt = s_sort + wave * (DET_SORT_CAP + 72);
+                            const int slot = wave % P.sort_slots;
+                            int *srt = s_sort + slot * (DET_SORT_CAP + 72);
+                            if (P.sort_slots < 16) {
+                                if (lane == 0) while (atomicCAS(&s_sort_lock[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); __builtin_amdgcn_wave_barrier();
+                            }
                             int w_ = off - ns;                                // scan order: rows ascending, columns ascending inside a row
 #pragma unroll
                             for (int ch = 0; ch < CHUNKS; ch++) {
@@ -668,6 +679,10 @@ __global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const floa
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                             const int win = srt[0];
                             mx_ = win & 0xFF; my_ = (win >> 8) & 0xFF;
+                            if (P.sort_slots < 16) {
+                                __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                if (lane == 0) __hip_atomic_store(&s_sort_lock[slot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                     }
                 }
@@ -997,6 +1012,23 @@ static hipError_t det_raise_lds_limits()
     return err;
 }
 
+// Dynamic LDS of k_grid_select: exclusion mask + cell tables (+ the sort areas of the libstdc++ tie order, FAST only).
+// *slots = sort areas that fit (<= 16); returns 0 when the image does not fit at all.
+static size_t det_select_lds(int w, int h, int cell, int mode, int fast_tie, int *slots)
+{
+    const int nw = w / cell, nh = h / cell, ncells = nw * nh, wpr = (w + 31) / 32;
+    const size_t base = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
+    const size_t limit = 160 * 1024 - 256;                           // less the kernel's static LDS (locks, counters)
+    *slots = 0;
+    if (base > limit) return 0;
+    if (mode != 0 || fast_tie != OV2_FAST_TIE_LIBSTDCXX) return base;
+    const size_t area = (size_t)(DET_SORT_CAP + 72) * 4;
+    const size_t fit = (limit - base) / area;
+    if (fit == 0) return 0;
+    *slots = fit > 16 ? 16 : (int)fit;
+    return base + (size_t)*slots * area;
+}
+
 // The three launches of a detection (response + candidates per cell, selection, sub-pixel refinement) for `items` images
 // that lie `B.img_stride` bytes apart; every pointer addresses item 0.  Asynchronous on the context's stream.
 static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int h, int im_stride, int cell, int items, DetBatch B,
@@ -1004,7 +1036,8 @@ static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int 
                           uint8_t *maps_d, CellCand *cand_d, float2 *out_d, SelectOut *so_d, int do_subpix)
 {
     const int nw = w / cell, nh = h / cell, ncells = nw * nh, npx = cell * cell, wpr = (w + 31) / 32;
-    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
+    int sort_slots = 0;
+    const size_t sel_lds = det_select_lds(w, h, cell, mode, ctx->det_fast_tie, &sort_slots);
     B.ncells = ncells; B.cur = cur_d; B.ncur_all = ncur;
     if (mode == 0) {
         int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
@@ -1016,7 +1049,7 @@ static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int 
     SelectParams P;
     P.w = w; P.h = h; P.cs = cell; P.nwcells = nw; P.nhcells = nh; P.radius = cell / 4; P.mask_words_per_row = wpr;
     P.mode = mode; P.mask_mode = mask_mode; P.ncur = ncur;
-    P.fast_tie = ctx->det_fast_tie;
+    P.fast_tie = ctx->det_fast_tie; P.sort_slots = sort_slots > 0 ? sort_slots : 1;
     P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
     P.quality = quality;
 #define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                               \
@@ -1055,9 +1088,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     const int nw = w / cell, nh = h / cell, ncells = nw * nh;
     if (ncells == 0) return OV2_OK;
     const int npx = cell * cell;
-    const int wpr = (w + 31) / 32;
-    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
-    OV2_REQUIRE(sel_lds <= 160 * 1024, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask");
+    { int slots_; OV2_REQUIRE(det_select_lds(w, h, cell, mode, ctx->det_fast_tie, &slots_) != 0, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask"); }
 
     // device scratch: [img w*h][maps][cur 8*ncur][out 8*2*ncells][SelectOut]
     const size_t o_img = 0;
@@ -1200,13 +1231,12 @@ static int detect_batch(ov2_ctx *ctx, int mode, const ov2_pyr *pyr, int cell, co
     OV2_REQUIRE(cur_cap >= 0 && (ncur_d == nullptr || cur_xy_d != nullptr), OV2_EINVAL, "bad current keypoints");
     OV2_HIP_CHECK(hipSetDevice(ctx->device));
     OV2_HIP_CHECK(det_raise_lds_limits());
-    const int nw = w / cell, nh = h / cell, ncells = nw * nh, npx = cell * cell, wpr = (w + 31) / 32;
+    const int nw = w / cell, nh = h / cell, ncells = nw * nh, npx = cell * cell;
     for (int i = 0; i < items; i++) out_n_h[i] = 0;
     if (ncells == 0) return OV2_OK;
     const int cap = mode == 0 ? ncells : 2 * ncells;
     OV2_REQUIRE(out_cap >= cap, OV2_EINVAL, "out_cap too small: (w/cell)*(h/cell) points per item for FAST, twice that for single scale");
-    const size_t sel_lds = (size_t)h * wpr * 4 + 64 * 4 + (size_t)ncells * 16 + (size_t)nh * 4 + (((size_t)(nh + 1) * (nw + 1) + 3) & ~(size_t)3) + (size_t)ncells * 8;
-    OV2_REQUIRE(sel_lds <= 160 * 1024, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask");
+    { int slots_; OV2_REQUIRE(det_select_lds(w, h, cell, mode, ctx->det_fast_tie, &slots_) != 0, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask"); }
     const int chunk = std::min(items, 256);
     const size_t map_bytes = (size_t)ncells * npx * (mode == 0 ? 1 : 4);
     const size_t o_map = 0, o_cand = (o_map + (size_t)chunk * map_bytes + 255) & ~(size_t)255;

@@ -171,7 +171,7 @@ static int stage_and_upload(ov2_btracker *t, int n, const uint8_t *const *img_h,
         if (t->up_n[which]) { OV2_HIP_CHECK(hipEventSynchronize(t->up_ev[which])); t->up_n[which] = 0; }
         for (int b = 0; b < n; b++) {
             uint8_t *dst = t->himg[which] + (size_t)b * t->img_bytes;
-            if ((size_t)stride == t->img_pitch) memcpy(dst, img_h[b], (size_t)stride * h);
+            if ((size_t)stride == t->img_pitch) memcpy(dst, img_h[b], (size_t)stride * (h - 1) + (size_t)w);   // the last row holds w valid bytes only
             else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * t->img_pitch, img_h[b] + (size_t)y * stride, (size_t)w);
         }
     }
@@ -439,13 +439,15 @@ int ov2_btracker_track_frame_begin(ov2_btracker *t, int n_active, const uint8_t 
     if (rc != OV2_OK) return rc;
     // preprocessImage: already under way on the prep stream (the context's stream waits for the pyramids' event), or in order here
     const int old_cur = t->cur;
+    // the bookkeeping (prepq / pre_count) is committed only when the whole step has been enqueued: a failure further down leaves
+    // the tracker where it was, and the same frames can be passed again
     auto preprocess = [&]() -> int {
-        if (prepared) { t->prepq.pop_front(); return ov2_pyr_wait_ready(ctx, t->pyr[t->cur]); }
+        if (prepared) return ov2_pyr_wait_ready(ctx, t->pyr[t->cur]);
         const int rcp = enqueue_preprocess(t, ctx, t->pyr[t->cur], which, n_active);
         if (rcp != OV2_OK) return rcp;
-        t->pre_count++;
         return ov2_pyr_mark_ready(ctx, t->pyr[t->cur]);
     };
+    auto commit = [&]() { if (prepared) t->prepq.pop_front(); else t->pre_count++; t->frames++; };
     t->cur = (int)(t->frames % BT_SETS);                                 // prev_pyr_.swap(cur_pyr_)  (:1169): frame k lives in set k % BT_SETS
     ov2_btracker::Pending &P = t->pend;
     P.n_active = n_active; P.use_prior = klt_use_prior; P.kps = kps_xy_h; P.has_prior = has_prior_h;
@@ -455,7 +457,7 @@ int ov2_btracker_track_frame_begin(ov2_btracker *t, int n_active, const uint8_t 
         // first frame (trackMono returns right after preprocessImage) or nothing to track anywhere
         rc = preprocess();
         if (rc != OV2_OK) { t->cur = old_cur; return rc; }
-        t->frames++;
+        commit();
         P.tracked = false; P.on = true;
         return OV2_OK;
     }
@@ -463,7 +465,7 @@ int ov2_btracker_track_frame_begin(ov2_btracker *t, int n_active, const uint8_t 
     rc = preprocess();
     if (rc == OV2_OK) rc = enqueue_klt(t, t->pyr[t->prev()], t->pyr[t->cur], n_active);
     if (rc != OV2_OK) { t->cur = old_cur; return rc; }
-    t->frames++;
+    commit();
     P.tracked = true; P.on = true;
     return OV2_OK;
 }

@@ -5,6 +5,7 @@
 // builds per keyframe.  Construct it where the reference constructs its FeatureExtractor / FeatureTracker, BEFORE the mapper
 // and estimator threads start (src/ov2slam.cpp:91-113): the tracker captures its hipGraphs at construction.
 #pragma once
+#include <atomic>
 #include <memory>
 #include "ov2_types.hpp"
 #include "feature_extractor.hpp"
@@ -49,16 +50,31 @@ struct SlamGpu {
     // One context per calling thread for the reference's STATIC entry points (MultiViewGeometry::ceresPnP runs on the SLAM thread
     // and on the loop closer's, src/visual_front_end.cpp:791, src/loop_closer.cpp:882) and for the threads that have no member
     // context above (LoopCloser::run, the final fullBA on the mapper thread uses `mapper`): created on first use, destroyed with the thread.
+    // Keyed by instance (uid: an address can be reused) and device; the deterministic option is (re)applied when it changes.
     Context &threadContext() const
     {
-        static thread_local std::unique_ptr<Context> tls;
-        if (!tls) tls.reset(new Context(device));
-        return *tls;
+        struct Tls { unsigned long uid = 0; int device = -1; int det = -1; std::unique_ptr<Context> ctx; };
+        static thread_local Tls tls;
+        if (!tls.ctx || tls.uid != uid || tls.device != device) {
+            tls.ctx.reset(new Context(device));
+            tls.uid = uid; tls.device = device; tls.det = -1;
+        }
+        const int det = deterministic_ba.load(std::memory_order_relaxed) ? 1 : 0;
+        if (tls.det != det) { ov2_ctx_set_option(tls.ctx->get(), OV2_OPT_BA_DETERMINISTIC, det); tls.det = det; }
+        return *tls.ctx;
     }
-    // OV2_OPT_BA_DETERMINISTIC on the contexts that run bundle adjustments (SlamParams::bhip_deterministic_ba_): the reference solves
-    // with num_threads = 1 and is reproducible from run to run; the library's default accumulates with fp64 atomics (1.7x faster)
-    void setDeterministicBA(bool on) { ov2_ctx_set_option(estimator.get(), OV2_OPT_BA_DETERMINISTIC, on ? 1 : 0); deterministic_ba = on; }
-    bool deterministic_ba = false;
+    // OV2_OPT_BA_DETERMINISTIC on every context that runs bundle adjustments (SlamParams::bhip_deterministic_ba_): localBA on
+    // `estimator`, the final fullBA on `mapper`, looseBA / structureOnlyBA / ceresPnP on the calling thread's context.  The reference
+    // solves with num_threads = 1 and is reproducible from run to run; the library's default accumulates with fp64 atomics (1.7x faster)
+    void setDeterministicBA(bool on)
+    {
+        ov2_ctx_set_option(estimator.get(), OV2_OPT_BA_DETERMINISTIC, on ? 1 : 0);
+        ov2_ctx_set_option(mapper.get(), OV2_OPT_BA_DETERMINISTIC, on ? 1 : 0);
+        deterministic_ba.store(on, std::memory_order_relaxed);
+    }
+    std::atomic<bool> deterministic_ba{false};
+    const unsigned long uid = nextUid();
+    static unsigned long nextUid() { static std::atomic<unsigned long> n{0}; return ++n; }
 };
 
 }  // namespace ov2

@@ -266,7 +266,7 @@ class Optimizer:
             out.update(chi2=chi2[:n_res], depthpos=dpos[:n_res])
         return out
 
-    def localBA_batch(self, probs, buse_robust_cost=True, want_chi2=True, stop=None):
+    def localBA_batch(self, probs, buse_robust_cost=True, want_chi2=True, stop=None, raise_on_error=True):
         """Optimizer::localBA's solve stage for a lock-step batch of sequences (BASELINE configs[4]): one ov2_local_ba_batch call,
         every kernel of the solver launched once for all problems.  `probs`: inverse-depth problems (make_ba_problem layout);
         `stop`: per-problem stop requests (the estimators' bstop_localba_, read after the first pass) or None.
@@ -294,12 +294,14 @@ class Optimizer:
                 R.chi2_last_eval = _dp(o["_chi2"]); R.depthpos_last_eval = _u8p(o["_dpos"])
             outs.append(o)
         nb = C.c_int(0)
-        L.check(lib.ov2_local_ba_batch(self.ctx.h, n, PA, OA, RA, C.byref(nb)))
+        rc_all = lib.ov2_local_ba_batch(self.ctx.h, n, PA, OA, RA, C.byref(nb))
+        if raise_on_error:
+            L.check(rc_all)         # otherwise: every problem was attempted, the dicts carry `status` (0 = that result is valid)
         res = []
         for i, o in enumerate(outs):
             R = RA[i]; n_res = o["_n_res"]
             d = dict(poses=o["poses"], invdepth=o["_lam"][:o["_n_lm"]], bad_obs=o["_bad"][:n_res].astype(bool), bad_after_pass1=o["_bad1"][:n_res].astype(bool),
-                     l2_done=bool(R.l2_done), pass2_error=int(R.pass2_error), iterations=(R.iterations[0], R.iterations[1]),
+                     l2_done=bool(R.l2_done), pass2_error=int(R.pass2_error), status=int(R.status), iterations=(R.iterations[0], R.iterations[1]),
                      num_successful_steps=(R.num_successful_steps[0], R.num_successful_steps[1]), termination=(R.termination[0], R.termination[1]),
                      initial_cost=(R.initial_cost[0], R.initial_cost[1]), final_cost=(R.final_cost[0], R.final_cost[1]),
                      solve_ms=(R.solve_ms[0], R.solve_ms[1]), n_bad=(R.n_bad_pass1, R.n_bad_total))

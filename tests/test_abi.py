@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libov2slam_hip.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
-    assert lib.ov2_version() == _lib.OV2_ABI_VERSION == 500
+    assert lib.ov2_version() == _lib.OV2_ABI_VERSION == 600
 
 
 def test_no_cpu_fallback_without_gpu():

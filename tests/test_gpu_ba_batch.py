@@ -104,3 +104,19 @@ def test_batch_falls_back_for_problems_it_does_not_cover(gpu_ctx):
     bad = dict(small); bad["res_lm"] = small["res_lm"].copy(); bad["res_lm"][0] = 10**6
     with pytest.raises(ov2slam_amd.Ov2Error):
         ov2slam_amd.Optimizer(gpu_ctx).localBA_batch([small, bad])
+
+
+def test_batch_reports_a_status_per_problem(gpu_ctx):
+    """a left-out problem that ov2_local_ba rejects (OV2_RES_PNP blocks: OV2_EUNSUPPORTED) must neither hide the valid
+    results of the others nor stop the left-out problems after it (include/ov2slam_hip.h ov2_local_ba_result::status)."""
+    from ov2slam_amd import _lib as L
+    small = synth.make_ba_problem(12, 400, 8, stereo=True, seed=3)
+    large = synth.make_ba_problem(120, 1500, 10, stereo=True, seed=5)
+    pnp = synth.make_pnp_problem(100, seed=2)
+    with pytest.raises(ov2slam_amd.Ov2Error):
+        ov2slam_amd.Optimizer(gpu_ctx).localBA_batch([small, pnp, large])
+    res, nb = ov2slam_amd.Optimizer(gpu_ctx).localBA_batch([small, pnp, large], raise_on_error=False)
+    assert nb == 1
+    assert [r["status"] for r in res] == [L.OV2_OK, L.OV2_EUNSUPPORTED, L.OV2_OK]
+    _same(res[0], ov2slam_amd.Optimizer(gpu_ctx).localBA(small))
+    _same(res[2], ov2slam_amd.Optimizer(gpu_ctx).localBA(large), tight=1e-6)

@@ -290,3 +290,32 @@ def test_batched_device_resident_detectors():
     r = subprocess.run([sys.executable, "-c", _BATCH_DETECT_SCRIPT, root], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BATCH_DETECT_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
+
+
+@pytest.mark.parametrize("tie", [L.OV2_FAST_TIE_SCAN_ORDER, L.OV2_FAST_TIE_LIBSTDCXX])
+def test_grid_fast_720p_sort_areas_share_the_lds(gpu_ctx, oracle, tie):
+    """on 1280x720 at cell 35 the exclusion mask and cell tables take ~133 KB of the 160 KB LDS; the sort areas of the
+    libstdc++ tie order are carved out of what is left (fewer than one per wavefront, taken under a lock) instead of a static 37 KB
+    that made the launch fail.  A low threshold on noise leaves many equal responses per cell, so the sort path runs."""
+    rng = np.random.default_rng(41)
+    base, _, _ = synth.frame_pair(1280, 720, seed=21)
+    noise = rng.integers(0, 256, (720, 1280), dtype=np.uint8)
+    prev = gpu_ctx.get_option(L.OV2_OPT_FAST_TIE)
+    gpu_ctx.set_option(L.OV2_OPT_FAST_TIE, tie)
+    try:
+        for img, th0 in ((base, 10), (noise, 5), (noise, 20)):
+            cur = synth.grid_keypoints(1280, 720, 35, rng)[::4]
+            for mode in (L.OV2_MASK_AS_EXECUTED, L.OV2_MASK_INTENDED):
+                fx = ov2slam_amd.FeatureExtractor(gpu_ctx, nfast_th=th0, mask_mode=mode)
+                g = fx.detectGridFAST(img, 35, cur, subpix=False)
+                with oracle.fast_tie_mode(tie):
+                    r, rth = oracle.detect_grid_fast(img, 35, cur, th0, mode, subpix=False)
+                assert g.shape == r.shape and np.array_equal(_bits(g), _bits(r)) and fx.nfast_th_ == rth
+                assert len(r) > 100
+    finally:
+        gpu_ctx.set_option(L.OV2_OPT_FAST_TIE, prev)
+    # an image whose mask alone exceeds the LDS is refused with OV2_EUNSUPPORTED, not a launch failure
+    big = rng.integers(0, 256, (1200, 1920), dtype=np.uint8)
+    with pytest.raises(ov2slam_amd.Ov2Error) as e:
+        ov2slam_amd.FeatureExtractor(gpu_ctx, nfast_th=10).detectGridFAST(big, 35, np.zeros((0, 2), np.float32), subpix=False)
+    assert e.value.code == L.OV2_EUNSUPPORTED
