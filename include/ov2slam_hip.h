@@ -113,6 +113,8 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
 #define OV2_OPT_FAST_TIE           12
 #define OV2_FAST_TIE_SCAN_ORDER    0
 #define OV2_FAST_TIE_LIBSTDCXX     1
+#define OV2_OPT_BA_TRACE           13   /* 1: ov2_ba_solve / ov2_ba_solve_resident / ov2_xyz_ba_solve / each pass of ov2_local_ba record the
+                                           iteration summaries of the solve (ov2_ba_get_trace); the batch entry point does not */
 int  ov2_ctx_set_option(ov2_ctx *ctx, int option, int value);
 int  ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value);
 
@@ -482,6 +484,18 @@ void ov2_ba_default_options(ov2_ba_options *o);
  * fullBA) a sparse-W / HBM-Cholesky path takes over by itself, same results, up to 1024 optimised keyframes (the dense reduced
  * system: 3 x 302 MB at the cap), with or without OV2_RES_PNP blocks; past that OV2_EUNSUPPORTED with a message, nothing enqueued. */
 int  ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
+
+/* Iteration trace of the LAST one-problem solve of this context (OV2_OPT_BA_TRACE = 1): one entry per iteration that Ceres'
+ * TrustRegionMinimizer pushes into Solver::Summary::iterations (Thirdparty/ceres-solver/internal/ceres/trust_region_minimizer.cc:313-337;
+ * include/ceres/iteration_callback.h:45-150) -- entry 0 is the starting point; an iteration that ends the solve inside the loop
+ * (parameter / function tolerance, :706-748) is not recorded, as in Ceres.  gradient_norm is NaN (the device forms the max norm only).
+ * *n = entries recorded by the solve (the library keeps the first 64), buf receives min(*n, 64, cap).  tests/test_gpu_ba.py compares it
+ * with the oracle's trace; tests/test_reference_trlm.py compares both with Ceres' own loop compiled in place.                       */
+typedef struct {
+    int iteration, step_is_valid, step_is_successful, reserved_;
+    double cost, cost_change, gradient_max_norm, gradient_norm, step_norm, relative_decrease, trust_region_radius;
+} ov2_ba_iter;
+int  ov2_ba_get_trace(ov2_ctx *ctx, ov2_ba_iter *buf, int cap, int *n);
 
 /* Same solve on a problem that is already resident in HBM (upload once, solve many times from the
  * same initial parameters); used by bench.py so that the timed region starts with inputs in HBM. */

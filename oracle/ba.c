@@ -674,6 +674,12 @@ static double vec_norm_diff(const double *a, const double *b, int n)
     return s;
 }
 
+/* per-iteration trace (tests only): what Ceres records in Solver::Summary::iterations (trust_region_minimizer.cc:313-337) */
+static __thread orc_ba_iter *g_trace = NULL;
+static __thread int g_trace_cap = 0;
+static __thread int *g_trace_n = NULL;
+void orc_ba_set_trace(orc_ba_iter *buf, int cap, int *n) { g_trace = buf; g_trace_cap = cap; g_trace_n = n; if (n) *n = 0; }
+
 int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result *res)
 {
     if (!p || !o || !res || p->n_kf <= 0 || p->n_lm < 0 || p->n_res < 0) return -1;
@@ -751,21 +757,25 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
     int step_successful = 1;             /* iteration 0 counts as successful */
     int term = ORC_TERM_NO_CONVERGENCE;
     int n_success = 0, n_steps = 0;
-    double gmax = 0;
+    double gmax = 0, gnorm = 0;
+    /* the iteration summary being filled (IterationZero, trust_region_minimizer.cc:195-231) */
+    orc_ba_iter cur; memset(&cur, 0, sizeof(cur));
     /* gradient max norm at x: |x - Plus(x, -g)|_inf */
     #define GRAD_MAX_NORM()                                                                         \
         do {                                                                                       \
-            gmax = 0;                                                                              \
+            gmax = 0; gnorm = 0;                                                                   \
             for (int k_ = 0; k_ < p->n_kf; k_++) {                                                \
                 if (w.pose_col[k_] < 0) continue;                                                  \
                 double d_[6], out_[7];                                                             \
                 for (int c_ = 0; c_ < 6; c_++) d_[c_] = -gf[w.pose_col[k_] + c_];                  \
                 orc_se3_left_plus(x_pose + 7 * k_, d_, out_);                                      \
-                for (int c_ = 0; c_ < 7; c_++) { double v_ = fabs(x_pose[7 * k_ + c_] - out_[c_]); if (v_ > gmax) gmax = v_; } \
+                for (int c_ = 0; c_ < 7; c_++) { double v_ = fabs(x_pose[7 * k_ + c_] - out_[c_]); if (v_ > gmax) gmax = v_; gnorm += v_ * v_; } \
             }                                                                                      \
-            for (int l_ = 0; l_ < p->n_lm; l_++) { if (w.lm_ptr[l_] == w.lm_ptr[l_ + 1]) continue; double v_ = fabs(gl[l_]); if (v_ > gmax) gmax = v_; } \
+            for (int l_ = 0; l_ < p->n_lm; l_++) { if (w.lm_ptr[l_] == w.lm_ptr[l_ + 1]) continue; double v_ = fabs(gl[l_]); if (v_ > gmax) gmax = v_; gnorm += v_ * v_; } \
+            gnorm = sqrt(gnorm);                                                                   \
         } while (0)
     GRAD_MAX_NORM();
+    cur.iteration = 0; cur.step_is_valid = 1; cur.step_is_successful = 1; cur.cost = x_cost; cur.gradient_max_norm = gmax; cur.gradient_norm = gnorm;
 
     for (;;) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
@@ -773,11 +783,14 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
             n_success++;
             if (x_cost < minimum_cost) minimum_cost = x_cost;
         }
+        cur.trust_region_radius = radius;
+        if (g_trace_n) { if (g_trace && *g_trace_n < g_trace_cap) g_trace[*g_trace_n] = cur; (*g_trace_n)++; }
         if (iteration >= o->max_iter) { term = ORC_TERM_NO_CONVERGENCE; break; }
         if (step_successful && gmax <= o->gradient_tolerance) { term = ORC_TERM_GRADIENT_TOL; break; }
         if (radius <= o->min_radius) { term = ORC_TERM_MIN_RADIUS; break; }
         iteration++;
         step_successful = 0;
+        { const double pg = cur.gradient_norm, pgm = cur.gradient_max_norm; memset(&cur, 0, sizeof(cur)); cur.iteration = iteration; cur.gradient_norm = pg; cur.gradient_max_norm = pgm; }
 
         /* ComputeTrustRegionStep (LevenbergMarquardtStrategy::ComputeStep) */
         if (!reuse_diagonal) ba_col_sqnorm(&w, diag_f, diag_l);
@@ -813,8 +826,10 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
             if (++num_invalid >= o->max_consecutive_invalid_steps) { term = ORC_TERM_INVALID_STEPS; break; }
             orc_lm_step_rejected(&radius, &decrease_factor);
             reuse_diagonal = 1;
+            cur.cost = x_cost;                         /* a step of length zero and no progress (:476-484) */
             continue;
         }
+        cur.step_is_valid = 1;
         num_invalid = 0;
         /* delta = step .* scale ; candidate = Plus(x, delta) */
         memcpy(c_pose, x_pose, sizeof(double) * (size_t)NP);
@@ -830,8 +845,10 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
         double step_sq = 0;
         for (int k = 0; k < p->n_kf; k++) if (w.pose_col[k] >= 0) step_sq += vec_norm_diff(x_pose + 7 * k, c_pose + 7 * k, 7);
         for (int l = 0; l < p->n_lm; l++) if (w.lm_ptr[l] != w.lm_ptr[l + 1]) step_sq += (x_lam[l] - c_lam[l]) * (x_lam[l] - c_lam[l]);
+        cur.step_norm = sqrt(step_sq);
         if (sqrt(step_sq) <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { term = ORC_TERM_PARAMETER_TOL; break; }
         /* FunctionToleranceReached */
+        cur.cost_change = x_cost - cand_cost;
         if (fabs(x_cost - cand_cost) <= o->function_tolerance * x_cost) { term = ORC_TERM_FUNCTION_TOL; break; }
         /* IsStepSuccessful */
         double rel;
@@ -840,6 +857,7 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
             const double r2 = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
             rel = r1 > r2 ? r1 : r2;
         }
+        cur.relative_decrease = rel;
         if (rel > o->min_relative_decrease) {
             /* HandleSuccessfulStep */
             memcpy(x_pose, c_pose, sizeof(double) * (size_t)NP);
@@ -852,6 +870,7 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
             if (o->jacobi_scaling) ba_scale_columns(&w);
             GRAD_MAX_NORM();
             step_successful = 1;
+            cur.step_is_successful = 1; cur.cost = x_cost; cur.gradient_max_norm = gmax; cur.gradient_norm = gnorm;
             orc_lm_step_accepted(rel, &radius, &decrease_factor, o->max_radius);
             reuse_diagonal = 0;
             /* step_evaluator_->StepAccepted(candidate_cost, model_cost_change) */
@@ -860,6 +879,7 @@ int orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result
             else { ev_nonmono++; if (ev_cur > ev_cand) { ev_cand = ev_cur; ev_acc_cand = 0; } }
             if (ev_nonmono == 0) { ev_ref = ev_cand; ev_acc_ref = ev_acc_cand; }
         } else {
+            cur.cost = cand_cost;                      /* :119-127: the rejected candidate's cost, the gradient norms of the last accepted point */
             orc_lm_step_rejected(&radius, &decrease_factor);
             reuse_diagonal = 1;
         }

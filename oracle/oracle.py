@@ -413,9 +413,19 @@ def ba_default_options(**kw):
     return o
 
 
-def ba_solve(prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None):
-    """prob: dict in the layout produced by ov2slam_amd.synth.make_ba_problem."""
-    opts = opts or ba_default_options()
+class BAIter(C.Structure):
+    """orc_ba_iter / ref_trlm_iter share the leading layout (ints, then doubles)"""
+    _fields_ = [("iteration", C.c_int), ("step_is_valid", C.c_int), ("step_is_successful", C.c_int), ("pad_", C.c_int),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double), ("gradient_norm", C.c_double),
+                ("step_norm", C.c_double), ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double)]
+
+
+TRACE_FIELDS = ("iteration", "step_is_valid", "step_is_successful", "cost", "cost_change", "gradient_max_norm", "gradient_norm",
+                "step_norm", "relative_decrease", "trust_region_radius")
+
+
+def pack_ba(prob, res_active=None, chi2_init=None, depthpos_init=None):
+    """-> (orc_ba_problem, orc_ba_result, output arrays, keep-alive dict) for a dict in the layout of ov2slam_amd.synth.make_ba_problem"""
     keep = {}
 
     def arr(name, dt):
@@ -445,11 +455,37 @@ def ba_solve(prob, opts=None, res_active=None, chi2_init=None, depthpos_init=Non
     R = _BAResult()
     R.poses_out = poses_out.ctypes.data; R.invdepth_out = lam_out.ctypes.data
     R.chi2_last_eval = chi2.ctypes.data; R.depthpos_last_eval = dpos.ctypes.data
-    rc = lib().orc_ba_solve(C.byref(P), C.byref(opts), C.byref(R))
+    return P, R, dict(poses=poses_out, invdepth=lam_out, chi2=chi2, depthpos=dpos), keep
+
+
+def unpack_ba(R, out):
+    return dict(out, iterations=R.iterations, num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost,
+                final_cost=R.final_cost, termination=R.termination)
+
+
+def trace_rows(buf, n):
+    return [{f: getattr(buf[i], f) for f in TRACE_FIELDS} for i in range(n)]
+
+
+def ba_solve(prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None, trace=False):
+    """prob: dict in the layout produced by ov2slam_amd.synth.make_ba_problem.  trace: also return the per-iteration records
+    (orc_ba_set_trace) under "trace"."""
+    opts = opts or ba_default_options()
+    P, R, out, keep = pack_ba(prob, res_active, chi2_init, depthpos_init)
+    L = lib()
+    if trace:
+        buf = (BAIter * 64)(); n = C.c_int(0)
+        L.orc_ba_set_trace(buf, 64, C.byref(n))
+    try:
+        rc = L.orc_ba_solve(C.byref(P), C.byref(opts), C.byref(R))
+    finally:
+        if trace:
+            L.orc_ba_set_trace(None, 0, None)
     assert rc == 0, rc
-    return dict(poses=poses_out, invdepth=lam_out, chi2=chi2, depthpos=dpos, iterations=R.iterations,
-                num_successful_steps=R.num_successful_steps, initial_cost=R.initial_cost, final_cost=R.final_cost,
-                termination=R.termination)
+    d = unpack_ba(R, out)
+    if trace:
+        d["trace"] = trace_rows(buf, min(n.value, 64))
+    return d
 
 
 def huber(a, s):

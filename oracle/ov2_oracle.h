@@ -251,6 +251,15 @@ typedef struct {
 
 void orc_ba_default_options(orc_ba_options *o);
 int  orc_ba_solve(const orc_ba_problem *p, const orc_ba_options *o, orc_ba_result *r);
+/* Per-iteration trace of the NEXT orc_ba_solve calls of the calling thread (tests only): one entry per iteration Ceres records in
+ * Solver::Summary::iterations (trust_region_minimizer.cc:313-337; entry 0 = the starting point; an iteration that ends the solve inside
+ * the loop -- parameter / function tolerance -- is not recorded, as in Ceres).  *n counts every entry, buf keeps the first cap.
+ * orc_ba_set_trace(NULL, 0, NULL) switches it off.  Checked against Ceres' own loop by tests/test_reference_trlm.py.               */
+typedef struct {
+    int iteration, step_is_valid, step_is_successful, pad_;
+    double cost, cost_change, gradient_max_norm, gradient_norm, step_norm, relative_decrease, trust_region_radius;
+} orc_ba_iter;
+void orc_ba_set_trace(orc_ba_iter *buf, int cap, int *n);
 
 /* building blocks exposed for the known-answer tests */
 void orc_huber(double a, double s, double rho[3]);                 /* loss_function.cc:48-62  */

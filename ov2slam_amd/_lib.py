@@ -22,6 +22,7 @@ OV2_SOBEL_DY_OPENCV_ROWFILTER, OV2_SOBEL_DY_EXACT_SUM = 0, 1
 OV2_OPT_LK_IMPL, OV2_OPT_TRACK_IMPL, OV2_OPT_CLAHE_STRIPS, OV2_OPT_BA_FORCE_LARGE, OV2_OPT_BA_LIN_DIRECT = 2, 3, 4, 5, 6
 OV2_OPT_BA_SCHUR_CHUNK, OV2_OPT_BA_XYZ_LIN_WAVES, OV2_OPT_BA_POSE_ONLY_FUSED, OV2_OPT_BA_DETERMINISTIC, OV2_OPT_DEBUG = 7, 8, 9, 10, 11
 OV2_OPT_FAST_TIE = 12
+OV2_OPT_BA_TRACE = 13
 OV2_FAST_TIE_SCAN_ORDER, OV2_FAST_TIE_LIBSTDCXX = 0, 1
 OV2_LK_IMPL_AUTO, OV2_LK_IMPL_ROW, OV2_LK_IMPL_LANE3 = 0, 1, 2
 OV2_TRACK_IMPL_WAVE, OV2_TRACK_IMPL_ROW = 0, 1
@@ -81,6 +82,13 @@ class LocalBAResult(C.Structure):
         ("iterations", C.c_int * 2), ("num_successful_steps", C.c_int * 2), ("termination", C.c_int * 2), ("initial_cost", C.c_double * 2),
         ("final_cost", C.c_double * 2), ("solve_ms", C.c_double * 2), ("status", C.c_int),
     ]
+
+
+class BAIter(C.Structure):
+    """ov2_ba_iter"""
+    _fields_ = [("iteration", C.c_int), ("step_is_valid", C.c_int), ("step_is_successful", C.c_int), ("reserved_", C.c_int),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double), ("gradient_norm", C.c_double),
+                ("step_norm", C.c_double), ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double)]
 
 
 class SBAProblem(C.Structure):
@@ -209,6 +217,7 @@ SIGNATURES = {
     "ov2_structure_ba": (_i, [_vp, C.POINTER(SBAProblem), C.POINTER(BAOptions), C.POINTER(SBAResult)]),
     "ov2_xyz_ba_solve": (_i, [_vp, C.POINTER(XYZBAProblem), C.POINTER(BAOptions), C.POINTER(XYZBAResult)]),
     "ov2_ba_solve": (_i, [_vp, C.POINTER(BAProblem), C.POINTER(BAOptions), C.POINTER(BAResult)]),
+    "ov2_ba_get_trace": (_i, [_vp, C.POINTER(BAIter), _i, C.POINTER(_i)]),
     "ov2_ba_create": (_i, [_vp, C.POINTER(BAProblem), _pp]),
     "ov2_ba_solve_resident": (_i, [_vp, _vp, C.POINTER(BAOptions), C.POINTER(BAResult)]),
     "ov2_ba_destroy": (None, [_vp]),

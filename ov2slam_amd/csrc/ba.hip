@@ -47,6 +47,8 @@
 #define BA_MAX_NFP 6144     // 1024 optimised keyframes: H, G, S are dense nfp x nfp doubles (302 MB each at the cap)
 
 #define BA_PART_MAX 2048
+#define BA_TRACE_CAP 64
+typedef ov2_ba_iter BAIterRec;   // the iteration summary Ceres pushes into Solver::Summary::iterations (OV2_OPT_BA_TRACE)
 struct BACtl {
     // accumulators
     double cost_acc;
@@ -63,6 +65,10 @@ struct BACtl {
     int reuse_diag;
     int iteration, n_steps, n_success, num_invalid, termination, done;
     int need_lin, fresh_lin, step_successful, step_valid, lin_fail, scaled;
+    // OV2_OPT_BA_TRACE: the summary of the iteration under way and where finished ones go (NULL: no trace)
+    BAIterRec cur;
+    BAIterRec *trace;
+    int n_trace;
 };
 
 struct BADev {                    // device pointers + sizes (passed by value to kernels)
@@ -198,12 +204,17 @@ __device__ __forceinline__ void d_ctl_iter_begin(BACtl &cl, const BAOpt &O, int 
         }
         ctl->fresh_lin = 0;
         ctl->reuse_diag = 0;
+        // IterationZero / HandleSuccessfulStep -> EvaluateGradientAndJacobian: cost and gradient norm of the new point
+        ctl->cur.cost = ctl->x_cost; ctl->cur.gradient_max_norm = gmax;
+        if (ctl->cur.iteration == 0) { ctl->cur.step_is_valid = 1; ctl->cur.step_is_successful = 1; }
     }
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (ctl->step_successful) {
         ctl->n_success++;
         if (ctl->x_cost < ctl->minimum_cost) ctl->minimum_cost = ctl->x_cost;
     }
+    ctl->cur.trust_region_radius = ctl->radius;
+    if (ctl->trace) { if (ctl->n_trace < BA_TRACE_CAP) ctl->trace[ctl->n_trace] = ctl->cur; ctl->n_trace++; }
     if (ctl->iteration >= O.max_iter) { ctl->termination = OV2_TERM_NO_CONVERGENCE; ctl->done = 1; }
     else if (ctl->step_successful && ctl->gmax <= O.gtol) { ctl->termination = OV2_TERM_GRADIENT_TOL; ctl->done = 1; }
     else if (ctl->radius <= O.min_radius) { ctl->termination = OV2_TERM_MIN_RADIUS; ctl->done = 1; }
@@ -214,6 +225,9 @@ __device__ __forceinline__ void d_ctl_iter_begin(BACtl &cl, const BAOpt &O, int 
         ctl->lin_fail = 0;
         ctl->n_steps++;
         ctl->acc1 = 0; ctl->acc2 = 0; ctl->acc3 = 0; ctl->acc_sn = 0; ctl->acc_xn = 0; ctl->bad_step = 0;
+        // the next summary: iteration number, the gradient norm of the last accepted point (trust_region_minimizer.cc:87-93, :124-126)
+        ctl->cur.iteration = ctl->iteration; ctl->cur.step_is_valid = 0; ctl->cur.step_is_successful = 0;
+        ctl->cur.cost = 0; ctl->cur.cost_change = 0; ctl->cur.step_norm = 0; ctl->cur.relative_decrease = 0;
     }
 }
 
@@ -233,9 +247,11 @@ __device__ __forceinline__ int d_ctl_candidate(BACtl &cl, const BAOpt &O, int ok
         if (++ctl->num_invalid >= O.max_invalid) { ctl->termination = OV2_TERM_INVALID_STEPS; ctl->done = 1; }
         else { ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1; }
         ctl->step_valid = 0;
+        ctl->cur.cost = ctl->x_cost;                       // "a step of length zero and no progress" (:476-484)
     } else {
         ctl->num_invalid = 0;
         ctl->step_valid = 1;
+        ctl->cur.step_is_valid = 1;
     }
     return valid;
 }
@@ -248,14 +264,17 @@ __device__ __forceinline__ int d_ctl_decide(BACtl &cl, const BAOpt &O, double SN
     const double cand = ctl->cost_acc;
     ctl->cost_acc = 0;
     ctl->cand_cost = cand;
+    ctl->cur.step_norm = sqrt(SN); ctl->cur.cost_change = ctl->x_cost - cand;
     if (sqrt(SN) <= O.ptol * (ctl->x_norm + O.ptol)) { ctl->termination = OV2_TERM_PARAMETER_TOL; ctl->done = 1; }
     else if (fabs(ctl->x_cost - cand) <= O.ftol * ctl->x_cost) { ctl->termination = OV2_TERM_FUNCTION_TOL; ctl->done = 1; }
     else {
         const double mcc = ctl->model_cost_change;
         const double r1 = (ctl->ev_cur - cand) / mcc, r2 = (ctl->ev_ref - cand) / (ctl->ev_acc_ref + mcc);
         const double rel = fmax(r1, r2);
+        ctl->cur.relative_decrease = rel;
         if (rel > O.min_rel_decrease) {
             accept = 1;
+            ctl->cur.step_is_successful = 1;               // (cost and gradient norm: the next k_ba_iter_begin, from the fresh linearisation)
             ctl->x_norm = sqrt(XN);
             ctl->step_successful = 1;
             ctl->need_lin = 1;
@@ -270,6 +289,7 @@ __device__ __forceinline__ int d_ctl_decide(BACtl &cl, const BAOpt &O, double SN
             if (ctl->ev_nonmono == 0) { ctl->ev_ref = ctl->ev_cand; ctl->ev_acc_ref = ctl->ev_acc_cand; }
         } else {
             ctl->radius = ctl->radius / ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diag = 1;
+            ctl->cur.cost = cand;                          // the rejected candidate's cost (:119-127)
         }
     }
     return accept;
@@ -3132,6 +3152,13 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     h_ctl.radius = o->initial_radius; h_ctl.decrease_factor = 2.0; h_ctl.x_norm = -1.0;
     h_ctl.need_lin = 1; h_ctl.step_successful = 1;
     h_ctl.termination = OV2_TERM_NO_CONVERGENCE;
+    h_ctl.cur.gradient_norm = NAN;                          // (the device forms the max norm only)
+    ctx->ba_trace_n = 0;
+    if (ctx->ba_trace) {
+        if (!ctx->ba_trace_d) OV2_HIP_CHECK(hipMalloc(&ctx->ba_trace_d, sizeof(BAIterRec) * BA_TRACE_CAP));
+        if (!ctx->ba_trace_h) { ctx->ba_trace_h = malloc(sizeof(BAIterRec) * BA_TRACE_CAP); OV2_REQUIRE(ctx->ba_trace_h, OV2_ENOMEM, "trace buffer"); }
+        h_ctl.trace = (BAIterRec *)ctx->ba_trace_d;
+    }
     // one optimised pose, pose-only residual blocks, no landmarks (ceresPnP): the whole loop in one kernel (OV2_OPT_BA_POSE_ONLY_FUSED
     // = 0 keeps the multi-kernel path for A/B runs)
     const bool fused_po = fused_po_path;
@@ -3304,6 +3331,11 @@ static int ba_run(ov2_ctx *ctx, ov2_ba_dev *dev, const ov2_ba_options *o, ov2_ba
     if (r->chi2_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->chi2_last_eval, D.chi2, 8 * (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
     if (r->depthpos_last_eval && dev->n_res > 0) OV2_HIP_CHECK(hipMemcpyAsync(r->depthpos_last_eval, D.dpos, (size_t)dev->n_res, hipMemcpyDeviceToHost, s));
     OV2_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_ctl.trace) {
+        ctx->ba_trace_n = h_ctl.n_trace;
+        const int nrec = std::min(h_ctl.n_trace, BA_TRACE_CAP);
+        if (nrec > 0) OV2_HIP_CHECK(hipMemcpy(ctx->ba_trace_h, ctx->ba_trace_d, sizeof(BAIterRec) * (size_t)nrec, hipMemcpyDeviceToHost));
+    }
     float ms = 0;
     OV2_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     r->iterations = h_ctl.n_steps; r->num_successful_steps = h_ctl.n_success;
@@ -3709,6 +3741,15 @@ void ov2_ba_default_options(ov2_ba_options *o)
     o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32; o->min_relative_decrease = 1e-3; o->jacobi_scaling = 1;
     o->max_consecutive_invalid_steps = 5;
     o->max_solver_time_s = 0.0;
+}
+
+int ov2_ba_get_trace(ov2_ctx *ctx, ov2_ba_iter *buf, int cap, int *n)
+{
+    OV2_REQUIRE(ctx && n && cap >= 0 && (cap == 0 || buf), OV2_EINVAL, "NULL argument");
+    *n = ctx->ba_trace_n;
+    const int k = std::min(std::min(ctx->ba_trace_n, BA_TRACE_CAP), cap);
+    if (k > 0) memcpy(buf, ctx->ba_trace_h, sizeof(ov2_ba_iter) * (size_t)k);
+    return OV2_OK;
 }
 
 int ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r)

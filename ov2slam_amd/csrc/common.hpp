@@ -56,6 +56,8 @@ struct ov2_ctx {
     int ba_xyz_lin_waves = 0;                  // OV2_OPT_BA_XYZ_LIN_WAVES (0 = auto, 1, 2)
     int ba_pose_only_fused = 1;                // OV2_OPT_BA_POSE_ONLY_FUSED
     int ba_deterministic = 0;                  // OV2_OPT_BA_DETERMINISTIC
+    int ba_trace = 0;                          // OV2_OPT_BA_TRACE: the one-problem solves record their iteration summaries (ov2_ba_get_trace)
+    void *ba_trace_d = nullptr, *ba_trace_h = nullptr; int ba_trace_n = 0;
     int det_fast_tie = 1;                      // OV2_OPT_FAST_TIE: OV2_FAST_TIE_LIBSTDCXX (the reference as built with g++)
     void *ba_det_pool = nullptr; size_t ba_det_bytes = 0;   // OV2_OPT_BA_DETERMINISTIC: per-work-group copies of H / F^T b / G (grow-only)
     // ov2_local_ba_batch: persistent host threads that prepare the problems of a batch (created with the first batch; ba.hip owns the type)

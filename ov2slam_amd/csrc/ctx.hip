@@ -162,6 +162,8 @@ void ov2_ctx_destroy(ov2_ctx *ctx)
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->stat_slots) (void)hipFree(ctx->stat_slots);
     if (ctx->ba_det_pool) (void)hipFree(ctx->ba_det_pool);
+    if (ctx->ba_trace_d) (void)hipFree(ctx->ba_trace_d);
+    free(ctx->ba_trace_h);
     if (ctx->ba_host_pool && ctx->ba_host_pool_free) ctx->ba_host_pool_free(ctx->ba_host_pool);
     for (int i = 0; i < 2; i++) if (ctx->ba_ev[i]) (void)hipEventDestroy(ctx->ba_ev[i]);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
@@ -205,6 +207,7 @@ int ov2_ctx_set_option(ov2_ctx *ctx, int option, int value)
         ctx->ba_xyz_lin_waves = value; return OV2_OK;
     case OV2_OPT_BA_POSE_ONLY_FUSED: ctx->ba_pose_only_fused = value != 0; return OV2_OK;
     case OV2_OPT_BA_DETERMINISTIC:   ctx->ba_deterministic = value != 0; return OV2_OK;
+    case OV2_OPT_BA_TRACE:           ctx->ba_trace = value != 0; return OV2_OK;
     case OV2_OPT_DEBUG:              ctx->debug = value != 0; return OV2_OK;
     case OV2_OPT_FAST_TIE:
         OV2_REQUIRE(value == OV2_FAST_TIE_SCAN_ORDER || value == OV2_FAST_TIE_LIBSTDCXX, OV2_EINVAL, "OV2_OPT_FAST_TIE takes 0 or 1");
@@ -229,6 +232,7 @@ int ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value)
     case OV2_OPT_BA_XYZ_LIN_WAVES:   *value = ctx->ba_xyz_lin_waves; return OV2_OK;
     case OV2_OPT_BA_POSE_ONLY_FUSED: *value = ctx->ba_pose_only_fused; return OV2_OK;
     case OV2_OPT_BA_DETERMINISTIC:   *value = ctx->ba_deterministic; return OV2_OK;
+    case OV2_OPT_BA_TRACE:           *value = ctx->ba_trace; return OV2_OK;
     case OV2_OPT_DEBUG:              *value = ctx->debug; return OV2_OK;
     case OV2_OPT_FAST_TIE:           *value = ctx->det_fast_tie; return OV2_OK;
     default:

@@ -63,8 +63,28 @@ def default_options(lib, **kw):
     return o
 
 
-def solve(ctx, prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None):
-    """One ceres::Solve (ov2_ba_solve).  Returns a dict like oracle.ba_solve."""
+TRACE_FIELDS = ("iteration", "step_is_valid", "step_is_successful", "cost", "cost_change", "gradient_max_norm", "gradient_norm",
+                "step_norm", "relative_decrease", "trust_region_radius")
+
+
+def last_trace(ctx):
+    """ov2_ba_get_trace: the iteration summaries of the context's last one-problem solve (OV2_OPT_BA_TRACE must have been on)"""
+    buf = (L.BAIter * 64)(); n = C.c_int(0)
+    L.check(ctx.lib.ov2_ba_get_trace(ctx.h, buf, 64, C.byref(n)))
+    return [{f: getattr(buf[i], f) for f in TRACE_FIELDS} for i in range(min(n.value, 64))]
+
+
+def solve(ctx, prob, opts=None, res_active=None, chi2_init=None, depthpos_init=None, trace=False):
+    """One ceres::Solve (ov2_ba_solve).  Returns a dict like oracle.ba_solve (trace: with the iteration summaries under "trace")."""
+    if trace:
+        prev = ctx.get_option(L.OV2_OPT_BA_TRACE)
+        ctx.set_option(L.OV2_OPT_BA_TRACE, 1)
+        try:
+            d = solve(ctx, prob, opts, res_active, chi2_init, depthpos_init)
+            d["trace"] = last_trace(ctx)
+        finally:
+            ctx.set_option(L.OV2_OPT_BA_TRACE, prev)
+        return d
     lib = ctx.lib
     opts = opts or default_options(lib)
     P, keep = pack_problem(prob, res_active)
