@@ -93,6 +93,16 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
  *                           the winner among ties is the standard library's choice.  OV2_FAST_TIE_LIBSTDCXX (default): libstdc++'s
  *                           introsort restated -- the reference as built with g++, cell for cell (tests/test_reference_factors.py runs
  *                           the reference's own source); OV2_FAST_TIE_SCAN_ORDER: the first in scan order (what a stable sort gives)
+ * OV2_OPT_LK_ACC            accumulator type of calcOpticalFlowPyrLK's sums (normal matrix, mismatch vector).  OpenCV's LKTrackerInvoker
+ *                           is written against `acctype`: int64 on ARM without NEON, FLOAT everywhere else (lkpyramid.cpp).
+ *                           OV2_LK_ACC_INT64 (default): exact integer sums -- independent of summation order, the form every kernel
+ *                           implements and the oracle's canonical mode.  OV2_LK_ACC_FLOAT_UI4: float accumulators in the order an x86
+ *                           OpenCV 4.x build (128-bit universal intrinsics, no FMA) adds them -- what the reference executes at
+ *                           src/feature_tracker.cpp:66-69 / :113-116 on a desktop; restated from the public source (oracle:
+ *                           ORC_LK_ACC_FLOAT_UI4), bit-exact against that restatement, never checked against an OpenCV binary.
+ *                           Applies to ov2_fb_klt* / ov2_lk_track (row-per-lane kernel, any window), ov2_tracker_* / ov2_btracker_* /
+ *                           ov2_stereo_match* (both kernels); a tracker captures its graphs at creation: set the option before.
+ *                           Measured on EuRoC-like frames: no status flips, positions within 1.5e-4 px of the INT64 mode.
  * OV2_OPT_DEBUG             1: timing laps of ov2_local_ba / detection on stderr (initial value: environment OV2_DEBUG at
  *                           ov2_ctx_create, the only environment variable the library ever reads)                          */
 #define OV2_OPT_LK_IMPL            2
@@ -113,6 +123,9 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
 #define OV2_OPT_FAST_TIE           12
 #define OV2_FAST_TIE_SCAN_ORDER    0
 #define OV2_FAST_TIE_LIBSTDCXX     1
+#define OV2_OPT_LK_ACC             14
+#define OV2_LK_ACC_INT64           0
+#define OV2_LK_ACC_FLOAT_UI4       1
 #define OV2_OPT_BA_TRACE           13   /* 1: ov2_ba_solve / ov2_ba_solve_resident / ov2_xyz_ba_solve / each pass of ov2_local_ba record the
                                            iteration summaries of the solve (ov2_ba_get_trace); the batch entry point does not */
 int  ov2_ctx_set_option(ov2_ctx *ctx, int option, int value);

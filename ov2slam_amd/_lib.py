@@ -23,6 +23,8 @@ OV2_OPT_LK_IMPL, OV2_OPT_TRACK_IMPL, OV2_OPT_CLAHE_STRIPS, OV2_OPT_BA_FORCE_LARG
 OV2_OPT_BA_SCHUR_CHUNK, OV2_OPT_BA_XYZ_LIN_WAVES, OV2_OPT_BA_POSE_ONLY_FUSED, OV2_OPT_BA_DETERMINISTIC, OV2_OPT_DEBUG = 7, 8, 9, 10, 11
 OV2_OPT_FAST_TIE = 12
 OV2_OPT_BA_TRACE = 13
+OV2_OPT_LK_ACC = 14
+OV2_LK_ACC_INT64, OV2_LK_ACC_FLOAT_UI4 = 0, 1
 OV2_FAST_TIE_SCAN_ORDER, OV2_FAST_TIE_LIBSTDCXX = 0, 1
 OV2_LK_IMPL_AUTO, OV2_LK_IMPL_ROW, OV2_LK_IMPL_LANE3 = 0, 1, 2
 OV2_TRACK_IMPL_WAVE, OV2_TRACK_IMPL_ROW = 0, 1

@@ -49,6 +49,7 @@ struct ov2_ctx {
     // ov2_ctx_create: the entry points are called from several threads of a host that may setenv() concurrently.
     int lk_impl = OV2_LK_IMPL_AUTO;            // OV2_OPT_LK_IMPL
     int track_impl = OV2_TRACK_IMPL_WAVE;      // OV2_OPT_TRACK_IMPL
+    int lk_acc = OV2_LK_ACC_INT64;             // OV2_OPT_LK_ACC
     int clahe_strips = -1;                     // OV2_OPT_CLAHE_STRIPS: -1 auto, 0 never, 1 whenever the geometry allows
     int ba_force_large = 0;                    // OV2_OPT_BA_FORCE_LARGE
     int ba_lin_direct = 0;                     // OV2_OPT_BA_LIN_DIRECT
@@ -135,4 +136,5 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
                          const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
                          const float *sad_x = nullptr, float sad_up = 0.f,       // sad_x: stereo mode (lk.hip: k_track_klt)
                          int track_impl = OV2_TRACK_IMPL_WAVE,
-                         int items = 1);   // items > 1 (trackb.hip): batch items [0, items) of both pyramids, n_max point slots and one n_dev entry per item
+                         int items = 1,    // items > 1 (trackb.hip): batch items [0, items) of both pyramids, n_max point slots and one n_dev entry per item
+                         int lk_acc = OV2_LK_ACC_INT64);   // OV2_OPT_LK_ACC   // items > 1 (trackb.hip): batch items [0, items) of both pyramids, n_max point slots and one n_dev entry per item

@@ -203,7 +203,13 @@ struct LKPointState {
 
 // One pyramid level for the keypoint owned by this 16-lane row.
 // I = template level (image + derivative), J = search level (image only).
-template <int WIN>
+// FACC (OV2_OPT_LK_ACC = OV2_LK_ACC_FLOAT_UI4): the sums of the normal matrix and of the mismatch vector in FLOAT accumulators, in the
+// order an x86 OpenCV 4.x build executes them (`typedef float acctype` + 128-bit universal intrinsics, no FMA; public lkpyramid.cpp,
+// restated by oracle/frontend.c ORC_LK_ACC_FLOAT_UI4): the first 4 * (WIN / 4) columns of a window row feed four lane accumulators per
+// sum (lane = x & 3) row after row, the remaining columns a scalar accumulator; for the mismatch vector the first 8 * (WIN / 8)
+// columns feed eight lanes with (float)(d[p] g[p] + d[p + 4] g[p + 4]) (v_dotprod adds the pair exactly), the rest a scalar.  Float
+// addition does not associate: every lane of the keypoint's 16-lane row replays the chain in order, pulling row y's terms from lane y.
+template <int WIN, bool FACC>
 __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, const PyrLevelDesc &LI,
                                          const uint8_t *__restrict__ itemJ, const PyrLevelDesc &LJ,
                                          const LKParams &prm, int level, int top_level, bool use_initial,
@@ -300,11 +306,35 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
             if (row_active) { s11 += m24(ixval, ixval); s12 += m24(ixval, iyval); s22 += m24(iyval, iyval); }
         }
         // per-lane partials: WIN * 4080^2 < 2^31 for WIN <= 15
-        A11d = row_allreduce_exact(s11);
-        A12d = row_allreduce_exact(s12);
-        A22d = row_allreduce_exact(s22);
+        if (!FACC) {
+            A11d = row_allreduce_exact(s11);
+            A12d = row_allreduce_exact(s12);
+            A22d = row_allreduce_exact(s22);
+        } else { A11d = A12d = A22d = 0; }
     }
-    const float A11 = (float)A11d * FLT_SCALE, A12 = (float)A12d * FLT_SCALE, A22 = (float)A22d * FLT_SCALE;
+    float A11, A12, A22;
+    if (!FACC) { A11 = (float)A11d * FLT_SCALE; A12 = (float)A12d * FLT_SCALE; A22 = (float)A22d * FLT_SCALE; }
+    else {
+        constexpr int SIMD_A = 4 * (WIN / 4);
+        float q11[4] = {0.f, 0.f, 0.f, 0.f}, q12[4] = {0.f, 0.f, 0.f, 0.f}, q22[4] = {0.f, 0.f, 0.f, 0.f}, f11 = 0.f, f12 = 0.f, f22 = 0.f;
+#pragma unroll 1
+        for (int y = 0; y < WIN; y++) {
+#pragma unroll
+            for (int x = 0; x < WIN; x++) {
+                const int ixv = __shfl(dIx[x], y, 16), iyv = __shfl(dIy[x], y, 16);
+                if (x < SIMD_A) {                                   // qA = qA + fx * fx  (v_muladd without FMA in baseline builds)
+                    const float fx = (float)ixv, fy = (float)iyv;
+                    q22[x & 3] = q22[x & 3] + fy * fy; q12[x & 3] = q12[x & 3] + fx * fy; q11[x & 3] = q11[x & 3] + fx * fx;
+                } else {                                            // iA11 += (itemtype)(ixval * ixval)
+                    f11 += (float)(ixv * ixv); f12 += (float)(ixv * iyv); f22 += (float)(iyv * iyv);
+                }
+            }
+        }
+        if (SIMD_A > 0) {                                           // v_reduce_sum: (a0 + a2) + (a1 + a3)
+            f11 += (q11[0] + q11[2]) + (q11[1] + q11[3]); f12 += (q12[0] + q12[2]) + (q12[1] + q12[3]); f22 += (q22[0] + q22[2]) + (q22[1] + q22[3]);
+        }
+        A11 = f11 * FLT_SCALE; A12 = f12 * FLT_SCALE; A22 = f22 * FLT_SCALE;
+    }
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
     if (prm.flags & OV2_LK_GET_MIN_EIGENVALS) st.err = minEig;
@@ -341,16 +371,49 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
         }
         const RowBytes<WIN> r1 = row_from_next_lane<WIN>(r0);
         int sb1 = 0, sb2 = 0;
+        int dv[WIN];
 #pragma unroll
         for (int x = 0; x < WIN; x++) {
             const int diff = descale(m24(r0.px(x), iw00) + m24(r0.px(x + 1), iw01) + m24(r1.px(x), iw10) + m24(r1.px(x + 1), iw11), 14 - 5) - Iw[x];
+            dv[x] = diff;
             sb1 += m24(diff, dIx[x]);
             sb2 += m24(diff, dIy[x]);
         }
-        if (!row_active) { sb1 = 0; sb2 = 0; }
-        // |diff * dI| <= 8160*4080 -> per-lane partial < WIN * 3.33e7 < 2^31 for WIN <= 15
-        const float b1 = (float)row_allreduce_exact(sb1) * FLT_SCALE;
-        const float b2 = (float)row_allreduce_exact(sb2) * FLT_SCALE;
+        float b1, b2;
+        if (!FACC) {
+            if (!row_active) { sb1 = 0; sb2 = 0; }
+            // |diff * dI| <= 8160*4080 -> per-lane partial < WIN * 3.33e7 < 2^31 for WIN <= 15
+            b1 = (float)row_allreduce_exact(sb1) * FLT_SCALE;
+            b2 = (float)row_allreduce_exact(sb2) * FLT_SCALE;
+        } else {
+            // this lane's (= window row's) terms, then the chains over the rows in order
+            constexpr int SIMD_B = 8 * (WIN / 8), NT = WIN - SIMD_B;
+            float tq[8], tx[NT > 0 ? NT : 1], ty[NT > 0 ? NT : 1];
+            if (SIMD_B > 0) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {                       // lanes (x, y, x, y) of qb0 / qb1: pixels m and m + 4
+                    tq[2 * m] = (float)(dv[m] * dIx[m] + dv[m + 4] * dIx[m + 4]);
+                    tq[2 * m + 1] = (float)(dv[m] * dIy[m] + dv[m + 4] * dIy[m + 4]);
+                }
+            }
+#pragma unroll
+            for (int x = SIMD_B; x < WIN; x++) { tx[x - SIMD_B] = (float)(dv[x] * dIx[x]); ty[x - SIMD_B] = (float)(dv[x] * dIy[x]); }
+            float qb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, fb1 = 0.f, fb2 = 0.f;
+#pragma unroll 1
+            for (int y = 0; y < WIN; y++) {
+                if (SIMD_B > 0) {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) qb[m] = qb[m] + __shfl(tq[m], y, 16);
+                }
+#pragma unroll
+                for (int x = 0; x < NT; x++) { fb1 += __shfl(tx[x], y, 16); fb2 += __shfl(ty[x], y, 16); }
+            }
+            if (SIMD_B > 0) {                                       // qb0 = lanes 0..3, qb1 = lanes 4..7: s = qb0 + qb1; ib1 += s0 + s2, ib2 += s1 + s3
+                const float s0 = qb[0] + qb[4], s1 = qb[1] + qb[5], s2 = qb[2] + qb[6], s3 = qb[3] + qb[7];
+                fb1 += s0 + s2; fb2 += s1 + s3;
+            }
+            b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
+        }
         const float dx = (A12 * b2 - A22 * b1) * D;
         const float dy = (A12 * b1 - A11 * b2) * D;
         nextx += dx; nexty += dy;
@@ -367,7 +430,7 @@ __device__ __forceinline__ void lk_level(const uint8_t *__restrict__ itemI, cons
 // fbKltTracking for the keypoint owned by this 16-lane row: forward levels max_level..0 (feature_tracker.cpp:66-69),
 // the status / err / border filter (:79-101), the backward track at level 0 from the original keypoint (:113-116) and
 // the forward-backward distance test (:119-134).  Returns the status; (fx, fy) = vpriorkps[i] after the forward call.
-template <int WIN>
+template <int WIN, bool FACC>
 __device__ __forceinline__ int fb_track_point(const uint8_t *__restrict__ itemP, const uint8_t *__restrict__ itemC,
                                               const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int max_level,
                                               float2 kp, float2 pr, int r, float &fx, float &fy, LKPointState &st)
@@ -375,7 +438,7 @@ __device__ __forceinline__ int fb_track_point(const uint8_t *__restrict__ itemP,
     st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0; st.visits = 0;
     // forward: prev -> cur, levels max_level..0   (feature_tracker.cpp:66-69)
     for (int level = max_level; level >= 0; level--)
-        lk_level<WIN>(itemP, P.lv[level], itemC, C.lv[level], prm, level, max_level,
+        lk_level<WIN, FACC>(itemP, P.lv[level], itemC, C.lv[level], prm, level, max_level,
                       (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, r, st);
     fx = st.nx; fy = st.ny;
     int ok = st.status;
@@ -388,7 +451,7 @@ __device__ __forceinline__ int fb_track_point(const uint8_t *__restrict__ itemP,
             // backward: cur -> prev at level 0, initial guess = original keypoint (:113-116)
             LKPointState sb;
             sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0; sb.visits = 0;
-            lk_level<WIN>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
+            lk_level<WIN, FACC>(itemC, C.lv[0], itemP, P.lv[0], prm, 0, 0, true, fx, fy, r, sb);
             st.iters += sb.iters; st.visits += sb.visits;
             if (!sb.status) ok = 0;
             else {
@@ -401,7 +464,7 @@ __device__ __forceinline__ int fb_track_point(const uint8_t *__restrict__ itemP,
     return ok;
 }
 
-template <int WIN>
+template <int WIN, bool FACC>
 __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams prm,
                                                 const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                 uint8_t *__restrict__ status, float *__restrict__ err_out,
@@ -423,7 +486,7 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
         const uint8_t *itemC = C.base + (long long)b * C.item_stride;
         LKPointState st;
         float fx, fy;
-        const int ok = fb_track_point<WIN>(itemP, itemC, P, C, prm, prm.max_level, kps[gi], priors[gi], r, fx, fy, st);
+        const int ok = fb_track_point<WIN, FACC>(itemP, itemC, P, C, prm, prm.max_level, kps[gi], priors[gi], r, fx, fy, st);
         if (r == 0) {
             priors[gi] = make_float2(fx, fy);
             status[gi] = (uint8_t)ok;
@@ -453,7 +516,7 @@ __global__ __launch_bounds__(256) void k_fb_klt(PyrDesc P, PyrDesc C, LKParams p
 // cross-keypoint decision of the reference (:225-230: fewer than a third of the prior tracks good -> retry from the
 // keypoints themselves) is taken by the host from the bit-1 count (ov2_tracker_klt, track.hip).
 // One wavefront per work-group (1 or 4 keypoints, see the launcher): a single frame has ~300 keypoints on 1024 SIMDs.
-template <int WIN>
+template <int WIN, bool FACC>
 __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams prm, int lvl_prior, int lvl_full,
                                                   const int *__restrict__ n_dev, const float2 *__restrict__ kps,
                                                   const float2 *__restrict__ priors, const uint8_t *__restrict__ flags,
@@ -487,7 +550,7 @@ __global__ __launch_bounds__(64) void k_track_klt(PyrDesc P, PyrDesc C, LKParams
     float fx = 0.f, fy = 0.f;
     for (int attempt = 0; attempt < 2; attempt++) {
         LKPointState st;
-        ok = fb_track_point<WIN>(pb, cb, P, C, prm, max_level, kp, pr, r, fx, fy, st);
+        ok = fb_track_point<WIN, FACC>(pb, cb, P, C, prm, max_level, kp, pr, r, fx, fy, st);
         iters += st.iters;
         if (ok || !has_prior || attempt == 1) break;
         pr = make_float2(fx, fy);                                         // visual_front_end.cpp:213-217, map_manager.cpp:533-538
@@ -538,9 +601,10 @@ static bool lk_use_row_kernel(const ov2_ctx *ctx, long long points)
 template <int WIN>
 static void launch_fb_klt(hipStream_t s, dim3 grid, const PyrDesc &P, const PyrDesc &C, const LKParams &prm,
                           const float2 *kps, float2 *priors, uint8_t *status, float *err, int *iters,
-                          const int *n_per_item, unsigned long long *stats)
+                          const int *n_per_item, unsigned long long *stats, int lk_acc)
 {
-    hipLaunchKernelGGL(k_fb_klt<WIN>, grid, dim3(256), 0, s, P, C, prm, kps, priors, status, err, iters, n_per_item, stats);
+    if (lk_acc == OV2_LK_ACC_FLOAT_UI4) hipLaunchKernelGGL((k_fb_klt<WIN, true>), grid, dim3(256), 0, s, P, C, prm, kps, priors, status, err, iters, n_per_item, stats);
+    else hipLaunchKernelGGL((k_fb_klt<WIN, false>), grid, dim3(256), 0, s, P, C, prm, kps, priors, status, err, iters, n_per_item, stats);
 }
 
 static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LKParams prm,
@@ -560,7 +624,8 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
         if (int rc = ctx->reserve_stat_slots()) return rc;
         slots = ctx->stat_slots;
     }
-    if (prm.win == 9 && !lk_use_row_kernel(ctx, (long long)prm.n_max * P.batch)) {
+    // (the float-accumulator mode lives in the row kernel: the 3-lanes-per-keypoint kernel sums exact integers only)
+    if (prm.win == 9 && ctx->lk_acc == OV2_LK_ACC_INT64 && !lk_use_row_kernel(ctx, (long long)prm.n_max * P.batch)) {
         ov2_launch_fb_klt3(ctx->stream, P, C, prm.max_level, prm.max_iter, prm.eps2, prm.min_eig_th, prm.flags, prm.err_th,
                            prm.fb_dist, prm.do_fb, prm.n_max, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots);
         if (slots) hipLaunchKernelGGL(k_lk_stats_fold, dim3(1), dim3(LK_STAT_SLOTS), 0, ctx->stream, slots, stats_d);
@@ -568,11 +633,11 @@ static int lk_dispatch(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, LK
         return OV2_OK;
     }
     switch (prm.win) {
-    case 5:  launch_fb_klt<5>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
-    case 7:  launch_fb_klt<7>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
-    case 9:  launch_fb_klt<9>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
-    case 11: launch_fb_klt<11>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
-    case 13: launch_fb_klt<13>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots); break;
+    case 5:  launch_fb_klt<5>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots, ctx->lk_acc); break;
+    case 7:  launch_fb_klt<7>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots, ctx->lk_acc); break;
+    case 9:  launch_fb_klt<9>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots, ctx->lk_acc); break;
+    case 11: launch_fb_klt<11>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots, ctx->lk_acc); break;
+    case 13: launch_fb_klt<13>(ctx->stream, grid, P, C, prm, kps_d, priors_d, status_d, err_d, iters_d, n_per_item_d, slots, ctx->lk_acc); break;
     default:
         ov2_set_error("LK window %d has no kernel instance (supported: 5,7,9,11,13; the reference ships 9)", prm.win);
         return OV2_EUNSUPPORTED;
@@ -605,7 +670,7 @@ static LKParams make_params(const ov2_pyr *pyr, int win, int max_level, int max_
 int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur, int win, int lvl_prior, int lvl_full,
                          int max_iter, float eps, float err_th, float fb_dist, int n_max, const int *n_dev,
                          const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                         const float *sad_x, float sad_up, int track_impl, int items)
+                         const float *sad_x, float sad_up, int track_impl, int items, int lk_acc)
 {
     const PyrDesc &P = prev->d, &C = cur->d;
     OV2_REQUIRE(P.n_levels == C.n_levels && items >= 1 && P.batch >= items && C.batch >= items && P.win == C.win && win == P.win, OV2_EINVAL,
@@ -618,11 +683,13 @@ int ov2_launch_track_klt(hipStream_t s, const ov2_pyr *prev, const ov2_pyr *cur,
     // level's search block requested while the current level iterates.  Other windows (and OV2_OPT_TRACK_IMPL = ROW): the
     // row-per-lane kernel, four keypoints per wavefront
     if (win == 9 && track_impl == OV2_TRACK_IMPL_WAVE)
-        return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up, items);
+        return ov2_launch_track_klt_w(s, P, C, prm, lp, lf, n_max, n_dev, kps, priors, flags, out_xy, status, iters, sad_x, sad_up, items, lk_acc);
     constexpr int kpw = 4;
     dim3 grid((n_max + kpw - 1) / kpw, items), block(16 * kpw);
-#define OV2_TK(W) hipLaunchKernelGGL(k_track_klt<W>, grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
-                                     (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up)
+#define OV2_TK(W) do { if (lk_acc == OV2_LK_ACC_FLOAT_UI4) hipLaunchKernelGGL((k_track_klt<W, true>), grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
+                                     (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up); \
+                       else hipLaunchKernelGGL((k_track_klt<W, false>), grid, block, 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, \
+                                     (const float2 *)priors, flags, (float2 *)out_xy, status, iters, sad_x, sad_up); } while (0)
     switch (win) {
     case 5:  OV2_TK(5); break;
     case 7:  OV2_TK(7); break;

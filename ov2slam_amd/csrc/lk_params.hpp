@@ -15,4 +15,4 @@ struct LKParams {
 // lkw.hip: a whole wavefront per keypoint (window 9): the single-frame kernel of record
 int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int lp, int lf, int n_max, const int *n_dev,
                            const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                           const float *sad_x, float sad_up, int items = 1);
+                           const float *sad_x, float sad_up, int items = 1, int lk_acc = OV2_LK_ACC_INT64);

@@ -29,6 +29,8 @@
 #define W_JROWS 16                    // search neighbourhood rows, 20 bytes each
 #define W_R 3                         // margin of the search block around the start position
 #define W_GRID 10                     // derivative grid (WIN + 1)^2
+#define W_LDS_INT (W_IROWS * 4 + W_JROWS * 5 + W_GRID * W_GRID + 4)   // dwords of the integer-sum kernel
+#define W_FACC_PIX 84                 // float-accumulator mode: packed template gradients + the trip's differences, one dword per window pixel each
 
 template <int CTRL>
 __device__ __forceinline__ int w_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
@@ -77,8 +79,15 @@ __device__ __forceinline__ void w_store_J(uint32_t *Jb, int lane, const uint32_t
     if (lane + 64 < W_JROWS * 5) Jb[lane + 64] = v[1];
 }
 
+__device__ __forceinline__ float w_lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 // One pyramid level for the keypoint owned by this wavefront.  pre_* : a search block requested earlier (by the previous level's
 // visit) for origin (pre_x0, pre_y0), pre_ok != 0 when the registers pre_v hold it.
+// FACC (OV2_OPT_LK_ACC = OV2_LK_ACC_FLOAT_UI4, see lk.hip): float accumulators in the order of an x86 OpenCV 4.x build.  Window 9: the
+// normal matrix has 4 lane accumulators per sum over columns 0..7 (lane = x & 3) and a scalar one for column 8; the mismatch vector 8 lane
+// accumulators fed with (float)(d[p] g[p] + d[p + 4] g[p + 4]) and two scalars for column 8.  Each accumulator is ONE lane of the wavefront
+// here (15 resp. 10 lanes busy), walking the rows in order over values the other lanes left in LDS; the folds go through v_readlane.
+template <bool FACC>
 __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const PyrLevelDesc &LI, const uint8_t *__restrict__ itemJ,
                                         const PyrLevelDesc &LJ, const PyrLevelDesc *LJnext, const LKParams &prm, int level, int top_level,
                                         bool use_initial, float px0, float py0, int lane, uint32_t *lds, WState &st,
@@ -180,7 +189,42 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
         }
     }
     // per-lane partials <= 2 * 4080^2, 16-lane rows < 2^31
-    const float A11 = (float)w_sum_exact(s11) * FLT_SCALE, A12 = (float)w_sum_exact(s12) * FLT_SCALE, A22 = (float)w_sum_exact(s22) * FLT_SCALE;
+    float A11, A12, A22;
+    uint32_t *Gp = lds + W_LDS_INT;                                // [FACC] packed (dIx, dIy) per window pixel
+    int *Dv = (int *)(Gp + W_FACC_PIX);                            // [FACC] the trip's I - J differences per window pixel
+    if (!FACC) { A11 = (float)w_sum_exact(s11) * FLT_SCALE; A12 = (float)w_sum_exact(s12) * FLT_SCALE; A22 = (float)w_sum_exact(s22) * FLT_SCALE; }
+    else {
+#pragma unroll
+        for (int k = 0; k < 2; k++) { const int p = lane + 64 * k; if (p < W_NPIX) Gp[p] = ((uint32_t)Ix[k] & 0xFFFFu) | ((uint32_t)Iy[k] << 16); }
+        w_sync();
+        // lanes 0..11: lane accumulator (lane & 3) of A11 / A12 / A22 (lane >> 2) over columns x = lane & 3 and x + 4; lanes 12..14: column 8
+        const bool tail = lane >= 12;
+        const int typ = tail ? lane - 12 : lane >> 2, kk = lane & 3;
+        float acc = 0.f;
+        if (lane < 15) {
+#pragma unroll
+            for (int y = 0; y < WIN; y++) {
+                if (!tail) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {                 // qA = qA + fx * fx, no FMA
+                        const uint32_t g = Gp[y * WIN + kk + 4 * hh];
+                        const float fx = (float)(int)(short)(g & 0xFFFFu), fy = (float)((int)g >> 16);
+                        const float v = typ == 0 ? fx * fx : (typ == 1 ? fx * fy : fy * fy);
+                        acc = acc + v;
+                    }
+                } else {                                            // iA11 += (itemtype)(ixval * ixval)
+                    const uint32_t g = Gp[y * WIN + 8];
+                    const int ixv = (int)(short)(g & 0xFFFFu), iyv = (int)g >> 16;
+                    acc += (float)(typ == 0 ? ixv * ixv : (typ == 1 ? ixv * iyv : iyv * iyv));
+                }
+            }
+        }
+        // v_reduce_sum: (a0 + a2) + (a1 + a3), added to the scalar accumulator
+        const float f11 = w_lane_f(acc, 12) + ((w_lane_f(acc, 0) + w_lane_f(acc, 2)) + (w_lane_f(acc, 1) + w_lane_f(acc, 3)));
+        const float f12 = w_lane_f(acc, 13) + ((w_lane_f(acc, 4) + w_lane_f(acc, 6)) + (w_lane_f(acc, 5) + w_lane_f(acc, 7)));
+        const float f22 = w_lane_f(acc, 14) + ((w_lane_f(acc, 8) + w_lane_f(acc, 10)) + (w_lane_f(acc, 9) + w_lane_f(acc, 11)));
+        A11 = f11 * FLT_SCALE; A12 = f12 * FLT_SCALE; A22 = f22 * FLT_SCALE;
+    }
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
     if (prm.flags & OV2_LK_GET_MIN_EIGENVALS) st.err = minEig;
@@ -223,6 +267,7 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
         }
         const int jsh = jx0 & 3;
         int sb1 = 0, sb2 = 0;
+        if (FACC) w_sync();                                         // the previous trip's reads of Dv are done
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int p = lane + 64 * k;
@@ -230,13 +275,41 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
                 const int y = p / WIN, x = p - y * WIN;
                 const uint8_t *ps = Jbb + (oy + y) * 20 + jsh + ox + x;
                 const int diff = w_descale(w_m24(ps[0], iw00) + w_m24(ps[1], iw01) + w_m24(ps[20], iw10) + w_m24(ps[21], iw11), 14 - 5) - Iw[k];
+                if (FACC) Dv[p] = diff;
                 sb1 += w_m24(diff, Ix[k]);
                 sb2 += w_m24(diff, Iy[k]);
             }
         }
-        // |diff * dI| <= 8160 * 4080: per-lane partial < 6.7e7, 16-lane rows < 2^31
-        const float b1 = (float)w_sum_exact(sb1) * FLT_SCALE;
-        const float b2 = (float)w_sum_exact(sb2) * FLT_SCALE;
+        float b1, b2;
+        if (!FACC) {
+            // |diff * dI| <= 8160 * 4080: per-lane partial < 6.7e7, 16-lane rows < 2^31
+            b1 = (float)w_sum_exact(sb1) * FLT_SCALE;
+            b2 = (float)w_sum_exact(sb2) * FLT_SCALE;
+        } else {
+            w_sync();
+            // lanes 0..7 = (qb0[0..3], qb1[0..3]): pixel pair (lane >> 1, + 4), component lane & 1 (x, y); lanes 8, 9: column 8
+            const int comp = lane & 1, pair = (lane >> 1) & 3;
+            float acc = 0.f;
+            if (lane < 10) {
+#pragma unroll
+                for (int y = 0; y < WIN; y++) {
+                    if (lane < 8) {
+                        const int p0 = y * WIN + pair;
+                        const uint32_t g0 = Gp[p0], g4 = Gp[p0 + 4];
+                        const int c0 = comp ? (int)g0 >> 16 : (int)(short)(g0 & 0xFFFFu), c4 = comp ? (int)g4 >> 16 : (int)(short)(g4 & 0xFFFFu);
+                        acc = acc + (float)(Dv[p0] * c0 + Dv[p0 + 4] * c4);      // v_dotprod: the pair's products added exactly, then v_cvt_f32
+                    } else {
+                        const uint32_t g = Gp[y * WIN + 8];
+                        const int c = comp ? (int)g >> 16 : (int)(short)(g & 0xFFFFu);
+                        acc += (float)(Dv[y * WIN + 8] * c);                    // ib += (itemtype)(diff * dI)
+                    }
+                }
+            }
+            const float s0 = w_lane_f(acc, 0) + w_lane_f(acc, 4), s1 = w_lane_f(acc, 1) + w_lane_f(acc, 5);
+            const float s2 = w_lane_f(acc, 2) + w_lane_f(acc, 6), s3 = w_lane_f(acc, 3) + w_lane_f(acc, 7);
+            const float fb1 = w_lane_f(acc, 8) + (s0 + s2), fb2 = w_lane_f(acc, 9) + (s1 + s3);
+            b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
+        }
         const float dx = (A12 * b2 - A22 * b1) * D;
         const float dy = (A12 * b1 - A11 * b2) * D;
         nextx += dx; nexty += dy;
@@ -252,6 +325,7 @@ __device__ __forceinline__ void w_level(const uint8_t *__restrict__ itemI, const
 
 // fbKltTracking for this wavefront's keypoint (feature_tracker.cpp:35-137): forward levels, filter, backward level 0, fb test
 // pb / cb: the batch item of the previous / current pyramid this keypoint belongs to
+template <bool FACC>
 __device__ __forceinline__ int w_fb_track_point(const uint8_t *__restrict__ pb, const uint8_t *__restrict__ cb, const PyrDesc &P, const PyrDesc &C,
                                                 const LKParams &prm, int max_level, float2 kp, float2 pr,
                                                 int lane, uint32_t *lds, float &fx, float &fy, int &iters)
@@ -260,7 +334,7 @@ __device__ __forceinline__ int w_fb_track_point(const uint8_t *__restrict__ pb, 
     st.nx = pr.x; st.ny = pr.y; st.status = 1; st.err = 0.f; st.iters = 0;
     bool pre_ok = false; int pre_x0 = 0, pre_y0 = 0; uint32_t pre_v[2] = {0u, 0u};
     for (int level = max_level; level >= 0; level--)
-        w_level(pb, P.lv[level], cb, C.lv[level], level > 0 ? &C.lv[level - 1] : nullptr, prm, level, max_level,
+        w_level<FACC>(pb, P.lv[level], cb, C.lv[level], level > 0 ? &C.lv[level - 1] : nullptr, prm, level, max_level,
                 (prm.flags & OV2_LK_USE_INITIAL_FLOW) != 0, kp.x, kp.y, lane, lds, st, pre_ok, pre_x0, pre_y0, pre_v);
     fx = st.nx; fy = st.ny;
     iters = st.iters;
@@ -273,7 +347,7 @@ __device__ __forceinline__ int w_fb_track_point(const uint8_t *__restrict__ pb, 
             WState sb;                                                                     // backward: cur -> prev at level 0 from the keypoint (:113-116)
             sb.nx = kp.x; sb.ny = kp.y; sb.status = 1; sb.err = 0.f; sb.iters = 0;
             pre_ok = false;
-            w_level(cb, C.lv[0], pb, P.lv[0], nullptr, prm, 0, 0, true, fx, fy, lane, lds, sb, pre_ok, pre_x0, pre_y0, pre_v);
+            w_level<FACC>(cb, C.lv[0], pb, P.lv[0], nullptr, prm, 0, 0, true, fx, fy, lane, lds, sb, pre_ok, pre_x0, pre_y0, pre_v);
             iters += sb.iters;
             if (!sb.status) ok = 0;
             else {
@@ -287,13 +361,14 @@ __device__ __forceinline__ int w_fb_track_point(const uint8_t *__restrict__ pb, 
 }
 
 // VisualFrontEnd::kltTracking / the LK part of MapManager::stereoMatching in ONE launch: same contract as k_track_klt (lk.hip)
+template <bool FACC>
 __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKParams prm, int lvl_prior, int lvl_full,
                                                     const int *__restrict__ n_dev, const float2 *__restrict__ kps,
                                                     const float2 *__restrict__ priors, const uint8_t *__restrict__ flags,
                                                     float2 *__restrict__ out_xy, uint8_t *__restrict__ status,
                                                     int *__restrict__ iters_out, const float *__restrict__ sad_x, float sad_up)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[W_IROWS * 4 + W_JROWS * 5 + W_GRID * W_GRID + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[W_LDS_INT + (FACC ? 2 * W_FACC_PIX : 0)];
     // blockIdx.y: batch item (lock-step tracker, trackb.hip: n_max point slots and one count per item; 0 for one camera)
     const int item = blockIdx.y;
     const int n = n_dev ? n_dev[item] : prm.n_max;
@@ -315,7 +390,7 @@ __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKPara
     float fx = 0.f, fy = 0.f;
     for (int attempt = 0; attempt < 2; attempt++) {
         int it = 0;
-        ok = w_fb_track_point(pb, cb, P, C, prm, max_level, kp, pr, lane, lds, fx, fy, it);
+        ok = w_fb_track_point<FACC>(pb, cb, P, C, prm, max_level, kp, pr, lane, lds, fx, fy, it);
         iters += it;
         if (ok || !has_prior || attempt == 1) break;
         pr = make_float2(fx, fy);                                   // visual_front_end.cpp:213-217, map_manager.cpp:533-538
@@ -330,10 +405,14 @@ __global__ __launch_bounds__(64) void k_track_klt_w(PyrDesc P, PyrDesc C, LKPara
 
 int ov2_launch_track_klt_w(hipStream_t s, const PyrDesc &P, const PyrDesc &C, const LKParams &prm, int lp, int lf, int n_max, const int *n_dev,
                            const float *kps, const float *priors, const uint8_t *flags, float *out_xy, uint8_t *status, int *iters,
-                           const float *sad_x, float sad_up, int items)
+                           const float *sad_x, float sad_up, int items, int lk_acc)
 {
-    hipLaunchKernelGGL(k_track_klt_w, dim3(n_max, items), dim3(64), 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, (const float2 *)priors, flags,
-                       (float2 *)out_xy, status, iters, sad_x, sad_up);
+    if (lk_acc == OV2_LK_ACC_FLOAT_UI4)
+        hipLaunchKernelGGL(k_track_klt_w<true>, dim3(n_max, items), dim3(64), 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, (const float2 *)priors, flags,
+                           (float2 *)out_xy, status, iters, sad_x, sad_up);
+    else
+        hipLaunchKernelGGL(k_track_klt_w<false>, dim3(n_max, items), dim3(64), 0, s, P, C, prm, lp, lf, n_dev, (const float2 *)kps, (const float2 *)priors, flags,
+                           (float2 *)out_xy, status, iters, sad_x, sad_up);
     OV2_HIP_CHECK(hipGetLastError());
     return OV2_OK;
 }

@@ -285,7 +285,7 @@ int ov2_stereo_match(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, in
         sad_d = (const float *)(ds + o_s);
     }
     rc = ov2_launch_track_klt(ctx->stream, left, right, nklt_win_size, 1, lvl, max_iter, eps, nklt_err, fmax_fbklt_dist, n, nullptr,
-                              (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr, sad_d, up, ctx->track_impl);
+                              (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr, sad_d, up, ctx->track_impl, 1, ctx->lk_acc);
     if (rc != OV2_OK) return rc;
     hipLaunchKernelGGL(k_epipolar_check, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_u),
                        (float2 *)(ds + o_o), n, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok, (const int *)nullptr);
@@ -358,7 +358,7 @@ int ov2_stereo_match_batch(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *rig
     else OV2_HIP_CHECK(hipMemsetAsync(ds + o_s, 0xBF, 4 * N, ctx->stream));                       // "nothing found" (see ov2_stereo_match)
     rc = ov2_launch_track_klt(ctx->stream, left, right, nklt_win_size, 1, lvl, max_iter, eps, nklt_err, fmax_fbklt_dist, n_max, n_d,
                               (const float *)(ds + o_k), (const float *)(ds + o_p), ds + o_f, (float *)(ds + o_o), ds + o_st, nullptr,
-                              (const float *)(ds + o_s), up, ctx->track_impl, n_items);
+                              (const float *)(ds + o_s), up, ctx->track_impl, n_items, ctx->lk_acc);
     if (rc != OV2_OK) return rc;
     hipLaunchKernelGGL(k_epipolar_check, dim3((n_max + 255) / 256, n_items), dim3(256), 0, ctx->stream, E, c, (const float2 *)(ds + o_u),
                        (float2 *)(ds + o_o), n_max, (float2 *)(ds + o_r), (float *)(ds + o_e), ds + o_ok, n_d);

@@ -130,7 +130,7 @@ static int enqueue_klt(ov2_btracker *t, const ov2_pyr *prev, const ov2_pyr *cur,
     uint8_t *k = t->kblk;
     int rc = ov2_launch_track_klt(ctx->stream, prev, cur, c.win, c.prior_pyr_lvl, c.nklt_pyr_lvl, c.max_iter, c.eps, c.err_th, c.fb_dist,
                                   c.n_max, (const int *)(k + t->o_n), (const float *)(k + t->o_kps), (const float *)(k + t->o_pri),
-                                  k + t->o_flg, (float *)(k + t->o_out), k + t->o_st, nullptr, nullptr, 0.f, ctx->track_impl, n);
+                                  k + t->o_flg, (float *)(k + t->o_out), k + t->o_st, nullptr, nullptr, 0.f, ctx->track_impl, n, ctx->lk_acc);
     if (rc != OV2_OK) return rc;
     if (t->has_calib) {
         rc = ov2_launch_compute_keypoints(ctx->stream, t->calib, (const float *)(k + t->o_out), c.n_max, (const int *)(k + t->o_n),

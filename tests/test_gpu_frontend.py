@@ -280,3 +280,50 @@ def test_two_contexts_concurrently(oracle, euroc_pair):
     ts = [threading.Thread(target=worker, args=(lvl,)) for lvl in (1, 3, 1, 3)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("win", [9, 5, 7, 11, 13])
+def test_fbklt_float_accumulators_as_executed_on_x86(gpu_ctx, oracle, euroc_pair, win):
+    """OV2_OPT_LK_ACC = OV2_LK_ACC_FLOAT_UI4: the sums of calcOpticalFlowPyrLK in FLOAT accumulators, in the order of an x86 OpenCV 4.x
+    build (acctype float, 128-bit universal intrinsics: 4 lane accumulators + a scalar for the normal matrix, v_dotprod pairs in 8 lanes
+    + a scalar for the mismatch vector) -- what src/feature_tracker.cpp:66-69 executes on a desktop.  Bit for bit (positions, status,
+    Gauss-Newton trips, min-eigenvalue err) against the oracle in ORC_LK_ACC_FLOAT_UI4, every window instance of the row kernel
+    (SIMD widths 0 / 4 / 8 / 12 columns), forward-backward and single calls, edge points, drifting tracks; and it is a different
+    computation from the default: some positions must differ from the INT64 mode."""
+    from ov2slam_amd import _lib as L
+    d = euroc_pair
+    # contrast x 5: with the soft texture of the synthetic pair every sum stays below 2^24 and float accumulation is exact -- the two
+    # modes would return the same bits and the test would prove nothing
+    gain = lambda im: np.clip((im.astype(np.float32) - 128.0) * 5.0 + 128.0, 0, 255).astype(np.uint8)
+    Gp, Rp = _pyr_pair(gpu_ctx, oracle, gain(d["prev"]), win, 3)
+    Gc, Rc = _pyr_pair(gpu_ctx, oracle, gain(d["cur"]), win, 3)
+    trk = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01)
+    rng = np.random.default_rng(100 + win)
+    kps = np.concatenate([d["kps"], np.array([[0.4, 0.2], [751.5, 479.5], [-3.0, 100.0], [300.0, -2.5]], np.float32)])
+    pri = np.concatenate([d["pri"], kps[-4:] + rng.normal(0, 2, (4, 2)).astype(np.float32)])
+    int_out, int_st = trk.fbKltTracking(Gp, Gc, win, 3, 30., 0.5, kps, pri)
+    n_diff = 0
+    with gpu_ctx.options(lk_acc=L.OV2_LK_ACC_FLOAT_UI4), oracle.lk_acc_mode(oracle.LK_ACC_FLOAT_UI4):
+        for lvl in (3, 0):
+            gout, gst, gstats = trk.fbKltTracking(Gp, Gc, win, lvl, 30., 0.5, kps, pri, return_stats=True)
+            rout, rst, rstats = oracle.fb_klt(Rp, Rc, win, lvl, 30., 0.5, kps, pri)
+            assert np.array_equal(gst, rst)
+            _assert_same_float_bits(gout, rout, "float accumulators, win %d lvl %d" % (win, lvl))
+            assert gstats[0] == rstats[0]
+            if lvl == 3:
+                both = gst.astype(bool) & int_st.astype(bool)
+                n_diff = int((np.ascontiguousarray(gout[both]).view(np.uint32) != np.ascontiguousarray(int_out[both]).view(np.uint32)).any(axis=1).sum())
+                assert np.abs(gout[both] - int_out[both]).max() < 5e-3          # the two modes stay within a few 1e-4 px of each other
+        gp, gs, ge, gi = trk.calcOpticalFlowPyrLK(Gp, Gc, d["kps"], d["pri"], win, 3)
+        rp, rs, re_, ri = oracle.lk_track(Rp, Rc, d["kps"], d["pri"], win, 3)
+        assert np.array_equal(gs, rs) and np.array_equal(gi, ri)
+        _assert_same_float_bits(gp, rp, "next points")
+        _assert_same_float_bits(ge, re_, "min-eigenvalue err")
+        far = (d["gt"] + 12.0).astype(np.float32)                              # re-fetched search blocks
+        gout, gst = trk.fbKltTracking(Gp, Gc, win, 3, 30., 0.5, d["kps"], far)
+        rout, rst, _ = oracle.fb_klt(Rp, Rc, win, 3, 30., 0.5, d["kps"], far)
+        assert np.array_equal(gst, rst)
+        _assert_same_float_bits(gout, rout, "far priors win %d" % win)
+    if win >= 9:       # (small windows: fewer terms, the sums stay exact more often)
+        assert n_diff > 0, "the float mode returned the INT64 mode's bits everywhere: it did not run"
+    assert gpu_ctx.get_option(L.OV2_OPT_LK_ACC) == L.OV2_LK_ACC_INT64

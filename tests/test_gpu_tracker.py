@@ -67,9 +67,11 @@ def test_track_frame_matches_oracle(gpu_ctx, oracle, wh, use_clahe, use_graph, i
         _track_frame_case(gpu_ctx, oracle, wh, use_clahe, use_graph)
 
 
-def _track_frame_case(gpu_ctx, oracle, wh, use_clahe, use_graph):
+def _track_frame_case(gpu_ctx, oracle, wh, use_clahe, use_graph, gain=1.0):
     w, h = wh
     views, flow = _sequence(w, h, 5, seed=31)
+    if gain != 1.0:
+        views = [np.clip((v.astype(np.float32) - 128.0) * gain + 128.0, 0, 255).astype(np.uint8) for v in views]
     rng = np.random.default_rng(5)
     trk = ov2slam_amd.VisualFrontEndTracker(gpu_ctx, w, h, use_clahe=use_clahe, fclahe_val=CLIP, nbmaxkps=512, use_graph=use_graph)
     out, st, p3p = trk.trackFrame(views[0], np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
@@ -226,3 +228,24 @@ def test_tracker_computes_keypoints_in_the_same_enqueue(gpu_ctx, oracle, use_gra
         with pytest.raises(ov2slam_amd.Ov2Error):
             trk.lastKeypoints(1)
         trk.close()
+
+
+@pytest.mark.parametrize("impl", ["wave", "row"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_track_frame_float_accumulators(gpu_ctx, oracle, use_graph, impl):
+    """The per-frame tracker with OV2_OPT_LK_ACC = OV2_LK_ACC_FLOAT_UI4 (set before the tracker captures its graphs): both kernels of the
+    fused kltTracking launch against the oracle in ORC_LK_ACC_FLOAT_UI4, bit for bit -- the as-executed arithmetic of an x86 OpenCV."""
+    from ov2slam_amd import _lib as L
+    with gpu_ctx.options(track_impl=L.OV2_TRACK_IMPL_ROW if impl == "row" else L.OV2_TRACK_IMPL_WAVE, lk_acc=L.OV2_LK_ACC_FLOAT_UI4), \
+            oracle.lk_acc_mode(oracle.LK_ACC_FLOAT_UI4):
+        _track_frame_case(gpu_ctx, oracle, (752, 480), True, use_graph)              # (CLAHE stretches the contrast by itself)
+        _track_frame_case(gpu_ctx, oracle, (376, 240), False, use_graph, gain=5.0)
+    # the inputs do separate the two modes: the oracle's float and integer accumulators disagree on some of these tracks
+    w, h = 376, 240
+    views, flow = _sequence(w, h, 2, seed=31)
+    views = [np.clip((v.astype(np.float32) - 128.0) * 5.0 + 128.0, 0, 255).astype(np.uint8) for v in views]
+    kps, pri, hp = _points(w, h, flow, 0, np.random.default_rng(5), 1.0)
+    a = _oracle_frame(oracle, views[0], views[1], kps, pri, hp, False, w, h)[0]
+    with oracle.lk_acc_mode(oracle.LK_ACC_FLOAT_UI4):
+        b = _oracle_frame(oracle, views[0], views[1], kps, pri, hp, False, w, h)[0]
+    assert not np.array_equal(_bits(a), _bits(b))
