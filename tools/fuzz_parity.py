@@ -75,6 +75,11 @@ for case in range(N):
         ro, rs, rst = O.fb_klt(Rp, Rc, 9, nl, 30., 0.5, kps, pri)
         check("fbklt_" + impl, np.array_equal(gs, rs) and np.array_equal(go.view(np.uint32), ro.view(np.uint32)) and gst[0] == rst[0], dict(info, n=n, nl=nl))
     ctx.set_option(L.OV2_OPT_LK_IMPL, L.OV2_LK_IMPL_AUTO)
+    # ---- LK with the float accumulators of an x86 OpenCV build (OV2_OPT_LK_ACC), against the oracle in the same mode ----
+    with ctx.options(lk_acc=L.OV2_LK_ACC_FLOAT_UI4), O.lk_acc_mode(O.LK_ACC_FLOAT_UI4):
+        go, gs, gst = trk.fbKltTracking(Gp, Gc, 9, nl, 30., 0.5, kps, pri, return_stats=True)
+        ro, rs, rst = O.fb_klt(Rp, Rc, 9, nl, 30., 0.5, kps, pri)
+        check("fbklt_float_acc", np.array_equal(gs, rs) and np.array_equal(go.view(np.uint32), ro.view(np.uint32)) and gst[0] == rst[0], dict(info, n=n, nl=nl))
     # ---- stereo SAD scan on a random level ----
     sl = int(rng.integers(0, Gp.levels))
     lw, lh = Gp.level_size(sl)
@@ -122,34 +127,39 @@ for case in range(N):
         check("singlescale_d", np.array_equal(ga.view(np.uint32), gb.view(np.uint32)) and fa.dmaxquality_ == fb.dmaxquality_, dict(info, cell=cell))
     # ---- single-sequence tracker: preprocessImage + kltTracking (visual_front_end.cpp:1143-1177, :132-275) ----
     if w >= 150 and h >= 150 and case % 2 == 0:
-        use_clahe = bool(rng.integers(0, 2)); clipv = float(rng.choice([1.0, 3.0, 8.0]))
-        cap = int(rng.choice([512, 512, 64, 150]))                         # small capacities: keypoints beyond it run as further chunks
-        t = ov2slam_amd.VisualFrontEndTracker(ctx, w, h, use_clahe=use_clahe, fclahe_val=clipv, nbmaxkps=cap, use_graph=bool(rng.integers(0, 2)))
-        with_cal = bool(rng.integers(0, 2))
-        if with_cal:                                                       # Frame::computeKeypoint inside the frame's enqueue
-            tcal = ov2slam_amd.CameraCalibration(ctx, "pinhole", 458.654, 457.296, w / 2.0, h / 2.0, D=(-0.2834, 0.0739, 0.00019, 1.76e-05))
-            t.setCalibration(tcal)
-        t.trackFrame(prev, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
-        nk = int(rng.integers(1, 500))
-        tk = np.stack([rng.uniform(-4, w + 4, nk), rng.uniform(-4, h + 4, nk)], 1).astype(np.float32)
-        hp = (rng.uniform(size=nk) < rng.uniform(0, 1)).astype(np.uint8)
-        tp = np.where(hp[:, None] > 0, tk - shift + rng.normal(0, rng.choice([0.5, 3.0, 15.0]), tk.shape), tk).astype(np.float32)
-        use_prior = bool(rng.integers(0, 4))
-        if use_prior:
-            go, gs, gp3p = t.trackFrame(cur, tk, tp, hp)
-        else:
-            t.preprocessImage(cur); go, gs, gp3p = t.kltTracking(tk, tp, hp, klt_use_prior=False)
-        a, b = (O.clahe(prev, clipv, w // 50, h // 50), O.clahe(cur, clipv, w // 50, h // 50)) if use_clahe else (prev, cur)
-        ro, rok, rretry, rp3p = O.klt_tracking(O.Pyramid(a, 9, 3), O.Pyramid(b, 9, 3), tk, tp, hp, klt_use_prior=use_prior)
-        check("tracker", gp3p == rp3p and np.array_equal((gs & 1).astype(bool), rok) and np.array_equal((gs & 2).astype(bool), rretry)
-              and np.array_equal(np.ascontiguousarray(go, np.float32).view(np.uint32), np.ascontiguousarray(ro, np.float32).view(np.uint32)),
-              dict(info, n=nk, clahe=use_clahe, prior=use_prior, cap=cap))
-        if with_cal:
-            gu, gb = t.lastKeypoints(nk)
-            ru, rb = O.compute_keypoints(O.CAM_PINHOLE, tcal.K, tcal.D, tcal.iK, go)
-            check("tracker_keypoints", np.array_equal(gu.view(np.uint32), ru.view(np.uint32)) and np.array_equal(gb.view(np.uint64), rb.view(np.uint64)),
-                  dict(info, n=nk, cap=cap))
-        t.close()
+        import contextlib
+        facc = int(rng.integers(0, 3)) == 0          # a third of the tracker cases with the float accumulators (both kernels: the wave kernel by default)
+        with contextlib.ExitStack() as stack:
+            if facc:
+                stack.enter_context(ctx.options(lk_acc=L.OV2_LK_ACC_FLOAT_UI4)); stack.enter_context(O.lk_acc_mode(O.LK_ACC_FLOAT_UI4))
+            use_clahe = bool(rng.integers(0, 2)); clipv = float(rng.choice([1.0, 3.0, 8.0]))
+            cap = int(rng.choice([512, 512, 64, 150]))                         # small capacities: keypoints beyond it run as further chunks
+            t = ov2slam_amd.VisualFrontEndTracker(ctx, w, h, use_clahe=use_clahe, fclahe_val=clipv, nbmaxkps=cap, use_graph=bool(rng.integers(0, 2)))
+            with_cal = bool(rng.integers(0, 2))
+            if with_cal:                                                       # Frame::computeKeypoint inside the frame's enqueue
+                tcal = ov2slam_amd.CameraCalibration(ctx, "pinhole", 458.654, 457.296, w / 2.0, h / 2.0, D=(-0.2834, 0.0739, 0.00019, 1.76e-05))
+                t.setCalibration(tcal)
+            t.trackFrame(prev, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), None)
+            nk = int(rng.integers(1, 500))
+            tk = np.stack([rng.uniform(-4, w + 4, nk), rng.uniform(-4, h + 4, nk)], 1).astype(np.float32)
+            hp = (rng.uniform(size=nk) < rng.uniform(0, 1)).astype(np.uint8)
+            tp = np.where(hp[:, None] > 0, tk - shift + rng.normal(0, rng.choice([0.5, 3.0, 15.0]), tk.shape), tk).astype(np.float32)
+            use_prior = bool(rng.integers(0, 4))
+            if use_prior:
+                go, gs, gp3p = t.trackFrame(cur, tk, tp, hp)
+            else:
+                t.preprocessImage(cur); go, gs, gp3p = t.kltTracking(tk, tp, hp, klt_use_prior=False)
+            a, b = (O.clahe(prev, clipv, w // 50, h // 50), O.clahe(cur, clipv, w // 50, h // 50)) if use_clahe else (prev, cur)
+            ro, rok, rretry, rp3p = O.klt_tracking(O.Pyramid(a, 9, 3), O.Pyramid(b, 9, 3), tk, tp, hp, klt_use_prior=use_prior)
+            check("tracker", gp3p == rp3p and np.array_equal((gs & 1).astype(bool), rok) and np.array_equal((gs & 2).astype(bool), rretry)
+                  and np.array_equal(np.ascontiguousarray(go, np.float32).view(np.uint32), np.ascontiguousarray(ro, np.float32).view(np.uint32)),
+                  dict(info, n=nk, clahe=use_clahe, prior=use_prior, cap=cap, float_acc=facc))
+            if with_cal:
+                gu, gb = t.lastKeypoints(nk)
+                ru, rb = O.compute_keypoints(O.CAM_PINHOLE, tcal.K, tcal.D, tcal.iK, go)
+                check("tracker_keypoints", np.array_equal(gu.view(np.uint32), ru.view(np.uint32)) and np.array_equal(gb.view(np.uint64), rb.view(np.uint64)),
+                      dict(info, n=nk, cap=cap))
+            t.close()
     # ---- bundle adjustment: random small problems, both landmark forms, both problem-size paths ----
     if case % 4 == 0:
         from ov2slam_amd import optimizer
