@@ -123,6 +123,8 @@ void *ov2_ctx_stream(ov2_ctx *ctx);        /* the hipStream_t, for event timing 
 #define OV2_OPT_FAST_TIE           12
 #define OV2_FAST_TIE_SCAN_ORDER    0
 #define OV2_FAST_TIE_LIBSTDCXX     1
+#define OV2_OPT_DETECT_STRIP       15   /* detectSingleScale's response kernel: -1 auto (the strip kernel for batches: the free cells of an image side by
+                                           side, ~59 of 64 lanes busy on 35-pixel cells), 0 one wavefront per cell, 1 the strip kernel; same bits */
 #define OV2_OPT_LK_ACC             14
 #define OV2_LK_ACC_INT64           0
 #define OV2_LK_ACC_FLOAT_UI4       1

@@ -24,6 +24,7 @@ OV2_OPT_BA_SCHUR_CHUNK, OV2_OPT_BA_XYZ_LIN_WAVES, OV2_OPT_BA_POSE_ONLY_FUSED, OV
 OV2_OPT_FAST_TIE = 12
 OV2_OPT_BA_TRACE = 13
 OV2_OPT_LK_ACC = 14
+OV2_OPT_DETECT_STRIP = 15
 OV2_LK_ACC_INT64, OV2_LK_ACC_FLOAT_UI4 = 0, 1
 OV2_FAST_TIE_SCAN_ORDER, OV2_FAST_TIE_LIBSTDCXX = 0, 1
 OV2_LK_IMPL_AUTO, OV2_LK_IMPL_ROW, OV2_LK_IMPL_LANE3 = 0, 1, 2

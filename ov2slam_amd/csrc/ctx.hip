@@ -208,6 +208,9 @@ int ov2_ctx_set_option(ov2_ctx *ctx, int option, int value)
     case OV2_OPT_BA_POSE_ONLY_FUSED: ctx->ba_pose_only_fused = value != 0; return OV2_OK;
     case OV2_OPT_BA_DETERMINISTIC:   ctx->ba_deterministic = value != 0; return OV2_OK;
     case OV2_OPT_BA_TRACE:           ctx->ba_trace = value != 0; return OV2_OK;
+    case OV2_OPT_DETECT_STRIP:
+        OV2_REQUIRE(value >= -1 && value <= 1, OV2_EINVAL, "OV2_OPT_DETECT_STRIP takes -1, 0 or 1");
+        ctx->det_strip = value; return OV2_OK;
     case OV2_OPT_LK_ACC:
         OV2_REQUIRE(value == OV2_LK_ACC_INT64 || value == OV2_LK_ACC_FLOAT_UI4, OV2_EINVAL, "OV2_OPT_LK_ACC takes OV2_LK_ACC_INT64 or OV2_LK_ACC_FLOAT_UI4");
         ctx->lk_acc = value; return OV2_OK;
@@ -236,6 +239,7 @@ int ov2_ctx_get_option(ov2_ctx *ctx, int option, int *value)
     case OV2_OPT_BA_POSE_ONLY_FUSED: *value = ctx->ba_pose_only_fused; return OV2_OK;
     case OV2_OPT_BA_DETERMINISTIC:   *value = ctx->ba_deterministic; return OV2_OK;
     case OV2_OPT_BA_TRACE:           *value = ctx->ba_trace; return OV2_OK;
+    case OV2_OPT_DETECT_STRIP:       *value = ctx->det_strip; return OV2_OK;
     case OV2_OPT_LK_ACC:             *value = ctx->lk_acc; return OV2_OK;
     case OV2_OPT_DEBUG:              *value = ctx->debug; return OV2_OK;
     case OV2_OPT_FAST_TIE:           *value = ctx->det_fast_tie; return OV2_OK;

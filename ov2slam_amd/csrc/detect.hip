@@ -27,6 +27,9 @@
 #pragma clang fp contract(off)
 
 #define DET_MAX_CELL 64
+#ifndef DET_CHUNK
+#define DET_CHUNK 1024     // images per pass of the batch entry points (the response maps of a pass live in the scratch: 1.3 MB per EuRoC image)
+#endif
 
 __device__ __forceinline__ int d_reflect101(int p, int len)
 {
@@ -359,6 +362,237 @@ __global__ __launch_bounds__(64) void k_mineig_cells(const uint8_t *__restrict__
         const int p2y = bi2 / cs, p2x = bi2 - p2y * cs;
         cd.p2 = bi2 == 0x7FFFFFFF ? -1 : (p2x | (p2y << 16)); cd.v2 = bv2;
         cand_out[cell] = cd;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The same responses for BATCHES of images: k_mineig_strip.  One wavefront per cell keeps 35 of 64 lanes busy on the reference's
+// 35-pixel cells and marches occupied cells' wavefronts to an early exit; the kernel is VALU-issue bound (profiles/r6_detect_*), so
+// lanes are what there is to win.  Here the FREE cells of an image are laid side by side as one strip of columns (cells are Mats of
+// their own: REFLECT_101 at the cell's edges, so neighbours in the strip need not be neighbours in the image) and a work-group of K
+// wavefronts takes NCELL of them: lane = strip column, wavefront k owns columns [k O, (k + 1) O) and carries two more on either
+// side -- a column's Sobel needs its neighbours' blurred pixels, its box sum their products -- so that no value ever crosses a
+// wavefront (59 of 64 lanes own a column for cs = 35: NCELL = 5, K = 3).  Every lane runs, for its column, exactly the sequence of
+// operations the one-wavefront-per-cell kernel runs (same rounding, same order: the maps and candidates are bit-identical); the
+// neighbours come through DPP wave shifts instead of ds_bpermute, a wavefront's lambda_min columns are staged in LDS (row pitch 65:
+// row writes and column reads both conflict-free) for the second candidate and for the map store -- the owned columns of one cell
+// are ONE contiguous run of the column-major map, written with coalesced stores (a lane storing its own column row by row touches
+// 64 cache lines per instruction: measured 2.2x the whole kernel) --, the per-cell arg-max reductions are 64-bit LDS atomics on
+// (ordered value, ~index).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float d_wave_from_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true)); }   // wave_shr:1: lane i <- lane i - 1
+__device__ __forceinline__ float d_wave_from_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true)); }  // wave_shl:1: lane i <- lane i + 1
+__device__ __forceinline__ int d_wave_from_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ int d_wave_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned long long d_argmax_key(float v, int idx)
+{
+    unsigned u = __float_as_uint(v);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;                // monotone map float -> unsigned
+    return ((unsigned long long)u << 32) | (unsigned)(0x7FFFFFFF - idx);      // larger value first, then the smaller index
+}
+__device__ __forceinline__ float d_argmax_key_value(unsigned long long k)
+{
+    unsigned u = (unsigned)(k >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
+}
+
+#define STRIP_MAX_CELLS 8
+// the free cells of every image in raster order (the reference's loops `continue` on cells that hold a current keypoint, :296-319):
+// free_list[item * (ncells + 1)] = count, then the cell indices.  One wavefront per image.
+__global__ __launch_bounds__(64) void k_free_cells(int cs, int nwcells, DetBatch B, int *__restrict__ free_list)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned *occ = (unsigned *)smem;
+    const int item = blockIdx.x, lane = threadIdx.x, ncells = B.ncells, nhcells = ncells / nwcells;
+    const int occ_words = (ncells + 31) / 32;
+    for (int i = lane; i < occ_words; i += 64) occ[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int n = B.ncur ? B.ncur[item] : B.ncur_all;
+    if (n > 0 && B.cur != nullptr) {
+        const float2 *cur = B.cur + (long long)item * B.cur_stride;
+        for (int i = lane; i < n; i += 64) {
+            const float2 p = cur[i];
+            const int r = (int)(p.y / (float)cs), c = (int)(p.x / (float)cs);
+            if (r >= 0 && r < nhcells && c >= 0 && c < nwcells) atomicOr(&occ[(r * nwcells + c) >> 5], 1u << ((r * nwcells + c) & 31));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int *out = free_list + (long long)item * (ncells + 1);
+    int seen = 0;
+    for (int base = 0; base < ncells; base += 64) {
+        const int c = base + lane;
+        const bool fr = c < ncells && !((occ[c >> 5] >> (c & 31)) & 1u);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(fr);
+        if (fr) out[1 + seen + __popcll(m & ((1ull << lane) - 1ull))] = c;
+        seen += __popcll(m);
+    }
+    if (lane == 0) out[0] = seen;
+}
+__global__ __launch_bounds__(512) void k_mineig_strip(const uint8_t *__restrict__ img, int w, int h, int stride,
+                                                      int cs, int nwcells, float *__restrict__ hmap_out, int dy_order,
+                                                      int radius, CellCand *__restrict__ cand_out, DetBatch B, int ncell_wg, int owned,
+                                                      const int *__restrict__ free_list)
+{
+    extern __shared__ __align__(16) unsigned char smem[];       // the blurred columns: cs rows x blockDim bytes, then the wavefronts' lambda_min
+    __shared__ int s_hw[64];
+    __shared__ int s_cell[STRIP_MAX_CELLS];
+    __shared__ int s_nmine;
+    __shared__ unsigned long long s_key1[STRIP_MAX_CELLS], s_key2[STRIP_MAX_CELLS];
+    const int item = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x;
+    const int npx = cs * cs, ncells = B.ncells;
+    img += (long long)item * B.img_stride;
+    hmap_out += (long long)item * ncells * npx;
+    cand_out += (long long)item * ncells;
+    // ---- this work-group's share of the image's free cells (k_free_cells) ----
+    if (tid < STRIP_MAX_CELLS) { s_key1[tid] = 0; s_key2[tid] = 0; s_cell[tid] = -1; }
+    if (tid == 0) d_circle_halfwidths(s_hw, radius);
+    {
+        const int *fl = free_list + (long long)item * (ncells + 1);
+        const int first = blockIdx.x * ncell_wg, left = fl[0] - first;
+        if (left <= 0) return;                                     // (work-group uniform)
+        if (tid == 0) s_nmine = left > ncell_wg ? ncell_wg : left;
+        __syncthreads();
+        if (tid < ncell_wg && tid < left) s_cell[tid] = fl[1 + first + tid];
+    }
+    __syncthreads();
+    const int nmine = s_nmine;
+    if (nmine == 0) return;
+    // ---- this lane's column ----
+    const int g = wave * owned - 2 + lane;                     // strip column; two carried columns on either side of the owned range
+    const int ncols = nmine * cs;
+    const bool valid = g >= 0 && g < ncols;
+    const bool owns = valid && lane >= 2 && lane < 2 + owned;
+    const int gc = valid ? g : 0;
+    const int slot = gc / cs, x = gc - slot * cs;
+    const int cell = s_cell[slot];
+    const int x0 = (cell % nwcells) * cs, y0 = (cell / nwcells) * cs;
+    uint8_t *blur = smem + tid;                                 // row y of this column: blur[y * nt]
+    float *lamw = (float *)(smem + ((cs * nt + 15) & ~15)) + wave * cs * 65;     // this wavefront's lambda_min: lamw[y * 65 + lane]
+    // ---- GaussianBlur 3x3 on the parent image (REFLECT_101 at the IMAGE border), (1 2 1) x (1 2 1), (s + 8) >> 4 ----
+    {
+        const int gx0 = d_reflect101(x0 + x - 1, w), gx1 = d_reflect101(x0 + x, w), gx2 = d_reflect101(x0 + x + 1, w);
+        auto hrow = [&](int gy) {
+            const uint8_t *row = img + (long long)d_reflect101(gy, h) * stride;
+            return (int)row[gx0] + 2 * (int)row[gx1] + (int)row[gx2];
+        };
+        for (int j0 = 0; j0 < cs; j0 += 8) {
+            int hv[10];
+#pragma unroll
+            for (int u = 0; u < 10; u++) hv[u] = hrow(y0 + j0 - 1 + u);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j0 + u < cs) blur[(j0 + u) * nt] = (uint8_t)((hv[u] + 2 * hv[u + 1] + hv[u + 2] + 8) >> 4);
+        }
+    }
+    // (a lane reads back its OWN bytes only: no barrier)
+    const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = (float)(2.0 * (1.0 / (4.0 * 3.0 * 255.0)));
+    const bool at_l = x == 0, at_r = x == cs - 1;
+    // per image row of the cell: this column's blurred pixel and its REFLECT_101 neighbours, as the row filter sees them
+    auto blur_row = [&](int yy, int &bl, int &bc, int &br) {
+        bc = blur[yy * nt];
+        const int L = d_wave_from_left(bc), R = d_wave_from_right(bc);
+        bl = at_l ? R : L; br = at_r ? L : R;
+    };
+    // Sobel pieces of one blurred row: d = right - left (dx's row term), s = the smoothed row (dy's row term, in the selected order)
+    struct RowT { float d, s; int sx; };
+    auto row_terms = [&](int yy) {
+        int bl, bc, br;
+        blur_row(yy, bl, bc, br);
+        RowT t;
+        t.d = (float)(br - bl);
+        t.sx = bl + 2 * bc + br;
+        t.s = ((float)bl * f1 + (float)bc * f0) + (float)br * f1;
+        return t;
+    };
+    auto rowsum = [&](const RowT &tm, const RowT &tc, const RowT &tp, double (&sum)[3]) {
+        const float dx = (tm.d + tp.d) * f1 + tc.d * f0;
+        float dy;
+        if (dy_order == OV2_SOBEL_DY_EXACT_SUM) dy = ((float)tp.sx - (float)tm.sx) * f1;
+        else dy = tp.s - tm.s;
+        const float v0 = dx * dx, v1 = dx * dy, v2 = dy * dy;
+        const float L0 = d_wave_from_left(v0), L1 = d_wave_from_left(v1), L2 = d_wave_from_left(v2);
+        const float R0 = d_wave_from_right(v0), R1 = d_wave_from_right(v1), R2 = d_wave_from_right(v2);
+        const float l0 = at_l ? R0 : L0, l1 = at_l ? R1 : L1, l2 = at_l ? R2 : L2;
+        const float q0 = at_r ? L0 : R0, q1 = at_r ? L1 : R1, q2 = at_r ? L2 : R2;
+        sum[0] = (double)l0; sum[0] = sum[0] + (double)v0; sum[0] = sum[0] + (double)q0;
+        sum[1] = (double)l1; sum[1] = sum[1] + (double)v1; sum[1] = sum[1] + (double)q1;
+        sum[2] = (double)l2; sum[2] = sum[2] + (double)v2; sum[2] = sum[2] + (double)q2;
+    };
+    // blurred rows y - 1, y, y + 1 of the Sobel stencil (REFLECT_101 at the cell's top / bottom: row -1 = row 1, row cs = row cs - 2)
+    RowT t0 = row_terms(0), t1 = row_terms(1), t2 = row_terms(cs > 2 ? 2 : cs - 1);
+    double rp[3] = {0, 0, 0}, rc[3], rn[3], SUM[3];
+    rowsum(t1, t0, t1, rc);                                     // row 0: rows (1, 0, 1)
+    rowsum(t0, t1, t2, rn);                                     // row 1: rows (0, 1, 2)
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) { SUM[ch] = 0; SUM[ch] += rn[ch]; SUM[ch] += rc[ch]; }
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+    // ta, tb: blurred rows y + 1 and y + 2 when rn is about to be computed for row y + 2  (rows (y + 1, y + 2, y + 3))
+    RowT ta = t1, tb = t2;
+    for (int y = 0; y < cs; y++) {
+        float cov[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double nxt = (y + 1 <= cs - 1) ? rn[ch] : rp[ch];
+            const double prv = (y == 0) ? rn[ch] : rp[ch];
+            const double s0 = SUM[ch] + nxt;
+            cov[ch] = (float)s0;
+            SUM[ch] = s0 - prv;
+        }
+        const float a = cov[0] * 0.5f, b = cov[1], c = cov[2] * 0.5f;
+        const float lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        lamw[y * 65 + lane] = lm;
+        if (owns && lm > bv) { bv = lm; bi = y * cs + x; }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { rp[ch] = rc[ch]; rc[ch] = rn[ch]; }
+        if (y + 2 <= cs - 1) {                                  // (wave-uniform) row y + 2: blurred rows y + 1, y + 2, y + 3 (reflected at the bottom)
+            const int y3 = y + 3 <= cs - 1 ? y + 3 : cs - 2;
+            const RowT tn = (y + 3 <= cs - 1) ? row_terms(y3) : ta;            // row cs reflects to row cs - 2 = the stencil's top row
+            rowsum(ta, tb, tn, rn);
+            ta = tb; tb = tn;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- the map: this wavefront's owned columns, cell by cell one contiguous run of the column-major layout ----
+    {
+        const int c_first = wave * owned, c_end = min(ncols, c_first + owned);          // owned strip columns [c_first, c_end)
+        const int total = (c_end - c_first) * cs;
+        // element e of the run: column c_first + e / cs, row e % cs (advanced incrementally: 64 elements per trip)
+        int col = c_first + lane / cs, yy = lane - (lane / cs) * cs;
+        const int dcol = 64 / cs, dy = 64 - dcol * cs;
+        for (int e = lane; e < total; e += 64) {
+            const int sl = col / cs, xx = col - sl * cs;
+            hmap_out[(long long)s_cell[sl] * npx + xx * cs + yy] = lamw[yy * 65 + (col - c_first + 2)];
+            col += dcol; yy += dy;
+            if (yy >= cs) { yy -= cs; col++; }
+        }
+    }
+    // ---- candidates: first maximum of the cell in raster order, then the first maximum outside the disc around it ----
+    if (owns && bi != 0x7FFFFFFF) atomicMax(&s_key1[slot], d_argmax_key(bv, bi));
+    __syncthreads();
+    const unsigned long long k1 = s_key1[slot];
+    const int bi1 = 0x7FFFFFFF - (int)(unsigned)(k1 & 0xFFFFFFFFull);
+    const int p1y = bi1 / cs, p1x = bi1 - p1y * cs;
+    float bv2 = -INFINITY; int bi2 = 0x7FFFFFFF;
+    if (owns) {
+        const int adx = x > p1x ? x - p1x : p1x - x;
+        for (int y = 0; y < cs; y++) {
+            const int ady = y > p1y ? y - p1y : p1y - y;
+            const bool in_disc = ady <= radius && s_hw[ady < 64 ? ady : 63] >= 0 && adx <= s_hw[ady < 64 ? ady : 63];
+            const float v = lamw[y * 65 + lane];
+            if (!in_disc && v > bv2) { bv2 = v; bi2 = y * cs + x; }
+        }
+        if (bi2 != 0x7FFFFFFF) atomicMax(&s_key2[slot], d_argmax_key(bv2, bi2));
+    }
+    __syncthreads();
+    if (tid < nmine) {
+        const unsigned long long a1 = s_key1[tid], a2 = s_key2[tid];
+        CellCand cd;
+        const int i1 = 0x7FFFFFFF - (int)(unsigned)(a1 & 0xFFFFFFFFull);
+        cd.p1 = (i1 % cs) | ((i1 / cs) << 16); cd.v1 = d_argmax_key_value(a1);
+        if (a2 == 0) { cd.p2 = -1; cd.v2 = -INFINITY; }
+        else { const int i2 = 0x7FFFFFFF - (int)(unsigned)(a2 & 0xFFFFFFFFull); cd.p2 = (i2 % cs) | ((i2 / cs) << 16); cd.v2 = d_argmax_key_value(a2); }
+        cand_out[s_cell[tid]] = cd;
     }
 }
 
@@ -861,40 +1095,68 @@ __device__ void d_get_rect_subpix(const uint8_t *__restrict__ src, int src_step,
 // one pixel (i, j) of getRectSubPix(u8 -> f32), patch PW x PW around (cx, cy): the same three code paths as
 // d_get_rect_subpix, evaluated per pixel (the fast path's `prev` recurrence only couples neighbouring columns:
 // dst[j] = (j ? float(t[j-1] * s) : (1-a)(b1 p[0] + b2 p'[0])) + t[j],  t[j] = a12 p[j+1] + a22 p'[j+1])
+// What of getRectSubPix depends on the patch centre only: computed once per Gauss-Newton trip, not once per pixel (the fp64 division
+// of the fast path's `s` alone is ~40 instructions)
+struct RectCtx {
+    int fast, inner, ipx, ipy;
+    float a12, a22, b1, b2, a1m, a11, a21;
+    double s;
+};
 template <int PW>
-__device__ __forceinline__ float d_rect_subpix_px(const uint8_t *__restrict__ src, int src_step, int sw, int sh, float cx_f, float cy_f, int i, int j)
+__device__ __forceinline__ RectCtx d_rect_ctx(int sw, int sh, float cx_f, float cy_f)
 {
+    RectCtx c;
     const int pw = PW, ph = PW;
     const double cxd = (double)cx_f - (pw - 1) * 0.5, cyd = (double)cy_f - (ph - 1) * 0.5;
     int ipx = (int)floor(cxd), ipy = (int)floor(cyd);
-    if (0 <= ipx && ipx + pw < sw && 0 <= ipy && ipy + ph < sh) {
+    c.fast = (0 <= ipx && ipx + pw < sw && 0 <= ipy && ipy + ph < sh) ? 1 : 0;
+    c.inner = 0; c.a11 = c.a21 = 0.f; c.s = 0; c.a1m = 0.f;
+    if (c.fast) {
         float a = (float)(cxd - ipx), b = (float)(cyd - ipy);
         a = a > 0.0001f ? a : 0.0001f;
-        const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
-        const double s = (1. - (double)a) / (double)a;
-        const uint8_t *p = src + (long long)(ipy + i) * src_step + ipx;
-        const float t = a12 * p[j + 1] + a22 * p[j + 1 + src_step];
-        float prev;
-        if (j == 0) prev = (1 - a) * (b1 * p[0] + b2 * p[src_step]);
-        else { const float tp = a12 * p[j] + a22 * p[j + src_step]; prev = (float)(tp * s); }
-        return prev + t;
+        c.a12 = a * (1.f - b); c.a22 = a * b; c.b1 = 1.f - b; c.b2 = b;
+        c.s = (1. - (double)a) / (double)a;
+        c.a1m = 1 - a;
+        c.ipx = ipx; c.ipy = ipy;
+        return c;
     }
     const float cx = cx_f - (pw - 1) * 0.5f, cy = cy_f - (ph - 1) * 0.5f;
     ipx = (int)floorf(cx); ipy = (int)floorf(cy);
     const float a = cx - ipx, b = cy - ipy;
-    const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
-    const float b1 = 1.f - b, b2 = b;
+    c.a11 = (1.f - a) * (1.f - b); c.a12 = a * (1.f - b); c.a21 = (1.f - a) * b; c.a22 = a * b;
+    c.b1 = 1.f - b; c.b2 = b;
+    c.inner = (0 <= ipx && ipx < sw - pw && 0 <= ipy && ipy < sh - ph) ? 1 : 0;
+    c.ipx = ipx; c.ipy = ipy;
+    return c;
+}
+// d_get_rect_subpix, evaluated per pixel (the fast path's `prev` recurrence only couples neighbouring columns:
+// dst[j] = (j ? float(t[j-1] * s) : (1-a)(b1 p[0] + b2 p'[0])) + t[j],  t[j] = a12 p[j+1] + a22 p'[j+1])
+__device__ __forceinline__ float d_rect_px(const RectCtx &c, const uint8_t *__restrict__ src, int src_step, int sw, int sh, int i, int j)
+{
+    if (c.fast) {
+        const uint8_t *p = src + (long long)(c.ipy + i) * src_step + c.ipx;
+        const float t = c.a12 * p[j + 1] + c.a22 * p[j + 1 + src_step];
+        float prev;
+        if (j == 0) prev = c.a1m * (c.b1 * p[0] + c.b2 * p[src_step]);
+        else { const float tp = c.a12 * p[j] + c.a22 * p[j + src_step]; prev = (float)(tp * c.s); }
+        return prev + t;
+    }
     // rows / columns of adjustRect == replicated border; columns left of the image or without a right neighbour
     // use the vertical-only weights
-    int y0 = ipy + i, y1 = y0 + 1;
+    int y0 = c.ipy + i, y1 = y0 + 1;
     y0 = min(max(y0, 0), sh - 1); y1 = min(max(y1, 0), sh - 1);
     const uint8_t *r0 = src + (long long)y0 * src_step, *r1 = src + (long long)y1 * src_step;
-    const int x = ipx + j;
-    if (0 <= ipx && ipx < sw - pw && 0 <= ipy && ipy < sh - ph)
-        return r0[x] * a11 + r0[x + 1] * a12 + r1[x] * a21 + r1[x + 1] * a22;
-    if (x < 0) return r0[0] * b1 + r1[0] * b2;
-    if (x >= sw - 1) return r0[sw - 1] * b1 + r1[sw - 1] * b2;
-    return r0[x] * a11 + r0[x + 1] * a12 + r1[x] * a21 + r1[x + 1] * a22;
+    const int x = c.ipx + j;
+    if (c.inner) return r0[x] * c.a11 + r0[x + 1] * c.a12 + r1[x] * c.a21 + r1[x + 1] * c.a22;
+    if (x < 0) return r0[0] * c.b1 + r1[0] * c.b2;
+    if (x >= sw - 1) return r0[sw - 1] * c.b1 + r1[sw - 1] * c.b2;
+    return r0[x] * c.a11 + r0[x + 1] * c.a12 + r1[x] * c.a21 + r1[x + 1] * c.a22;
+}
+template <int PW>
+__device__ __forceinline__ float d_rect_subpix_px(const uint8_t *__restrict__ src, int src_step, int sw, int sh, float cx_f, float cy_f, int i, int j)
+{
+    const RectCtx c = d_rect_ctx<PW>(sw, sh, cx_f, cy_f);
+    return d_rect_px(c, src, src_step, sw, sh, i, j);
 }
 
 // One WAVEFRONT per point: the (WINW+2)^2 patch and the per-pixel gradient products are evaluated by all lanes,
@@ -917,7 +1179,8 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
     int iter = 0;
     bool go = true;
     while (go) {
-        for (int e = lane; e < SW * SW; e += 64) { const int i = e / SW, j = e - i * SW; sub[e] = d_rect_subpix_px<SW>(img, P.stride, P.w, P.h, cIx, cIy, i, j); }
+        const RectCtx rc = d_rect_ctx<SW>(P.w, P.h, cIx, cIy);
+        for (int e = lane; e < SW * SW; e += 64) { const int i = e / SW, j = e - i * SW; sub[e] = d_rect_px(rc, img, P.stride, P.w, P.h, i, j); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (int e = lane; e < NPIX; e += 64) {
             const int i = e / WINW, j = e - i * WINW;
@@ -937,7 +1200,17 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
         // the five sums in the reference's raster order, one lane each (a wave64 fp64 add occupies the SIMD for 8 cycles
         // whether one lane is active or five: 49 dependent adds instead of 245)
         double acc = 0;
-        if (lane < 5) for (int e = 0; e < NPIX; e++) acc += prod[e][lane];
+        // (the reads of a window row are issued together, then added in order: one LDS round trip per row instead of one per term)
+        if (lane < 5) {
+#pragma unroll
+            for (int r = 0; r < WINW; r++) {
+                double v[WINW];
+#pragma unroll
+                for (int k = 0; k < WINW; k++) v[k] = prod[r * WINW + k][lane];
+#pragma unroll
+                for (int k = 0; k < WINW; k++) acc += v[k];
+            }
+        }
         const double a = __shfl(acc, 0, 64), b = __shfl(acc, 1, 64), c = __shfl(acc, 2, 64), bb1 = __shfl(acc, 3, 64), bb2 = __shfl(acc, 4, 64);
         if (lane == 0) {
             const double det = a * c - b * b;
@@ -958,6 +1231,7 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
     if (fabs((double)(cIx - cT.x)) > HALF || fabs((double)(cIy - cT.y)) > HALF) { cIx = cT.x; cIy = cT.y; }
     if (lane == 0) xy[pt] = make_float2(cIx, cIy);
 }
+
 
 // ---------------------------------------------------------------------------------
 // host side
@@ -1004,7 +1278,7 @@ static hipError_t det_raise_lds_limits()
             if (e != hipSuccess) return e;
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
         };
-        const void *fns[] = {(const void *)k_mineig_cells,
+        const void *fns[] = {(const void *)k_mineig_cells, (const void *)k_mineig_strip,
                              (const void *)k_grid_select<0, 36, 1>, (const void *)k_grid_select<0, 52, 1>, (const void *)k_grid_select<0, 32, 2>,
                              (const void *)k_grid_select<1, 36, 1>, (const void *)k_grid_select<1, 52, 1>, (const void *)k_grid_select<1, 32, 2>};
         for (const void *fn : fns) if (err == hipSuccess) err = raise(fn);
@@ -1042,6 +1316,23 @@ static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int 
     if (mode == 0) {
         int th = fast_th < 0 ? 0 : (fast_th > 255 ? 255 : fast_th);
         hipLaunchKernelGGL(k_fast_cells, dim3(ncells * items), dim3(256), 0, ctx->stream, im, w, h, im_stride, cell, nw, th, maps_d, mask_mode, cand_d, B);
+    } else if (ctx->det_strip == 1 || (ctx->det_strip < 0 && (long long)ncells * items >= 2048)) {
+        // batches: the free cells of an image side by side, several per work-group (k_mineig_strip); the cells per group / wavefronts
+        // per group that leave the fewest lanes idle: a wavefront owns at most 60 of its 64 columns
+        int best_n = 1, best_k = (cell + 59) / 60;
+        double best_e = (double)cell / (64.0 * best_k);
+        for (int nc = 2; nc <= STRIP_MAX_CELLS; nc++) {
+            const int k = (nc * cell + 59) / 60;
+            if (k > 8) break;
+            const double e = (double)nc * cell / (64.0 * k);
+            if (e > best_e + 1e-9) { best_e = e; best_n = nc; best_k = k; }
+        }
+        const int owned = (best_n * cell + best_k - 1) / best_k;
+        const size_t lds = (((size_t)cell * 64 * best_k + 15) & ~(size_t)15) + (size_t)best_k * cell * 65 * 4;
+        int *free_d = (int *)(cand_d + (size_t)items * ncells);          // (the callers reserve it behind the candidates)
+        hipLaunchKernelGGL(k_free_cells, dim3(items), dim3(64), (size_t)(ncells + 31) / 32 * 4, ctx->stream, cell, nw, B, free_d);
+        hipLaunchKernelGGL(k_mineig_strip, dim3((ncells + best_n - 1) / best_n, items), dim3(64 * best_k), lds, ctx->stream, im, w, h, im_stride, cell, nw,
+                           (float *)maps_d, ctx->sobel_dy_order, cell / 4, cand_d, B, best_n, owned, (const int *)free_d);
     } else {
         const size_t lds = (size_t)npx * 5 + 16;                      // lambda_min (float) + blurred cell (byte) per pixel
         hipLaunchKernelGGL(k_mineig_cells, dim3(ncells * items), dim3(64), lds, ctx->stream, im, w, h, im_stride, cell, nw, (float *)maps_d, ctx->sobel_dy_order, cell / 4, cand_d, B);
@@ -1098,7 +1389,7 @@ static int detect_common(ov2_ctx *ctx, int mode, const uint8_t *img_h, const uin
     const size_t o_out = (o_cur + 8 * (size_t)(ncur > 0 ? ncur : 1) + 255) & ~(size_t)255;
     const size_t o_so = o_out + 16 * (size_t)ncells;
     const size_t o_cand = (o_so + sizeof(SelectOut) + 255) & ~(size_t)255;
-    const size_t total = o_cand + sizeof(CellCand) * (size_t)ncells;
+    const size_t total = o_cand + sizeof(CellCand) * (size_t)ncells + 4 * ((size_t)ncells + 1);        // candidates, then the free-cell list (k_free_cells)
     int rc = ctx->reserve_device(total);  if (rc) return rc;
     rc = ctx->reserve_host(16 * (size_t)ncells + sizeof(SelectOut)); if (rc) return rc;
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
@@ -1237,10 +1528,10 @@ static int detect_batch(ov2_ctx *ctx, int mode, const ov2_pyr *pyr, int cell, co
     const int cap = mode == 0 ? ncells : 2 * ncells;
     OV2_REQUIRE(out_cap >= cap, OV2_EINVAL, "out_cap too small: (w/cell)*(h/cell) points per item for FAST, twice that for single scale");
     { int slots_; OV2_REQUIRE(det_select_lds(w, h, cell, mode, ctx->det_fast_tie, &slots_) != 0, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask"); }
-    const int chunk = std::min(items, 256);
+    const int chunk = std::min(items, DET_CHUNK);
     const size_t map_bytes = (size_t)ncells * npx * (mode == 0 ? 1 : 4);
     const size_t o_map = 0, o_cand = (o_map + (size_t)chunk * map_bytes + 255) & ~(size_t)255;
-    const size_t o_so = (o_cand + (size_t)chunk * ncells * sizeof(CellCand) + 255) & ~(size_t)255;
+    const size_t o_so = (o_cand + (size_t)chunk * (ncells * sizeof(CellCand) + 4 * ((size_t)ncells + 1)) + 255) & ~(size_t)255;   // candidates + free-cell lists
     const size_t o_par = (o_so + (size_t)items * sizeof(SelectOut) + 255) & ~(size_t)255;       // per-item threshold / quality
     const size_t total = o_par + (size_t)items * 8;
     rc = ctx->reserve_device(total); if (rc) return rc;

@@ -11,6 +11,15 @@ from ov2slam_amd import _lib as L
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["cell", "strip"], autouse=True)
+def mineig_kernel(request, gpu_ctx):
+    """Every test of this file runs with both response kernels of detectSingleScale -- one wavefront per cell (k_mineig_cells) and the
+    batch form (k_mineig_strip: the free cells of an image as one strip of columns, several cells per work-group) -- pinned through
+    OV2_OPT_DETECT_STRIP; left alone the library picks by launch size and single images would only see the first."""
+    with gpu_ctx.options(detect_strip=1 if request.param == "strip" else 0):
+        yield request.param
+
+
 def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
