@@ -11,16 +11,20 @@ if os.environ.get("OV2_LK_MICRO_LIB"):          # knock-out experiments: time a 
     L.LIB_PATH = os.environ["OV2_LK_MICRO_LIB"]
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-views, kps, pri = bench.make_inputs(S, 1234)
+view_sets, kps, pri = bench.make_inputs(S, 1234)      # (sets, NF+1, H, W): sequence s shows view set s % sets
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
 ctx = ov2slam_amd.Context(0, stream=stream.cuda_stream)
 lib = ctx.lib
 W, H, NK = bench.W, bench.H, bench.NKPS
-fr = torch.from_numpy(views).to(dev)[:, None].expand(-1, S, H, W).contiguous()
+_sets = torch.from_numpy(np.ascontiguousarray(view_sets[:, :2])).to(dev)                     # the first two views of every set
+_idx = torch.arange(S, device=dev) % view_sets.shape[0]
+fr = torch.stack([_sets[:, 0][_idx], _sets[:, 1][_idx]])
 P0 = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=S); P1 = ov2slam_amd.Pyramid(ctx, W, H, 9, 3, batch=S)
 vp = lambda t: C.c_void_p(t.data_ptr())
-L.check(lib.ov2_pyr_build_d(ctx.h, P0.h_pyr, vp(fr[0]), W, W * H)); L.check(lib.ov2_pyr_build_d(ctx.h, P1.h_pyr, vp(fr[1]), W, W * H))
+# the bench's pre-processing (CLAHE + pyramid), like the step the kernel runs in
+clahe = lib.ov2_pyr_build_clahe_d
+L.check(clahe(ctx.h, P0.h_pyr, vp(fr[0]), W, W * H, C.c_double(3.0), W // 50, H // 50)); L.check(clahe(ctx.h, P1.h_pyr, vp(fr[1]), W, W * H, C.c_double(3.0), W // 50, H // 50))
 k = torch.from_numpy(kps[0]).to(dev); p0 = torch.from_numpy(pri[0]).to(dev); p = p0.clone()
 st = torch.zeros((S, NK), dtype=torch.uint8, device=dev); stats = torch.zeros(2, dtype=torch.int64, device=dev)
 print("S=%d points=%d" % (S, S * NK))
