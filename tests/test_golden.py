@@ -33,3 +33,19 @@ def test_cpp_adapters_compile_with_cv_types():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DOV2_WITH_OPENCV",
                         "-I" + os.path.join(HERE, "fake_opencv"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_verbatim_signatures_compile_and_link():
+    """ov2slam_amd/host/verbatim.hpp (the reference's exact cv:: signatures over a thread-local context and a hash-validated pyramid
+    cache) and its GPU test driver compile and LINK against the library with -DOV2_WITH_OPENCV and the stand-in <opencv2/core.hpp>."""
+    import tempfile
+    root = os.path.dirname(HERE)
+    libdir = os.path.join(root, "ov2slam_amd")
+    if not os.path.exists(os.path.join(libdir, "libov2slam_hip.so")):
+        import pytest
+        pytest.skip("libov2slam_hip.so not built")
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run(["g++", "-std=c++17", "-O0", "-Wall", "-Werror", "-DOV2_WITH_OPENCV", "-I" + os.path.join(HERE, "fake_opencv"),
+                            os.path.join(HERE, "cpp", "verbatim_run.cpp"), "-o", os.path.join(td, "v"), "-L", libdir, "-lov2slam_hip",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -112,3 +112,35 @@ def test_cpp_adapters_run_and_match(gpu_ctx, oracle, tmp_path):
     assert c_flags[2] == g["iterations"][0] and (not g["l2_done"] or c_flags[3] == g["iterations"][1])
     assert np.array_equal(c_badobs.astype(bool), np.asarray(g["bad_obs"]).astype(bool))
     assert np.allclose(c_poses.reshape(-1, 7), g["poses"], rtol=0, atol=1e-9) and np.allclose(c_lam, g["invdepth"], rtol=1e-9, atol=1e-12)
+
+
+def test_verbatim_signatures_route(gpu_ctx, oracle, tmp_path):
+    """ov2slam_amd/host/verbatim.hpp: the reference's EXACT signatures -- fbKltTracking(const std::vector<cv::Mat> &, ...),
+    detectSingleScale / detectGridFAST(const cv::Mat &, ...) (include/feature_tracker.hpp:45, include/feature_extractor.hpp:40-46) -- on a
+    thread-local context with the device pyramid looked up by the level-0 Mat (hash-validated: the reference re-uses its buffers).
+    tests/cpp/verbatim_run.cpp (compiled with -DOV2_WITH_OPENCV against tests/fake_opencv: the image has no OpenCV) checks inside that
+    this route returns the bits of the Context / Pyramid route and that the cache hits / refreshes as it must; here its outputs are
+    compared with the ctypes mirror and the oracle."""
+    exe = tmp_path / "verbatim_run"
+    libdir = os.path.join(ROOT, "ov2slam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-DOV2_WITH_OPENCV", "-I", os.path.join(ROOT, "tests", "fake_opencv"),
+                           os.path.join(ROOT, "tests", "cpp", "verbatim_run.cpp"), "-o", str(exe), "-L", libdir, "-lov2slam_hip", "-Wl,-rpath," + libdir])
+    w, h, cell = 752, 480, 35
+    prev, cur, flow = synth.frame_pair(w, h, seed=12, shift=(2.6, -1.7), theta=0.003)
+    rng = np.random.default_rng(9)
+    kps = synth.grid_keypoints(w, h, cell, rng)
+    pri = (flow(kps) + rng.normal(0, 1.0, kps.shape)).astype(np.float32)
+    case, res = tmp_path / "case.bin", tmp_path / "res.bin"
+    with open(case, "wb") as f:
+        _wr(f, np.array([w, h, cell], np.int32)); _wr(f, prev); _wr(f, cur); _wr(f, kps.astype(np.float32)); _wr(f, pri)
+    r = subprocess.run([str(exe), str(case), str(res)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "verbatim ok" in r.stdout, r.stdout + r.stderr
+    with open(res, "rb") as f:
+        c_fb, c_st, c_det = _rd(f, np.float32).reshape(-1, 2), _rd(f, np.uint8), _rd(f, np.float32).reshape(-1, 2)
+    Gp = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(prev); Gc = ov2slam_amd.Pyramid(gpu_ctx, w, h, 9, 3).build(cur)
+    g_fb, g_st = ov2slam_amd.FeatureTracker(gpu_ctx, 30, 0.01).fbKltTracking(Gp, Gc, 9, 3, 30., 0.5, kps, pri)
+    assert np.array_equal(_bits(c_fb), _bits(g_fb)) and np.array_equal(c_st.astype(bool), g_st.astype(bool)) and c_st.mean() > 0.8
+    o_fb, o_st, _ = oracle.fb_klt(oracle.Pyramid(prev, 9, 3), oracle.Pyramid(cur, 9, 3), 9, 3, 30., 0.5, kps, pri)
+    assert np.array_equal(_bits(c_fb), _bits(o_fb)) and np.array_equal(c_st.astype(bool), o_st)
+    o_det, _ = oracle.detect_singlescale(cur, cell, kps[:len(kps) // 3], (5, 5, w - 10, h - 10), 0.001, True)
+    assert np.array_equal(_bits(c_det), _bits(o_det))
