@@ -12,11 +12,18 @@
  *     them.  The oracle restates the public OpenCV 3.4/4.x
  *     algorithms named at each function and is pinned only by self-consistency
  *     tests + independent numpy/scipy cross-checks.
- *   - local BA: sub-steps pinned by the known-answer tests vendored under
- *     /root/reference/Thirdparty/ceres-solver/internal/ceres/ (the _test.cc files)
- *     (Huber loss, corrector, LM radius schedule, Schur vs dense) and by a
- *     dense numpy/scipy LM cross-check; Optimizer::localBA outputs themselves
- *     have no reference golden vectors.
+ *     Round 5: the reference's first-party control flow (src/feature_tracker.cpp, src/feature_extractor.cpp compiled in place, oracle/ref)
+ *     runs on top of these restatements and agrees with them; that pins the walk between the OpenCV calls, not the calls.
+ *     ORC_LK_ACC_FLOAT_* restate the float-accumulator orders of stock x86 builds (the device implements FLOAT_UI4 too, round 6).
+ *   - local BA: PINNED against the reference's own sources executed here (oracle/ref, oracle/_ref/*.so):
+ *     every factor / the SE(3) parameterisation / the parameter blocks against src/ceres_parametrization.cpp compiled in place
+ *     (tests/test_reference_factors.py, <= 1e-11), and -- round 6 -- the whole Levenberg-Marquardt iteration against Ceres' own
+ *     trust_region_minimizer.cc, trust_region_step_evaluator.cc, levenberg_marquardt_strategy.cc, corrector.cc, loss_function.cc
+ *     compiled in place and driving those factors (tests/test_reference_trlm.py: identical decisions, traces within 2e-9).
+ *     Both against stand-in Eigen / Sophus headers (absent from the image): rounding-level agreement, not bit-exact, and not a
+ *     "reference build" in the sense of a CPU baseline.  Sub-steps additionally by the known-answer tests vendored under
+ *     /root/reference/Thirdparty/ceres-solver/internal/ceres/ (the _test.cc files).  Optimizer::localBA outputs end to end have no
+ *     reference golden vectors (tools/ref_capture would produce them on a box with Eigen + Ceres).
  *
  * All file:line citations are relative to /root/reference/.
  */
