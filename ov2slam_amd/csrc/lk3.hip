@@ -54,6 +54,16 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // global_load_dwordx4 needs dword alignment only
+// LDS reads at BYTE granularity (gfx950 serves unaligned ds_read_b96): the twelve bytes p[0..11] of a staged row from the window's
+// own first column -- no v_alignbyte to shift the row into place, one LDS instruction per row instead of two
+#ifndef L3_UNALIGNED_LDS
+#define L3_UNALIGNED_LDS 1
+#endif
+typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+#ifndef L3_UNALIGNED_GLOBAL
+#define L3_UNALIGNED_GLOBAL 1
+#endif
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 
 // ---- packed 16-bit helpers (carrier type: uint32_t = two 16-bit fields, element 0 in the low half) ----
 // Every quantity of the LK inner loops fits 16 bits: pixels (8), bilinear weights (<= 2^14), Scharr sums
@@ -178,12 +188,18 @@ __device__ __forceinline__ void l3_fetch_J_rows(uint32_t *slot, const uint8_t *j
                 p = jroi + (long long)y * LJ.img_pitch + xa;
             }
             if (OV2_LK3_KO & 2) p = jroi + sub * 64 + k * 32;
+#if L3_UNALIGNED_GLOBAL
+            // the row's sixteen bytes from its own first column: ONE request at byte granularity (the memory pipeline serves
+            // unaligned dwordx4), nothing to shift
+            *(u32x4 *)(dst + 12 * k) = *(const u32x4_a1 *)(p + sh);
+#else
             const u32x4 lo = *(const u32x4_a4 *)p;
             const uint32_t hi = *(const uint32_t *)(p + 16);
             u32x4 o;
             o.x = __builtin_amdgcn_alignbyte(lo.y, lo.x, sh); o.y = __builtin_amdgcn_alignbyte(lo.z, lo.y, sh);
             o.z = __builtin_amdgcn_alignbyte(lo.w, lo.z, sh); o.w = __builtin_amdgcn_alignbyte(hi, lo.w, sh);
             *(u32x4 *)(dst + 12 * k) = o;
+#endif
         }
     }
 }
@@ -315,8 +331,13 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
         // soon as derivative rows j, j+1 exist.  E[m][i] = (p[2i], p[2i+1]) of image row m;
         // DX[d][i] = (dx[2i], dx[2i+1]) with column c <-> ipx + c.
         auto load_row = [&](int m, uint32_t (&e)[6]) {
+#if L3_UNALIGNED_LDS
+            const u32x3_a1 w = *(const u32x3_a1 *)((const uint8_t *)(tsrc + 4 * (r0 + m)) + ish);
+            const uint32_t d0 = w.x, d1 = w.y, d2 = w.z;
+#else
             const u32x4 w = *(const u32x4 *)(tsrc + 4 * (r0 + m));
             const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, ish), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, ish), d2 = __builtin_amdgcn_alignbyte(w.w, w.z, ish);
+#endif
             e[0] = bytes01(d0); e[1] = bytes23(d0); e[2] = bytes01(d1); e[3] = bytes23(d1); e[4] = bytes01(d2); e[5] = bytes23(d2);
         };
         // derivative positions outside the image are 0 (rare: only for windows overlapping the image border)
@@ -439,14 +460,23 @@ __device__ __forceinline__ void l3_level(const uint8_t *__restrict__ itemI, cons
                     l3_lds_sync();
                     ox = L3_NBH_R; oy = L3_NBH_R;
                 }
-                const uint32_t sh = (uint32_t)(ox & 3);
                 // source rows iny + 3 sub + m (m = 0..3), bytes [inx, inx + WIN]
-                const uint32_t *s0 = slot + jb + 4 * (oy + 3 * sub) + (ox >> 2);
                 uint32_t P[4][9];                                              // P[m][x] = (p[x], p[x+1])
+#if L3_UNALIGNED_LDS
+                const uint8_t *s0 = (const uint8_t *)(slot + jb + 4 * (oy + 3 * sub)) + ox;
+#else
+                const uint32_t sh = (uint32_t)(ox & 3);
+                const uint32_t *s0 = slot + jb + 4 * (oy + 3 * sub) + (ox >> 2);
+#endif
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
+#if L3_UNALIGNED_LDS
+                    const u32x3_a1 w = *(const u32x3_a1 *)(s0 + 16 * m);
+                    const uint32_t d0 = w.x, d1 = w.y, d2 = w.z;
+#else
                     const uint32_t a0 = s0[4 * m], a1 = s0[4 * m + 1], a2 = s0[4 * m + 2], a3 = s0[4 * m + 3];
                     const uint32_t d0 = __builtin_amdgcn_alignbyte(a1, a0, sh), d1 = __builtin_amdgcn_alignbyte(a2, a1, sh), d2 = __builtin_amdgcn_alignbyte(a3, a2, sh);
+#endif
                     P[m][0] = bytes01(d0); P[m][2] = bytes23(d0); P[m][4] = bytes01(d1); P[m][6] = bytes23(d1); P[m][8] = bytes01(d2);
                     P[m][1] = odd_pair(P[m][2], P[m][0]); P[m][3] = odd_pair(P[m][4], P[m][2]);
                     P[m][5] = odd_pair(P[m][6], P[m][4]); P[m][7] = odd_pair(P[m][8], P[m][6]);

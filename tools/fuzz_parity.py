@@ -190,7 +190,41 @@ for case in range(N):
             if ba_close(g, r, key): return
             if ba_close(g, r, key, 100.0):
                 loose.append((name, dict(binfo, **ba_diff(g, r, key)))); print("LOOSE", name, loose[-1][1], flush=True)
-            else: check(name, False, dict(binfo, **ba_diff(g, r, key)))
+                return
+            # beyond 100x: is it the problem or the solver?  The arithmetic noise floor of THIS problem = the oracle against
+            # itself with the residual blocks in another (equally valid) order -- Ceres sums in block order, so a permuted problem
+            # is the same Ceres problem with another rounding.  A device result inside 4x that spread, with identical iteration /
+            # termination / step pattern, is listed as ill-conditioned with both numbers; anything else is a mismatch.
+            fl = ba_noise_floor(key)
+            d = ba_diff(g, r, key); m = np.isfinite(r["chi2"]) & np.isfinite(g["chi2"])
+            dchi = float(np.abs(g["chi2"][m] - r["chi2"][m]).max()) if m.any() else 0.0
+            same = (g["iterations"] == r["iterations"] and g["termination"] == r["termination"] and g["num_successful_steps"] == r["num_successful_steps"]
+                    and np.array_equal(np.isfinite(g["chi2"]), np.isfinite(r["chi2"])))
+            if (fl is not None and same and d["dpos"] <= 4 * fl["dpos"] and d["dlm"] <= 4 * fl["dlm"] and dchi <= 4 * fl["dchi2"]
+                    and abs(g["final_cost"] - r["final_cost"]) <= 4 * fl["dcost"]):
+                loose.append((name + " (ill-conditioned draw)", dict(binfo, **d, dchi2=dchi, oracle_self_spread=fl)))
+                print("ILL-CONDITIONED", name, loose[-1][1], flush=True)
+            else: check(name, False, dict(binfo, **d, dchi2=dchi, oracle_self_spread=fl))
+
+        floor_cache = {}
+        def ba_noise_floor(key, trials=3):
+            if key in floor_cache: return floor_cache[key]
+            q = pb; r0 = O.xyz_ba_solve(q, O.ba_default_options(**kw)) if key == "xyz" else O.ba_solve(q, O.ba_default_options(**kw))
+            prng = np.random.default_rng(bseed + 77); out = dict(dpos=0.0, dlm=0.0, dchi2=0.0, dcost=0.0)
+            for _ in range(trials):
+                perm = prng.permutation(q["n_res"]); q2 = dict(q)
+                for kk, v in q.items():
+                    if kk.startswith("res_") or kk == "is_outlier": q2[kk] = np.ascontiguousarray(v[perm])
+                r2 = O.xyz_ba_solve(q2, O.ba_default_options(**kw)) if key == "xyz" else O.ba_solve(q2, O.ba_default_options(**kw))
+                if (r2["iterations"], r2["termination"], r2["num_successful_steps"]) != (r0["iterations"], r0["termination"], r0["num_successful_steps"]):
+                    out = dict(dpos=np.inf, dlm=np.inf, dchi2=np.inf, dcost=np.inf, note="the oracle's own step pattern depends on the block order"); break
+                c2 = np.empty_like(r2["chi2"]); c2[perm] = r2["chi2"]; m = np.isfinite(r0["chi2"]) & np.isfinite(c2)
+                out["dpos"] = max(out["dpos"], float(np.abs(r2["poses"][:, :3] - r0["poses"][:, :3]).max()))
+                out["dlm"] = max(out["dlm"], float(np.abs(r2[key] - r0[key]).max()))
+                out["dchi2"] = max(out["dchi2"], float(np.abs(c2[m] - r0["chi2"][m]).max()) if m.any() else 0.0)
+                out["dcost"] = max(out["dcost"], abs(r2["final_cost"] - r0["final_cost"]))
+            floor_cache[key] = out
+            return out
         pb = synth.make_ba_problem(n_kf, n_lm, min(obs, n_kf), stereo=stereo, seed=bseed)
         r = O.ba_solve(pb, O.ba_default_options(**kw))
         for big in (0, 1):
