@@ -709,12 +709,20 @@ __device__ void d_fk_std_sort(int *first, int n, int *stk)
     else d_fk_insertion_sort(first, first + n);
 }
 #undef FK_LESS
+#ifndef DET_SEL_THREADS_BATCH
+#define DET_SEL_THREADS_BATCH 512
+#endif
+#ifndef DET_SEL_MIN_WAVES
+#define DET_SEL_MIN_WAVES 4          // wavefronts per SIMD the batch instance is compiled for (register cap 512 / this)
+#endif
 #define DET_SORT_CAP 512        // corners of a cell that can enter the emulated sort (non-adjacent after NMS: <= 32 x 32 / 2 for cs = 64, halved again by N3)
 
 // MODE 0 = FAST scores (bytes), 1 = min-eigenvalue (floats); a cell row (<= MAXROW * CHUNKS columns) is held in registers
 // MAXROW columns at a time: (36,1) and (52,1) cover the reference cell sizes with compile-time column indices, (32,2) the rest
-template <int MODE, int MAXROW, int CHUNKS>
-__global__ __launch_bounds__(1024) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
+// NT: threads of the launch -- 1024 for one image (a wavefront per row of cells: latency), DET_SEL_THREADS_BATCH for batches (throughput:
+// fewer wavefronts and registers per work-group, more work-groups per CU)
+template <int MODE, int MAXROW, int CHUNKS, int NT>
+__global__ __launch_bounds__(NT, NT == 1024 ? 1 : DET_SEL_MIN_WAVES) void k_grid_select(SelectParams P, const float2 *__restrict__ cur_xy,
                                                       const uint8_t *__restrict__ nms_maps,
                                                       const float *__restrict__ hmaps, const CellCand *__restrict__ cand,
                                                       float2 *__restrict__ out_xy, SelectOut *__restrict__ out, DetBatch B)
@@ -1279,8 +1287,11 @@ static hipError_t det_raise_lds_limits()
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
         };
         const void *fns[] = {(const void *)k_mineig_cells, (const void *)k_mineig_strip,
-                             (const void *)k_grid_select<0, 36, 1>, (const void *)k_grid_select<0, 52, 1>, (const void *)k_grid_select<0, 32, 2>,
-                             (const void *)k_grid_select<1, 36, 1>, (const void *)k_grid_select<1, 52, 1>, (const void *)k_grid_select<1, 32, 2>};
+                             (const void *)k_grid_select<0, 36, 1, 1024>, (const void *)k_grid_select<0, 52, 1, 1024>, (const void *)k_grid_select<0, 32, 2, 1024>,
+                             (const void *)k_grid_select<1, 36, 1, 1024>, (const void *)k_grid_select<1, 52, 1, 1024>, (const void *)k_grid_select<1, 32, 2, 1024>,
+                             (const void *)k_grid_select<0, 36, 1, DET_SEL_THREADS_BATCH>, (const void *)k_grid_select<0, 52, 1, DET_SEL_THREADS_BATCH>,
+                             (const void *)k_grid_select<0, 32, 2, DET_SEL_THREADS_BATCH>, (const void *)k_grid_select<1, 36, 1, DET_SEL_THREADS_BATCH>,
+                             (const void *)k_grid_select<1, 52, 1, DET_SEL_THREADS_BATCH>, (const void *)k_grid_select<1, 32, 2, DET_SEL_THREADS_BATCH>};
         for (const void *fn : fns) if (err == hipSuccess) err = raise(fn);
     });
     return err;
@@ -1343,9 +1354,15 @@ static int enqueue_detect(ov2_ctx *ctx, int mode, const uint8_t *im, int w, int 
     P.fast_tie = ctx->det_fast_tie; P.sort_slots = sort_slots > 0 ? sort_slots : 1;
     P.roi_x = roi ? roi[0] : 0; P.roi_y = roi ? roi[1] : 0; P.roi_w = roi ? roi[2] : w; P.roi_h = roi ? roi[3] : h;
     P.quality = quality;
+    // One image: sixteen wavefronts, a row of cells each (latency).  Batches: EIGHT (rows w, w + 8 -- the anti-diagonal dependence keeps
+    // at most nwcells / 2 rows busy at a time anyway), so that two work-groups share a CU's sixteen wavefront slots (106 VGPRs: four
+    // per SIMD) instead of one
+    const bool sel_batch = items >= 64;
 #define OV2_LAUNCH_SELECT(MD, MR, CH)                                                                                               \
-    hipLaunchKernelGGL((k_grid_select<MD, MR, CH>), dim3(items), dim3(1024), sel_lds, ctx->stream, P, cur_d, (const uint8_t *)maps_d,     \
-                       (const float *)maps_d, (const CellCand *)cand_d, out_d, so_d, B)
+    do { if (sel_batch) hipLaunchKernelGGL((k_grid_select<MD, MR, CH, DET_SEL_THREADS_BATCH>), dim3(items), dim3(DET_SEL_THREADS_BATCH), sel_lds, ctx->stream, P, cur_d, \
+                       (const uint8_t *)maps_d, (const float *)maps_d, (const CellCand *)cand_d, out_d, so_d, B);                   \
+         else hipLaunchKernelGGL((k_grid_select<MD, MR, CH, 1024>), dim3(items), dim3(1024), sel_lds, ctx->stream, P, cur_d, (const uint8_t *)maps_d,     \
+                       (const float *)maps_d, (const CellCand *)cand_d, out_d, so_d, B); } while (0)
     if (mode == 0) { if (cell <= 36) OV2_LAUNCH_SELECT(0, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(0, 52, 1); else OV2_LAUNCH_SELECT(0, 32, 2); }
     else { if (cell <= 36) OV2_LAUNCH_SELECT(1, 36, 1); else if (cell <= 52) OV2_LAUNCH_SELECT(1, 52, 1); else OV2_LAUNCH_SELECT(1, 32, 2); }
 #undef OV2_LAUNCH_SELECT
