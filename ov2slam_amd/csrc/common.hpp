@@ -60,6 +60,7 @@ struct ov2_ctx {
     int ba_trace = 0;                          // OV2_OPT_BA_TRACE: the one-problem solves record their iteration summaries (ov2_ba_get_trace)
     void *ba_trace_d = nullptr, *ba_trace_h = nullptr; int ba_trace_n = 0;
     int det_fast_tie = 1;                      // OV2_OPT_FAST_TIE: OV2_FAST_TIE_LIBSTDCXX (the reference as built with g++)
+    hipStream_t det_aux_stream = nullptr; hipEvent_t det_ev[2] = {nullptr, nullptr};   // batched detectors: the passes alternate between the context's stream and this one
     int det_strip = -1;                        // OV2_OPT_DETECT_STRIP: -1 auto (batches), 0 one wavefront per cell, 1 the strip kernel
     void *ba_det_pool = nullptr; size_t ba_det_bytes = 0;   // OV2_OPT_BA_DETERMINISTIC: per-work-group copies of H / F^T b / G (grow-only)
     // ov2_local_ba_batch: persistent host threads that prepare the problems of a batch (created with the first batch; ba.hip owns the type)

@@ -169,6 +169,8 @@ void ov2_ctx_destroy(ov2_ctx *ctx)
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_img) (void)hipHostFree(ctx->h_img);
     if (ctx->img_ev) (void)hipEventDestroy(ctx->img_ev);
+    if (ctx->det_aux_stream) { (void)hipStreamSynchronize(ctx->det_aux_stream); (void)hipStreamDestroy(ctx->det_aux_stream); }
+    for (int i = 0; i < 2; i++) if (ctx->det_ev[i]) (void)hipEventDestroy(ctx->det_ev[i]);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -27,6 +27,9 @@
 #pragma clang fp contract(off)
 
 #define DET_MAX_CELL 64
+#ifndef DET_TWO_STREAMS
+#define DET_TWO_STREAMS 1
+#endif
 #ifndef DET_CHUNK
 #define DET_CHUNK 1024     // images per pass of the batch entry points (the response maps of a pass live in the scratch: 1.3 MB per EuRoC image)
 #endif
@@ -1545,10 +1548,16 @@ static int detect_batch(ov2_ctx *ctx, int mode, const ov2_pyr *pyr, int cell, co
     const int cap = mode == 0 ? ncells : 2 * ncells;
     OV2_REQUIRE(out_cap >= cap, OV2_EINVAL, "out_cap too small: (w/cell)*(h/cell) points per item for FAST, twice that for single scale");
     { int slots_; OV2_REQUIRE(det_select_lds(w, h, cell, mode, ctx->det_fast_tie, &slots_) != 0, OV2_EUNSUPPORTED, "image too large for the LDS-resident exclusion mask"); }
-    const int chunk = std::min(items, DET_CHUNK);
+    // Passes of `chunk` images share the response / candidate scratch.  More than one pass: TWO scratch sets of half a chunk, the passes
+    // alternating between the context's stream and an auxiliary one -- the selection sweep of a pass (a dependency chain: two work-groups
+    // per CU, the vector units nearly idle) then runs beside the response kernel of the next pass (issue-bound) instead of between two of them
+    const bool two = DET_TWO_STREAMS && items > DET_CHUNK / 2;
+    const int chunk = two ? DET_CHUNK / 2 : std::min(items, DET_CHUNK);
     const size_t map_bytes = (size_t)ncells * npx * (mode == 0 ? 1 : 4);
-    const size_t o_map = 0, o_cand = (o_map + (size_t)chunk * map_bytes + 255) & ~(size_t)255;
-    const size_t o_so = (o_cand + (size_t)chunk * (ncells * sizeof(CellCand) + 4 * ((size_t)ncells + 1)) + 255) & ~(size_t)255;   // candidates + free-cell lists
+    const size_t set_bytes = (((size_t)chunk * map_bytes + 255) & ~(size_t)255) +
+                             (((size_t)chunk * (ncells * sizeof(CellCand) + 4 * ((size_t)ncells + 1)) + 255) & ~(size_t)255);   // maps; candidates + free-cell lists
+    const size_t o_cand_in_set = ((size_t)chunk * map_bytes + 255) & ~(size_t)255;
+    const size_t o_so = (two ? 2 : 1) * set_bytes;
     const size_t o_par = (o_so + (size_t)items * sizeof(SelectOut) + 255) & ~(size_t)255;       // per-item threshold / quality
     const size_t total = o_par + (size_t)items * 8;
     rc = ctx->reserve_device(total); if (rc) return rc;
@@ -1556,18 +1565,37 @@ static int detect_batch(ov2_ctx *ctx, int mode, const ov2_pyr *pyr, int cell, co
     uint8_t *ds = (uint8_t *)ctx->d_scratch;
     if (mode == 0) OV2_HIP_CHECK(hipMemcpyAsync(ds + o_par, fast_th_inout, 4 * (size_t)items, hipMemcpyHostToDevice, ctx->stream));
     else OV2_HIP_CHECK(hipMemcpyAsync(ds + o_par, quality_inout, 8 * (size_t)items, hipMemcpyHostToDevice, ctx->stream));
-    for (int c0 = 0; c0 < items; c0 += chunk) {
+    hipStream_t main_stream = ctx->stream;
+    if (two) {
+        if (!ctx->det_aux_stream) {
+            OV2_HIP_CHECK(hipStreamCreateWithFlags(&ctx->det_aux_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) OV2_HIP_CHECK(hipEventCreateWithFlags(&ctx->det_ev[i], hipEventDisableTiming));
+        }
+        OV2_HIP_CHECK(hipEventRecord(ctx->det_ev[0], main_stream));                     // what precedes this call on the context's stream (the pyramid, the parameters)
+        OV2_HIP_CHECK(hipStreamWaitEvent(ctx->det_aux_stream, ctx->det_ev[0], 0));
+    }
+    int pass = 0;
+    for (int c0 = 0; c0 < items; c0 += chunk, pass++) {
         const int n = std::min(chunk, items - c0);
+        const size_t o_set = two ? (size_t)(pass & 1) * set_bytes : 0;
         DetBatch B;
         memset(&B, 0, sizeof(B));
         B.img_stride = (long long)pyr->d.item_stride; B.cur_stride = cur_cap; B.out_stride = out_cap;
         B.ncur = ncur_d ? ncur_d + c0 : nullptr;
         if (mode == 0) B.fast_th = (const int *)(ds + o_par) + c0; else B.quality = (const double *)(ds + o_par) + c0;
+        if (two && (pass & 1)) ctx->stream = ctx->det_aux_stream;                       // (the launchers enqueue on the context's stream; a context belongs to one thread)
         rc = enqueue_detect(ctx, mode, img + (long long)c0 * pyr->d.item_stride, w, h, stride, cell, n, B, 0, mask_mode, roi, 0.0, 0,
-                            (const float2 *)cur_xy_d + (long long)c0 * cur_cap, ds + o_map, (CellCand *)(ds + o_cand),
+                            (const float2 *)cur_xy_d + (long long)c0 * cur_cap, ds + o_set, (CellCand *)(ds + o_set + o_cand_in_set),
                             (float2 *)out_xy_d + (long long)c0 * out_cap, (SelectOut *)(ds + o_so) + c0, do_subpix);
-        if (rc) return rc;
+        ctx->stream = main_stream;
+        if (rc) break;
     }
+    if (two) {                                                                          // join (also on an error: nothing of this call may outlive it on the auxiliary stream)
+        const hipError_t e1 = hipEventRecord(ctx->det_ev[1], ctx->det_aux_stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->det_ev[1], 0) : e1;
+        if (e2 != hipSuccess) { (void)hipStreamSynchronize(ctx->det_aux_stream); if (!rc) { ov2_set_error("detect_batch join: %s", hipGetErrorString(e2)); rc = OV2_EHIP; } }
+    }
+    if (rc) return rc;
     SelectOut *so = (SelectOut *)ctx->h_scratch;
     OV2_HIP_CHECK(hipMemcpyAsync(so, ds + o_so, (size_t)items * sizeof(SelectOut), hipMemcpyDeviceToHost, ctx->stream));
     OV2_HIP_CHECK(hipStreamSynchronize(ctx->stream));
