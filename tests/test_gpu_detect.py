@@ -276,15 +276,37 @@ out = d_out.cpu().numpy()
 for b in (0, 7):
     ref = ov2slam_amd.FeatureExtractor(ctx, dmaxquality=1e-3).detectSingleScale(imgs[b], CELL, np.zeros((0, 2), np.float32), roi)
     assert n[b] == len(ref) and np.array_equal(out[b, :n[b]].view(np.uint32), ref.view(np.uint32))
-# more items than one scratch chunk holds (256): items 0..299 cycle through the 11 images
-B2 = 300
-P2 = ov2slam_amd.Pyramid(ctx, W, H, 9, 0, batch=B2).build(np.stack([imgs[i % B] for i in range(B2)]))
-d_out = torch.zeros((B2, cap, 2), dtype=torch.float32, device="cuda"); q = np.full(B2, 1e-3)
+# more items than one pass holds: beyond 512 items the passes (512 each, two scratch sets) alternate between the context's stream and an
+# auxiliary one -- 1100 items = three passes (main, auxiliary, main); items cycle through the 11 images AND their keypoint lists / thresholds
+B2 = 1100
+idx = np.arange(B2) % B
+P2 = ov2slam_amd.Pyramid(ctx, W, H, 9, 0, batch=B2).build(np.stack([imgs[i] for i in idx]))
+d_cur2 = torch.from_numpy(np.ascontiguousarray(curs[idx])).cuda(); d_n2 = torch.from_numpy(np.ascontiguousarray(ncur[idx])).cuda()
+cap = 2 * ncells
+d_out = torch.zeros((B2, cap, 2), dtype=torch.float32, device="cuda")
+qb = np.array([1e-3, 1e-2, 1e-4, 1e-3, 0.5, 1e-3, 1e-3, 1e-5, 1e-3, 1e-3, 1e-2], np.float64)
+q1 = qb.copy(); q2 = qb[idx].copy()
+d_ref = torch.zeros((B, cap, 2), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
-n2 = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P2, CELL, 0, 0, 0, roi, q, d_out.data_ptr(), cap)
-out2 = d_out.cpu().numpy()
-for i in (0, 255, 256, 299):
-    assert n2[i] == n[i % B] and np.array_equal(out2[i, :n2[i]], out[i % B, :n2[i]]), ("chunked batch", i)
+n1 = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P, CELL, d_cur.data_ptr(), NCUR, d_n.data_ptr(), roi, q1, d_ref.data_ptr(), cap)
+n2 = ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, P2, CELL, d_cur2.data_ptr(), NCUR, d_n2.data_ptr(), roi, q2, d_out.data_ptr(), cap)
+ref, out2 = d_ref.cpu().numpy(), d_out.cpu().numpy()
+for i in range(B2):
+    assert n2[i] == n1[i % B] and q2[i] == q1[i % B], ("multi-pass batch: count / adapted quality", i)
+    assert np.array_equal(out2[i, :n2[i]].view(np.uint32), ref[i % B, :n2[i]].view(np.uint32)), ("multi-pass batch", i)
+d_out = torch.zeros((B2, ncells, 2), dtype=torch.float32, device="cuda"); d_ref = torch.zeros((B, ncells, 2), dtype=torch.float32, device="cuda")
+thb = np.array([10, 20, 5, 10, 40, 7, 10, 10, 3, 10, 60], np.int32)
+t1 = thb.copy(); t2 = thb[idx].copy()
+torch.cuda.synchronize()
+n1 = ov2slam_amd.FeatureExtractor.detectGridFASTBatch(ctx, P, CELL, d_cur.data_ptr(), NCUR, d_n.data_ptr(), t1, d_ref.data_ptr(), ncells)
+n2 = ov2slam_amd.FeatureExtractor.detectGridFASTBatch(ctx, P2, CELL, d_cur2.data_ptr(), NCUR, d_n2.data_ptr(), t2, d_out.data_ptr(), ncells)
+ref, out2 = d_ref.cpu().numpy(), d_out.cpu().numpy()
+for i in range(B2):
+    assert n2[i] == n1[i % B] and t2[i] == t1[i % B], ("multi-pass FAST batch: count / adapted threshold", i)
+    assert np.array_equal(out2[i, :n2[i]].view(np.uint32), ref[i % B, :n2[i]].view(np.uint32)), ("multi-pass FAST batch", i)
+# the context's stream is usable right after (the auxiliary stream was joined): a single-image call gives the usual answer
+ref0 = ov2slam_amd.FeatureExtractor(ctx, dmaxquality=1e-3).detectSingleScale(imgs[0], CELL, np.zeros((0, 2), np.float32), roi)
+assert len(ref0) == n[0]
 print("BATCH_DETECT_OK")
 """
 
