@@ -19,6 +19,7 @@
 //      Bit-identical results to the serial raster order.
 //   3. k_corner_subpix : cv::cornerSubPix, one wavefront per point (parallel patch, ordered accumulation).
 #include "common.hpp"
+#include <limits.h>
 #include <float.h>
 #include <math.h>
 #include <algorithm>
@@ -1189,9 +1190,47 @@ __global__ __launch_bounds__(64) void k_corner_subpix(SubpixParams P, const uint
     float cIx = cT.x, cIy = cT.y;
     int iter = 0;
     bool go = true;
+    // The patch's source pixels stay in REGISTERS between iterations: a lane's patch pixels (one per pass of 64) need the bytes
+    // p[j], p[j+1] of two rows, and those change only when the patch's integer origin moves -- after the first step or two of a
+    // converging point it does not, so most iterations issue no global load at all.  In a batch the kernel is bound by its fp64 issue
+    // slots and this changes nothing (profiles/r6_detect_notes.txt); for ONE image (or the eleven of a lock-step step) a wavefront runs
+    // alone on its SIMD and the two load round trips per iteration were the longest link of its dependent chain.  Same float operations
+    // in the same order as d_rect_px.
+    constexpr int NPASS = (SW * SW + 63) / 64;
+    float q00[NPASS], q01[NPASS], q10[NPASS], q11[NPASS];
+    int pj[NPASS], poff[NPASS];
+#pragma unroll
+    for (int k = 0; k < NPASS; k++) {
+        const int e = min(lane + 64 * k, SW * SW - 1), i = e / SW;
+        pj[k] = e - i * SW; poff[k] = i * P.stride + pj[k];
+        q00[k] = q01[k] = q10[k] = q11[k] = 0.f;
+    }
+    int c_ipx = INT_MIN, c_ipy = INT_MIN;
     while (go) {
         const RectCtx rc = d_rect_ctx<SW>(P.w, P.h, cIx, cIy);
-        for (int e = lane; e < SW * SW; e += 64) { const int i = e / SW, j = e - i * SW; sub[e] = d_rect_px(rc, img, P.stride, P.w, P.h, i, j); }
+        if (__builtin_amdgcn_readfirstlane(rc.fast)) {
+            const int ipx = __builtin_amdgcn_readfirstlane(rc.ipx), ipy = __builtin_amdgcn_readfirstlane(rc.ipy);
+            if (ipx != c_ipx || ipy != c_ipy) {
+                const uint8_t *p0 = img + (long long)ipy * P.stride + ipx;
+#pragma unroll
+                for (int k = 0; k < NPASS; k++) {
+                    const uint8_t *p = p0 + poff[k];
+                    q00[k] = (float)p[0]; q01[k] = (float)p[1]; q10[k] = (float)p[P.stride]; q11[k] = (float)p[P.stride + 1];
+                }
+                c_ipx = ipx; c_ipy = ipy;
+            }
+#pragma unroll
+            for (int k = 0; k < NPASS; k++) {
+                const float t = rc.a12 * q01[k] + rc.a22 * q11[k];
+                float prev;
+                if (pj[k] == 0) prev = rc.a1m * (rc.b1 * q00[k] + rc.b2 * q10[k]);
+                else { const float tp = rc.a12 * q00[k] + rc.a22 * q10[k]; prev = (float)(tp * rc.s); }
+                if (lane + 64 * k < SW * SW) sub[lane + 64 * k] = prev + t;
+            }
+        } else {
+            c_ipx = INT_MIN;                                              // (the border paths read through d_rect_px every time)
+            for (int e = lane; e < SW * SW; e += 64) { const int i = e / SW, j = e - i * SW; sub[e] = d_rect_px(rc, img, P.stride, P.w, P.h, i, j); }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (int e = lane; e < NPIX; e += 64) {
             const int i = e / WINW, j = e - i * WINW;
