@@ -51,8 +51,8 @@ def step(i, ev=None):
 
 res = {0: [], 1: []}
 for r in range(ROUNDS):
-    for mode in (0, 1):
-        ctx.set_option(L.OV2_OPT_PYR_ASYNC_LEVELS, mode)
+    for mode in ((0, 1) if hasattr(L, "OV2_OPT_PYR_ASYNC_LEVELS") else (0,)):      # (the option exists only with profiles/r6_async_pyramid_levels.patch applied)
+        if hasattr(L, "OV2_OPT_PYR_ASYNC_LEVELS"): ctx.set_option(L.OV2_OPT_PYR_ASYNC_LEVELS, mode)
         pre(P[0], 0)
         for i in range(5): step(i)
         torch.cuda.synchronize()
@@ -65,4 +65,4 @@ for r in range(ROUNDS):
         res[mode].append(ms)
         print("async_levels=%d: %.3f ms per step (%.0f frames/s); LK pass A %.3f ms, pass B %.3f ms; tracked %.3f / %.3f" %
               (mode, ms, S / ms * 1e3, a, b, stA.float().mean().item(), stB.float().mean().item()), flush=True)
-print("median ms per step: serial %.3f, levels beside pass A %.3f" % (float(np.median(res[0])), float(np.median(res[1]))))
+print("median ms per step: serial %.3f%s" % (float(np.median(res[0])), ", levels beside pass A %.3f" % float(np.median(res[1])) if res[1] else ""))
