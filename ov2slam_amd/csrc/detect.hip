@@ -1606,10 +1606,8 @@ static int detect_batch(ov2_ctx *ctx, int mode, const ov2_pyr *pyr, int cell, co
     else OV2_HIP_CHECK(hipMemcpyAsync(ds + o_par, quality_inout, 8 * (size_t)items, hipMemcpyHostToDevice, ctx->stream));
     hipStream_t main_stream = ctx->stream;
     if (two) {
-        if (!ctx->det_aux_stream) {
-            OV2_HIP_CHECK(hipStreamCreateWithFlags(&ctx->det_aux_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 2; i++) OV2_HIP_CHECK(hipEventCreateWithFlags(&ctx->det_ev[i], hipEventDisableTiming));
-        }
+        if (!ctx->det_aux_stream) OV2_HIP_CHECK(hipStreamCreateWithFlags(&ctx->det_aux_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) if (!ctx->det_ev[i]) OV2_HIP_CHECK(hipEventCreateWithFlags(&ctx->det_ev[i], hipEventDisableTiming));
         OV2_HIP_CHECK(hipEventRecord(ctx->det_ev[0], main_stream));                     // what precedes this call on the context's stream (the pyramid, the parameters)
         OV2_HIP_CHECK(hipStreamWaitEvent(ctx->det_aux_stream, ctx->det_ev[0], 0));
     }
