@@ -1070,7 +1070,24 @@ def main():
         ncur_d = torch.full((S,), n_half, dtype=torch.int32, device=dev)
         top_ms, n_top = timed_detect(cur_half.data_ptr(), n_half, ncur_d.data_ptr())
         step_ms = elapsed / args.steps * 1e3
+        # ... and MEASURED: twenty tracking steps with the top-up detector on the current frame after every fifth (one call, its counts come back:
+        # one synchronisation per keyframe step, as a lock-step host would see it)
+        base = args.warmup + args.steps
+        base += base % 2                                            # (even: the walk's pyramid parity)
+        preprocess(hp[base % 2], a_img[walk_view(base)])            # (the sections above left other frames in the pyramids: re-prime the walk)
+        for i in range(5): step(base + i, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(5, 25):
+            step(base + i, False)
+            if i % 5 == 4:
+                qual[:] = 1e-3
+                ov2slam_amd.FeatureExtractor.detectSingleScaleBatch(ctx, pyrs[(base + i + 1) % 2], CELL, cur_half.data_ptr(), n_half, ncur_d.data_ptr(), roi, qual,
+                                                                    det_out.data_ptr(), cap)
+        torch.cuda.synchronize()
+        kf_ms = (time.perf_counter() - t1) / 20 * 1e3
         det_batch = {"detect_singlescale_batch_ms": det_ms, "images": S, "us_per_image": det_ms * 1e3 / S,
+                     "frames_per_s_with_keyframe_every_5th_measured": S / (kf_ms * 1e-3), "ms_per_step_with_keyframe_every_5th_measured": kf_ms,
                      "points_per_image": float(n_det.mean()),
                      "topup_ms": top_ms, "topup_us_per_image": top_ms * 1e3 / S, "topup_points_per_image": float(n_top.mean()),
                      "topup_current_keypoints": n_half,
@@ -1174,6 +1191,7 @@ def main():
         if uniform is not None:
             out["same_content_in_every_sequence"] = uniform
         out["value_incl_detect"] = det_batch.get("frames_per_s_with_keyframe_every_5th") if isinstance(det_batch, dict) else None
+        out["value_incl_detect_measured"] = det_batch.get("frames_per_s_with_keyframe_every_5th_measured") if isinstance(det_batch, dict) else None
         # ---- pre-processing (everything of the step that is not k_fb_klt3): SURVEY.md 8(d) bytes against the time the step spends
         # there; per kernel, duration and HBM bytes by the counters of the committed PMC passes (tools/profile.sh, FETCH_SIZE x 2:
         # the gfx950 correction of the guide, WRITE_SIZE as read), same workload and batch only
